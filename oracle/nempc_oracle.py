@@ -1,0 +1,382 @@
+"""CPU oracle for the NMPC callback path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+may import this module.  The product path (``pyneuralempc_amd``) never does; it goes through
+the C-ABI HIP library and fails loudly when that library is missing.
+
+What it is: an fp64 NumPy restatement of the per-iterate evaluation the reference hands to its
+NLP solver -- ``f, grad f, g, jac g`` and the Lagrangian Hessian -- for a feed-forward tanh MLP
+dynamics model under the Discret / Unity / RK4 transcriptions.  File:line citations are into
+``/root/reference/pyNeuralEMPC``.
+
+Parity pinning (see DESIGN.md "Oracle"):
+  * integrator / glue / bounds / warm-start arithmetic: pinned against the *imported reference
+    modules themselves* (integrator/{discret,unity,rk4}.py, constraints.py, optimizer/slsqp.py,
+    controller.py) through the golden vectors in ``tests/golden`` produced by
+    ``tests/golden/make_golden.py``.
+  * the derivative of the network itself is delegated by the reference to TensorFlow / JAX
+    autodiff (model/tensorflow.py:53-75, model/jax.py:52-62), which are un-vendored, un-pinned
+    (setup.py:20) and not installed here.  That piece is restated analytically (chain rule of a
+    tanh MLP) and pinned by an independent AD (``torch.func`` fp64) and by finite differences
+    in ``tests/test_oracle.py``.  The reference ships no test or fixture for it.
+
+Layouts (all row-major, identical to the reference):
+  z        (n,)      n = H*(nx+nu);  z[:H*nx] = states (H,nx),  z[H*nx:] = controls (H,nu)
+                     optimizer/ipopt.py:20-28
+  x_prev   (H,nx)    [x0 ; states[:-1]]                               integrator/discret.py:22
+  g        (m,)      integrator defects (H*nx) then each extra constraint in list order
+                     optimizer/ipopt.py:44-52
+  jac      (m,n)     dense                                           optimizer/ipopt.py:88-96
+"""
+from __future__ import annotations
+
+import numpy as np
+
+DISCRET, UNITY, RK4 = 0, 1, 2
+INTEGRATOR_NAMES = {DISCRET: "discret", UNITY: "unity", RK4: "rk4"}
+
+
+# --------------------------------------------------------------------------------------
+# Network: a_0 = xi ; a_l = tanh(a_{l-1} W_l + b_l) ; f = a_{L-1} W_L + b_L  (Keras kernel (in,out))
+# restates what model/tensorflow.py:49-51 evaluates with model.predict on [x | u] rows
+# --------------------------------------------------------------------------------------
+class MLP:
+    def __init__(self, weights, biases):
+        self.W = [np.asarray(w, dtype=np.float64) for w in weights]
+        self.b = [np.asarray(b, dtype=np.float64) for b in biases]
+        assert len(self.W) == len(self.b) and len(self.W) >= 1
+        for w, b in zip(self.W, self.b):
+            assert w.ndim == 2 and b.shape == (w.shape[1],)
+        for w0, w1 in zip(self.W[:-1], self.W[1:]):
+            assert w0.shape[1] == w1.shape[0]
+        self.n_in = self.W[0].shape[0]
+        self.n_out = self.W[-1].shape[1]
+
+    @staticmethod
+    def random(n_in, hidden, n_out, seed=0):
+        """SURVEY.md 8(d) synthetic weights: W ~ N(0, 1/fan_in), b ~ N(0, 0.1^2)."""
+        rng = np.random.default_rng(seed)
+        dims = [n_in] + list(hidden) + [n_out]
+        W, b = [], []
+        for i, o in zip(dims[:-1], dims[1:]):
+            W.append(rng.normal(0.0, 1.0 / np.sqrt(i), size=(i, o)))
+            b.append(rng.normal(0.0, 0.1, size=(o,)))
+        return MLP(W, b)
+
+    def _acts(self, xi):
+        acts = [np.asarray(xi, dtype=np.float64)]
+        for w, b in zip(self.W[:-1], self.b[:-1]):
+            acts.append(np.tanh(acts[-1] @ w + b))
+        return acts
+
+    def forward(self, xi):
+        """(R, n_in) -> (R, n_out)"""
+        acts = self._acts(xi)
+        return acts[-1] @ self.W[-1] + self.b[-1]
+
+    def forward_jac(self, xi):
+        """(R, n_in) -> f (R, n_out), J (R, n_out, n_in).
+
+        Reverse sweep: J = W_L^T diag(1-a_{L-1}^2) W_{L-1}^T ... diag(1-a_1^2) W_1^T, the same
+        value tf.GradientTape.jacobian returns per row (model/tensorflow.py:58-62) restricted
+        to the t==t' blocks.
+        """
+        acts = self._acts(xi)
+        f = acts[-1] @ self.W[-1] + self.b[-1]
+        R = f.shape[0]
+        # cot[r, k, j] : d f_k / d z_l[j] walking back through the layers
+        cot = np.broadcast_to(self.W[-1].T[None, :, :], (R, self.n_out, self.W[-1].shape[0])).copy()
+        for l in range(len(self.W) - 2, -1, -1):
+            cot = cot * (1.0 - acts[l + 1] ** 2)[:, None, :]
+            cot = cot @ self.W[l].T
+        return f, cot
+
+    def forward_jac_hess(self, xi):
+        """(R, n_in) -> f, J (R,n_out,n_in), Hs (R,n_out,n_in,n_in) (second derivatives).
+
+        Forward second-order propagation
+            D_l = diag(s'(z_l)) W_l^T D_{l-1}
+            S_l[i,p,q] = s''(z_l[i]) P[i,p] P[i,q] + s'(z_l[i]) (W_l^T S_{l-1})[i,p,q],  P = W_l^T D_{l-1}
+        with s = tanh: s' = 1-a^2, s'' = -2a(1-a^2); last layer linear.  Value-equivalent to the
+        tf.hessians / jax.hessian call of model/tensorflow.py:80-85, model/jax.py:74 per row.
+        """
+        xi = np.asarray(xi, dtype=np.float64)
+        R, nin = xi.shape
+        a = xi
+        D = np.broadcast_to(np.eye(nin)[None], (R, nin, nin)).copy()
+        S = np.zeros((R, nin, nin, nin))
+        for l, (w, b) in enumerate(zip(self.W, self.b)):
+            P = np.einsum("ji,rjp->rip", w, D)
+            WS = np.einsum("ji,rjpq->ripq", w, S)
+            z = a @ w + b
+            if l < len(self.W) - 1:
+                a = np.tanh(z)
+                s1 = 1.0 - a * a
+                s2 = -2.0 * a * s1
+                D = s1[:, :, None] * P
+                S = s2[:, :, None, None] * P[:, :, :, None] * P[:, :, None, :] + s1[:, :, None, None] * WS
+            else:
+                a, D, S = z, P, WS
+        return a, D, S
+
+
+# --------------------------------------------------------------------------------------
+# One-step map Phi(x_prev, u) and its per-row derivatives (tiles), for the three integrators
+# --------------------------------------------------------------------------------------
+def step_rows(net: MLP, kind: int, DT: float, x_prev, u, want_hess=False):
+    """Rows (R,nx),(R,nu) -> Phi (R,nx), dPhi (R,nx,nx+nu) [, d2Phi (R,nx,nx+nu,nx+nu)].
+
+    DISCRET: Phi = x + f(x,u)          integrator/discret.py:27
+    UNITY  : Phi = f(x,u)              integrator/unity.py:29
+    RK4    : Phi = x + DT/6 (k1+2k2+2k3+k4), u held over the step      integrator/rk4.py:69-80
+             stage Jacobians chained as dk_{i+1} = Jf(xi_i) (I + c_i DT [dk_i; 0])   rk4.py:147-159
+             stage Hessians   h_{i+1} = R^T Hf(xi_i) R + c_i DT sum_j Jf[:,j] h_i[j]   rk4.py:246-266
+
+    NOTE the reference adds the identity d x/d x of DISCRET and RK4 *outside* the model
+    Jacobian (discret.py:52, rk4.py:168); here it is folded into dPhi, the dense assembly
+    below therefore adds no extra +I.  Same numbers.
+    """
+    x_prev = np.asarray(x_prev, dtype=np.float64)
+    u = np.asarray(u, dtype=np.float64)
+    R, nx = x_prev.shape
+    nu = u.shape[1]
+    nin = nx + nu
+    Ex = np.zeros((nx, nin))
+    Ex[:, :nx] = np.eye(nx)
+
+    def net_eval(xs):
+        xi = np.concatenate([xs, u], axis=1)
+        if want_hess:
+            return net.forward_jac_hess(xi)
+        f, J = net.forward_jac(xi)
+        return f, J, None
+
+    if kind in (DISCRET, UNITY):
+        f, J, Hs = net_eval(x_prev)
+        if kind == DISCRET:
+            return x_prev + f, J + Ex[None], Hs
+        return f, J, Hs
+
+    assert kind == RK4
+    cs = (0.5, 0.5, 1.0)
+    wts = (1.0, 2.0, 2.0, 1.0)
+    k, dk, hk = net_eval(x_prev)
+    acc_k = wts[0] * k
+    acc_dk = wts[0] * dk
+    acc_h = wts[0] * hk if want_hess else None
+    for s in range(3):
+        c = cs[s] * DT
+        Rm = np.broadcast_to(np.eye(nin)[None], (R, nin, nin)).copy()
+        Rm[:, :nx, :] += c * dk
+        kn, Jn, Hn = net_eval(x_prev + c * k)
+        dkn = Jn @ Rm
+        if want_hess:
+            hn = np.einsum("rpa,rkab,rbq->rkpq", Rm.transpose(0, 2, 1), Hn, Rm)
+            hn = hn + c * np.einsum("rkj,rjpq->rkpq", Jn[:, :, :nx], hk)
+            hk = hn
+            acc_h = acc_h + wts[s + 1] * hn
+        k, dk = kn, dkn
+        acc_k = acc_k + wts[s + 1] * kn
+        acc_dk = acc_dk + wts[s + 1] * dkn
+    phi = x_prev + (DT / 6.0) * acc_k
+    dphi = (DT / 6.0) * acc_dk + Ex[None]
+    d2phi = (DT / 6.0) * acc_h if want_hess else None
+    return phi, dphi, d2phi
+
+
+# --------------------------------------------------------------------------------------
+# Problem description shared by all callbacks
+# --------------------------------------------------------------------------------------
+class Problem:
+    """One NLP family: dims, integrator, network, quadratic objective, optional box rows.
+
+    Objective (covers the two instances in the reference, examples/lotka_volterra/run.py:79-84
+    linear  sum(u*c)  and test.py:55-60 quadratic sum((u-2)^2)):
+        f = sum_t (x_t-xref_t)^T Q (x_t-xref_t) + (u_t-uref_t)^T R (u_t-uref_t) + cx_t.x_t + cu_t.u_t
+    Box rows (BASELINE config 5): extra rows  g_box = states.ravel()  with bounds [lo, hi]
+    (an INTER-type Constraint in the sense of constraints.py:57-63).
+    """
+
+    def __init__(self, net, H, nx, nu, kind=DISCRET, DT=1.0, Q=None, R=None, xref=None, uref=None,
+                 cx=None, cu=None, box=None):
+        assert net.n_in == nx + nu and net.n_out == nx
+        self.net, self.H, self.nx, self.nu, self.kind, self.DT = net, H, nx, nu, kind, float(DT)
+        self.n = H * (nx + nu)
+        self.Q = np.eye(nx) if Q is None else np.asarray(Q, dtype=np.float64).reshape(nx, nx)
+        self.R = 0.1 * np.eye(nu) if R is None else np.asarray(R, dtype=np.float64).reshape(nu, nu)
+
+        def _tv(v, d):
+            if v is None:
+                return np.zeros((H, d))
+            return np.broadcast_to(np.asarray(v, dtype=np.float64), (H, d)).copy()
+
+        self.xref, self.uref = _tv(xref, nx), _tv(uref, nu)
+        self.cx, self.cu = _tv(cx, nx), _tv(cu, nu)
+        self.box = None
+        if box is not None:
+            lo, hi = box
+            self.box = (np.broadcast_to(np.asarray(lo, dtype=np.float64), (nx,)).copy(),
+                        np.broadcast_to(np.asarray(hi, dtype=np.float64), (nx,)).copy())
+        self.m = H * nx + (H * nx if self.box is not None else 0)
+
+    # ---- optimizer/ipopt.py:20-28
+    def split(self, z):
+        H, nx, nu = self.H, self.nx, self.nu
+        z = np.asarray(z, dtype=np.float64)
+        return z[: H * nx].reshape(H, nx), z[H * nx:].reshape(H, nu)
+
+    # ---- optimizer/ipopt.py:30-42 with the quadratic family standing in for objective/jax.py
+    def objective(self, z):
+        x, u = self.split(z)
+        dx, du = x - self.xref, u - self.uref
+        return float(np.einsum("ti,ij,tj->", dx, self.Q, dx) + np.einsum("ti,ij,tj->", du, self.R, du)
+                     + np.sum(self.cx * x) + np.sum(self.cu * u))
+
+    def gradient(self, z):
+        x, u = self.split(z)
+        gx = (x - self.xref) @ (self.Q + self.Q.T).T + self.cx
+        gu = (u - self.uref) @ (self.R + self.R.T).T + self.cu
+        return np.concatenate([gx.ravel(), gu.ravel()])
+
+    def objective_hessian(self):
+        n, H, nx, nu = self.n, self.H, self.nx, self.nu
+        Hm = np.zeros((n, n))
+        for t in range(H):
+            Hm[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx] = self.Q + self.Q.T
+            o = H * nx + t * nu
+            Hm[o:o + nu, o:o + nu] = self.R + self.R.T
+        return Hm
+
+    # ---- per-row tiles
+    def tiles(self, z, x0, want_hess=False):
+        x, u = self.split(z)
+        x_prev = np.concatenate([np.asarray(x0, dtype=np.float64).reshape(1, -1), x[:-1]], axis=0)
+        phi, dphi, d2phi = step_rows(self.net, self.kind, self.DT, x_prev, u, want_hess)
+        return x, phi, dphi, d2phi
+
+    # ---- optimizer/ipopt.py:44-52 ; integrator/discret.py:13-30
+    def constraints(self, z, x0):
+        x, phi, _, _ = self.tiles(z, x0)
+        g = (phi - x).ravel()
+        if self.box is not None:
+            g = np.concatenate([g, x.ravel()])
+        return g
+
+    # ---- optimizer/ipopt.py:88-96 ; integrator/discret.py:32-58 ; rk4.py:113-178
+    def jacobian(self, z, x0):
+        H, nx, nu, n = self.H, self.nx, self.nu, self.n
+        _, _, dphi, _ = self.tiles(z, x0)
+        J = np.zeros((self.m, n))
+        for t in range(H):
+            r = slice(t * nx, (t + 1) * nx)
+            J[r, t * nx:(t + 1) * nx] -= np.eye(nx)
+            if t > 0:  # x0 is data, not a variable: the t=0 state block has no column
+                J[r, (t - 1) * nx:t * nx] += dphi[t, :, :nx]
+            J[r, H * nx + t * nu:H * nx + (t + 1) * nu] += dphi[t, :, nx:]
+        if self.box is not None:
+            J[H * nx:, :H * nx] = np.eye(H * nx)
+        return J
+
+    def tiles_AB(self, z, x0):
+        """Compact contract: g (H*nx,), A (H,nx,nx) = dPhi/dx_prev, Bt (H,nx,nu) = dPhi/du."""
+        x, phi, dphi, _ = self.tiles(z, x0)
+        return (phi - x).ravel(), dphi[:, :, : self.nx].copy(), dphi[:, :, self.nx:].copy()
+
+    def constraint_bounds(self):
+        """optimizer/ipopt.py:104-108 ; integrator/base.py:119-123"""
+        cl = np.zeros(self.H * self.nx)
+        cu = np.zeros(self.H * self.nx)
+        if self.box is not None:
+            cl = np.concatenate([cl, np.tile(self.box[0], self.H)])
+            cu = np.concatenate([cu, np.tile(self.box[1], self.H)])
+        return cl, cu
+
+    # ---- optimizer/ipopt.py:66-86 (dense Lagrangian Hessian before the tril gather)
+    def lagrangian_hessian(self, z, x0, lam, sigma):
+        """sigma * d2f + sum_i lam_i d2g_i, dense (n,n).  Box rows are linear: no contribution.
+
+        Placement of the per-row (nx+nu)^2 blocks follows integrator/discret.py:61-81 /
+        rk4.py:267-285: row t's x-part maps to variable block t-1 (dropped for t=0), its
+        u-part to control block t.
+        """
+        H, nx, nu, n = self.H, self.nx, self.nu, self.n
+        lam = np.asarray(lam, dtype=np.float64)
+        _, _, _, d2phi = self.tiles(z, x0, want_hess=True)
+        Hm = sigma * self.objective_hessian()
+        for t in range(H):
+            blk = np.einsum("k,kpq->pq", lam[t * nx:(t + 1) * nx], d2phi[t])
+            uo = H * nx + t * nu
+            Hm[uo:uo + nu, uo:uo + nu] += blk[nx:, nx:]
+            if t > 0:
+                xo = (t - 1) * nx
+                Hm[xo:xo + nx, xo:xo + nx] += blk[:nx, :nx]
+                Hm[xo:xo + nx, uo:uo + nu] += blk[:nx, nx:]
+                Hm[uo:uo + nu, xo:xo + nx] += blk[nx:, :nx]
+        return Hm
+
+    def hessian_structure(self):
+        """Exact structural lower-triangular pattern, row-major ordered like
+        np.nonzero(np.tril(.)) in optimizer/ipopt.py:55-62.  (The reference samples three random
+        points, integrator/base.py:89-115; the structural pattern is its superset.)"""
+        H, nx, nu, n = self.H, self.nx, self.nu, self.n
+        M = np.zeros((n, n), dtype=bool)
+        for t in range(H):
+            uo = H * nx + t * nu
+            M[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx] = True   # objective Q block
+            M[uo:uo + nu, uo:uo + nu] = True
+            if t > 0:
+                xo = (t - 1) * nx
+                M[xo:xo + nx, xo:xo + nx] = True
+                M[xo:xo + nx, uo:uo + nu] = True
+                M[uo:uo + nu, xo:xo + nx] = True
+        return np.nonzero(np.tril(M))
+
+    def hessian_values(self, z, x0, lam, sigma):
+        r, c = self.hessian_structure()
+        return self.lagrangian_hessian(z, x0, lam, sigma)[r, c]
+
+    # ---- batched convenience (python loop over problems = "reference-shaped" CPU mode)
+    def eval_batch(self, Z, X0, dense=True):
+        B = Z.shape[0]
+        f = np.empty(B)
+        grad = np.empty((B, self.n))
+        g = np.empty((B, self.m))
+        jac = np.empty((B, self.m, self.n)) if dense else None
+        for b in range(B):
+            f[b] = self.objective(Z[b])
+            grad[b] = self.gradient(Z[b])
+            g[b] = self.constraints(Z[b], X0[b])
+            if dense:
+                jac[b] = self.jacobian(Z[b], X0[b])
+        return f, grad, g, jac
+
+
+# --------------------------------------------------------------------------------------
+# Synthetic inputs of SURVEY.md 8(d) -- shared by tests, smoke and bench
+# --------------------------------------------------------------------------------------
+def synthetic_inputs(B, H, nx, nu, seed=1):
+    rng = np.random.default_rng(seed)
+    X0 = rng.uniform(-1.0, 1.0, size=(B, nx))
+    states = rng.normal(0.0, 1.0, size=(B, H, nx))
+    u = rng.uniform(-1.0, 1.0, size=(B, H, nu))
+    Z = np.concatenate([states.reshape(B, -1), u.reshape(B, -1)], axis=1)
+    return Z, X0
+
+
+def warm_start_shift(prev, H, nx, nu):
+    """optimizer/ipopt.py:141-147 == slsqp.py:155-161: drop step 0, repeat the last step."""
+    prev = np.asarray(prev, dtype=np.float64)
+    return np.concatenate([prev[nx:nx * H], prev[nx * (H - 1):nx * H],
+                           prev[nx * H + nu:(nx + nu) * H], prev[nx * H + nu * (H - 1):nx * H + nu * H]])
+
+
+def cold_start(x0, H, nu):
+    """optimizer/ipopt.py:149: [x0 tiled H ; zeros(H*nu)]."""
+    return np.concatenate([np.tile(np.asarray(x0, dtype=np.float64), H), np.zeros(H * nu)])
+
+
+def domain_bounds(states_constraint, control_constraint, H):
+    """constraints.py:26-30."""
+    lb = [e[0] for e in states_constraint] * H + [e[0] for e in control_constraint] * H
+    ub = [e[1] for e in states_constraint] * H + [e[1] for e in control_constraint] * H
+    return np.array(lb, dtype=np.float64), np.array(ub, dtype=np.float64)

@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own NumPy code.
+
+Run only in the build container (needs /root/reference, read-only; it never travels to the GPU
+box -- only the .npz files this script writes do):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+How the reference is imported: its package __init__ files pull tensorflow / jax,
+which are not installed, so empty package shells are registered in sys.modules first and the
+NumPy-only modules are imported from their files: model/base.py, integrator/{base,discret,unity,
+rk4}.py, constraints.py, objective/base.py, optimizer/{base,slsqp,ipopt}.py, controller.py.
+optimizer/ipopt.py has a top-level ``import cyipopt``; an attribute-less placeholder module is
+registered for that name so the pure-NumPy glue class ``IpoptProblem`` can be imported.
+``Ipopt.solve`` (the only user of cyipopt) is never called.
+
+What the reference cannot supply: Model.jacobian / Model.hessian / ObjectiveFunc.gradient are
+TensorFlow / JAX autodiff calls there.  The plug-ins below subclass the reference's own ``Model``
+and ``ObjectiveFunc`` ABCs, produce the reference's *layouts* (block layout [all-x | all-u],
+model/tensorflow.py:68-73) and take the per-row derivative *values* from oracle.MLP, which is
+pinned separately by torch.func AD and finite differences (tests/test_oracle.py).
+Everything downstream of those plug-ins in the stored outputs is reference arithmetic.
+"""
+import importlib.util
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/pyNeuralEMPC"
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+from oracle import nempc_oracle as orc  # noqa: E402
+
+
+def _shell(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, file):
+    spec = importlib.util.spec_from_file_location(name, file)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def import_reference():
+    root = _shell("pyNeuralEMPC", REF)
+    for sub in ("model", "integrator", "optimizer", "objective"):
+        setattr(root, sub, _shell(f"pyNeuralEMPC.{sub}", f"{REF}/{sub}"))
+    sys.modules.setdefault("cyipopt", types.ModuleType("cyipopt"))  # placeholder, see docstring
+    ref = types.SimpleNamespace()
+    ref.model_base = _load("pyNeuralEMPC.model.base", f"{REF}/model/base.py")
+    ref.constraints = _load("pyNeuralEMPC.constraints", f"{REF}/constraints.py")
+    ref.objective_base = _load("pyNeuralEMPC.objective.base", f"{REF}/objective/base.py")
+    ref.integ_base = _load("pyNeuralEMPC.integrator.base", f"{REF}/integrator/base.py")
+    ref.discret = _load("pyNeuralEMPC.integrator.discret", f"{REF}/integrator/discret.py")
+    ref.unity = _load("pyNeuralEMPC.integrator.unity", f"{REF}/integrator/unity.py")
+    ref.rk4 = _load("pyNeuralEMPC.integrator.rk4", f"{REF}/integrator/rk4.py")
+    ref.opt_base = _load("pyNeuralEMPC.optimizer.base", f"{REF}/optimizer/base.py")
+    ref.slsqp = _load("pyNeuralEMPC.optimizer.slsqp", f"{REF}/optimizer/slsqp.py")
+    ref.ipopt = _load("pyNeuralEMPC.optimizer.ipopt", f"{REF}/optimizer/ipopt.py")
+    opt = sys.modules["pyNeuralEMPC.optimizer"]
+    opt.Ipopt, opt.Optimizer, opt.Slsqp = ref.ipopt.Ipopt, ref.opt_base.Optimizer, ref.slsqp.Slsqp
+    ref.controller = _load("pyNeuralEMPC.controller", f"{REF}/controller.py")
+    return ref
+
+
+def make_plugins(ref):
+    class NumpyMLPModel(ref.model_base.Model):
+        """fp64 stand-in for KerasTFModel: same call signature and output layouts."""
+
+        def __init__(self, net, x_dim, u_dim):
+            super().__init__(x_dim, u_dim, 0, 0)
+            self.net = net
+
+        def forward(self, x, u, p=None, tvp=None):
+            return self.net.forward(np.concatenate([x, u], axis=1))
+
+        def jacobian(self, x, u, p=None, tvp=None):
+            H, nx, nu = x.shape[0], self.x_dim, self.u_dim
+            _, J = self.net.forward_jac(np.concatenate([x, u], axis=1))
+            out = np.zeros((H * nx, H * nx + H * nu))
+            for t in range(H):
+                out[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx] = J[t, :, :nx]
+                out[t * nx:(t + 1) * nx, H * nx + t * nu:H * nx + (t + 1) * nu] = J[t, :, nx:]
+            return out
+
+        def hessian(self, x, u, p=None, tvp=None):
+            H, nx, nu = x.shape[0], self.x_dim, self.u_dim
+            _, _, S = self.net.forward_jac_hess(np.concatenate([x, u], axis=1))
+            n = H * (nx + nu)
+            out = np.zeros((H, nx, n, n))
+            for t in range(H):
+                xs = slice(t * nx, (t + 1) * nx)
+                us = slice(H * nx + t * nu, H * nx + (t + 1) * nu)
+                out[t][:, xs, xs] = S[t][:, :nx, :nx]
+                out[t][:, xs, us] = S[t][:, :nx, nx:]
+                out[t][:, us, xs] = S[t][:, nx:, :nx]
+                out[t][:, us, us] = S[t][:, nx:, nx:]
+            return out
+
+    class QuadObjective(ref.objective_base.ObjectiveFunc):
+        """Closed-form member of the objective family; call-site signature of ipopt.py:33,40,71."""
+
+        def __init__(self, prob):
+            super().__init__()
+            self.prob = prob
+
+        def _z(self, states, u):
+            return np.concatenate([states.ravel(), u.ravel()])
+
+        def forward(self, states, u, p=None, tvp=None):
+            return self.prob.objective(self._z(states, u))
+
+        def gradient(self, states, u, p=None, tvp=None):
+            return self.prob.gradient(self._z(states, u))
+
+        def hessian(self, states, u, p=None, tvp=None):
+            return self.prob.objective_hessian()
+
+        def hessianstructure(self, H, model):
+            return (self.prob.objective_hessian() != 0.0).astype(np.float64)
+
+    class BoxStateRows(ref.constraints.Constraint):
+        """rows = states.ravel() in [lo, hi]  (no concrete row constraint exists in the reference)."""
+
+        def __init__(self, lo, hi, nx, nu):
+            self.lo, self.hi, self.nx, self.nu = np.asarray(lo, float), np.asarray(hi, float), nx, nu
+
+        def forward(self, x, u, p=None, tvp=None):
+            return x.reshape(-1).copy()
+
+        def jacobian(self, x, u, p=None, tvp=None):
+            H = x.shape[0]
+            return np.concatenate([np.eye(H * self.nx), np.zeros((H * self.nx, H * self.nu))], axis=1)
+
+        def hessian(self, x, u, p=None, tvp=None):
+            H = x.shape[0]
+            n = H * (self.nx + self.nu)
+            return np.zeros((H * self.nx, n, n))
+
+        def get_dim(self, H):
+            return H * self.nx
+
+        def get_lower_bounds(self, H):
+            return np.tile(self.lo, H)
+
+        def get_upper_bounds(self, H):
+            return np.tile(self.hi, H)
+
+    return NumpyMLPModel, QuadObjective, BoxStateRows
+
+
+CASES = {
+    # name: (nx, nu, hidden, H, kind, DT, box, B, with_hessian)
+    "c1_discret": (2, 1, [30, 30], 10, orc.DISCRET, 1.0, None, 3, True),
+    "c2_discret": (2, 1, [64, 64], 20, orc.DISCRET, 1.0, None, 4, True),
+    "c2_unity": (2, 1, [64, 64], 20, orc.UNITY, 1.0, None, 2, True),
+    "c2_rk4": (2, 1, [64, 64], 20, orc.RK4, 0.1, None, 2, True),     # nx+nu=3: rk4.hessian usable
+    "c3_rk4": (6, 3, [128, 128, 128], 30, orc.RK4, 0.1, None, 2, False),
+    "c3_discret": (6, 3, [128, 128, 128], 30, orc.DISCRET, 1.0, None, 1, False),
+    "c5_box": (2, 1, [64, 64], 50, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True),
+    "odd_dims": (3, 2, [48, 32], 7, orc.RK4, 0.05, None, 2, False),  # ragged: widths not equal, H odd
+    "h1": (2, 1, [16], 1, orc.DISCRET, 1.0, None, 2, True),            # degenerate horizon
+}
+
+
+def build_case(ref, plugins, name, spec):
+    NumpyMLPModel, QuadObjective, BoxStateRows = plugins
+    nx, nu, hidden, H, kind, DT, box, B, with_h = spec
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=0)
+    rng = np.random.default_rng(7)
+    xref = rng.normal(size=(H, nx)) * 0.3
+    uref = rng.normal(size=(H, nu)) * 0.3
+    cu = rng.normal(size=(H, nu)) * 0.1
+    Q = np.eye(nx) + 0.1 * rng.normal(size=(nx, nx))
+    Rm = 0.1 * np.eye(nu)
+    prob = orc.Problem(net, H, nx, nu, kind, DT, Q=Q, R=Rm, xref=xref, uref=uref, cu=cu, box=box)
+    model = NumpyMLPModel(net, nx, nu)
+    if kind == orc.DISCRET:
+        integ = ref.discret.DiscretIntegrator(model, H)
+    elif kind == orc.UNITY:
+        integ = ref.unity.UnityIntegrator(model, H)
+    else:
+        integ = ref.rk4.RK4Integrator(model, H, DT)
+    ctrs = [BoxStateRows(np.full(nx, box[0]), np.full(nx, box[1]), nx, nu)] if box is not None else []
+    obj = QuadObjective(prob)
+    Z, X0 = orc.synthetic_inputs(B, H, nx, nu, seed=1)
+    lam = np.random.default_rng(3).normal(size=(B, prob.m))
+    sigma = np.array([1.0, 0.5, 2.0, 0.0])[:B] if B <= 4 else np.ones(B)
+
+    out = {"nx": nx, "nu": nu, "H": H, "kind": kind, "DT": DT, "hidden": np.array(hidden),
+           "Z": Z, "X0": X0, "Q": Q, "R": Rm, "xref": xref, "uref": uref, "cu": cu,
+           "lam": lam, "sigma": sigma, "has_box": int(box is not None)}
+    if box is not None:
+        out["box_lo"], out["box_hi"] = np.full(nx, box[0]), np.full(nx, box[1])
+    for i, (w, b) in enumerate(zip(net.W, net.b)):
+        out[f"W{i}"], out[f"b{i}"] = w, b
+
+    f, grad, g, jac, hvals, hdense = [], [], [], [], [], []
+    g_int, j_int = [], []
+    for b in range(B):
+        pb = ref.ipopt.IpoptProblem(X0[b], obj, ctrs, integ)
+        f.append(pb.objective(Z[b]))
+        grad.append(pb.gradient(Z[b]))
+        g.append(pb.constraints(Z[b]))
+        jac.append(pb.jacobian(Z[b]))
+        states, u = Z[b][:H * nx].reshape(H, nx), Z[b][H * nx:].reshape(H, nu)
+        g_int.append(integ.forward(states, u, X0[b]))
+        j_int.append(integ.jacobian(states, u, X0[b]))
+        if with_h:
+            np.random.seed(11)  # integrator/base.py:96-97 samples with the global RNG
+            rows, cols = pb.hessianstructure()
+            out["h_rows"], out["h_cols"] = rows, cols
+            hvals.append(pb.hessian(Z[b], lam[b], sigma[b]))
+            ih = integ.hessian(states, u, X0[b])
+            hdense.append(sigma[b] * obj.hessian(states, u) + np.einsum("i,ipq->pq", lam[b][:H * nx], ih))
+    out.update(f=np.array(f), grad=np.array(grad), g=np.array(g), jac=np.array(jac),
+               g_int=np.array(g_int), jac_int=np.array(j_int))
+    out["cl"], out["cu_bound"] = pb.get_constraint_lower_bounds(), pb.get_constraint_upper_bounds()
+    if with_h:
+        out["hvals"], out["hdense"] = np.array(hvals), np.array(hdense)
+
+    # SLSQP glue splits (slsqp.py:54-110); INTER rows crash in the reference (slsqp.py:67-68) -> eq only there
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sp = ref.slsqp.SlsqpProblem(X0[0], obj, [] if box is not None else ctrs, integ)
+        out["slsqp_eq"] = sp.constraints(Z[0], eq=True)
+        out["slsqp_eq_jac"] = sp.jacobian(Z[0], eq=True)
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(f"{name}: n={prob.n} m={prob.m} B={B} nnz(jac)={int((jac[0] != 0).sum())}")
+
+
+def build_misc(ref, plugins):
+    """Bounds vectors, warm-start shift, and one full NMPC.next trajectory through reference SLSQP."""
+    NumpyMLPModel, QuadObjective, _ = plugins
+    out = {}
+    dc = ref.constraints.DomainConstraint(states_constraint=[[-np.inf, 1.0], [-2.0, np.inf]],
+                                          control_constraint=[[-1.0, 0.2]])
+    out["dom_lb"], out["dom_ub"] = np.array(dc.get_lower_bounds(5)), np.array(dc.get_upper_bounds(5))
+
+    nx, nu, H = 2, 1, 10
+    net = orc.MLP.random(nx + nu, [30, 30], nx, seed=0)
+    # damp the net so the closed loop is well behaved: x+ = x + 0.2 f(x,u)
+    net.W[-1] *= 0.2
+    net.b[-1] *= 0.2
+    prob = orc.Problem(net, H, nx, nu, orc.DISCRET, 1.0, Q=np.eye(nx), R=0.1 * np.eye(nu))
+    model = NumpyMLPModel(net, nx, nu)
+    integ = ref.discret.DiscretIntegrator(model, H)
+    obj = QuadObjective(prob)
+    dom = ref.constraints.DomainConstraint(states_constraint=[[-5.0, 5.0]] * nx, control_constraint=[[-1.0, 1.0]] * nu)
+    opt = ref.slsqp.Slsqp(max_iteration=200, tolerance=1e-10, verbose=0, init_with_last_result=True)
+    mpc = ref.controller.NMPC(integ, obj, [dom], H, 1.0, optimizer=opt)
+    x0 = np.array([0.7, -0.4])
+    # record the initial guess the reference hands to scipy (cold start slsqp.py:163, warm start slsqp.py:155-161)
+    inits = []
+    real_minimize = ref.slsqp.minimize
+
+    def recording_minimize(fun, x_init, *a, **k):
+        inits.append(np.array(x_init, dtype=np.float64))
+        return real_minimize(fun, x_init, *a, **k)
+
+    ref.slsqp.minimize = recording_minimize
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        states, u = mpc.next(x0)
+        first = opt.prev_result.copy()
+        x1 = states[0].copy()
+        states2, u2 = mpc.next(x1)   # warm-start branch
+    ref.slsqp.minimize = real_minimize
+    out.update(nmpc_x0=x0, nmpc_states=states, nmpc_u=u, nmpc_prev=first, nmpc_x1=x1,
+               nmpc_states2=states2, nmpc_u2=u2, nmpc_H=H, cold_init=inits[0], warm_from_first=inits[1])
+    for i, (w, b) in enumerate(zip(net.W, net.b)):
+        out[f"W{i}"], out[f"b{i}"] = w, b
+    np.savez_compressed(os.path.join(HERE, "misc.npz"), **out)
+    print("misc: NMPC.next ok, max|g| at solution =",
+          float(np.abs(integ.forward(states, u, x0)).max()))
+
+
+def main():
+    ref = import_reference()
+    plugins = make_plugins(ref)
+    for name, spec in CASES.items():
+        build_case(ref, plugins, name, spec)
+    build_misc(ref, plugins)
+
+
+if __name__ == "__main__":
+    main()

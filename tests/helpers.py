@@ -1,0 +1,26 @@
+"""Shared test helpers: load a golden case and rebuild the matching oracle Problem."""
+import os
+
+import numpy as np
+
+from oracle import nempc_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASE_NAMES = ["c1_discret", "c2_discret", "c2_unity", "c2_rk4", "c3_rk4", "c3_discret", "c5_box",
+              "odd_dims", "h1"]
+
+
+def load_case(name):
+    d = dict(np.load(os.path.join(GOLDEN, f"{name}.npz")))
+    nl = sum(1 for k in d if k.startswith("W"))
+    W = [d[f"W{i}"] for i in range(nl)]
+    b = [d[f"b{i}"] for i in range(nl)]
+    return d, W, b
+
+
+def oracle_problem(d, W, b):
+    net = orc.MLP(W, b)
+    box = (d["box_lo"], d["box_hi"]) if int(d["has_box"]) else None
+    return orc.Problem(net, int(d["H"]), int(d["nx"]), int(d["nu"]), int(d["kind"]), float(d["DT"]),
+                       Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"], box=box)

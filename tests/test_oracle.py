@@ -1,0 +1,141 @@
+"""CPU tests: the oracle against the reference-generated golden vectors, and the network
+derivative (the piece the reference delegates to TF/JAX autodiff) against torch AD and FD."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nempc_oracle as orc
+from helpers import CASE_NAMES, load_case, oracle_problem
+
+TOL = dict(rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_oracle_matches_reference_golden(name):
+    d, W, b = load_case(name)
+    prob = oracle_problem(d, W, b)
+    B = d["Z"].shape[0]
+    for i in range(B):
+        z, x0 = d["Z"][i], d["X0"][i]
+        np.testing.assert_allclose(prob.objective(z), d["f"][i], **TOL)
+        np.testing.assert_allclose(prob.gradient(z), d["grad"][i], **TOL)
+        np.testing.assert_allclose(prob.constraints(z, x0), d["g"][i], **TOL)
+        np.testing.assert_allclose(prob.jacobian(z, x0), d["jac"][i], **TOL)
+        # integrator-only outputs (no glue)
+        nxh = prob.H * prob.nx
+        np.testing.assert_allclose(prob.constraints(z, x0)[:nxh], d["g_int"][i], **TOL)
+        np.testing.assert_allclose(prob.jacobian(z, x0)[:nxh], d["jac_int"][i], **TOL)
+    cl, cu = prob.constraint_bounds()
+    np.testing.assert_array_equal(cl, d["cl"])
+    np.testing.assert_array_equal(cu, d["cu_bound"])
+    # structural zeros are exact zeros in both
+    assert np.array_equal(prob.jacobian(d["Z"][0], d["X0"][0]) != 0, d["jac"][0] != 0)
+
+
+@pytest.mark.parametrize("name", [n for n in CASE_NAMES if n not in ("c3_rk4", "c3_discret", "odd_dims")])
+def test_oracle_hessian_matches_reference_golden(name):
+    d, W, b = load_case(name)
+    prob = oracle_problem(d, W, b)
+    rows, cols = prob.hessian_structure()
+    ours = set(zip(rows.tolist(), cols.tolist()))
+    ref_pat = set(zip(d["h_rows"].tolist(), d["h_cols"].tolist()))
+    assert ref_pat <= ours, "reference's sampled pattern must be inside the structural pattern"
+    for i in range(d["Z"].shape[0]):
+        Hm = prob.lagrangian_hessian(d["Z"][i], d["X0"][i], d["lam"][i], float(d["sigma"][i]))
+        np.testing.assert_allclose(Hm, d["hdense"][i], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(Hm[d["h_rows"], d["h_cols"]], d["hvals"][i], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(Hm, Hm.T, rtol=1e-11, atol=1e-13)
+        # nothing outside the structural pattern
+        mask = np.zeros_like(Hm, dtype=bool)
+        mask[rows, cols] = True
+        assert np.all(np.tril(Hm)[~mask] == 0.0)
+
+
+def test_slsqp_glue_rows():
+    d, W, b = load_case("c2_discret")
+    prob = oracle_problem(d, W, b)
+    np.testing.assert_allclose(prob.constraints(d["Z"][0], d["X0"][0]), d["slsqp_eq"], **TOL)
+    np.testing.assert_allclose(prob.jacobian(d["Z"][0], d["X0"][0]), d["slsqp_eq_jac"], **TOL)
+
+
+def test_bounds_and_warm_start_against_reference():
+    m = dict(np.load(__import__("os").path.join(__import__("helpers").GOLDEN, "misc.npz")))
+    lb, ub = orc.domain_bounds([[-np.inf, 1.0], [-2.0, np.inf]], [[-1.0, 0.2]], 5)
+    np.testing.assert_array_equal(lb, m["dom_lb"])
+    np.testing.assert_array_equal(ub, m["dom_ub"])
+    H = int(m["nmpc_H"])
+    np.testing.assert_array_equal(orc.cold_start(m["nmpc_x0"], H, 1), m["cold_init"])
+    np.testing.assert_array_equal(orc.warm_start_shift(m["nmpc_prev"], H, 2, 1), m["warm_from_first"])
+
+
+# ---- the network derivative: independent AD (torch.func, fp64) ----
+def _torch_net(W, b):
+    Wt = [torch.tensor(w, dtype=torch.float64) for w in W]
+    bt = [torch.tensor(x, dtype=torch.float64) for x in b]
+
+    def f(xi):
+        a = xi
+        for w, bb in zip(Wt[:-1], bt[:-1]):
+            a = torch.tanh(a @ w + bb)
+        return a @ Wt[-1] + bt[-1]
+    return f
+
+
+@pytest.mark.parametrize("dims", [(3, [64, 64], 2), (9, [128, 128, 128], 6), (5, [48, 32], 3), (3, [16], 2)])
+def test_mlp_derivatives_vs_torch_ad(dims):
+    nin, hidden, nout = dims
+    net = orc.MLP.random(nin, hidden, nout, seed=4)
+    xi = np.random.default_rng(5).normal(size=(6, nin))
+    f, J, S = net.forward_jac_hess(xi)
+    f2, J2 = net.forward_jac(xi)
+    np.testing.assert_allclose(f, f2, rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(J, J2, rtol=1e-12, atol=1e-13)
+    tf = _torch_net(net.W, net.b)
+    for r in range(xi.shape[0]):
+        x = torch.tensor(xi[r], dtype=torch.float64)
+        np.testing.assert_allclose(tf(x).numpy(), f[r], rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(torch.func.jacrev(tf)(x).numpy(), J[r], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(torch.func.hessian(tf)(x).numpy(), S[r], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind,DT", [(orc.DISCRET, 1.0), (orc.UNITY, 1.0), (orc.RK4, 0.1), (orc.RK4, 0.5)])
+def test_step_derivatives_vs_torch_ad(kind, DT):
+    nx, nu = 3, 2
+    net = orc.MLP.random(nx + nu, [24, 24], nx, seed=2)
+    rng = np.random.default_rng(9)
+    xp, u = rng.normal(size=(4, nx)), rng.normal(size=(4, nu))
+    phi, dphi, d2phi = orc.step_rows(net, kind, DT, xp, u, want_hess=True)
+    tf = _torch_net(net.W, net.b)
+
+    def step(xi):
+        x, uu = xi[:nx], xi[nx:]
+        f = lambda xs: tf(torch.cat([xs, uu]))
+        if kind == orc.DISCRET:
+            return x + f(x)
+        if kind == orc.UNITY:
+            return f(x)
+        k1 = f(x); k2 = f(x + 0.5 * DT * k1); k3 = f(x + 0.5 * DT * k2); k4 = f(x + DT * k3)
+        return x + DT / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+    for r in range(4):
+        xi = torch.tensor(np.concatenate([xp[r], u[r]]), dtype=torch.float64)
+        np.testing.assert_allclose(step(xi).numpy(), phi[r], rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(torch.func.jacrev(step)(xi).numpy(), dphi[r], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(torch.func.hessian(step)(xi).numpy(), d2phi[r], rtol=1e-9, atol=1e-11)
+
+
+def test_jacobian_and_gradient_vs_finite_differences():
+    d, W, b = load_case("c2_rk4")
+    prob = oracle_problem(d, W, b)
+    z, x0 = d["Z"][0], d["X0"][0]
+    J = prob.jacobian(z, x0)
+    gr = prob.gradient(z)
+    eps = 1e-6
+    Jfd = np.zeros_like(J)
+    gfd = np.zeros_like(gr)
+    for j in range(prob.n):
+        e = np.zeros(prob.n); e[j] = eps
+        Jfd[:, j] = (prob.constraints(z + e, x0) - prob.constraints(z - e, x0)) / (2 * eps)
+        gfd[j] = (prob.objective(z + e) - prob.objective(z - e)) / (2 * eps)
+    assert np.abs(J - Jfd).max() < 1e-8
+    assert np.abs(gr - gfd).max() < 1e-7
