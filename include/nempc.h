@@ -1,0 +1,142 @@
+/*
+ * nempc.h -- C ABI of the MI355X-native NMPC callback engine (libnempc.so).
+ *
+ * The reference (Enderdead/pyNeuralEMPC) is pure Python and has no FFI of its own; what this
+ * library replaces is the arithmetic behind the five solver callbacks of
+ *     pyNeuralEMPC/optimizer/ipopt.py:30-96   (objective / gradient / constraints / jacobian / hessian)
+ * i.e.   integrator/{discret,unity,rk4}.py  forward + jacobian (+ hessian),
+ *        model/tensorflow.py:49-109         network forward / per-row jacobian / hessian,
+ *        objective/jax.py:28-57             f, grad f, hess f   (quadratic + linear family),
+ *        constraints.py:36-96               extra constraint rows (box rows on the states),
+ * evaluated for a BATCH of B independent problems per call (the reference solves one).
+ *
+ * Conventions
+ *  - every `const void*` / `void*` named Z, X0, f, grad, g, jac_*, lambda, sigma, hvals is a
+ *    DEVICE pointer owned by the caller, holding elements of the handle's dtype
+ *    (NEMPC_F64 -> double, NEMPC_F32 -> float), dense row-major, no padding;
+ *  - weights / objective / bounds setters take HOST pointers to double;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls enqueue work and
+ *    return; use nempc_sync or your own stream/event to wait;
+ *  - every function returns 0 (NEMPC_OK) or a negative NEMPC_E* code and never throws;
+ *    nempc_last_error() gives the message of the calling thread's last failure;
+ *  - a handle is not re-entrant: one in-flight evaluation per handle (use one handle per stream).
+ *
+ * Layouts (identical to the reference, optimizer/ipopt.py:20-28):
+ *    z  (n)      n = H*(nx+nu): z[0:H*nx] states (H,nx) row-major, z[H*nx:] controls (H,nu)
+ *    g  (m)      m = H*nx defects [+ H*nx box rows = states.ravel() when enabled]
+ *    jac_dense   (m,n) row-major -- what IpoptProblem.jacobian returns (ipopt.py:88-96)
+ *    jac_tiles   (H,nx,nx+nu): row t = d Phi(x_{t-1},u_t) / d [x_{t-1} | u_t]  (compact contract)
+ */
+#ifndef NEMPC_H
+#define NEMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEMPC_ABI_VERSION 1
+#define NEMPC_MAX_LAYERS 8 /* dense layers incl. the linear output layer */
+
+/* status codes */
+#define NEMPC_OK 0
+#define NEMPC_EINVAL (-1)   /* bad argument / dims */
+#define NEMPC_ENOMEM (-2)   /* device allocation failed */
+#define NEMPC_EHIP (-3)     /* a HIP runtime call failed */
+#define NEMPC_ESTATE (-4)   /* call order: weights / objective not set yet */
+#define NEMPC_EUNSUPPORTED (-5)
+
+/* dtype */
+#define NEMPC_F64 0
+#define NEMPC_F32 1
+
+/* integrator kind -- integrator/discret.py, unity.py, rk4.py */
+#define NEMPC_DISCRET 0 /* Phi = x + f(x,u) */
+#define NEMPC_UNITY 1   /* Phi = f(x,u) */
+#define NEMPC_RK4 2     /* Phi = x + DT/6 (k1 + 2k2 + 2k3 + k4) */
+
+/* row-kernel implementation */
+#define NEMPC_KERNEL_AUTO 0
+#define NEMPC_KERNEL_VALU 1 /* generic thread-per-row kernel, any dims */
+#define NEMPC_KERNEL_MFMA 2 /* matrix-core kernel, padded hidden width in {32,64,128}, <=3 hidden layers */
+
+typedef struct nempc_handle_s* nempc_handle;
+
+typedef struct nempc_config {
+    int32_t abi_version;              /* = NEMPC_ABI_VERSION */
+    int32_t device;                   /* HIP device ordinal */
+    int32_t dtype;                    /* NEMPC_F64 | NEMPC_F32 */
+    int32_t integrator;               /* NEMPC_DISCRET | NEMPC_UNITY | NEMPC_RK4 */
+    int32_t H, nx, nu;                /* Integrator.H, Model.x_dim, Model.u_dim */
+    int32_t n_layers;                 /* dense layers, >= 1; all but the last use tanh */
+    int32_t widths[NEMPC_MAX_LAYERS]; /* output width of each layer; widths[n_layers-1] == nx */
+    int32_t max_batch;                /* capacity B_max of the workspaces */
+    int32_t kernel;                   /* NEMPC_KERNEL_* */
+    int32_t reserved;
+    double DT;                        /* RK4 step (RK4Integrator.DT, rk4.py:49) */
+} nempc_config;
+
+/* lifetime ------------------------------------------------------------------------------- */
+int nempc_create(const nempc_config* cfg, nempc_handle* out);
+int nempc_destroy(nempc_handle h);
+
+/* network weights: W[l] is (in_l, out_l) row-major -- the Keras `kernel` layout used by
+ * KerasTFModel (model/tensorflow.py:8-51); b[l] is (out_l). Host doubles. */
+int nempc_set_weights(nempc_handle h, const double* const* W, const double* const* b);
+
+/* objective family standing in for JAXObjectifFunc (objective/jax.py:16-57):
+ *   f = sum_t (x_t-xref_t)^T Q (x_t-xref_t) + (u_t-uref_t)^T R (u_t-uref_t) + cx_t.x_t + cu_t.u_t
+ * Q (nx,nx), R (nu,nu), xref/cx (H,nx), uref/cu (H,nu); any pointer may be NULL (= zeros;
+ * Q NULL = identity, R NULL = 0.1*identity, the SURVEY 8(d) defaults). Host doubles. */
+int nempc_set_objective(nempc_handle h, const double* Q, const double* R, const double* xref,
+                        const double* uref, const double* cx, const double* cu);
+
+/* extra constraint rows g_box = states.ravel() (a Constraint in the sense of constraints.py:36-63
+ * with constant selector Jacobian); lo/hi (nx) host doubles are only reported back through
+ * nempc_constraint_bounds. enabled=0 removes the rows. */
+int nempc_set_box_rows(nempc_handle h, int enabled, const double* lo, const double* hi);
+
+/* sizes: n, m, structural nnz of jac, nnz of the lower-triangular Lagrangian Hessian */
+int nempc_dims(nempc_handle h, int32_t* n, int32_t* m, int32_t* nnz_jac, int32_t* nnz_hess);
+
+/* cl, cu (m) host doubles -- IpoptProblem.get_constraint_{lower,upper}_bounds, ipopt.py:104-108 */
+int nempc_constraint_bounds(nempc_handle h, double* cl, double* cu);
+
+/* sparsity patterns, host int32, row-major sorted (the order of np.nonzero):
+ * jacobian pattern (nnz_jac) and lower-triangular Hessian pattern (nnz_hess) -- replaces the
+ * random-sampling probe of integrator/base.py:89-115 + ipopt.py:55-62 by the exact band pattern */
+int nempc_jac_structure(nempc_handle h, int32_t* rows, int32_t* cols);
+int nempc_hess_structure(nempc_handle h, int32_t* rows, int32_t* cols);
+
+/* one batched evaluation of the hessian-free callbacks for B <= max_batch problems.
+ *   Z (B,n), X0 (B,nx) inputs.  Outputs, each may be NULL to skip:
+ *   f (B)            IpoptProblem.objective    ipopt.py:30-35
+ *   grad (B,n)       IpoptProblem.gradient     ipopt.py:37-42
+ *   g (B,m)          IpoptProblem.constraints  ipopt.py:44-52
+ *   jac_dense (B,m,n)IpoptProblem.jacobian     ipopt.py:88-96
+ *   jac_tiles (B,H,nx,nx+nu)  compact per-step tiles (rk4.py:85-92 shape)
+ *   jac_sparse (B,nnz_jac)    values in nempc_jac_structure order */
+int nempc_eval(nempc_handle h, int32_t B, const void* Z, const void* X0, void* f, void* grad,
+               void* g, void* jac_dense, void* jac_tiles, void* jac_sparse, void* stream);
+
+/* Lagrangian Hessian values, IpoptProblem.hessian ipopt.py:66-86:
+ *   hvals (B,nnz_hess) = (sigma_b * d2f + sum_i lambda_{b,i} d2g_i)[rows, cols]
+ *   lambda (B,m), sigma (B).  Optional outputs (may be NULL): hdense (B,n,n) full symmetric matrix;
+ *   hblocks (B,H,nx+nu,nx+nu) the per-step blocks sum_k lambda_{t,k} d2 Phi_k / d[x_{t-1}|u_t]^2
+ *   (the lambda-contracted form of Model.hessian, model/tensorflow.py:77-109). */
+int nempc_hess(nempc_handle h, int32_t B, const void* Z, const void* X0, const void* lambda,
+               const void* sigma, void* hvals, void* hdense, void* hblocks, void* stream);
+
+int nempc_sync(nempc_handle h, void* stream);
+
+/* which row kernel the handle resolved to (NEMPC_KERNEL_VALU | NEMPC_KERNEL_MFMA) */
+int nempc_kernel_variant(nempc_handle h);
+
+const char* nempc_last_error(void);
+int nempc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEMPC_H */

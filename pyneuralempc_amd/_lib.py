@@ -1,0 +1,78 @@
+"""ctypes binding of libnempc.so (include/nempc.h).  There is no CPU fallback: if the library is
+missing or no HIP device is visible the callers fail with a clear error."""
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libnempc.so")
+
+ABI_VERSION = 1
+MAX_LAYERS = 8
+F64, F32 = 0, 1
+DISCRET, UNITY, RK4 = 0, 1, 2
+KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA = 0, 1, 2
+KERNEL_NAMES = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA}
+INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
+
+EXPORTS = ["nempc_create", "nempc_destroy", "nempc_set_weights", "nempc_set_objective", "nempc_set_box_rows",
+           "nempc_dims", "nempc_constraint_bounds", "nempc_jac_structure", "nempc_hess_structure", "nempc_eval",
+           "nempc_hess", "nempc_sync", "nempc_kernel_variant", "nempc_last_error", "nempc_abi_version"]
+
+
+class NempcError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libnempc error {code}: {message}")
+        self.code = code
+
+
+class NempcConfig(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_int32), ("device", ctypes.c_int32), ("dtype", ctypes.c_int32),
+                ("integrator", ctypes.c_int32), ("H", ctypes.c_int32), ("nx", ctypes.c_int32),
+                ("nu", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("widths", ctypes.c_int32 * MAX_LAYERS),
+                ("max_batch", ctypes.c_int32), ("kernel", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("DT", ctypes.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """Load libnempc.so once and declare every prototype of include/nempc.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `python -m pyneuralempc_amd._build` "
+                           "(or __graft_entry__.build()); pyneuralempc_amd has no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, dp = ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_double)
+    ip = ctypes.POINTER(ctypes.c_int32)
+    dpp = ctypes.POINTER(dp)
+    lib.nempc_create.argtypes = [ctypes.POINTER(NempcConfig), ctypes.POINTER(vp)]
+    lib.nempc_destroy.argtypes = [vp]
+    lib.nempc_set_weights.argtypes = [vp, dpp, dpp]
+    lib.nempc_set_objective.argtypes = [vp, dp, dp, dp, dp, dp, dp]
+    lib.nempc_set_box_rows.argtypes = [vp, ctypes.c_int, dp, dp]
+    lib.nempc_dims.argtypes = [vp, ip, ip, ip, ip]
+    lib.nempc_constraint_bounds.argtypes = [vp, dp, dp]
+    lib.nempc_jac_structure.argtypes = [vp, ip, ip]
+    lib.nempc_hess_structure.argtypes = [vp, ip, ip]
+    lib.nempc_eval.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.nempc_hess.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.nempc_sync.argtypes = [vp, vp]
+    lib.nempc_kernel_variant.argtypes = [vp]
+    lib.nempc_last_error.argtypes = []
+    lib.nempc_last_error.restype = ctypes.c_char_p
+    lib.nempc_abi_version.argtypes = []
+    for name in EXPORTS:
+        if name != "nempc_last_error":
+            getattr(lib, name).restype = ctypes.c_int
+    if lib.nempc_abi_version() != ABI_VERSION:
+        raise RuntimeError("libnempc.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NempcError(rc, load().nempc_last_error().decode("utf-8", "replace"))

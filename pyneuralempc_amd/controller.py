@@ -1,0 +1,76 @@
+"""NMPC facade (reference: pyNeuralEMPC/controller.py:7-113): argument checks, problem assembly
+through the optimizer's factory, solve, reshape."""
+import numpy as np
+
+from .constraints import DomainConstraint
+from .optimizer import Ipopt, Optimizer
+
+
+class NMPC:
+    def __init__(self, integrator, objective_func, constraint_list, H, DT, optimizer=None, use_hessian=True):
+        self.integrator = integrator
+        self.objective_func = objective_func
+        self.constraint_list = constraint_list
+        domains = [c for c in constraint_list if isinstance(c, DomainConstraint)]
+        if not domains:
+            raise IndexError("constraint_list must contain a DomainConstraint")
+        # like the reference (controller.py:13-14) the first DomainConstraint is taken OUT of the caller's list
+        self.domain_constraint = domains[0]
+        self.constraint_list.remove(self.domain_constraint)
+        self.H = H
+        self.DT = DT
+        # the reference's default argument `optimizer=Ipopt()` is one instance shared by every NMPC
+        # (controller.py:8); a fresh one per controller is used here
+        self.optimizer = Ipopt() if optimizer is None else optimizer
+        # stored and, as in the reference, NOT forwarded to the problem factory (controller.py:18,
+        # optimizer/base.py:78): the solve runs hessian-free unless the optimizer opts in
+        self.use_hessian = use_hessian
+
+    def _check(self, x0, p, tvp, init_x, init_u):
+        model = self.integrator.model
+        assert len(x0.shape) == 1, "x0 must be a vector"
+        assert x0.shape[0] == model.x_dim, "x0 dim must set according to your model !"
+        if p is not None:
+            assert len(p.shape) == 1, "p must be a vector"
+            assert p.shape[0] == model.p_dim, "p dim must set according to your model !"
+        if tvp is not None:
+            assert len(tvp.shape) == 2, "tvp must be a vector"
+            assert tvp.shape[1] == model.tvp_dim, "tvp dim must set according to your model !"
+            assert tvp.shape[0] == self.H, "tvp first dim must set according to the horizon size !"
+        assert (init_x is None) == (init_u is None), "you must give both init values"
+        if init_x is not None:
+            assert init_x.shape[1] == model.x_dim, ("init_x dim must have the good feature size "
+                                                    f"(expected {model.x_dim})")
+            assert init_u.shape[1] == model.u_dim, ("init_u dim mist have the good feature size "
+                                                    f"(expected {model.u_dim})")
+
+    def get_pb(self, x0: np.array, p=None, tvp=None, init_x=None, init_u=None):
+        self._check(x0, p, tvp, init_x, init_u)
+        factory = self.optimizer.get_factory()
+        factory.set_x0(x0)
+        factory.set_objective(self.objective_func)
+        factory.set_integrator(self.integrator)
+        factory.set_constraints(self.constraint_list)
+        if init_x is not None:
+            factory.set_init_values(init_x, init_u)
+        if tvp is not None:
+            factory.set_tvp(tvp)
+        if p is not None:
+            factory.set_p(p)
+        if getattr(self.optimizer, "exact_hessian", False):
+            factory.set_use_hessian(bool(self.use_hessian))
+        return factory.getProblemInterface()
+
+    def next(self, x0: np.array, p=None, tvp=None, init_x=None, init_u=None):
+        """Solve one MPC problem; returns (states (H,nx), u (H,nu)) or (None, None) on solver failure."""
+        pb = self.get_pb(x0, p=p, tvp=tvp, init_x=init_x, init_u=init_u)
+        status = self.optimizer.solve(pb, self.domain_constraint)
+        if status != Optimizer.SUCCESS:
+            return None, None
+        model = self.integrator.model
+        z = self.optimizer.prev_result
+        nxh = model.x_dim * self.integrator.H
+        return z[:nxh].reshape(self.integrator.H, -1), z[nxh:].reshape(self.integrator.H, -1)
+
+
+MPC = NMPC  # BASELINE.json's north_star calls the entry point controller.MPC

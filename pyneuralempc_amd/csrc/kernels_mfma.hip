@@ -1,0 +1,132 @@
+// Host side of the matrix-core row kernel: shape gate, weight packing, launch geometry.
+#include <algorithm>
+#include <cmath>
+
+#include "kernels_mfma_impl.h"
+
+namespace nempc {
+
+namespace {
+
+int padded_width(const Handle& h) {
+    int w = 0;
+    for (int l = 0; l < h.nl - 1; ++l) w = std::max(w, h.dout[l]);
+    if (w <= 32) return 32;
+    if (w <= 64) return 64;
+    if (w <= 128) return 128;
+    return 0;
+}
+
+MfmaOffsets make_offsets(int wp, int nh, int ks, int nx) {
+    const int MT = wp / 16;
+    MfmaOffsets o{};
+    int p = 0;
+    o.w0f = p; p += ks * MT * 64;
+    for (int l = 1; l < nh; ++l) { o.wf[l] = p; p += MT * MT * 4 * 64; }
+    o.wLf = p; p += MT * 4 * 64;
+    for (int l = 1; l < nh; ++l) { o.wb[l] = p; p += MT * MT * 4 * 64; }
+    o.w0b = p; p += MT * 4 * 64;
+    o.seed = p; p += nx * MT * 16;
+    for (int l = 0; l < nh; ++l) { o.bias[l] = p; p += MT * 16; }
+    o.biasL = p; p += 16;
+    o.total = p;
+    return o;
+}
+
+int scratch_elems(const Handle& h) {
+    const int nx = h.cfg.nx, nin = h.nin;
+    return 16 * nin + 2 * 16 * nx + 4 * 16 * nx * nin;
+}
+
+}  // namespace
+
+bool mfma_supported(const Handle& h) {
+    const int nh = h.nl - 1;
+    if (nh < 1 || nh > 3) return false;
+    if (h.cfg.nx > 16 || h.nin > 16) return false;
+    return padded_width(h) != 0;
+}
+
+void mfma_free(Handle& h) {
+    if (h.mfma.blob) (void)hipFree(h.mfma.blob);
+    h.mfma.blob = nullptr;
+}
+
+// Pack every layer into MFMA A-operand fragments (lane-linear: element [frag*64 + lane]).
+// lane = kq*16 + i16 supplies A[M index i16][K index kq]; the K index of k-step (mt, r) stands for
+// feature 16*mt + row(kq, r) where row() is the accumulator register->row map of the dtype
+// (f64: kq + 4r, f32: 4kq + r), so that accumulator register r of tile mt is the matching B operand.
+int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b) {
+    const int wp = padded_width(h), nh = h.nl - 1, MT = wp / 16;
+    const int nx = h.cfg.nx, nin = h.nin, ks = (nin + 3) / 4, L = h.nl - 1;
+    const bool f64 = h.cfg.dtype == NEMPC_F64;
+    auto row = [&](int q, int r) { return f64 ? MfmaOps<double>::row(q, r) : MfmaOps<float>::row(q, r); };
+    const MfmaOffsets o = make_offsets(wp, nh, ks, nx);
+    std::vector<double> blob((size_t)o.total, 0.0);
+    auto Wat = [&](int l, int i, int j) -> double {
+        return (i < h.din[l] && j < h.dout[l]) ? W[l][(size_t)i * h.dout[l] + j] : 0.0;
+    };
+    for (int lane = 0; lane < 64; ++lane) {
+        const int i16 = lane & 15, kq = lane >> 4;
+        for (int k = 0; k < ks; ++k)
+            for (int mo = 0; mo < MT; ++mo) blob[o.w0f + (k * MT + mo) * 64 + lane] = Wat(0, 4 * k + kq, 16 * mo + i16);
+        for (int mt = 0; mt < MT; ++mt)
+            for (int r = 0; r < 4; ++r) {
+                const int kf = 16 * mt + row(kq, r);
+                for (int l = 1; l < nh; ++l)
+                    for (int mo = 0; mo < MT; ++mo) {
+                        blob[o.wf[l] + ((mt * 4 + r) * MT + mo) * 64 + lane] = Wat(l, kf, 16 * mo + i16);
+                        blob[o.wb[l] + ((mt * 4 + r) * MT + mo) * 64 + lane] = Wat(l, 16 * mo + i16, kf);
+                    }
+                blob[o.wLf + (mt * 4 + r) * 64 + lane] = (i16 < nx) ? Wat(L, kf, i16) : 0.0;
+                blob[o.w0b + (mt * 4 + r) * 64 + lane] = (i16 < nin) ? Wat(0, i16, kf) : 0.0;
+            }
+    }
+    for (int q = 0; q < 4; ++q)
+        for (int r = 0; r < 4; ++r) {
+            for (int mt = 0; mt < MT; ++mt) {
+                const int f = 16 * mt + row(q, r);
+                for (int k = 0; k < nx; ++k) blob[o.seed + k * MT * 16 + (mt * 4 + r) * 4 + q] = Wat(L, f, k);
+                for (int l = 0; l < nh; ++l) blob[o.bias[l] + (mt * 4 + r) * 4 + q] = (f < h.dout[l]) ? b[l][f] : 0.0;
+            }
+            const int oo = row(q, r);
+            blob[o.biasL + r * 4 + q] = (oo < nx) ? b[L][oo] : 0.0;
+        }
+
+    mfma_free(h);
+    hipError_t e = hipMalloc(&h.mfma.blob, blob.size() * h.esz);
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc(mfma blob): ") + hipGetErrorString(e));
+        return NEMPC_ENOMEM;
+    }
+    if (f64) {
+        NEMPC_HIP(hipMemcpy(h.mfma.blob, blob.data(), blob.size() * 8, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> tmp(blob.begin(), blob.end());
+        NEMPC_HIP(hipMemcpy(h.mfma.blob, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+    }
+    h.mfma.wp = wp;
+    h.mfma.nh = nh;
+    h.mfma.kin = 4 * ks;
+    h.mfma.blob_elems = blob.size();
+    return NEMPC_OK;
+}
+
+int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s) {
+    if (!h.mfma.blob) {
+        set_error("launch_rows_mfma: weights not packed");
+        return NEMPC_ESTATE;
+    }
+    MfmaParams p{};
+    p.blob = h.mfma.blob;
+    p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + 3) / 4;
+    p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx);
+    p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
+    p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
+    p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
+    p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
+    p.scratch_per_wave = (scratch_elems(h) + 1) & ~1;
+    return h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+}
+
+}  // namespace nempc

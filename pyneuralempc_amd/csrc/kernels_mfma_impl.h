@@ -1,0 +1,363 @@
+// Matrix-core row kernel (gfx950): one wavefront owns a tile of 16 (problem, step) rows.
+//
+// Formulation ("features on M, rows on N"): every dense layer is computed transposed,
+//     Z^T (features x 16 rows) = W^T (features x K) . A^T (K x 16 rows)
+// with v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32.  The weight fragment is the MFMA A operand,
+// the activations are the B operand.  Because the C/D accumulator layout of these instructions puts
+// the 16 batch rows on lane&15 and the feature index on (lane>>4, register), an accumulator register
+// IS a valid B operand of the next layer's k-step: activations never leave registers and never get
+// transposed; only the (host pre-packed) weight fragments are permuted to match.  The reverse sweep
+// (one cotangent per network output) uses the same trick with W instead of W^T.
+//
+//   forward   a_l = tanh(W_l^T a_{l-1} + b_l),  f = W_L^T a_{L-1} + b_L
+//   reverse   c = W_L[:,k] (1-a^2);  c <- (W_l c) (1-a_{l-1}^2) ... ;  J[k,:] = W_1 c
+//   (value-equivalent to what tf.GradientTape.jacobian yields per row, model/tensorflow.py:53-75)
+//
+// The per-row integrator algebra (rk4.py:147-159 chain rule, discret.py:52 identity) runs on a
+// small per-wave LDS scratch after each stage; the tile's outputs leave through coalesced stores.
+//
+// Packed weight blob: see mfma_pack_weights() in kernels_mfma.hip (lane-linear fragments, so a
+// fragment read is one conflict-free ds_read / one fully coalesced global load).
+#pragma once
+
+#include "nempc_internal.h"
+
+namespace nempc {
+
+struct MfmaOffsets {  // element offsets into the packed blob
+    int w0f, wLf, w0b, seed, biasL;
+    int wf[3], wb[3], bias[3];
+    int total;
+};
+
+struct MfmaParams {
+    const void* blob;
+    MfmaOffsets off;
+    int nx, nu, nin, ks;  // ks = padded-input k-steps (ceil(nin/4))
+    int kind;
+    double DT;
+    int B, H, m, box;
+    const void* Z;
+    const void* X0;
+    void* g;
+    void* tiles;
+    int ntiles;
+    int scratch_per_wave;  // elements
+};
+
+template <typename T>
+struct MfmaOps;
+
+template <>
+struct MfmaOps<double> {
+    typedef double V4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ V4 mma(double a, double b, V4 c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __host__ __device__ __forceinline__ int row(int q, int r) { return q + 4 * r; }
+    static __device__ __forceinline__ double tanh_(double x) { return tanh(x); }
+};
+
+template <>
+struct MfmaOps<float> {
+    typedef float V4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ V4 mma(float a, float b, V4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __host__ __device__ __forceinline__ int row(int q, int r) { return 4 * q + r; }
+    static __device__ __forceinline__ float tanh_(float x) { return tanhf(x); }
+};
+
+// same-wave LDS hand-off between lanes: DS ops of one wave execute in order; keep the compiler from
+// moving accesses across the point
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// acc[mo] += sum over k-steps (mt, r) of  W-fragment[(mt*4+r)*MO + mo] x bop[mt][r]
+// Fragments are lane-linear (64 elements each).  LDS-resident weights: plain loop, the compiler
+// schedules the ds_reads.  Global (L2) weights: explicit one-step-ahead prefetch fenced by
+// sched_barrier so that hipcc does not hoist hundreds of fragment loads and spill.
+template <typename T, int MT_IN, int MO, bool WLDS>
+__device__ __forceinline__ void layer_mma(const T* __restrict__ w, int lane,
+                                          const typename MfmaOps<T>::V4 (&bop)[MT_IN],
+                                          typename MfmaOps<T>::V4 (&acc)[MO]) {
+    using Ops = MfmaOps<T>;
+    if constexpr (WLDS) {
+#pragma unroll
+        for (int mt = 0; mt < MT_IN; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int mo = 0; mo < MO; ++mo)
+                    acc[mo] = Ops::mma(w[((mt * 4 + r) * MO + mo) * 64 + lane], bop[mt][r], acc[mo]);
+    } else {
+        // the fragments do not depend on the enclosing cotangent / stage loops: without an opaque
+        // offset LICM hoists every one of them out of those loops and the kernel spills
+        int opaque = 0;
+        asm volatile("" : "+s"(opaque));
+        w += opaque;
+        T wcur[MO], wnxt[MO];
+#pragma unroll
+        for (int mo = 0; mo < MO; ++mo) wcur[mo] = w[mo * 64 + lane];
+#pragma unroll
+        for (int it = 0; it < MT_IN * 4; ++it) {
+            if (it + 1 < MT_IN * 4) {
+#pragma unroll
+                for (int mo = 0; mo < MO; ++mo) wnxt[mo] = w[((it + 1) * MO + mo) * 64 + lane];
+            }
+#pragma unroll
+            for (int mo = 0; mo < MO; ++mo) acc[mo] = Ops::mma(wcur[mo], bop[it >> 2][it & 3], acc[mo]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mo = 0; mo < MO; ++mo) wcur[mo] = wnxt[mo];
+        }
+    }
+}
+
+template <typename T, int WP, int NH, bool WLDS, int MAXWAVES>
+__global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) {
+    using Ops = MfmaOps<T>;
+    using V4 = typename Ops::V4;
+    constexpr int MT = WP / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const T* __restrict__ gblob = static_cast<const T*>(p.blob);
+
+    const T* wsrc;
+    T* scratch;
+    if (WLDS) {
+        for (int i = threadIdx.x; i < p.off.total; i += blockDim.x) lds[i] = gblob[i];
+        __syncthreads();
+        wsrc = lds;
+        scratch = lds + ((p.off.total + 1) & ~1) + wave * p.scratch_per_wave;
+    } else {
+        wsrc = gblob;
+        scratch = lds + wave * p.scratch_per_wave;
+    }
+
+    const int nx = p.nx, nu = p.nu, nin = p.nin, H = p.H;
+    const int n = H * nin;
+    const size_t R = (size_t)p.B * H;
+    const T* __restrict__ Z = static_cast<const T*>(p.Z);
+    const T* __restrict__ X0 = static_cast<const T*>(p.X0);
+    T* __restrict__ gout = static_cast<T*>(p.g);
+    T* __restrict__ tiles = static_cast<T*>(p.tiles);
+    const bool rk4 = p.kind == NEMPC_RK4;
+    const int nstages = rk4 ? 4 : 1;
+    const T DT = (T)p.DT;
+
+    // per-wave scratch carve-up (elements): xi0[16][nin] kcur[16][nx] acck[16][nx] J/dk/accdk/dkn [16][nx][nin]
+    const int jsz = 16 * nx * nin;
+    T* s_xi0 = scratch;
+    T* s_k = s_xi0 + 16 * nin;
+    T* s_acck = s_k + 16 * nx;
+    T* s_J = s_acck + 16 * nx;
+    T* s_dk = s_J + jsz;
+    T* s_accdk = s_dk + jsz;
+    T* s_dkn = s_accdk + jsz;
+
+    for (int tile = blockIdx.x * nwaves + wave; tile < p.ntiles; tile += gridDim.x * nwaves) {
+        const size_t row0 = (size_t)tile * 16;
+
+        // ---- stage the tile's inputs xi0[c][d] = [x_{t-1} ; u_t]  (discret.py:22, ipopt.py:20-28)
+        for (int e = lane; e < 16 * nin; e += 64) {
+            const int cc = e / nin, d = e - cc * nin;
+            const size_t r = row0 + cc;
+            T v = T(0);
+            if (r < R) {
+                const int b = (int)(r / H), t = (int)(r - (size_t)b * H);
+                const T* z = Z + (size_t)b * n;
+                if (d < nx) v = (t == 0) ? X0[(size_t)b * nx + d] : z[(t - 1) * nx + d];
+                else v = z[H * nx + t * nu + (d - nx)];
+            }
+            s_xi0[e] = v;
+        }
+        wave_sync();
+
+        for (int stage = 0; stage < nstages; ++stage) {
+            const T cdt = (stage == 0) ? T(0) : ((stage == 3) ? DT : T(0.5) * DT);
+            // ---- B operand of the first layer: xin[ks] = xi[4ks+q] of row c
+            T xin[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int d = 4 * ks + q;
+                T v = T(0);
+                if (ks < p.ks && d < nin) {
+                    v = s_xi0[c * nin + d];
+                    if (stage > 0 && d < nx) v = fma(cdt, s_k[c * nx + d], v);
+                }
+                xin[ks] = v;
+            }
+            wave_sync();  // s_k is overwritten below
+
+            // ---- forward
+            V4 a[NH][MT];
+            {
+                const T* bias = wsrc + p.off.bias[0];
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[0][mo][r] = bias[(mo * 4 + r) * 4 + q];
+                const T* w = wsrc + p.off.w0f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < p.ks) {
+#pragma unroll
+                        for (int mo = 0; mo < MT; ++mo)
+                            a[0][mo] = Ops::mma(w[(ks * MT + mo) * 64 + lane], xin[ks], a[0][mo]);
+                    }
+                }
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[0][mo][r] = Ops::tanh_(a[0][mo][r]);
+            }
+#pragma unroll
+            for (int l = 1; l < NH; ++l) {
+                const T* bias = wsrc + p.off.bias[l];
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[l][mo][r] = bias[(mo * 4 + r) * 4 + q];
+                layer_mma<T, MT, MT, WLDS>(wsrc + p.off.wf[l], lane, a[l - 1], a[l]);
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[l][mo][r] = Ops::tanh_(a[l][mo][r]);
+            }
+            {
+                V4 fo;
+                const T* bias = wsrc + p.off.biasL;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) fo[r] = bias[r * 4 + q];
+                V4 fo1[1] = {fo};
+                layer_mma<T, MT, 1, WLDS>(wsrc + p.off.wLf, lane, a[NH - 1], fo1);
+                fo = fo1[0];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = Ops::row(q, r);
+                    if (o < nx) s_k[c * nx + o] = fo[r];
+                }
+            }
+            // 1 - a^2 once, reused by every cotangent
+#pragma unroll
+            for (int l = 0; l < NH; ++l)
+#pragma unroll
+                for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[l][mo][r] = T(1) - a[l][mo][r] * a[l][mo][r];
+
+            // ---- reverse sweep, one cotangent per network output
+            for (int k = 0; k < nx; ++k) {
+                V4 cv[MT];
+                const T* seed = wsrc + p.off.seed + k * MT * 16;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cv[mt][r] = seed[(mt * 4 + r) * 4 + q] * a[NH - 1][mt][r];
+#pragma unroll
+                for (int l = NH - 1; l >= 1; --l) {
+                    V4 cn[MT];
+#pragma unroll
+                    for (int mo = 0; mo < MT; ++mo) cn[mo] = V4{T(0), T(0), T(0), T(0)};
+                    layer_mma<T, MT, MT, WLDS>(wsrc + p.off.wb[l], lane, cv, cn);
+#pragma unroll
+                    for (int mo = 0; mo < MT; ++mo) cv[mo] = cn[mo] * a[l - 1][mo];
+                }
+                V4 jk1[1] = {V4{T(0), T(0), T(0), T(0)}};
+                layer_mma<T, MT, 1, WLDS>(wsrc + p.off.w0b, lane, cv, jk1);
+                const V4 jk = jk1[0];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int d = Ops::row(q, r);
+                    if (d < nin) s_J[(c * nx + k) * nin + d] = jk[r];
+                }
+            }
+            wave_sync();
+
+            // ---- RK4 chain rule on the scratch (rk4.py:147-159)
+            if (rk4) {
+                if (stage == 0) {
+                    for (int e = lane; e < jsz; e += 64) {
+                        const T v = s_J[e];
+                        s_dk[e] = v;
+                        s_accdk[e] = v;
+                    }
+                    for (int e = lane; e < 16 * nx; e += 64) s_acck[e] = s_k[e];
+                } else {
+                    const T wgt = (stage == 3) ? T(1) : T(2);
+                    for (int e = lane; e < jsz; e += 64) {
+                        const int cc = e / (nx * nin), rem = e - cc * nx * nin;
+                        const int i = rem / nin, d = rem - i * nin;
+                        T v = T(0);
+                        for (int e2 = 0; e2 < nx; ++e2)
+                            v = fma(s_J[(cc * nx + i) * nin + e2], s_dk[(cc * nx + e2) * nin + d], v);
+                        s_dkn[e] = fma(cdt, v, s_J[e]);
+                    }
+                    wave_sync();
+                    for (int e = lane; e < jsz; e += 64) {
+                        const T v = s_dkn[e];
+                        s_dk[e] = v;
+                        s_accdk[e] = fma(wgt, v, s_accdk[e]);
+                    }
+                    for (int e = lane; e < 16 * nx; e += 64) s_acck[e] = fma(wgt, s_k[e], s_acck[e]);
+                }
+                wave_sync();
+            }
+        }
+
+        // ---- outputs: tiles (16 rows contiguous in memory) and defects
+        const T s6 = DT / T(6);
+        for (int e = lane; e < jsz; e += 64) {
+            const int cc = e / (nx * nin), rem = e - cc * nx * nin;
+            const int i = rem / nin, d = rem - i * nin;
+            if (row0 + cc < R) {
+                T v;
+                if (rk4) v = s6 * s_accdk[e] + (d == i ? T(1) : T(0));
+                else v = s_J[e] + ((p.kind == NEMPC_DISCRET && d == i) ? T(1) : T(0));
+                tiles[row0 * nx * nin + e] = v;
+            }
+        }
+        for (int e = lane; e < 16 * nx; e += 64) {
+            const int cc = e / nx, i = e - cc * nx;
+            const size_t r = row0 + cc;
+            if (r < R) {
+                const int b = (int)(r / H), t = (int)(r - (size_t)b * H);
+                const T xp = s_xi0[cc * nin + i];
+                T phi;
+                if (rk4) phi = xp + s6 * s_acck[e];
+                else phi = (p.kind == NEMPC_DISCRET ? xp : T(0)) + s_k[e];
+                const T xt = Z[(size_t)b * n + t * nx + i];
+                gout[(size_t)b * p.m + t * nx + i] = phi - xt;
+                if (p.box) gout[(size_t)b * p.m + (size_t)H * nx + t * nx + i] = xt;
+            }
+        }
+        wave_sync();
+    }
+}
+
+template <typename T, int WP, int NH, bool WLDS, int MAXWAVES>
+int launch_one(const MfmaParams& p, int waves, int grid, size_t lds_bytes, hipStream_t s) {
+    auto kern = rows_mfma_kernel<T, WP, NH, WLDS, MAXWAVES>;
+    static thread_local size_t configured = 0;
+    if (lds_bytes > 65536 && lds_bytes > configured) {
+        NEMPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds_bytes));
+        configured = lds_bytes;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds_bytes, s, p);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
+// picks the instantiation for (WP, NH, weights-in-LDS)
+template <typename T>
+int launch_rows_mfma_typed(const Handle& h, MfmaParams p, hipStream_t s);
+
+}  // namespace nempc

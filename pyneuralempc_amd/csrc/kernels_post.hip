@@ -1,0 +1,187 @@
+// Objective + assembly kernels (HBM-bound streaming work; no matrix cores here).
+//
+//  objective_kernel      f, grad f of the quadratic/linear family   (objective/jax.py:28-41 stand-in)
+//  assemble_dense_kernel tiles -> dense (B,m,n) row-major Jacobian  (integrator/discret.py:38-56,
+//                        rk4.py:120-176, optimizer/ipopt.py:88-96): every output element is a constant
+//                        (0, -1, +1) or one tile element; a per-handle int32 map built once on the host
+//                        says which, so the kernel is a pure gather + 16-byte coalesced store stream.
+//  assemble_sparse_kernel same map restricted to the structural non-zeros.
+//  assemble_hess_*       per-row Lagrangian blocks -> tril values / dense (n,n)  (ipopt.py:66-86)
+#include "nempc_internal.h"
+
+namespace nempc {
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T map_value(int32_t code, const T* __restrict__ tile) {
+    if (code >= 0) return tile[code];
+    return code == MAP_ZERO ? T(0) : (code == MAP_MINUS_ONE ? T(-1) : T(1));
+}
+
+// one wave per problem; lanes stride over the horizon
+template <typename T>
+__global__ __launch_bounds__(64) void objective_kernel(int B, int H, int nx, int nu, ObjOffsets o,
+                                                       const T* __restrict__ P, const T* __restrict__ Z,
+                                                       T* __restrict__ f, T* __restrict__ grad) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int n = H * (nx + nu);
+    const T* z = Z + (size_t)b * n;
+    const T *Q = P + o.Q, *Qs = P + o.Qs, *Rm = P + o.R, *Rs = P + o.Rs;
+    const T *xref = P + o.xref, *uref = P + o.uref, *cx = P + o.cx, *cu = P + o.cu;
+    double acc = 0.0;
+    for (int t = threadIdx.x; t < H; t += 64) {
+        const T* x = z + t * nx;
+        const T* u = z + H * nx + t * nu;
+        for (int i = 0; i < nx; ++i) {
+            const T dxi = x[i] - xref[t * nx + i];
+            T qd = T(0), qsd = T(0);
+            for (int j = 0; j < nx; ++j) {
+                const T dxj = x[j] - xref[t * nx + j];
+                qd = fma(Q[i * nx + j], dxj, qd);
+                qsd = fma(Qs[i * nx + j], dxj, qsd);
+            }
+            acc += (double)(dxi * qd + cx[t * nx + i] * x[i]);
+            if (grad) grad[(size_t)b * n + t * nx + i] = qsd + cx[t * nx + i];
+        }
+        for (int i = 0; i < nu; ++i) {
+            const T dui = u[i] - uref[t * nu + i];
+            T rd = T(0), rsd = T(0);
+            for (int j = 0; j < nu; ++j) {
+                const T duj = u[j] - uref[t * nu + j];
+                rd = fma(Rm[i * nu + j], duj, rd);
+                rsd = fma(Rs[i * nu + j], duj, rsd);
+            }
+            acc += (double)(dui * rd + cu[t * nu + i] * u[i]);
+            if (grad) grad[(size_t)b * n + H * nx + t * nu + i] = rsd + cu[t * nu + i];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (f && threadIdx.x == 0) f[b] = (T)acc;
+}
+
+// grid (ceil(m*n / (2*256)), B); each lane produces two consecutive elements -> one 16-byte (f64) store
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_dense_kernel(int mn, int tile_elems, const int32_t* __restrict__ map,
+                                                             const T* __restrict__ tiles, T* __restrict__ jac) {
+    const int b = blockIdx.y;
+    const T* tile = tiles + (size_t)b * tile_elems;
+    T* out = jac + (size_t)b * mn;
+    const int e = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (e + 1 < mn) {
+        const int32_t c0 = map[e], c1 = map[e + 1];
+        const T v0 = map_value<T>(c0, tile), v1 = map_value<T>(c1, tile);
+        if ((reinterpret_cast<uintptr_t>(out + e) & (2 * sizeof(T) - 1)) == 0) {
+            typedef T vec2 __attribute__((ext_vector_type(2)));
+            vec2 v;
+            v.x = v0; v.y = v1;
+            *reinterpret_cast<vec2*>(out + e) = v;
+        } else {
+            out[e] = v0; out[e + 1] = v1;
+        }
+    } else if (e < mn) {
+        out[e] = map_value<T>(map[e], tile);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_sparse_kernel(int nnz, int tile_elems, const int32_t* __restrict__ map,
+                                                              const T* __restrict__ tiles, T* __restrict__ vals) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nnz) vals[(size_t)b * nnz + e] = map_value<T>(map[e], tiles + (size_t)b * tile_elems);
+}
+
+// hvals[b][e] = sigma_b * objc[e] + (map[e] >= 0 ? blocks[b][map[e]] : 0)
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_hess_kernel(int cnt, int blk_elems, const int32_t* __restrict__ map,
+                                                            const T* __restrict__ objc, const T* __restrict__ blocks,
+                                                            const T* __restrict__ sigma, T* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < cnt) {
+        const int32_t c = map[e];
+        T v = sigma[b] * objc[e];
+        if (c >= 0) v += blocks[(size_t)b * blk_elems + c];
+        out[(size_t)b * cnt + e] = v;
+    }
+}
+
+}  // namespace
+
+int launch_objective(Handle& h, int B, const void* Z, void* f, void* grad, hipStream_t s) {
+    ObjOffsets o = obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu);
+    if (h.cfg.dtype == NEMPC_F64)
+        hipLaunchKernelGGL(objective_kernel<double>, dim3(B), dim3(64), 0, s, B, h.cfg.H, h.cfg.nx, h.cfg.nu, o,
+                           (const double*)h.d_obj, (const double*)Z, (double*)f, (double*)grad);
+    else
+        hipLaunchKernelGGL(objective_kernel<float>, dim3(B), dim3(64), 0, s, B, h.cfg.H, h.cfg.nx, h.cfg.nu, o,
+                           (const float*)h.d_obj, (const float*)Z, (float*)f, (float*)grad);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
+int launch_assemble_dense(Handle& h, int B, const void* tiles, void* jac, hipStream_t s) {
+    const int mn = h.m * h.n;
+    const int te = h.cfg.H * h.cfg.nx * h.nin;
+    const dim3 block(256), grid((unsigned)((mn + 511) / 512), (unsigned)B);
+    if (h.cfg.dtype == NEMPC_F64)
+        hipLaunchKernelGGL(assemble_dense_kernel<double>, grid, block, 0, s, mn, te, h.d_dense_map,
+                           (const double*)tiles, (double*)jac);
+    else
+        hipLaunchKernelGGL(assemble_dense_kernel<float>, grid, block, 0, s, mn, te, h.d_dense_map,
+                           (const float*)tiles, (float*)jac);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
+int launch_assemble_sparse(Handle& h, int B, const void* tiles, void* vals, hipStream_t s) {
+    const int nnz = (int)h.jac_rows.size();
+    const int te = h.cfg.H * h.cfg.nx * h.nin;
+    const dim3 block(256), grid((unsigned)((nnz + 255) / 256), (unsigned)B);
+    if (h.cfg.dtype == NEMPC_F64)
+        hipLaunchKernelGGL(assemble_sparse_kernel<double>, grid, block, 0, s, nnz, te, h.d_sparse_map,
+                           (const double*)tiles, (double*)vals);
+    else
+        hipLaunchKernelGGL(assemble_sparse_kernel<float>, grid, block, 0, s, nnz, te, h.d_sparse_map,
+                           (const float*)tiles, (float*)vals);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
+// d_hess_map layout: [0,nnz) tril map | [nnz, nnz+n*n) dense map ; objc follows the same split in d_hess_objc
+int launch_assemble_hess(Handle& h, int B, const void* blocks, const void* sigma, void* hvals, void* hdense,
+                         hipStream_t s) {
+    const int nnz = (int)h.hess_rows.size();
+    const int nn = h.n * h.n;
+    const int be = h.cfg.H * h.nin * h.nin;
+    const dim3 block(256);
+    const size_t esz = h.esz;
+    const char* objc = (const char*)h.d_obj + (size_t)obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu).total * esz;
+    if (hvals) {
+        const dim3 grid((unsigned)((nnz + 255) / 256), (unsigned)B);
+        if (h.cfg.dtype == NEMPC_F64)
+            hipLaunchKernelGGL(assemble_hess_kernel<double>, grid, block, 0, s, nnz, be, h.d_hess_map,
+                               (const double*)objc, (const double*)blocks, (const double*)sigma, (double*)hvals);
+        else
+            hipLaunchKernelGGL(assemble_hess_kernel<float>, grid, block, 0, s, nnz, be, h.d_hess_map,
+                               (const float*)objc, (const float*)blocks, (const float*)sigma, (float*)hvals);
+    }
+    if (hdense) {
+        const dim3 grid((unsigned)((nn + 255) / 256), (unsigned)B);
+        if (h.cfg.dtype == NEMPC_F64)
+            hipLaunchKernelGGL(assemble_hess_kernel<double>, grid, block, 0, s, nn, be, h.d_hess_map + nnz,
+                               (const double*)(objc + (size_t)nnz * esz), (const double*)blocks,
+                               (const double*)sigma, (double*)hdense);
+        else
+            hipLaunchKernelGGL(assemble_hess_kernel<float>, grid, block, 0, s, nn, be, h.d_hess_map + nnz,
+                               (const float*)(objc + (size_t)nnz * esz), (const float*)blocks, (const float*)sigma,
+                               (float*)hdense);
+    }
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
+}  // namespace nempc

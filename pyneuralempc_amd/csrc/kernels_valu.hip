@@ -1,0 +1,389 @@
+// Generic row kernel: one thread per (problem b, step t) row, any layer dims, fp64 or fp32.
+//
+// This is the shape-agnostic path (and the A/B baseline for the matrix-core kernel in
+// kernels_mfma.hip).  Each lane walks the network for its own row; per-row intermediates live in a
+// global workspace laid out [slot][row] so that every access is coalesced across the wave, and the
+// weights are wave-uniform (scalar loads).  Outputs are register-blocked 8 wide.
+//
+// Math per row (reference call sites integrator/discret.py:22-30,48-56,
+// unity.py:24-32, rk4.py:66-80,137-159):
+//   xi = [x_{t-1} ; u_t],  f(xi) = tanh-MLP,  J = df/dxi by one reverse sweep per output,
+//   DISCRET Phi = x + f, dPhi = J + [I 0];  UNITY Phi = f;  RK4 per rk4.py with
+//   dk_{i+1} = J_{i+1} + c_i DT J_{i+1}[:, :nx] dk_i   (== J_{i+1} (I + c_i DT [dk_i; 0])).
+#include "nempc_internal.h"
+
+namespace nempc {
+
+namespace {
+
+struct NetDev {
+    int nl, nin, nx, nu, maxw;
+    int din[NEMPC_MAX_LAYERS], dout[NEMPC_MAX_LAYERS];
+    const void* W[NEMPC_MAX_LAYERS];
+    const void* Wt[NEMPC_MAX_LAYERS];
+    const void* b[NEMPC_MAX_LAYERS];
+};
+
+struct WsOff {  // slot offsets (multiply by Rcap)
+    int xi, act, cot, fout, jst, kcur, dk, acck, accdk, dkn, P, total;
+};
+
+WsOff ws_offsets(const Handle& h) {
+    WsOff o;
+    int nhid = h.nl - 1, p = 0;
+    o.xi = p; p += h.nin;
+    o.act = p; p += nhid * h.maxw;
+    o.cot = p; p += 2 * h.maxw;
+    o.fout = p; p += h.cfg.nx;
+    o.jst = p; p += h.cfg.nx * h.nin;
+    o.kcur = p; p += h.cfg.nx;
+    o.dk = p; p += h.cfg.nx * h.nin;
+    o.acck = p; p += h.cfg.nx;
+    o.accdk = p; p += h.cfg.nx * h.nin;
+    o.dkn = p; p += h.cfg.nx * h.nin;
+    o.P = p; p += nhid * h.maxw * h.nin;
+    o.total = p;
+    return o;
+}
+
+template <typename T>
+__device__ __forceinline__ T dev_tanh(T x);
+template <>
+__device__ __forceinline__ double dev_tanh<double>(double x) { return tanh(x); }
+template <>
+__device__ __forceinline__ float dev_tanh<float>(float x) { return tanhf(x); }
+
+// forward through the network for this lane's row; hidden activations -> ws act, output -> ws fout
+template <typename T>
+__device__ void net_forward(const NetDev& net, T* ws, const WsOff& o, size_t R, size_t r) {
+    for (int l = 0; l < net.nl; ++l) {
+        const T* W = (const T*)net.W[l];
+        const T* bias = (const T*)net.b[l];
+        const int win = net.din[l], wout = net.dout[l];
+        const T* in = (l == 0) ? ws + (size_t)o.xi * R : ws + (size_t)(o.act + (l - 1) * net.maxw) * R;
+        const bool last = (l == net.nl - 1);
+        T* out = last ? ws + (size_t)o.fout * R : ws + (size_t)(o.act + l * net.maxw) * R;
+        for (int jb = 0; jb < wout; jb += 8) {
+            T acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = (jb + q < wout) ? bias[jb + q] : T(0);
+            if (jb + 8 <= wout) {
+                for (int i = 0; i < win; ++i) {
+                    const T a = in[(size_t)i * R + r];
+                    const T* w = W + (size_t)i * wout + jb;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] = fma(a, w[q], acc[q]);
+                }
+            } else {
+                for (int i = 0; i < win; ++i) {
+                    const T a = in[(size_t)i * R + r];
+                    const T* w = W + (size_t)i * wout + jb;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (jb + q < wout) acc[q] = fma(a, w[q], acc[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (jb + q < wout) out[(size_t)(jb + q) * R + r] = last ? acc[q] : dev_tanh<T>(acc[q]);
+        }
+    }
+}
+
+// reverse sweep for output k: J[k][d] -> ws jst.  mult != nullptr is unused here (see hessian).
+template <typename T>
+__device__ void net_jacobian_row(const NetDev& net, T* ws, const WsOff& o, size_t R, size_t r, int k) {
+    const int nl = net.nl;
+    T* jrow = ws + (size_t)(o.jst + k * net.nin) * R;
+    if (nl == 1) {
+        const T* W0 = (const T*)net.W[0];
+        for (int d = 0; d < net.nin; ++d) jrow[(size_t)d * R + r] = W0[(size_t)d * net.dout[0] + k];
+        return;
+    }
+    // seed at the last hidden layer: cot[j] = W_L[j][k] (1 - a^2)
+    int cur = 0;
+    {
+        const T* WL = (const T*)net.W[nl - 1];
+        const int w = net.din[nl - 1];
+        const T* a = ws + (size_t)(o.act + (nl - 2) * net.maxw) * R;
+        T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;
+        for (int j = 0; j < w; ++j) {
+            const T av = a[(size_t)j * R + r];
+            c[(size_t)j * R + r] = WL[(size_t)j * net.dout[nl - 1] + k] * (T(1) - av * av);
+        }
+    }
+    // hidden layers nl-2 .. 1 : cot_in[i] = (sum_j W_l[i][j] cot[j]) (1 - a_{l-1}[i]^2)
+    for (int l = nl - 2; l >= 0; --l) {
+        const T* Wt = (const T*)net.Wt[l];  // (out, in) row-major: Wt[j][i] = W[i][j]
+        const int win = net.din[l], wout = net.dout[l];
+        const T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;
+        const bool first = (l == 0);
+        T* cn = first ? jrow : ws + (size_t)(o.cot + (cur ^ 1) * net.maxw) * R;
+        const T* aprev = first ? nullptr : ws + (size_t)(o.act + (l - 1) * net.maxw) * R;
+        for (int ib = 0; ib < win; ib += 8) {
+            T acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = T(0);
+            for (int j = 0; j < wout; ++j) {
+                const T cv = c[(size_t)j * R + r];
+                const T* w = Wt + (size_t)j * win + ib;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (ib + q < win) acc[q] = fma(cv, w[q], acc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (ib + q < win) {
+                    T v = acc[q];
+                    if (!first) {
+                        const T av = aprev[(size_t)(ib + q) * R + r];
+                        v *= (T(1) - av * av);
+                    }
+                    cn[(size_t)(ib + q) * R + r] = v;
+                }
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rows_valu_kernel(NetDev net, WsOff o, int kind, T DT, int B, int H,
+                                                        size_t Rcap, const T* __restrict__ Z,
+                                                        const T* __restrict__ X0, T* __restrict__ g, int m,
+                                                        int box, T* __restrict__ tiles, T* __restrict__ ws) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (size_t)B * H) return;
+    const int b = (int)(r / H), t = (int)(r % H);
+    const int nx = net.nx, nu = net.nu, nin = net.nin;
+    const int n = H * nin;
+    const size_t R = Rcap;
+    const T* z = Z + (size_t)b * n;
+
+    T* xi = ws + (size_t)o.xi * R;
+    for (int i = 0; i < nx; ++i) xi[(size_t)i * R + r] = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
+    for (int j = 0; j < nu; ++j) xi[(size_t)(nx + j) * R + r] = z[H * nx + t * nu + j];
+
+    T* fout = ws + (size_t)o.fout * R;
+    T* jst = ws + (size_t)o.jst * R;
+    T* gout = g + (size_t)b * m + (size_t)t * nx;
+    T* tile = tiles + ((size_t)b * H + t) * nx * nin;
+
+    net_forward<T>(net, ws, o, R, r);
+    for (int k = 0; k < nx; ++k) net_jacobian_row<T>(net, ws, o, R, r, k);
+
+    if (kind != NEMPC_RK4) {
+        for (int i = 0; i < nx; ++i) {
+            const T xp = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
+            const T phi = (kind == NEMPC_DISCRET ? xp : T(0)) + fout[(size_t)i * R + r];
+            gout[i] = phi - z[t * nx + i];
+            for (int d = 0; d < nin; ++d) {
+                T v = jst[(size_t)(i * nin + d) * R + r];
+                if (kind == NEMPC_DISCRET && d == i) v += T(1);
+                tile[i * nin + d] = v;
+            }
+        }
+    } else {
+        T* kcur = ws + (size_t)o.kcur * R;
+        T* dk = ws + (size_t)o.dk * R;
+        T* acck = ws + (size_t)o.acck * R;
+        T* accdk = ws + (size_t)o.accdk * R;
+        T* dkn = ws + (size_t)o.dkn * R;
+        for (int i = 0; i < nx; ++i) {
+            const T kv = fout[(size_t)i * R + r];
+            kcur[(size_t)i * R + r] = kv;
+            acck[(size_t)i * R + r] = kv;
+            for (int d = 0; d < nin; ++d) {
+                const T jv = jst[(size_t)(i * nin + d) * R + r];
+                dk[(size_t)(i * nin + d) * R + r] = jv;
+                accdk[(size_t)(i * nin + d) * R + r] = jv;
+            }
+        }
+        for (int s = 0; s < 3; ++s) {
+            const T c = (s == 2 ? T(1) : T(0.5)) * DT;
+            const T wgt = (s == 2 ? T(1) : T(2));
+            for (int i = 0; i < nx; ++i) {
+                const T xp = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
+                xi[(size_t)i * R + r] = xp + c * kcur[(size_t)i * R + r];
+            }
+            net_forward<T>(net, ws, o, R, r);
+            for (int k = 0; k < nx; ++k) net_jacobian_row<T>(net, ws, o, R, r, k);
+            for (int i = 0; i < nx; ++i) {
+                for (int d = 0; d < nin; ++d) {
+                    T v = T(0);
+                    for (int e = 0; e < nx; ++e)
+                        v = fma(jst[(size_t)(i * nin + e) * R + r], dk[(size_t)(e * nin + d) * R + r], v);
+                    dkn[(size_t)(i * nin + d) * R + r] = jst[(size_t)(i * nin + d) * R + r] + c * v;
+                }
+            }
+            for (int i = 0; i < nx; ++i) {
+                const T kv = fout[(size_t)i * R + r];
+                kcur[(size_t)i * R + r] = kv;
+                acck[(size_t)i * R + r] += wgt * kv;
+                for (int d = 0; d < nin; ++d) {
+                    const T v = dkn[(size_t)(i * nin + d) * R + r];
+                    dk[(size_t)(i * nin + d) * R + r] = v;
+                    accdk[(size_t)(i * nin + d) * R + r] += wgt * v;
+                }
+            }
+        }
+        const T s6 = DT / T(6);
+        for (int i = 0; i < nx; ++i) {
+            const T xp = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
+            gout[i] = (xp + s6 * acck[(size_t)i * R + r]) - z[t * nx + i];
+            for (int d = 0; d < nin; ++d) {
+                T v = s6 * accdk[(size_t)(i * nin + d) * R + r];
+                if (d == i) v += T(1);
+                tile[i * nin + d] = v;
+            }
+        }
+    }
+    if (box)
+        for (int i = 0; i < nx; ++i) g[(size_t)b * m + (size_t)H * nx + t * nx + i] = z[t * nx + i];
+}
+
+// Per-row Lagrangian block  Hblk[p][q] = sum_k lam_k d2 Phi_k / dxi_p dxi_q  for DISCRET / UNITY
+// (Phi = [x +] f, so d2Phi = d2f):   Hblk = sum_l P_l^T diag(delta_l * s''(z_l)) P_l
+// with P_l = W_l^T D_{l-1} the pre-activation tangents (forward mode, nin directions),
+// delta_l = d(lam.f)/d a_l (one reverse sweep) and s'' = -2 a (1 - a^2).
+// Value-equivalent to model/tensorflow.py:77-109 contracted as in optimizer/ipopt.py:79-80.
+template <typename T>
+__global__ __launch_bounds__(256) void rowhess_valu_kernel(NetDev net, WsOff o, int B, int H, size_t Rcap,
+                                                           const T* __restrict__ Z, const T* __restrict__ X0,
+                                                           const T* __restrict__ lam, int m,
+                                                           T* __restrict__ blocks, T* __restrict__ ws) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (size_t)B * H) return;
+    const int b = (int)(r / H), t = (int)(r % H);
+    const int nx = net.nx, nu = net.nu, nin = net.nin, nl = net.nl;
+    const int n = H * nin;
+    const size_t R = Rcap;
+    const T* z = Z + (size_t)b * n;
+    T* blk = blocks + ((size_t)b * H + t) * nin * nin;
+
+    for (int p = 0; p < nin * nin; ++p) blk[p] = T(0);
+    if (nl == 1) return;  // linear network: no curvature
+
+    T* xi = ws + (size_t)o.xi * R;
+    for (int i = 0; i < nx; ++i) xi[(size_t)i * R + r] = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
+    for (int j = 0; j < nu; ++j) xi[(size_t)(nx + j) * R + r] = z[H * nx + t * nu + j];
+    net_forward<T>(net, ws, o, R, r);
+
+    // forward tangents: P_l[i][p] (pre-activation), stored per hidden layer; D_l = (1-a^2) P_l
+    for (int l = 0; l < nl - 1; ++l) {
+        const T* W = (const T*)net.W[l];
+        const int win = net.din[l], wout = net.dout[l];
+        T* P = ws + (size_t)(o.P + l * net.maxw * nin) * R;
+        const T* Pprev = (l == 0) ? nullptr : ws + (size_t)(o.P + (l - 1) * net.maxw * nin) * R;
+        const T* aprev = (l == 0) ? nullptr : ws + (size_t)(o.act + (l - 1) * net.maxw) * R;
+        for (int p = 0; p < nin; ++p) {
+            for (int j = 0; j < wout; ++j) {
+                T acc = T(0);
+                if (l == 0) {
+                    acc = W[(size_t)p * wout + j];
+                } else {
+                    for (int i = 0; i < win; ++i) {
+                        const T av = aprev[(size_t)i * R + r];
+                        acc = fma(W[(size_t)i * wout + j], (T(1) - av * av) * Pprev[(size_t)(i * nin + p) * R + r],
+                                  acc);
+                    }
+                }
+                P[(size_t)(j * nin + p) * R + r] = acc;
+            }
+        }
+    }
+    // reverse sweep for delta_l = d(lam . f)/d a_l, accumulate the blocks on the way down
+    int cur = 0;
+    {
+        const T* WL = (const T*)net.W[nl - 1];
+        const int w = net.din[nl - 1];
+        T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;
+        for (int j = 0; j < w; ++j) {
+            T acc = T(0);
+            for (int k = 0; k < nx; ++k) acc = fma(WL[(size_t)j * nx + k], lam[(size_t)b * m + t * nx + k], acc);
+            c[(size_t)j * R + r] = acc;
+        }
+    }
+    for (int l = nl - 2; l >= 0; --l) {
+        const int wout = net.dout[l];
+        const T* a = ws + (size_t)(o.act + l * net.maxw) * R;
+        const T* P = ws + (size_t)(o.P + l * net.maxw * nin) * R;
+        T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;  // delta_l (wrt a_l)
+        for (int j = 0; j < wout; ++j) {
+            const T av = a[(size_t)j * R + r];
+            const T s1 = T(1) - av * av;
+            const T wgt = c[(size_t)j * R + r] * (T(-2) * av * s1);
+            for (int p = 0; p < nin; ++p) {
+                const T pp = wgt * P[(size_t)(j * nin + p) * R + r];
+                for (int q = 0; q <= p; ++q) blk[p * nin + q] = fma(pp, P[(size_t)(j * nin + q) * R + r], blk[p * nin + q]);
+            }
+            c[(size_t)j * R + r] *= s1;  // now cot wrt z_l
+        }
+        if (l > 0) {
+            const T* Wt = (const T*)net.Wt[l];
+            const int win = net.din[l];
+            T* cn = ws + (size_t)(o.cot + (cur ^ 1) * net.maxw) * R;
+            for (int i = 0; i < win; ++i) {
+                T acc = T(0);
+                for (int j = 0; j < wout; ++j) acc = fma(Wt[(size_t)j * win + i], c[(size_t)j * R + r], acc);
+                cn[(size_t)i * R + r] = acc;
+            }
+            cur ^= 1;
+        }
+    }
+    for (int p = 0; p < nin; ++p)
+        for (int q = p + 1; q < nin; ++q) blk[p * nin + q] = blk[q * nin + p];
+}
+
+NetDev make_netdev(const Handle& h) {
+    NetDev nd{};
+    nd.nl = h.nl; nd.nin = h.nin; nd.nx = h.cfg.nx; nd.nu = h.cfg.nu; nd.maxw = h.maxw;
+    for (int l = 0; l < h.nl; ++l) {
+        nd.din[l] = h.din[l]; nd.dout[l] = h.dout[l];
+        nd.W[l] = h.d_W[l]; nd.Wt[l] = h.d_Wt[l]; nd.b[l] = h.d_b[l];
+    }
+    return nd;
+}
+
+}  // namespace
+
+size_t valu_workspace_elems(const Handle& h) {
+    return (size_t)ws_offsets(h).total * (size_t)h.cfg.max_batch * (size_t)h.cfg.H;
+}
+
+int launch_rows_valu(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s) {
+    const size_t rows = (size_t)B * h.cfg.H;
+    const size_t Rcap = (size_t)h.cfg.max_batch * h.cfg.H;
+    const dim3 block(256), grid((unsigned)((rows + 255) / 256));
+    NetDev nd = make_netdev(h);
+    WsOff o = ws_offsets(h);
+    if (h.cfg.dtype == NEMPC_F64)
+        hipLaunchKernelGGL(rows_valu_kernel<double>, grid, block, 0, s, nd, o, h.cfg.integrator, h.cfg.DT, B,
+                           h.cfg.H, Rcap, (const double*)Z, (const double*)X0, (double*)g, h.m, (int)h.box,
+                           (double*)tiles, (double*)h.d_valu_ws);
+    else
+        hipLaunchKernelGGL(rows_valu_kernel<float>, grid, block, 0, s, nd, o, h.cfg.integrator, (float)h.cfg.DT, B,
+                           h.cfg.H, Rcap, (const float*)Z, (const float*)X0, (float*)g, h.m, (int)h.box,
+                           (float*)tiles, (float*)h.d_valu_ws);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
+int launch_rowhess_valu(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
+                        hipStream_t s) {
+    const size_t rows = (size_t)B * h.cfg.H;
+    const size_t Rcap = (size_t)h.cfg.max_batch * h.cfg.H;
+    const dim3 block(256), grid((unsigned)((rows + 255) / 256));
+    NetDev nd = make_netdev(h);
+    WsOff o = ws_offsets(h);
+    if (h.cfg.dtype == NEMPC_F64)
+        hipLaunchKernelGGL(rowhess_valu_kernel<double>, grid, block, 0, s, nd, o, B, h.cfg.H, Rcap, (const double*)Z,
+                           (const double*)X0, (const double*)lambda, h.m, (double*)blocks, (double*)h.d_valu_ws);
+    else
+        hipLaunchKernelGGL(rowhess_valu_kernel<float>, grid, block, 0, s, nd, o, B, h.cfg.H, Rcap, (const float*)Z,
+                           (const float*)X0, (const float*)lambda, h.m, (float*)blocks, (float*)h.d_valu_ws);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
+}  // namespace nempc

@@ -1,0 +1,486 @@
+// C ABI of libnempc.so: handle lifetime, parameter upload, structure export, launch sequencing.
+// See include/nempc.h for the contract and the reference call sites each entry point stands for.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "nempc_internal.h"
+
+namespace nempc {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char* what) {
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return NEMPC_EHIP;
+}
+
+namespace {
+
+int fail(int code, const std::string& msg) {
+    set_error(msg);
+    return code;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+        if (prev == dev) prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+template <typename T>
+int upload_as(const std::vector<double>& src, void* dst) {
+    std::vector<T> tmp(src.size());
+    for (size_t i = 0; i < src.size(); ++i) tmp[i] = (T)src[i];
+    NEMPC_HIP(hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+    return NEMPC_OK;
+}
+
+int upload(const Handle& h, const std::vector<double>& src, void* dst) {
+    if (src.empty()) return NEMPC_OK;
+    return h.cfg.dtype == NEMPC_F64 ? upload_as<double>(src, dst) : upload_as<float>(src, dst);
+}
+
+int dev_alloc(void** p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+        return NEMPC_ENOMEM;
+    }
+    return NEMPC_OK;
+}
+
+void dev_free(void*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+// which per-row block element feeds Hessian entry (r,c), and the objective constant there
+int32_t hess_code(const Handle& h, int r, int c, const std::vector<double>& Qs, const std::vector<double>& Rs,
+                  double* objc) {
+    const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu, nin = h.nin;
+    *objc = 0.0;
+    const bool rx = r < H * nx, cx = c < H * nx;
+    if (rx && cx) {
+        const int tr = r / nx, ir = r % nx, tc = c / nx, ic = c % nx;
+        if (tr != tc) return -1;
+        *objc = Qs[ir * nx + ic];
+        return (tr + 1 < H) ? (tr + 1) * nin * nin + ir * nin + ic : -1;
+    }
+    if (!rx && !cx) {
+        const int tr = (r - H * nx) / nu, a = (r - H * nx) % nu, tc = (c - H * nx) / nu, bq = (c - H * nx) % nu;
+        if (tr != tc) return -1;
+        *objc = Rs[a * nu + bq];
+        return tr * nin * nin + (nx + a) * nin + (nx + bq);
+    }
+    // mixed: u_t with x_{t-1}
+    const int ui = rx ? c : r, xi = rx ? r : c;
+    const int tu = (ui - H * nx) / nu, a = (ui - H * nx) % nu, tx = xi / nx, ix = xi % nx;
+    if (tu != tx + 1) return -1;
+    return rx ? tu * nin * nin + ix * nin + (nx + a) : tu * nin * nin + (nx + a) * nin + ix;
+}
+
+bool hess_structural(const Handle& h, int r, int c) {
+    const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu;
+    const bool rx = r < H * nx, cx = c < H * nx;
+    if (rx && cx) return r / nx == c / nx;
+    if (!rx && !cx) return (r - H * nx) / nu == (c - H * nx) / nu;
+    const int ui = rx ? c : r, xi = rx ? r : c;
+    return (ui - H * nx) / nu == xi / nx + 1;
+}
+
+struct ObjHost {
+    std::vector<double> Q, R, xref, uref, cx, cu;
+};
+
+int rebuild_structure(Handle& h) {
+    const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu, nin = h.nin, n = h.n;
+    h.m = H * nx + (h.box ? H * nx : 0);
+    const int m = h.m;
+    std::vector<int32_t> dense((size_t)m * n, MAP_ZERO), sparse;
+    h.jac_rows.clear();
+    h.jac_cols.clear();
+    auto put = [&](int r, int c, int32_t code) {
+        dense[(size_t)r * n + c] = code;
+        h.jac_rows.push_back(r);
+        h.jac_cols.push_back(c);
+        sparse.push_back(code);
+    };
+    for (int t = 0; t < H; ++t)
+        for (int i = 0; i < nx; ++i) {
+            const int r = t * nx + i;
+            const int base = t * nx * nin + i * nin;
+            if (t > 0)
+                for (int j = 0; j < nx; ++j) put(r, (t - 1) * nx + j, base + j);
+            put(r, t * nx + i, MAP_MINUS_ONE);
+            for (int j = 0; j < nu; ++j) put(r, H * nx + t * nu + j, base + nx + j);
+        }
+    if (h.box)
+        for (int k = 0; k < H * nx; ++k) put(H * nx + k, k, MAP_PLUS_ONE);
+
+    void* p = h.d_dense_map;
+    dev_free(p);
+    p = h.d_sparse_map;
+    dev_free(p);
+    p = h.d_g_ws;
+    dev_free(p);
+    int rc;
+    if ((rc = dev_alloc((void**)&h.d_dense_map, dense.size() * sizeof(int32_t)))) return rc;
+    if ((rc = dev_alloc((void**)&h.d_sparse_map, sparse.size() * sizeof(int32_t)))) return rc;
+    if ((rc = dev_alloc(&h.d_g_ws, (size_t)h.cfg.max_batch * m * h.esz))) return rc;
+    NEMPC_HIP(hipMemcpy(h.d_dense_map, dense.data(), dense.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    NEMPC_HIP(hipMemcpy(h.d_sparse_map, sparse.data(), sparse.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return NEMPC_OK;
+}
+
+int upload_objective(Handle& h, const ObjHost& o) {
+    const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu, n = h.n;
+    ObjOffsets off = obj_offsets(H, nx, nu);
+    std::vector<double> Qs(nx * nx), Rs(nu * nu);
+    for (int i = 0; i < nx; ++i)
+        for (int j = 0; j < nx; ++j) Qs[i * nx + j] = o.Q[i * nx + j] + o.Q[j * nx + i];
+    for (int i = 0; i < nu; ++i)
+        for (int j = 0; j < nu; ++j) Rs[i * nu + j] = o.R[i * nu + j] + o.R[j * nu + i];
+
+    // Hessian structure (tril, row-major) + maps + objective constants
+    h.hess_rows.clear();
+    h.hess_cols.clear();
+    std::vector<int32_t> hmap;
+    std::vector<double> objc;
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c <= r; ++c)
+            if (hess_structural(h, r, c)) {
+                double oc;
+                hmap.push_back(hess_code(h, r, c, Qs, Rs, &oc));
+                objc.push_back(oc);
+                h.hess_rows.push_back(r);
+                h.hess_cols.push_back(c);
+            }
+    const size_t nnz = hmap.size();
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) {
+            double oc = 0.0;
+            int32_t code = -1;
+            if (hess_structural(h, r, c)) code = hess_code(h, r, c, Qs, Rs, &oc);
+            hmap.push_back(code);
+            objc.push_back(oc);
+        }
+
+    std::vector<double> all((size_t)off.total);
+    std::copy(o.Q.begin(), o.Q.end(), all.begin() + off.Q);
+    std::copy(Qs.begin(), Qs.end(), all.begin() + off.Qs);
+    std::copy(o.R.begin(), o.R.end(), all.begin() + off.R);
+    std::copy(Rs.begin(), Rs.end(), all.begin() + off.Rs);
+    std::copy(o.xref.begin(), o.xref.end(), all.begin() + off.xref);
+    std::copy(o.uref.begin(), o.uref.end(), all.begin() + off.uref);
+    std::copy(o.cx.begin(), o.cx.end(), all.begin() + off.cx);
+    std::copy(o.cu.begin(), o.cu.end(), all.begin() + off.cu);
+    all.insert(all.end(), objc.begin(), objc.end());
+
+    void* p = h.d_obj;
+    dev_free(p);
+    p = h.d_hess_map;
+    dev_free(p);
+    int rc;
+    if ((rc = dev_alloc(&h.d_obj, all.size() * h.esz))) return rc;
+    if ((rc = dev_alloc((void**)&h.d_hess_map, hmap.size() * sizeof(int32_t)))) return rc;
+    if ((rc = upload(h, all, h.d_obj))) return rc;
+    NEMPC_HIP(hipMemcpy(h.d_hess_map, hmap.data(), hmap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    (void)nnz;
+    h.have_objective = true;
+    return NEMPC_OK;
+}
+
+void destroy_impl(Handle* h) {
+    for (int l = 0; l < NEMPC_MAX_LAYERS; ++l) {
+        dev_free(h->d_W[l]);
+        dev_free(h->d_Wt[l]);
+        dev_free(h->d_b[l]);
+    }
+    mfma_free(*h);
+    dev_free(h->d_obj);
+    void* p = h->d_dense_map; dev_free(p); h->d_dense_map = nullptr;
+    p = h->d_sparse_map; dev_free(p); h->d_sparse_map = nullptr;
+    p = h->d_hess_map; dev_free(p); h->d_hess_map = nullptr;
+    dev_free(h->d_tiles_ws);
+    dev_free(h->d_g_ws);
+    dev_free(h->d_valu_ws);
+    dev_free(h->d_hess_ws);
+    delete h;
+}
+
+}  // namespace
+}  // namespace nempc
+
+using namespace nempc;
+
+extern "C" {
+
+int nempc_abi_version(void) { return NEMPC_ABI_VERSION; }
+
+const char* nempc_last_error(void) { return g_last_error.c_str(); }
+
+int nempc_create(const nempc_config* cfg, nempc_handle* out) {
+    if (!cfg || !out) return fail(NEMPC_EINVAL, "nempc_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != NEMPC_ABI_VERSION) return fail(NEMPC_EINVAL, "nempc_create: abi_version mismatch");
+    if (cfg->dtype != NEMPC_F64 && cfg->dtype != NEMPC_F32) return fail(NEMPC_EINVAL, "nempc_create: bad dtype");
+    if (cfg->integrator < NEMPC_DISCRET || cfg->integrator > NEMPC_RK4)
+        return fail(NEMPC_EINVAL, "nempc_create: bad integrator kind");
+    if (cfg->H < 1 || cfg->nx < 1 || cfg->nu < 1) return fail(NEMPC_EINVAL, "nempc_create: H, nx, nu must be >= 1");
+    if (cfg->n_layers < 1 || cfg->n_layers > NEMPC_MAX_LAYERS)
+        return fail(NEMPC_EINVAL, "nempc_create: n_layers out of range");
+    if (cfg->widths[cfg->n_layers - 1] != cfg->nx)
+        return fail(NEMPC_EINVAL, "nempc_create: last layer width must equal nx (model output = state dim)");
+    for (int l = 0; l < cfg->n_layers; ++l)
+        if (cfg->widths[l] < 1) return fail(NEMPC_EINVAL, "nempc_create: layer width must be >= 1");
+    if (cfg->max_batch < 1) return fail(NEMPC_EINVAL, "nempc_create: max_batch must be >= 1");
+    if (cfg->kernel < NEMPC_KERNEL_AUTO || cfg->kernel > NEMPC_KERNEL_MFMA)
+        return fail(NEMPC_EINVAL, "nempc_create: bad kernel selector");
+    if (cfg->integrator == NEMPC_RK4 && !(cfg->DT > 0.0)) return fail(NEMPC_EINVAL, "nempc_create: RK4 needs DT > 0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(NEMPC_EHIP, "nempc_create: no HIP device visible (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(NEMPC_EINVAL, "nempc_create: device ordinal out of range");
+    DeviceGuard dg(cfg->device);
+    if (!dg.ok) return fail(NEMPC_EHIP, "nempc_create: hipSetDevice failed");
+
+    Handle* h = new (std::nothrow) Handle();
+    if (!h) return fail(NEMPC_ENOMEM, "nempc_create: out of host memory");
+    h->cfg = *cfg;
+    h->esz = cfg->dtype == NEMPC_F64 ? 8 : 4;
+    h->nin = cfg->nx + cfg->nu;
+    h->n = cfg->H * h->nin;
+    h->nl = cfg->n_layers;
+    h->maxw = 1;
+    for (int l = 0; l < h->nl; ++l) {
+        h->din[l] = l == 0 ? h->nin : cfg->widths[l - 1];
+        h->dout[l] = cfg->widths[l];
+        if (l < h->nl - 1 && h->dout[l] > h->maxw) h->maxw = h->dout[l];
+    }
+    h->variant = NEMPC_KERNEL_VALU;
+    if (cfg->kernel == NEMPC_KERNEL_MFMA) {
+        if (!mfma_supported(*h)) {
+            delete h;
+            return fail(NEMPC_EUNSUPPORTED, "nempc_create: MFMA row kernel does not cover these layer dims");
+        }
+        h->variant = NEMPC_KERNEL_MFMA;
+    } else if (cfg->kernel == NEMPC_KERNEL_AUTO && mfma_supported(*h)) {
+        h->variant = NEMPC_KERNEL_MFMA;
+    }
+
+    int rc = NEMPC_OK;
+    const size_t Bm = (size_t)cfg->max_batch;
+    do {
+        if ((rc = dev_alloc(&h->d_tiles_ws, Bm * cfg->H * cfg->nx * h->nin * h->esz))) break;
+        h->valu_ws_elems = valu_workspace_elems(*h);
+        if ((rc = dev_alloc(&h->d_valu_ws, h->valu_ws_elems * h->esz))) break;
+        if ((rc = dev_alloc(&h->d_hess_ws, Bm * cfg->H * h->nin * h->nin * h->esz))) break;
+        if ((rc = rebuild_structure(*h))) break;
+        ObjHost o;
+        const int nx = cfg->nx, nu = cfg->nu, H = cfg->H;
+        o.Q.assign(nx * nx, 0.0);
+        o.R.assign(nu * nu, 0.0);
+        for (int i = 0; i < nx; ++i) o.Q[i * nx + i] = 1.0;
+        for (int i = 0; i < nu; ++i) o.R[i * nu + i] = 0.1;
+        o.xref.assign(H * nx, 0.0); o.cx.assign(H * nx, 0.0);
+        o.uref.assign(H * nu, 0.0); o.cu.assign(H * nu, 0.0);
+        if ((rc = upload_objective(*h, o))) break;
+    } while (0);
+    if (rc) {
+        std::string keep = g_last_error;
+        destroy_impl(h);
+        set_error(keep);
+        return rc;
+    }
+    *out = reinterpret_cast<nempc_handle>(h);
+    return NEMPC_OK;
+}
+
+int nempc_destroy(nempc_handle hh) {
+    if (!hh) return NEMPC_OK;
+    Handle* h = reinterpret_cast<Handle*>(hh);
+    DeviceGuard dg(h->cfg.device);
+    destroy_impl(h);
+    return NEMPC_OK;
+}
+
+int nempc_set_weights(nempc_handle hh, const double* const* W, const double* const* b) {
+    if (!hh || !W || !b) return fail(NEMPC_EINVAL, "nempc_set_weights: null argument");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    DeviceGuard dg(h.cfg.device);
+    if (!dg.ok) return fail(NEMPC_EHIP, "nempc_set_weights: hipSetDevice failed");
+    for (int l = 0; l < h.nl; ++l) {
+        if (!W[l] || !b[l]) return fail(NEMPC_EINVAL, "nempc_set_weights: null layer pointer");
+        const int win = h.din[l], wout = h.dout[l];
+        for (size_t i = 0; i < (size_t)win * wout; ++i)
+            if (!std::isfinite(W[l][i])) return fail(NEMPC_EINVAL, "nempc_set_weights: non-finite weight");
+        std::vector<double> w(W[l], W[l] + (size_t)win * wout), wt((size_t)win * wout), bb(b[l], b[l] + wout);
+        for (int i = 0; i < win; ++i)
+            for (int j = 0; j < wout; ++j) wt[(size_t)j * win + i] = w[(size_t)i * wout + j];
+        int rc;
+        dev_free(h.d_W[l]); dev_free(h.d_Wt[l]); dev_free(h.d_b[l]);
+        if ((rc = dev_alloc(&h.d_W[l], w.size() * h.esz))) return rc;
+        if ((rc = dev_alloc(&h.d_Wt[l], wt.size() * h.esz))) return rc;
+        if ((rc = dev_alloc(&h.d_b[l], bb.size() * h.esz))) return rc;
+        if ((rc = upload(h, w, h.d_W[l]))) return rc;
+        if ((rc = upload(h, wt, h.d_Wt[l]))) return rc;
+        if ((rc = upload(h, bb, h.d_b[l]))) return rc;
+    }
+    if (h.variant == NEMPC_KERNEL_MFMA) {
+        int rc = mfma_pack_weights(h, W, b);
+        if (rc) return rc;
+    }
+    h.have_weights = true;
+    return NEMPC_OK;
+}
+
+int nempc_set_objective(nempc_handle hh, const double* Q, const double* R, const double* xref, const double* uref,
+                        const double* cx, const double* cu) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_set_objective: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    DeviceGuard dg(h.cfg.device);
+    if (!dg.ok) return fail(NEMPC_EHIP, "nempc_set_objective: hipSetDevice failed");
+    const int nx = h.cfg.nx, nu = h.cfg.nu, H = h.cfg.H;
+    ObjHost o;
+    o.Q.assign(nx * nx, 0.0);
+    o.R.assign(nu * nu, 0.0);
+    if (Q) o.Q.assign(Q, Q + nx * nx); else for (int i = 0; i < nx; ++i) o.Q[i * nx + i] = 1.0;
+    if (R) o.R.assign(R, R + nu * nu); else for (int i = 0; i < nu; ++i) o.R[i * nu + i] = 0.1;
+    o.xref.assign(H * nx, 0.0); o.cx.assign(H * nx, 0.0);
+    o.uref.assign(H * nu, 0.0); o.cu.assign(H * nu, 0.0);
+    if (xref) o.xref.assign(xref, xref + H * nx);
+    if (uref) o.uref.assign(uref, uref + H * nu);
+    if (cx) o.cx.assign(cx, cx + H * nx);
+    if (cu) o.cu.assign(cu, cu + H * nu);
+    return upload_objective(h, o);
+}
+
+int nempc_set_box_rows(nempc_handle hh, int enabled, const double* lo, const double* hi) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_set_box_rows: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    DeviceGuard dg(h.cfg.device);
+    if (!dg.ok) return fail(NEMPC_EHIP, "nempc_set_box_rows: hipSetDevice failed");
+    if (enabled && (!lo || !hi)) return fail(NEMPC_EINVAL, "nempc_set_box_rows: lo/hi required when enabled");
+    h.box = enabled != 0;
+    h.box_lo.clear();
+    h.box_hi.clear();
+    if (h.box) {
+        h.box_lo.assign(lo, lo + h.cfg.nx);
+        h.box_hi.assign(hi, hi + h.cfg.nx);
+    }
+    return rebuild_structure(h);
+}
+
+int nempc_dims(nempc_handle hh, int32_t* n, int32_t* m, int32_t* nnz_jac, int32_t* nnz_hess) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_dims: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    if (n) *n = h.n;
+    if (m) *m = h.m;
+    if (nnz_jac) *nnz_jac = (int32_t)h.jac_rows.size();
+    if (nnz_hess) *nnz_hess = (int32_t)h.hess_rows.size();
+    return NEMPC_OK;
+}
+
+int nempc_constraint_bounds(nempc_handle hh, double* cl, double* cu) {
+    if (!hh || !cl || !cu) return fail(NEMPC_EINVAL, "nempc_constraint_bounds: null argument");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    const int hx = h.cfg.H * h.cfg.nx;
+    for (int i = 0; i < hx; ++i) cl[i] = cu[i] = 0.0;
+    if (h.box)
+        for (int t = 0; t < h.cfg.H; ++t)
+            for (int i = 0; i < h.cfg.nx; ++i) {
+                cl[hx + t * h.cfg.nx + i] = h.box_lo[i];
+                cu[hx + t * h.cfg.nx + i] = h.box_hi[i];
+            }
+    return NEMPC_OK;
+}
+
+int nempc_jac_structure(nempc_handle hh, int32_t* rows, int32_t* cols) {
+    if (!hh || !rows || !cols) return fail(NEMPC_EINVAL, "nempc_jac_structure: null argument");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    std::memcpy(rows, h.jac_rows.data(), h.jac_rows.size() * sizeof(int32_t));
+    std::memcpy(cols, h.jac_cols.data(), h.jac_cols.size() * sizeof(int32_t));
+    return NEMPC_OK;
+}
+
+int nempc_hess_structure(nempc_handle hh, int32_t* rows, int32_t* cols) {
+    if (!hh || !rows || !cols) return fail(NEMPC_EINVAL, "nempc_hess_structure: null argument");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    std::memcpy(rows, h.hess_rows.data(), h.hess_rows.size() * sizeof(int32_t));
+    std::memcpy(cols, h.hess_cols.data(), h.hess_cols.size() * sizeof(int32_t));
+    return NEMPC_OK;
+}
+
+int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* f, void* grad, void* g,
+               void* jac_dense, void* jac_tiles, void* jac_sparse, void* stream) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_eval: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    if (B < 0 || B > h.cfg.max_batch) return fail(NEMPC_EINVAL, "nempc_eval: B outside [0, max_batch]");
+    if (B == 0) return NEMPC_OK;
+    if (!Z) return fail(NEMPC_EINVAL, "nempc_eval: Z is null");
+    const bool need_rows = g || jac_dense || jac_tiles || jac_sparse;
+    if (need_rows && !X0) return fail(NEMPC_EINVAL, "nempc_eval: X0 is null");
+    if (need_rows && !h.have_weights) return fail(NEMPC_ESTATE, "nempc_eval: call nempc_set_weights first");
+    DeviceGuard dg(h.cfg.device);
+    if (!dg.ok) return fail(NEMPC_EHIP, "nempc_eval: hipSetDevice failed");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    if (need_rows) {
+        void* tiles = jac_tiles ? jac_tiles : h.d_tiles_ws;
+        void* gout = g ? g : h.d_g_ws;
+        rc = h.variant == NEMPC_KERNEL_MFMA ? launch_rows_mfma(h, B, Z, X0, gout, tiles, s)
+                                            : launch_rows_valu(h, B, Z, X0, gout, tiles, s);
+        if (rc) return rc;
+        if (jac_dense && (rc = launch_assemble_dense(h, B, tiles, jac_dense, s))) return rc;
+        if (jac_sparse && (rc = launch_assemble_sparse(h, B, tiles, jac_sparse, s))) return rc;
+    }
+    if ((f || grad) && (rc = launch_objective(h, B, Z, f, grad, s))) return rc;
+    return NEMPC_OK;
+}
+
+int nempc_hess(nempc_handle hh, int32_t B, const void* Z, const void* X0, const void* lambda, const void* sigma,
+               void* hvals, void* hdense, void* hblocks, void* stream) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_hess: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    if (B < 0 || B > h.cfg.max_batch) return fail(NEMPC_EINVAL, "nempc_hess: B outside [0, max_batch]");
+    if (B == 0) return NEMPC_OK;
+    if (!Z || !X0 || !lambda || !sigma) return fail(NEMPC_EINVAL, "nempc_hess: null input");
+    if (!h.have_weights) return fail(NEMPC_ESTATE, "nempc_hess: call nempc_set_weights first");
+    if (h.cfg.integrator == NEMPC_RK4)
+        return fail(NEMPC_EUNSUPPORTED, "nempc_hess: the RK4 Lagrangian Hessian is not on the device yet");
+    DeviceGuard dg(h.cfg.device);
+    if (!dg.ok) return fail(NEMPC_EHIP, "nempc_hess: hipSetDevice failed");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    void* blocks = hblocks ? hblocks : h.d_hess_ws;
+    if ((rc = launch_rowhess_valu(h, B, Z, X0, lambda, blocks, s))) return rc;
+    if (!hvals && !hdense) return NEMPC_OK;
+    return launch_assemble_hess(h, B, blocks, sigma, hvals, hdense, s);
+}
+
+int nempc_sync(nempc_handle hh, void* stream) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_sync: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    DeviceGuard dg(h.cfg.device);
+    NEMPC_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+    return NEMPC_OK;
+}
+
+int nempc_kernel_variant(nempc_handle hh) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_kernel_variant: null handle");
+    return reinterpret_cast<Handle*>(hh)->variant;
+}
+
+}  // extern "C"

@@ -1,0 +1,256 @@
+"""Batched callback engine: the thin host wrapper over the C ABI.
+
+One ``CallbackEngine`` = one ``nempc_handle``: a fixed problem family (dims, integrator, network,
+objective, optional box rows) evaluated for a batch of B independent problems per call on one
+MI355X.  torch is used for device memory and streams only; every number is produced by the HIP
+kernels in csrc/.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_TORCH_DTYPES = {torch.float64: _lib.F64, torch.float32: _lib.F32}
+
+
+def _as_c_double(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+class CallbackEngine:
+    def __init__(self, weights, biases, H, nx, nu, integrator="discret", DT=1.0, dtype=torch.float64,
+                 device="cuda", max_batch=1, kernel="auto"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("pyneuralempc_amd needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("CallbackEngine runs on a HIP device only")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if dtype not in _TORCH_DTYPES:
+            raise ValueError("dtype must be torch.float64 or torch.float32")
+        self.dtype = dtype
+        self.H, self.nx, self.nu, self.nin = int(H), int(nx), int(nu), int(nx) + int(nu)
+        self.integrator = integrator if isinstance(integrator, int) else _lib.INTEGRATOR_IDS[integrator]
+        self.DT = float(DT)
+        self.kernel = kernel
+        self._weights = [np.ascontiguousarray(w, dtype=np.float64) for w in weights]
+        self._biases = [np.ascontiguousarray(b, dtype=np.float64).reshape(-1) for b in biases]
+        if len(self._weights) != len(self._biases) or not self._weights:
+            raise ValueError("weights and biases must be non-empty lists of equal length")
+        if len(self._weights) > _lib.MAX_LAYERS:
+            raise ValueError(f"at most {_lib.MAX_LAYERS} dense layers are supported")
+        prev = self.nin
+        for w, b in zip(self._weights, self._biases):
+            if w.ndim != 2 or w.shape[0] != prev or b.shape != (w.shape[1],):
+                raise ValueError("layer shapes do not chain: expected kernel (in,out) and bias (out,)")
+            prev = w.shape[1]
+        if prev != self.nx:
+            raise ValueError("Your model do not provide a suitable output dim ! It must get the same dim as the "
+                             "state dim.")
+        self._objective = None
+        self._box = None
+        self._handle = None
+        self.max_batch = 0
+        self._buffers = {}
+        self._create(int(max_batch))
+
+    # ------------------------------------------------------------------ handle management
+    def _create(self, max_batch):
+        self._destroy()
+        cfg = _lib.NempcConfig()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.device = self.device.index
+        cfg.dtype = _TORCH_DTYPES[self.dtype]
+        cfg.integrator = self.integrator
+        cfg.H, cfg.nx, cfg.nu = self.H, self.nx, self.nu
+        cfg.n_layers = len(self._weights)
+        for i, w in enumerate(self._weights):
+            cfg.widths[i] = w.shape[1]
+        cfg.max_batch = max_batch
+        cfg.kernel = _lib.KERNEL_NAMES[self.kernel] if isinstance(self.kernel, str) else int(self.kernel)
+        cfg.DT = self.DT
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._handle = h
+        self.max_batch = max_batch
+        nl = len(self._weights)
+        dp = ctypes.POINTER(ctypes.c_double)
+        Wp = (dp * nl)(*[w.ctypes.data_as(dp) for w in self._weights])
+        bp = (dp * nl)(*[b.ctypes.data_as(dp) for b in self._biases])
+        _lib.check(self.lib.nempc_set_weights(self._handle, Wp, bp))
+        if self._objective is not None:
+            self.set_objective(**self._objective)
+        if self._box is not None:
+            self.set_box_rows(*self._box)
+        self._refresh_dims()
+        self._buffers = {}
+
+    def _destroy(self):
+        if getattr(self, "_handle", None):
+            self.lib.nempc_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def __getstate__(self):
+        raise TypeError("CallbackEngine holds device handles and is not picklable; pickle the plugin objects")
+
+    def _refresh_dims(self):
+        n, m, nj, nh = (ctypes.c_int32() for _ in range(4))
+        _lib.check(self.lib.nempc_dims(self._handle, ctypes.byref(n), ctypes.byref(m), ctypes.byref(nj),
+                                       ctypes.byref(nh)))
+        self.n, self.m, self.nnz_jac, self.nnz_hess = n.value, m.value, nj.value, nh.value
+
+    def reserve(self, B):
+        """Grow the handle's workspaces to hold B problems (recreates the handle)."""
+        if B > self.max_batch:
+            self._create(int(B))
+
+    @property
+    def kernel_variant(self):
+        v = self.lib.nempc_kernel_variant(self._handle)
+        return {_lib.KERNEL_VALU: "valu", _lib.KERNEL_MFMA: "mfma"}[v]
+
+    # ------------------------------------------------------------------ parameters
+    def set_objective(self, Q=None, R=None, xref=None, uref=None, cx=None, cu=None):
+        H, nx, nu = self.H, self.nx, self.nu
+        keep, ptrs = [], []
+        for v, shape in ((Q, (nx, nx)), (R, (nu, nu)), (xref, (H, nx)), (uref, (H, nu)), (cx, (H, nx)),
+                         (cu, (H, nu))):
+            if v is None:
+                ptrs.append(None)
+            else:
+                a, p = _as_c_double(np.broadcast_to(np.asarray(v, dtype=np.float64), shape))
+                keep.append(a)
+                ptrs.append(p)
+        _lib.check(self.lib.nempc_set_objective(self._handle, *ptrs))
+        self._objective = dict(Q=Q, R=R, xref=xref, uref=uref, cx=cx, cu=cu)
+        self._refresh_dims()
+
+    def set_box_rows(self, lo, hi):
+        if lo is None:
+            _lib.check(self.lib.nempc_set_box_rows(self._handle, 0, None, None))
+            self._box = None
+        else:
+            a, pa = _as_c_double(np.broadcast_to(np.asarray(lo, dtype=np.float64), (self.nx,)))
+            b, pb = _as_c_double(np.broadcast_to(np.asarray(hi, dtype=np.float64), (self.nx,)))
+            _lib.check(self.lib.nempc_set_box_rows(self._handle, 1, pa, pb))
+            self._box = (lo, hi)
+        self._refresh_dims()
+        self._buffers = {}
+
+    # ------------------------------------------------------------------ structure / bounds (host)
+    def constraint_bounds(self):
+        cl, cu = np.empty(self.m), np.empty(self.m)
+        dp = ctypes.POINTER(ctypes.c_double)
+        _lib.check(self.lib.nempc_constraint_bounds(self._handle, cl.ctypes.data_as(dp), cu.ctypes.data_as(dp)))
+        return cl, cu
+
+    def jac_structure(self):
+        r, c = np.empty(self.nnz_jac, dtype=np.int32), np.empty(self.nnz_jac, dtype=np.int32)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        _lib.check(self.lib.nempc_jac_structure(self._handle, r.ctypes.data_as(ip), c.ctypes.data_as(ip)))
+        return r, c
+
+    def hess_structure(self):
+        r, c = np.empty(self.nnz_hess, dtype=np.int32), np.empty(self.nnz_hess, dtype=np.int32)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        _lib.check(self.lib.nempc_hess_structure(self._handle, r.ctypes.data_as(ip), c.ctypes.data_as(ip)))
+        return r, c
+
+    # ------------------------------------------------------------------ evaluation
+    def _check_in(self, t, shape, name):
+        if not isinstance(t, torch.Tensor) or t.device != self.device or t.dtype != self.dtype:
+            raise ValueError(f"{name} must be a {self.dtype} tensor on {self.device}")
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} must have shape {tuple(shape)}, got {tuple(t.shape)}")
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+
+    def _out(self, name, shape):
+        key = (name, tuple(shape))
+        buf = self._buffers.get(key)
+        if buf is None:
+            buf = torch.empty(shape, dtype=self.dtype, device=self.device)
+            self._buffers[key] = buf
+        return buf
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def eval(self, Z, X0, want=("f", "grad", "g", "jac_dense"), out=None):
+        """One batched callback evaluation.  Z (B,n), X0 (B,nx) device tensors.  Returns a dict with
+        the requested outputs (device tensors, reused between calls unless `out` supplies them):
+        f (B,), grad (B,n), g (B,m), jac_dense (B,m,n), jac_tiles (B,H,nx,nx+nu), jac_sparse (B,nnz_jac).
+        Asynchronous on the current torch stream."""
+        B = int(Z.shape[0])
+        self._check_in(Z, (B, self.n), "Z")
+        self._check_in(X0, (B, self.nx), "X0")
+        self.reserve(B)
+        shapes = {"f": (B,), "grad": (B, self.n), "g": (B, self.m), "jac_dense": (B, self.m, self.n),
+                  "jac_tiles": (B, self.H, self.nx, self.nin), "jac_sparse": (B, self.nnz_jac)}
+        res, ptr = {}, {}
+        for k in shapes:
+            if k in want:
+                t = out[k] if (out is not None and k in out) else self._out(k, shapes[k])
+                self._check_in(t, shapes[k], k)
+                res[k] = t
+                ptr[k] = ctypes.c_void_p(t.data_ptr())
+            else:
+                ptr[k] = None
+        unknown = set(want) - set(shapes)
+        if unknown:
+            raise ValueError(f"unknown outputs requested: {sorted(unknown)}")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nempc_eval(self._handle, B, ctypes.c_void_p(Z.data_ptr()),
+                                           ctypes.c_void_p(X0.data_ptr()), ptr["f"], ptr["grad"], ptr["g"],
+                                           ptr["jac_dense"], ptr["jac_tiles"], ptr["jac_sparse"], self._stream()))
+        return res
+
+    def hess(self, Z, X0, lam, sigma, want=("hvals",)):
+        """Lagrangian Hessian: hvals (B,nnz_hess) in hess_structure() order, optional hdense (B,n,n)
+        and hblocks (B,H,nx+nu,nx+nu)."""
+        B = int(Z.shape[0])
+        self._check_in(Z, (B, self.n), "Z")
+        self._check_in(X0, (B, self.nx), "X0")
+        self._check_in(lam, (B, self.m), "lam")
+        self._check_in(sigma, (B,), "sigma")
+        self.reserve(B)
+        shapes = {"hvals": (B, self.nnz_hess), "hdense": (B, self.n, self.n),
+                  "hblocks": (B, self.H, self.nin, self.nin)}
+        res, ptr = {}, {}
+        for k in shapes:
+            if k in want:
+                res[k] = self._out(k, shapes[k])
+                ptr[k] = ctypes.c_void_p(res[k].data_ptr())
+            else:
+                ptr[k] = None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nempc_hess(self._handle, B, ctypes.c_void_p(Z.data_ptr()),
+                                           ctypes.c_void_p(X0.data_ptr()), ctypes.c_void_p(lam.data_ptr()),
+                                           ctypes.c_void_p(sigma.data_ptr()), ptr["hvals"], ptr["hdense"],
+                                           ptr["hblocks"], self._stream()))
+        return res
+
+    def sync(self):
+        _lib.check(self.lib.nempc_sync(self._handle, self._stream()))
+
+    # ------------------------------------------------------------------ host convenience (B=1 drop-in path)
+    def to_device(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device, self.dtype)
+
+    def eval_numpy(self, Z, X0, want=("f", "grad", "g", "jac_dense")):
+        Z = np.atleast_2d(np.asarray(Z, dtype=np.float64))
+        X0 = np.atleast_2d(np.asarray(X0, dtype=np.float64))
+        res = self.eval(self.to_device(Z), self.to_device(X0), want)
+        return {k: v.to("cpu", torch.float64).numpy() for k, v in res.items()}

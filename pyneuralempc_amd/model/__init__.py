@@ -1,0 +1,7 @@
+# Links between user models and the solving system (reference: pyNeuralEMPC/model/__init__.py).
+from . import base
+from . import mlp
+from . import tensorflow
+from .base import Model
+from .mlp import MLPModel
+from .tensorflow import KerasTFModel

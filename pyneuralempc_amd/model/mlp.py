@@ -1,0 +1,107 @@
+"""Feed-forward tanh network evaluated on the device (reference: model/tensorflow.py:8-109,
+model/jax.py:32-88 -- there the derivatives come from TF / JAX autodiff of the whole (H, .) batch,
+here from the analytic per-row sweeps in csrc/)."""
+import numpy as np
+import torch
+
+from .base import Model
+from ..engine import CallbackEngine
+
+
+class MLPModel(Model):
+    """x_{next-ish} = f([x | u]) with f = Dense-tanh ... Dense-linear.
+
+    weights[l] is the Keras ``kernel`` (in, out), biases[l] is (out,).  The output width must be
+    x_dim and the input width x_dim + u_dim (same checks as KerasTFModel.__init__)."""
+
+    def __init__(self, weights, biases, x_dim, u_dim, p_dim=0, tvp_dim=0, dtype=torch.float64, device="cuda",
+                 kernel="auto"):
+        if (p_dim or 0) > 0 or (tvp_dim or 0) > 0:
+            raise NotImplementedError("p / tvp inputs are not on the device path yet (SURVEY.md 8f-3)")
+        weights = [np.asarray(w, dtype=np.float64) for w in weights]
+        biases = [np.asarray(b, dtype=np.float64).reshape(-1) for b in biases]
+        if len(weights) == 0 or len(weights) != len(biases):
+            raise ValueError("weights and biases must be non-empty lists of equal length")
+        if weights[-1].shape[1] != x_dim:
+            raise ValueError("Your model do not provide a suitable output dim ! \n It must get the same dim as "
+                             "the state dim.")
+        if weights[0].shape[0] != x_dim + u_dim:
+            raise ValueError("Your model do not provide a suitable input dim ! \n It must get the same dim as the "
+                             "sum of all input vars (x, u, p, tvp).")
+        super().__init__(x_dim, u_dim, 0, 0)
+        self.weights, self.biases = weights, biases
+        self.dtype, self.device, self.kernel = dtype, device, kernel
+        self._row_engine = None
+
+    # device handles never travel through pickle (the reference drops its Keras model the same way,
+    # model/tensorflow.py:31-37)
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_row_engine"] = None
+        return d
+
+    def make_engine(self, H, integrator, DT=1.0, max_batch=1):
+        return CallbackEngine(self.weights, self.biases, H, self.x_dim, self.u_dim, integrator=integrator, DT=DT,
+                              dtype=self.dtype, device=self.device, max_batch=max_batch, kernel=self.kernel)
+
+    def _rows(self, R):
+        # H=1 UNITY problem per row: x_prev = X0[r], u = Z[r, nx:], and with the state slot of Z
+        # zero the defect Phi - 0 is exactly f(x, u)
+        if self._row_engine is None:
+            self._row_engine = self.make_engine(1, "unity", max_batch=max(R, 1))
+        self._row_engine.reserve(R)
+        return self._row_engine
+
+    def rows_batch(self, X, U, want_jac=True):
+        """Device API: X (R,nx), U (R,nu) tensors -> f (R,nx) [, J (R,nx,nx+nu)]."""
+        R = X.shape[0]
+        eng = self._rows(R)
+        Z = torch.cat([torch.zeros_like(X), U], dim=1).contiguous()
+        res = eng.eval(Z, X.contiguous(), want=("g", "jac_tiles") if want_jac else ("g",))
+        f = res["g"]
+        return (f, res["jac_tiles"].reshape(R, self.x_dim, self.x_dim + self.u_dim)) if want_jac else f
+
+    def _to_dev(self, x, u):
+        eng = self._rows(np.asarray(x).shape[0])
+        return eng.to_device(x), eng.to_device(u)
+
+    def forward(self, x, u, p=None, tvp=None):
+        X, U = self._to_dev(x, u)
+        return self.rows_batch(X, U, want_jac=False).to("cpu", torch.float64).numpy()
+
+    def jacobian(self, x, u, p=None, tvp=None):
+        """Block layout of the reference, (H*nx, H*nx + H*nu) with columns [all x | all u]
+        (model/tensorflow.py:68-73); only the t == t' blocks are non-zero."""
+        X, U = self._to_dev(x, u)
+        _, J = self.rows_batch(X, U)
+        J = J.to("cpu", torch.float64).numpy()
+        H, nx, nu = J.shape[0], self.x_dim, self.u_dim
+        out = np.zeros((H * nx, H * nx + H * nu))
+        for t in range(H):
+            out[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx] = J[t, :, :nx]
+            out[t * nx:(t + 1) * nx, H * nx + t * nu:H * nx + (t + 1) * nu] = J[t, :, nx:]
+        return out
+
+    def hessian(self, x, u, p=None, tvp=None):
+        """(H, nx, H*(nx+nu), H*(nx+nu)) in the same block column order (model/tensorflow.py:87-109).
+        One device call per output component (one-hot multipliers)."""
+        X, U = self._to_dev(x, u)
+        R, nx, nu = X.shape[0], self.x_dim, self.u_dim
+        nin = nx + nu
+        eng = self._rows(R)
+        Z = torch.cat([torch.zeros_like(X), U], dim=1).contiguous()
+        sigma = torch.zeros(R, dtype=eng.dtype, device=eng.device)
+        n = R * nin
+        out = np.zeros((R, nx, n, n))
+        for k in range(nx):
+            lam = torch.zeros(R, eng.m, dtype=eng.dtype, device=eng.device)
+            lam[:, k] = 1.0
+            blk = eng.hess(Z, X.contiguous(), lam, sigma, want=("hblocks",))["hblocks"]
+            blk = blk.reshape(R, nin, nin).to("cpu", torch.float64).numpy()
+            for t in range(R):
+                xs, us = slice(t * nx, (t + 1) * nx), slice(R * nx + t * nu, R * nx + (t + 1) * nu)
+                out[t, k][xs, xs] = blk[t, :nx, :nx]
+                out[t, k][xs, us] = blk[t, :nx, nx:]
+                out[t, k][us, xs] = blk[t, nx:, :nx]
+                out[t, k][us, us] = blk[t, nx:, nx:]
+        return out

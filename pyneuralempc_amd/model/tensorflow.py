@@ -1,0 +1,52 @@
+"""KerasTFModel drop-in (reference: model/tensorflow.py:8-109) without importing TensorFlow.
+
+The reference wraps a live Keras model and differentiates it with tf.GradientTape on the CPU.
+Here the Keras object is only *read*: its Dense kernels/biases are copied once and the network is
+evaluated by the HIP kernels.  Anything that is not a stack of Dense layers with tanh hidden
+activations and a linear output is rejected loudly."""
+import numpy as np
+
+from .mlp import MLPModel
+
+
+def _activation_name(layer):
+    act = getattr(layer, "activation", None)
+    if act is None:
+        return "linear"
+    return getattr(act, "__name__", str(act))
+
+
+def extract_dense_stack(keras_model):
+    """-> (weights, biases) from a duck-typed Keras Sequential/Functional model of Dense layers."""
+    layers = [l for l in getattr(keras_model, "layers", []) if len(l.get_weights()) > 0]
+    if not layers:
+        raise ValueError("The provided model has no parameterised layers")
+    weights, biases = [], []
+    for i, layer in enumerate(layers):
+        params = layer.get_weights()
+        if len(params) != 2 or np.ndim(params[0]) != 2 or np.ndim(params[1]) != 1:
+            raise NotImplementedError("Only Dense layers (kernel, bias) are supported on the device path")
+        name = _activation_name(layer)
+        expected = "linear" if i == len(layers) - 1 else "tanh"
+        if name != expected:
+            raise NotImplementedError(f"layer {i}: activation '{name}' unsupported (need tanh hidden layers and a "
+                                      "linear output layer)")
+        weights.append(np.asarray(params[0], dtype=np.float64))
+        biases.append(np.asarray(params[1], dtype=np.float64))
+    return weights, biases
+
+
+class KerasTFModel(MLPModel):
+    def __init__(self, model, x_dim: int, u_dim: int, p_dim=0, tvp_dim=0, standardScaler=None, **device_kwargs):
+        if standardScaler is not None:
+            raise NotImplementedError("This feature isn't supported yet !")
+        if len(model.input_shape) != 2:
+            raise NotImplementedError("Recurrent neural network are not supported atm.")
+        if model.output_shape[-1] != x_dim:
+            raise ValueError("Your Keras model do not provide a suitable output dim ! \n It must get the same dim "
+                             "as the state dim.")
+        if model.input_shape[-1] != sum((x_dim, u_dim, p_dim, tvp_dim)):
+            raise ValueError("Your Keras model do not provide a suitable input dim ! \n It must get the same dim as "
+                             "the sum of all input vars (x, u, p, tvp).")
+        weights, biases = extract_dense_stack(model)
+        super().__init__(weights, biases, x_dim, u_dim, p_dim, tvp_dim, **device_kwargs)

@@ -1,0 +1,5 @@
+# Objective functions (reference: pyNeuralEMPC/objective/__init__.py).
+from . import base
+from . import quadratic
+from .base import ObjectiveFunc, ManualObjectifFunc
+from .quadratic import QuadraticObjective

@@ -1,0 +1,238 @@
+"""Solver-glue interfaces (reference: pyNeuralEMPC/optimizer/base.py:7-149).
+
+The object handed to cyipopt / scipy is a ProblemInterface; its five callbacks are the drop-in
+boundary of this build: behind them sits one fused device evaluation per iterate (``_CallbackGlue``).
+"""
+import numpy as np
+import torch
+
+from ..constraints import BoxStateConstraint, Constraint, DomainConstraint  # noqa: F401
+from ..integrator.base import DeviceIntegrator
+from ..objective.quadratic import QuadraticObjective
+
+
+class ProblemInterface:
+    def __init__(self, use_hessian: bool):
+        self.use_hessian = use_hessian
+
+    def objective(self, x):
+        raise NotImplementedError("")
+
+    def gradient(self, x):
+        raise NotImplementedError("")
+
+    def constraints(self, x):
+        raise NotImplementedError("")
+
+    def hessianstructure(self):
+        raise NotImplementedError("")
+
+    def hessian(self, x, lagrange, obj_factor):
+        raise NotImplementedError("")
+
+    def jacobian(self, x):
+        raise NotImplementedError("")
+
+    def get_constraint_lower_bounds(self):
+        raise NotImplementedError("")
+
+    def get_constraint_upper_bounds(self):
+        raise NotImplementedError("")
+
+    def get_init_value(self):
+        raise NotImplementedError("")
+
+    def get_init_variables(self):
+        raise NotImplementedError("")
+
+
+class ProblemInterfaceHessianFree:
+    """View of a problem without hessian / hessianstructure, so that Ipopt falls back to its
+    quasi-Newton update (reference: optimizer/base.py:7-32)."""
+
+    def __init__(self, core):
+        self.core = core
+        for name in ("objective", "gradient", "constraints", "jacobian", "get_constraint_lower_bounds",
+                     "get_constraint_upper_bounds", "get_init_value"):
+            setattr(self, name, getattr(core, name))
+
+
+class ProblemFactory:
+    def __init__(self):
+        self.x0 = None
+        self.p = None
+        self.tvp = None
+        self.objective = None
+        self.constraints = None
+        self.use_hessian = False
+        self.integrator = None
+        self.init_u, self.init_x = None, None
+
+    def getProblemInterface(self) -> ProblemInterface:
+        for value, name in ((self.x0, "x0"), (self.objective, "objective"), (self.constraints, "constraints"),
+                            (self.integrator, "integrator")):
+            if value is None:
+                raise RuntimeError(f"Not ready yet ! {name} is missing")
+        return self._process()
+
+    def set_integrator(self, integrator):
+        self.integrator = integrator
+
+    def set_x0(self, x0):
+        self.x0 = x0
+
+    def set_init_values(self, init_x, init_u):
+        self.init_x = init_x
+        self.init_u = init_u
+
+    def set_p(self, p):
+        self.p = p
+
+    def set_tvp(self, tvp):
+        self.tvp = tvp
+
+    def set_objective(self, obj):
+        self.objective = obj
+
+    def set_constraints(self, ctrs: list):
+        self.constraints = ctrs
+
+    def set_use_hessian(self, hessian: bool):
+        self.use_hessian = hessian
+
+    def _process(self):
+        raise NotImplementedError("")
+
+
+class Optimizer:
+    FAIL = 1
+    SUCCESS = 0
+
+    def __init__(self):
+        pass
+
+    def get_factory(self) -> ProblemFactory:
+        """Return the solver's associated factory."""
+
+    def solve(self, problem: ProblemInterface, domain_constraint: DomainConstraint):
+        raise NotImplementedError("")
+
+
+def cold_start(x0, H, u_dim):
+    """[x0 tiled H ; zeros(H*u_dim)]  (reference: optimizer/ipopt.py:149, slsqp.py:163)."""
+    return np.concatenate([np.tile(np.asarray(x0, dtype=np.float64), H), np.zeros(H * u_dim)])
+
+
+def warm_start_shift(prev, H, x_dim, u_dim):
+    """Previous solution advanced by one step, last step repeated (ipopt.py:141-147, slsqp.py:155-161)."""
+    prev = np.asarray(prev, dtype=np.float64)
+    xs, us = prev[:H * x_dim].reshape(H, x_dim), prev[H * x_dim:].reshape(H, u_dim)
+    return np.concatenate([xs[1:].ravel(), xs[-1], us[1:].ravel(), us[-1]])
+
+
+class _FusedEvaluator:
+    """integrator + QuadraticObjective [+ BoxStateConstraint] on ONE engine: a single device call
+    yields f, grad f, g, dense jac g for an iterate; results are cached per (z, x0) because the
+    solvers ask for the four pieces in separate callbacks."""
+
+    def __init__(self, integrator, objective, box):
+        model = integrator.model
+        self.engine = model.make_engine(integrator.H, integrator.KIND, DT=integrator.DT, max_batch=1)
+        self.engine.set_objective(**objective.resolved(integrator.H, model.x_dim, model.u_dim))
+        if box is not None:
+            lo, hi = box._bounds(model.x_dim)
+            self.engine.set_box_rows(lo, hi)
+        self._key = None
+        self._val = None
+        self.n_device_evals = 0
+
+    def evaluate(self, z, x0):
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        if self._key is not None and np.array_equal(self._key[0], z) and np.array_equal(self._key[1], x0):
+            return self._val
+        res = self.engine.eval_numpy(z[None, :], np.asarray(x0, dtype=np.float64)[None, :],
+                                     want=("f", "grad", "g", "jac_dense"))
+        self._key = (z.copy(), np.array(x0, dtype=np.float64))
+        self._val = {k: v[0] for k, v in res.items()}
+        self.n_device_evals += 1
+        return self._val
+
+    def hessian_values(self, z, x0, lagrange, obj_factor):
+        eng = self.engine
+        lam = eng.to_device(np.asarray(lagrange, dtype=np.float64)[None, :])
+        sig = eng.to_device(np.array([obj_factor], dtype=np.float64))
+        out = eng.hess(eng.to_device(np.asarray(z)[None, :]), eng.to_device(np.asarray(x0)[None, :]), lam, sig)
+        return out["hvals"][0].to("cpu", torch.float64).numpy()
+
+
+class _CallbackGlue:
+    """Shared body of IpoptProblem / SlsqpProblem: split z, fan out, concatenate
+    (reference: optimizer/ipopt.py:20-108, slsqp.py:25-110)."""
+
+    def _setup(self, x0, objective_func, constraints, integrator, p, tvp):
+        self.x0 = x0
+        self.objective_func = objective_func
+        self.constraints_list = constraints
+        self.integrator = integrator
+        model = integrator.model
+        self.x_dim, self.u_dim, self.p_dim, self.tvp_dim = model.x_dim, model.u_dim, model.p_dim, model.tvp_dim
+        self.H = integrator.H
+        self.p = p
+        self.tvp = tvp
+        self._fused = None
+        boxes = [c for c in constraints if isinstance(c, BoxStateConstraint)]
+        if (isinstance(integrator, DeviceIntegrator) and isinstance(objective_func, QuadraticObjective)
+                and len(boxes) == len(constraints) and len(boxes) <= 1 and p is None and tvp is None):
+            key = (id(objective_func), id(boxes[0]) if boxes else None)
+            cache = integrator._fused
+            if key not in cache:
+                cache[key] = _FusedEvaluator(integrator, objective_func, boxes[0] if boxes else None)
+            self._fused = cache[key]
+
+    def _split(self, x):
+        nxh = self.x_dim * self.H
+        states = x[:nxh].reshape(self.H, self.x_dim)
+        u = x[nxh:nxh + self.u_dim * self.H].reshape(self.H, self.u_dim)
+        return states, u, self.tvp, self.p
+
+    def _objective(self, x):
+        if self._fused is not None:
+            return float(self._fused.evaluate(x, self.x0)["f"])
+        states, u, tvp, p = self._split(x)
+        return self.objective_func.forward(states, u, p=p, tvp=tvp)
+
+    def _gradient(self, x):
+        if self._fused is not None:
+            return self._fused.evaluate(x, self.x0)["grad"].copy()
+        states, u, tvp, p = self._split(x)
+        return self.objective_func.gradient(states, u, p=p, tvp=tvp)
+
+    def _all_constraints(self, x):
+        if self._fused is not None:
+            return self._fused.evaluate(x, self.x0)["g"].copy()
+        states, u, tvp, p = self._split(x)
+        parts = [self.integrator.forward(states, u, self.x0, p=p, tvp=tvp)]
+        parts += [c.forward(states, u, p=p, tvp=tvp) for c in self.constraints_list]
+        return np.concatenate(parts)
+
+    def _all_jacobian(self, x):
+        if self._fused is not None:
+            return self._fused.evaluate(x, self.x0)["jac_dense"].copy()
+        states, u, tvp, p = self._split(x)
+        parts = [self.integrator.jacobian(states, u, self.x0, p=p, tvp=tvp)]
+        parts += [c.jacobian(states, u, p=p, tvp=tvp) for c in self.constraints_list]
+        return np.concatenate(parts, axis=0)
+
+    def get_constraint_lower_bounds(self):
+        return np.concatenate([np.asarray(c.get_lower_bounds(self.H), dtype=np.float64)
+                               for c in [self.integrator, ] + self.constraints_list])
+
+    def get_constraint_upper_bounds(self):
+        return np.concatenate([np.asarray(c.get_upper_bounds(self.H), dtype=np.float64)
+                               for c in [self.integrator, ] + self.constraints_list])
+
+    def get_init_value(self):
+        return self.x0
+
+    def get_init_variables(self):
+        return self.init_x, self.init_u

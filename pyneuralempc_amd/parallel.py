@@ -1,0 +1,54 @@
+"""Multi-GPU: independent MPC problem instances are sharded over ranks (one process per GPU);
+there is no collective on the callback path.  The only exchange is one all-gather (RCCL over xGMI
+with backend "nccl"; "gloo" in CPU tests) of the solved first controls u0 per MPC step --
+(B/G)*nu elements per rank, latency-bound.  The reference has no distributed code."""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(B, rank, world):
+    """Contiguous [lo, hi) slice of B problems owned by `rank`; sizes differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, rem = divmod(B, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def first_controls(Z, H, nx, nu):
+    """u0 of every problem: z[H*nx : H*nx+nu]  (layout optimizer/ipopt.py:20-28)."""
+    return Z[:, H * nx:H * nx + nu].contiguous()
+
+
+def allgather_u0(u0_local, total=None, group=None):
+    """Gather (b_r, nu) per rank into (sum_r b_r, nu), rank-major.  Equal shards use one
+    all_gather_into_tensor on a persistent-sized buffer; ragged shards pad to the largest."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return u0_local
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    b, nu = u0_local.shape
+    if total is None:
+        sizes = torch.tensor([b], dtype=torch.int64, device=u0_local.device)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes, group=group)
+        counts = [int(s.item()) for s in all_sizes]
+    else:
+        counts = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
+        if counts[rank] != b:
+            raise ValueError("local shard size does not match shard_bounds(total, rank, world)")
+    bmax = max(counts)
+    if all(c == bmax for c in counts):
+        out = torch.empty(world * b, nu, dtype=u0_local.dtype, device=u0_local.device)
+        try:
+            dist.all_gather_into_tensor(out, u0_local.contiguous(), group=group)
+        except (RuntimeError, NotImplementedError):  # backend without the fused form
+            parts = [torch.empty_like(u0_local) for _ in range(world)]
+            dist.all_gather(parts, u0_local.contiguous(), group=group)
+            out = torch.cat(parts, dim=0)
+        return out
+    padded = torch.zeros(bmax, nu, dtype=u0_local.dtype, device=u0_local.device)
+    padded[:b] = u0_local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)

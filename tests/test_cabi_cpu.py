@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nempc.h declares; no compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "nempc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nempc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pyneuralempc_amd import _lib
+    lib = _lib.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"libnempc.so does not export {s}"
+    assert sorted(_lib.EXPORTS) == syms
+    assert lib.nempc_abi_version() == _lib.ABI_VERSION
+
+
+def test_config_struct_matches_header_layout():
+    from pyneuralempc_amd import _lib
+    # 8 int32 + 8 widths + 3 int32 = 19 int32 (76 B) -> padded to 80, + double = 88
+    assert ctypes.sizeof(_lib.NempcConfig) == 88
+    assert _lib.NempcConfig.DT.offset == 80
+
+
+def test_create_validates_before_touching_the_device_and_fails_loudly_without_gpu():
+    import torch
+    from pyneuralempc_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.NempcConfig()
+    h = ctypes.c_void_p()
+    cfg.abi_version = 99
+    assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"abi_version" in lib.nempc_last_error()
+    cfg.abi_version = _lib.ABI_VERSION
+    cfg.dtype, cfg.integrator, cfg.H, cfg.nx, cfg.nu, cfg.n_layers = 0, 0, 0, 2, 1, 1
+    assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    cfg.H = 4
+    cfg.widths[0] = 3          # last width != nx
+    assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    cfg.widths[0] = 2
+    cfg.max_batch = 1
+    cfg.integrator, cfg.DT = 2, 0.0   # RK4 without DT
+    assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    if not torch.cuda.is_available():
+        cfg.integrator = 0
+        rc = lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h))
+        assert rc == -3 and b"no HIP device" in lib.nempc_last_error()
+        assert not h.value
+    assert lib.nempc_destroy(None) == 0
+    assert lib.nempc_eval(None, 1, None, None, None, None, None, None, None, None, None) == -1
+
+
+def test_engine_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pyneuralempc_amd import CallbackEngine
+    import numpy as np
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        CallbackEngine([np.zeros((3, 2))], [np.zeros(2)], 4, 2, 1)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "pyneuralempc_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"

@@ -1,0 +1,212 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference-generated golden vectors and
+against the CPU oracle on seeded inputs.  fp64 tolerance 1e-12 abs + 1e-12 rel;
+fp32 configs 1e-4 relative to the fp64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nempc_oracle as orc
+from helpers import CASE_NAMES, load_case, oracle_problem
+
+pytestmark = pytest.mark.gpu
+
+F64 = dict(rtol=1e-12, atol=1e-12)
+KIND_NAME = {0: "discret", 1: "unity", 2: "rk4"}
+
+
+def _engine(d, W, b, dtype, kernel, max_batch=8):
+    from pyneuralempc_amd import CallbackEngine
+    eng = CallbackEngine(W, b, int(d["H"]), int(d["nx"]), int(d["nu"]), integrator=KIND_NAME[int(d["kind"])],
+                         DT=float(d["DT"]), dtype=dtype, device="cuda:0", max_batch=max_batch, kernel=kernel)
+    eng.set_objective(Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"])
+    if int(d["has_box"]):
+        eng.set_box_rows(d["box_lo"], d["box_hi"])
+    return eng
+
+
+def _f32_close(a, b, what):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(1.0, np.abs(b).max())
+    err = np.abs(a - b).max() / scale
+    assert err < 1e-4, f"{what}: max rel err {err:.3e}"
+
+
+ALL = ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")
+
+
+@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_golden_fp64(name, kernel):
+    d, W, b = load_case(name)
+    eng = _engine(d, W, b, torch.float64, kernel)
+    assert eng.kernel_variant == kernel
+    res = eng.eval_numpy(d["Z"], d["X0"], want=ALL)
+    np.testing.assert_allclose(res["f"], d["f"], **F64)
+    np.testing.assert_allclose(res["grad"], d["grad"], **F64)
+    np.testing.assert_allclose(res["g"], d["g"], **F64)
+    np.testing.assert_allclose(res["jac_dense"], d["jac"], **F64)
+    # structural zeros are exact zeros, and the sparse / tile contracts agree with the dense one bit for bit
+    assert np.array_equal(res["jac_dense"] != 0, d["jac"] != 0)
+    rows, cols = eng.jac_structure()
+    assert np.array_equal(res["jac_sparse"], res["jac_dense"][:, rows, cols])
+    prob = oracle_problem(d, W, b)
+    for i in range(d["Z"].shape[0]):
+        _, A, Bt = prob.tiles_AB(d["Z"][i], d["X0"][i])
+        np.testing.assert_allclose(res["jac_tiles"][i][:, :, :prob.nx], A, **F64)
+        np.testing.assert_allclose(res["jac_tiles"][i][:, :, prob.nx:], Bt, **F64)
+    cl, cu = eng.constraint_bounds()
+    np.testing.assert_array_equal(cl, d["cl"])
+    np.testing.assert_array_equal(cu, d["cu_bound"])
+
+
+@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+@pytest.mark.parametrize("name", ["c2_discret", "c3_rk4", "c3_discret", "c5_box", "odd_dims"])
+def test_golden_fp32(name, kernel):
+    d, W, b = load_case(name)
+    eng = _engine(d, W, b, torch.float32, kernel)
+    res = eng.eval_numpy(d["Z"], d["X0"], want=ALL)
+    for k, ref in (("f", d["f"]), ("grad", d["grad"]), ("g", d["g"]), ("jac_dense", d["jac"])):
+        _f32_close(res[k], ref, f"{name}/{k}")
+    assert np.array_equal(res["jac_dense"] != 0, d["jac"] != 0)
+
+
+@pytest.mark.parametrize("name", [n for n in CASE_NAMES if n not in ("c3_rk4", "c2_rk4", "odd_dims", "c3_discret")])
+def test_golden_hessian_fp64(name):
+    d, W, b = load_case(name)
+    eng = _engine(d, W, b, torch.float64, "auto")
+    Z, X0 = eng.to_device(d["Z"]), eng.to_device(d["X0"])
+    lam, sig = eng.to_device(d["lam"]), eng.to_device(d["sigma"])
+    out = eng.hess(Z, X0, lam, sig, want=("hvals", "hdense"))
+    hd = out["hdense"].cpu().numpy()
+    hv = out["hvals"].cpu().numpy()
+    np.testing.assert_allclose(hd, d["hdense"], rtol=1e-11, atol=1e-12)
+    rows, cols = eng.hess_structure()
+    assert np.array_equal(hv, hd[:, rows, cols])
+    # the reference's sampled pattern is inside ours and its values agree
+    ours = set(zip(rows.tolist(), cols.tolist()))
+    assert set(zip(d["h_rows"].tolist(), d["h_cols"].tolist())) <= ours
+    np.testing.assert_allclose(hd[:, d["h_rows"], d["h_cols"]], d["hvals"], rtol=1e-11, atol=1e-12)
+    prob = oracle_problem(d, W, b)
+    orows, ocols = prob.hessian_structure()
+    assert np.array_equal(rows, orows) and np.array_equal(cols, ocols)
+
+
+def test_rk4_hessian_is_refused_loudly():
+    from pyneuralempc_amd._lib import NempcError
+    d, W, b = load_case("c2_rk4")
+    eng = _engine(d, W, b, torch.float64, "auto")
+    Z, X0 = eng.to_device(d["Z"]), eng.to_device(d["X0"])
+    with pytest.raises(NempcError):
+        eng.hess(Z, X0, eng.to_device(d["lam"]), eng.to_device(d["sigma"]))
+
+
+@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+@pytest.mark.parametrize("cfg", [
+    # (nx, nu, hidden, H, kind, DT, box, B)   B*H deliberately not a multiple of 16
+    (2, 1, [64, 64], 20, orc.DISCRET, 1.0, None, 37),
+    (2, 1, [64, 64], 50, orc.DISCRET, 1.0, (-2.0, 2.0), 9),
+    (6, 3, [128, 128, 128], 30, orc.RK4, 0.1, None, 5),
+    (4, 2, [32], 3, orc.UNITY, 1.0, None, 11),
+    (3, 2, [48, 32], 7, orc.RK4, 0.05, None, 13),
+    (1, 1, [20, 20, 20], 5, orc.DISCRET, 1.0, None, 7),
+    (16, 1, [64], 2, orc.DISCRET, 1.0, None, 3),     # nx at the MFMA-path limit... nin = 17 -> VALU only
+    (12, 4, [96, 96], 4, orc.RK4, 0.2, None, 3),      # nin = 16: MFMA-path limit
+])
+def test_against_oracle_seeded_fp64(cfg, kernel):
+    nx, nu, hidden, H, kind, DT, box, B = cfg
+    from pyneuralempc_amd import CallbackEngine
+    from pyneuralempc_amd._lib import NempcError
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=3)
+    prob = orc.Problem(net, H, nx, nu, kind, DT, box=box)
+    try:
+        eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=KIND_NAME[kind], DT=DT, dtype=torch.float64,
+                             device="cuda:0", max_batch=B, kernel=kernel)
+    except NempcError:
+        assert kernel == "mfma" and nx + nu > 16   # documented shape gate of the matrix-core kernel
+        return
+    if box is not None:
+        eng.set_box_rows(*box)
+    Z, X0 = orc.synthetic_inputs(B, H, nx, nu, seed=5)
+    res = eng.eval_numpy(Z, X0, want=ALL)
+    f, grad, g, jac = prob.eval_batch(Z, X0)
+    np.testing.assert_allclose(res["f"], f, **F64)
+    np.testing.assert_allclose(res["grad"], grad, **F64)
+    np.testing.assert_allclose(res["g"], g, rtol=1e-12, atol=2e-12)
+    np.testing.assert_allclose(res["jac_dense"], jac, rtol=1e-11, atol=2e-12)
+
+
+def test_batch_invariance_and_reuse():
+    """A problem's result does not depend on its position in the batch nor on the batch size
+    (bit-exact), and repeated calls on reused output buffers are deterministic."""
+    d, W, b = load_case("c2_discret")
+    eng = _engine(d, W, b, torch.float64, "mfma", max_batch=64)
+    Z, X0 = orc.synthetic_inputs(50, 20, 2, 1, seed=8)
+    full = {k: v.copy() for k, v in eng.eval_numpy(Z, X0, want=ALL).items()}
+    perm = np.random.default_rng(0).permutation(50)
+    shuf = eng.eval_numpy(Z[perm], X0[perm], want=ALL)
+    for k in ALL:
+        assert np.array_equal(shuf[k], full[k][perm]), k
+    one = eng.eval_numpy(Z[17:18], X0[17:18], want=ALL)
+    for k in ALL:
+        assert np.array_equal(one[k][0], full[k][17]), k
+    again = eng.eval_numpy(Z, X0, want=ALL)
+    for k in ALL:
+        assert np.array_equal(again[k], full[k]), k
+
+
+def test_full_size_properties_c2():
+    """BASELINE sizes (B=1024, H=20): directional finite differences of g and f against the device
+    Jacobian / gradient, valu-vs-mfma agreement, exact structural zeros."""
+    B, H, nx, nu = 1024, 20, 2, 1
+    net = orc.MLP.random(3, [64, 64], 2, seed=0)
+    from pyneuralempc_amd import CallbackEngine
+    engs = {k: CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B, kernel=k)
+            for k in ("valu", "mfma")}
+    Z, X0 = orc.synthetic_inputs(B, H, nx, nu, seed=1)
+    r = {k: {kk: v.copy() for kk, v in e.eval_numpy(Z, X0, want=ALL).items()} for k, e in engs.items()}
+    for k in ("f", "grad", "g", "jac_dense"):
+        np.testing.assert_allclose(r["mfma"][k], r["valu"][k], rtol=1e-12, atol=1e-12)
+    rows, cols = engs["mfma"].jac_structure()
+    mask = np.zeros((40, 60), dtype=bool)
+    mask[rows, cols] = True
+    assert np.all(r["mfma"]["jac_dense"][:, ~mask] == 0.0)
+    v = np.random.default_rng(2).normal(size=Z.shape)
+    eps = 1e-6
+    gp = engs["mfma"].eval_numpy(Z + eps * v, X0, want=("f", "g"))
+    gp = {k: x.copy() for k, x in gp.items()}
+    gm = engs["mfma"].eval_numpy(Z - eps * v, X0, want=("f", "g"))
+    jv = np.einsum("bmn,bn->bm", r["mfma"]["jac_dense"], v)
+    assert np.abs((gp["g"] - gm["g"]) / (2 * eps) - jv).max() < 1e-7
+    gv = np.einsum("bn,bn->b", r["mfma"]["grad"], v)
+    assert np.abs((gp["f"] - gm["f"]) / (2 * eps) - gv).max() < 1e-6
+    # spot-check a slice against the oracle
+    prob = orc.Problem(net, H, nx, nu)
+    f, grad, g, jac = prob.eval_batch(Z[500:516], X0[500:516])
+    np.testing.assert_allclose(r["mfma"]["jac_dense"][500:516], jac, **F64)
+    np.testing.assert_allclose(r["mfma"]["g"][500:516], g, **F64)
+
+
+def test_edge_cases():
+    from pyneuralempc_amd import CallbackEngine
+    from pyneuralempc_amd._lib import NempcError
+    net = orc.MLP.random(3, [16], 2, seed=0)
+    eng = CallbackEngine(net.W, net.b, 4, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=2)
+    # empty batch
+    Z0 = torch.empty(0, eng.n, dtype=torch.float64, device="cuda:0")
+    X00 = torch.empty(0, 2, dtype=torch.float64, device="cuda:0")
+    assert eng.eval(Z0, X00)["g"].shape == (0, eng.m)
+    # wrong dtype / shape are refused on the host
+    with pytest.raises(ValueError):
+        eng.eval(torch.zeros(1, eng.n, dtype=torch.float32, device="cuda:0"), torch.zeros(1, 2, dtype=torch.float64, device="cuda:0"))
+    with pytest.raises(ValueError):
+        eng.eval(torch.zeros(1, eng.n + 1, dtype=torch.float64, device="cuda:0"), torch.zeros(1, 2, dtype=torch.float64, device="cuda:0"))
+    # growth beyond max_batch re-creates the handle transparently
+    Z, X0 = orc.synthetic_inputs(33, 4, 2, 1, seed=2)
+    res = eng.eval_numpy(Z, X0)
+    prob = orc.Problem(net, 4, 2, 1)
+    np.testing.assert_allclose(res["jac_dense"], prob.eval_batch(Z, X0)[3], **F64)
+    # bad construction arguments come back as library errors / ValueError, not crashes
+    with pytest.raises(ValueError):
+        CallbackEngine(net.W, net.b, 4, 3, 1, device="cuda:0")
+    with pytest.raises(NempcError):
+        CallbackEngine(net.W, net.b, 0, 2, 1, device="cuda:0")

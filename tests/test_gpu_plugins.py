@@ -1,0 +1,193 @@
+"""GPU: the reference-shaped plug-in surface (Model / Integrator / Objective / Constraint / Optimizer /
+NMPC) driven like the reference's own scripts, checked against reference-generated goldens."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nempc_oracle as orc
+from helpers import GOLDEN, load_case, oracle_problem
+
+pytestmark = pytest.mark.gpu
+F64 = dict(rtol=1e-12, atol=1e-12)
+
+
+def _integrator(d, W, b):
+    import pyneuralempc_amd as nEMPC
+    model = nEMPC.model.MLPModel(W, b, int(d["nx"]), int(d["nu"]), device="cuda:0")
+    H, kind = int(d["H"]), int(d["kind"])
+    if kind == orc.DISCRET:
+        return nEMPC.integrator.discret.DiscretIntegrator(model, H)
+    if kind == orc.UNITY:
+        return nEMPC.integrator.unity.UnityIntegrator(model, H)
+    return nEMPC.integrator.rk4.RK4Integrator(model, H, float(d["DT"]), cache_mode=True)
+
+
+@pytest.mark.parametrize("name", ["c1_discret", "c2_unity", "c2_rk4", "odd_dims"])
+def test_integrator_forward_jacobian_like_reference(name):
+    d, W, b = load_case(name)
+    integ = _integrator(d, W, b)
+    H, nx, nu = int(d["H"]), int(d["nx"]), int(d["nu"])
+    for i in range(d["Z"].shape[0]):
+        z = d["Z"][i]
+        states, u = z[:H * nx].reshape(H, nx), z[H * nx:].reshape(H, nu)
+        np.testing.assert_allclose(integ.forward(states, u, d["X0"][i]), d["g_int"][i], **F64)
+        np.testing.assert_allclose(integ.jacobian(states, u, d["X0"][i]), d["jac_int"][i], **F64)
+    assert integ.get_lower_bounds(H) == [0.0] * (H * nx) and integ.get_upper_bounds(H) == [0.0] * (H * nx)
+    with pytest.raises(AssertionError):
+        integ.forward(states.ravel(), u, d["X0"][0])
+
+
+def test_model_plugin_layouts():
+    d, W, b = load_case("c1_discret")
+    import pyneuralempc_amd as nEMPC
+    model = nEMPC.model.MLPModel(W, b, 2, 1, device="cuda:0")
+    net = orc.MLP(W, b)
+    rng = np.random.default_rng(0)
+    x, u = rng.normal(size=(6, 2)), rng.normal(size=(6, 1))
+    xi = np.concatenate([x, u], axis=1)
+    f, J, S = net.forward_jac_hess(xi)
+    np.testing.assert_allclose(model.forward(x, u), f, **F64)
+    MJ = model.jacobian(x, u)
+    assert MJ.shape == (12, 18)
+    Hs = model.hessian(x, u)
+    assert Hs.shape == (6, 2, 18, 18)
+    for t in range(6):
+        np.testing.assert_allclose(MJ[2 * t:2 * t + 2, 2 * t:2 * t + 2], J[t][:, :2], **F64)
+        np.testing.assert_allclose(MJ[2 * t:2 * t + 2, 12 + t:13 + t], J[t][:, 2:], **F64)
+        np.testing.assert_allclose(Hs[t][:, 2 * t:2 * t + 2, 2 * t:2 * t + 2], S[t][:, :2, :2], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(Hs[t][:, 12 + t, 2 * t:2 * t + 2], S[t][:, 2, :2], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(Hs[t][:, 12 + t, 12 + t], S[t][:, 2, 2], rtol=1e-11, atol=1e-12)
+    mask = np.ones((12, 18), dtype=bool)
+    for t in range(6):
+        mask[2 * t:2 * t + 2, 2 * t:2 * t + 2] = False
+        mask[2 * t:2 * t + 2, 12 + t] = False
+    assert not MJ[mask].any()
+
+
+def test_integrator_hessian_blocks_like_reference():
+    d, W, b = load_case("c1_discret")
+    integ = _integrator(d, W, b)
+    H, nx, nu = 10, 2, 1
+    z = d["Z"][0]
+    states, u = z[:H * nx].reshape(H, nx), z[H * nx:].reshape(H, nu)
+    ih = integ.hessian(states, u, d["X0"][0])
+    assert ih.shape == (H * nx, 30, 30)
+    prob = oracle_problem(d, W, b)
+    contracted = np.einsum("i,ipq->pq", d["lam"][0][:H * nx], ih) + float(d["sigma"][0]) * prob.objective_hessian()
+    np.testing.assert_allclose(contracted, d["hdense"][0], rtol=1e-11, atol=1e-12)
+    S = integ.hessianstructure()
+    assert np.all((np.abs(ih).sum(axis=0) != 0) <= (S != 0))
+
+
+@pytest.mark.parametrize("name", ["c2_discret", "c5_box"])
+def test_problem_glue_like_reference(name):
+    """IpoptProblem / SlsqpProblem callbacks (one fused device evaluation per iterate)."""
+    import pyneuralempc_amd as nEMPC
+    from pyneuralempc_amd.optimizer.ipopt import IpoptProblem
+    from pyneuralempc_amd.optimizer.slsqp import SlsqpProblem
+    d, W, b = load_case(name)
+    integ = _integrator(d, W, b)
+    obj = nEMPC.objective.QuadraticObjective(Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"],
+                                             device="cuda:0")
+    ctrs = [nEMPC.constraints.BoxStateConstraint(d["box_lo"], d["box_hi"])] if int(d["has_box"]) else []
+    for i in range(d["Z"].shape[0]):
+        pb = IpoptProblem(d["X0"][i], obj, ctrs, integ)
+        assert pb._fused is not None
+        z = d["Z"][i]
+        np.testing.assert_allclose(pb.objective(z), d["f"][i], **F64)
+        np.testing.assert_allclose(pb.gradient(z), d["grad"][i], **F64)
+        np.testing.assert_allclose(pb.constraints(z), d["g"][i], **F64)
+        np.testing.assert_allclose(pb.jacobian(z), d["jac"][i], **F64)
+        assert pb._fused.n_device_evals == i + 1, "four callbacks of one iterate share one device evaluation"
+        rows, cols = pb.hessianstructure()
+        hv = pb.hessian(z, d["lam"][i], float(d["sigma"][i]))
+        np.testing.assert_allclose(hv, d["hdense"][i][rows, cols], rtol=1e-11, atol=1e-12)
+    np.testing.assert_array_equal(pb.get_constraint_lower_bounds(), d["cl"])
+    np.testing.assert_array_equal(pb.get_constraint_upper_bounds(), d["cu_bound"])
+    jr, jc = pb.jacobianstructure()
+    assert np.array_equal(np.stack(np.nonzero(d["jac"][0] != 0)), np.stack([jr, jc]))
+    sp = SlsqpProblem(d["X0"][0], obj, ctrs, integ)
+    np.testing.assert_allclose(sp.constraints(d["Z"][0], eq=True), d["slsqp_eq"], **F64)
+    np.testing.assert_allclose(sp.jacobian(d["Z"][0], eq=True), d["slsqp_eq_jac"], **F64)
+    if ctrs:
+        gi = sp.constraints(d["Z"][0], eq=False)
+        st = d["Z"][0][:100]
+        np.testing.assert_allclose(gi, np.concatenate([st + 2.0, 2.0 - st]), **F64)
+        assert sp.jacobian(d["Z"][0], eq=False).shape == (200, 150)
+        assert len(sp.get_constraints_dict()) == 2
+
+
+def test_generic_plugin_path_matches_fused_path():
+    """User-defined Objective / Constraint plug-ins (host callables) go through the unfused glue and
+    must give the same numbers as the fused device path."""
+    import pyneuralempc_amd as nEMPC
+    from pyneuralempc_amd.optimizer.ipopt import IpoptProblem
+    d, W, b = load_case("c5_box")
+    integ = _integrator(d, W, b)
+    prob = oracle_problem(d, W, b)
+    zcat = lambda s, u: np.concatenate([s.ravel(), u.ravel()])
+    man = nEMPC.objective.ManualObjectifFunc(lambda s, u, p, t: prob.objective(zcat(s, u)),
+                                             lambda s, u, p, t: prob.gradient(zcat(s, u)),
+                                             lambda s, u, p, t: prob.objective_hessian())
+
+    class MyBox(nEMPC.constraints.Constraint):      # not the recognised class -> unfused
+        def forward(self, x, u, p=None, tvp=None): return x.reshape(-1).copy()
+        def jacobian(self, x, u, p=None, tvp=None):
+            return np.concatenate([np.eye(x.size), np.zeros((x.size, u.size))], axis=1)
+        def get_dim(self, H): return 2 * H
+        def get_lower_bounds(self, H): return np.full(2 * H, -2.0)
+        def get_upper_bounds(self, H): return np.full(2 * H, 2.0)
+
+    pb = IpoptProblem(d["X0"][0], man, [MyBox()], integ)
+    assert pb._fused is None
+    z = d["Z"][0]
+    np.testing.assert_allclose(pb.objective(z), d["f"][0], **F64)
+    np.testing.assert_allclose(pb.gradient(z), d["grad"][0], **F64)
+    np.testing.assert_allclose(pb.constraints(z), d["g"][0], **F64)
+    np.testing.assert_allclose(pb.jacobian(z), d["jac"][0], **F64)
+    np.testing.assert_array_equal(pb.get_constraint_lower_bounds(), d["cl"])
+
+
+def test_nmpc_next_slsqp_matches_reference_trajectory():
+    """controller.NMPC.next end to end (SLSQP on the CPU drives the device callbacks) against the
+    trajectory the reference produced with the same network, objective, bounds and options."""
+    import pyneuralempc_amd as nEMPC
+    m = dict(np.load(os.path.join(GOLDEN, "misc.npz")))
+    W = [m[f"W{i}"] for i in range(3)]
+    b = [m[f"b{i}"] for i in range(3)]
+    H = int(m["nmpc_H"])
+    model = nEMPC.model.MLPModel(W, b, 2, 1, device="cuda:0")
+    integ = nEMPC.integrator.discret.DiscretIntegrator(model, H)
+    obj = nEMPC.objective.QuadraticObjective(Q=np.eye(2), R=0.1 * np.eye(1), device="cuda:0")
+    dom = nEMPC.constraints.DomainConstraint(states_constraint=[[-5.0, 5.0]] * 2, control_constraint=[[-1.0, 1.0]])
+    opt = nEMPC.optimizer.Slsqp(max_iteration=200, tolerance=1e-10, verbose=0, init_with_last_result=True)
+    mpc = nEMPC.controller.NMPC(integ, obj, [dom], H, 1.0, optimizer=opt)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        states, u = mpc.next(m["nmpc_x0"])
+        np.testing.assert_allclose(states, m["nmpc_states"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(u, m["nmpc_u"], rtol=1e-6, atol=1e-7)
+        states2, u2 = mpc.next(m["nmpc_x1"])      # warm-started second solve
+        np.testing.assert_allclose(states2, m["nmpc_states2"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(u2, m["nmpc_u2"], rtol=1e-6, atol=1e-7)
+    assert np.abs(integ.forward(states, u, m["nmpc_x0"])).max() < 1e-8
+
+
+def test_ipopt_optimizer_fails_loudly_without_cyipopt():
+    import pyneuralempc_amd as nEMPC
+    try:
+        import cyipopt  # noqa: F401
+        pytest.skip("cyipopt installed")
+    except ImportError:
+        pass
+    d, W, b = load_case("c1_discret")
+    integ = _integrator(d, W, b)
+    obj = nEMPC.objective.QuadraticObjective(device="cuda:0")
+    dom = nEMPC.constraints.DomainConstraint([[-5, 5]] * 2, [[-1, 1]])
+    mpc = nEMPC.controller.NMPC(integ, obj, [dom], 10, 1.0)
+    assert isinstance(mpc.optimizer, nEMPC.optimizer.Ipopt)
+    with pytest.raises(ImportError, match="cyipopt"):
+        mpc.next(d["X0"][0])

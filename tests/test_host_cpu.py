@@ -1,0 +1,152 @@
+"""CPU: host-side logic of the plug-in surface (no device work)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def misc():
+    return dict(np.load(os.path.join(GOLDEN, "misc.npz")))
+
+
+def test_start_vectors_match_reference(misc):
+    from pyneuralempc_amd.optimizer.base import cold_start, warm_start_shift
+    H = int(misc["nmpc_H"])
+    np.testing.assert_array_equal(cold_start(misc["nmpc_x0"], H, 1), misc["cold_init"])
+    np.testing.assert_array_equal(warm_start_shift(misc["nmpc_prev"], H, 2, 1), misc["warm_from_first"])
+
+
+def test_domain_constraint_bounds_match_reference(misc):
+    from pyneuralempc_amd.constraints import DomainConstraint
+    dc = DomainConstraint(states_constraint=[[-np.inf, 1.0], [-2.0, np.inf]], control_constraint=[[-1.0, 0.2]])
+    np.testing.assert_array_equal(np.array(dc.get_lower_bounds(5)), misc["dom_lb"])
+    np.testing.assert_array_equal(np.array(dc.get_upper_bounds(5)), misc["dom_ub"])
+    assert dc.get_dim(5) == (2, 1)
+    with pytest.raises(ValueError):
+        DomainConstraint([], [[0, 1]])
+    with pytest.raises(ValueError):
+        DomainConstraint([[0, 1]], [])
+    with pytest.raises(ValueError):
+        DomainConstraint([[0, 1, 2]], [[0, 1]])
+
+
+def test_constraint_types():
+    from pyneuralempc_amd.constraints import (BoxStateConstraint, Constraint, EqualityConstraint,
+                                              InequalityConstraint)
+
+    class E(EqualityConstraint):
+        def get_dim(self, H): return 3 * H
+
+    class I(InequalityConstraint):
+        def get_dim(self, H): return H
+
+    assert E().get_type(4) == Constraint.EQ_TYPE and len(E().get_lower_bounds(4)) == 12
+    assert I().get_type(4) == Constraint.INEQ_TYPE and np.all(np.isinf(I().get_upper_bounds(4)))
+    box = BoxStateConstraint(-2.0, 2.0, x_dim=2)
+    assert box.get_type(5) == Constraint.INTER_TYPE and box.get_dim(5) == 10
+    x, u = np.arange(10.0).reshape(5, 2), np.zeros((5, 1))
+    np.testing.assert_array_equal(box.forward(x, u), x.ravel())
+    J = box.jacobian(x, u)
+    assert J.shape == (10, 15) and np.array_equal(J[:, :10], np.eye(10)) and not J[:, 10:].any()
+    assert box.hessian(x, u).shape == (10, 15, 15)
+    with pytest.raises(ValueError):
+        BoxStateConstraint(-1.0, 1.0)
+
+
+def test_factory_and_controller_contract():
+    from pyneuralempc_amd.constraints import DomainConstraint
+    from pyneuralempc_amd.controller import MPC, NMPC
+    from pyneuralempc_amd.optimizer import Optimizer, Slsqp
+    from pyneuralempc_amd.optimizer.base import ProblemFactory
+    assert MPC is NMPC and Optimizer.SUCCESS == 0 and Optimizer.FAIL == 1
+    f = ProblemFactory()
+    with pytest.raises(RuntimeError, match="x0 is missing"):
+        f.getProblemInterface()
+    f.set_x0(np.zeros(2))
+    with pytest.raises(RuntimeError, match="objective is missing"):
+        f.getProblemInterface()
+
+    class FakeModel:
+        x_dim, u_dim, p_dim, tvp_dim = 2, 1, 0, 0
+
+    class FakeIntegrator:
+        model, H = FakeModel(), 3
+
+    dom = DomainConstraint([[-1, 1]] * 2, [[-1, 1]])
+    lst = [dom]
+    mpc = NMPC(FakeIntegrator(), object(), lst, 3, 1.0, optimizer=Slsqp())
+    assert lst == [] and mpc.domain_constraint is dom       # reference behaviour: list is mutated
+    with pytest.raises(AssertionError, match="x0 must be a vector"):
+        mpc.next(np.zeros((1, 2)))
+    with pytest.raises(AssertionError, match="x0 dim"):
+        mpc.next(np.zeros(3))
+    with pytest.raises(AssertionError, match="both init values"):
+        mpc.next(np.zeros(2), init_x=np.zeros((3, 2)))
+    with pytest.raises(IndexError):
+        NMPC(FakeIntegrator(), object(), [], 3, 1.0, optimizer=Slsqp())
+
+
+def test_keras_adapter_validation_without_device():
+    from pyneuralempc_amd.model.tensorflow import KerasTFModel, extract_dense_stack
+
+    def tanh(x): return x
+
+    def linear(x): return x
+
+    def relu(x): return x
+
+    class Layer:
+        def __init__(self, w, b, act): self.w, self.b, self.activation = w, b, act
+        def get_weights(self): return [self.w, self.b]
+
+    class Fake:
+        def __init__(self, layers, nin, nout):
+            self.layers, self.input_shape, self.output_shape = layers, (None, nin), (None, nout)
+
+    good = Fake([Layer(np.ones((3, 8)), np.zeros(8), tanh), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2)
+    W, b = extract_dense_stack(good)
+    assert [w.shape for w in W] == [(3, 8), (8, 2)]
+    m = KerasTFModel(good, x_dim=2, u_dim=1)
+    assert (m.x_dim, m.u_dim, m.p_dim, m.tvp_dim) == (2, 1, 0, 0)
+    m2 = pickle.loads(pickle.dumps(m))
+    assert m2._row_engine is None and np.array_equal(m2.weights[0], m.weights[0])
+    with pytest.raises(ValueError, match="output dim"):
+        KerasTFModel(good, x_dim=3, u_dim=1)
+    with pytest.raises(ValueError, match="input dim"):
+        KerasTFModel(good, x_dim=2, u_dim=2)
+    with pytest.raises(NotImplementedError):
+        KerasTFModel(good, x_dim=2, u_dim=1, standardScaler=object())
+    bad = Fake([Layer(np.ones((3, 8)), np.zeros(8), relu), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2)
+    with pytest.raises(NotImplementedError, match="activation"):
+        KerasTFModel(bad, x_dim=2, u_dim=1)
+    rnn = Fake(good.layers, 3, 2)
+    rnn.input_shape = (None, 5, 3)
+    with pytest.raises(NotImplementedError, match="Recurrent"):
+        KerasTFModel(rnn, x_dim=2, u_dim=1)
+
+
+def test_integrator_rejects_foreign_models():
+    from pyneuralempc_amd.integrator import DiscretIntegrator
+    from pyneuralempc_amd.model.base import Model
+    with pytest.raises(ValueError):
+        DiscretIntegrator(object(), 5)
+    with pytest.raises(NotImplementedError):
+        DiscretIntegrator(Model(2, 1), 5)
+
+
+def test_quadratic_objective_host_side():
+    from pyneuralempc_amd.objective import ManualObjectifFunc, QuadraticObjective
+    q = QuadraticObjective(Q=[[1.0, 0.5], [0.0, 2.0]], R=[[0.3]])
+
+    class M:
+        x_dim, u_dim = 2, 1
+    Hm = q.hessian(np.zeros((3, 2)), np.zeros((3, 1)))
+    assert Hm.shape == (9, 9) and np.allclose(Hm[:2, :2], [[2.0, 0.5], [0.5, 4.0]]) and np.isclose(Hm[6, 6], 0.6)
+    S = q.hessianstructure(3, M())
+    assert np.array_equal(S != 0, Hm != 0)
+    man = ManualObjectifFunc(lambda s, u, p, t: 1.0, lambda s, u, p, t: np.zeros(3), lambda s, u, p, t: np.eye(3))
+    assert man.forward(None, None) == 1.0 and man.hessian(None, None).shape == (3, 3)

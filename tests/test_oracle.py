@@ -139,3 +139,17 @@ def test_jacobian_and_gradient_vs_finite_differences():
         gfd[j] = (prob.objective(z + e) - prob.objective(z - e)) / (2 * eps)
     assert np.abs(J - Jfd).max() < 1e-8
     assert np.abs(gr - gfd).max() < 1e-7
+
+
+@pytest.mark.parametrize("name", ["c2_discret", "c2_unity", "c3_rk4", "c5_box", "odd_dims", "h1"])
+def test_c_oracle_matches_numpy_oracle(name):
+    from oracle.c_oracle import COracle
+    d, W, b = load_case(name)
+    prob = oracle_problem(d, W, b)
+    Z, X0 = orc.synthetic_inputs(5, prob.H, prob.nx, prob.nu, seed=21)
+    f, grad, g, jac = prob.eval_batch(Z, X0)
+    cf, cgrad, cg, cjac = COracle(prob).eval(Z, X0)
+    np.testing.assert_allclose(cf, f, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(cgrad, grad, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(cg, g, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(cjac, jac, rtol=1e-11, atol=1e-12)
