@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: the config's)")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "valu", "mfma"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "valu", "mfma", "mfma_tile"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 

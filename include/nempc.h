@@ -59,7 +59,9 @@ extern "C" {
 /* row-kernel implementation */
 #define NEMPC_KERNEL_AUTO 0
 #define NEMPC_KERNEL_VALU 1 /* generic thread-per-row kernel, any dims */
-#define NEMPC_KERNEL_MFMA 2 /* matrix-core kernel, padded hidden width in {32,64,128}, <=3 hidden layers */
+#define NEMPC_KERNEL_MFMA 2 /* matrix-core kernels, padded hidden width in {32,64,128}, <=3 hidden layers:
+                               CU-cooperative kernel when the packed weights fit in LDS, else wave-per-tile */
+#define NEMPC_KERNEL_MFMA_TILE 3 /* force the wave-per-tile matrix-core kernel (A/B measurements) */
 
 typedef struct nempc_handle_s* nempc_handle;
 
@@ -130,7 +132,7 @@ int nempc_hess(nempc_handle h, int32_t B, const void* Z, const void* X0, const v
 
 int nempc_sync(nempc_handle h, void* stream);
 
-/* which row kernel the handle resolved to (NEMPC_KERNEL_VALU | NEMPC_KERNEL_MFMA) */
+/* which row kernel the handle resolved to (NEMPC_KERNEL_VALU | NEMPC_KERNEL_MFMA | NEMPC_KERNEL_MFMA_TILE) */
 int nempc_kernel_variant(nempc_handle h);
 
 const char* nempc_last_error(void);

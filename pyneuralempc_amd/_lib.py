@@ -10,8 +10,8 @@ ABI_VERSION = 1
 MAX_LAYERS = 8
 F64, F32 = 0, 1
 DISCRET, UNITY, RK4 = 0, 1, 2
-KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA = 0, 1, 2
-KERNEL_NAMES = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA}
+KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_TILE = 0, 1, 2, 3
+KERNEL_NAMES = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA, "mfma_tile": KERNEL_MFMA_TILE}
 INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
 
 EXPORTS = ["nempc_create", "nempc_destroy", "nempc_set_weights", "nempc_set_objective", "nempc_set_box_rows",

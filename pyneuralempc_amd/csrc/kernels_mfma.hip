@@ -126,6 +126,7 @@ int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, v
     p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
     p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
     p.scratch_per_wave = (scratch_elems(h) + 1) & ~1;
+    p.dbg = h.d_dbg;
     return h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
 }
 

@@ -43,7 +43,25 @@ struct MfmaParams {
     void* tiles;
     int ntiles;
     int scratch_per_wave;  // elements
+    long long* dbg;        // diagnostic builds only (-DNEMPC_STAMPS): per-wave phase stamps of workgroup 0
 };
+
+// In-kernel stamps exist only in the diagnostic library built by tools/diag_stamps.py; the shipped
+// kernels contain none.
+#ifdef NEMPC_STAMPS
+#define NEMPC_STAMP(idx)                                                                   \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        unsigned long long _t;                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (p.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) p.dbg[(threadIdx.x >> 6) * 64 + (idx)] = (long long)_t; \
+    } while (0)
+#else
+#define NEMPC_STAMP(idx) \
+    do {                 \
+    } while (0)
+#endif
 
 // tanh for the row kernels.  ocml's tanh(double) costs ~670 cycles per wave-instruction on gfx950
 // (tools/ubench_f64.hip); the form below, t = 1 - 2 / (exp(2|x|) + 1) with a degree-13 polynomial
@@ -115,6 +133,30 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup-cooperative copy of the packed blob into LDS: 16-byte loads, eight in flight per lane.
+// (A scalar element-per-iteration loop serialises ~40 dependent L2 round trips per launch, which
+// measured as ~15 us of the first version's 41 us.)  n_elems is a multiple of 16.
+template <typename T>
+__device__ __forceinline__ void copy_blob_to_lds(const T* __restrict__ g, T* l, int n_elems, int tid, int nthreads) {
+    typedef T vec __attribute__((ext_vector_type(16 / sizeof(T))));
+    const vec* __restrict__ gs = reinterpret_cast<const vec*>(g);
+    vec* ls = reinterpret_cast<vec*>(l);
+    const int nvec = n_elems / (int)(16 / sizeof(T));
+    for (int i = tid; i < nvec; i += nthreads * 8) {
+        vec tmp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = i + u * nthreads;
+            if (idx < nvec) tmp[u] = gs[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = i + u * nthreads;
+            if (idx < nvec) ls[idx] = tmp[u];
+        }
+    }
+}
+
 // acc[mo] += sum over k-steps (mt, r) of  W-fragment[(mt*4+r)*MO + mo] x bop[mt][r]
 // Fragments are lane-linear (64 elements each).  LDS-resident weights: plain loop, the compiler
 // schedules the ds_reads.  Global (L2) weights: explicit one-step-ahead prefetch fenced by
@@ -171,7 +213,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
     const T* wsrc;
     T* scratch;
     if (WLDS) {
-        for (int i = threadIdx.x; i < p.off.total; i += blockDim.x) lds[i] = gblob[i];
+        copy_blob_to_lds<T>(gblob, lds, p.off.total, threadIdx.x, blockDim.x);
         __syncthreads();
         wsrc = lds;
         scratch = lds + ((p.off.total + 1) & ~1) + wave * p.scratch_per_wave;

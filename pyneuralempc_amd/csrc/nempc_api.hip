@@ -246,7 +246,7 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
     for (int l = 0; l < cfg->n_layers; ++l)
         if (cfg->widths[l] < 1) return fail(NEMPC_EINVAL, "nempc_create: layer width must be >= 1");
     if (cfg->max_batch < 1) return fail(NEMPC_EINVAL, "nempc_create: max_batch must be >= 1");
-    if (cfg->kernel < NEMPC_KERNEL_AUTO || cfg->kernel > NEMPC_KERNEL_MFMA)
+    if (cfg->kernel < NEMPC_KERNEL_AUTO || cfg->kernel > NEMPC_KERNEL_MFMA_TILE)
         return fail(NEMPC_EINVAL, "nempc_create: bad kernel selector");
     if (cfg->integrator == NEMPC_RK4 && !(cfg->DT > 0.0)) return fail(NEMPC_EINVAL, "nempc_create: RK4 needs DT > 0");
     int ndev = 0;
@@ -270,12 +270,12 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
         if (l < h->nl - 1 && h->dout[l] > h->maxw) h->maxw = h->dout[l];
     }
     h->variant = NEMPC_KERNEL_VALU;
-    if (cfg->kernel == NEMPC_KERNEL_MFMA) {
+    if (cfg->kernel == NEMPC_KERNEL_MFMA || cfg->kernel == NEMPC_KERNEL_MFMA_TILE) {
         if (!mfma_supported(*h)) {
             delete h;
             return fail(NEMPC_EUNSUPPORTED, "nempc_create: MFMA row kernel does not cover these layer dims");
         }
-        h->variant = NEMPC_KERNEL_MFMA;
+        h->variant = cfg->kernel;
     } else if (cfg->kernel == NEMPC_KERNEL_AUTO && mfma_supported(*h)) {
         h->variant = NEMPC_KERNEL_MFMA;
     }
@@ -338,7 +338,7 @@ int nempc_set_weights(nempc_handle hh, const double* const* W, const double* con
         if ((rc = upload(h, wt, h.d_Wt[l]))) return rc;
         if ((rc = upload(h, bb, h.d_b[l]))) return rc;
     }
-    if (h.variant == NEMPC_KERNEL_MFMA) {
+    if (h.variant != NEMPC_KERNEL_VALU) {
         int rc = mfma_pack_weights(h, W, b);
         if (rc) return rc;
     }
@@ -440,7 +440,7 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
     if (need_rows) {
         void* tiles = jac_tiles ? jac_tiles : h.d_tiles_ws;
         void* gout = g ? g : h.d_g_ws;
-        rc = h.variant == NEMPC_KERNEL_MFMA ? launch_rows_mfma(h, B, Z, X0, gout, tiles, s)
+        rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, gout, tiles, s)
                                             : launch_rows_valu(h, B, Z, X0, gout, tiles, s);
         if (rc) return rc;
         if (jac_dense && (rc = launch_assemble_dense(h, B, tiles, jac_dense, s))) return rc;
@@ -477,6 +477,22 @@ int nempc_sync(nempc_handle hh, void* stream) {
     NEMPC_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
     return NEMPC_OK;
 }
+
+#ifdef NEMPC_STAMPS
+// diagnostic library only (tools/diag_stamps.py): allocate / read the stamp buffer (16 waves x 64 stamps)
+int nempc_debug_stamps(nempc_handle hh, long long* host_out) {
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    DeviceGuard dg(h.cfg.device);
+    if (!h.d_dbg) {
+        NEMPC_HIP(hipMalloc((void**)&h.d_dbg, sizeof(long long) * 1024));
+        NEMPC_HIP(hipMemset(h.d_dbg, 0, sizeof(long long) * 1024));
+        return NEMPC_OK;
+    }
+    NEMPC_HIP(hipDeviceSynchronize());
+    NEMPC_HIP(hipMemcpy(host_out, h.d_dbg, sizeof(long long) * 1024, hipMemcpyDeviceToHost));
+    return NEMPC_OK;
+}
+#endif
 
 int nempc_kernel_variant(nempc_handle hh) {
     if (!hh) return fail(NEMPC_EINVAL, "nempc_kernel_variant: null handle");

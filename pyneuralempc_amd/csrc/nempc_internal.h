@@ -70,6 +70,7 @@ struct Handle {
     void* d_valu_ws = nullptr;   // scratch of the generic row kernel
     size_t valu_ws_elems = 0;
     void* d_hess_ws = nullptr;   // (Bmax,H,nin,nin) per-row Lagrangian blocks
+    long long* d_dbg = nullptr;  // diagnostic builds only
 };
 
 struct ObjOffsets {  // element offsets into Handle::d_obj

@@ -119,7 +119,7 @@ class CallbackEngine:
     @property
     def kernel_variant(self):
         v = self.lib.nempc_kernel_variant(self._handle)
-        return {_lib.KERNEL_VALU: "valu", _lib.KERNEL_MFMA: "mfma"}[v]
+        return {_lib.KERNEL_VALU: "valu", _lib.KERNEL_MFMA: "mfma", _lib.KERNEL_MFMA_TILE: "mfma_tile"}[v]
 
     # ------------------------------------------------------------------ parameters
     def set_objective(self, Q=None, R=None, xref=None, uref=None, cx=None, cu=None):

@@ -34,7 +34,7 @@ def _f32_close(a, b, what):
 ALL = ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+@pytest.mark.parametrize("kernel", ["valu", "mfma", "mfma_tile"])
 @pytest.mark.parametrize("name", CASE_NAMES)
 def test_golden_fp64(name, kernel):
     d, W, b = load_case(name)
@@ -59,7 +59,7 @@ def test_golden_fp64(name, kernel):
     np.testing.assert_array_equal(cu, d["cu_bound"])
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+@pytest.mark.parametrize("kernel", ["valu", "mfma", "mfma_tile"])
 @pytest.mark.parametrize("name", ["c2_discret", "c3_rk4", "c3_discret", "c5_box", "odd_dims"])
 def test_golden_fp32(name, kernel):
     d, W, b = load_case(name)
@@ -100,7 +100,7 @@ def test_rk4_hessian_is_refused_loudly():
         eng.hess(Z, X0, eng.to_device(d["lam"]), eng.to_device(d["sigma"]))
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma"])
+@pytest.mark.parametrize("kernel", ["valu", "mfma", "mfma_tile"])
 @pytest.mark.parametrize("cfg", [
     # (nx, nu, hidden, H, kind, DT, box, B)   B*H deliberately not a multiple of 16
     (2, 1, [64, 64], 20, orc.DISCRET, 1.0, None, 37),
@@ -122,7 +122,7 @@ def test_against_oracle_seeded_fp64(cfg, kernel):
         eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=KIND_NAME[kind], DT=DT, dtype=torch.float64,
                              device="cuda:0", max_batch=B, kernel=kernel)
     except NempcError:
-        assert kernel == "mfma" and nx + nu > 16   # documented shape gate of the matrix-core kernel
+        assert kernel.startswith("mfma") and nx + nu > 16   # documented shape gate of the matrix-core kernel
         return
     if box is not None:
         eng.set_box_rows(*box)
@@ -161,11 +161,12 @@ def test_full_size_properties_c2():
     net = orc.MLP.random(3, [64, 64], 2, seed=0)
     from pyneuralempc_amd import CallbackEngine
     engs = {k: CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B, kernel=k)
-            for k in ("valu", "mfma")}
+            for k in ("valu", "mfma", "mfma_tile")}
     Z, X0 = orc.synthetic_inputs(B, H, nx, nu, seed=1)
     r = {k: {kk: v.copy() for kk, v in e.eval_numpy(Z, X0, want=ALL).items()} for k, e in engs.items()}
     for k in ("f", "grad", "g", "jac_dense"):
         np.testing.assert_allclose(r["mfma"][k], r["valu"][k], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(r["mfma_tile"][k], r["valu"][k], rtol=1e-12, atol=1e-12)
     rows, cols = engs["mfma"].jac_structure()
     mask = np.zeros((40, 60), dtype=bool)
     mask[rows, cols] = True
