@@ -35,7 +35,7 @@ MfmaOffsets make_offsets(int wp, int nh, int ks, int nx) {
 
 int scratch_elems(const Handle& h) {
     const int nx = h.cfg.nx, nin = h.nin;
-    return 16 * nin + 2 * 16 * nx + 4 * 16 * nx * nin;
+    return 16 * nin + 2 * 16 * nx + 4 * 16 * nx * nin + 16 * nx;  // last 16*nx: x_t slot of the cooperative kernel
 }
 
 }  // namespace
@@ -124,6 +124,7 @@ int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, v
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
     p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
+    
     p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
     p.scratch_per_wave = (scratch_elems(h) + 1) & ~1;
     p.dbg = h.d_dbg;

@@ -37,12 +37,13 @@ if __name__ == "__main__":
     eng.lib.nempc_debug_stamps(eng._handle, None)
     Z, X0 = orc.synthetic_inputs(B, 20, 2, 1, seed=1)
     Z, X0 = eng.to_device(Z), eng.to_device(X0)
+    want = ("g", "jac_dense") if (len(sys.argv) > 3 and sys.argv[3] == "dense") else ("g", "jac_tiles")
     for _ in range(3):
-        eng.eval(Z, X0, ("g", "jac_tiles"))
+        eng.eval(Z, X0, want)
     buf = np.zeros(1024, dtype=np.int64)
     eng.lib.nempc_debug_stamps(eng._handle, buf.ctypes.data_as(ctypes.c_void_p))
     st = buf.reshape(16, 64)
     for w in range(8):
-        s = st[w][:12]
+        s = st[w][:13]
         if s[0] == 0: continue
-        print(f"wave {w}: t0..: " + " ".join(f"{int(b - a):>7d}" for a, b in zip(s[:-1], s[1:]) if b and a) + f"   (stamps 0..9; total {int(s[9]-s[0])})")
+        print(f"wave {w}: " + " ".join(f"{i}:{int(s[i + 1] - s[i]):>6d}" for i in range(12) if s[i] and s[i + 1]) + f"   total {int(s[12]-s[0])}")
