@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: the config's)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "valu", "mfma", "mfma_tile"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--hessian", action="store_true", help="also time the Lagrangian-Hessian callback (reported apart)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,6 +172,13 @@ def main():
     ai = work["flops"] / work["dense_bytes"]
     ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
 
+    hess_info = None
+    if args.hessian and cfg["integrator"] != "rk4":
+        lam = torch.randn(B, eng.m, dtype=tdtype, device=dev)
+        sig = torch.ones(B, dtype=tdtype, device=dev)
+        t_h = timed(lambda: eng.hess(Z, X0, lam, sig), max(args.steps // 4, 10))
+        hess_info = {"hess_us": t_h * 1e6, "nnz_hess": eng.nnz_hess, "hess_batch_evals_per_s": 1.0 / t_h}
+
     # ---- accuracy vs the CPU oracle on a sample (the metric's second half)
     res = eng.eval(Z[:32].contiguous(), X0[:32].contiguous(), want)
     res = {k: v.to("cpu", torch.float64).numpy() for k, v in res.items()}
@@ -202,6 +210,8 @@ def main():
                                         "frac": ach_gbs / PEAK_HBM_GBS, "bytes_per_eval_dense_contract":
                                             work["dense_bytes"], "eval_us": t_all * 1e6},
         }
+        if hess_info:
+            out["hessian_callback"] = hess_info
         if world == 1 and not args.no_cpu:
             cb, _ = cpu_baseline(cfg)
             out["cpu_baseline"] = cb

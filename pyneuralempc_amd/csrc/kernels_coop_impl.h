@@ -87,6 +87,7 @@ struct CoopCtx {
     T* gout;
     T* tiles;
     int nx, nu, nin, H, n, m, NR, jsz, spt, nstages, ks, kind, box, xt_off, inv_nin;
+    unsigned inv32_jrow, inv32_nx;  // ceil(2^32 / d) for d >= 2: item / d == umulhi(item, inv32) while item * d < 2^32
     size_t R;
     bool rk4;
     T DT;
@@ -330,32 +331,32 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
     COOP_STAMP(9);
     // ---- outputs: compact tiles (16 rows contiguous in memory) and defects
     const T s6 = DT / T(6);
-    {
-        constexpr int ROWS = NT * 16;
-        const int ncol = nx * nin + nx;   // tile columns, then defect columns
-        for (int item = tid; item < ncol * ROWS; item += NTHREADS) {
-            const int col = item / ROWS, idx = item - col * ROWS;
-            const int b = RI[2 * idx], t = RI[2 * idx + 1];
+    // tiles: the pass's NT*16 rows are contiguous in memory -> lanes run over the flat element index (coalesced)
+    const int jrow = nx * nin;
+    for (int item = tid; item < NT * jsz; item += NTHREADS) {
+        const int idx = jrow == 1 ? item : (int)__umulhi((unsigned)item, cx.inv32_jrow), kd = item - idx * jrow;
+        if (RI[2 * idx] >= 0) {
+            const int i = (kd * cx.inv_nin) >> 16, d = kd - i * nin;
+            const T* sj = SCR + (idx >> 4) * spt + 16 * nin + 2 * 16 * nx + (idx & 15) * jrow;
+            const T ident = (d == i && (rk4 || cx.kind == NEMPC_DISCRET)) ? T(1) : T(0);
+            cx.tiles[(size_t)t0 * 16 * jrow + item] = (rk4 ? s6 * sj[2 * jsz + kd] : sj[kd]) + ident;
+        }
+    }
+    // defects: lanes run over (row, state) with the state fastest -> contiguous inside a problem
+    for (int item = tid; item < NT * 16 * nx; item += NTHREADS) {
+        const int idx = nx == 1 ? item : (int)__umulhi((unsigned)item, cx.inv32_nx), i = item - idx * nx;
+        const int b = RI[2 * idx], t = RI[2 * idx + 1];
+        if (b >= 0) {
             const int cc = idx & 15;
-            T* s_xi0 = SCR + (idx >> 4) * spt;
-            if (col < nx * nin) {
-                const int kd = col;
-                const int i = (kd * cx.inv_nin) >> 16, d = kd - i * nin;
-                T* sj = s_xi0 + 16 * nin + 2 * 16 * nx + cc * nx * nin;
-                const T ident = (d == i && (rk4 || cx.kind == NEMPC_DISCRET)) ? T(1) : T(0);
-                const T v = (rk4 ? s6 * sj[2 * jsz + kd] : sj[kd]) + ident;
-                if (cx.tiles && b >= 0) cx.tiles[((size_t)t0 * 16 + idx) * nx * nin + kd] = v;
-            } else if (b >= 0) {
-                const int i = col - nx * nin;
-                const T* sk = s_xi0 + 16 * nin;
-                const T xp = s_xi0[cc * nin + i];
-                T phi;
-                if (rk4) phi = xp + s6 * sk[16 * nx + cc * nx + i];
-                else phi = (cx.kind == NEMPC_DISCRET ? xp : T(0)) + sk[cc * nx + i];
-                const T xt = s_xi0[cx.xt_off + cc * nx + i];
-                cx.gout[(size_t)b * cx.m + t * nx + i] = phi - xt;
-                if (cx.box) cx.gout[(size_t)b * cx.m + (size_t)H * nx + t * nx + i] = xt;
-            }
+            const T* s_xi0 = SCR + (idx >> 4) * spt;
+            const T* sk = s_xi0 + 16 * nin;
+            const T xp = s_xi0[cc * nin + i];
+            T phi;
+            if (rk4) phi = xp + s6 * sk[16 * nx + cc * nx + i];
+            else phi = (cx.kind == NEMPC_DISCRET ? xp : T(0)) + sk[cc * nx + i];
+            const T xt = s_xi0[cx.xt_off + cc * nx + i];
+            cx.gout[(size_t)b * cx.m + t * nx + i] = phi - xt;
+            if (cx.box) cx.gout[(size_t)b * cx.m + (size_t)H * nx + t * nx + i] = xt;
         }
     }
     __syncthreads();
@@ -411,6 +412,8 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams
     cx.jsz = 16 * p.nx * p.nin;
     cx.spt = p.scratch_per_wave;
     cx.xt_off = 16 * p.nin + 2 * 16 * p.nx + 4 * cx.jsz;  // after the wave-tile kernel's carve-up
+    cx.inv32_jrow = (unsigned)((0x100000000ull + (unsigned)(p.nx * p.nin) - 1) / (unsigned)(p.nx * p.nin));
+    cx.inv32_nx = (unsigned)((0x100000000ull + (unsigned)p.nx - 1) / (unsigned)p.nx);
     cx.inv_nin = (65536 + p.nin - 1) / p.nin;              // kd / nin == (kd * inv_nin) >> 16 for kd < 256
     cx.rk4 = p.kind == NEMPC_RK4;
     cx.nstages = cx.rk4 ? 4 : 1;

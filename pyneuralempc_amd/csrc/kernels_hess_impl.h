@@ -1,0 +1,217 @@
+// Matrix-core kernel for the per-row Lagrangian blocks of the Hessian callback (DISCRET / UNITY):
+//     Hblk[p][d] = d^2 (lambda . f) / d xi_p d xi_d          (nx+nu square per (problem, step) row)
+// i.e. the lambda-contracted form of Model.hessian (model/tensorflow.py:77-109) that
+// IpoptProblem.hessian sums with the multipliers (optimizer/ipopt.py:66-86).
+//
+// Method: forward-over-reverse.  One wave owns a tile of 16 rows (same operand layout as
+// kernels_mfma_impl.h: features on the MFMA M dimension, rows on N, activations never leave registers).
+//   base sweep    a_l (forward), delta_l = d(lambda.f)/d a_l (reverse); kept as
+//                 S1_l = 1 - a_l^2  and  E_l = -2 delta_l a_l      (so that d(delta_l * S1_l) =
+//                 S1_l * d delta_l + E_l * d a_l)
+//   per input p   tangent forward  da_0 = S1_0 * W_0[p,:],  da_l = S1_l * (W_l^T da_{l-1})
+//                 tangent reverse  dcz_{L} = E_L * da_L,  dcz_{l-1} = S1_{l-1} * (W_l dcz_l) + E_{l-1} * da_{l-1}
+//                 column           H[:, p] = W_0 dcz_0        (skinny MFMA, like the Jacobian's last step)
+// MFMA count per tile: base (forward + reverse) + nin * (2 hidden sweeps + 1 skinny), all K >= 16
+// contractions on the matrix cores; the VALU only does the elementwise products.
+// One wave per SIMD (the register budget is ~300 of the 512 unified VGPRs for fp64 2x64).
+#pragma once
+
+#include "kernels_mfma_impl.h"
+
+namespace nempc {
+
+struct HessParams {
+    MfmaParams base;     // blob, offsets, dims, Z, X0 (g/tiles unused)
+    const void* lambda;  // (B, m)
+    void* blocks;        // (B, H, nin, nin)
+    int p0tab, wLb, ksx; // extra blob tables: first-layer rows, output-layer fragments for W_L lambda, ceil(nx/4)
+};
+
+template <typename T, int WP, int NH, bool WLDS>
+__global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
+    using Ops = MfmaOps<T>;
+    using V4 = typename Ops::V4;
+    constexpr int MT = WP / 16;
+    const MfmaParams& p = hp.base;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const T* __restrict__ gblob = static_cast<const T*>(p.blob);
+    const T* wsrc;
+    T* scratch;
+    if (WLDS) {
+        copy_blob_to_lds<T>(gblob, lds, p.off.total, threadIdx.x, blockDim.x);
+        __syncthreads();
+        wsrc = lds;
+        scratch = lds + ((p.off.total + 1) & ~1) + wave * p.scratch_per_wave;
+    } else {
+        wsrc = gblob;
+        scratch = lds + wave * p.scratch_per_wave;
+    }
+    const int nx = p.nx, nu = p.nu, nin = p.nin, H = p.H;
+    const int n = H * nin;
+    const size_t R = (size_t)p.B * H;
+    const T* __restrict__ Z = static_cast<const T*>(p.Z);
+    const T* __restrict__ X0 = static_cast<const T*>(p.X0);
+    const T* __restrict__ lam = static_cast<const T*>(hp.lambda);
+    T* __restrict__ blocks = static_cast<T*>(hp.blocks);
+
+    // per-wave scratch: xi0[16][nin] | lam[16][nx] | Hs[16][nin][nin]
+    T* s_xi0 = scratch;
+    T* s_lam = s_xi0 + 16 * nin;
+    T* s_H = s_lam + 16 * nx;
+
+    for (int tile = blockIdx.x * nwaves + wave; tile < p.ntiles; tile += gridDim.x * nwaves) {
+        const size_t row0 = (size_t)tile * 16;
+        for (int e = lane; e < 16 * (nin + nx); e += 64) {
+            const int cc = e & 15, d = e >> 4;   // d over nin inputs then nx multipliers
+            const size_t r = row0 + cc;
+            T v = T(0);
+            if (r < R) {
+                const int b = (int)((unsigned)r / (unsigned)H), t = (int)((unsigned)r - (unsigned)b * (unsigned)H);
+                const T* z = Z + (size_t)b * n;
+                if (d < nx) v = (t == 0) ? X0[(size_t)b * nx + d] : z[(t - 1) * nx + d];
+                else if (d < nin) v = z[H * nx + t * nu + (d - nx)];
+                else v = lam[(size_t)b * p.m + t * nx + (d - nin)];
+            }
+            if (d < nin) s_xi0[cc * nin + d] = v;
+            else s_lam[cc * nx + (d - nin)] = v;
+        }
+        wave_sync();
+
+        // ---- forward values
+        V4 S1[NH][MT];  // holds a_l first, then 1 - a_l^2
+        {
+            T xin[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int d = 4 * ks + q;
+                xin[ks] = (ks < p.ks && d < nin) ? s_xi0[c * nin + d] : T(0);
+            }
+            const T* bias = wsrc + p.off.bias[0];
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S1[0][mo][r] = bias[(mo * 4 + r) * 4 + q];
+            const T* w = wsrc + p.off.w0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < p.ks) {
+#pragma unroll
+                    for (int mo = 0; mo < MT; ++mo) S1[0][mo] = Ops::mma(w[(ks * MT + mo) * 64 + lane], xin[ks], S1[0][mo]);
+                }
+            }
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S1[0][mo][r] = Ops::tanh_(S1[0][mo][r]);
+        }
+#pragma unroll
+        for (int l = 1; l < NH; ++l) {
+            const T* bias = wsrc + p.off.bias[l];
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S1[l][mo][r] = bias[(mo * 4 + r) * 4 + q];
+            layer_mma<T, MT, MT, WLDS>(wsrc + p.off.wf[l], lane, S1[l - 1], S1[l]);
+#pragma unroll
+            for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) S1[l][mo][r] = Ops::tanh_(S1[l][mo][r]);
+        }
+
+        // ---- base reverse sweep: delta_l, then S1_l = 1 - a_l^2 and E_l = -2 delta_l a_l
+        V4 E[NH][MT];
+        {
+            V4 dl[MT];
+            T lamB[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int d = 4 * ks + q;
+                lamB[ks] = (ks < hp.ksx && d < nx) ? s_lam[c * nx + d] : T(0);
+            }
+            const T* w = wsrc + hp.wLb;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                dl[mt] = V4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    if (ks < hp.ksx) dl[mt] = Ops::mma(w[(ks * MT + mt) * 64 + lane], lamB[ks], dl[mt]);
+            }
+#pragma unroll
+            for (int l = NH - 1; l >= 0; --l) {
+                V4 cz[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const V4 a = S1[l][mt];
+                    const V4 s1 = T(1) - a * a;
+                    E[l][mt] = T(-2) * dl[mt] * a;
+                    S1[l][mt] = s1;
+                    cz[mt] = dl[mt] * s1;
+                }
+                if (l > 0) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) dl[mt] = V4{T(0), T(0), T(0), T(0)};
+                    layer_mma<T, MT, MT, WLDS>(wsrc + p.off.wb[l], lane, cz, dl);
+                }
+            }
+        }
+
+        // ---- one tangent sweep per input direction
+        for (int pd = 0; pd < nin; ++pd) {
+            V4 da[NH][MT];
+            {
+                const T* tab = wsrc + hp.p0tab + pd * MT * 16;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) da[0][mt][r] = S1[0][mt][r] * tab[(mt * 4 + r) * 4 + q];
+            }
+#pragma unroll
+            for (int l = 1; l < NH; ++l) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) da[l][mt] = V4{T(0), T(0), T(0), T(0)};
+                layer_mma<T, MT, MT, WLDS>(wsrc + p.off.wf[l], lane, da[l - 1], da[l]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) da[l][mt] = da[l][mt] * S1[l][mt];
+            }
+            V4 dcz[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) dcz[mt] = E[NH - 1][mt] * da[NH - 1][mt];
+#pragma unroll
+            for (int l = NH - 1; l >= 1; --l) {
+                V4 ddl[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) ddl[mt] = V4{T(0), T(0), T(0), T(0)};
+                layer_mma<T, MT, MT, WLDS>(wsrc + p.off.wb[l], lane, dcz, ddl);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) dcz[mt] = S1[l - 1][mt] * ddl[mt] + E[l - 1][mt] * da[l - 1][mt];
+            }
+            V4 hcol[1] = {V4{T(0), T(0), T(0), T(0)}};
+            layer_mma<T, MT, 1, WLDS>(wsrc + p.off.w0b, lane, dcz, hcol);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = Ops::row(q, r);
+                if (d < nin) s_H[(c * nin + pd) * nin + d] = hcol[0][r];
+            }
+        }
+        wave_sync();
+
+        // ---- output: exactly symmetric blocks (lower triangle mirrored), 16 rows contiguous in memory
+        const int bsz = nin * nin;
+        for (int e = lane; e < 16 * bsz; e += 64) {
+            const int cc = e / bsz, rem = e - cc * bsz;
+            const int a1 = rem / nin, a2 = rem - a1 * nin;
+            const int hi = a1 > a2 ? a1 : a2, lo = a1 > a2 ? a2 : a1;
+            if (row0 + cc < R) blocks[row0 * bsz + e] = s_H[(cc * nin + hi) * nin + lo];
+        }
+        wave_sync();
+    }
+}
+
+template <typename T>
+int launch_rowhess_mfma_typed(const Handle& h, HessParams hp, hipStream_t s);
+
+}  // namespace nempc

@@ -2,7 +2,7 @@
 #include <algorithm>
 #include <cmath>
 
-#include "kernels_mfma_impl.h"
+#include "kernels_hess_impl.h"
 
 namespace nempc {
 
@@ -17,7 +17,7 @@ int padded_width(const Handle& h) {
     return 0;
 }
 
-MfmaOffsets make_offsets(int wp, int nh, int ks, int nx) {
+MfmaOffsets make_offsets(int wp, int nh, int ks, int nx, int nin) {
     const int MT = wp / 16;
     MfmaOffsets o{};
     int p = 0;
@@ -26,6 +26,8 @@ MfmaOffsets make_offsets(int wp, int nh, int ks, int nx) {
     o.wLf = p; p += MT * 4 * 64;
     for (int l = 1; l < nh; ++l) { o.wb[l] = p; p += MT * MT * 4 * 64; }
     o.w0b = p; p += MT * 4 * 64;
+    o.p0tab = p; p += nin * MT * 16;
+    o.wLb = p; p += ((nx + 3) / 4) * MT * 64;
     o.seed = p; p += nx * MT * 16;
     for (int l = 0; l < nh; ++l) { o.bias[l] = p; p += MT * 16; }
     o.biasL = p; p += 16;
@@ -61,7 +63,7 @@ int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b)
     const int nx = h.cfg.nx, nin = h.nin, ks = (nin + 3) / 4, L = h.nl - 1;
     const bool f64 = h.cfg.dtype == NEMPC_F64;
     auto row = [&](int q, int r) { return f64 ? MfmaOps<double>::row(q, r) : MfmaOps<float>::row(q, r); };
-    const MfmaOffsets o = make_offsets(wp, nh, ks, nx);
+    const MfmaOffsets o = make_offsets(wp, nh, ks, nx, nin);
     std::vector<double> blob((size_t)o.total, 0.0);
     auto Wat = [&](int l, int i, int j) -> double {
         return (i < h.din[l] && j < h.dout[l]) ? W[l][(size_t)i * h.dout[l] + j] : 0.0;
@@ -82,10 +84,17 @@ int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b)
                 blob[o.w0b + (mt * 4 + r) * 64 + lane] = (i16 < nin) ? Wat(0, i16, kf) : 0.0;
             }
     }
+    for (int lane = 0; lane < 64; ++lane) {   // W_L as an A operand with M = hidden unit, K = network output
+        const int i16 = lane & 15, kq = lane >> 4;
+        for (int k = 0; k < (nx + 3) / 4; ++k)
+            for (int mt = 0; mt < MT; ++mt)
+                blob[o.wLb + (k * MT + mt) * 64 + lane] = (4 * k + kq < nx) ? Wat(L, 16 * mt + i16, 4 * k + kq) : 0.0;
+    }
     for (int q = 0; q < 4; ++q)
         for (int r = 0; r < 4; ++r) {
             for (int mt = 0; mt < MT; ++mt) {
                 const int f = 16 * mt + row(q, r);
+                for (int pp = 0; pp < nin; ++pp) blob[o.p0tab + pp * MT * 16 + (mt * 4 + r) * 4 + q] = Wat(0, pp, f);
                 for (int k = 0; k < nx; ++k) blob[o.seed + k * MT * 16 + (mt * 4 + r) * 4 + q] = Wat(L, f, k);
                 for (int l = 0; l < nh; ++l) blob[o.bias[l] + (mt * 4 + r) * 4 + q] = (f < h.dout[l]) ? b[l][f] : 0.0;
             }
@@ -120,7 +129,7 @@ int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, v
     MfmaParams p{};
     p.blob = h.mfma.blob;
     p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + 3) / 4;
-    p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx);
+    p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin);
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
     p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
@@ -129,6 +138,29 @@ int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, v
     p.scratch_per_wave = (scratch_elems(h) + 1) & ~1;
     p.dbg = h.d_dbg;
     return h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+}
+
+int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
+                        hipStream_t s) {
+    if (!h.mfma.blob) {
+        set_error("launch_rowhess_mfma: weights not packed");
+        return NEMPC_ESTATE;
+    }
+    HessParams hp{};
+    MfmaParams& p = hp.base;
+    p.blob = h.mfma.blob;
+    p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + 3) / 4;
+    p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin);
+    p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
+    p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
+    p.Z = Z; p.X0 = X0; p.g = nullptr; p.tiles = nullptr;
+    p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
+    p.scratch_per_wave = (16 * h.nin + 16 * h.cfg.nx + 16 * h.nin * h.nin + 1) & ~1;
+    p.dbg = nullptr;
+    hp.lambda = lambda; hp.blocks = blocks;
+    hp.p0tab = p.off.p0tab; hp.wLb = p.off.wLb; hp.ksx = (h.cfg.nx + 3) / 4;
+    return h.cfg.dtype == NEMPC_F64 ? launch_rowhess_mfma_typed<double>(h, hp, s)
+                                    : launch_rowhess_mfma_typed<float>(h, hp, s);
 }
 
 }  // namespace nempc

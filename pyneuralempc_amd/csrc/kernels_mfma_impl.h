@@ -26,6 +26,7 @@ namespace nempc {
 
 struct MfmaOffsets {  // element offsets into the packed blob
     int w0f, wLf, w0b, seed, biasL;
+    int p0tab, wLb;  // Hessian kernel tables: first-layer rows W_0[p,:], output-layer fragments for W_L lambda
     int wf[3], wb[3], bias[3];
     int total;
 };

@@ -443,8 +443,9 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
         rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, gout, tiles, s)
                                             : launch_rows_valu(h, B, Z, X0, gout, tiles, s);
         if (rc) return rc;
-        if (jac_dense && (rc = launch_assemble_dense(h, B, tiles, jac_dense, s))) return rc;
         if (jac_sparse && (rc = launch_assemble_sparse(h, B, tiles, jac_sparse, s))) return rc;
+        if (jac_dense && (f || grad)) return launch_post(h, B, tiles, jac_dense, Z, f, grad, s);
+        if (jac_dense && (rc = launch_assemble_dense(h, B, tiles, jac_dense, s))) return rc;
     }
     if ((f || grad) && (rc = launch_objective(h, B, Z, f, grad, s))) return rc;
     return NEMPC_OK;
@@ -465,7 +466,9 @@ int nempc_hess(nempc_handle hh, int32_t B, const void* Z, const void* X0, const 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
     void* blocks = hblocks ? hblocks : h.d_hess_ws;
-    if ((rc = launch_rowhess_valu(h, B, Z, X0, lambda, blocks, s))) return rc;
+    rc = h.variant != NEMPC_KERNEL_VALU ? launch_rowhess_mfma(h, B, Z, X0, lambda, blocks, s)
+                                        : launch_rowhess_valu(h, B, Z, X0, lambda, blocks, s);
+    if (rc) return rc;
     if (!hvals && !hdense) return NEMPC_OK;
     return launch_assemble_hess(h, B, blocks, sigma, hvals, hdense, s);
 }

@@ -102,11 +102,14 @@ bool mfma_supported(const Handle& h);
 int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b);
 int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s);
 void mfma_free(Handle& h);
+int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
+                        hipStream_t s);
 
 // ---- kernels_post.hip : objective, dense / sparse assembly, hessian assembly
 int launch_objective(Handle& h, int B, const void* Z, void* f, void* grad, hipStream_t s);
 int launch_assemble_dense(Handle& h, int B, const void* tiles, void* jac, hipStream_t s);
 int launch_assemble_sparse(Handle& h, int B, const void* tiles, void* vals, hipStream_t s);
+int launch_post(Handle& h, int B, const void* tiles, void* jac, const void* Z, void* f, void* grad, hipStream_t s);
 int launch_assemble_hess(Handle& h, int B, const void* blocks, const void* sigma, void* hvals, void* hdense,
                          hipStream_t s);
 

@@ -70,10 +70,11 @@ def test_golden_fp32(name, kernel):
     assert np.array_equal(res["jac_dense"] != 0, d["jac"] != 0)
 
 
+@pytest.mark.parametrize("kernel", ["valu", "mfma", "mfma_tile"])
 @pytest.mark.parametrize("name", [n for n in CASE_NAMES if n not in ("c3_rk4", "c2_rk4", "odd_dims", "c3_discret")])
-def test_golden_hessian_fp64(name):
+def test_golden_hessian_fp64(name, kernel):
     d, W, b = load_case(name)
-    eng = _engine(d, W, b, torch.float64, "auto")
+    eng = _engine(d, W, b, torch.float64, kernel)
     Z, X0 = eng.to_device(d["Z"]), eng.to_device(d["X0"])
     lam, sig = eng.to_device(d["lam"]), eng.to_device(d["sigma"])
     out = eng.hess(Z, X0, lam, sig, want=("hvals", "hdense"))
@@ -89,6 +90,31 @@ def test_golden_hessian_fp64(name):
     prob = oracle_problem(d, W, b)
     orows, ocols = prob.hessian_structure()
     assert np.array_equal(rows, orows) and np.array_equal(cols, ocols)
+
+
+@pytest.mark.parametrize("cfg", [(6, 3, [128, 128, 128], 30, 7), (3, 2, [48, 32], 7, 5), (12, 4, [96, 96], 4, 3),
+                                 (2, 1, [64, 64], 50, 40)])
+def test_hessian_against_oracle_seeded(cfg):
+    """Lagrangian-Hessian blocks of the matrix-core kernel vs the oracle (which carries no golden for these
+    shapes: the reference's own integrator Hessian only exists for nx+nu = 3) and vs the generic kernel."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, hidden, H, B = cfg
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=3)
+    prob = orc.Problem(net, H, nx, nu, orc.DISCRET)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=5)
+    lamh = np.random.default_rng(6).normal(size=(B, prob.m))
+    sigh = np.random.default_rng(7).uniform(0.0, 2.0, size=B)
+    dense = {}
+    for kernel in ("mfma", "valu"):
+        eng = CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B, kernel=kernel)
+        out = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lamh), eng.to_device(sigh),
+                       want=("hvals", "hdense"))
+        dense[kernel] = out["hdense"].cpu().numpy()
+        assert np.array_equal(dense[kernel], np.transpose(dense[kernel], (0, 2, 1)))   # exactly symmetric
+    np.testing.assert_allclose(dense["mfma"], dense["valu"], rtol=1e-10, atol=1e-11)
+    for i in range(min(B, 3)):
+        np.testing.assert_allclose(dense["mfma"][i], prob.lagrangian_hessian(Zh[i], X0h[i], lamh[i], sigh[i]),
+                                   rtol=1e-10, atol=1e-11)
 
 
 def test_rk4_hessian_is_refused_loudly():
