@@ -168,7 +168,8 @@ def main():
     work = algorithmic_work(cfg, B, eng.m, eng.n)
     peak_tf = PEAK_F64_TFLOPS if cfg["dtype"] == "f64" else PEAK_F32_TFLOPS
     ach_tf = work["flops"] / t_rows / 1e12
-    ach_gbs = work["dense_bytes"] / t_all / 1e9
+    t_step = wall / args.steps                      # the timed region itself (max over ranks)
+    ach_gbs = work["dense_bytes"] / t_step / 1e9
     ai = work["flops"] / work["dense_bytes"]
     ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
 
@@ -208,8 +209,18 @@ def main():
                          "arithmetic_intensity_dense": ai, "ridge": ridge},
             "roofline_hbm_whole_eval": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": ach_gbs / PEAK_HBM_GBS, "bytes_per_eval_dense_contract":
-                                            work["dense_bytes"], "eval_us": t_all * 1e6},
+                                            work["dense_bytes"], "eval_us": t_step * 1e6, "eval_us_event_loop": t_all * 1e6},
         }
+        # HBM bytes of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+        pmc_file = os.path.join(REPO, "profiles", "r01_c2_b1024_pmc.json")
+        if args.config == "c2" and B == 1024 and eng.kernel_variant == "mfma" and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            for k, v in pmc.items():
+                if k.startswith("rows_coop_kernel") and "hbm_traffic_bytes" in v:
+                    out["roofline"]["traffic"] = v["hbm_traffic_bytes"]
+                    out["roofline"]["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch, profiles/r01_c2_b1024_pmc.json; "
+                                                       "WRITE_SIZE of this kernel's 8-byte stores is uncalibrated "
+                                                       "(algorithmic: 0.51 MB read, 1.3 MB written)")
         if hess_info:
             out["hessian_callback"] = hess_info
         if world == 1 and not args.no_cpu:
