@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for kind in ("fetch", "write", "mfma"):
     for f in glob.glob(f"{src}_{kind}/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            agg[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("nempc::", "").replace("(anonymous namespace)::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("nempc::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, v in agg.items():
     if "copyBuffer" in k:
