@@ -52,12 +52,20 @@ namespace nempc {
 struct CoopLayout {  // element offsets inside dynamic LDS
     int w0f;         // layer-0 fragments          ks * MT * 64
     int tail;        // seed | bias_l | biasL      (off.total - off.seed)
-    int x;           // exchange buffer            TPW * MT * 256
+    int x;           // exchange buffer            2 halves of TPW * MT * 256
+    int xhalf;
     int part;        // partials                   (1+nx) * TPW * MT * NR * 64
     int scratch;     // per-tile scratch           TPW * scratch_per_tile
     int rowinfo;     // (b, t) per tile row as int2  TPW * 16 * 2 ints (stored in T-sized slots)
     int total;
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0): in this kernel
+// that would stall the first barrier on the weight-slice loads (first needed a layer later) and every
+// pass's last barrier on the acknowledgement of its global stores.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 template <typename T>
 __host__ __device__ inline int coop_nr(int nin) {
@@ -87,12 +95,89 @@ struct CoopCtx {
     T* gout;
     T* tiles;
     int nx, nu, nin, H, n, m, NR, jsz, spt, nstages, ks, kind, box, xt_off, inv_nin;
-    unsigned inv32_jrow, inv32_nx;  // ceil(2^32 / d) for d >= 2: item / d == umulhi(item, inv32) while item * d < 2^32
+    unsigned inv32_jrow, inv32_nx;
+    int xhalf;                      // elements per half of the double-buffered exchange area  // ceil(2^32 / d) for d >= 2: item / d == umulhi(item, inv32) while item * d < 2^32
     size_t R;
     bool rk4;
     T DT;
     long long* dbg;
 };
+
+// Inputs of a pass, fetched into registers first (so the loads can be issued ahead of the weight-slice
+// loads: VMEM returns in order) and written to LDS later.  Items = (column, row): columns are the nx+nu
+// network inputs followed by the nx current states x_t; rows are the pass's tile rows.
+template <typename T, int MT, int TPW>
+struct StageRegs {
+    static constexpr int ITEMS = 2;   // covers (nx+nu)+nx <= 2*MT*64/(TPW*16) columns; wider problems stage directly
+    T v[ITEMS];
+    int b[ITEMS], t[ITEMS];
+};
+
+template <typename T, int MT, int TPW>
+__device__ __forceinline__ void stage_load(const CoopCtx<T>& cx, int t0, int nrows, int tid, StageRegs<T, MT, TPW>& sr) {
+    constexpr int ROWS = TPW * 16, NTHREADS = MT * 64;
+    const int ncol = cx.nin + cx.nx;
+#pragma unroll
+    for (int it = 0; it < StageRegs<T, MT, TPW>::ITEMS; ++it) {
+        const int item = tid + it * NTHREADS;
+        const int col = item / ROWS, idx = item - col * ROWS;
+        T v = T(0);
+        int b = -1, t = 0;
+        const size_t r = (size_t)t0 * 16 + idx;
+        if (col < ncol && idx < nrows && r < cx.R) {
+            b = (int)((unsigned)r / (unsigned)cx.H);
+            t = (int)((unsigned)r - (unsigned)b * (unsigned)cx.H);
+            const T* z = cx.Z + (size_t)b * cx.n;
+            if (col < cx.nx) v = (t == 0) ? cx.X0[(size_t)b * cx.nx + col] : z[(t - 1) * cx.nx + col];
+            else if (col < cx.nin) v = z[cx.H * cx.nx + t * cx.nu + (col - cx.nx)];
+            else v = z[t * cx.nx + (col - cx.nin)];
+        }
+        sr.v[it] = v; sr.b[it] = b; sr.t[it] = t;
+    }
+}
+
+template <typename T, int MT, int TPW>
+__device__ __forceinline__ void stage_store(const CoopCtx<T>& cx, int nrows, int tid, const StageRegs<T, MT, TPW>& sr) {
+    constexpr int ROWS = TPW * 16, NTHREADS = MT * 64;
+    const int ncol = cx.nin + cx.nx;
+#pragma unroll
+    for (int it = 0; it < StageRegs<T, MT, TPW>::ITEMS; ++it) {
+        const int item = tid + it * NTHREADS;
+        const int col = item / ROWS, idx = item - col * ROWS;
+        if (col < ncol && idx < nrows) {
+            T* tile = cx.SCR + (idx >> 4) * cx.spt;
+            if (col < cx.nin) tile[(idx & 15) * cx.nin + col] = sr.v[it];
+            else tile[cx.xt_off + (idx & 15) * cx.nx + (col - cx.nin)] = sr.v[it];
+            if (col == 0) { cx.RI[2 * idx] = sr.b[it]; cx.RI[2 * idx + 1] = sr.t[it]; }
+        }
+    }
+}
+
+// Fallback for problems with more input columns than StageRegs holds: load and store in one go.
+template <typename T, int MT, int TPW>
+__device__ __forceinline__ void stage_direct(const CoopCtx<T>& cx, int t0, int nrows, int tid) {
+    constexpr int ROWS = TPW * 16, NTHREADS = MT * 64;
+    const int ncol = cx.nin + cx.nx;
+    for (int item = tid; item < ncol * ROWS; item += NTHREADS) {
+        const int col = item / ROWS, idx = item - col * ROWS;
+        if (idx >= nrows) continue;
+        T v = T(0);
+        int b = -1, t = 0;
+        const size_t r = (size_t)t0 * 16 + idx;
+        if (r < cx.R) {
+            b = (int)((unsigned)r / (unsigned)cx.H);
+            t = (int)((unsigned)r - (unsigned)b * (unsigned)cx.H);
+            const T* z = cx.Z + (size_t)b * cx.n;
+            if (col < cx.nx) v = (t == 0) ? cx.X0[(size_t)b * cx.nx + col] : z[(t - 1) * cx.nx + col];
+            else if (col < cx.nin) v = z[cx.H * cx.nx + t * cx.nu + (col - cx.nx)];
+            else v = z[t * cx.nx + (col - cx.nin)];
+        }
+        T* tile = cx.SCR + (idx >> 4) * cx.spt;
+        if (col < cx.nin) tile[(idx & 15) * cx.nin + col] = v;
+        else tile[cx.xt_off + (idx & 15) * cx.nx + (col - cx.nin)] = v;
+        if (col == 0) { cx.RI[2 * idx] = b; cx.RI[2 * idx + 1] = t; }
+    }
+}
 
 // One pass over NT (compile-time) tiles starting at tile t0.  NT is a template parameter on purpose:
 // with a runtime tile count every per-tile MFMA sat in its own basic block and hipcc copied the whole
@@ -106,6 +191,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
     const int lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
     T* X = cx.X;
+    int xsel = 0;
     T* PART = cx.PART;
     T* SCR = cx.SCR;
     const T* __restrict__ Z = cx.Z;
@@ -115,29 +201,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
     const bool rk4 = cx.rk4;
     const T DT = cx.DT;
 
-    COOP_STAMP(2);
-    // ---- stage inputs xi0[row][d] = [x_{t-1} ; u_t]  (discret.py:22, ipopt.py:20-28); one input column per
-    // wave, lanes over the pass's NT*16 rows; (b,t) of every row is kept in LDS for the epilogue
     int* RI = cx.RI;
-    for (int d = w; d < nin; d += MT) {
-        for (int idx = lane; idx < NT * 16; idx += 64) {
-            const size_t r = (size_t)t0 * 16 + idx;
-            T v = T(0);
-            int b = -1, t = 0;
-            if (r < R) {
-                b = (int)((unsigned)r / (unsigned)H);
-                t = (int)((unsigned)r - (unsigned)b * (unsigned)H);
-                const T* z = Z + (size_t)b * n;
-                if (d < nx) v = (t == 0) ? X0[(size_t)b * nx + d] : z[(t - 1) * nx + d];
-                else v = z[H * nx + t * nu + (d - nx)];
-            }
-            SCR[(idx >> 4) * spt + (idx & 15) * nin + d] = v;
-            if (d == 0) { RI[2 * idx] = b; RI[2 * idx + 1] = t; }
-            if (d < nx)  // x_t for the defect, fetched now so the epilogue has no global load on its path
-                SCR[(idx >> 4) * spt + cx.xt_off + (idx & 15) * nx + d] = (r < R) ? Z[(size_t)b * n + t * nx + d] : T(0);
-        }
-    }
-    __syncthreads();
     COOP_STAMP(3);
 
     for (int stage = 0; stage < cx.nstages; ++stage) {
@@ -171,15 +235,18 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                 for (int r = 0; r < 4; ++r) a[0][j][r] = Ops::tanh_(a[0][j][r]);
         }
         COOP_STAMP(4);
-        // ---- hidden-to-hidden layers
+        // ---- hidden-to-hidden layers.  The exchange buffer has two halves used alternately: a wave may
+        // publish exchange e+1 while a slower wave still reads exchange e; the barrier of e+1 then fences
+        // the readers of e before anyone writes e+2 into the same half.
 #pragma unroll
         for (int l = 1; l < NH; ++l) {
-            __syncthreads();  // X free (previous readers done)
+            X = cx.X + (xsel & 1) * cx.xhalf;
+            ++xsel;
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) X[((j * MT + w) * 4 + r) * 64 + lane] = a[l - 1][j][r];
-            __syncthreads();
+            lds_barrier();
             const T* bias = cx.seed + cx.bias_off[l] + w * 16;
             V4 b0;
 #pragma unroll
@@ -228,12 +295,13 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
             }
 #pragma unroll
             for (int l = NH - 1; l >= 1; --l) {
-                __syncthreads();
+                X = cx.X + (xsel & 1) * cx.xhalf;
+                ++xsel;
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) X[((j * MT + w) * 4 + r) * 64 + lane] = cv[j][r];
-                __syncthreads();
+                lds_barrier();
                 V4 cn[NT];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) cn[j] = V4{T(0), T(0), T(0), T(0)};
@@ -258,7 +326,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
             }
         }
         COOP_STAMP(7);
-        __syncthreads();
+        lds_barrier();
         COOP_STAMP(8);
 
         // ---- reduce the K-split partials: f -> s_k[cc][o], J -> s_J[cc][k][d]; items = (column, row), flat
@@ -281,7 +349,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                 else SCR[j * spt + 16 * nin + 2 * 16 * nx + cc * nx * nin + kd] = v;
             }
         }
-        __syncthreads();
+        lds_barrier();
 
         // ---- RK4 chain rule on the per-tile scratch (rk4.py:147-159)
         if (rk4) {
@@ -310,7 +378,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                         v = fma(sj[(cc * nx + i) * nin + e3], sj[jsz + (cc * nx + e3) * nin + d], v);
                     SCR[j * spt + 16 * nin + 2 * 16 * nx + 3 * jsz + e2] = fma(cdt, v, sj[e2]);
                 }
-                __syncthreads();
+                lds_barrier();
                 for (int e = tid; e < NT * jsz; e += NTHREADS) {
                     const int j = e / jsz, e2 = e - j * jsz;
                     T* sj = SCR + j * spt + 16 * nin + 2 * 16 * nx;
@@ -324,7 +392,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                     sk[16 * nx + e2] = fma(wgt, sk[e2], sk[16 * nx + e2]);
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
     }
 
@@ -359,7 +427,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
             if (cx.box) cx.gout[(size_t)b * cx.m + (size_t)H * nx + t * nx + i] = xt;
         }
     }
-    __syncthreads();
+    lds_barrier();
     COOP_STAMP(11);
 }
 
@@ -375,31 +443,13 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams
     const T* __restrict__ gblob = static_cast<const T*>(p.blob);
     NEMPC_STAMP(0);
 
-    // small tables -> LDS first (their loads are the ones the first barrier has to wait for) ...
-    copy_blob_to_lds<T>(gblob + p.off.w0f, lds + lay.w0f, p.ks * MT * 64, tid, NTHREADS);
-    copy_blob_to_lds<T>(gblob + p.off.seed, lds + lay.tail, p.off.total - p.off.seed, tid, NTHREADS);
-    // ... then this wave's weight slices -> registers (kept for every pass); first needed by hidden layer 1,
-    // so their L2 latency hides under staging and layer 0
-    CoopWeights<T, WP, NH> W;
-#pragma unroll
-    for (int l = 1; l < NH; ++l)
-#pragma unroll
-        for (int i = 0; i < MT * 4; ++i) {
-            W.wf[l - 1][i] = gblob[p.off.wf[l] + (i * MT + w) * 64 + lane];
-            W.wb[l - 1][i] = gblob[p.off.wb[l] + (i * MT + w) * 64 + lane];
-        }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        W.wL[r] = gblob[p.off.wLf + (w * 4 + r) * 64 + lane];
-        W.w0b[r] = gblob[p.off.w0b + (w * 4 + r) * 64 + lane];
-    }
-
     CoopCtx<T> cx;
     cx.w0f = lds + lay.w0f;
     cx.seed = lds + lay.tail;
     for (int l = 0; l < 3; ++l) cx.bias_off[l] = p.off.bias[l] - p.off.seed;
     cx.biasL_off = p.off.biasL - p.off.seed;
     cx.X = lds + lay.x;
+    cx.xhalf = lay.xhalf;
     cx.PART = lds + lay.part;
     cx.SCR = lds + lay.scratch;
     cx.RI = reinterpret_cast<int*>(lds + lay.rowinfo);
@@ -422,23 +472,57 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams
     cx.DT = (T)p.DT;
     cx.dbg = p.dbg;
 
-    // contiguous, balanced range of tiles for this workgroup
-    const int per = p.ntiles / gridDim.x, rem = p.ntiles % gridDim.x;
-    const int t_begin = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
-    const int t_end = t_begin + per + (blockIdx.x < rem ? 1 : 0);
-    __syncthreads();
+    // contiguous, balanced range of tiles for this workgroup (quotient / remainder computed on the host)
+    const int t_begin = blockIdx.x * p.tiles_per_wg + ((int)blockIdx.x < p.tiles_rem ? (int)blockIdx.x : p.tiles_rem);
+    const int t_end = t_begin + p.tiles_per_wg + ((int)blockIdx.x < p.tiles_rem ? 1 : 0);
+
+    // first pass's inputs: loads issued BEFORE the weight-slice loads, consumed (LDS stores) after them
+    StageRegs<T, MT, TPW> sr;
+    int t0 = t_begin;
+    int nact = t_end - t0 < TPW ? t_end - t0 : TPW;
+    const bool early = (cx.nin + cx.nx) * TPW * 16 <= StageRegs<T, MT, TPW>::ITEMS * NTHREADS;
+    if (early) stage_load<T, MT, TPW>(cx, t0, nact * 16, tid, sr);
+    // small tables -> LDS ...
+    copy_blob_to_lds<T>(gblob + p.off.w0f, lds + lay.w0f, p.ks * MT * 64, tid, NTHREADS);
+    copy_blob_to_lds<T>(gblob + p.off.seed, lds + lay.tail, p.off.total - p.off.seed, tid, NTHREADS);
+    // ... then this wave's weight slices -> registers (kept for every pass); first needed by hidden layer 1,
+    // so their latency hides under layer 0 of the first pass
+    CoopWeights<T, WP, NH> W;
+#pragma unroll
+    for (int l = 1; l < NH; ++l)
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) {
+#ifdef NEMPC_EXP_NOWEIGHTS   // timing experiment only: how much of the prologue is the weight fetch
+            W.wf[l - 1][i] = T(1e-3) * T(lane + i);
+            W.wb[l - 1][i] = T(1e-3) * T(lane - i);
+#else
+            W.wf[l - 1][i] = gblob[p.off.wf[l] + (i * MT + w) * 64 + lane];
+            W.wb[l - 1][i] = gblob[p.off.wb[l] + (i * MT + w) * 64 + lane];
+#endif
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        W.wL[r] = gblob[p.off.wLf + (w * 4 + r) * 64 + lane];
+        W.w0b[r] = gblob[p.off.w0b + (w * 4 + r) * 64 + lane];
+    }
     NEMPC_STAMP(1);
 
-    int t0 = t_begin;
     while (t0 < t_end) {
-        const int left = t_end - t0;
-        const int passes_left = (left + TPW - 1) / TPW;
-        const int nact = (left + passes_left - 1) / passes_left;  // even pass sizes, <= TPW
+        if (early) stage_store<T, MT, TPW>(cx, nact * 16, tid, sr);
+        else stage_direct<T, MT, TPW>(cx, t0, nact * 16, tid);
+        lds_barrier();
         if (nact == 1) coop_pass<T, WP, NH, 1>(cx, W, t0, tid);
         if constexpr (TPW >= 2) { if (nact == 2) coop_pass<T, WP, NH, 2>(cx, W, t0, tid); }
         if constexpr (TPW >= 3) { if (nact == 3) coop_pass<T, WP, NH, 3>(cx, W, t0, tid); }
         if constexpr (TPW >= 4) { if (nact == 4) coop_pass<T, WP, NH, 4>(cx, W, t0, tid); }
         t0 += nact;
+#ifdef NEMPC_STAMPS
+        cx.dbg = nullptr;   // diagnostic build: keep the FIRST pass's stamps
+#endif
+        if (t0 < t_end) {
+            nact = t_end - t0 < TPW ? t_end - t0 : TPW;
+            if (early) stage_load<T, MT, TPW>(cx, t0, nact * 16, tid, sr);
+        }
     }
     NEMPC_STAMP(12);
 }

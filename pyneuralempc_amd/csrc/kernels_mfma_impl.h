@@ -43,6 +43,7 @@ struct MfmaParams {
     void* g;
     void* tiles;
     int ntiles;
+    int tiles_per_wg, tiles_rem;  // cooperative kernel: ntiles = grid * tiles_per_wg + tiles_rem
     int scratch_per_wave;  // elements
     long long* dbg;        // diagnostic builds only (-DNEMPC_STAMPS): per-wave phase stamps of workgroup 0
 };

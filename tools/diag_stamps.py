@@ -14,7 +14,7 @@ def build():
     objs = []
     for src in _build.SOURCES:
         o = os.path.join(out, src.replace(".hip", ".o"))
-        subprocess.run([_build._hipcc()] + _build.FLAGS + ["-DNEMPC_STAMPS", "-c", os.path.join(_build.CSRC, src), "-o", o], check=True)
+        subprocess.run([_build._hipcc()] + _build.FLAGS + ["-DNEMPC_STAMPS"] + [f for f in sys.argv if f.startswith("-D")] + ["-c", os.path.join(_build.CSRC, src), "-o", o], check=True)
         objs.append(o)
     lib = os.path.join(out, "libnempc_stamps.so")
     subprocess.run([_build._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)

@@ -116,6 +116,36 @@ __global__ void tanh_acc(const double* in, double* o_ref, double* o_fast, int n)
     }
 }
 
+// do f64 MFMA and f64 VALU overlap on one SIMD?  512 threads = 2 waves per SIMD; waves 0-3 run MFMAs,
+// waves 4-7 run independent v_fma_f64 (mode 0: both, 1: MFMA waves only, 2: VALU waves only)
+__global__ void coexec_f64(double* out, long long* cyc, int iters, int mode) {
+    const int wave = threadIdx.x >> 6;
+    const bool mf = wave < 4;
+    d4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = d4{0, 0, 0, 0};
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4;
+    double v[8];
+    for (int i = 0; i < 8; ++i) v[i] = a + i;
+    long long t0 = clock64();
+    if (mf && mode != 2) {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    } else if (!mf && mode != 1) {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = fma(v[i], b, a);     // 64 DP FMAs per iteration = 256 cycles
+    }
+    long long t1 = clock64();
+    double s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 8; ++i) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0 && (wave == 0 || wave == 4)) cyc[blockIdx.x * 2 + (wave >> 2)] = t1 - t0;
+}
+
 static double median(std::vector<long long>& v) {
     std::sort(v.begin(), v.end());
     return (double)v[v.size() / 2];
@@ -164,6 +194,23 @@ int main() {
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("f32 mfma wall: %d waves/SIMD  %.2f ms  -> %.1f TFLOP/s\n", threads / 256, ms, flops / ms / 1e9);
+    }
+    {
+        long long* dc2;
+        CK(hipMalloc(&dc2, sizeof(long long) * blocks * 2));
+        std::vector<long long> c2(blocks * 2);
+        const char* names[3] = {"both", "mfma waves only", "valu waves only"};
+        for (int mode = 0; mode < 3; ++mode) {
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            hipLaunchKernelGGL(coexec_f64, dim3(blocks), dim3(512), 0, 0, dout, dc2, 100, mode);
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(coexec_f64, dim3(blocks), dim3(512), 0, 0, dout, dc2, 4000, mode);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("coexec f64 [%s]: wall %.3f ms (4000 iters: 16000 MFMAs = 1.02M cycles alone; 256k DP FMAs = 1.02M cycles alone)\n", names[mode], ms);
+        }
     }
     // tanh
     const int n = blocks * 512 * 16;
