@@ -25,7 +25,7 @@ struct NetDev {
 };
 
 struct WsOff {  // slot offsets (multiply by Rcap)
-    int xi, act, cot, fout, jst, kcur, dk, acck, accdk, dkn, P, total;
+    int xi, act, cot, fout, jst, kcur, dk, acck, accdk, dkn, P, rk_xin, rk_J, rk_dk, rk_nu, htmp, htmp2, total;
 };
 
 WsOff ws_offsets(const Handle& h) {
@@ -42,6 +42,13 @@ WsOff ws_offsets(const Handle& h) {
     o.accdk = p; p += h.cfg.nx * h.nin;
     o.dkn = p; p += h.cfg.nx * h.nin;
     o.P = p; p += nhid * h.maxw * h.nin;
+    // RK4 Lagrangian Hessian: per stage input, Jacobian, previous chain Jacobian, stage multiplier; two nin^2 temporaries
+    o.rk_xin = p; p += 4 * h.nin;
+    o.rk_J = p; p += 4 * h.cfg.nx * h.nin;
+    o.rk_dk = p; p += 4 * h.cfg.nx * h.nin;
+    o.rk_nu = p; p += 4 * h.cfg.nx;
+    o.htmp = p; p += h.nin * h.nin;
+    o.htmp2 = p; p += h.nin * h.nin;
     o.total = p;
     return o;
 }
@@ -242,31 +249,18 @@ __global__ __launch_bounds__(256) void rows_valu_kernel(NetDev net, WsOff o, int
         for (int i = 0; i < nx; ++i) g[(size_t)b * m + (size_t)H * nx + t * nx + i] = z[t * nx + i];
 }
 
-// Per-row Lagrangian block  Hblk[p][q] = sum_k lam_k d2 Phi_k / dxi_p dxi_q  for DISCRET / UNITY
-// (Phi = [x +] f, so d2Phi = d2f):   Hblk = sum_l P_l^T diag(delta_l * s''(z_l)) P_l
+// Contracted network Hessian at the input currently held in ws.xi:
+//     hout[p][q] = sum_k mult_k d2 f_k / dxi_p dxi_q  =  sum_l P_l^T diag(delta_l * s''(z_l)) P_l
 // with P_l = W_l^T D_{l-1} the pre-activation tangents (forward mode, nin directions),
-// delta_l = d(lam.f)/d a_l (one reverse sweep) and s'' = -2 a (1 - a^2).
+// delta_l = d(mult . f)/d a_l (one reverse sweep) and s'' = -2 a (1 - a^2).
 // Value-equivalent to model/tensorflow.py:77-109 contracted as in optimizer/ipopt.py:79-80.
+// mult[k * mstride], hout[(p*nin+q) * hstride] (full symmetric block, lower triangle mirrored).
 template <typename T>
-__global__ __launch_bounds__(256) void rowhess_valu_kernel(NetDev net, WsOff o, int B, int H, size_t Rcap,
-                                                           const T* __restrict__ Z, const T* __restrict__ X0,
-                                                           const T* __restrict__ lam, int m,
-                                                           T* __restrict__ blocks, T* __restrict__ ws) {
-    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= (size_t)B * H) return;
-    const int b = (int)(r / H), t = (int)(r % H);
-    const int nx = net.nx, nu = net.nu, nin = net.nin, nl = net.nl;
-    const int n = H * nin;
-    const size_t R = Rcap;
-    const T* z = Z + (size_t)b * n;
-    T* blk = blocks + ((size_t)b * H + t) * nin * nin;
-
-    for (int p = 0; p < nin * nin; ++p) blk[p] = T(0);
+__device__ void net_hessian_contracted(const NetDev& net, T* ws, const WsOff& o, size_t R, size_t r, const T* mult,
+                                       size_t mstride, T* hout, size_t hstride) {
+    const int nx = net.nx, nin = net.nin, nl = net.nl;
+    for (int p = 0; p < nin * nin; ++p) hout[(size_t)p * hstride] = T(0);
     if (nl == 1) return;  // linear network: no curvature
-
-    T* xi = ws + (size_t)o.xi * R;
-    for (int i = 0; i < nx; ++i) xi[(size_t)i * R + r] = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
-    for (int j = 0; j < nu; ++j) xi[(size_t)(nx + j) * R + r] = z[H * nx + t * nu + j];
     net_forward<T>(net, ws, o, R, r);
 
     // forward tangents: P_l[i][p] (pre-activation), stored per hidden layer; D_l = (1-a^2) P_l
@@ -292,7 +286,7 @@ __global__ __launch_bounds__(256) void rowhess_valu_kernel(NetDev net, WsOff o, 
             }
         }
     }
-    // reverse sweep for delta_l = d(lam . f)/d a_l, accumulate the blocks on the way down
+    // reverse sweep for delta_l = d(mult . f)/d a_l, accumulate the block on the way down
     int cur = 0;
     {
         const T* WL = (const T*)net.W[nl - 1];
@@ -300,7 +294,7 @@ __global__ __launch_bounds__(256) void rowhess_valu_kernel(NetDev net, WsOff o, 
         T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;
         for (int j = 0; j < w; ++j) {
             T acc = T(0);
-            for (int k = 0; k < nx; ++k) acc = fma(WL[(size_t)j * nx + k], lam[(size_t)b * m + t * nx + k], acc);
+            for (int k = 0; k < nx; ++k) acc = fma(WL[(size_t)j * nx + k], mult[(size_t)k * mstride], acc);
             c[(size_t)j * R + r] = acc;
         }
     }
@@ -315,7 +309,9 @@ __global__ __launch_bounds__(256) void rowhess_valu_kernel(NetDev net, WsOff o, 
             const T wgt = c[(size_t)j * R + r] * (T(-2) * av * s1);
             for (int p = 0; p < nin; ++p) {
                 const T pp = wgt * P[(size_t)(j * nin + p) * R + r];
-                for (int q = 0; q <= p; ++q) blk[p * nin + q] = fma(pp, P[(size_t)(j * nin + q) * R + r], blk[p * nin + q]);
+                for (int q = 0; q <= p; ++q)
+                    hout[(size_t)(p * nin + q) * hstride] =
+                        fma(pp, P[(size_t)(j * nin + q) * R + r], hout[(size_t)(p * nin + q) * hstride]);
             }
             c[(size_t)j * R + r] *= s1;  // now cot wrt z_l
         }
@@ -332,7 +328,123 @@ __global__ __launch_bounds__(256) void rowhess_valu_kernel(NetDev net, WsOff o, 
         }
     }
     for (int p = 0; p < nin; ++p)
-        for (int q = p + 1; q < nin; ++q) blk[p * nin + q] = blk[q * nin + p];
+        for (int q = p + 1; q < nin; ++q) hout[(size_t)(p * nin + q) * hstride] = hout[(size_t)(q * nin + p) * hstride];
+}
+
+// Per-row Lagrangian block  Hblk = sum_k lam_k d2 Phi_k / d[x_{t-1}|u_t]^2.
+//   DISCRET / UNITY: Phi = [x +] f, so d2Phi = d2f at xi.
+//   RK4 (value-equivalent to rk4.py:181-285, which the reference hard-wires to nx+nu = 3): with stage inputs
+//   xi_s = xi + c_s E k_{s-1}, chain Jacobians dk_s = J_s R_s, R_s = I + c_s [dk_{s-1}; 0] (rk4.py:246-263),
+//       d2(lam.Phi) = sum_s R_s^T ( sum_i nu_s[i] Hf_i(xi_s) ) R_s,
+//   stage multipliers by the adjoint recursion nu_3 = DT/6 lam, nu_{s-1} = DT/6 w_{s-1} lam + c_s J_s[:, :nx]^T nu_s.
+template <typename T>
+__global__ __launch_bounds__(256) void rowhess_valu_kernel(NetDev net, WsOff o, int kind, T DT, int B, int H,
+                                                           size_t Rcap, const T* __restrict__ Z,
+                                                           const T* __restrict__ X0, const T* __restrict__ lam, int m,
+                                                           T* __restrict__ blocks, T* __restrict__ ws) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (size_t)B * H) return;
+    const int b = (int)(r / H), t = (int)(r % H);
+    const int nx = net.nx, nu = net.nu, nin = net.nin;
+    const int n = H * nin;
+    const size_t R = Rcap;
+    const T* z = Z + (size_t)b * n;
+    T* blk = blocks + ((size_t)b * H + t) * nin * nin;
+    const T* lrow = lam + (size_t)b * m + (size_t)t * nx;
+
+    T* xi = ws + (size_t)o.xi * R;
+    for (int i = 0; i < nx; ++i) xi[(size_t)i * R + r] = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
+    for (int j = 0; j < nu; ++j) xi[(size_t)(nx + j) * R + r] = z[H * nx + t * nu + j];
+    if (kind != NEMPC_RK4) {
+        net_hessian_contracted<T>(net, ws, o, R, r, lrow, 1, blk, 1);
+        return;
+    }
+
+    T* fout = ws + (size_t)o.fout * R;
+    T* jst = ws + (size_t)o.jst * R;
+    T* dk = ws + (size_t)o.dk * R;
+    T* dkn = ws + (size_t)o.dkn * R;
+    T* sxin = ws + (size_t)o.rk_xin * R;
+    T* sJ = ws + (size_t)o.rk_J * R;
+    T* sdk = ws + (size_t)o.rk_dk * R;
+    T* snu = ws + (size_t)o.rk_nu * R;
+    const int jn = nx * nin;
+    // ---- forward over the four stages, keeping xi_s, J_s and dk_{s-1}
+    for (int s = 0; s < 4; ++s) {
+        const T c = (s == 0) ? T(0) : ((s == 3) ? DT : T(0.5) * DT);
+        if (s > 0)
+            for (int i = 0; i < nx; ++i) {
+                const T xp = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
+                xi[(size_t)i * R + r] = xp + c * fout[(size_t)i * R + r];   // fout still holds k_{s-1}
+            }
+        for (int d = 0; d < nin; ++d) sxin[(size_t)(s * nin + d) * R + r] = xi[(size_t)d * R + r];
+        net_forward<T>(net, ws, o, R, r);
+        for (int k = 0; k < nx; ++k) net_jacobian_row<T>(net, ws, o, R, r, k);
+        for (int e = 0; e < jn; ++e) {
+            sJ[(size_t)(s * jn + e) * R + r] = jst[(size_t)e * R + r];
+            sdk[(size_t)(s * jn + e) * R + r] = (s == 0) ? T(0) : dk[(size_t)e * R + r];   // dk_{s-1}
+        }
+        if (s == 0) {
+            for (int e = 0; e < jn; ++e) dk[(size_t)e * R + r] = jst[(size_t)e * R + r];
+        } else {
+            for (int i = 0; i < nx; ++i)
+                for (int d = 0; d < nin; ++d) {
+                    T v = T(0);
+                    for (int e = 0; e < nx; ++e)
+                        v = fma(jst[(size_t)(i * nin + e) * R + r], dk[(size_t)(e * nin + d) * R + r], v);
+                    dkn[(size_t)(i * nin + d) * R + r] = jst[(size_t)(i * nin + d) * R + r] + c * v;
+                }
+            for (int e = 0; e < jn; ++e) dk[(size_t)e * R + r] = dkn[(size_t)e * R + r];
+        }
+    }
+    // ---- adjoint recursion for the stage multipliers
+    const T s6 = DT / T(6);
+    for (int i = 0; i < nx; ++i) snu[(size_t)(3 * nx + i) * R + r] = s6 * lrow[i];
+    for (int s = 3; s >= 1; --s) {
+        const T c = (s == 3) ? DT : T(0.5) * DT;
+        const T wprev = (s - 1 == 0) ? T(1) : T(2);
+        for (int j = 0; j < nx; ++j) {
+            T v = T(0);
+            for (int i = 0; i < nx; ++i)
+                v = fma(sJ[(size_t)(s * jn + i * nin + j) * R + r], snu[(size_t)(s * nx + i) * R + r], v);
+            snu[(size_t)((s - 1) * nx + j) * R + r] = s6 * wprev * lrow[j] + c * v;
+        }
+    }
+    // ---- blk = sum_s R_s^T Htilde_s R_s
+    T* ht = ws + (size_t)o.htmp * R;
+    T* ht2 = ws + (size_t)o.htmp2 * R;
+    for (int p = 0; p < nin * nin; ++p) blk[p] = T(0);
+    for (int s = 0; s < 4; ++s) {
+        const T c = (s == 0) ? T(0) : ((s == 3) ? DT : T(0.5) * DT);
+        for (int d = 0; d < nin; ++d) xi[(size_t)d * R + r] = sxin[(size_t)(s * nin + d) * R + r];
+        net_hessian_contracted<T>(net, ws, o, R, r, snu + (size_t)(s * nx) * R + r, R, ht + r, R);
+        if (s == 0) {
+            for (int p = 0; p < nin * nin; ++p) blk[p] += ht[(size_t)p * R + r];
+            continue;
+        }
+        // ht2 = Htilde R ;  R[a][q] = delta_aq + (a < nx ? c dk_{s-1}[a][q] : 0)
+        for (int a = 0; a < nin; ++a)
+            for (int q = 0; q < nin; ++q) {
+                T v = ht[(size_t)(a * nin + q) * R + r];
+                for (int e = 0; e < nx; ++e)
+                    v = fma(ht[(size_t)(a * nin + e) * R + r], c * sdk[(size_t)(s * jn + e * nin + q) * R + r], v);
+                ht2[(size_t)(a * nin + q) * R + r] = v;
+            }
+        for (int p = 0; p < nin; ++p)
+            for (int q = 0; q < nin; ++q) {
+                T v = ht2[(size_t)(p * nin + q) * R + r];
+                for (int e = 0; e < nx; ++e)
+                    v = fma(c * sdk[(size_t)(s * jn + e * nin + p) * R + r], ht2[(size_t)(e * nin + q) * R + r], v);
+                blk[p * nin + q] += v;
+            }
+    }
+    // exact symmetry (the two triangles are rounded differently by the congruence products)
+    for (int p = 0; p < nin; ++p)
+        for (int q = p + 1; q < nin; ++q) {
+            const T v = T(0.5) * (blk[p * nin + q] + blk[q * nin + p]);
+            blk[p * nin + q] = v;
+            blk[q * nin + p] = v;
+        }
 }
 
 NetDev make_netdev(const Handle& h) {
@@ -377,11 +489,13 @@ int launch_rowhess_valu(Handle& h, int B, const void* Z, const void* X0, const v
     NetDev nd = make_netdev(h);
     WsOff o = ws_offsets(h);
     if (h.cfg.dtype == NEMPC_F64)
-        hipLaunchKernelGGL(rowhess_valu_kernel<double>, grid, block, 0, s, nd, o, B, h.cfg.H, Rcap, (const double*)Z,
-                           (const double*)X0, (const double*)lambda, h.m, (double*)blocks, (double*)h.d_valu_ws);
+        hipLaunchKernelGGL(rowhess_valu_kernel<double>, grid, block, 0, s, nd, o, h.cfg.integrator, h.cfg.DT, B, h.cfg.H,
+                           Rcap, (const double*)Z, (const double*)X0, (const double*)lambda, h.m, (double*)blocks,
+                           (double*)h.d_valu_ws);
     else
-        hipLaunchKernelGGL(rowhess_valu_kernel<float>, grid, block, 0, s, nd, o, B, h.cfg.H, Rcap, (const float*)Z,
-                           (const float*)X0, (const float*)lambda, h.m, (float*)blocks, (float*)h.d_valu_ws);
+        hipLaunchKernelGGL(rowhess_valu_kernel<float>, grid, block, 0, s, nd, o, h.cfg.integrator, (float)h.cfg.DT, B,
+                           h.cfg.H, Rcap, (const float*)Z, (const float*)X0, (const float*)lambda, h.m, (float*)blocks,
+                           (float*)h.d_valu_ws);
     NEMPC_HIP(hipGetLastError());
     return NEMPC_OK;
 }

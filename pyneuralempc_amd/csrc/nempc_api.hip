@@ -459,15 +459,15 @@ int nempc_hess(nempc_handle hh, int32_t B, const void* Z, const void* X0, const 
     if (B == 0) return NEMPC_OK;
     if (!Z || !X0 || !lambda || !sigma) return fail(NEMPC_EINVAL, "nempc_hess: null input");
     if (!h.have_weights) return fail(NEMPC_ESTATE, "nempc_hess: call nempc_set_weights first");
-    if (h.cfg.integrator == NEMPC_RK4)
-        return fail(NEMPC_EUNSUPPORTED, "nempc_hess: the RK4 Lagrangian Hessian is not on the device yet");
     DeviceGuard dg(h.cfg.device);
     if (!dg.ok) return fail(NEMPC_EHIP, "nempc_hess: hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
     void* blocks = hblocks ? hblocks : h.d_hess_ws;
-    rc = h.variant != NEMPC_KERNEL_VALU ? launch_rowhess_mfma(h, B, Z, X0, lambda, blocks, s)
-                                        : launch_rowhess_valu(h, B, Z, X0, lambda, blocks, s);
+    // RK4 blocks (four chained stages + adjoint stage multipliers) run on the generic kernel for every variant
+    rc = (h.variant != NEMPC_KERNEL_VALU && h.cfg.integrator != NEMPC_RK4)
+             ? launch_rowhess_mfma(h, B, Z, X0, lambda, blocks, s)
+             : launch_rowhess_valu(h, B, Z, X0, lambda, blocks, s);
     if (rc) return rc;
     if (!hvals && !hdense) return NEMPC_OK;
     return launch_assemble_hess(h, B, blocks, sigma, hvals, hdense, s);

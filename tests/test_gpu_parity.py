@@ -71,7 +71,7 @@ def test_golden_fp32(name, kernel):
 
 
 @pytest.mark.parametrize("kernel", ["valu", "mfma", "mfma_tile"])
-@pytest.mark.parametrize("name", [n for n in CASE_NAMES if n not in ("c3_rk4", "c2_rk4", "odd_dims", "c3_discret")])
+@pytest.mark.parametrize("name", [n for n in CASE_NAMES if n not in ("c3_rk4", "odd_dims", "c3_discret")])
 def test_golden_hessian_fp64(name, kernel):
     d, W, b = load_case(name)
     eng = _engine(d, W, b, torch.float64, kernel)
@@ -117,13 +117,27 @@ def test_hessian_against_oracle_seeded(cfg):
                                    rtol=1e-10, atol=1e-11)
 
 
-def test_rk4_hessian_is_refused_loudly():
-    from pyneuralempc_amd._lib import NempcError
-    d, W, b = load_case("c2_rk4")
-    eng = _engine(d, W, b, torch.float64, "auto")
-    Z, X0 = eng.to_device(d["Z"]), eng.to_device(d["X0"])
-    with pytest.raises(NempcError):
-        eng.hess(Z, X0, eng.to_device(d["lam"]), eng.to_device(d["sigma"]))
+@pytest.mark.parametrize("cfg", [(6, 3, [128, 128, 128], 30, 0.1, 2), (3, 2, [48, 32], 7, 0.05, 5), (2, 1, [64, 64], 20, 0.5, 9),
+                                 (1, 1, [20], 3, 0.2, 4)])
+def test_rk4_hessian_against_oracle(cfg):
+    """RK4 Lagrangian Hessian for general dims (the reference's own RK4Integrator.hessian is hard-wired to
+    nx+nu = 3, rk4.py:246; the golden c2_rk4 case above pins that one, the oracle the rest)."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, hidden, H, DT, B = cfg
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=3)
+    prob = orc.Problem(net, H, nx, nu, orc.RK4, DT)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=5)
+    lamh = np.random.default_rng(6).normal(size=(B, prob.m))
+    sigh = np.random.default_rng(7).uniform(0.0, 2.0, size=B)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator="rk4", DT=DT, dtype=torch.float64, device="cuda:0",
+                         max_batch=B)
+    out = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lamh), eng.to_device(sigh),
+                   want=("hvals", "hdense"))
+    hd = out["hdense"].cpu().numpy()
+    assert np.array_equal(hd, np.transpose(hd, (0, 2, 1)))
+    for i in range(B):
+        np.testing.assert_allclose(hd[i], prob.lagrangian_hessian(Zh[i], X0h[i], lamh[i], sigh[i]),
+                                   rtol=1e-10, atol=1e-11)
 
 
 @pytest.mark.parametrize("kernel", ["valu", "mfma", "mfma_tile"])
