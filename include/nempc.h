@@ -130,6 +130,30 @@ int nempc_eval(nempc_handle h, int32_t B, const void* Z, const void* X0, void* f
 int nempc_hess(nempc_handle h, int32_t B, const void* Z, const void* X0, const void* lambda,
                const void* sigma, void* hvals, void* hdense, void* hblocks, void* stream);
 
+/* Batched on-device solver (no reference counterpart: the reference hands ONE problem at a time to Ipopt /
+ * SLSQP on the CPU, optimizer/ipopt.py:138-195, slsqp.py:143-197).  Solves the B problems
+ *     min f(z)  s.t.  integrator defects = 0,  lb <= z <= ub
+ * in lock step by Gauss-Newton SQP: per iterate one callback evaluation, one Riccati (block-tridiagonal KKT)
+ * solve per problem, l1-merit backtracking; finite variable bounds through a log barrier.
+ *   X0 (B,nx) device; Z (B,n) device: initial guess in, solution out; lb/ub (n) HOST doubles (NULL = unbounded,
+ *   +-INFINITY allowed; the vectors DomainConstraint.get_lower/upper_bounds produce, constraints.py:26-30);
+ *   status (B) device int32 out: 0 converged (Optimizer.SUCCESS), 1 not converged (Optimizer.FAIL);
+ *   *iters (host, optional) outer iterations run.  Synchronises the stream internally (convergence polls).
+ *   Box ROWS (nempc_set_box_rows) are not handled here -- express state bounds as variable bounds. */
+typedef struct nempc_solver_opts {
+    int32_t max_iter;        /* outer iterations, e.g. 200 */
+    int32_t max_linesearch;  /* backtracking halvings per iteration, e.g. 6 */
+    int32_t check_every;     /* host convergence poll period in iterations, e.g. 4 */
+    int32_t reserved;
+    double tol_constraint;   /* max |defect| at convergence, e.g. 1e-8 */
+    double tol_step;         /* max |dz| <= tol_step * (1 + max |z|), e.g. 1e-8 */
+    double mu_init, mu_min, mu_factor; /* barrier schedule, e.g. 1e-1, 1e-9, 0.2 */
+    double reg;              /* initial Levenberg term on the control Hessian, e.g. 1e-9 */
+} nempc_solver_opts;
+
+int nempc_solve(nempc_handle h, int32_t B, const void* X0, void* Z, const double* lb, const double* ub,
+                const nempc_solver_opts* opts, int32_t* status, int32_t* iters, void* stream);
+
 int nempc_sync(nempc_handle h, void* stream);
 
 /* which row kernel the handle resolved to (NEMPC_KERNEL_VALU | NEMPC_KERNEL_MFMA | NEMPC_KERNEL_MFMA_TILE) */

@@ -16,7 +16,7 @@ INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
 
 EXPORTS = ["nempc_create", "nempc_destroy", "nempc_set_weights", "nempc_set_objective", "nempc_set_box_rows",
            "nempc_dims", "nempc_constraint_bounds", "nempc_jac_structure", "nempc_hess_structure", "nempc_eval",
-           "nempc_hess", "nempc_sync", "nempc_kernel_variant", "nempc_last_error", "nempc_abi_version"]
+           "nempc_hess", "nempc_solve", "nempc_sync", "nempc_kernel_variant", "nempc_last_error", "nempc_abi_version"]
 
 
 class NempcError(RuntimeError):
@@ -31,6 +31,13 @@ class NempcConfig(ctypes.Structure):
                 ("nu", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("widths", ctypes.c_int32 * MAX_LAYERS),
                 ("max_batch", ctypes.c_int32), ("kernel", ctypes.c_int32), ("reserved", ctypes.c_int32),
                 ("DT", ctypes.c_double)]
+
+
+class NempcSolverOpts(ctypes.Structure):
+    _fields_ = [("max_iter", ctypes.c_int32), ("max_linesearch", ctypes.c_int32), ("check_every", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("tol_constraint", ctypes.c_double), ("tol_step", ctypes.c_double),
+                ("mu_init", ctypes.c_double), ("mu_min", ctypes.c_double), ("mu_factor", ctypes.c_double),
+                ("reg", ctypes.c_double)]
 
 
 _lib = None
@@ -59,6 +66,7 @@ def load():
     lib.nempc_hess_structure.argtypes = [vp, ip, ip]
     lib.nempc_eval.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.nempc_hess.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.nempc_solve.argtypes = [vp, i32, vp, vp, dp, dp, ctypes.POINTER(NempcSolverOpts), vp, ip, vp]
     lib.nempc_sync.argtypes = [vp, vp]
     lib.nempc_kernel_variant.argtypes = [vp]
     lib.nempc_last_error.argtypes = []

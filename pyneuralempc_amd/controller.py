@@ -73,4 +73,34 @@ class NMPC:
         return z[:nxh].reshape(self.integrator.H, -1), z[nxh:].reshape(self.integrator.H, -1)
 
 
+    def next_batch(self, X0, init_z=None, **solver_opts):
+        """Solve B MPC problems at once on the device (no reference counterpart).  X0 (B,nx) NumPy
+        array or device tensor.  Needs the fused device path (device integrator + QuadraticObjective, no extra
+        constraint rows; state limits go into the DomainConstraint).  Returns (states (B,H,nx), u (B,H,nu),
+        status (B,) with Optimizer.SUCCESS / FAIL per problem) as NumPy arrays."""
+        import torch
+        from .optimizer.base import _FusedEvaluator
+        from .objective.quadratic import QuadraticObjective
+        from .integrator.base import DeviceIntegrator
+        if not (isinstance(self.integrator, DeviceIntegrator) and isinstance(self.objective_func, QuadraticObjective)
+                and len(self.constraint_list) == 0):
+            raise NotImplementedError("next_batch needs a device integrator, a QuadraticObjective and no extra "
+                                      "constraint rows")
+        key = (id(self.objective_func), None)
+        cache = self.integrator._fused
+        if key not in cache:
+            cache[key] = _FusedEvaluator(self.integrator, self.objective_func, None)
+        eng = cache[key].engine
+        H = self.integrator.H
+        X0t = X0 if isinstance(X0, torch.Tensor) else eng.to_device(np.atleast_2d(np.asarray(X0, dtype=np.float64)))
+        Zi = None if init_z is None else (init_z if isinstance(init_z, torch.Tensor) else eng.to_device(init_z))
+        lb = np.asarray(self.domain_constraint.get_lower_bounds(H), dtype=np.float64)
+        ub = np.asarray(self.domain_constraint.get_upper_bounds(H), dtype=np.float64)
+        Z, status, iters = eng.solve(X0t.contiguous(), Zi, lb, ub, **solver_opts)
+        self.last_batch_iterations = iters
+        z = Z.to("cpu", torch.float64).numpy()
+        B, nx, nu = z.shape[0], eng.nx, eng.nu
+        return z[:, :H * nx].reshape(B, H, nx), z[:, H * nx:].reshape(B, H, nu), status.cpu().numpy()
+
+
 MPC = NMPC  # BASELINE.json's north_star calls the entry point controller.MPC

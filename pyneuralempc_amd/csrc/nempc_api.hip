@@ -209,6 +209,7 @@ void destroy_impl(Handle* h) {
         dev_free(h->d_b[l]);
     }
     mfma_free(*h);
+    solver_free(*h);
     dev_free(h->d_obj);
     void* p = h->d_dense_map; dev_free(p); h->d_dense_map = nullptr;
     p = h->d_sparse_map; dev_free(p); h->d_sparse_map = nullptr;
@@ -471,6 +472,23 @@ int nempc_hess(nempc_handle hh, int32_t B, const void* Z, const void* X0, const 
     if (rc) return rc;
     if (!hvals && !hdense) return NEMPC_OK;
     return launch_assemble_hess(h, B, blocks, sigma, hvals, hdense, s);
+}
+
+int nempc_solve(nempc_handle hh, int32_t B, const void* X0, void* Z, const double* lb, const double* ub,
+                const nempc_solver_opts* opts, int32_t* status, int32_t* iters, void* stream) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_solve: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    if (B < 0 || B > h.cfg.max_batch) return fail(NEMPC_EINVAL, "nempc_solve: B outside [0, max_batch]");
+    if (B == 0) { if (iters) *iters = 0; return NEMPC_OK; }
+    if (!X0 || !Z || !opts || !status) return fail(NEMPC_EINVAL, "nempc_solve: null argument");
+    if (!h.have_weights) return fail(NEMPC_ESTATE, "nempc_solve: call nempc_set_weights first");
+    if (h.box) return fail(NEMPC_EUNSUPPORTED, "nempc_solve: box rows are not handled; pass state bounds as lb/ub");
+    if (opts->max_iter < 1 || opts->max_linesearch < 1 || !(opts->mu_factor > 0.0 && opts->mu_factor < 1.0) ||
+        !(opts->mu_init > 0.0) || !(opts->mu_min > 0.0))
+        return fail(NEMPC_EINVAL, "nempc_solve: bad options");
+    DeviceGuard dg(h.cfg.device);
+    if (!dg.ok) return fail(NEMPC_EHIP, "nempc_solve: hipSetDevice failed");
+    return solver_run(h, B, X0, Z, lb, ub, *opts, status, iters, reinterpret_cast<hipStream_t>(stream));
 }
 
 int nempc_sync(nempc_handle hh, void* stream) {

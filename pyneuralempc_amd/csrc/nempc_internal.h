@@ -71,6 +71,7 @@ struct Handle {
     size_t valu_ws_elems = 0;
     void* d_hess_ws = nullptr;   // (Bmax,H,nin,nin) per-row Lagrangian blocks
     long long* d_dbg = nullptr;  // diagnostic builds only
+    void* solver_ws = nullptr;   // solver.hip
 };
 
 struct ObjOffsets {  // element offsets into Handle::d_obj
@@ -112,5 +113,10 @@ int launch_assemble_sparse(Handle& h, int B, const void* tiles, void* vals, hipS
 int launch_post(Handle& h, int B, const void* tiles, void* jac, const void* Z, void* f, void* grad, hipStream_t s);
 int launch_assemble_hess(Handle& h, int B, const void* blocks, const void* sigma, void* hvals, void* hdense,
                          hipStream_t s);
+
+// ---- solver.hip : batched Gauss-Newton SQP
+int solver_run(Handle& h, int B, const void* X0, void* Z, const double* lb, const double* ub,
+               const nempc_solver_opts& o, int32_t* status_dev, int32_t* iters_host, hipStream_t s);
+void solver_free(Handle& h);
 
 }  // namespace nempc

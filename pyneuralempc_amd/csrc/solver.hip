@@ -1,0 +1,645 @@
+// Batched on-device NMPC solver ("a lock-step batched iteration on device over the
+// banded KKT system turns evals/sec into solved-MPC/sec").  The reference solves one problem at a time with a
+// CPU solver (Ipopt via cyipopt, optimizer/ipopt.py:138-195, or SciPy SLSQP, optimizer/slsqp.py:143-197);
+// this is the batched counterpart that consumes the same callbacks for B problems at once.
+//
+// Method: SQP with the exact Lagrangian Hessian on the multiple-shooting NLP
+//     min f(z)  s.t.  Phi(x_{t-1},u_t) - x_t = 0,  lb <= z <= ub      (z as in optimizer/ipopt.py:20-28)
+// * Hessian = objective blocks + the per-step Lagrangian blocks sum_k lambda_{t,k} d2 Phi_k / d[x_{t-1}|u_t]^2 of
+//   the Hessian callback (a pure Gauss-Newton model was tried first: with multipliers of order 10 and a tanh
+//   network it needs 50-200 iterations and damped steps; the exact blocks give 5-20 full steps).  The blocks
+//   couple only (x_{t-1}, u_t), so every QP is still an LQ problem in the linearised dynamics
+//   dx_t = A_t dx_{t-1} + B_t du_t + g_t, solved exactly by one backward Riccati sweep and one forward sweep per
+//   problem (block-tridiagonal KKT, O(H (nx+nu)^3)).  Indefinite control Hessians Quu are handled the DDP way:
+//   the sweep restarts with a larger Levenberg term.  Multipliers = Riccati costates of the previous step;
+// * variable bounds (DomainConstraint, constraints.py:3-33) enter as a log barrier whose diagonal terms keep the
+//   LQ structure; mu is decreased per problem once its barrier sub-problem has converged;
+// * globalisation: l1 merit f_mu + nu |g|_1 with nu tracking the Riccati costates, backtracking from the
+//   fraction-to-the-boundary step.
+// Every problem carries its own mu, nu, step length and status; the batch advances in lock step and finished
+// problems idle.  All arithmetic is in kernels here; the callbacks are the handle's own row/objective kernels.
+#include <cmath>
+#include <limits>
+
+#include "nempc_internal.h"
+
+namespace nempc {
+
+namespace {
+
+constexpr int INFO_LAM = 0, INFO_STEP = 1, INFO_AMAX = 2, INFO_G1 = 3, INFO_GINF = 4, INFO_D0 = 5, INFO_ZINF = 6,
+              INFO_N = 8;
+
+struct SolverArgs {
+    int B, H, nx, nu, nin, n, m;
+    const void* Z; const void* grad; const void* g; const void* tiles;   // at the current iterate
+    const void* hblk;                                                    // (B,H,nin,nin) Lagrangian blocks
+    void* lam; void* lamn;                                               // (B,m) multipliers: current, LQ costates
+    const void* obj;  ObjOffsets oo;                                     // Qs, Rs live in the objective block
+    const void* lb; const void* ub;                                      // (n) device, dtype T, +-inf allowed
+    void* mu; void* pen; void* reg; void* alpha; void* phi0; void* dir;  // (B) per problem (pen = l1 penalty)
+    int* status; int* lsdone; int* n_active;
+    void* dz; void* info;                                                // (B,n), (B,INFO_N)
+    void* Kst; void* kst; void* Pst; void* pst;                          // Riccati storage per problem
+    void* tmp; size_t tmp_stride;                                        // global temporaries when LDS is too small
+    int use_lds;                                                         // 1: per-problem working set staged in LDS
+    int ppw;                                                             // problems per workgroup (LDS mode)
+    int lds_stride;                                                      // elements per problem in LDS (odd)
+    double tol_g, tol_step, mu_min, mu_factor;
+};
+
+template <typename T>
+__device__ __forceinline__ void barrier_terms(T z, T lo, T hi, T mu, T& gadd, T& hadd) {
+    if (mu > T(0)) {
+        if (lo > -std::numeric_limits<T>::max()) { const T d = z - lo; gadd -= mu / d; hadd += mu / (d * d); }
+        if (hi < std::numeric_limits<T>::max()) { const T d = hi - z; gadd += mu / d; hadd += mu / (d * d); }
+    }
+}
+
+// One thread per problem.  The sweep is a long chain of tiny dependent matrix products: straight from global
+// memory every operand costs a ~600-cycle round trip (measured 720 us per call at B=1024, 2/1, H=20).  So a
+// workgroup first copies the whole working set of its `ppw` problems (iterate, gradient, defects, tiles,
+// Lagrangian blocks) into LDS with coalesced loads, the first ppw lanes then run their sweeps out of LDS
+// (per-problem stride odd -> conflict-free), and the step / costates are copied back cooperatively.
+// Problems whose working set does not fit in LDS fall back to global temporaries (ppw = 64, use_lds = 0).
+// NX, NU > 0: dimensions fixed at compile time -- every small loop unrolls and the temporaries live in registers
+// (2/1 and 6/3, the BASELINE shapes); NX = NU = 0: runtime dimensions, temporaries in LDS / global memory.
+template <typename T, int NX, int NU>
+__global__ __launch_bounds__(64) void solver_lq_kernel(SolverArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+    const int lane = threadIdx.x;
+    constexpr bool FIX = NX > 0;
+    const int H = a.H, nx = FIX ? NX : a.nx, nu = FIX ? NU : a.nu, nin = nx + nu, n = a.n;
+    const int ppw = a.use_lds ? a.ppw : 64;
+    const int b = blockIdx.x * ppw + lane;
+    const bool mine = lane < ppw && b < a.B;
+    // element offsets of the per-problem LDS block
+    const int Lz = 0, Lgr = Lz + n, Lgc = Lgr + n, Ltl = Lgc + H * nx, LW = Ltl + H * nx * nin, LK = LW + H * nin * nin,
+              Lk = LK + H * nu * nx, LP = Lk + H * nu, Lp = LP + H * nx * nx, Llam = Lp + H * nx, Ldz = Llam + H * nx,
+              Ltmp = Ldz + n;
+    if (a.use_lds) {
+        for (int pp = 0; pp < ppw; ++pp) {
+            const int bp = blockIdx.x * ppw + pp;
+            if (bp >= a.B) break;
+            T* blk = lds + (size_t)pp * a.lds_stride;
+            const T* sz = (const T*)a.Z + (size_t)bp * n;
+            const T* sg = (const T*)a.grad + (size_t)bp * n;
+            const T* sc = (const T*)a.g + (size_t)bp * a.m;
+            const T* st = (const T*)a.tiles + (size_t)bp * H * nx * nin;
+            const T* sw = (const T*)a.hblk + (size_t)bp * H * nin * nin;
+            for (int i = lane; i < n; i += 64) { blk[Lz + i] = sz[i]; blk[Lgr + i] = sg[i]; }
+            for (int i = lane; i < H * nx; i += 64) blk[Lgc + i] = sc[i];
+            for (int i = lane; i < H * nx * nin; i += 64) blk[Ltl + i] = st[i];
+            for (int i = lane; i < H * nin * nin; i += 64) blk[LW + i] = sw[i];
+        }
+        __syncthreads();
+    }
+    T* dzg = mine ? (T*)a.dz + (size_t)b * n : nullptr;
+    if (mine && a.status[b] >= 0) {
+        // finished problem: zero step (written through the copy-out below in LDS mode)
+        T* dzp = a.use_lds ? lds + (size_t)lane * a.lds_stride + Ldz : dzg;
+        for (int i = 0; i < n; ++i) dzp[i] = T(0);
+        if (a.use_lds) {
+            T* lp = lds + (size_t)lane * a.lds_stride + Llam;
+            const T* lcur = (const T*)a.lam + (size_t)b * a.m;
+            for (int i = 0; i < H * nx; ++i) lp[i] = lcur[i];
+        }
+    } else if (mine) {
+    T* info = (T*)a.info + (size_t)b * INFO_N;
+    T* blk = lds + (size_t)lane * a.lds_stride;
+    T* tb = a.use_lds ? blk + Ltmp : (T*)a.tmp + b;
+    const size_t ts = a.use_lds ? 1 : a.tmp_stride;
+    T tmpv[FIX ? (3 * NX * NX + 3 * NX * NU + NU * NU + 5 * NX + 3 * NU) : 1];
+#define TMP(e) (*(FIX ? &tmpv[FIX ? (e) : 0] : &tb[(size_t)(e) * ts]))
+    int off = 0;
+    const int oP = off; off += nx * nx;
+    const int oPA = off; off += nx * nx;
+    const int oPn = off; off += nx * nx;
+    const int oPB = off; off += nx * nu;
+    const int oQux = off; off += nu * nx;
+    const int oK = off; off += nu * nx;
+    const int oQuu = off; off += nu * nu;
+    const int oPc = off; off += nx;
+    const int op = off; off += nx;
+    const int opn = off; off += nx;
+    const int odx = off; off += nx;
+    const int odxn = off; off += nx;
+    const int oqu = off; off += nu;
+    const int okv = off; off += nu;
+    const int odu = off; off += nu;
+
+    const T* z = a.use_lds ? blk + Lz : (const T*)a.Z + (size_t)b * n;
+    const T* gr = a.use_lds ? blk + Lgr : (const T*)a.grad + (size_t)b * n;
+    const T* gc = a.use_lds ? blk + Lgc : (const T*)a.g + (size_t)b * a.m;
+    const T* tl = a.use_lds ? blk + Ltl : (const T*)a.tiles + (size_t)b * H * nx * nin;
+    const T* Wb = a.use_lds ? blk + LW : (const T*)a.hblk + (size_t)b * H * nin * nin;
+    const T* Qs = (const T*)a.obj + a.oo.Qs;
+    const T* Rs = (const T*)a.obj + a.oo.Rs;
+    const T* lb = (const T*)a.lb;
+    const T* ub = (const T*)a.ub;
+    const T mu = ((const T*)a.mu)[b];
+    T reg = ((const T*)a.reg)[b];
+    T* Kst = a.use_lds ? blk + LK : (T*)a.Kst + (size_t)b * H * nu * nx;
+    T* kst = a.use_lds ? blk + Lk : (T*)a.kst + (size_t)b * H * nu;
+    T* Pst = a.use_lds ? blk + LP : (T*)a.Pst + (size_t)b * H * nx * nx;
+    T* pst = a.use_lds ? blk + Lp : (T*)a.pst + (size_t)b * H * nx;
+    T* dz = a.use_lds ? blk + Ldz : dzg;
+    const int uo = H * nx;
+
+    for (int attempt = 0; attempt < 14; ++attempt) {
+    bool pd = true;
+    // terminal value function: V_{H-1}(dx) = 1/2 dx' Hx dx + gx' dx
+    #pragma unroll
+    for (int i = 0; i < nx; ++i) {
+        T ga = T(0), ha = T(0);
+        barrier_terms<T>(z[(H - 1) * nx + i], lb[(H - 1) * nx + i], ub[(H - 1) * nx + i], mu, ga, ha);
+        #pragma unroll
+        for (int j = 0; j < nx; ++j) TMP(oP + i * nx + j) = Qs[i * nx + j] + (i == j ? ha : T(0));
+        TMP(op + i) = gr[(H - 1) * nx + i] + ga;
+    }
+    for (int t = H - 1; t >= 0 && pd; --t) {
+        const T* At = tl + (size_t)t * nx * nin;   // [i][0:nx] = A, [i][nx:] = B
+        const T* Wt = Wb + (size_t)t * nin * nin;  // Lagrangian block over (x_{t-1}, u_t)
+        #pragma unroll
+        for (int i = 0; i < nx; ++i) {
+            #pragma unroll
+            for (int j = 0; j < nx; ++j) Pst[(size_t)t * nx * nx + i * nx + j] = TMP(oP + i * nx + j);
+            pst[(size_t)t * nx + i] = TMP(op + i);
+        }
+        // PA = P A, PB = P B, Pc = P c + p
+        #pragma unroll
+        for (int i = 0; i < nx; ++i) {
+            if (t > 0)
+                #pragma unroll
+                for (int j = 0; j < nx; ++j) {
+                    T v = T(0);
+                    #pragma unroll
+                    for (int k = 0; k < nx; ++k) v = fma(TMP(oP + i * nx + k), At[k * nin + j], v);
+                    TMP(oPA + i * nx + j) = v;
+                }
+            #pragma unroll
+            for (int j = 0; j < nu; ++j) {
+                T v = T(0);
+                #pragma unroll
+                for (int k = 0; k < nx; ++k) v = fma(TMP(oP + i * nx + k), At[k * nin + nx + j], v);
+                TMP(oPB + i * nu + j) = v;
+            }
+            T v = TMP(op + i);
+            #pragma unroll
+            for (int k = 0; k < nx; ++k) v = fma(TMP(oP + i * nx + k), gc[t * nx + k], v);
+            TMP(oPc + i) = v;
+        }
+        // Quu = Rs + barrier + reg + B' PB ; qu = gu + barrier + B' Pc ; Qux = B' PA
+        #pragma unroll
+        for (int i = 0; i < nu; ++i) {
+            T ga = T(0), ha = T(0);
+            barrier_terms<T>(z[uo + t * nu + i], lb[uo + t * nu + i], ub[uo + t * nu + i], mu, ga, ha);
+            #pragma unroll
+            for (int j = 0; j < nu; ++j) {
+                T v = Rs[i * nu + j] + Wt[(nx + i) * nin + nx + j] + (i == j ? ha + reg : T(0));
+                #pragma unroll
+                for (int k = 0; k < nx; ++k) v = fma(At[k * nin + nx + i], TMP(oPB + k * nu + j), v);
+                TMP(oQuu + i * nu + j) = v;
+            }
+            T v = gr[uo + t * nu + i] + ga;
+            #pragma unroll
+            for (int k = 0; k < nx; ++k) v = fma(At[k * nin + nx + i], TMP(oPc + k), v);
+            TMP(oqu + i) = v;
+            if (t > 0)
+                #pragma unroll
+                for (int j = 0; j < nx; ++j) {
+                    T w = Wt[(nx + i) * nin + j];
+                    #pragma unroll
+                    for (int k = 0; k < nx; ++k) w = fma(At[k * nin + nx + i], TMP(oPA + k * nx + j), w);
+                    TMP(oQux + i * nx + j) = w;
+                }
+        }
+        // Cholesky Quu = L L' (lower, in place)
+        #pragma unroll
+        for (int j = 0; j < nu; ++j) {
+            T d = TMP(oQuu + j * nu + j);
+            #pragma unroll
+            for (int k = 0; k < j; ++k) d -= TMP(oQuu + j * nu + k) * TMP(oQuu + j * nu + k);
+            if (!(d > T(1e-12))) { pd = false; break; }   // not positive definite: restart with more damping
+            d = sqrt(d);
+            TMP(oQuu + j * nu + j) = d;
+            #pragma unroll
+            for (int i = j + 1; i < nu; ++i) {
+                T v = TMP(oQuu + i * nu + j);
+                #pragma unroll
+                for (int k = 0; k < j; ++k) v -= TMP(oQuu + i * nu + k) * TMP(oQuu + j * nu + k);
+                TMP(oQuu + i * nu + j) = v / d;
+            }
+        }
+        if (!pd) break;
+        // kv = -Quu^-1 qu ; K = -Quu^-1 Qux   (forward then backward substitution, column by column)
+        const int ncolK = t > 0 ? nx : 0;
+        for (int col = -1; col < ncolK; ++col) {
+            #pragma unroll
+            for (int i = 0; i < nu; ++i) {
+                T v = (col < 0) ? TMP(oqu + i) : TMP(oQux + i * nx + col);
+                #pragma unroll
+                for (int k = 0; k < i; ++k) v -= TMP(oQuu + i * nu + k) * TMP(odu + k);
+                TMP(odu + i) = v / TMP(oQuu + i * nu + i);
+            }
+            #pragma unroll
+            for (int i = nu - 1; i >= 0; --i) {
+                T v = TMP(odu + i);
+                #pragma unroll
+                for (int k = i + 1; k < nu; ++k) v -= TMP(oQuu + k * nu + i) * TMP(odu + k);
+                v /= TMP(oQuu + i * nu + i);
+                TMP(odu + i) = v;
+            }
+            #pragma unroll
+            for (int i = 0; i < nu; ++i) {
+                if (col < 0) { TMP(okv + i) = -TMP(odu + i); kst[(size_t)t * nu + i] = -TMP(odu + i); }
+                else { TMP(oK + i * nx + col) = -TMP(odu + i); Kst[(size_t)t * nu * nx + i * nx + col] = -TMP(odu + i); }
+            }
+        }
+        if (t > 0) {
+            // P_{t-1} = Hx_{t-1} + A' PA + Qux' K ; p_{t-1} = gx_{t-1} + A' Pc + Qux' kv
+            #pragma unroll
+            for (int i = 0; i < nx; ++i) {
+                T ga = T(0), ha = T(0);
+                barrier_terms<T>(z[(t - 1) * nx + i], lb[(t - 1) * nx + i], ub[(t - 1) * nx + i], mu, ga, ha);
+                #pragma unroll
+                for (int j = 0; j < nx; ++j) {
+                    T v = Qs[i * nx + j] + Wt[i * nin + j] + (i == j ? ha : T(0));
+                    #pragma unroll
+                    for (int k = 0; k < nx; ++k) v = fma(At[k * nin + i], TMP(oPA + k * nx + j), v);
+                    #pragma unroll
+                    for (int k = 0; k < nu; ++k) v = fma(TMP(oQux + k * nx + i), TMP(oK + k * nx + j), v);
+                    TMP(oPn + i * nx + j) = v;
+                }
+                T v = gr[(t - 1) * nx + i] + ga;
+                #pragma unroll
+                for (int k = 0; k < nx; ++k) v = fma(At[k * nin + i], TMP(oPc + k), v);
+                #pragma unroll
+                for (int k = 0; k < nu; ++k) v = fma(TMP(oQux + k * nx + i), TMP(okv + k), v);
+                TMP(opn + i) = v;
+            }
+            #pragma unroll
+            for (int i = 0; i < nx; ++i) {
+                #pragma unroll
+                for (int j = 0; j < nx; ++j) TMP(oP + i * nx + j) = T(0.5) * (TMP(oPn + i * nx + j) + TMP(oPn + j * nx + i));
+                TMP(op + i) = TMP(opn + i);
+            }
+        }
+    }
+    if (pd) break;
+    reg = fmax(reg * T(10), T(1e-6));
+    }
+    ((T*)a.reg)[b] = reg;
+    T* lamn = a.use_lds ? blk + Llam : (T*)a.lamn + (size_t)b * a.m;
+    // forward sweep
+    T lam_inf = T(0), step_inf = T(0), amax = T(1), D0 = T(0), g1 = T(0), ginf = T(0), zinf = T(0);
+    const T tau = T(0.995);
+    #pragma unroll
+    for (int i = 0; i < nx; ++i) TMP(odx + i) = T(0);
+    for (int t = 0; t < H; ++t) {
+        const T* At = tl + (size_t)t * nx * nin;
+        #pragma unroll
+        for (int i = 0; i < nu; ++i) {
+            T v = kst[(size_t)t * nu + i];
+            if (t > 0)
+                #pragma unroll
+                for (int k = 0; k < nx; ++k) v = fma(Kst[(size_t)t * nu * nx + i * nx + k], TMP(odx + k), v);
+            TMP(odu + i) = v;
+        }
+        #pragma unroll
+        for (int i = 0; i < nx; ++i) {
+            T v = gc[t * nx + i];
+            if (t > 0)
+                #pragma unroll
+                for (int k = 0; k < nx; ++k) v = fma(At[i * nin + k], TMP(odx + k), v);
+            #pragma unroll
+            for (int k = 0; k < nu; ++k) v = fma(At[i * nin + nx + k], TMP(odu + k), v);
+            TMP(odxn + i) = v;
+        }
+        #pragma unroll
+        for (int i = 0; i < nx; ++i) {
+            T lam = pst[(size_t)t * nx + i];
+            #pragma unroll
+            for (int k = 0; k < nx; ++k) lam = fma(Pst[(size_t)t * nx * nx + i * nx + k], TMP(odxn + k), lam);
+            lam_inf = fmax(lam_inf, fabs(lam));
+            lamn[t * nx + i] = lam;
+            const T d = TMP(odxn + i), zz = z[t * nx + i], lo = lb[t * nx + i], hi = ub[t * nx + i];
+            dz[t * nx + i] = d;
+            step_inf = fmax(step_inf, fabs(d));
+            zinf = fmax(zinf, fabs(zz));
+            T ga = T(0), ha = T(0);
+            barrier_terms<T>(zz, lo, hi, mu, ga, ha);
+            D0 = fma(gr[t * nx + i] + ga, d, D0);
+            if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
+            if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
+            const T gv = fabs(gc[t * nx + i]);
+            g1 += gv;
+            ginf = fmax(ginf, gv);
+            TMP(odx + i) = d;
+        }
+        #pragma unroll
+        for (int i = 0; i < nu; ++i) {
+            const T d = TMP(odu + i), zz = z[uo + t * nu + i], lo = lb[uo + t * nu + i], hi = ub[uo + t * nu + i];
+            dz[uo + t * nu + i] = d;
+            step_inf = fmax(step_inf, fabs(d));
+            zinf = fmax(zinf, fabs(zz));
+            T ga = T(0), ha = T(0);
+            barrier_terms<T>(zz, lo, hi, mu, ga, ha);
+            D0 = fma(gr[uo + t * nu + i] + ga, d, D0);
+            if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
+            if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
+        }
+    }
+    info[INFO_LAM] = lam_inf; info[INFO_STEP] = step_inf; info[INFO_AMAX] = amax; info[INFO_G1] = g1;
+    info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf;
+#undef TMP
+    }
+    if (a.use_lds) {
+        __syncthreads();
+        for (int pp = 0; pp < ppw; ++pp) {
+            const int bp = blockIdx.x * ppw + pp;
+            if (bp >= a.B) break;
+            const T* blk = lds + (size_t)pp * a.lds_stride;
+            T* dd = (T*)a.dz + (size_t)bp * n;
+            T* dl = (T*)a.lamn + (size_t)bp * a.m;
+            for (int i = lane; i < n; i += 64) dd[i] = blk[Ldz + i];
+            for (int i = lane; i < H * nx; i += 64) dl[i] = blk[Llam + i];
+        }
+    }
+}
+
+// log-barrier value of one problem's variables, summed by a wave
+template <typename T>
+__device__ __forceinline__ double barrier_value(const T* z, const T* lb, const T* ub, int n, T mu, int lane) {
+    double acc = 0.0;
+    if (mu > T(0))
+        for (int i = lane; i < n; i += 64) {
+            if (lb[i] > -std::numeric_limits<T>::max()) acc -= (double)mu * log((double)(z[i] - lb[i]));
+            if (ub[i] < std::numeric_limits<T>::max()) acc -= (double)mu * log((double)(ub[i] - z[i]));
+        }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    return __shfl(acc, 0, 64);
+}
+
+template <typename T>
+__device__ __forceinline__ double l1_norm(const T* g, int m, int lane) {
+    double acc = 0.0;
+    for (int i = lane; i < m; i += 64) acc += fabs((double)g[i]);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    return __shfl(acc, 0, 64);
+}
+
+// mode 0: after the LQ solve -- convergence / barrier update, penalty update, merit at the iterate, first step length
+// mode 1: after evaluating the trial point -- Armijo test, accept (copy) or halve
+template <typename T>
+__global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, int mode, const T* __restrict__ f,
+                                                          const T* __restrict__ Zt, const T* __restrict__ gt,
+                                                          const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B) return;
+    T* mu = (T*)a.mu; T* nu = (T*)a.pen; T* reg = (T*)a.reg; T* alpha = (T*)a.alpha; T* phi0 = (T*)a.phi0; T* dir = (T*)a.dir;
+    const T* info = (const T*)a.info + (size_t)b * INFO_N;
+    const T* lb = (const T*)a.lb;
+    const T* ub = (const T*)a.ub;
+    const int H = a.H, nx = a.nx;
+    if (mode == 0) {
+        if (a.status[b] >= 0) { if (lane == 0) a.lsdone[b] = 1; return; }
+        // converged for the current barrier parameter?  Sub-problems with mu above its floor are only solved to
+        // an accuracy proportional to mu (kappa = 10); the last one to the requested tolerances.
+        const bool last_mu = !(mu[b] > (T)a.mu_min * T(1.0001));
+        const T tg = last_mu ? (T)a.tol_g : fmax((T)a.tol_g, T(10) * mu[b]);
+        const T tsx = last_mu ? (T)a.tol_step * (T(1) + info[INFO_ZINF]) : fmax((T)a.tol_step, T(10) * mu[b]) * (T(1) + info[INFO_ZINF]);
+        const bool conv = info[INFO_GINF] <= tg && info[INFO_STEP] <= tsx;
+        if (conv) {
+            if (!last_mu) {
+                // superlinear decrease: mu <- max(mu_min, min(mu_factor * mu, mu^1.5))
+                if (lane == 0) mu[b] = fmax(fmin(mu[b] * (T)a.mu_factor, mu[b] * sqrt(mu[b])), (T)a.mu_min);
+                // new sub-problem: skip this step (direction was computed for the old mu)
+                if (lane == 0) { a.lsdone[b] = 1; atomicAdd(a.n_active, 1); }
+            } else {
+                if (lane == 0) { a.status[b] = 0; a.lsdone[b] = 1; }
+            }
+            return;
+        }
+        const T* z = Zcur + (size_t)b * a.n;
+        const T* g = (const T*)a.g + (size_t)b * a.m;
+        const double bar = barrier_value<T>(z, lb, ub, a.n, mu[b], lane);
+        const double g1 = l1_norm<T>(g, H * nx, lane);
+        if (lane == 0) {
+            const T nun = fmax(nu[b], T(1.5) * info[INFO_LAM] + T(1e-3));
+            nu[b] = nun;
+            phi0[b] = (T)((double)f[b] + bar + (double)nun * g1);
+            dir[b] = info[INFO_D0] - nun * (T)g1;
+            alpha[b] = info[INFO_AMAX];
+            a.lsdone[b] = 0;
+            atomicAdd(a.n_active, 1);
+        }
+        return;
+    }
+    if (a.lsdone[b]) return;
+    const T* zt = Zt + (size_t)b * a.n;
+    const double bar = barrier_value<T>(zt, lb, ub, a.n, mu[b], lane);
+    const double g1 = l1_norm<T>(gt + (size_t)b * a.m, H * nx, lane);
+    const T phit = (T)((double)ft[b] + bar + (double)nu[b] * g1);
+    const T al = alpha[b];
+    // Armijo on the l1 merit; the directional derivative is negative for a descent direction
+    const bool ok = (phit == phit) && phit <= phi0[b] + T(1e-4) * al * fmin(dir[b], T(0)) + T(1e-12) * fabs(phi0[b]);
+    if (ok) {
+        for (int i = lane; i < a.n; i += 64) Zcur[(size_t)b * a.n + i] = zt[i];
+        T* lam = (T*)a.lam + (size_t)b * a.m;
+        const T* lamn = (const T*)a.lamn + (size_t)b * a.m;
+        for (int i = lane; i < H * nx; i += 64) lam[i] = fma(al, lamn[i] - lam[i], lam[i]);
+        if (lane == 0) { a.lsdone[b] = 1; reg[b] = fmax(reg[b] * T(0.1), T(1e-9)); }
+    } else if (lane == 0) {
+        alpha[b] = al * T(0.5);
+        if (!last_ls) atomicAdd(a.n_active, 1);   // still searching: the host polls this to stop the backtracking early
+        if (last_ls) { a.lsdone[b] = 1; reg[b] = fmin(fmax(reg[b] * T(100), T(1e-6)), T(1e8)); }   // no progress: damp the next LQ solve
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void solver_trial_kernel(int B, int n, const T* __restrict__ Z, const T* __restrict__ dz,
+                                                           const T* __restrict__ alpha, const int* __restrict__ lsdone,
+                                                           T* __restrict__ Zt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * n) return;
+    const int b = (int)(i / n);
+    Zt[i] = lsdone[b] ? Z[i] : fma(alpha[b], dz[i], Z[i]);
+}
+
+// strictly interior start + per-problem state
+template <typename T>
+__global__ __launch_bounds__(256) void solver_init_kernel(int B, int n, T* __restrict__ Z, const T* __restrict__ lb,
+                                                          const T* __restrict__ ub, T* mu, T* nu, T* reg, int* status,
+                                                          T mu0, T reg0, int has_bounds) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)B) { mu[i] = has_bounds ? mu0 : T(0); nu[i] = T(1); reg[i] = reg0; status[i] = -1; }
+    if (i >= (size_t)B * n) return;
+    const int k = (int)(i % n);
+    const T lo = lb[k], hi = ub[k];
+    const bool flo = lo > -std::numeric_limits<T>::max(), fhi = hi < std::numeric_limits<T>::max();
+    T z = Z[i];
+    T marg = T(1e-2);
+    if (flo && fhi) marg = fmin(marg, T(0.25) * (hi - lo));
+    if (flo) z = fmax(z, lo + marg);
+    if (fhi) z = fmin(z, hi - marg);
+    Z[i] = z;
+}
+
+__global__ void solver_finalize_kernel(int B, int* status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && status[b] < 0) status[b] = 1;
+}
+
+struct SolverWs {
+    void *Zt = nullptr, *f = nullptr, *ft = nullptr, *grad = nullptr, *g = nullptr, *gt = nullptr, *tiles = nullptr;
+    void *lb = nullptr, *ub = nullptr, *mu = nullptr, *nu = nullptr, *reg = nullptr, *alpha = nullptr, *phi0 = nullptr,
+         *dir = nullptr, *hblk = nullptr, *lam = nullptr, *lamn = nullptr, *sig = nullptr, *dz = nullptr, *info = nullptr, *Kst = nullptr, *kst = nullptr, *Pst = nullptr, *pst = nullptr,
+         *tmp = nullptr;
+    int *lsdone = nullptr, *n_active = nullptr;
+    int cap = 0;
+};
+
+int lq_tmp_elems(int nx, int nu) { return 3 * nx * nx + 3 * nx * nu + nu * nu + 5 * nx + 3 * nu; }
+
+}  // namespace
+
+void solver_free(Handle& h) {
+    SolverWs* w = static_cast<SolverWs*>(h.solver_ws);
+    if (!w) return;
+    void** ptrs[] = {&w->Zt, &w->f, &w->ft, &w->grad, &w->g, &w->gt, &w->tiles, &w->lb, &w->ub, &w->mu, &w->nu, &w->reg,
+                     &w->alpha, &w->phi0, &w->dir, &w->hblk, &w->lam, &w->lamn, &w->sig, &w->dz, &w->info, &w->Kst, &w->kst, &w->Pst, &w->pst, &w->tmp};
+    for (void** p : ptrs)
+        if (*p) (void)hipFree(*p);
+    if (w->lsdone) (void)hipFree(w->lsdone);
+    if (w->n_active) (void)hipFree(w->n_active);
+    delete w;
+    h.solver_ws = nullptr;
+}
+
+template <typename T>
+static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* lb, const double* ub,
+                       const nempc_solver_opts& o, int32_t* status_dev, int32_t* iters_host, hipStream_t s) {
+    const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu, nin = h.nin, n = h.n, m = h.m;
+    if (!h.solver_ws) h.solver_ws = new SolverWs();
+    SolverWs& w = *static_cast<SolverWs*>(h.solver_ws);
+    if (w.cap < B) {
+        solver_free(h);
+        h.solver_ws = new SolverWs();
+        SolverWs& w2 = *static_cast<SolverWs*>(h.solver_ws);
+        const size_t e = sizeof(T), Bn = (size_t)B;
+        struct { void** p; size_t bytes; } al[] = {
+            {&w2.Zt, Bn * n * e}, {&w2.f, Bn * e}, {&w2.ft, Bn * e}, {&w2.grad, Bn * n * e}, {&w2.g, Bn * m * e},
+            {&w2.gt, Bn * m * e}, {&w2.tiles, Bn * H * nx * nin * e}, {&w2.lb, (size_t)n * e}, {&w2.ub, (size_t)n * e},
+            {&w2.mu, Bn * e}, {&w2.nu, Bn * e}, {&w2.reg, Bn * e}, {&w2.alpha, Bn * e}, {&w2.phi0, Bn * e},
+            {&w2.dir, Bn * e}, {&w2.hblk, Bn * H * nin * nin * e}, {&w2.lam, Bn * m * e}, {&w2.lamn, Bn * m * e},
+            {&w2.sig, Bn * e}, {&w2.dz, Bn * n * e}, {&w2.info, Bn * INFO_N * e}, {&w2.Kst, Bn * H * nu * nx * e},
+            {&w2.kst, Bn * H * nu * e}, {&w2.Pst, Bn * H * nx * nx * e}, {&w2.pst, Bn * H * nx * e},
+            {&w2.tmp, Bn * lq_tmp_elems(nx, nu) * e}};
+        for (auto& x : al) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
+        NEMPC_HIP(hipMalloc((void**)&w2.lsdone, Bn * sizeof(int)));
+        NEMPC_HIP(hipMalloc((void**)&w2.n_active, sizeof(int)));
+        w2.cap = B;
+    }
+    SolverWs& ws = *static_cast<SolverWs*>(h.solver_ws);
+    // bounds -> device (dtype T); +-inf become +-max so that comparisons stay exact
+    std::vector<T> hl(n), hu(n);
+    bool has_bounds = false;
+    const T big = std::numeric_limits<T>::max();
+    for (int i = 0; i < n; ++i) {
+        const double lo = lb ? lb[i] : -INFINITY, hi = ub ? ub[i] : INFINITY;
+        if (lo > hi) { set_error("nempc_solve: lb > ub"); return NEMPC_EINVAL; }
+        hl[i] = std::isfinite(lo) ? (T)lo : -big;
+        hu[i] = std::isfinite(hi) ? (T)hi : big;
+        has_bounds = has_bounds || std::isfinite(lo) || std::isfinite(hi);
+    }
+    NEMPC_HIP(hipMemcpyAsync(ws.lb, hl.data(), n * sizeof(T), hipMemcpyHostToDevice, s));
+    NEMPC_HIP(hipMemcpyAsync(ws.ub, hu.data(), n * sizeof(T), hipMemcpyHostToDevice, s));
+    NEMPC_HIP(hipStreamSynchronize(s));   // hl / hu are stack-owned
+
+    const unsigned gBn = (unsigned)(((size_t)B * n + 255) / 256);
+    hipLaunchKernelGGL(solver_init_kernel<T>, dim3(gBn), dim3(256), 0, s, B, n, (T*)Z, (const T*)ws.lb, (const T*)ws.ub,
+                       (T*)ws.mu, (T*)ws.nu, (T*)ws.reg, status_dev, (T)o.mu_init, (T)o.reg, has_bounds ? 1 : 0);
+
+    SolverArgs a{};
+    a.B = B; a.H = H; a.nx = nx; a.nu = nu; a.nin = nin; a.n = n; a.m = m;
+    a.Z = Z; a.grad = ws.grad; a.g = ws.g; a.tiles = ws.tiles;
+    a.hblk = ws.hblk; a.lam = ws.lam; a.lamn = ws.lamn;
+    NEMPC_HIP(hipMemsetAsync(ws.lam, 0, (size_t)B * m * sizeof(T), s));
+    a.obj = h.d_obj; a.oo = obj_offsets(H, nx, nu);
+    a.lb = ws.lb; a.ub = ws.ub; a.mu = ws.mu; a.pen = ws.nu; a.reg = ws.reg; a.alpha = ws.alpha; a.phi0 = ws.phi0;
+    a.dir = ws.dir; a.status = status_dev; a.lsdone = ws.lsdone; a.n_active = ws.n_active;
+    a.dz = ws.dz; a.info = ws.info; a.Kst = ws.Kst; a.kst = ws.kst; a.Pst = ws.Pst; a.pst = ws.pst;
+    a.tmp = ws.tmp; a.tmp_stride = (size_t)B;
+    int per_problem = 2 * n + 2 * H * nx + H * nx * nin + H * nin * nin + H * nu * nx + H * nu + H * nx * nx + H * nx + n +
+                      lq_tmp_elems(nx, nu);
+    per_problem |= 1;   // odd stride: the ppw lanes of a sweep hit different LDS banks
+    int ppw = (int)((size_t)150 * 1024 / ((size_t)per_problem * sizeof(T)));
+    if (ppw > 16) ppw = 16;
+    a.use_lds = ppw >= 1;
+    a.ppw = ppw;
+    a.lds_stride = per_problem;
+    const size_t lds_need = a.use_lds ? (size_t)ppw * per_problem * sizeof(T) : 0;
+    a.tol_g = o.tol_constraint; a.tol_step = o.tol_step; a.mu_min = has_bounds ? o.mu_min : 0.0; a.mu_factor = o.mu_factor;
+    auto lqk = (nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1> : ((nx == 6 && nu == 3) ? solver_lq_kernel<T, 6, 3> : solver_lq_kernel<T, 0, 0>);
+    if (a.use_lds && lds_need > 65536)
+        NEMPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lqk),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+
+    int it = 0, rc;
+    const int check = o.check_every > 0 ? o.check_every : 4;
+    for (; it < o.max_iter; ++it) {
+        // callbacks at the iterate: defects + tiles (row kernel), f + grad (objective kernel)
+        rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, ws.g, ws.tiles, s)
+                                            : launch_rows_valu(h, B, Z, X0, ws.g, ws.tiles, s);
+        if (rc) return rc;
+        if ((rc = launch_objective(h, B, Z, ws.f, ws.grad, s))) return rc;
+        // per-step Lagrangian blocks with the current multipliers (all zero on the first iterate: Gauss-Newton step)
+        rc = (h.variant != NEMPC_KERNEL_VALU && h.cfg.integrator != NEMPC_RK4)
+                 ? launch_rowhess_mfma(h, B, Z, X0, ws.lam, ws.hblk, s)
+                 : launch_rowhess_valu(h, B, Z, X0, ws.lam, ws.hblk, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (B + a.ppw - 1) / a.ppw : (B + 63) / 64), dim3(64), lds_need,
+                           s, a);
+        NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, sizeof(int), s));
+        hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(B), dim3(64), 0, s, a, 0, (const T*)ws.f, (const T*)nullptr,
+                           (const T*)nullptr, (const T*)nullptr, (T*)Z, 0);
+        if ((it + 1) % check == 0 || it + 1 == o.max_iter) {
+            int nact = 0;
+            NEMPC_HIP(hipMemcpyAsync(&nact, ws.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+            NEMPC_HIP(hipStreamSynchronize(s));
+            if (nact == 0) { ++it; break; }
+        }
+        for (int ls = 0; ls < o.max_linesearch; ++ls) {
+            hipLaunchKernelGGL(solver_trial_kernel<T>, dim3(gBn), dim3(256), 0, s, B, n, (const T*)Z, (const T*)ws.dz,
+                               (const T*)ws.alpha, (const int*)ws.lsdone, (T*)ws.Zt);
+            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, ws.Zt, X0, ws.gt, h.d_tiles_ws, s)
+                                                : launch_rows_valu(h, B, ws.Zt, X0, ws.gt, h.d_tiles_ws, s);
+            if (rc) return rc;
+            if ((rc = launch_objective(h, B, ws.Zt, ws.ft, nullptr, s))) return rc;
+            NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, sizeof(int), s));
+            hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(B), dim3(64), 0, s, a, 1, (const T*)ws.f, (const T*)ws.Zt,
+                               (const T*)ws.gt, (const T*)ws.ft, (T*)Z, ls + 1 == o.max_linesearch ? 1 : 0);
+            // most iterations accept the first trial for every problem: one small poll saves the remaining
+            // max_linesearch-1 callback evaluations
+            int pending = 0;
+            NEMPC_HIP(hipMemcpyAsync(&pending, ws.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+            NEMPC_HIP(hipStreamSynchronize(s));
+            if (pending == 0) break;
+        }
+    }
+    hipLaunchKernelGGL(solver_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, status_dev);
+    NEMPC_HIP(hipGetLastError());
+    NEMPC_HIP(hipStreamSynchronize(s));
+    if (iters_host) *iters_host = it;
+    return NEMPC_OK;
+}
+
+int solver_run(Handle& h, int B, const void* X0, void* Z, const double* lb, const double* ub,
+               const nempc_solver_opts& o, int32_t* status_dev, int32_t* iters_host, hipStream_t s) {
+    return h.cfg.dtype == NEMPC_F64 ? solve_typed<double>(h, B, X0, Z, lb, ub, o, status_dev, iters_host, s)
+                                    : solve_typed<float>(h, B, X0, Z, lb, ub, o, status_dev, iters_host, s);
+}
+
+}  // namespace nempc

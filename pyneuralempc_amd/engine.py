@@ -242,6 +242,39 @@ class CallbackEngine:
                                            ptr["hblocks"], self._stream()))
         return res
 
+    def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=100, max_linesearch=6, check_every=2,
+              tol_constraint=1e-8, tol_step=1e-8, mu_init=1e-1, mu_min=1e-9, mu_factor=0.2, reg=1e-9):
+        """Batched on-device solve (Gauss-Newton SQP, see csrc/solver.hip).  X0 (B,nx) device tensor; Z_init (B,n)
+        or None for the reference's cold start [x0 tiled H ; zeros] (optimizer/ipopt.py:149); lb/ub (n) host
+        vectors as DomainConstraint produces them.  Returns (Z (B,n), status (B,) int32 [0 ok / 1 fail], iters)."""
+        B = int(X0.shape[0])
+        self._check_in(X0, (B, self.nx), "X0")
+        self.reserve(B)
+        if Z_init is None:
+            Z = torch.cat([X0.repeat(1, self.H), torch.zeros(B, self.H * self.nu, dtype=self.dtype, device=self.device)],
+                          dim=1).contiguous()
+        else:
+            self._check_in(Z_init, (B, self.n), "Z_init")
+            Z = Z_init.clone()
+        keep, ptrs = [], []
+        for v in (lb, ub):
+            if v is None:
+                ptrs.append(None)
+            else:
+                a, p = _as_c_double(np.broadcast_to(np.asarray(v, dtype=np.float64), (self.n,)))
+                keep.append(a)
+                ptrs.append(p)
+        opts = _lib.NempcSolverOpts(max_iter=max_iter, max_linesearch=max_linesearch, check_every=check_every,
+                                    tol_constraint=tol_constraint, tol_step=tol_step, mu_init=mu_init, mu_min=mu_min,
+                                    mu_factor=mu_factor, reg=reg)
+        status = torch.empty(B, dtype=torch.int32, device=self.device)
+        iters = ctypes.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nempc_solve(self._handle, B, ctypes.c_void_p(X0.data_ptr()), ctypes.c_void_p(Z.data_ptr()),
+                                            ptrs[0], ptrs[1], ctypes.byref(opts), ctypes.c_void_p(status.data_ptr()),
+                                            ctypes.byref(iters), self._stream()))
+        return Z, status, iters.value
+
     def sync(self):
         _lib.check(self.lib.nempc_sync(self._handle, self._stream()))
 
