@@ -176,7 +176,6 @@ def main():
     # ---- batched on-device solver + the one collective of the design: all-gather of the solved u0
     solver_info = None
     if cfg["box"] is None:
-        damp = orc.MLP(net.W, net.b)
         lbv = np.concatenate([np.full(cfg["H"] * cfg["nx"], -3.0), np.full(cfg["H"] * cfg["nu"], -0.5)])
         Xs = eng.to_device(np.random.default_rng(100 + rank).uniform(-0.5, 0.5, size=(B, cfg["nx"])))
         eng.solve(Xs, lb=lbv, ub=-lbv, max_iter=5)   # warm
