@@ -67,26 +67,31 @@ __global__ __launch_bounds__(64) void objective_kernel(int B, int H, int nx, int
     if ((int)blockIdx.x < B) objective_body<T>(blockIdx.x, H, nx, nu, o, P, Z, f, grad);
 }
 
-// grid (ceil(m*n / (2*256)), B); each lane produces two consecutive elements -> one 16-byte (f64) store
+// grid (ceil(m*n / (256 * 16/sizeof(T))), B)
+// each lane produces 16 bytes of consecutive output (2 doubles / 4 floats) -> one dwordx4 store when aligned
 template <typename T>
 __device__ __forceinline__ void assemble_dense_body(int b, int mn, int tile_elems, const int32_t* __restrict__ map,
                                                     const T* __restrict__ tiles, T* __restrict__ jac) {
+    constexpr int NV = 16 / (int)sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(NV)));
     const T* tile = tiles + (size_t)b * tile_elems;
     T* out = jac + (size_t)b * mn;
-    const int e = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
-    if (e + 1 < mn) {
-        const int32_t c0 = map[e], c1 = map[e + 1];
-        const T v0 = map_value<T>(c0, tile), v1 = map_value<T>(c1, tile);
-        if ((reinterpret_cast<uintptr_t>(out + e) & (2 * sizeof(T) - 1)) == 0) {
-            typedef T vec2 __attribute__((ext_vector_type(2)));
-            vec2 v;
-            v.x = v0; v.y = v1;
-            *reinterpret_cast<vec2*>(out + e) = v;
+    const int e = NV * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (e + NV <= mn) {
+        T v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = map_value<T>(map[e + k], tile);
+        if ((reinterpret_cast<uintptr_t>(out + e) & 15) == 0) {
+            vecT vv;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) vv[k] = v[k];
+            *reinterpret_cast<vecT*>(out + e) = vv;
         } else {
-            out[e] = v0; out[e + 1] = v1;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) out[e + k] = v[k];
         }
-    } else if (e < mn) {
-        out[e] = map_value<T>(map[e], tile);
+    } else {
+        for (int k = 0; k < NV && e + k < mn; ++k) out[e + k] = map_value<T>(map[e + k], tile);
     }
 }
 
@@ -151,7 +156,8 @@ int launch_objective(Handle& h, int B, const void* Z, void* f, void* grad, hipSt
 int launch_assemble_dense(Handle& h, int B, const void* tiles, void* jac, hipStream_t s) {
     const int mn = h.m * h.n;
     const int te = h.cfg.H * h.cfg.nx * h.nin;
-    const dim3 block(256), grid((unsigned)((mn + 511) / 512), (unsigned)B);
+    const int per_block = 256 * (16 / (int)h.esz);
+    const dim3 block(256), grid((unsigned)((mn + per_block - 1) / per_block), (unsigned)B);
     if (h.cfg.dtype == NEMPC_F64)
         hipLaunchKernelGGL(assemble_dense_kernel<double>, grid, block, 0, s, mn, te, h.d_dense_map,
                            (const double*)tiles, (double*)jac);
@@ -165,7 +171,8 @@ int launch_assemble_dense(Handle& h, int B, const void* tiles, void* jac, hipStr
 int launch_post(Handle& h, int B, const void* tiles, void* jac, const void* Z, void* f, void* grad, hipStream_t s) {
     const int mn = h.m * h.n;
     const int te = h.cfg.H * h.cfg.nx * h.nin;
-    const int nb = (mn + 511) / 512;
+    const int per_block = 256 * (16 / (int)h.esz);
+    const int nb = (mn + per_block - 1) / per_block;
     ObjOffsets o = obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu);
     const dim3 block(256), grid((unsigned)(nb + 1), (unsigned)B);
     if (h.cfg.dtype == NEMPC_F64)
