@@ -67,8 +67,11 @@ __global__ __launch_bounds__(64) void objective_kernel(int B, int H, int nx, int
     if ((int)blockIdx.x < B) objective_body<T>(blockIdx.x, H, nx, nu, o, P, Z, f, grad);
 }
 
-// grid (ceil(m*n / (256 * 16/sizeof(T))), B)
-// each lane produces 16 bytes of consecutive output (2 doubles / 4 floats) -> one dwordx4 store when aligned
+// grid (ceil(m*n / (256 * kAsmVPT * 16/sizeof(T))), B)
+// each lane produces VPT x 16 bytes (2 doubles / 4 floats per store), the VPT stores of a lane 256 lanes apart so
+// that every store instruction of a wave is contiguous; the map / tile loads of all VPT vectors are issued
+// before the first store (memory-level parallelism instead of one dependent L2 round trip per store)
+constexpr int kAsmVPT = 4;
 template <typename T>
 __device__ __forceinline__ void assemble_dense_body(int b, int mn, int tile_elems, const int32_t* __restrict__ map,
                                                     const T* __restrict__ tiles, T* __restrict__ jac) {
@@ -76,22 +79,32 @@ __device__ __forceinline__ void assemble_dense_body(int b, int mn, int tile_elem
     typedef T vecT __attribute__((ext_vector_type(NV)));
     const T* tile = tiles + (size_t)b * tile_elems;
     T* out = jac + (size_t)b * mn;
-    const int e = NV * (blockIdx.x * blockDim.x + threadIdx.x);
-    if (e + NV <= mn) {
-        T v[NV];
+    const int base = NV * (blockIdx.x * (256 * kAsmVPT) + threadIdx.x);
+    int32_t code[kAsmVPT][NV];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] = map_value<T>(map[e + k], tile);
-        if ((reinterpret_cast<uintptr_t>(out + e) & 15) == 0) {
+    for (int u = 0; u < kAsmVPT; ++u) {
+        const int e = base + u * 256 * NV;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) code[u][k] = (e + k < mn) ? map[e + k] : MAP_ZERO;
+    }
+    T v[kAsmVPT][NV];
+#pragma unroll
+    for (int u = 0; u < kAsmVPT; ++u)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[u][k] = map_value<T>(code[u][k], tile);
+#pragma unroll
+    for (int u = 0; u < kAsmVPT; ++u) {
+        const int e = base + u * 256 * NV;
+        if (e + NV <= mn && (reinterpret_cast<uintptr_t>(out + e) & 15) == 0) {
             vecT vv;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) vv[k] = v[k];
+            for (int k = 0; k < NV; ++k) vv[k] = v[u][k];
             *reinterpret_cast<vecT*>(out + e) = vv;
         } else {
 #pragma unroll
-            for (int k = 0; k < NV; ++k) out[e + k] = v[k];
+            for (int k = 0; k < NV; ++k)
+                if (e + k < mn) out[e + k] = v[u][k];
         }
-    } else {
-        for (int k = 0; k < NV && e + k < mn; ++k) out[e + k] = map_value<T>(map[e + k], tile);
     }
 }
 
@@ -156,7 +169,7 @@ int launch_objective(Handle& h, int B, const void* Z, void* f, void* grad, hipSt
 int launch_assemble_dense(Handle& h, int B, const void* tiles, void* jac, hipStream_t s) {
     const int mn = h.m * h.n;
     const int te = h.cfg.H * h.cfg.nx * h.nin;
-    const int per_block = 256 * (16 / (int)h.esz);
+    const int per_block = 256 * kAsmVPT * (16 / (int)h.esz);
     const dim3 block(256), grid((unsigned)((mn + per_block - 1) / per_block), (unsigned)B);
     if (h.cfg.dtype == NEMPC_F64)
         hipLaunchKernelGGL(assemble_dense_kernel<double>, grid, block, 0, s, mn, te, h.d_dense_map,
@@ -171,7 +184,7 @@ int launch_assemble_dense(Handle& h, int B, const void* tiles, void* jac, hipStr
 int launch_post(Handle& h, int B, const void* tiles, void* jac, const void* Z, void* f, void* grad, hipStream_t s) {
     const int mn = h.m * h.n;
     const int te = h.cfg.H * h.cfg.nx * h.nin;
-    const int per_block = 256 * (16 / (int)h.esz);
+    const int per_block = 256 * kAsmVPT * (16 / (int)h.esz);
     const int nb = (mn + per_block - 1) / per_block;
     ObjOffsets o = obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu);
     const dim3 block(256), grid((unsigned)(nb + 1), (unsigned)B);

@@ -217,6 +217,27 @@ class CallbackEngine:
                                            ptr["jac_dense"], ptr["jac_tiles"], ptr["jac_sparse"], self._stream()))
         return res
 
+    def bind(self, Z, X0, want=("f", "grad", "g", "jac_dense")):
+        """Pre-validated evaluation for hot loops: returns (launch, outputs) where launch() re-evaluates the
+        callbacks at the CURRENT contents of Z / X0 into the fixed `outputs` tensors with one ctypes call (no
+        per-call allocation or checking).  Valid while Z, X0 and the outputs stay alive and the handle is not
+        re-created (reserve / set_box_rows)."""
+        B = int(Z.shape[0])
+        res = self.eval(Z, X0, want)                      # validates, allocates outputs, warms the kernels
+        ptr = {k: (ctypes.c_void_p(res[k].data_ptr()) if k in res else None)
+               for k in ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")}
+        handle, fn = self._handle, self.lib.nempc_eval
+        zp, xp = ctypes.c_void_p(Z.data_ptr()), ctypes.c_void_p(X0.data_ptr())
+        stream = self._stream()
+        args = (handle, B, zp, xp, ptr["f"], ptr["grad"], ptr["g"], ptr["jac_dense"], ptr["jac_tiles"],
+                ptr["jac_sparse"], stream)
+
+        def launch():
+            rc = fn(*args)
+            if rc:
+                _lib.check(rc)
+        return launch, res
+
     def hess(self, Z, X0, lam, sigma, want=("hvals",)):
         """Lagrangian Hessian: hvals (B,nnz_hess) in hess_structure() order, optional hdense (B,n,n)
         and hblocks (B,H,nx+nu,nx+nu)."""

@@ -251,3 +251,22 @@ def test_edge_cases():
         CallbackEngine(net.W, net.b, 4, 3, 1, device="cuda:0")
     with pytest.raises(NempcError):
         CallbackEngine(net.W, net.b, 0, 2, 1, device="cuda:0")
+
+
+def test_bound_launcher_tracks_input_contents():
+    """engine.bind: the pre-validated launcher re-reads Z / X0 each call and writes the same output tensors."""
+    d, W, b = load_case("c2_discret")
+    eng = _engine(d, W, b, torch.float64, "auto")
+    Z, X0 = eng.to_device(d["Z"]), eng.to_device(d["X0"])
+    launch, outs = eng.bind(Z, X0)
+    launch()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(outs["jac_dense"].cpu().numpy(), d["jac"], **F64)
+    Z2, X02 = orc.synthetic_inputs(Z.shape[0], 20, 2, 1, seed=31)
+    Z.copy_(eng.to_device(Z2)); X0.copy_(eng.to_device(X02))
+    launch()
+    torch.cuda.synchronize()
+    prob = oracle_problem(d, W, b)
+    f, grad, g, jac = prob.eval_batch(Z2, X02)
+    np.testing.assert_allclose(outs["jac_dense"].cpu().numpy(), jac, **F64)
+    np.testing.assert_allclose(outs["f"].cpu().numpy(), f, **F64)
