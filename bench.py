@@ -239,7 +239,7 @@ def main():
                        "row_kernel": eng.kernel_variant, "parallelism": f"problem-sharded x{world}"},
             "batch_evals_per_s": args.steps / wall,
             "jacobian_max_abs_err_vs_cpu": errs["jac"], "max_abs_err_vs_cpu": errs,
-            "roofline": {"bound": "mfma", "kernel": f"rows_{eng.kernel_variant}_kernel", "achieved": ach_tf,
+            "roofline": {"bound": "mfma", "kernel": eng.last_row_kernel, "achieved": ach_tf,
                          "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf, "traffic": None,
                          "kernel_us": t_rows * 1e6, "flops_per_launch": work["flops"],
                          "arithmetic_intensity_dense": ai, "ridge": ridge},
@@ -252,7 +252,7 @@ def main():
         if args.config == "c2" and B == 1024 and eng.kernel_variant == "mfma" and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             for k, v in pmc.items():
-                if k.startswith("rows_coop_kernel") and "hbm_traffic_bytes" in v:
+                if k.startswith(str(eng.last_row_kernel)) and "hbm_traffic_bytes" in v:
                     out["roofline"]["traffic"] = v["hbm_traffic_bytes"]
                     out["roofline"]["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch, profiles/r01_c2_b1024_pmc.json; "
                                                        "WRITE_SIZE of this kernel's 8-byte stores is uncalibrated "

@@ -159,6 +159,10 @@ int nempc_sync(nempc_handle h, void* stream);
 /* which row kernel the handle resolved to (NEMPC_KERNEL_VALU | NEMPC_KERNEL_MFMA | NEMPC_KERNEL_MFMA_TILE) */
 int nempc_kernel_variant(nempc_handle h);
 
+/* row kernel the handle's most recent evaluation actually launched: 1 generic (rows_valu_kernel),
+ * 2 cooperative matrix-core (rows_coop_kernel), 3 wave-per-tile matrix-core (rows_mfma_kernel); 0 = none yet */
+int nempc_last_row_kernel(nempc_handle h);
+
 const char* nempc_last_error(void);
 int nempc_abi_version(void);
 

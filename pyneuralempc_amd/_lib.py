@@ -16,7 +16,7 @@ INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
 
 EXPORTS = ["nempc_create", "nempc_destroy", "nempc_set_weights", "nempc_set_objective", "nempc_set_box_rows",
            "nempc_dims", "nempc_constraint_bounds", "nempc_jac_structure", "nempc_hess_structure", "nempc_eval",
-           "nempc_hess", "nempc_solve", "nempc_sync", "nempc_kernel_variant", "nempc_last_error", "nempc_abi_version"]
+           "nempc_hess", "nempc_solve", "nempc_sync", "nempc_kernel_variant", "nempc_last_row_kernel", "nempc_last_error", "nempc_abi_version"]
 
 
 class NempcError(RuntimeError):
@@ -69,6 +69,7 @@ def load():
     lib.nempc_solve.argtypes = [vp, i32, vp, vp, dp, dp, ctypes.POINTER(NempcSolverOpts), vp, ip, vp]
     lib.nempc_sync.argtypes = [vp, vp]
     lib.nempc_kernel_variant.argtypes = [vp]
+    lib.nempc_last_row_kernel.argtypes = [vp]
     lib.nempc_last_error.argtypes = []
     lib.nempc_last_error.restype = ctypes.c_char_p
     lib.nempc_abi_version.argtypes = []

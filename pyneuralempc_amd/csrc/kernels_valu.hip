@@ -464,6 +464,7 @@ size_t valu_workspace_elems(const Handle& h) {
 }
 
 int launch_rows_valu(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s) {
+    h.last_row_kernel = 1;
     const size_t rows = (size_t)B * h.cfg.H;
     const size_t Rcap = (size_t)h.cfg.max_batch * h.cfg.H;
     const dim3 block(256), grid((unsigned)((rows + 255) / 256));

@@ -515,6 +515,11 @@ int nempc_debug_stamps(nempc_handle hh, long long* host_out) {
 }
 #endif
 
+int nempc_last_row_kernel(nempc_handle hh) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_last_row_kernel: null handle");
+    return reinterpret_cast<Handle*>(hh)->last_row_kernel;
+}
+
 int nempc_kernel_variant(nempc_handle hh) {
     if (!hh) return fail(NEMPC_EINVAL, "nempc_kernel_variant: null handle");
     return reinterpret_cast<Handle*>(hh)->variant;

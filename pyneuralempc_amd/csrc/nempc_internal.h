@@ -72,6 +72,7 @@ struct Handle {
     void* d_hess_ws = nullptr;   // (Bmax,H,nin,nin) per-row Lagrangian blocks
     long long* d_dbg = nullptr;  // diagnostic builds only
     void* solver_ws = nullptr;   // solver.hip
+    mutable int last_row_kernel = 0;  // 1 valu, 2 coop, 3 wave-tile
 };
 
 struct ObjOffsets {  // element offsets into Handle::d_obj

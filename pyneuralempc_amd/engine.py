@@ -121,6 +121,12 @@ class CallbackEngine:
         v = self.lib.nempc_kernel_variant(self._handle)
         return {_lib.KERNEL_VALU: "valu", _lib.KERNEL_MFMA: "mfma", _lib.KERNEL_MFMA_TILE: "mfma_tile"}[v]
 
+    @property
+    def last_row_kernel(self):
+        """Name of the row kernel the most recent evaluation launched."""
+        return {0: None, 1: "rows_valu_kernel", 2: "rows_coop_kernel", 3: "rows_mfma_kernel"}[
+            self.lib.nempc_last_row_kernel(self._handle)]
+
     # ------------------------------------------------------------------ parameters
     def set_objective(self, Q=None, R=None, xref=None, uref=None, cx=None, cu=None):
         H, nx, nu = self.H, self.nx, self.nu
