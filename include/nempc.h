@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define NEMPC_ABI_VERSION 1
+#define NEMPC_ABI_VERSION 2
 #define NEMPC_MAX_LAYERS 8 /* dense layers incl. the linear output layer */
 
 /* status codes */
@@ -75,7 +75,9 @@ typedef struct nempc_config {
     int32_t widths[NEMPC_MAX_LAYERS]; /* output width of each layer; widths[n_layers-1] == nx */
     int32_t max_batch;                /* capacity B_max of the workspaces */
     int32_t kernel;                   /* NEMPC_KERNEL_* */
-    int32_t reserved;
+    int32_t n_extra;                  /* extra per-step network inputs after [x | u]: tvp_dim + p_dim of the reference's
+                                         Model (model/tensorflow.py:39-47); they feed the network but are not decision
+                                         variables: no Jacobian / Hessian columns (tensorflow.py:65-66). 0 = none */
     double DT;                        /* RK4 step (RK4Integrator.DT, rk4.py:49) */
 } nempc_config;
 
@@ -93,6 +95,12 @@ int nempc_set_weights(nempc_handle h, const double* const* W, const double* cons
  * Q NULL = identity, R NULL = 0.1*identity, the SURVEY 8(d) defaults). Host doubles. */
 int nempc_set_objective(nempc_handle h, const double* Q, const double* R, const double* xref,
                         const double* uref, const double* cx, const double* cu);
+
+/* bind the extra network inputs for subsequent nempc_eval / nempc_hess / nempc_solve calls: E (B,H,n_extra) device,
+ * dtype of the handle, row t of problem b = [tvp_t ; p] (time-varying parameters then constant parameters, the
+ * concatenation order of KerasTFModel._gather_input).  The pointer is stored, not copied; required when
+ * n_extra > 0.  */
+int nempc_bind_extra(nempc_handle h, const void* E);
 
 /* extra constraint rows g_box = states.ravel() (a Constraint in the sense of constraints.py:36-63
  * with constant selector Jacobian); lo/hi (nx) host doubles are only reported back through

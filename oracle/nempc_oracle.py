@@ -123,7 +123,7 @@ class MLP:
 # --------------------------------------------------------------------------------------
 # One-step map Phi(x_prev, u) and its per-row derivatives (tiles), for the three integrators
 # --------------------------------------------------------------------------------------
-def step_rows(net: MLP, kind: int, DT: float, x_prev, u, want_hess=False):
+def step_rows(net: MLP, kind: int, DT: float, x_prev, u, want_hess=False, extra=None):
     """Rows (R,nx),(R,nu) -> Phi (R,nx), dPhi (R,nx,nx+nu) [, d2Phi (R,nx,nx+nu,nx+nu)].
 
     DISCRET: Phi = x + f(x,u)          integrator/discret.py:27
@@ -144,12 +144,15 @@ def step_rows(net: MLP, kind: int, DT: float, x_prev, u, want_hess=False):
     Ex = np.zeros((nx, nin))
     Ex[:, :nx] = np.eye(nx)
 
+    # extra (R, ne): per-row network inputs after [x | u] -- [tvp_t ; p] in the reference's concatenation order
+    # (model/tensorflow.py:39-47); they get no derivative columns (tensorflow.py:65-66)
     def net_eval(xs):
-        xi = np.concatenate([xs, u], axis=1)
+        xi = np.concatenate([xs, u] + ([np.asarray(extra, dtype=np.float64)] if extra is not None else []), axis=1)
         if want_hess:
-            return net.forward_jac_hess(xi)
+            f, J, S = net.forward_jac_hess(xi)
+            return f, J[:, :, :nin], S[:, :, :nin, :nin]
         f, J = net.forward_jac(xi)
-        return f, J, None
+        return f, J[:, :, :nin], None
 
     if kind in (DISCRET, UNITY):
         f, J, Hs = net_eval(x_prev)
@@ -198,8 +201,9 @@ class Problem:
     """
 
     def __init__(self, net, H, nx, nu, kind=DISCRET, DT=1.0, Q=None, R=None, xref=None, uref=None,
-                 cx=None, cu=None, box=None):
-        assert net.n_in == nx + nu and net.n_out == nx
+                 cx=None, cu=None, box=None, extra=None):
+        self.extra = None if extra is None else np.asarray(extra, dtype=np.float64).reshape(H, -1)
+        assert net.n_in == nx + nu + (0 if self.extra is None else self.extra.shape[1]) and net.n_out == nx
         self.net, self.H, self.nx, self.nu, self.kind, self.DT = net, H, nx, nu, kind, float(DT)
         self.n = H * (nx + nu)
         self.Q = np.eye(nx) if Q is None else np.asarray(Q, dtype=np.float64).reshape(nx, nx)
@@ -251,7 +255,7 @@ class Problem:
     def tiles(self, z, x0, want_hess=False):
         x, u = self.split(z)
         x_prev = np.concatenate([np.asarray(x0, dtype=np.float64).reshape(1, -1), x[:-1]], axis=0)
-        phi, dphi, d2phi = step_rows(self.net, self.kind, self.DT, x_prev, u, want_hess)
+        phi, dphi, d2phi = step_rows(self.net, self.kind, self.DT, x_prev, u, want_hess, extra=self.extra)
         return x, phi, dphi, d2phi
 
     # ---- optimizer/ipopt.py:44-52 ; integrator/discret.py:13-30

@@ -94,7 +94,8 @@ struct CoopCtx {
     const T* X0;
     T* gout;
     T* tiles;
-    int nx, nu, nin, H, n, m, NR, jsz, spt, nstages, ks, kind, box, xt_off, inv_nin;
+    int nx, nu, nin, H, n, m, NR, jsz, spt, nstages, ks, kind, box, xt_off, ex_off, ne, inv_nin;
+    const T* extra;
     unsigned inv32_jrow, inv32_nx;
     int xhalf;                      // elements per half of the double-buffered exchange area  // ceil(2^32 / d) for d >= 2: item / d == umulhi(item, inv32) while item * d < 2^32
     size_t R;
@@ -116,7 +117,7 @@ struct StageRegs {
 template <typename T, int MT, int TPW>
 __device__ __forceinline__ void stage_load(const CoopCtx<T>& cx, int t0, int nrows, int tid, StageRegs<T, MT, TPW>& sr) {
     constexpr int ROWS = TPW * 16, NTHREADS = MT * 64;
-    const int ncol = cx.nin + cx.nx;
+    const int ncol = cx.nin + cx.nx + cx.ne;
 #pragma unroll
     for (int it = 0; it < StageRegs<T, MT, TPW>::ITEMS; ++it) {
         const int item = tid + it * NTHREADS;
@@ -130,7 +131,8 @@ __device__ __forceinline__ void stage_load(const CoopCtx<T>& cx, int t0, int nro
             const T* z = cx.Z + (size_t)b * cx.n;
             if (col < cx.nx) v = (t == 0) ? cx.X0[(size_t)b * cx.nx + col] : z[(t - 1) * cx.nx + col];
             else if (col < cx.nin) v = z[cx.H * cx.nx + t * cx.nu + (col - cx.nx)];
-            else v = z[t * cx.nx + (col - cx.nin)];
+            else if (col < cx.nin + cx.nx) v = z[t * cx.nx + (col - cx.nin)];
+            else v = cx.extra[r * cx.ne + (col - cx.nin - cx.nx)];
         }
         sr.v[it] = v; sr.b[it] = b; sr.t[it] = t;
     }
@@ -139,7 +141,7 @@ __device__ __forceinline__ void stage_load(const CoopCtx<T>& cx, int t0, int nro
 template <typename T, int MT, int TPW>
 __device__ __forceinline__ void stage_store(const CoopCtx<T>& cx, int nrows, int tid, const StageRegs<T, MT, TPW>& sr) {
     constexpr int ROWS = TPW * 16, NTHREADS = MT * 64;
-    const int ncol = cx.nin + cx.nx;
+    const int ncol = cx.nin + cx.nx + cx.ne;
 #pragma unroll
     for (int it = 0; it < StageRegs<T, MT, TPW>::ITEMS; ++it) {
         const int item = tid + it * NTHREADS;
@@ -147,7 +149,8 @@ __device__ __forceinline__ void stage_store(const CoopCtx<T>& cx, int nrows, int
         if (col < ncol && idx < nrows) {
             T* tile = cx.SCR + (idx >> 4) * cx.spt;
             if (col < cx.nin) tile[(idx & 15) * cx.nin + col] = sr.v[it];
-            else tile[cx.xt_off + (idx & 15) * cx.nx + (col - cx.nin)] = sr.v[it];
+            else if (col < cx.nin + cx.nx) tile[cx.xt_off + (idx & 15) * cx.nx + (col - cx.nin)] = sr.v[it];
+            else tile[cx.ex_off + (idx & 15) * cx.ne + (col - cx.nin - cx.nx)] = sr.v[it];
             if (col == 0) { cx.RI[2 * idx] = sr.b[it]; cx.RI[2 * idx + 1] = sr.t[it]; }
         }
     }
@@ -157,7 +160,7 @@ __device__ __forceinline__ void stage_store(const CoopCtx<T>& cx, int nrows, int
 template <typename T, int MT, int TPW>
 __device__ __forceinline__ void stage_direct(const CoopCtx<T>& cx, int t0, int nrows, int tid) {
     constexpr int ROWS = TPW * 16, NTHREADS = MT * 64;
-    const int ncol = cx.nin + cx.nx;
+    const int ncol = cx.nin + cx.nx + cx.ne;
     for (int item = tid; item < ncol * ROWS; item += NTHREADS) {
         const int col = item / ROWS, idx = item - col * ROWS;
         if (idx >= nrows) continue;
@@ -170,11 +173,13 @@ __device__ __forceinline__ void stage_direct(const CoopCtx<T>& cx, int t0, int n
             const T* z = cx.Z + (size_t)b * cx.n;
             if (col < cx.nx) v = (t == 0) ? cx.X0[(size_t)b * cx.nx + col] : z[(t - 1) * cx.nx + col];
             else if (col < cx.nin) v = z[cx.H * cx.nx + t * cx.nu + (col - cx.nx)];
-            else v = z[t * cx.nx + (col - cx.nin)];
+            else if (col < cx.nin + cx.nx) v = z[t * cx.nx + (col - cx.nin)];
+            else v = cx.extra[r * cx.ne + (col - cx.nin - cx.nx)];
         }
         T* tile = cx.SCR + (idx >> 4) * cx.spt;
         if (col < cx.nin) tile[(idx & 15) * cx.nin + col] = v;
-        else tile[cx.xt_off + (idx & 15) * cx.nx + (col - cx.nin)] = v;
+        else if (col < cx.nin + cx.nx) tile[cx.xt_off + (idx & 15) * cx.nx + (col - cx.nin)] = v;
+        else tile[cx.ex_off + (idx & 15) * cx.ne + (col - cx.nin - cx.nx)] = v;
         if (col == 0) { cx.RI[2 * idx] = b; cx.RI[2 * idx + 1] = t; }
     }
 }
@@ -225,6 +230,8 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                     if (d < nin) {
                         v = s_xi0[c * nin + d];
                         if (stage > 0 && d < nx) v = fma(cdt, s_xi0[16 * nin + c * nx + d], v);
+                    } else if (d < nin + cx.ne) {
+                        v = s_xi0[cx.ex_off + c * cx.ne + (d - nin)];
                     }
                     a[0][j] = Ops::mma(wfrag, v, a[0][j]);
                 }
@@ -462,6 +469,9 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams
     cx.jsz = 16 * p.nx * p.nin;
     cx.spt = p.scratch_per_wave;
     cx.xt_off = 16 * p.nin + 2 * 16 * p.nx + 4 * cx.jsz;  // after the wave-tile kernel's carve-up
+    cx.ex_off = cx.xt_off + 16 * p.nx;                    // [16][ne] extra inputs
+    cx.ne = p.ne;
+    cx.extra = static_cast<const T*>(p.extra);
     cx.inv32_jrow = (unsigned)((0x100000000ull + (unsigned)(p.nx * p.nin) - 1) / (unsigned)(p.nx * p.nin));
     cx.inv32_nx = (unsigned)((0x100000000ull + (unsigned)p.nx - 1) / (unsigned)p.nx);
     cx.inv_nin = (65536 + p.nin - 1) / p.nin;              // kd / nin == (kd * inv_nin) >> 16 for kd < 256
@@ -480,7 +490,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams
     StageRegs<T, MT, TPW> sr;
     int t0 = t_begin;
     int nact = t_end - t0 < TPW ? t_end - t0 : TPW;
-    const bool early = (cx.nin + cx.nx) * TPW * 16 <= StageRegs<T, MT, TPW>::ITEMS * NTHREADS;
+    const bool early = (cx.nin + cx.nx + cx.ne) * TPW * 16 <= StageRegs<T, MT, TPW>::ITEMS * NTHREADS;
     if (early) stage_load<T, MT, TPW>(cx, t0, nact * 16, tid, sr);
     // small tables -> LDS ...
     copy_blob_to_lds<T>(gblob + p.off.w0f, lds + lay.w0f, p.ks * MT * 64, tid, NTHREADS);

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
     T* s_xi0 = scratch;
     T* s_lam = s_xi0 + 16 * nin;
     T* s_H = s_lam + 16 * nx;
+    T* s_ex = s_H + 16 * nin * nin;   // [16][ne] extra inputs
 
     for (int tile = blockIdx.x * nwaves + wave; tile < p.ntiles; tile += gridDim.x * nwaves) {
         const size_t row0 = (size_t)tile * 16;
@@ -79,6 +80,11 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
             if (d < nin) s_xi0[cc * nin + d] = v;
             else s_lam[cc * nx + (d - nin)] = v;
         }
+        for (int e = lane; e < 16 * p.ne; e += 64) {
+            const int cc = e / p.ne, j = e - cc * p.ne;
+            const size_t r = row0 + cc;
+            s_ex[e] = (r < R) ? static_cast<const T*>(p.extra)[r * p.ne + j] : T(0);
+        }
         wave_sync();
 
         // ---- forward values
@@ -88,7 +94,8 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int d = 4 * ks + q;
-                xin[ks] = (ks < p.ks && d < nin) ? s_xi0[c * nin + d] : T(0);
+                xin[ks] = (ks < p.ks && d < nin) ? s_xi0[c * nin + d]
+                                                  : ((ks < p.ks && d < nin + p.ne) ? s_ex[c * p.ne + (d - nin)] : T(0));
             }
             const T* bias = wsrc + p.off.bias[0];
 #pragma unroll

@@ -37,7 +37,7 @@ MfmaOffsets make_offsets(int wp, int nh, int ks, int nx, int nin) {
 
 int scratch_elems(const Handle& h) {
     const int nx = h.cfg.nx, nin = h.nin;
-    return 16 * nin + 2 * 16 * nx + 4 * 16 * nx * nin + 16 * nx;  // last 16*nx: x_t slot of the cooperative kernel
+    return 16 * nin + 2 * 16 * nx + 4 * 16 * nx * nin + 16 * nx + 16 * h.ne;  // + x_t slot (cooperative kernel) + extra inputs
 }
 
 }  // namespace
@@ -45,7 +45,7 @@ int scratch_elems(const Handle& h) {
 bool mfma_supported(const Handle& h) {
     const int nh = h.nl - 1;
     if (nh < 1 || nh > 3) return false;
-    if (h.cfg.nx > 16 || h.nin > 16) return false;
+    if (h.cfg.nx > 16 || h.nin + h.ne > 16) return false;
     return padded_width(h) != 0;
 }
 
@@ -60,7 +60,7 @@ void mfma_free(Handle& h) {
 // (f64: kq + 4r, f32: 4kq + r), so that accumulator register r of tile mt is the matching B operand.
 int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b) {
     const int wp = padded_width(h), nh = h.nl - 1, MT = wp / 16;
-    const int nx = h.cfg.nx, nin = h.nin, ks = (nin + 3) / 4, L = h.nl - 1;
+    const int nx = h.cfg.nx, nin = h.nin, ks = (nin + h.ne + 3) / 4, L = h.nl - 1;
     const bool f64 = h.cfg.dtype == NEMPC_F64;
     auto row = [&](int q, int r) { return f64 ? MfmaOps<double>::row(q, r) : MfmaOps<float>::row(q, r); };
     const MfmaOffsets o = make_offsets(wp, nh, ks, nx, nin);
@@ -128,7 +128,8 @@ int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, v
     }
     MfmaParams p{};
     p.blob = h.mfma.blob;
-    p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + 3) / 4;
+    p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4;
+    p.ne = h.ne; p.extra = h.d_extra;
     p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin);
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
@@ -149,13 +150,14 @@ int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const v
     HessParams hp{};
     MfmaParams& p = hp.base;
     p.blob = h.mfma.blob;
-    p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + 3) / 4;
+    p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4;
+    p.ne = h.ne; p.extra = h.d_extra;
     p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin);
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
     p.Z = Z; p.X0 = X0; p.g = nullptr; p.tiles = nullptr;
     p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
-    p.scratch_per_wave = (16 * h.nin + 16 * h.cfg.nx + 16 * h.nin * h.nin + 1) & ~1;
+    p.scratch_per_wave = (16 * h.nin + 16 * h.cfg.nx + 16 * h.nin * h.nin + 16 * h.ne + 1) & ~1;
     p.dbg = nullptr;
     hp.lambda = lambda; hp.blocks = blocks;
     hp.p0tab = p.off.p0tab; hp.wLb = p.off.wLb; hp.ksx = (h.cfg.nx + 3) / 4;

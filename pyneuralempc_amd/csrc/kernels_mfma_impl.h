@@ -34,7 +34,9 @@ struct MfmaOffsets {  // element offsets into the packed blob
 struct MfmaParams {
     const void* blob;
     MfmaOffsets off;
-    int nx, nu, nin, ks;  // ks = padded-input k-steps (ceil(nin/4))
+    int nx, nu, nin, ks;  // ks = padded-input k-steps (ceil((nin+ne)/4))
+    int ne;               // extra network inputs per row (tvp, p); no Jacobian columns
+    const void* extra;    // (B,H,ne) or null
     int kind;
     double DT;
     int B, H, m, box;
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
     T* s_dk = s_J + jsz;
     T* s_accdk = s_dk + jsz;
     T* s_dkn = s_accdk + jsz;
+    T* s_ex = s_dkn + jsz + 16 * nx;   // [16][ne] extra inputs (after the cooperative kernel's x_t slot)
 
     for (int tile = blockIdx.x * nwaves + wave; tile < p.ntiles; tile += gridDim.x * nwaves) {
         const size_t row0 = (size_t)tile * 16;
@@ -261,6 +264,11 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
             }
             s_xi0[e] = v;
         }
+        for (int e = lane; e < 16 * p.ne; e += 64) {
+            const int cc = e / p.ne, j = e - cc * p.ne;
+            const size_t r = row0 + cc;
+            s_ex[e] = (r < R) ? static_cast<const T*>(p.extra)[r * p.ne + j] : T(0);
+        }
         wave_sync();
 
         for (int stage = 0; stage < nstages; ++stage) {
@@ -274,6 +282,8 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
                 if (ks < p.ks && d < nin) {
                     v = s_xi0[c * nin + d];
                     if (stage > 0 && d < nx) v = fma(cdt, s_k[c * nx + d], v);
+                } else if (ks < p.ks && d < nin + p.ne) {
+                    v = s_ex[c * p.ne + (d - nin)];
                 }
                 xin[ks] = v;
             }

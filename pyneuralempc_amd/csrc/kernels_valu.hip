@@ -17,7 +17,8 @@ namespace nempc {
 namespace {
 
 struct NetDev {
-    int nl, nin, nx, nu, maxw;
+    int nl, nin, nx, nu, maxw, ne;   // nin = nx+nu decision inputs; the network reads nin + ne values per row
+    const void* extra;               // (B,H,ne) or null
     int din[NEMPC_MAX_LAYERS], dout[NEMPC_MAX_LAYERS];
     const void* W[NEMPC_MAX_LAYERS];
     const void* Wt[NEMPC_MAX_LAYERS];
@@ -31,7 +32,7 @@ struct WsOff {  // slot offsets (multiply by Rcap)
 WsOff ws_offsets(const Handle& h) {
     WsOff o;
     int nhid = h.nl - 1, p = 0;
-    o.xi = p; p += h.nin;
+    o.xi = p; p += h.nin + h.ne;
     o.act = p; p += nhid * h.maxw;
     o.cot = p; p += 2 * h.maxw;
     o.fout = p; p += h.cfg.nx;
@@ -140,7 +141,7 @@ __device__ void net_jacobian_row(const NetDev& net, T* ws, const WsOff& o, size_
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if (ib + q < win) {
+                if (ib + q < win && (!first || ib + q < net.nin)) {   // extra inputs (tvp, p) get no Jacobian column
                     T v = acc[q];
                     if (!first) {
                         const T av = aprev[(size_t)(ib + q) * R + r];
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(256) void rows_valu_kernel(NetDev net, WsOff o, int
     T* xi = ws + (size_t)o.xi * R;
     for (int i = 0; i < nx; ++i) xi[(size_t)i * R + r] = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
     for (int j = 0; j < nu; ++j) xi[(size_t)(nx + j) * R + r] = z[H * nx + t * nu + j];
+    for (int j = 0; j < net.ne; ++j) xi[(size_t)(nin + j) * R + r] = ((const T*)net.extra)[((size_t)b * H + t) * net.ne + j];
 
     T* fout = ws + (size_t)o.fout * R;
     T* jst = ws + (size_t)o.jst * R;
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(256) void rowhess_valu_kernel(NetDev net, WsOff o, 
     T* xi = ws + (size_t)o.xi * R;
     for (int i = 0; i < nx; ++i) xi[(size_t)i * R + r] = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
     for (int j = 0; j < nu; ++j) xi[(size_t)(nx + j) * R + r] = z[H * nx + t * nu + j];
+    for (int j = 0; j < net.ne; ++j) xi[(size_t)(nin + j) * R + r] = ((const T*)net.extra)[((size_t)b * H + t) * net.ne + j];
     if (kind != NEMPC_RK4) {
         net_hessian_contracted<T>(net, ws, o, R, r, lrow, 1, blk, 1);
         return;
@@ -450,6 +453,7 @@ __global__ __launch_bounds__(256) void rowhess_valu_kernel(NetDev net, WsOff o, 
 NetDev make_netdev(const Handle& h) {
     NetDev nd{};
     nd.nl = h.nl; nd.nin = h.nin; nd.nx = h.cfg.nx; nd.nu = h.cfg.nu; nd.maxw = h.maxw;
+    nd.ne = h.ne; nd.extra = h.d_extra;
     for (int l = 0; l < h.nl; ++l) {
         nd.din[l] = h.din[l]; nd.dout[l] = h.dout[l];
         nd.W[l] = h.d_W[l]; nd.Wt[l] = h.d_Wt[l]; nd.b[l] = h.d_b[l];

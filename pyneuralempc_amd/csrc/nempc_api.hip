@@ -247,6 +247,7 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
     for (int l = 0; l < cfg->n_layers; ++l)
         if (cfg->widths[l] < 1) return fail(NEMPC_EINVAL, "nempc_create: layer width must be >= 1");
     if (cfg->max_batch < 1) return fail(NEMPC_EINVAL, "nempc_create: max_batch must be >= 1");
+    if (cfg->n_extra < 0) return fail(NEMPC_EINVAL, "nempc_create: n_extra must be >= 0");
     if (cfg->kernel < NEMPC_KERNEL_AUTO || cfg->kernel > NEMPC_KERNEL_MFMA_TILE)
         return fail(NEMPC_EINVAL, "nempc_create: bad kernel selector");
     if (cfg->integrator == NEMPC_RK4 && !(cfg->DT > 0.0)) return fail(NEMPC_EINVAL, "nempc_create: RK4 needs DT > 0");
@@ -262,11 +263,12 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
     h->cfg = *cfg;
     h->esz = cfg->dtype == NEMPC_F64 ? 8 : 4;
     h->nin = cfg->nx + cfg->nu;
+    h->ne = cfg->n_extra;
     h->n = cfg->H * h->nin;
     h->nl = cfg->n_layers;
     h->maxw = 1;
     for (int l = 0; l < h->nl; ++l) {
-        h->din[l] = l == 0 ? h->nin : cfg->widths[l - 1];
+        h->din[l] = l == 0 ? h->nin + h->ne : cfg->widths[l - 1];
         h->dout[l] = cfg->widths[l];
         if (l < h->nl - 1 && h->dout[l] > h->maxw) h->maxw = h->dout[l];
     }
@@ -368,6 +370,14 @@ int nempc_set_objective(nempc_handle hh, const double* Q, const double* R, const
     return upload_objective(h, o);
 }
 
+int nempc_bind_extra(nempc_handle hh, const void* E) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_bind_extra: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    if (h.ne == 0 && E) return fail(NEMPC_EINVAL, "nempc_bind_extra: the handle was created with n_extra = 0");
+    h.d_extra = E;
+    return NEMPC_OK;
+}
+
 int nempc_set_box_rows(nempc_handle hh, int enabled, const double* lo, const double* hi) {
     if (!hh) return fail(NEMPC_EINVAL, "nempc_set_box_rows: null handle");
     Handle& h = *reinterpret_cast<Handle*>(hh);
@@ -434,6 +444,7 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
     const bool need_rows = g || jac_dense || jac_tiles || jac_sparse;
     if (need_rows && !X0) return fail(NEMPC_EINVAL, "nempc_eval: X0 is null");
     if (need_rows && !h.have_weights) return fail(NEMPC_ESTATE, "nempc_eval: call nempc_set_weights first");
+    if (need_rows && h.ne > 0 && !h.d_extra) return fail(NEMPC_ESTATE, "nempc_eval: n_extra > 0 but nempc_bind_extra was not called");
     DeviceGuard dg(h.cfg.device);
     if (!dg.ok) return fail(NEMPC_EHIP, "nempc_eval: hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -460,6 +471,7 @@ int nempc_hess(nempc_handle hh, int32_t B, const void* Z, const void* X0, const 
     if (B == 0) return NEMPC_OK;
     if (!Z || !X0 || !lambda || !sigma) return fail(NEMPC_EINVAL, "nempc_hess: null input");
     if (!h.have_weights) return fail(NEMPC_ESTATE, "nempc_hess: call nempc_set_weights first");
+    if (h.ne > 0 && !h.d_extra) return fail(NEMPC_ESTATE, "nempc_hess: n_extra > 0 but nempc_bind_extra was not called");
     DeviceGuard dg(h.cfg.device);
     if (!dg.ok) return fail(NEMPC_EHIP, "nempc_hess: hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -482,6 +494,7 @@ int nempc_solve(nempc_handle hh, int32_t B, const void* X0, void* Z, const doubl
     if (B == 0) { if (iters) *iters = 0; return NEMPC_OK; }
     if (!X0 || !Z || !opts || !status) return fail(NEMPC_EINVAL, "nempc_solve: null argument");
     if (!h.have_weights) return fail(NEMPC_ESTATE, "nempc_solve: call nempc_set_weights first");
+    if (h.ne > 0 && !h.d_extra) return fail(NEMPC_ESTATE, "nempc_solve: n_extra > 0 but nempc_bind_extra was not called");
     if (h.box) return fail(NEMPC_EUNSUPPORTED, "nempc_solve: box rows are not handled; pass state bounds as lb/ub");
     if (opts->max_iter < 1 || opts->max_linesearch < 1 || !(opts->mu_factor > 0.0 && opts->mu_factor < 1.0) ||
         !(opts->mu_init > 0.0) || !(opts->mu_min > 0.0))

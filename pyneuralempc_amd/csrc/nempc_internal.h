@@ -39,6 +39,8 @@ struct MfmaNet {
 struct Handle {
     nempc_config cfg{};
     int n = 0, m = 0, nin = 0, nl = 0;
+    int ne = 0;                  // extra network inputs (tvp + p); the network's input width is nin + ne
+    const void* d_extra = nullptr;  // bound by nempc_bind_extra, (B,H,ne)
     int din[NEMPC_MAX_LAYERS]{}, dout[NEMPC_MAX_LAYERS]{};
     int maxw = 0;
     bool box = false;

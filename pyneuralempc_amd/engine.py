@@ -22,7 +22,7 @@ def _as_c_double(a):
 
 class CallbackEngine:
     def __init__(self, weights, biases, H, nx, nu, integrator="discret", DT=1.0, dtype=torch.float64,
-                 device="cuda", max_batch=1, kernel="auto"):
+                 device="cuda", max_batch=1, kernel="auto", n_extra=0):
         if not torch.cuda.is_available():
             raise RuntimeError("pyneuralempc_amd needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -36,6 +36,8 @@ class CallbackEngine:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.dtype = dtype
         self.H, self.nx, self.nu, self.nin = int(H), int(nx), int(nu), int(nx) + int(nu)
+        self.n_extra = int(n_extra)   # tvp_dim + p_dim of the reference's Model: network inputs that are not variables
+        self._extra = None
         self.integrator = integrator if isinstance(integrator, int) else _lib.INTEGRATOR_IDS[integrator]
         self.DT = float(DT)
         self.kernel = kernel
@@ -45,7 +47,7 @@ class CallbackEngine:
             raise ValueError("weights and biases must be non-empty lists of equal length")
         if len(self._weights) > _lib.MAX_LAYERS:
             raise ValueError(f"at most {_lib.MAX_LAYERS} dense layers are supported")
-        prev = self.nin
+        prev = self.nin + self.n_extra
         for w, b in zip(self._weights, self._biases):
             if w.ndim != 2 or w.shape[0] != prev or b.shape != (w.shape[1],):
                 raise ValueError("layer shapes do not chain: expected kernel (in,out) and bias (out,)")
@@ -74,6 +76,7 @@ class CallbackEngine:
             cfg.widths[i] = w.shape[1]
         cfg.max_batch = max_batch
         cfg.kernel = _lib.KERNEL_NAMES[self.kernel] if isinstance(self.kernel, str) else int(self.kernel)
+        cfg.n_extra = self.n_extra
         cfg.DT = self.DT
         h = ctypes.c_void_p()
         _lib.check(self.lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)))
@@ -88,6 +91,8 @@ class CallbackEngine:
             self.set_objective(**self._objective)
         if self._box is not None:
             self.set_box_rows(*self._box)
+        if self._extra is not None:
+            _lib.check(self.lib.nempc_bind_extra(self._handle, ctypes.c_void_p(self._extra.data_ptr())))
         self._refresh_dims()
         self._buffers = {}
 
@@ -142,6 +147,20 @@ class CallbackEngine:
         _lib.check(self.lib.nempc_set_objective(self._handle, *ptrs))
         self._objective = dict(Q=Q, R=R, xref=xref, uref=uref, cx=cx, cu=cu)
         self._refresh_dims()
+
+    def bind_extra(self, E):
+        """Bind the extra network inputs (B,H,n_extra) = [tvp_t ; p] per step for the following evaluations
+        (reference: KerasTFModel._gather_input, model/tensorflow.py:39-47).  The tensor is kept alive here."""
+        if self.n_extra == 0:
+            raise ValueError("this engine was created with n_extra = 0")
+        if E.device != self.device or E.dtype != self.dtype or E.dim() != 3 or tuple(E.shape[1:]) != (self.H, self.n_extra):
+            raise ValueError(f"extra inputs must be a {self.dtype} tensor (B,{self.H},{self.n_extra}) on {self.device}")
+        self._extra = E.contiguous()
+        _lib.check(self.lib.nempc_bind_extra(self._handle, ctypes.c_void_p(self._extra.data_ptr())))
+
+    def _check_extra(self, B):
+        if self.n_extra and (self._extra is None or self._extra.shape[0] < B):
+            raise ValueError("n_extra > 0: call bind_extra with a (B,H,n_extra) tensor covering the batch first")
 
     def set_box_rows(self, lo, hi):
         if lo is None:
@@ -202,6 +221,7 @@ class CallbackEngine:
         B = int(Z.shape[0])
         self._check_in(Z, (B, self.n), "Z")
         self._check_in(X0, (B, self.nx), "X0")
+        self._check_extra(B)
         self.reserve(B)
         shapes = {"f": (B,), "grad": (B, self.n), "g": (B, self.m), "jac_dense": (B, self.m, self.n),
                   "jac_tiles": (B, self.H, self.nx, self.nin), "jac_sparse": (B, self.nnz_jac)}
@@ -252,6 +272,7 @@ class CallbackEngine:
         self._check_in(X0, (B, self.nx), "X0")
         self._check_in(lam, (B, self.m), "lam")
         self._check_in(sigma, (B,), "sigma")
+        self._check_extra(B)
         self.reserve(B)
         shapes = {"hvals": (B, self.nnz_hess), "hdense": (B, self.n, self.n),
                   "hblocks": (B, self.H, self.nin, self.nin)}

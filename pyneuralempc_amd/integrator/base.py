@@ -80,28 +80,31 @@ class DeviceIntegrator(Integrator):
         self._engine.reserve(max_batch)
         return self._engine
 
-    def _pack(self, x, u, x0):
+    def _pack(self, x, u, x0, p=None, tvp=None):
         assert len(x.shape) == 2 and len(u.shape) == 2, "x and u tensor must have dim 2"
         assert len(x0.shape) == 1, "x0 shape must have dim 1"
         eng = self.engine(1)
+        ex = self.model.gather_extra(self.H, p, tvp)
+        if ex is not None:
+            eng.bind_extra(eng.to_device(ex[None]))
         z = np.concatenate([np.asarray(x, dtype=np.float64).reshape(-1), np.asarray(u, dtype=np.float64).reshape(-1)])
         return eng, eng.to_device(z[None, :]), eng.to_device(np.asarray(x0, dtype=np.float64)[None, :])
 
     # -- reference signatures (one problem, NumPy in / out) ---------------------------------
     def forward(self, x, u, x0, p=None, tvp=None):
-        eng, Z, X0 = self._pack(x, u, x0)
+        eng, Z, X0 = self._pack(x, u, x0, p, tvp)
         g = eng.eval(Z, X0, want=("g",))["g"]
         return g[0, :self.nb_contraints].to("cpu", torch.float64).numpy()
 
     def jacobian(self, x, u, x0, p=None, tvp=None):
-        eng, Z, X0 = self._pack(x, u, x0)
+        eng, Z, X0 = self._pack(x, u, x0, p, tvp)
         J = eng.eval(Z, X0, want=("jac_dense",))["jac_dense"]
         return J[0, :self.nb_contraints].to("cpu", torch.float64).numpy()
 
     def hessian(self, x, u, x0, p=None, tvp=None):
         """(H*nx, n, n) like integrator/discret.py:61-81: one device call per constraint row block
         (one-hot multipliers); meant for inspection, the solver path uses the contracted form."""
-        eng, Z, X0 = self._pack(x, u, x0)
+        eng, Z, X0 = self._pack(x, u, x0, p, tvp)
         n, m = eng.n, eng.m
         out = np.zeros((self.nb_contraints, n, n))
         sigma = torch.zeros(1, dtype=eng.dtype, device=eng.device)

@@ -137,6 +137,7 @@ class _FusedEvaluator:
 
     def __init__(self, integrator, objective, box):
         model = integrator.model
+        self.model = model
         self.engine = model.make_engine(integrator.H, integrator.KIND, DT=integrator.DT, max_batch=1)
         self.engine.set_objective(**objective.resolved(integrator.H, model.x_dim, model.u_dim))
         if box is not None:
@@ -145,6 +146,13 @@ class _FusedEvaluator:
         self._key = None
         self._val = None
         self.n_device_evals = 0
+
+    def set_parameters(self, p, tvp):
+        """Bind the problem's constant / time-varying parameters (extra network inputs) for the next evaluations."""
+        ex = self.model.gather_extra(self.engine.H, p, tvp)
+        if ex is not None:
+            self.engine.bind_extra(self.engine.to_device(ex[None]))
+            self._key = None
 
     def evaluate(self, z, x0):
         z = np.ascontiguousarray(z, dtype=np.float64)
@@ -182,12 +190,13 @@ class _CallbackGlue:
         self._fused = None
         boxes = [c for c in constraints if isinstance(c, BoxStateConstraint)]
         if (isinstance(integrator, DeviceIntegrator) and isinstance(objective_func, QuadraticObjective)
-                and len(boxes) == len(constraints) and len(boxes) <= 1 and p is None and tvp is None):
+                and len(boxes) == len(constraints) and len(boxes) <= 1):
             key = (id(objective_func), id(boxes[0]) if boxes else None)
             cache = integrator._fused
             if key not in cache:
                 cache[key] = _FusedEvaluator(integrator, objective_func, boxes[0] if boxes else None)
             self._fused = cache[key]
+            self._fused.set_parameters(p, tvp)
 
     def _split(self, x):
         nxh = self.x_dim * self.H

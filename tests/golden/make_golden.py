@@ -79,34 +79,44 @@ def make_plugins(ref):
     class NumpyMLPModel(ref.model_base.Model):
         """fp64 stand-in for KerasTFModel: same call signature and output layouts."""
 
-        def __init__(self, net, x_dim, u_dim):
-            super().__init__(x_dim, u_dim, 0, 0)
+        def __init__(self, net, x_dim, u_dim, p_dim=0, tvp_dim=0):
+            super().__init__(x_dim, u_dim, p_dim, tvp_dim)
             self.net = net
 
+        def _gather(self, x, u, p, tvp):
+            # KerasTFModel._gather_input (model/tensorflow.py:39-47): [x | u | tvp | p]; the reference's own p
+            # branch builds a 3-D array and cannot run, the intended "repeat p on every row" is used
+            parts = [x, u]
+            if tvp is not None:
+                parts.append(tvp)
+            if p is not None:
+                parts.append(np.tile(np.asarray(p).reshape(1, -1), (x.shape[0], 1)))
+            return np.concatenate(parts, axis=1)
+
         def forward(self, x, u, p=None, tvp=None):
-            return self.net.forward(np.concatenate([x, u], axis=1))
+            return self.net.forward(self._gather(x, u, p, tvp))
 
         def jacobian(self, x, u, p=None, tvp=None):
             H, nx, nu = x.shape[0], self.x_dim, self.u_dim
-            _, J = self.net.forward_jac(np.concatenate([x, u], axis=1))
+            _, J = self.net.forward_jac(self._gather(x, u, p, tvp))   # extra columns dropped below (tensorflow.py:65-66)
             out = np.zeros((H * nx, H * nx + H * nu))
             for t in range(H):
                 out[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx] = J[t, :, :nx]
-                out[t * nx:(t + 1) * nx, H * nx + t * nu:H * nx + (t + 1) * nu] = J[t, :, nx:]
+                out[t * nx:(t + 1) * nx, H * nx + t * nu:H * nx + (t + 1) * nu] = J[t, :, nx:nx + nu]
             return out
 
         def hessian(self, x, u, p=None, tvp=None):
             H, nx, nu = x.shape[0], self.x_dim, self.u_dim
-            _, _, S = self.net.forward_jac_hess(np.concatenate([x, u], axis=1))
+            _, _, S = self.net.forward_jac_hess(self._gather(x, u, p, tvp))
             n = H * (nx + nu)
             out = np.zeros((H, nx, n, n))
             for t in range(H):
                 xs = slice(t * nx, (t + 1) * nx)
                 us = slice(H * nx + t * nu, H * nx + (t + 1) * nu)
                 out[t][:, xs, xs] = S[t][:, :nx, :nx]
-                out[t][:, xs, us] = S[t][:, :nx, nx:]
-                out[t][:, us, xs] = S[t][:, nx:, :nx]
-                out[t][:, us, us] = S[t][:, nx:, nx:]
+                out[t][:, xs, us] = S[t][:, :nx, nx:nx + nu]
+                out[t][:, us, xs] = S[t][:, nx:nx + nu, :nx]
+                out[t][:, us, us] = S[t][:, nx:nx + nu, nx:nx + nu]
             return out
 
     class QuadObjective(ref.objective_base.ObjectiveFunc):
@@ -172,21 +182,30 @@ CASES = {
     "c5_box": (2, 1, [64, 64], 50, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True),
     "odd_dims": (3, 2, [48, 32], 7, orc.RK4, 0.05, None, 2, False),  # ragged: widths not equal, H odd
     "h1": (2, 1, [16], 1, orc.DISCRET, 1.0, None, 2, True),            # degenerate horizon
+    # time-varying + constant parameters as extra network inputs: (.., with_hessian, p_dim, tvp_dim)
+    "tvp_p_discret": (2, 1, [32, 32], 6, orc.DISCRET, 1.0, None, 2, True, 1, 2),
+    "tvp_p_rk4": (2, 1, [32, 32], 6, orc.RK4, 0.2, None, 2, True, 1, 2),
 }
 
 
 def build_case(ref, plugins, name, spec):
     NumpyMLPModel, QuadObjective, BoxStateRows = plugins
-    nx, nu, hidden, H, kind, DT, box, B, with_h = spec
-    net = orc.MLP.random(nx + nu, hidden, nx, seed=0)
+    nx, nu, hidden, H, kind, DT, box, B, with_h = spec[:9]
+    p_dim, tvp_dim = (spec[9], spec[10]) if len(spec) > 9 else (0, 0)
+    net = orc.MLP.random(nx + nu + p_dim + tvp_dim, hidden, nx, seed=0)
     rng = np.random.default_rng(7)
     xref = rng.normal(size=(H, nx)) * 0.3
     uref = rng.normal(size=(H, nu)) * 0.3
     cu = rng.normal(size=(H, nu)) * 0.1
     Q = np.eye(nx) + 0.1 * rng.normal(size=(nx, nx))
     Rm = 0.1 * np.eye(nu)
-    prob = orc.Problem(net, H, nx, nu, kind, DT, Q=Q, R=Rm, xref=xref, uref=uref, cu=cu, box=box)
-    model = NumpyMLPModel(net, nx, nu)
+    pvec = rng.normal(size=p_dim) if p_dim else None
+    tvp = rng.normal(size=(H, tvp_dim)) if tvp_dim else None
+    extra = None
+    if p_dim or tvp_dim:
+        extra = np.concatenate(([tvp] if tvp_dim else []) + ([np.tile(pvec.reshape(1, -1), (H, 1))] if p_dim else []), axis=1)
+    prob = orc.Problem(net, H, nx, nu, kind, DT, Q=Q, R=Rm, xref=xref, uref=uref, cu=cu, box=box, extra=extra)
+    model = NumpyMLPModel(net, nx, nu, p_dim, tvp_dim)
     if kind == orc.DISCRET:
         integ = ref.discret.DiscretIntegrator(model, H)
     elif kind == orc.UNITY:
@@ -201,7 +220,11 @@ def build_case(ref, plugins, name, spec):
 
     out = {"nx": nx, "nu": nu, "H": H, "kind": kind, "DT": DT, "hidden": np.array(hidden),
            "Z": Z, "X0": X0, "Q": Q, "R": Rm, "xref": xref, "uref": uref, "cu": cu,
-           "lam": lam, "sigma": sigma, "has_box": int(box is not None)}
+           "lam": lam, "sigma": sigma, "has_box": int(box is not None), "p_dim": p_dim, "tvp_dim": tvp_dim}
+    if p_dim:
+        out["p"] = pvec
+    if tvp_dim:
+        out["tvp"] = tvp
     if box is not None:
         out["box_lo"], out["box_hi"] = np.full(nx, box[0]), np.full(nx, box[1])
     for i, (w, b) in enumerate(zip(net.W, net.b)):
@@ -210,20 +233,20 @@ def build_case(ref, plugins, name, spec):
     f, grad, g, jac, hvals, hdense = [], [], [], [], [], []
     g_int, j_int = [], []
     for b in range(B):
-        pb = ref.ipopt.IpoptProblem(X0[b], obj, ctrs, integ)
+        pb = ref.ipopt.IpoptProblem(X0[b], obj, ctrs, integ, p=pvec, tvp=tvp)
         f.append(pb.objective(Z[b]))
         grad.append(pb.gradient(Z[b]))
         g.append(pb.constraints(Z[b]))
         jac.append(pb.jacobian(Z[b]))
         states, u = Z[b][:H * nx].reshape(H, nx), Z[b][H * nx:].reshape(H, nu)
-        g_int.append(integ.forward(states, u, X0[b]))
-        j_int.append(integ.jacobian(states, u, X0[b]))
+        g_int.append(integ.forward(states, u, X0[b], p=pvec, tvp=tvp))
+        j_int.append(integ.jacobian(states, u, X0[b], p=pvec, tvp=tvp))
         if with_h:
             np.random.seed(11)  # integrator/base.py:96-97 samples with the global RNG
             rows, cols = pb.hessianstructure()
             out["h_rows"], out["h_cols"] = rows, cols
             hvals.append(pb.hessian(Z[b], lam[b], sigma[b]))
-            ih = integ.hessian(states, u, X0[b])
+            ih = integ.hessian(states, u, X0[b], p=pvec, tvp=tvp)
             hdense.append(sigma[b] * obj.hessian(states, u) + np.einsum("i,ipq->pq", lam[b][:H * nx], ih))
     out.update(f=np.array(f), grad=np.array(grad), g=np.array(g), jac=np.array(jac),
                g_int=np.array(g_int), jac_int=np.array(j_int))
@@ -234,7 +257,7 @@ def build_case(ref, plugins, name, spec):
     # SLSQP glue splits (slsqp.py:54-110); INTER rows crash in the reference (slsqp.py:67-68) -> eq only there
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        sp = ref.slsqp.SlsqpProblem(X0[0], obj, [] if box is not None else ctrs, integ)
+        sp = ref.slsqp.SlsqpProblem(X0[0], obj, [] if box is not None else ctrs, integ, p=pvec, tvp=tvp)
         out["slsqp_eq"] = sp.constraints(Z[0], eq=True)
         out["slsqp_eq_jac"] = sp.jacobian(Z[0], eq=True)
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)

@@ -8,7 +8,18 @@ from oracle import nempc_oracle as orc
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 CASE_NAMES = ["c1_discret", "c2_discret", "c2_unity", "c2_rk4", "c3_rk4", "c3_discret", "c5_box",
-              "odd_dims", "h1"]
+              "odd_dims", "h1", "tvp_p_discret", "tvp_p_rk4"]
+
+
+def case_extra(d):
+    """(H, tvp_dim + p_dim) extra network inputs of a golden case, [tvp_t | p], or None."""
+    H = int(d["H"])
+    parts = []
+    if int(d.get("tvp_dim", 0)):
+        parts.append(d["tvp"])
+    if int(d.get("p_dim", 0)):
+        parts.append(np.tile(d["p"].reshape(1, -1), (H, 1)))
+    return np.concatenate(parts, axis=1) if parts else None
 
 
 def load_case(name):
@@ -23,4 +34,4 @@ def oracle_problem(d, W, b):
     net = orc.MLP(W, b)
     box = (d["box_lo"], d["box_hi"]) if int(d["has_box"]) else None
     return orc.Problem(net, int(d["H"]), int(d["nx"]), int(d["nu"]), int(d["kind"]), float(d["DT"]),
-                       Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"], box=box)
+                       Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"], box=box, extra=case_extra(d))

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import nempc_oracle as orc
-from helpers import CASE_NAMES, load_case, oracle_problem
+from helpers import CASE_NAMES, case_extra, load_case, oracle_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -16,8 +16,12 @@ KIND_NAME = {0: "discret", 1: "unity", 2: "rk4"}
 
 def _engine(d, W, b, dtype, kernel, max_batch=8):
     from pyneuralempc_amd import CallbackEngine
+    ex = case_extra(d)
     eng = CallbackEngine(W, b, int(d["H"]), int(d["nx"]), int(d["nu"]), integrator=KIND_NAME[int(d["kind"])],
-                         DT=float(d["DT"]), dtype=dtype, device="cuda:0", max_batch=max_batch, kernel=kernel)
+                         DT=float(d["DT"]), dtype=dtype, device="cuda:0", max_batch=max_batch, kernel=kernel,
+                         n_extra=0 if ex is None else ex.shape[1])
+    if ex is not None:   # the same parameters for every problem of the golden batch
+        eng.bind_extra(eng.to_device(np.broadcast_to(ex[None], (max_batch,) + ex.shape).copy()))
     eng.set_objective(Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"])
     if int(d["has_box"]):
         eng.set_box_rows(d["box_lo"], d["box_hi"])
