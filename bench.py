@@ -184,7 +184,7 @@ def main():
 
     # ---- batched on-device solver + the one collective of the design: all-gather of the solved u0
     solver_info = None
-    if cfg["box"] is None:
+    if cfg["box"] is None and cfg["integrator"] != "rk4":   # (RK4 Lagrangian blocks run on the generic kernel: minutes)
         lbv = np.concatenate([np.full(cfg["H"] * cfg["nx"], -3.0), np.full(cfg["H"] * cfg["nu"], -0.5)])
         Xs = eng.to_device(np.random.default_rng(100 + rank).uniform(-0.5, 0.5, size=(B, cfg["nx"])))
         eng.solve(Xs, lb=lbv, ub=-lbv, max_iter=5)   # warm
@@ -248,13 +248,13 @@ def main():
                                             work["dense_bytes"], "eval_us": t_step * 1e6, "eval_us_event_loop": t_all * 1e6},
         }
         # HBM bytes of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-        pmc_file = os.path.join(REPO, "profiles", "r01_c2_b1024_pmc.json")
+        pmc_file = os.path.join(REPO, "profiles", "r01b_c2_b1024_pmc.json")
         if args.config == "c2" and B == 1024 and eng.kernel_variant == "mfma" and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             for k, v in pmc.items():
                 if k.startswith(str(eng.last_row_kernel)) and "hbm_traffic_bytes" in v:
                     out["roofline"]["traffic"] = v["hbm_traffic_bytes"]
-                    out["roofline"]["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch, profiles/r01_c2_b1024_pmc.json; "
+                    out["roofline"]["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch, profiles/r01b_c2_b1024_pmc.json; "
                                                        "WRITE_SIZE of this kernel's 8-byte stores is uncalibrated "
                                                        "(algorithmic: 0.51 MB read, 1.3 MB written)")
         if solver_info:

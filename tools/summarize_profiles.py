@@ -13,6 +13,8 @@ for f in glob.glob(f"{src}_trace/*/*_kernel_stats.csv"):
     shutil.copy(f, os.path.join(out, f"{tag}_kernel_stats.csv"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for kind in ("fetch", "write", "mfma"):
+    if not glob.glob(f"{src}_{kind}"):
+        continue
     for f in glob.glob(f"{src}_{kind}/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("nempc::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
