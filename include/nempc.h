@@ -26,6 +26,14 @@
  *    g  (m)      m = H*nx defects [+ H*nx box rows = states.ravel() when enabled]
  *    jac_dense   (m,n) row-major -- what IpoptProblem.jacobian returns (ipopt.py:88-96)
  *    jac_tiles   (H,nx,nx+nu): row t = d Phi(x_{t-1},u_t) / d [x_{t-1} | u_t]  (compact contract)
+ *
+ * Rolling-window models (KerasTFModelRollingInput model/tensorflow.py:132-340, DiffDiscretJaxModelRollingWindow
+ * model/jax.py:93-259): with rolling_window = w > 1 the network of step t reads the last w states and controls,
+ *    xi_t = [ x_{t-w} .. x_{t-1} | u_{t-w+1} .. u_t | extras_t ]      (oldest first; newest first when
+ *                                                                      rolling_reverse, tensorflow.py:120-127)
+ * entries reaching before the horizon come from x0 and the history bound by nempc_bind_history.  The tile width
+ * becomes w*(nx+nu) (window columns in the network's input order); the dense Jacobian / Hessian get the band the
+ * reference builds with its projection matrices (jax.py:8-21, tensorflow.py:253-262, 312-340).
  */
 #ifndef NEMPC_H
 #define NEMPC_H
@@ -36,7 +44,7 @@
 extern "C" {
 #endif
 
-#define NEMPC_ABI_VERSION 2
+#define NEMPC_ABI_VERSION 3
 #define NEMPC_MAX_LAYERS 8 /* dense layers incl. the linear output layer */
 
 /* status codes */
@@ -78,6 +86,9 @@ typedef struct nempc_config {
     int32_t n_extra;                  /* extra per-step network inputs after [x | u]: tvp_dim + p_dim of the reference's
                                          Model (model/tensorflow.py:39-47); they feed the network but are not decision
                                          variables: no Jacobian / Hessian columns (tensorflow.py:65-66). 0 = none */
+    int32_t rolling_window;           /* w >= 1: steps of history the network reads (1 = plain model).  w > 1 needs
+                                         DISCRET or UNITY (the reference has no RK4 for rolling models) */
+    int32_t rolling_reverse;          /* 0: window rows oldest -> newest (forward_rolling=True); 1: newest first */
     double DT;                        /* RK4 step (RK4Integrator.DT, rk4.py:49) */
 } nempc_config;
 
@@ -102,6 +113,11 @@ int nempc_set_objective(nempc_handle h, const double* Q, const double* R, const 
  * n_extra > 0.  */
 int nempc_bind_extra(nempc_handle h, const void* E);
 
+/* history of a rolling-window model for subsequent calls (set_prev_data, model/tensorflow.py:178-189):
+ * hist_x (B, w-1, nx) = the w-1 states BEFORE x0, oldest first; hist_u (B, w-1, nu) = the w-1 controls before u_0.
+ * Device pointers of the handle's dtype, stored not copied; required when rolling_window > 1. */
+int nempc_bind_history(nempc_handle h, const void* hist_x, const void* hist_u);
+
 /* extra constraint rows g_box = states.ravel() (a Constraint in the sense of constraints.py:36-63
  * with constant selector Jacobian); lo/hi (nx) host doubles are only reported back through
  * nempc_constraint_bounds. enabled=0 removes the rows. */
@@ -125,7 +141,7 @@ int nempc_hess_structure(nempc_handle h, int32_t* rows, int32_t* cols);
  *   grad (B,n)       IpoptProblem.gradient     ipopt.py:37-42
  *   g (B,m)          IpoptProblem.constraints  ipopt.py:44-52
  *   jac_dense (B,m,n)IpoptProblem.jacobian     ipopt.py:88-96
- *   jac_tiles (B,H,nx,nx+nu)  compact per-step tiles (rk4.py:85-92 shape)
+ *   jac_tiles (B,H,nx,w*(nx+nu))  compact per-step tiles (rk4.py:85-92 shape; w = rolling_window)
  *   jac_sparse (B,nnz_jac)    values in nempc_jac_structure order */
 int nempc_eval(nempc_handle h, int32_t B, const void* Z, const void* X0, void* f, void* grad,
                void* g, void* jac_dense, void* jac_tiles, void* jac_sparse, void* stream);
@@ -133,7 +149,7 @@ int nempc_eval(nempc_handle h, int32_t B, const void* Z, const void* X0, void* f
 /* Lagrangian Hessian values, IpoptProblem.hessian ipopt.py:66-86:
  *   hvals (B,nnz_hess) = (sigma_b * d2f + sum_i lambda_{b,i} d2g_i)[rows, cols]
  *   lambda (B,m), sigma (B).  Optional outputs (may be NULL): hdense (B,n,n) full symmetric matrix;
- *   hblocks (B,H,nx+nu,nx+nu) the per-step blocks sum_k lambda_{t,k} d2 Phi_k / d[x_{t-1}|u_t]^2
+ *   hblocks (B,H,w*(nx+nu),w*(nx+nu)) the per-step blocks sum_k lambda_{t,k} d2 Phi_k / d[x_{t-1}|u_t]^2
  *   (the lambda-contracted form of Model.hessian, model/tensorflow.py:77-109). */
 int nempc_hess(nempc_handle h, int32_t B, const void* Z, const void* X0, const void* lambda,
                const void* sigma, void* hvals, void* hdense, void* hblocks, void* stream);
@@ -147,7 +163,8 @@ int nempc_hess(nempc_handle h, int32_t B, const void* Z, const void* X0, const v
  *   +-INFINITY allowed; the vectors DomainConstraint.get_lower/upper_bounds produce, constraints.py:26-30);
  *   status (B) device int32 out: 0 converged (Optimizer.SUCCESS), 1 not converged (Optimizer.FAIL);
  *   *iters (host, optional) outer iterations run.  Synchronises the stream internally (convergence polls).
- *   Box ROWS (nempc_set_box_rows) are not handled here -- express state bounds as variable bounds. */
+ *   Box ROWS (nempc_set_box_rows) are not handled here -- express state bounds as variable bounds.
+ *   rolling_window > 1 is NEMPC_EUNSUPPORTED (the stage structure the Riccati sweep relies on is gone). */
 typedef struct nempc_solver_opts {
     int32_t max_iter;        /* outer iterations, e.g. 200 */
     int32_t max_linesearch;  /* backtracking halvings per iteration, e.g. 6 */

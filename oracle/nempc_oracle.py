@@ -187,6 +187,49 @@ def step_rows(net: MLP, kind: int, DT: float, x_prev, u, want_hess=False, extra=
     return phi, dphi, d2phi
 
 
+def rolling_rows(x_prev, u, hist_x, hist_u, window, forward=True):
+    """Window inputs of a rolling model: (H,nx),(H,nu) + history (w-1,nx),(w-1,nu) -> (H, w*nx), (H, w*nu).
+
+    model/tensorflow.py:112-130 (rolling_input) == _gather_input_V2 (tensorflow.py:205-233) and
+    model/jax.py:137-151 (_gather_input + _slide_input): row t = rows t..t+w-1 of [history ; x_prev]
+    flattened oldest first (forward) or newest first (forward_rolling=False)."""
+    xe = np.concatenate([np.asarray(hist_x, dtype=np.float64).reshape(window - 1, -1), x_prev], axis=0)
+    ue = np.concatenate([np.asarray(hist_u, dtype=np.float64).reshape(window - 1, -1), u], axis=0)
+    H = x_prev.shape[0]
+    order = slice(None) if forward else slice(None, None, -1)
+    xr = np.stack([xe[t:t + window][order].reshape(-1) for t in range(H)], axis=0)
+    ur = np.stack([ue[t:t + window][order].reshape(-1) for t in range(H)], axis=0)
+    return xr, ur
+
+
+def step_rows_rolling(net: MLP, kind: int, x_prev, u, hist_x, hist_u, window, forward=True, want_hess=False,
+                      extra=None):
+    """Rolling-window rows: Phi (H,nx), dPhi (H,nx,w*(nx+nu)) [, d2Phi (H,nx,w*(nx+nu),w*(nx+nu))] with the
+    derivative columns in the network's input order [x window | u window].  DISCRET adds x_{t-1}
+    (integrator/discret.py:27) and its identity at the window slot of the current state; UNITY adds nothing.
+    The reference has no RK4 for rolling models."""
+    assert kind in (DISCRET, UNITY)
+    x_prev = np.asarray(x_prev, dtype=np.float64)
+    u = np.asarray(u, dtype=np.float64)
+    H, nx = x_prev.shape
+    nu = u.shape[1]
+    tw = window * (nx + nu)
+    xr, ur = rolling_rows(x_prev, u, hist_x, hist_u, window, forward)
+    xi = np.concatenate([xr, ur] + ([np.asarray(extra, dtype=np.float64)] if extra is not None else []), axis=1)
+    if want_hess:
+        f, J, S = net.forward_jac_hess(xi)
+        J, S = J[:, :, :tw], S[:, :, :tw, :tw]
+    else:
+        f, J = net.forward_jac(xi)
+        J, S = J[:, :, :tw], None
+    if kind == DISCRET:
+        cur = (window - 1) * nx if forward else 0
+        J = J.copy()
+        J[:, np.arange(nx), cur + np.arange(nx)] += 1.0
+        return x_prev + f, J, S
+    return f, J, S
+
+
 # --------------------------------------------------------------------------------------
 # Problem description shared by all callbacks
 # --------------------------------------------------------------------------------------
@@ -201,9 +244,15 @@ class Problem:
     """
 
     def __init__(self, net, H, nx, nu, kind=DISCRET, DT=1.0, Q=None, R=None, xref=None, uref=None,
-                 cx=None, cu=None, box=None, extra=None):
+                 cx=None, cu=None, box=None, extra=None, window=1, forward_rolling=True, hist_x=None, hist_u=None):
         self.extra = None if extra is None else np.asarray(extra, dtype=np.float64).reshape(H, -1)
-        assert net.n_in == nx + nu + (0 if self.extra is None else self.extra.shape[1]) and net.n_out == nx
+        # rolling-window models (model/tensorflow.py:132, model/jax.py:93): tile width tw = window*(nx+nu)
+        self.window, self.forward_rolling = int(window), bool(forward_rolling)
+        self.tw = self.window * (nx + nu)
+        self.hist_x = None if hist_x is None else np.asarray(hist_x, dtype=np.float64).reshape(self.window - 1, nx)
+        self.hist_u = None if hist_u is None else np.asarray(hist_u, dtype=np.float64).reshape(self.window - 1, nu)
+        assert self.window == 1 or (kind != RK4 and self.hist_x is not None and self.hist_u is not None)
+        assert net.n_in == self.tw + (0 if self.extra is None else self.extra.shape[1]) and net.n_out == nx
         self.net, self.H, self.nx, self.nu, self.kind, self.DT = net, H, nx, nu, kind, float(DT)
         self.n = H * (nx + nu)
         self.Q = np.eye(nx) if Q is None else np.asarray(Q, dtype=np.float64).reshape(nx, nx)
@@ -255,8 +304,26 @@ class Problem:
     def tiles(self, z, x0, want_hess=False):
         x, u = self.split(z)
         x_prev = np.concatenate([np.asarray(x0, dtype=np.float64).reshape(1, -1), x[:-1]], axis=0)
-        phi, dphi, d2phi = step_rows(self.net, self.kind, self.DT, x_prev, u, want_hess, extra=self.extra)
+        if self.window > 1:
+            phi, dphi, d2phi = step_rows_rolling(self.net, self.kind, x_prev, u, self.hist_x, self.hist_u, self.window,
+                                                 self.forward_rolling, want_hess, extra=self.extra)
+        else:
+            phi, dphi, d2phi = step_rows(self.net, self.kind, self.DT, x_prev, u, want_hess, extra=self.extra)
         return x, phi, dphi, d2phi
+
+    def tile_columns(self, t):
+        """Index into z of every tile / block column of step t, -1 where the window slot is data (x0, history).
+        Window slot j of the states is row t+j (forward) of [history ; x0 ; states[:-1]]: x0 and the history have
+        no column (integrator/discret.py:52-53 drops the first state block), state block s = that row - w."""
+        H, nx, nu, w = self.H, self.nx, self.nu, self.window
+        cols = -np.ones(self.tw, dtype=np.int64)
+        for j in range(w):
+            tau = t + (j - (w - 1) if self.forward_rolling else -j)   # index into [x0 ; states]
+            if tau >= 1:
+                cols[j * nx:(j + 1) * nx] = (tau - 1) * nx + np.arange(nx)
+            if tau >= 0:
+                cols[w * nx + j * nu:w * nx + (j + 1) * nu] = H * nx + tau * nu + np.arange(nu)
+        return cols
 
     # ---- optimizer/ipopt.py:44-52 ; integrator/discret.py:13-30
     def constraints(self, z, x0):
@@ -274,15 +341,16 @@ class Problem:
         for t in range(H):
             r = slice(t * nx, (t + 1) * nx)
             J[r, t * nx:(t + 1) * nx] -= np.eye(nx)
-            if t > 0:  # x0 is data, not a variable: the t=0 state block has no column
-                J[r, (t - 1) * nx:t * nx] += dphi[t, :, :nx]
-            J[r, H * nx + t * nu:H * nx + (t + 1) * nu] += dphi[t, :, nx:]
+            cols = self.tile_columns(t)     # x0 / history are data, not variables: no column
+            keep = cols >= 0
+            J[r, cols[keep]] += dphi[t][:, keep]
         if self.box is not None:
             J[H * nx:, :H * nx] = np.eye(H * nx)
         return J
 
     def tiles_AB(self, z, x0):
         """Compact contract: g (H*nx,), A (H,nx,nx) = dPhi/dx_prev, Bt (H,nx,nu) = dPhi/du."""
+        assert self.window == 1
         x, phi, dphi, _ = self.tiles(z, x0)
         return (phi - x).ravel(), dphi[:, :, : self.nx].copy(), dphi[:, :, self.nx:].copy()
 
@@ -309,13 +377,9 @@ class Problem:
         Hm = sigma * self.objective_hessian()
         for t in range(H):
             blk = np.einsum("k,kpq->pq", lam[t * nx:(t + 1) * nx], d2phi[t])
-            uo = H * nx + t * nu
-            Hm[uo:uo + nu, uo:uo + nu] += blk[nx:, nx:]
-            if t > 0:
-                xo = (t - 1) * nx
-                Hm[xo:xo + nx, xo:xo + nx] += blk[:nx, :nx]
-                Hm[xo:xo + nx, uo:uo + nu] += blk[:nx, nx:]
-                Hm[uo:uo + nu, xo:xo + nx] += blk[nx:, :nx]
+            cols = self.tile_columns(t)
+            keep = np.nonzero(cols >= 0)[0]
+            Hm[np.ix_(cols[keep], cols[keep])] += blk[np.ix_(keep, keep)]
         return Hm
 
     def hessian_structure(self):
@@ -327,12 +391,10 @@ class Problem:
         for t in range(H):
             uo = H * nx + t * nu
             M[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx] = True   # objective Q block
-            M[uo:uo + nu, uo:uo + nu] = True
-            if t > 0:
-                xo = (t - 1) * nx
-                M[xo:xo + nx, xo:xo + nx] = True
-                M[xo:xo + nx, uo:uo + nu] = True
-                M[uo:uo + nu, xo:xo + nx] = True
+            M[uo:uo + nu, uo:uo + nu] = True                     # objective R block
+            cols = self.tile_columns(t)
+            cols = cols[cols >= 0]
+            M[np.ix_(cols, cols)] = True                         # every pair of variables step t reads
         return np.nonzero(np.tril(M))
 
     def hessian_values(self, z, x0, lam, sigma):

@@ -1,5 +1,5 @@
 // Matrix-core kernel for the per-row Lagrangian blocks of the Hessian callback (DISCRET / UNITY):
-//     Hblk[p][d] = d^2 (lambda . f) / d xi_p d xi_d          (nx+nu square per (problem, step) row)
+//     Hblk[p][d] = d^2 (lambda . f) / d xi_p d xi_d          (w*(nx+nu) square per (problem, step) row)
 // i.e. the lambda-contracted form of Model.hessian (model/tensorflow.py:77-109) that
 // IpoptProblem.hessian sums with the multipliers (optimizer/ipopt.py:66-86).
 //
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
         wsrc = gblob;
         scratch = lds + wave * p.scratch_per_wave;
     }
-    const int nx = p.nx, nu = p.nu, nin = p.nin, H = p.H;
-    const int n = H * nin;
+    const int nx = p.nx, nin = p.nin, H = p.H;
+    const int n = p.gk.n;
     const size_t R = (size_t)p.B * H;
     const T* __restrict__ Z = static_cast<const T*>(p.Z);
     const T* __restrict__ X0 = static_cast<const T*>(p.X0);
@@ -72,9 +72,7 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
             T v = T(0);
             if (r < R) {
                 const int b = (int)((unsigned)r / (unsigned)H), t = (int)((unsigned)r - (unsigned)b * (unsigned)H);
-                const T* z = Z + (size_t)b * n;
-                if (d < nx) v = (t == 0) ? X0[(size_t)b * nx + d] : z[(t - 1) * nx + d];
-                else if (d < nin) v = z[H * nx + t * nu + (d - nx)];
+                if (d < nin) v = gather_input<T>(p.gk, Z + (size_t)b * n, X0, b, t, d);
                 else v = lam[(size_t)b * p.m + t * nx + (d - nin)];
             }
             if (d < nin) s_xi0[cc * nin + d] = v;

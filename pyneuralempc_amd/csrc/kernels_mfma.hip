@@ -134,7 +134,7 @@ int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, v
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
     p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
-    
+    p.gk = h.gather();
     p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
     p.scratch_per_wave = (scratch_elems(h) + 1) & ~1;
     p.dbg = h.d_dbg;
@@ -156,6 +156,7 @@ int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const v
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
     p.Z = Z; p.X0 = X0; p.g = nullptr; p.tiles = nullptr;
+    p.gk = h.gather();
     p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
     p.scratch_per_wave = (16 * h.nin + 16 * h.cfg.nx + 16 * h.nin * h.nin + 16 * h.ne + 1) & ~1;
     p.dbg = nullptr;

@@ -47,6 +47,7 @@ struct MfmaParams {
     int ntiles;
     int tiles_per_wg, tiles_rem;  // cooperative kernel: ntiles = grid * tiles_per_wg + tiles_rem
     int scratch_per_wave;  // elements
+    RowGather gk;          // input gather (rolling windows); nin above is the tile width w*(nx+nu)
     long long* dbg;        // diagnostic builds only (-DNEMPC_STAMPS): per-wave phase stamps of workgroup 0
 };
 
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
         scratch = lds + wave * p.scratch_per_wave;
     }
 
-    const int nx = p.nx, nu = p.nu, nin = p.nin, H = p.H;
-    const int n = H * nin;
+    const int nx = p.nx, nin = p.nin, H = p.H;
+    const int n = p.gk.n, xcur = p.gk.xcur;
     const size_t R = (size_t)p.B * H;
     const T* __restrict__ Z = static_cast<const T*>(p.Z);
     const T* __restrict__ X0 = static_cast<const T*>(p.X0);
@@ -251,16 +252,15 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
     for (int tile = blockIdx.x * nwaves + wave; tile < p.ntiles; tile += gridDim.x * nwaves) {
         const size_t row0 = (size_t)tile * 16;
 
-        // ---- stage the tile's inputs xi0[c][d] = [x_{t-1} ; u_t]  (discret.py:22, ipopt.py:20-28)
+        // ---- stage the tile's inputs xi0[c][d] = [x_{t-1} ; u_t]  (discret.py:22, ipopt.py:20-28), or the rolling
+        //      window of states / controls (tensorflow.py:112-130)
         for (int e = lane; e < 16 * nin; e += 64) {
             const int cc = e / nin, d = e - cc * nin;
             const size_t r = row0 + cc;
             T v = T(0);
             if (r < R) {
                 const int b = (int)(r / H), t = (int)(r - (size_t)b * H);
-                const T* z = Z + (size_t)b * n;
-                if (d < nx) v = (t == 0) ? X0[(size_t)b * nx + d] : z[(t - 1) * nx + d];
-                else v = z[H * nx + t * nu + (d - nx)];
+                v = gather_input<T>(p.gk, Z + (size_t)b * n, X0, b, t, d);
             }
             s_xi0[e] = v;
         }
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
             if (row0 + cc < R) {
                 T v;
                 if (rk4) v = s6 * s_accdk[e] + (d == i ? T(1) : T(0));
-                else v = s_J[e] + ((p.kind == NEMPC_DISCRET && d == i) ? T(1) : T(0));
+                else v = s_J[e] + ((p.kind == NEMPC_DISCRET && d == xcur + i) ? T(1) : T(0));
                 tiles[row0 * nx * nin + e] = v;
             }
         }
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
             const size_t r = row0 + cc;
             if (r < R) {
                 const int b = (int)(r / H), t = (int)(r - (size_t)b * H);
-                const T xp = s_xi0[cc * nin + i];
+                const T xp = s_xi0[cc * nin + xcur + i];
                 T phi;
                 if (rk4) phi = xp + s6 * s_acck[e];
                 else phi = (p.kind == NEMPC_DISCRET ? xp : T(0)) + s_k[e];

@@ -137,17 +137,21 @@ __global__ __launch_bounds__(256) void assemble_sparse_kernel(int nnz, int tile_
     if (e < nnz) vals[(size_t)b * nnz + e] = map_value<T>(map[e], tiles + (size_t)b * tile_elems);
 }
 
-// hvals[b][e] = sigma_b * objc[e] + (map[e] >= 0 ? blocks[b][map[e]] : 0)
+// hvals[b][e] = sigma_b * objc[e] + sum_k (map[e][k] >= 0 ? blocks[b][map[e][k]] : 0);  up to w per-row blocks reach
+// one entry with a rolling window of w steps (the reference sums them with its projection matrices,
+// model/tensorflow.py:312-330); w = 1 for plain models
 template <typename T>
-__global__ __launch_bounds__(256) void assemble_hess_kernel(int cnt, int blk_elems, const int32_t* __restrict__ map,
+__global__ __launch_bounds__(256) void assemble_hess_kernel(int cnt, int w, int blk_elems, const int32_t* __restrict__ map,
                                                             const T* __restrict__ objc, const T* __restrict__ blocks,
                                                             const T* __restrict__ sigma, T* __restrict__ out) {
     const int b = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < cnt) {
-        const int32_t c = map[e];
         T v = sigma[b] * objc[e];
-        if (c >= 0) v += blocks[(size_t)b * blk_elems + c];
+        for (int k = 0; k < w; ++k) {
+            const int32_t c = map[(size_t)e * w + k];
+            if (c >= 0) v += blocks[(size_t)b * blk_elems + c];
+        }
         out[(size_t)b * cnt + e] = v;
     }
 }
@@ -214,7 +218,7 @@ int launch_assemble_sparse(Handle& h, int B, const void* tiles, void* vals, hipS
     return NEMPC_OK;
 }
 
-// d_hess_map layout: [0,nnz) tril map | [nnz, nnz+n*n) dense map ; objc follows the same split in d_hess_objc
+// d_hess_map layout (w codes per entry): [0,nnz) tril map | [nnz, nnz+n*n) dense map ; objc follows the same split in d_hess_objc
 int launch_assemble_hess(Handle& h, int B, const void* blocks, const void* sigma, void* hvals, void* hdense,
                          hipStream_t s) {
     const int nnz = (int)h.hess_rows.size();
@@ -226,20 +230,20 @@ int launch_assemble_hess(Handle& h, int B, const void* blocks, const void* sigma
     if (hvals) {
         const dim3 grid((unsigned)((nnz + 255) / 256), (unsigned)B);
         if (h.cfg.dtype == NEMPC_F64)
-            hipLaunchKernelGGL(assemble_hess_kernel<double>, grid, block, 0, s, nnz, be, h.d_hess_map,
+            hipLaunchKernelGGL(assemble_hess_kernel<double>, grid, block, 0, s, nnz, h.w, be, h.d_hess_map,
                                (const double*)objc, (const double*)blocks, (const double*)sigma, (double*)hvals);
         else
-            hipLaunchKernelGGL(assemble_hess_kernel<float>, grid, block, 0, s, nnz, be, h.d_hess_map,
+            hipLaunchKernelGGL(assemble_hess_kernel<float>, grid, block, 0, s, nnz, h.w, be, h.d_hess_map,
                                (const float*)objc, (const float*)blocks, (const float*)sigma, (float*)hvals);
     }
     if (hdense) {
         const dim3 grid((unsigned)((nn + 255) / 256), (unsigned)B);
         if (h.cfg.dtype == NEMPC_F64)
-            hipLaunchKernelGGL(assemble_hess_kernel<double>, grid, block, 0, s, nn, be, h.d_hess_map + nnz,
+            hipLaunchKernelGGL(assemble_hess_kernel<double>, grid, block, 0, s, nn, h.w, be, h.d_hess_map + (size_t)nnz * h.w,
                                (const double*)(objc + (size_t)nnz * esz), (const double*)blocks,
                                (const double*)sigma, (double*)hdense);
         else
-            hipLaunchKernelGGL(assemble_hess_kernel<float>, grid, block, 0, s, nn, be, h.d_hess_map + nnz,
+            hipLaunchKernelGGL(assemble_hess_kernel<float>, grid, block, 0, s, nn, h.w, be, h.d_hess_map + (size_t)nnz * h.w,
                                (const float*)(objc + (size_t)nnz * esz), (const float*)blocks, (const float*)sigma,
                                (float*)hdense);
     }

@@ -7,7 +7,7 @@
 //
 // Math per row (reference call sites integrator/discret.py:22-30,48-56,
 // unity.py:24-32, rk4.py:66-80,137-159):
-//   xi = [x_{t-1} ; u_t],  f(xi) = tanh-MLP,  J = df/dxi by one reverse sweep per output,
+//   xi = [x_{t-1} ; u_t] (or the rolling window of both),  f(xi) = tanh-MLP,  J = df/dxi by one reverse sweep per output,
 //   DISCRET Phi = x + f, dPhi = J + [I 0];  UNITY Phi = f;  RK4 per rk4.py with
 //   dk_{i+1} = J_{i+1} + c_i DT J_{i+1}[:, :nx] dk_i   (== J_{i+1} (I + c_i DT [dk_i; 0])).
 #include "nempc_internal.h"
@@ -17,8 +17,9 @@ namespace nempc {
 namespace {
 
 struct NetDev {
-    int nl, nin, nx, nu, maxw, ne;   // nin = nx+nu decision inputs; the network reads nin + ne values per row
+    int nl, nin, nx, nu, maxw, ne;   // nin = w*(nx+nu) decision inputs (tile width); the network reads nin + ne values per row
     const void* extra;               // (B,H,ne) or null
+    RowGather gk;                    // where the nin window inputs of a row come from
     int din[NEMPC_MAX_LAYERS], dout[NEMPC_MAX_LAYERS];
     const void* W[NEMPC_MAX_LAYERS];
     const void* Wt[NEMPC_MAX_LAYERS];
@@ -163,14 +164,13 @@ __global__ __launch_bounds__(256) void rows_valu_kernel(NetDev net, WsOff o, int
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= (size_t)B * H) return;
     const int b = (int)(r / H), t = (int)(r % H);
-    const int nx = net.nx, nu = net.nu, nin = net.nin;
-    const int n = H * nin;
+    const int nx = net.nx, nin = net.nin;
+    const int n = net.gk.n;
     const size_t R = Rcap;
     const T* z = Z + (size_t)b * n;
 
     T* xi = ws + (size_t)o.xi * R;
-    for (int i = 0; i < nx; ++i) xi[(size_t)i * R + r] = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
-    for (int j = 0; j < nu; ++j) xi[(size_t)(nx + j) * R + r] = z[H * nx + t * nu + j];
+    for (int d = 0; d < nin; ++d) xi[(size_t)d * R + r] = gather_input<T>(net.gk, z, X0, b, t, d);
     for (int j = 0; j < net.ne; ++j) xi[(size_t)(nin + j) * R + r] = ((const T*)net.extra)[((size_t)b * H + t) * net.ne + j];
 
     T* fout = ws + (size_t)o.fout * R;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void rows_valu_kernel(NetDev net, WsOff o, int
             gout[i] = phi - z[t * nx + i];
             for (int d = 0; d < nin; ++d) {
                 T v = jst[(size_t)(i * nin + d) * R + r];
-                if (kind == NEMPC_DISCRET && d == i) v += T(1);
+                if (kind == NEMPC_DISCRET && d == net.gk.xcur + i) v += T(1);
                 tile[i * nin + d] = v;
             }
         }
@@ -347,16 +347,15 @@ __global__ __launch_bounds__(256) void rowhess_valu_kernel(NetDev net, WsOff o, 
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= (size_t)B * H) return;
     const int b = (int)(r / H), t = (int)(r % H);
-    const int nx = net.nx, nu = net.nu, nin = net.nin;
-    const int n = H * nin;
+    const int nx = net.nx, nin = net.nin;
+    const int n = net.gk.n;
     const size_t R = Rcap;
     const T* z = Z + (size_t)b * n;
     T* blk = blocks + ((size_t)b * H + t) * nin * nin;
     const T* lrow = lam + (size_t)b * m + (size_t)t * nx;
 
     T* xi = ws + (size_t)o.xi * R;
-    for (int i = 0; i < nx; ++i) xi[(size_t)i * R + r] = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
-    for (int j = 0; j < nu; ++j) xi[(size_t)(nx + j) * R + r] = z[H * nx + t * nu + j];
+    for (int d = 0; d < nin; ++d) xi[(size_t)d * R + r] = gather_input<T>(net.gk, z, X0, b, t, d);
     for (int j = 0; j < net.ne; ++j) xi[(size_t)(nin + j) * R + r] = ((const T*)net.extra)[((size_t)b * H + t) * net.ne + j];
     if (kind != NEMPC_RK4) {
         net_hessian_contracted<T>(net, ws, o, R, r, lrow, 1, blk, 1);
@@ -454,6 +453,7 @@ NetDev make_netdev(const Handle& h) {
     NetDev nd{};
     nd.nl = h.nl; nd.nin = h.nin; nd.nx = h.cfg.nx; nd.nu = h.cfg.nu; nd.maxw = h.maxw;
     nd.ne = h.ne; nd.extra = h.d_extra;
+    nd.gk = h.gather();
     for (int l = 0; l < h.nl; ++l) {
         nd.din[l] = h.din[l]; nd.dout[l] = h.dout[l];
         nd.W[l] = h.d_W[l]; nd.Wt[l] = h.d_Wt[l]; nd.b[l] = h.d_b[l];

@@ -1,5 +1,6 @@
 // C ABI of libnempc.so: handle lifetime, parameter upload, structure export, launch sequencing.
 // See include/nempc.h for the contract and the reference call sites each entry point stands for.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -66,38 +67,20 @@ void dev_free(void*& p) {
     p = nullptr;
 }
 
-// which per-row block element feeds Hessian entry (r,c), and the objective constant there
-int32_t hess_code(const Handle& h, int r, int c, const std::vector<double>& Qs, const std::vector<double>& Rs,
-                  double* objc) {
-    const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu, nin = h.nin;
-    *objc = 0.0;
-    const bool rx = r < H * nx, cx = c < H * nx;
-    if (rx && cx) {
-        const int tr = r / nx, ir = r % nx, tc = c / nx, ic = c % nx;
-        if (tr != tc) return -1;
-        *objc = Qs[ir * nx + ic];
-        return (tr + 1 < H) ? (tr + 1) * nin * nin + ir * nin + ic : -1;
+// decision variable (index into z) that tile / block column d of step t reads, or -1 when that window slot is
+// data (x0 or the bound history).  Column order = the network's input order: w state rows then w control rows,
+// oldest first unless rev (model/tensorflow.py:112-130).  For w = 1: [x_{t-1} | u_t].
+int window_var(const Handle& h, int t, int d) {
+    const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu, back = h.w - 1, wx = h.w * nx;
+    if (d < wx) {
+        const int j = d / nx, c = d % nx;
+        const int tau = t + (h.rev ? -j : j - back);   // index into [x0 ; states]
+        return tau >= 1 ? (tau - 1) * nx + c : -1;
     }
-    if (!rx && !cx) {
-        const int tr = (r - H * nx) / nu, a = (r - H * nx) % nu, tc = (c - H * nx) / nu, bq = (c - H * nx) % nu;
-        if (tr != tc) return -1;
-        *objc = Rs[a * nu + bq];
-        return tr * nin * nin + (nx + a) * nin + (nx + bq);
-    }
-    // mixed: u_t with x_{t-1}
-    const int ui = rx ? c : r, xi = rx ? r : c;
-    const int tu = (ui - H * nx) / nu, a = (ui - H * nx) % nu, tx = xi / nx, ix = xi % nx;
-    if (tu != tx + 1) return -1;
-    return rx ? tu * nin * nin + ix * nin + (nx + a) : tu * nin * nin + (nx + a) * nin + ix;
-}
-
-bool hess_structural(const Handle& h, int r, int c) {
-    const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu;
-    const bool rx = r < H * nx, cx = c < H * nx;
-    if (rx && cx) return r / nx == c / nx;
-    if (!rx && !cx) return (r - H * nx) / nu == (c - H * nx) / nu;
-    const int ui = rx ? c : r, xi = rx ? r : c;
-    return (ui - H * nx) / nu == xi / nx + 1;
+    d -= wx;
+    const int j = d / nu, c = d % nu;
+    const int tau = t + (h.rev ? -j : j - back);
+    return tau >= 0 ? H * nx + tau * nu + c : -1;
 }
 
 struct ObjHost {
@@ -117,14 +100,19 @@ int rebuild_structure(Handle& h) {
         h.jac_cols.push_back(c);
         sparse.push_back(code);
     };
+    std::vector<std::pair<int, int32_t>> ent;
     for (int t = 0; t < H; ++t)
         for (int i = 0; i < nx; ++i) {
             const int r = t * nx + i;
             const int base = t * nx * nin + i * nin;
-            if (t > 0)
-                for (int j = 0; j < nx; ++j) put(r, (t - 1) * nx + j, base + j);
-            put(r, t * nx + i, MAP_MINUS_ONE);
-            for (int j = 0; j < nu; ++j) put(r, H * nx + t * nu + j, base + nx + j);
+            ent.clear();
+            for (int d = 0; d < nin; ++d) {
+                const int v = window_var(h, t, d);
+                if (v >= 0) ent.emplace_back(v, base + d);
+            }
+            ent.emplace_back(t * nx + i, MAP_MINUS_ONE);   // -x_t; the window only reaches state blocks < t
+            std::sort(ent.begin(), ent.end());
+            for (const auto& e : ent) put(r, e.first, e.second);
         }
     if (h.box)
         for (int k = 0; k < H * nx; ++k) put(H * nx + k, k, MAP_PLUS_ONE);
@@ -153,28 +141,51 @@ int upload_objective(Handle& h, const ObjHost& o) {
     for (int i = 0; i < nu; ++i)
         for (int j = 0; j < nu; ++j) Rs[i * nu + j] = o.R[i * nu + j] + o.R[j * nu + i];
 
-    // Hessian structure (tril, row-major) + maps + objective constants
+    // Hessian structure (tril, row-major) + maps + objective constants.  Entry (r,c) sums the block elements of
+    // every step whose window holds both variables (<= w of them; exactly one for plain models,
+    // integrator/discret.py:61-81) on top of the constant objective term.
+    const int nin = h.nin, w = h.w;
+    std::vector<std::vector<int32_t>> codes((size_t)n * n);
+    std::vector<int> wv(nin);
+    for (int t = 0; t < H; ++t) {
+        for (int d = 0; d < nin; ++d) wv[d] = window_var(h, t, d);
+        for (int pp = 0; pp < nin; ++pp)
+            for (int qq = 0; qq < nin; ++qq)
+                if (wv[pp] >= 0 && wv[qq] >= 0) codes[(size_t)wv[pp] * n + wv[qq]].push_back(t * nin * nin + pp * nin + qq);
+    }
+    auto obj_const = [&](int r, int c, bool* structural) -> double {
+        *structural = false;
+        const bool rx = r < H * nx, cx = c < H * nx;
+        if (rx && cx && r / nx == c / nx) { *structural = true; return Qs[(r % nx) * nx + (c % nx)]; }
+        if (!rx && !cx && (r - H * nx) / nu == (c - H * nx) / nu) {
+            *structural = true;
+            return Rs[((r - H * nx) % nu) * nu + ((c - H * nx) % nu)];
+        }
+        return 0.0;
+    };
     h.hess_rows.clear();
     h.hess_cols.clear();
     std::vector<int32_t> hmap;
     std::vector<double> objc;
+    auto emit = [&](int r, int c, double oc) {
+        const auto& cs = codes[(size_t)r * n + c];
+        for (int k = 0; k < w; ++k) hmap.push_back(k < (int)cs.size() ? cs[k] : -1);
+        objc.push_back(oc);
+    };
     for (int r = 0; r < n; ++r)
-        for (int c = 0; c <= r; ++c)
-            if (hess_structural(h, r, c)) {
-                double oc;
-                hmap.push_back(hess_code(h, r, c, Qs, Rs, &oc));
-                objc.push_back(oc);
+        for (int c = 0; c <= r; ++c) {
+            bool st;
+            const double oc = obj_const(r, c, &st);
+            if (st || !codes[(size_t)r * n + c].empty()) {
+                emit(r, c, oc);
                 h.hess_rows.push_back(r);
                 h.hess_cols.push_back(c);
             }
-    const size_t nnz = hmap.size();
+        }
     for (int r = 0; r < n; ++r)
         for (int c = 0; c < n; ++c) {
-            double oc = 0.0;
-            int32_t code = -1;
-            if (hess_structural(h, r, c)) code = hess_code(h, r, c, Qs, Rs, &oc);
-            hmap.push_back(code);
-            objc.push_back(oc);
+            bool st;
+            emit(r, c, obj_const(r, c, &st));
         }
 
     std::vector<double> all((size_t)off.total);
@@ -197,7 +208,6 @@ int upload_objective(Handle& h, const ObjHost& o) {
     if ((rc = dev_alloc((void**)&h.d_hess_map, hmap.size() * sizeof(int32_t)))) return rc;
     if ((rc = upload(h, all, h.d_obj))) return rc;
     NEMPC_HIP(hipMemcpy(h.d_hess_map, hmap.data(), hmap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    (void)nnz;
     h.have_objective = true;
     return NEMPC_OK;
 }
@@ -251,6 +261,9 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
     if (cfg->kernel < NEMPC_KERNEL_AUTO || cfg->kernel > NEMPC_KERNEL_MFMA_TILE)
         return fail(NEMPC_EINVAL, "nempc_create: bad kernel selector");
     if (cfg->integrator == NEMPC_RK4 && !(cfg->DT > 0.0)) return fail(NEMPC_EINVAL, "nempc_create: RK4 needs DT > 0");
+    if (cfg->rolling_window < 1) return fail(NEMPC_EINVAL, "nempc_create: rolling_window must be >= 1");
+    if (cfg->rolling_window > 1 && cfg->integrator == NEMPC_RK4)
+        return fail(NEMPC_EUNSUPPORTED, "nempc_create: rolling-window models need the DISCRET or UNITY integrator");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(NEMPC_EHIP, "nempc_create: no HIP device visible (this library has no CPU fallback)");
@@ -262,9 +275,11 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
     if (!h) return fail(NEMPC_ENOMEM, "nempc_create: out of host memory");
     h->cfg = *cfg;
     h->esz = cfg->dtype == NEMPC_F64 ? 8 : 4;
-    h->nin = cfg->nx + cfg->nu;
+    h->w = cfg->rolling_window;
+    h->rev = cfg->rolling_reverse ? 1 : 0;
+    h->nin = h->w * (cfg->nx + cfg->nu);
     h->ne = cfg->n_extra;
-    h->n = cfg->H * h->nin;
+    h->n = cfg->H * (cfg->nx + cfg->nu);
     h->nl = cfg->n_layers;
     h->maxw = 1;
     for (int l = 0; l < h->nl; ++l) {
@@ -378,6 +393,17 @@ int nempc_bind_extra(nempc_handle hh, const void* E) {
     return NEMPC_OK;
 }
 
+int nempc_bind_history(nempc_handle hh, const void* hist_x, const void* hist_u) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_bind_history: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    if (h.w == 1 && (hist_x || hist_u))
+        return fail(NEMPC_EINVAL, "nempc_bind_history: the handle was created with rolling_window = 1");
+    if (h.w > 1 && (!hist_x != !hist_u)) return fail(NEMPC_EINVAL, "nempc_bind_history: bind both histories or neither");
+    h.d_hist_x = hist_x;
+    h.d_hist_u = hist_u;
+    return NEMPC_OK;
+}
+
 int nempc_set_box_rows(nempc_handle hh, int enabled, const double* lo, const double* hi) {
     if (!hh) return fail(NEMPC_EINVAL, "nempc_set_box_rows: null handle");
     Handle& h = *reinterpret_cast<Handle*>(hh);
@@ -445,6 +471,8 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
     if (need_rows && !X0) return fail(NEMPC_EINVAL, "nempc_eval: X0 is null");
     if (need_rows && !h.have_weights) return fail(NEMPC_ESTATE, "nempc_eval: call nempc_set_weights first");
     if (need_rows && h.ne > 0 && !h.d_extra) return fail(NEMPC_ESTATE, "nempc_eval: n_extra > 0 but nempc_bind_extra was not called");
+    if (need_rows && h.w > 1 && !h.d_hist_x)
+        return fail(NEMPC_ESTATE, "nempc_eval: rolling_window > 1 but nempc_bind_history was not called");
     DeviceGuard dg(h.cfg.device);
     if (!dg.ok) return fail(NEMPC_EHIP, "nempc_eval: hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -472,6 +500,8 @@ int nempc_hess(nempc_handle hh, int32_t B, const void* Z, const void* X0, const 
     if (!Z || !X0 || !lambda || !sigma) return fail(NEMPC_EINVAL, "nempc_hess: null input");
     if (!h.have_weights) return fail(NEMPC_ESTATE, "nempc_hess: call nempc_set_weights first");
     if (h.ne > 0 && !h.d_extra) return fail(NEMPC_ESTATE, "nempc_hess: n_extra > 0 but nempc_bind_extra was not called");
+    if (h.w > 1 && !h.d_hist_x)
+        return fail(NEMPC_ESTATE, "nempc_hess: rolling_window > 1 but nempc_bind_history was not called");
     DeviceGuard dg(h.cfg.device);
     if (!dg.ok) return fail(NEMPC_EHIP, "nempc_hess: hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -496,6 +526,7 @@ int nempc_solve(nempc_handle hh, int32_t B, const void* X0, void* Z, const doubl
     if (!h.have_weights) return fail(NEMPC_ESTATE, "nempc_solve: call nempc_set_weights first");
     if (h.ne > 0 && !h.d_extra) return fail(NEMPC_ESTATE, "nempc_solve: n_extra > 0 but nempc_bind_extra was not called");
     if (h.box) return fail(NEMPC_EUNSUPPORTED, "nempc_solve: box rows are not handled; pass state bounds as lb/ub");
+    if (h.w > 1) return fail(NEMPC_EUNSUPPORTED, "nempc_solve: rolling-window models are not handled by the batched solver");
     if (opts->max_iter < 1 || opts->max_linesearch < 1 || !(opts->mu_factor > 0.0 && opts->mu_factor < 1.0) ||
         !(opts->mu_init > 0.0) || !(opts->mu_min > 0.0))
         return fail(NEMPC_EINVAL, "nempc_solve: bad options");

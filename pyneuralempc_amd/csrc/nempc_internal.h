@@ -12,7 +12,7 @@
 namespace nempc {
 
 // codes of the dense / sparse assembly maps: >= 0 is an index into one problem's tile array
-// (H, nx, nx+nu); negative codes are constants
+// (H, nx, w*(nx+nu)); negative codes are constants
 constexpr int32_t MAP_ZERO = -1;
 constexpr int32_t MAP_MINUS_ONE = -2;
 constexpr int32_t MAP_PLUS_ONE = -3;
@@ -26,6 +26,41 @@ int hip_fail(hipError_t e, const char* what);
         if (_e != hipSuccess) return ::nempc::hip_fail(_e, #call); \
     } while (0)
 
+// How one (problem, step) row reads its network inputs: plain models read [x_{t-1} | u_t]; rolling-window models
+// (model/tensorflow.py:112-130 rolling_input) read the last w states and controls, reaching into x0 and the bound
+// history before the horizon.  Tile / block column d indexes the window in the network's input order.
+struct RowGather {
+    int H, nx, nu, n;       // n = H*(nx+nu)
+    int w, rev;             // window length, newest-first flag
+    int xcur;               // tile column of the current state x_{t-1}, component 0 (where DISCRET adds its identity)
+    const void* hx;         // (B, w-1, nx) states before x0, oldest first
+    const void* hu;         // (B, w-1, nu) controls before u_0
+};
+
+// value of window column d (< w*(nx+nu)) of row (b,t); z = this problem's decision vector
+template <typename T>
+__device__ __forceinline__ T gather_input(const RowGather& gk, const T* __restrict__ z, const T* __restrict__ X0,
+                                          int b, int t, int d) {
+    const int nx = gk.nx, nu = gk.nu;
+    if (gk.w == 1) {
+        if (d < nx) return t == 0 ? X0[(size_t)b * nx + d] : z[(t - 1) * nx + d];
+        return z[gk.H * nx + t * nu + (d - nx)];
+    }
+    const int wx = gk.w * nx, back = gk.w - 1;
+    if (d < wx) {
+        const int j = d / nx, c = d - j * nx;
+        const int tau = t + (gk.rev ? -j : j - back);   // index into [x0 ; states]: 0 is x0
+        if (tau >= 1) return z[(tau - 1) * nx + c];
+        if (tau == 0) return X0[(size_t)b * nx + c];
+        return static_cast<const T*>(gk.hx)[((size_t)b * back + (back + tau)) * nx + c];
+    }
+    d -= wx;
+    const int j = d / nu, c = d - j * nu;
+    const int tau = t + (gk.rev ? -j : j - back);
+    if (tau >= 0) return z[gk.H * nx + tau * nu + c];
+    return static_cast<const T*>(gk.hu)[((size_t)b * back + (back + tau)) * nu + c];
+}
+
 // MFMA-packed network (built by nempc_set_weights when the MFMA row kernel is selected)
 struct MfmaNet {
     int wp = 0;        // padded hidden width (multiple of 16): 32 | 64 | 128
@@ -38,9 +73,20 @@ struct MfmaNet {
 
 struct Handle {
     nempc_config cfg{};
-    int n = 0, m = 0, nin = 0, nl = 0;
+    int n = 0, m = 0, nl = 0;
+    int nin = 0;                 // tile width = decision inputs one row's network reads: w*(nx+nu)
     int ne = 0;                  // extra network inputs (tvp + p); the network's input width is nin + ne
     const void* d_extra = nullptr;  // bound by nempc_bind_extra, (B,H,ne)
+    int w = 1, rev = 0;          // rolling window (1 = plain model), newest-first flag
+    const void* d_hist_x = nullptr;  // bound by nempc_bind_history
+    const void* d_hist_u = nullptr;
+    RowGather gather() const {
+        RowGather gk;
+        gk.H = cfg.H; gk.nx = cfg.nx; gk.nu = cfg.nu; gk.n = n; gk.w = w; gk.rev = rev;
+        gk.xcur = rev ? 0 : (w - 1) * cfg.nx;
+        gk.hx = d_hist_x; gk.hu = d_hist_u;
+        return gk;
+    }
     int din[NEMPC_MAX_LAYERS]{}, dout[NEMPC_MAX_LAYERS]{};
     int maxw = 0;
     bool box = false;
@@ -64,7 +110,7 @@ struct Handle {
     std::vector<int32_t> jac_rows, jac_cols, hess_rows, hess_cols;
     int32_t* d_dense_map = nullptr;   // (m*n)
     int32_t* d_sparse_map = nullptr;  // (nnz_jac)
-    int32_t* d_hess_map = nullptr;    // (nnz_hess) index into the dense (n,n) scratch, see kernels_hess.hip
+    int32_t* d_hess_map = nullptr;    // (nnz_hess + n*n, w) per-row block elements summed into each entry; -1 = none
 
     // workspaces sized for max_batch
     void* d_tiles_ws = nullptr;  // (Bmax,H,nx,nin) when the caller does not ask for tiles

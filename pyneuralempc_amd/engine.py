@@ -22,7 +22,7 @@ def _as_c_double(a):
 
 class CallbackEngine:
     def __init__(self, weights, biases, H, nx, nu, integrator="discret", DT=1.0, dtype=torch.float64,
-                 device="cuda", max_batch=1, kernel="auto", n_extra=0):
+                 device="cuda", max_batch=1, kernel="auto", n_extra=0, rolling_window=1, forward_rolling=True):
         if not torch.cuda.is_available():
             raise RuntimeError("pyneuralempc_amd needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -35,7 +35,15 @@ class CallbackEngine:
         if dtype not in _TORCH_DTYPES:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.dtype = dtype
-        self.H, self.nx, self.nu, self.nin = int(H), int(nx), int(nu), int(nx) + int(nu)
+        # rolling-window models (model/tensorflow.py:132, model/jax.py:93): the network of step t reads the last
+        # `rolling_window` states and controls; nin is the tile width = number of decision inputs one step reads
+        self.rolling_window = int(rolling_window)
+        if self.rolling_window < 1:
+            raise ValueError("Your rolling windows need to be an integer gretter than 1.")
+        self.forward_rolling = bool(forward_rolling)
+        self._history = None
+        self.H, self.nx, self.nu = int(H), int(nx), int(nu)
+        self.nin = self.rolling_window * (self.nx + self.nu)
         self.n_extra = int(n_extra)   # tvp_dim + p_dim of the reference's Model: network inputs that are not variables
         self._extra = None
         self.integrator = integrator if isinstance(integrator, int) else _lib.INTEGRATOR_IDS[integrator]
@@ -77,6 +85,8 @@ class CallbackEngine:
         cfg.max_batch = max_batch
         cfg.kernel = _lib.KERNEL_NAMES[self.kernel] if isinstance(self.kernel, str) else int(self.kernel)
         cfg.n_extra = self.n_extra
+        cfg.rolling_window = self.rolling_window
+        cfg.rolling_reverse = 0 if self.forward_rolling else 1
         cfg.DT = self.DT
         h = ctypes.c_void_p()
         _lib.check(self.lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)))
@@ -93,6 +103,8 @@ class CallbackEngine:
             self.set_box_rows(*self._box)
         if self._extra is not None:
             _lib.check(self.lib.nempc_bind_extra(self._handle, ctypes.c_void_p(self._extra.data_ptr())))
+        if self._history is not None:
+            self.bind_history(*self._history)
         self._refresh_dims()
         self._buffers = {}
 
@@ -158,9 +170,27 @@ class CallbackEngine:
         self._extra = E.contiguous()
         _lib.check(self.lib.nempc_bind_extra(self._handle, ctypes.c_void_p(self._extra.data_ptr())))
 
+    def bind_history(self, hist_x, hist_u):
+        """Bind the history of a rolling-window model: hist_x (B, w-1, nx) states before x0 (oldest first), hist_u
+        (B, w-1, nu) controls before u_0 -- the batched form of set_prev_data (model/tensorflow.py:178-189)."""
+        back = self.rolling_window - 1
+        if back == 0:
+            raise ValueError("this engine was created with rolling_window = 1")
+        for t, d, name in ((hist_x, self.nx, "hist_x"), (hist_u, self.nu, "hist_u")):
+            if (not isinstance(t, torch.Tensor) or t.device != self.device or t.dtype != self.dtype or t.dim() != 3
+                    or tuple(t.shape[1:]) != (back, d)):
+                raise ValueError(f"{name} must be a {self.dtype} tensor (B,{back},{d}) on {self.device}")
+        if hist_x.shape[0] != hist_u.shape[0]:
+            raise ValueError("hist_x and hist_u must cover the same batch")
+        self._history = (hist_x.contiguous(), hist_u.contiguous())
+        _lib.check(self.lib.nempc_bind_history(self._handle, ctypes.c_void_p(self._history[0].data_ptr()),
+                                               ctypes.c_void_p(self._history[1].data_ptr())))
+
     def _check_extra(self, B):
         if self.n_extra and (self._extra is None or self._extra.shape[0] < B):
             raise ValueError("n_extra > 0: call bind_extra with a (B,H,n_extra) tensor covering the batch first")
+        if self.rolling_window > 1 and (self._history is None or self._history[0].shape[0] < B):
+            raise ValueError("You must give history window with set_prev_data before calling any inferance function.")
 
     def set_box_rows(self, lo, hi):
         if lo is None:
@@ -216,7 +246,7 @@ class CallbackEngine:
     def eval(self, Z, X0, want=("f", "grad", "g", "jac_dense"), out=None):
         """One batched callback evaluation.  Z (B,n), X0 (B,nx) device tensors.  Returns a dict with
         the requested outputs (device tensors, reused between calls unless `out` supplies them):
-        f (B,), grad (B,n), g (B,m), jac_dense (B,m,n), jac_tiles (B,H,nx,nx+nu), jac_sparse (B,nnz_jac).
+        f (B,), grad (B,n), g (B,m), jac_dense (B,m,n), jac_tiles (B,H,nx,w*(nx+nu)), jac_sparse (B,nnz_jac).
         Asynchronous on the current torch stream."""
         B = int(Z.shape[0])
         self._check_in(Z, (B, self.n), "Z")
@@ -266,7 +296,7 @@ class CallbackEngine:
 
     def hess(self, Z, X0, lam, sigma, want=("hvals",)):
         """Lagrangian Hessian: hvals (B,nnz_hess) in hess_structure() order, optional hdense (B,n,n)
-        and hblocks (B,H,nx+nu,nx+nu)."""
+        and hblocks (B,H,w*(nx+nu),w*(nx+nu))."""
         B = int(Z.shape[0])
         self._check_in(Z, (B, self.n), "Z")
         self._check_in(X0, (B, self.nx), "X0")

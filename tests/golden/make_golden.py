@@ -119,6 +119,69 @@ def make_plugins(ref):
                 out[t][:, us, us] = S[t][:, nx:nx + nu, nx:nx + nu]
             return out
 
+    class NumpyRollingMLPModel(ref.model_base.Model):
+        """fp64 stand-in for KerasTFModelRollingInput (model/tensorflow.py:132-340) /
+        DiffDiscretJaxModelRollingWindow (model/jax.py:93-259): same constructor arguments, set_prev_data, and
+        output layouts ([all x_t_1 | all u] columns).  The window -> variable projection is written the way
+        gen_jac_proj_mat (model/jax.py:8-21) writes it: variable (step i, component k) sits in the window of
+        step o at slot (w-1) - (o-i) (forward) or o-i (forward_rolling=False) for i <= o <= i+w-1."""
+
+        def __init__(self, net, x_dim, u_dim, p_dim=0, tvp_dim=0, rolling_window=2, forward_rolling=True):
+            super().__init__(x_dim, u_dim, p_dim, tvp_dim)
+            self.net, self.rolling_window, self.forward_rolling = net, rolling_window, forward_rolling
+            self.prev_x = self.prev_u = self.prev_tvp = None
+
+        def set_prev_data(self, x_prev, u_prev, tvp_prev=None):
+            assert x_prev.shape == (self.rolling_window - 1, self.x_dim)
+            assert u_prev.shape == (self.rolling_window - 1, self.u_dim)
+            self.prev_x, self.prev_u, self.prev_tvp = x_prev, u_prev, tvp_prev
+
+        def _roll(self, prev, cur):
+            ext = np.concatenate([prev, cur], axis=0)
+            w = self.rolling_window
+            rows = [ext[i:i + w] for i in range(cur.shape[0])]
+            if not self.forward_rolling:
+                rows = [r[::-1] for r in rows]
+            return np.stack([r.reshape(-1) for r in rows], axis=0)
+
+        def _gather(self, x, u, p, tvp):   # _gather_input_V2, tensorflow.py:205-233
+            parts = [self._roll(self.prev_x, x), self._roll(self.prev_u, u)]
+            if tvp is not None:
+                parts.append(self._roll(self.prev_tvp, tvp))
+            if p is not None:
+                parts.append(np.tile(np.asarray(p).reshape(1, -1), (x.shape[0], 1)))
+            return np.concatenate(parts, axis=1)
+
+        def _proj(self, T, dim):
+            # (T*dim variables, T steps, w*dim window slots) 0/1 selector, cf. gen_jac_proj_mat
+            w = self.rolling_window
+            P = np.zeros((T * dim, T, w * dim))
+            for i in range(T):
+                for k in range(dim):
+                    for o in range(i, min(T, i + w)):
+                        slot = (w - 1) - (o - i) if self.forward_rolling else (o - i)
+                        P[i * dim + k, o, slot * dim + k] = 1.0
+            return P
+
+        def forward(self, x, u, p=None, tvp=None):
+            return self.net.forward(self._gather(x, u, p, tvp))
+
+        def jacobian(self, x, u, p=None, tvp=None):
+            H, nx, nu, w = x.shape[0], self.x_dim, self.u_dim, self.rolling_window
+            _, J = self.net.forward_jac(self._gather(x, u, p, tvp))
+            jx = np.einsum("okc,voc->okv", J[:, :, :w * nx], self._proj(H, nx))
+            ju = np.einsum("okc,voc->okv", J[:, :, w * nx:w * (nx + nu)], self._proj(H, nu))
+            return np.concatenate([jx, ju], axis=2).reshape(H * nx, H * (nx + nu))
+
+        def hessian(self, x, u, p=None, tvp=None):
+            H, nx, nu, w = x.shape[0], self.x_dim, self.u_dim, self.rolling_window
+            _, _, S = self.net.forward_jac_hess(self._gather(x, u, p, tvp))
+            tw = w * (nx + nu)
+            P = np.zeros((H * (nx + nu), H, tw))            # all variables [x | u] x steps x window columns
+            P[:H * nx, :, :w * nx] = self._proj(H, nx)
+            P[H * nx:, :, w * nx:] = self._proj(H, nu)
+            return np.einsum("aoc,okcd,bod->okab", P, S[:, :, :tw, :tw], P)
+
     class QuadObjective(ref.objective_base.ObjectiveFunc):
         """Closed-form member of the objective family; call-site signature of ipopt.py:33,40,71."""
 
@@ -168,7 +231,7 @@ def make_plugins(ref):
         def get_upper_bounds(self, H):
             return np.tile(self.hi, H)
 
-    return NumpyMLPModel, QuadObjective, BoxStateRows
+    return NumpyMLPModel, QuadObjective, BoxStateRows, NumpyRollingMLPModel
 
 
 CASES = {
@@ -189,7 +252,7 @@ CASES = {
 
 
 def build_case(ref, plugins, name, spec):
-    NumpyMLPModel, QuadObjective, BoxStateRows = plugins
+    NumpyMLPModel, QuadObjective, BoxStateRows = plugins[:3]
     nx, nu, hidden, H, kind, DT, box, B, with_h = spec[:9]
     p_dim, tvp_dim = (spec[9], spec[10]) if len(spec) > 9 else (0, 0)
     net = orc.MLP.random(nx + nu + p_dim + tvp_dim, hidden, nx, seed=0)
@@ -264,9 +327,83 @@ def build_case(ref, plugins, name, spec):
     print(f"{name}: n={prob.n} m={prob.m} B={B} nnz(jac)={int((jac[0] != 0).sum())}")
 
 
+ROLLING_CASES = {
+    # name: dict(nx, nu, hidden, H, kind, window, forward, box, B, p_dim, tvp_dim)
+    "roll2_discret": dict(nx=2, nu=1, hidden=[32, 32], H=8, kind=orc.DISCRET, window=2, forward=True, box=None, B=3),
+    "roll3_unity_rev": dict(nx=2, nu=1, hidden=[24], H=7, kind=orc.UNITY, window=3, forward=False, box=(-2.0, 2.0), B=2),
+    "roll3_discret_rev": dict(nx=2, nu=1, hidden=[32, 32], H=6, kind=orc.DISCRET, window=3, forward=False, box=None, B=2),
+    "roll4_wide": dict(nx=3, nu=2, hidden=[40, 40], H=6, kind=orc.DISCRET, window=4, forward=True, box=None, B=2),
+    "roll2_tvp_p": dict(nx=2, nu=1, hidden=[32, 32], H=6, kind=orc.DISCRET, window=2, forward=True, box=None, B=2,
+                        p_dim=1, tvp_dim=1),
+    "roll4_short": dict(nx=2, nu=1, hidden=[16, 16], H=2, kind=orc.DISCRET, window=4, forward=True, box=None, B=2),
+}
+
+
+def build_rolling_case(ref, plugins, name, c):
+    """Rolling-window models under the reference's own DiscretIntegrator / UnityIntegrator / IpoptProblem."""
+    _, QuadObjective, BoxStateRows, NumpyRollingMLPModel = plugins
+    nx, nu, H, kind, w, fwd, box, B = c["nx"], c["nu"], c["H"], c["kind"], c["window"], c["forward"], c["box"], c["B"]
+    p_dim, tvp_dim = c.get("p_dim", 0), c.get("tvp_dim", 0)
+    net = orc.MLP.random(w * (nx + nu) + w * tvp_dim + p_dim, c["hidden"], nx, seed=0)
+    rng = np.random.default_rng(7)
+    xref = rng.normal(size=(H, nx)) * 0.3
+    uref = rng.normal(size=(H, nu)) * 0.3
+    cu = rng.normal(size=(H, nu)) * 0.1
+    Q = np.eye(nx) + 0.1 * rng.normal(size=(nx, nx))
+    Rm = 0.1 * np.eye(nu)
+    pvec = rng.normal(size=p_dim) if p_dim else None
+    tvp = rng.normal(size=(H, tvp_dim)) if tvp_dim else None
+    prev_tvp = rng.normal(size=(w - 1, tvp_dim)) if tvp_dim else None
+    hist_x = rng.normal(size=(B, w - 1, nx))
+    hist_u = rng.uniform(-1.0, 1.0, size=(B, w - 1, nu))
+    model = NumpyRollingMLPModel(net, nx, nu, p_dim, tvp_dim, rolling_window=w, forward_rolling=fwd)
+    integ = ref.discret.DiscretIntegrator(model, H) if kind == orc.DISCRET else ref.unity.UnityIntegrator(model, H)
+    ctrs = [BoxStateRows(np.full(nx, box[0]), np.full(nx, box[1]), nx, nu)] if box is not None else []
+    # objective values come from the closed-form family; the network argument of Problem is unused by them
+    obj = QuadObjective(orc.Problem(orc.MLP.random(nx + nu, [4], nx), H, nx, nu, Q=Q, R=Rm, xref=xref, uref=uref, cu=cu))
+    Z, X0 = orc.synthetic_inputs(B, H, nx, nu, seed=1)
+    m = H * nx * (2 if box is not None else 1)
+    lam = np.random.default_rng(3).normal(size=(B, m))
+    sigma = np.array([1.0, 0.5, 2.0, 0.0])[:B]
+
+    out = {"nx": nx, "nu": nu, "H": H, "kind": kind, "DT": 1.0, "hidden": np.array(c["hidden"]), "window": w,
+           "forward_rolling": int(fwd), "hist_x": hist_x, "hist_u": hist_u,
+           "Z": Z, "X0": X0, "Q": Q, "R": Rm, "xref": xref, "uref": uref, "cu": cu,
+           "lam": lam, "sigma": sigma, "has_box": int(box is not None), "p_dim": p_dim, "tvp_dim": tvp_dim}
+    if p_dim:
+        out["p"] = pvec
+    if tvp_dim:
+        out["tvp"], out["prev_tvp"] = tvp, prev_tvp
+    if box is not None:
+        out["box_lo"], out["box_hi"] = np.full(nx, box[0]), np.full(nx, box[1])
+    for i, (wt, b) in enumerate(zip(net.W, net.b)):
+        out[f"W{i}"], out[f"b{i}"] = wt, b
+
+    f, grad, g, jac, hvals, hdense = [], [], [], [], [], []
+    for b in range(B):
+        model.set_prev_data(hist_x[b], hist_u[b], tvp_prev=prev_tvp)
+        pb = ref.ipopt.IpoptProblem(X0[b], obj, ctrs, integ, p=pvec, tvp=tvp)
+        f.append(pb.objective(Z[b]))
+        grad.append(pb.gradient(Z[b]))
+        g.append(pb.constraints(Z[b]))
+        jac.append(pb.jacobian(Z[b]))
+        states, u = Z[b][:H * nx].reshape(H, nx), Z[b][H * nx:].reshape(H, nu)
+        np.random.seed(11)
+        rows, cols = pb.hessianstructure()
+        out["h_rows"], out["h_cols"] = rows, cols
+        hvals.append(pb.hessian(Z[b], lam[b], sigma[b]))
+        ih = integ.hessian(states, u, X0[b], p=pvec, tvp=tvp)
+        hdense.append(sigma[b] * obj.hessian(states, u) + np.einsum("i,ipq->pq", lam[b][:H * nx], ih))
+    out.update(f=np.array(f), grad=np.array(grad), g=np.array(g), jac=np.array(jac),
+               hvals=np.array(hvals), hdense=np.array(hdense))
+    out["cl"], out["cu_bound"] = pb.get_constraint_lower_bounds(), pb.get_constraint_upper_bounds()
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+    print(f"{name}: w={w} n={H * (nx + nu)} m={m} B={B} nnz(jac)={int((jac[0] != 0).sum())}")
+
+
 def build_misc(ref, plugins):
     """Bounds vectors, warm-start shift, and one full NMPC.next trajectory through reference SLSQP."""
-    NumpyMLPModel, QuadObjective, _ = plugins
+    NumpyMLPModel, QuadObjective = plugins[:2]
     out = {}
     dc = ref.constraints.DomainConstraint(states_constraint=[[-np.inf, 1.0], [-2.0, np.inf]],
                                           control_constraint=[[-1.0, 0.2]])
@@ -313,9 +450,15 @@ def build_misc(ref, plugins):
 def main():
     ref = import_reference()
     plugins = make_plugins(ref)
+    only = sys.argv[1:]
     for name, spec in CASES.items():
-        build_case(ref, plugins, name, spec)
-    build_misc(ref, plugins)
+        if not only or name in only:
+            build_case(ref, plugins, name, spec)
+    for name, spec in ROLLING_CASES.items():
+        if not only or name in only or "rolling" in only:
+            build_rolling_case(ref, plugins, name, spec)
+    if not only or "misc" in only:
+        build_misc(ref, plugins)
 
 
 if __name__ == "__main__":

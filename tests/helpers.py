@@ -9,14 +9,22 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 CASE_NAMES = ["c1_discret", "c2_discret", "c2_unity", "c2_rk4", "c3_rk4", "c3_discret", "c5_box",
               "odd_dims", "h1", "tvp_p_discret", "tvp_p_rk4"]
+ROLLING_NAMES = ["roll2_discret", "roll3_unity_rev", "roll3_discret_rev", "roll4_wide", "roll2_tvp_p", "roll4_short"]
 
 
 def case_extra(d):
-    """(H, tvp_dim + p_dim) extra network inputs of a golden case, [tvp_t | p], or None."""
+    """(H, tvp_dim + p_dim) extra network inputs of a golden case, [tvp_t | p], or None.  Rolling cases roll the
+    time-varying parameters like the states (model/tensorflow.py:218-228): (H, w*tvp_dim + p_dim)."""
     H = int(d["H"])
     parts = []
     if int(d.get("tvp_dim", 0)):
-        parts.append(d["tvp"])
+        w = int(d.get("window", 1))
+        if w > 1:
+            ext = np.concatenate([d["prev_tvp"], d["tvp"]], axis=0)
+            order = slice(None) if int(d["forward_rolling"]) else slice(None, None, -1)
+            parts.append(np.stack([ext[t:t + w][order].reshape(-1) for t in range(H)], axis=0))
+        else:
+            parts.append(d["tvp"])
     if int(d.get("p_dim", 0)):
         parts.append(np.tile(d["p"].reshape(1, -1), (H, 1)))
     return np.concatenate(parts, axis=1) if parts else None
@@ -30,8 +38,13 @@ def load_case(name):
     return d, W, b
 
 
-def oracle_problem(d, W, b):
+def oracle_problem(d, W, b, i=0):
+    """Oracle Problem of a golden case; for rolling cases with the history of problem i of the batch."""
     net = orc.MLP(W, b)
     box = (d["box_lo"], d["box_hi"]) if int(d["has_box"]) else None
+    w = int(d.get("window", 1))
+    roll = {} if w == 1 else dict(window=w, forward_rolling=bool(int(d["forward_rolling"])),
+                                  hist_x=d["hist_x"][i], hist_u=d["hist_u"][i])
     return orc.Problem(net, int(d["H"]), int(d["nx"]), int(d["nu"]), int(d["kind"]), float(d["DT"]),
-                       Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"], box=box, extra=case_extra(d))
+                       Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"], box=box, extra=case_extra(d),
+                       **roll)

@@ -27,9 +27,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_matches_header_layout():
     from pyneuralempc_amd import _lib
-    # 8 int32 + 8 widths + 3 int32 = 19 int32 (76 B) -> padded to 80, + double = 88
-    assert ctypes.sizeof(_lib.NempcConfig) == 88
-    assert _lib.NempcConfig.DT.offset == 80
+    # 8 int32 + 8 widths + 5 int32 = 21 int32 (84 B) -> padded to 88, + double = 96
+    assert ctypes.sizeof(_lib.NempcConfig) == 96
+    assert _lib.NempcConfig.rolling_window.offset == 76
+    assert _lib.NempcConfig.DT.offset == 88
 
 
 def test_create_validates_before_touching_the_device_and_fails_loudly_without_gpu():
@@ -51,6 +52,11 @@ def test_create_validates_before_touching_the_device_and_fails_loudly_without_gp
     cfg.max_batch = 1
     cfg.integrator, cfg.DT = 2, 0.0   # RK4 without DT
     assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    cfg.integrator, cfg.DT = 0, 1.0
+    assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"rolling_window" in lib.nempc_last_error()
+    cfg.rolling_window, cfg.integrator = 2, 2   # the reference has no RK4 for rolling-window models
+    assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -5
+    cfg.rolling_window = 1
     if not torch.cuda.is_available():
         cfg.integrator = 0
         rc = lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h))

@@ -1,0 +1,160 @@
+"""GPU parity for rolling-window models (KerasTFModelRollingInput model/tensorflow.py:132-340,
+DiffDiscretJaxModelRollingWindow model/jax.py:93-259): the HIP path through the C ABI against golden vectors
+produced by the reference's DiscretIntegrator / UnityIntegrator / IpoptProblem, and against the oracle on seeded
+batches with a different history per problem.  fp64 1e-12; fp32 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nempc_oracle as orc
+from helpers import ROLLING_NAMES, case_extra, load_case, oracle_problem
+
+pytestmark = pytest.mark.gpu
+
+F64 = dict(rtol=1e-12, atol=1e-12)
+KIND_NAME = {0: "discret", 1: "unity", 2: "rk4"}
+ALL = ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")
+
+
+def _kernels(d):
+    tw = int(d["window"]) * (int(d["nx"]) + int(d["nu"]))
+    ex = case_extra(d)
+    fits = tw + (0 if ex is None else ex.shape[1]) <= 16
+    return ["valu", "mfma", "mfma_tile"] if fits else ["valu"]
+
+
+def _engine(d, W, b, dtype, kernel):
+    from pyneuralempc_amd import CallbackEngine
+    ex = case_extra(d)
+    B = d["Z"].shape[0]
+    eng = CallbackEngine(W, b, int(d["H"]), int(d["nx"]), int(d["nu"]), integrator=KIND_NAME[int(d["kind"])],
+                         dtype=dtype, device="cuda:0", max_batch=B, kernel=kernel,
+                         n_extra=0 if ex is None else ex.shape[1], rolling_window=int(d["window"]),
+                         forward_rolling=bool(int(d["forward_rolling"])))
+    if ex is not None:
+        eng.bind_extra(eng.to_device(np.broadcast_to(ex[None], (B,) + ex.shape).copy()))
+    eng.bind_history(eng.to_device(d["hist_x"]), eng.to_device(d["hist_u"]))
+    eng.set_objective(Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"])
+    if int(d["has_box"]):
+        eng.set_box_rows(d["box_lo"], d["box_hi"])
+    return eng
+
+
+@pytest.mark.parametrize("name", ROLLING_NAMES)
+def test_rolling_golden_fp64(name):
+    d, W, b = load_case(name)
+    for kernel in _kernels(d):
+        eng = _engine(d, W, b, torch.float64, kernel)
+        assert eng.kernel_variant == kernel
+        res = eng.eval_numpy(d["Z"], d["X0"], want=ALL)
+        np.testing.assert_allclose(res["f"], d["f"], **F64)
+        np.testing.assert_allclose(res["grad"], d["grad"], **F64)
+        np.testing.assert_allclose(res["g"], d["g"], **F64)
+        np.testing.assert_allclose(res["jac_dense"], d["jac"], **F64)
+        assert np.array_equal(res["jac_dense"] != 0, d["jac"] != 0)
+        rows, cols = eng.jac_structure()
+        assert np.array_equal(res["jac_sparse"], res["jac_dense"][:, rows, cols])
+        assert np.all(np.diff(rows.astype(np.int64) * eng.n + cols) > 0)     # row-major sorted, no duplicates
+        for i in range(d["Z"].shape[0]):
+            _, _, dphi, _ = oracle_problem(d, W, b, i).tiles(d["Z"][i], d["X0"][i])
+            np.testing.assert_allclose(res["jac_tiles"][i], dphi, **F64)
+        cl, cu = eng.constraint_bounds()
+        np.testing.assert_array_equal(cl, d["cl"])
+        np.testing.assert_array_equal(cu, d["cu_bound"])
+        if kernel != "valu":
+            assert eng.last_row_kernel == "rows_mfma_kernel"
+
+
+@pytest.mark.parametrize("name", ROLLING_NAMES)
+def test_rolling_golden_hessian_fp64(name):
+    d, W, b = load_case(name)
+    for kernel in _kernels(d):
+        eng = _engine(d, W, b, torch.float64, kernel)
+        out = eng.hess(eng.to_device(d["Z"]), eng.to_device(d["X0"]), eng.to_device(d["lam"]),
+                       eng.to_device(d["sigma"]), want=("hvals", "hdense", "hblocks"))
+        hd, hv = out["hdense"].cpu().numpy(), out["hvals"].cpu().numpy()
+        np.testing.assert_allclose(hd, d["hdense"], rtol=1e-11, atol=1e-12)
+        rows, cols = eng.hess_structure()
+        assert np.array_equal(hv, hd[:, rows, cols])
+        np.testing.assert_allclose(hd[:, d["h_rows"], d["h_cols"]], d["hvals"], rtol=1e-11, atol=1e-12)
+        orows, ocols = oracle_problem(d, W, b).hessian_structure()
+        assert np.array_equal(rows, orows) and np.array_equal(cols, ocols)
+        assert np.array_equal(hd, np.transpose(hd, (0, 2, 1)))
+        mask = np.zeros(hd.shape[1:], dtype=bool)
+        mask[rows, cols] = True
+        assert np.all(np.tril(hd)[:, ~mask] == 0.0)
+
+
+@pytest.mark.parametrize("name", ["roll2_discret", "roll3_unity_rev", "roll4_wide"])
+def test_rolling_golden_fp32(name):
+    d, W, b = load_case(name)
+    for kernel in _kernels(d):
+        eng = _engine(d, W, b, torch.float32, kernel)
+        res = eng.eval_numpy(d["Z"], d["X0"], want=ALL)
+        for k, ref in (("f", d["f"]), ("grad", d["grad"]), ("g", d["g"]), ("jac_dense", d["jac"])):
+            scale = max(1.0, np.abs(ref).max())
+            assert np.abs(res[k] - ref).max() / scale < 1e-4, f"{name}/{kernel}/{k}"
+        assert np.array_equal(res["jac_dense"] != 0, d["jac"] != 0)
+
+
+@pytest.mark.parametrize("cfg", [(2, 1, [64, 64], 20, 2, True, 70), (2, 1, [64, 64], 20, 4, False, 37),
+                                 (3, 1, [32, 32, 32], 9, 3, True, 19), (4, 2, [48], 5, 5, True, 6)])
+def test_rolling_seeded_batches_against_oracle(cfg):
+    """Bigger batches (ragged last tile, per-problem histories) against the oracle; C2 dims with a window."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, hidden, H, w, fwd, B = cfg
+    tw = w * (nx + nu)
+    net = orc.MLP.random(tw, hidden, nx, seed=3)
+    rng = np.random.default_rng(11)
+    hx, hu = rng.normal(size=(B, w - 1, nx)), rng.uniform(-1, 1, size=(B, w - 1, nu))
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=5)
+    lamh = rng.normal(size=(B, H * nx))
+    sigh = rng.uniform(0.0, 2.0, size=B)
+    kernels = ["valu", "mfma"] if tw <= 16 else ["valu"]
+    for kernel in kernels:
+        eng = CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B, kernel=kernel,
+                             rolling_window=w, forward_rolling=fwd)
+        eng.bind_history(eng.to_device(hx), eng.to_device(hu))
+        res = eng.eval_numpy(Zh, X0h, want=("g", "jac_dense"))
+        out = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lamh), eng.to_device(sigh),
+                       want=("hdense",))
+        hd = out["hdense"].cpu().numpy()
+        for i in list(range(0, B, max(1, B // 5))) + [B - 1]:
+            prob = orc.Problem(net, H, nx, nu, orc.DISCRET, window=w, forward_rolling=fwd, hist_x=hx[i], hist_u=hu[i])
+            np.testing.assert_allclose(res["g"][i], prob.constraints(Zh[i], X0h[i]), **F64)
+            np.testing.assert_allclose(res["jac_dense"][i], prob.jacobian(Zh[i], X0h[i]), **F64)
+            np.testing.assert_allclose(hd[i], prob.lagrangian_hessian(Zh[i], X0h[i], lamh[i], sigh[i]),
+                                       rtol=1e-10, atol=1e-11)
+
+
+def test_rolling_window_of_one_is_the_plain_model():
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, H, B = 2, 1, 6, 5
+    net = orc.MLP.random(nx + nu, [32, 32], nx, seed=1)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=2)
+    a = CallbackEngine(net.W, net.b, H, nx, nu, device="cuda:0", max_batch=B)
+    b = CallbackEngine(net.W, net.b, H, nx, nu, device="cuda:0", max_batch=B, rolling_window=1, forward_rolling=False)
+    ra, rb = a.eval_numpy(Zh, X0h), b.eval_numpy(Zh, X0h)
+    for k in ra:
+        assert np.array_equal(ra[k], rb[k])
+
+
+def test_rolling_errors():
+    from pyneuralempc_amd import CallbackEngine
+    from pyneuralempc_amd._lib import NempcError
+    nx, nu, H = 2, 1, 4
+    net = orc.MLP.random(2 * (nx + nu), [16], nx, seed=1)
+    with pytest.raises(NempcError, match="DISCRET or UNITY"):
+        CallbackEngine(net.W, net.b, H, nx, nu, integrator="rk4", DT=0.1, device="cuda:0", rolling_window=2)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, device="cuda:0", max_batch=2, rolling_window=2)
+    Z, X0 = (eng.to_device(a) for a in orc.synthetic_inputs(2, H, nx, nu))
+    with pytest.raises(ValueError, match="set_prev_data"):
+        eng.eval(Z, X0)
+    with pytest.raises(ValueError, match="hist_x"):
+        eng.bind_history(torch.zeros(2, 2, nx, dtype=torch.float64, device="cuda:0"),
+                         torch.zeros(2, 1, nu, dtype=torch.float64, device="cuda:0"))
+    eng.bind_history(torch.zeros(2, 1, nx, dtype=torch.float64, device="cuda:0"),
+                     torch.zeros(2, 1, nu, dtype=torch.float64, device="cuda:0"))
+    eng.eval(Z, X0)
+    with pytest.raises(NempcError, match="rolling-window"):
+        eng.solve(X0)

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import nempc_oracle as orc
-from helpers import CASE_NAMES, load_case, oracle_problem
+from helpers import CASE_NAMES, ROLLING_NAMES, load_case, oracle_problem
 
 TOL = dict(rtol=1e-12, atol=1e-12)
 
@@ -49,6 +49,48 @@ def test_oracle_hessian_matches_reference_golden(name):
         mask = np.zeros_like(Hm, dtype=bool)
         mask[rows, cols] = True
         assert np.all(np.tril(Hm)[~mask] == 0.0)
+
+
+@pytest.mark.parametrize("name", ROLLING_NAMES)
+def test_oracle_rolling_window_matches_reference_golden(name):
+    """Rolling-window models under the reference's DiscretIntegrator / UnityIntegrator / IpoptProblem."""
+    d, W, b = load_case(name)
+    for i in range(d["Z"].shape[0]):
+        prob = oracle_problem(d, W, b, i)
+        z, x0 = d["Z"][i], d["X0"][i]
+        np.testing.assert_allclose(prob.objective(z), d["f"][i], **TOL)
+        np.testing.assert_allclose(prob.gradient(z), d["grad"][i], **TOL)
+        np.testing.assert_allclose(prob.constraints(z, x0), d["g"][i], **TOL)
+        np.testing.assert_allclose(prob.jacobian(z, x0), d["jac"][i], **TOL)
+        assert np.array_equal(prob.jacobian(z, x0) != 0, d["jac"][i] != 0)
+        Hm = prob.lagrangian_hessian(z, x0, d["lam"][i], float(d["sigma"][i]))
+        np.testing.assert_allclose(Hm, d["hdense"][i], rtol=1e-11, atol=1e-12)
+        np.testing.assert_allclose(Hm[d["h_rows"], d["h_cols"]], d["hvals"][i], rtol=1e-11, atol=1e-12)
+        rows, cols = prob.hessian_structure()
+        assert set(zip(d["h_rows"].tolist(), d["h_cols"].tolist())) <= set(zip(rows.tolist(), cols.tolist()))
+        mask = np.zeros_like(Hm, dtype=bool)
+        mask[rows, cols] = True
+        assert np.all(np.tril(Hm)[~mask] == 0.0)
+    cl, cu = prob.constraint_bounds()
+    np.testing.assert_array_equal(cl, d["cl"])
+    np.testing.assert_array_equal(cu, d["cu_bound"])
+
+
+def test_rolling_window_derivatives_vs_finite_differences():
+    d, W, b = load_case("roll3_discret_rev")
+    prob = oracle_problem(d, W, b, 1)
+    z, x0 = d["Z"][1], d["X0"][1]
+    J = prob.jacobian(z, x0)
+    lam = d["lam"][1]
+    Hm = prob.lagrangian_hessian(z, x0, lam, 0.0)
+    eps = 1e-6
+    Jfd, Hfd = np.zeros_like(J), np.zeros_like(Hm)
+    for j in range(prob.n):
+        e = np.zeros(prob.n); e[j] = eps
+        Jfd[:, j] = (prob.constraints(z + e, x0) - prob.constraints(z - e, x0)) / (2 * eps)
+        Hfd[:, j] = (lam @ prob.jacobian(z + e, x0) - lam @ prob.jacobian(z - e, x0)) / (2 * eps)
+    assert np.abs(J - Jfd).max() < 1e-8
+    assert np.abs(Hm - Hfd).max() < 1e-7
 
 
 def test_slsqp_glue_rows():
