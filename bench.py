@@ -55,8 +55,30 @@ def algorithmic_work(cfg, B, m, n):
     return dict(flops=flops * B, dense_bytes=dense_bytes * B, compact_bytes=compact_bytes * B)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box hands a one-GPU job
+    a share of the host, and more OpenMP threads than that share only get throttled)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return n
+
+
 def cpu_baseline(cfg, seconds=12.0):
-    """C/OpenMP oracle (oracle/nempc_oracle.c) on all host cores, bounded sample of the same workload."""
+    """C/OpenMP oracle (oracle/nempc_oracle.c) on the host cores this job may use, bounded sample of the same workload."""
     from oracle import nempc_oracle as orc
     from oracle.c_oracle import COracle
     kind = {"discret": orc.DISCRET, "unity": orc.UNITY, "rk4": orc.RK4}[cfg["integrator"]]
@@ -65,10 +87,11 @@ def cpu_baseline(cfg, seconds=12.0):
     Bs = 512
     Z, X0 = orc.synthetic_inputs(Bs, cfg["H"], cfg["nx"], cfg["nu"], seed=1)
     co = COracle(prob)
-    co.eval(Z, X0)  # warm
+    nthr = min(usable_cpus(), 128)
+    co.eval(Z, X0, nthreads=nthr)  # warm
     reps, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        co.eval(Z, X0)
+        co.eval(Z, X0, nthreads=nthr)
         reps += 1
     dt = time.perf_counter() - t0
     # single-thread, reference-shaped NumPy loop (per-problem, dense assembly) on a small sample, for context
@@ -81,7 +104,8 @@ def cpu_baseline(cfg, seconds=12.0):
     ref_rate = nref / (time.perf_counter() - t1)
     return {"value": Bs * reps / dt, "unit": "problem-evals/s", "cores": int(co.threads_used), "kind": "port",
             "sample": f"{reps} x {Bs} problem-evals of the same workload in {dt:.1f}s, C/OpenMP oracle "
-                      f"(oracle/nempc_oracle.c), host has {os.cpu_count()} logical cpus",
+                      f"(oracle/nempc_oracle.c) on {nthr} threads; host has {os.cpu_count()} logical cpus, "
+                      f"{usable_cpus()} usable by this job (affinity / cgroup quota)",
             "numpy_reference_shaped_1core": ref_rate}, prob
 
 
@@ -171,8 +195,21 @@ def main():
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) * 1e-3 / reps
 
+    def per_step_us(fn, reps):
+        """one HIP event pair per evaluation -> (p10, median, p90) in microseconds"""
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        fn(); torch.cuda.synchronize(dev)
+        evs[0].record()
+        for i in range(reps):
+            fn()
+            evs[i + 1].record()
+        torch.cuda.synchronize(dev)
+        d = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(reps)]) * 1e3
+        return [float(np.percentile(d, q)) for q in (10, 50, 90)]
+
     reps = max(args.steps, 50)
     t_rows = timed(eng.bind(Z, X0, ("g", "jac_tiles"))[0], reps)
+    step_pcts = per_step_us(step, reps)
     t_all = timed(step, reps)
     work = algorithmic_work(cfg, B, eng.m, eng.n)
     peak_tf = PEAK_F64_TFLOPS if cfg["dtype"] == "f64" else PEAK_F32_TFLOPS
@@ -184,13 +221,16 @@ def main():
 
     # ---- batched on-device solver + the one collective of the design: all-gather of the solved u0
     solver_info = None
-    if cfg["box"] is None and cfg["integrator"] != "rk4":   # (RK4 Lagrangian blocks run on the generic kernel: minutes)
+    # (RK4 Lagrangian blocks on the generic kernel take minutes at C3 dims: only with the matrix-core pipeline)
+    if cfg["box"] is None and (cfg["integrator"] != "rk4" or eng.kernel_variant != "valu"):
         lbv = np.concatenate([np.full(cfg["H"] * cfg["nx"], -3.0), np.full(cfg["H"] * cfg["nu"], -0.5)])
         Xs = eng.to_device(np.random.default_rng(100 + rank).uniform(-0.5, 0.5, size=(B, cfg["nx"])))
-        eng.solve(Xs, lb=lbv, ub=-lbv, max_iter=5)   # warm
+        # fp32 configs: tolerances an fp32 iterate can reach
+        tols = {} if cfg["dtype"] == "f64" else dict(tol_constraint=1e-4, tol_step=1e-4, mu_min=1e-5, reg=1e-6)
+        eng.solve(Xs, lb=lbv, ub=-lbv, max_iter=5, **tols)   # warm
         barrier()
         ts = time.perf_counter()
-        Zs, st, its = eng.solve(Xs, lb=lbv, ub=-lbv, max_iter=40)
+        Zs, st, its = eng.solve(Xs, lb=lbv, ub=-lbv, max_iter=40, **tols)
         torch.cuda.synchronize(dev)
         t_solve = time.perf_counter() - ts
         u0 = Zs[:, u0_off:u0_off + cfg["nu"]].contiguous()
@@ -210,7 +250,7 @@ def main():
                        "note": "SQP + Riccati, exact Lagrangian blocks, bounds |x|<=3 |u|<=0.5 via log barrier, <=40 iterations"}
 
     hess_info = None
-    if args.hessian and cfg["integrator"] != "rk4":
+    if args.hessian and (cfg["integrator"] != "rk4" or eng.kernel_variant != "valu"):
         lam = torch.randn(B, eng.m, dtype=tdtype, device=dev)
         sig = torch.ones(B, dtype=tdtype, device=dev)
         t_h = timed(lambda: eng.hess(Z, X0, lam, sig), max(args.steps // 4, 10))
@@ -245,7 +285,8 @@ def main():
                          "arithmetic_intensity_dense": ai, "ridge": ridge},
             "roofline_hbm_whole_eval": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                         "frac": ach_gbs / PEAK_HBM_GBS, "bytes_per_eval_dense_contract":
-                                            work["dense_bytes"], "eval_us": t_step * 1e6, "eval_us_event_loop": t_all * 1e6},
+                                            work["dense_bytes"], "eval_us": t_step * 1e6, "eval_us_event_loop": t_all * 1e6,
+                                        "eval_us_p10_median_p90": step_pcts},
         }
         # HBM bytes of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
         pmc_file = os.path.join(REPO, "profiles", "r01b_c2_b1024_pmc.json")

@@ -11,7 +11,7 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libnempc.so")
 SOURCES = ["nempc_api.hip", "kernels_valu.hip", "kernels_post.hip", "kernels_mfma.hip",
-           "kernels_mfma_f64.hip", "kernels_mfma_f32.hip", "solver.hip"]
+           "kernels_mfma_f64.hip", "kernels_mfma_f32.hip", "kernels_rk4hess.hip", "solver.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
 

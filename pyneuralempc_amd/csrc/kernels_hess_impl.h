@@ -25,6 +25,12 @@ struct HessParams {
     const void* lambda;  // (B, m)
     void* blocks;        // (B, H, nin, nin)
     int p0tab, wLb, ksx; // extra blob tables: first-layer rows, output-layer fragments for W_L lambda, ceil(nx/4)
+    // direct mode (RK4 pipeline, kernels_rk4hess.hip): the kernel's rows are (row, stage) pairs whose network input
+    // and multipliers are given explicitly instead of being gathered from Z / lambda
+    const void* xi_direct;   // record r at xi_direct + r * xi_stride, first nin values = xi
+    int xi_stride;
+    const void* lam_direct;  // (rows, nx) stage multipliers nu_s
+    int vdiv;                // rows per (problem, step) row: the extra inputs of row r are those of r / vdiv
 };
 
 template <typename T, int WP, int NH, bool WLDS>
@@ -52,7 +58,7 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
     }
     const int nx = p.nx, nin = p.nin, H = p.H;
     const int n = p.gk.n;
-    const size_t R = (size_t)p.B * H;
+    const size_t R = (size_t)p.B * H * (hp.xi_direct ? hp.vdiv : 1);
     const T* __restrict__ Z = static_cast<const T*>(p.Z);
     const T* __restrict__ X0 = static_cast<const T*>(p.X0);
     const T* __restrict__ lam = static_cast<const T*>(hp.lambda);
@@ -71,9 +77,14 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
             const size_t r = row0 + cc;
             T v = T(0);
             if (r < R) {
-                const int b = (int)((unsigned)r / (unsigned)H), t = (int)((unsigned)r - (unsigned)b * (unsigned)H);
-                if (d < nin) v = gather_input<T>(p.gk, Z + (size_t)b * n, X0, b, t, d);
-                else v = lam[(size_t)b * p.m + t * nx + (d - nin)];
+                if (hp.xi_direct) {
+                    if (d < nin) v = static_cast<const T*>(hp.xi_direct)[r * (size_t)hp.xi_stride + d];
+                    else v = static_cast<const T*>(hp.lam_direct)[r * nx + (d - nin)];
+                } else {
+                    const int b = (int)((unsigned)r / (unsigned)H), t = (int)((unsigned)r - (unsigned)b * (unsigned)H);
+                    if (d < nin) v = gather_input<T>(p.gk, Z + (size_t)b * n, X0, b, t, d);
+                    else v = lam[(size_t)b * p.m + t * nx + (d - nin)];
+                }
             }
             if (d < nin) s_xi0[cc * nin + d] = v;
             else s_lam[cc * nx + (d - nin)] = v;
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
         for (int e = lane; e < 16 * p.ne; e += 64) {
             const int cc = e / p.ne, j = e - cc * p.ne;
             const size_t r = row0 + cc;
-            s_ex[e] = (r < R) ? static_cast<const T*>(p.extra)[r * p.ne + j] : T(0);
+            s_ex[e] = (r < R) ? static_cast<const T*>(p.extra)[(hp.xi_direct ? r / hp.vdiv : r) * p.ne + j] : T(0);
         }
         wave_sync();
 

@@ -122,6 +122,11 @@ int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b)
 }
 
 int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s) {
+    return launch_rows_mfma_stages(h, B, Z, X0, g, tiles, nullptr, 0, s);
+}
+
+int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* stage_out,
+                            int stage_stride, hipStream_t s) {
     if (!h.mfma.blob) {
         set_error("launch_rows_mfma: weights not packed");
         return NEMPC_ESTATE;
@@ -135,6 +140,7 @@ int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, v
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
     p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
     p.gk = h.gather();
+    p.stage_out = stage_out; p.stage_stride = stage_stride;
     p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
     p.scratch_per_wave = (scratch_elems(h) + 1) & ~1;
     p.dbg = h.d_dbg;
@@ -143,6 +149,11 @@ int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, v
 
 int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
                         hipStream_t s) {
+    return launch_rowhess_mfma_direct(h, B, Z, X0, lambda, blocks, nullptr, 0, nullptr, 1, s);
+}
+
+int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
+                               const void* xi_direct, int xi_stride, const void* lam_direct, int vdiv, hipStream_t s) {
     if (!h.mfma.blob) {
         set_error("launch_rowhess_mfma: weights not packed");
         return NEMPC_ESTATE;
@@ -157,7 +168,8 @@ int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const v
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
     p.Z = Z; p.X0 = X0; p.g = nullptr; p.tiles = nullptr;
     p.gk = h.gather();
-    p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
+    p.ntiles = (int)(((size_t)B * h.cfg.H * (xi_direct ? vdiv : 1) + 15) / 16);
+    hp.xi_direct = xi_direct; hp.xi_stride = xi_stride; hp.lam_direct = lam_direct; hp.vdiv = vdiv;
     p.scratch_per_wave = (16 * h.nin + 16 * h.cfg.nx + 16 * h.nin * h.nin + 16 * h.ne + 1) & ~1;
     p.dbg = nullptr;
     hp.lambda = lambda; hp.blocks = blocks;

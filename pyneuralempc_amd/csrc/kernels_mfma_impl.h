@@ -48,6 +48,8 @@ struct MfmaParams {
     int tiles_per_wg, tiles_rem;  // cooperative kernel: ntiles = grid * tiles_per_wg + tiles_rem
     int scratch_per_wave;  // elements
     RowGather gk;          // input gather (rolling windows); nin above is the tile width w*(nx+nu)
+    void* stage_out;       // RK4 Hessian pipeline only: per (row, stage) record [xi_s (nin) | J_s (nx*nin) | dk_{s-1} (nx*nin)]
+    int stage_stride;      // elements per record = nin + 2*nx*nin
     long long* dbg;        // diagnostic builds only (-DNEMPC_STAMPS): per-wave phase stamps of workgroup 0
 };
 
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
     T* __restrict__ gout = static_cast<T*>(p.g);
     T* __restrict__ tiles = static_cast<T*>(p.tiles);
     const bool rk4 = p.kind == NEMPC_RK4;
+    const bool want_jac = p.tiles != nullptr;   // defect-only launches (line-search trials of the batched solver)
     const int nstages = rk4 ? 4 : 1;
     const T DT = (T)p.DT;
 
@@ -286,6 +289,8 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
                     v = s_ex[c * p.ne + (d - nin)];
                 }
                 xin[ks] = v;
+                if (p.stage_out && ks < p.ks && d < nin && row0 + c < R)
+                    static_cast<T*>(p.stage_out)[((row0 + c) * 4 + stage) * (size_t)p.stage_stride + d] = v;
             }
             wave_sync();  // s_k is overwritten below
 
@@ -339,15 +344,17 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
                 }
             }
             // 1 - a^2 once, reused by every cotangent
+            if (want_jac) {
 #pragma unroll
-            for (int l = 0; l < NH; ++l)
+                for (int l = 0; l < NH; ++l)
 #pragma unroll
-                for (int mo = 0; mo < MT; ++mo)
+                    for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a[l][mo][r] = T(1) - a[l][mo][r] * a[l][mo][r];
+                        for (int r = 0; r < 4; ++r) a[l][mo][r] = T(1) - a[l][mo][r] * a[l][mo][r];
+            }
 
-            // ---- reverse sweep, one cotangent per network output
-            for (int k = 0; k < nx; ++k) {
+            // ---- reverse sweep, one cotangent per network output (skipped by defect-only launches: tiles == null)
+            for (int k = 0; k < (want_jac ? nx : 0); ++k) {
                 V4 cv[MT];
                 const T* seed = wsrc + p.off.seed + k * MT * 16;
 #pragma unroll
@@ -374,10 +381,23 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
             }
             wave_sync();
 
+            // stage record for the Hessian pipeline: this stage's Jacobian and the chain Jacobian it was entered with
+            if (p.stage_out && want_jac) {
+                T* so = static_cast<T*>(p.stage_out);
+                const int jn = nx * nin;
+                for (int e = lane; e < jsz; e += 64) {
+                    const int cc = e / jn, rem = e - cc * jn;
+                    if (row0 + cc < R) {
+                        T* rec = so + ((row0 + cc) * 4 + stage) * (size_t)p.stage_stride + nin;
+                        rec[rem] = s_J[e];
+                        rec[jn + rem] = stage > 0 ? s_dk[e] : T(0);
+                    }
+                }
+            }
             // ---- RK4 chain rule on the scratch (rk4.py:147-159)
             if (rk4) {
                 if (stage == 0) {
-                    for (int e = lane; e < jsz; e += 64) {
+                    for (int e = lane; e < (want_jac ? jsz : 0); e += 64) {
                         const T v = s_J[e];
                         s_dk[e] = v;
                         s_accdk[e] = v;
@@ -385,7 +405,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
                     for (int e = lane; e < 16 * nx; e += 64) s_acck[e] = s_k[e];
                 } else {
                     const T wgt = (stage == 3) ? T(1) : T(2);
-                    for (int e = lane; e < jsz; e += 64) {
+                    for (int e = lane; e < (want_jac ? jsz : 0); e += 64) {
                         const int cc = e / (nx * nin), rem = e - cc * nx * nin;
                         const int i = rem / nin, d = rem - i * nin;
                         T v = T(0);
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
                         s_dkn[e] = fma(cdt, v, s_J[e]);
                     }
                     wave_sync();
-                    for (int e = lane; e < jsz; e += 64) {
+                    for (int e = lane; e < (want_jac ? jsz : 0); e += 64) {
                         const T v = s_dkn[e];
                         s_dk[e] = v;
                         s_accdk[e] = fma(wgt, v, s_accdk[e]);
@@ -407,7 +427,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
 
         // ---- outputs: tiles (16 rows contiguous in memory) and defects
         const T s6 = DT / T(6);
-        for (int e = lane; e < jsz; e += 64) {
+        for (int e = lane; e < (want_jac ? jsz : 0); e += 64) {
             const int cc = e / (nx * nin), rem = e - cc * nx * nin;
             const int i = rem / nin, d = rem - i * nin;
             if (row0 + cc < R) {

@@ -219,6 +219,7 @@ void destroy_impl(Handle* h) {
         dev_free(h->d_b[l]);
     }
     mfma_free(*h);
+    rk4hess_free(*h);
     solver_free(*h);
     dev_free(h->d_obj);
     void* p = h->d_dense_map; dev_free(p); h->d_dense_map = nullptr;
@@ -478,7 +479,9 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
     if (need_rows) {
-        void* tiles = jac_tiles ? jac_tiles : h.d_tiles_ws;
+        // defects only (IpoptProblem.constraints on its own): the matrix-core kernel skips its reverse sweeps
+        const bool need_tiles = jac_dense || jac_tiles || jac_sparse || h.variant == NEMPC_KERNEL_VALU;
+        void* tiles = jac_tiles ? jac_tiles : (need_tiles ? h.d_tiles_ws : nullptr);
         void* gout = g ? g : h.d_g_ws;
         rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, gout, tiles, s)
                                             : launch_rows_valu(h, B, Z, X0, gout, tiles, s);
@@ -507,10 +510,9 @@ int nempc_hess(nempc_handle hh, int32_t B, const void* Z, const void* X0, const 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
     void* blocks = hblocks ? hblocks : h.d_hess_ws;
-    // RK4 blocks (four chained stages + adjoint stage multipliers) run on the generic kernel for every variant
-    rc = (h.variant != NEMPC_KERNEL_VALU && h.cfg.integrator != NEMPC_RK4)
-             ? launch_rowhess_mfma(h, B, Z, X0, lambda, blocks, s)
-             : launch_rowhess_valu(h, B, Z, X0, lambda, blocks, s);
+    if (h.variant == NEMPC_KERNEL_VALU) rc = launch_rowhess_valu(h, B, Z, X0, lambda, blocks, s);
+    else if (h.cfg.integrator == NEMPC_RK4) rc = launch_rowhess_rk4_mfma(h, B, Z, X0, lambda, blocks, s);
+    else rc = launch_rowhess_mfma(h, B, Z, X0, lambda, blocks, s);
     if (rc) return rc;
     if (!hvals && !hdense) return NEMPC_OK;
     return launch_assemble_hess(h, B, blocks, sigma, hvals, hdense, s);

@@ -118,6 +118,9 @@ struct Handle {
     void* d_valu_ws = nullptr;   // scratch of the generic row kernel
     size_t valu_ws_elems = 0;
     void* d_hess_ws = nullptr;   // (Bmax,H,nin,nin) per-row Lagrangian blocks
+    void* d_rk4_stage = nullptr; // RK4 Hessian pipeline (allocated on first use): (Bmax*H, 4, nin + 2*nx*nin) stage records,
+    void* d_rk4_nu = nullptr;    //   (Bmax*H, 4, nx) stage multipliers,
+    void* d_rk4_ht = nullptr;    //   (Bmax*H, 4, nin, nin) contracted stage Hessians
     long long* d_dbg = nullptr;  // diagnostic builds only
     void* solver_ws = nullptr;   // solver.hip
     mutable int last_row_kernel = 0;  // 1 valu, 2 coop, 3 wave-tile
@@ -154,6 +157,16 @@ int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, v
 void mfma_free(Handle& h);
 int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
                         hipStream_t s);
+int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* stage_out,
+                            int stage_stride, hipStream_t s);
+int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
+                               const void* xi_direct, int xi_stride, const void* lam_direct, int vdiv, hipStream_t s);
+
+// ---- kernels_rk4hess.hip : RK4 Lagrangian blocks on the matrix cores (stage records -> stage multipliers ->
+//      contracted network Hessians of the four stage inputs -> congruence sum)
+int launch_rowhess_rk4_mfma(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
+                            hipStream_t s, void* g_out = nullptr, void* tiles_out = nullptr);
+void rk4hess_free(Handle& h);
 
 // ---- kernels_post.hip : objective, dense / sparse assembly, hessian assembly
 int launch_objective(Handle& h, int B, const void* Z, void* f, void* grad, hipStream_t s);

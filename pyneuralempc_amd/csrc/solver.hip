@@ -591,15 +591,20 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     const int check = o.check_every > 0 ? o.check_every : 4;
     for (; it < o.max_iter; ++it) {
         // callbacks at the iterate: defects + tiles (row kernel), f + grad (objective kernel)
-        rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, ws.g, ws.tiles, s)
-                                            : launch_rows_valu(h, B, Z, X0, ws.g, ws.tiles, s);
+        // and the per-step Lagrangian blocks with the current multipliers (all zero on the first iterate:
+        // Gauss-Newton step).  The RK4 matrix-core pipeline produces defects, tiles and blocks from one row launch.
+        const bool rk4_pipeline = h.variant != NEMPC_KERNEL_VALU && h.cfg.integrator == NEMPC_RK4;
+        if (rk4_pipeline) {
+            rc = launch_rowhess_rk4_mfma(h, B, Z, X0, ws.lam, ws.hblk, s, ws.g, ws.tiles);
+        } else {
+            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, ws.g, ws.tiles, s)
+                                                : launch_rows_valu(h, B, Z, X0, ws.g, ws.tiles, s);
+            if (rc) return rc;
+            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rowhess_mfma(h, B, Z, X0, ws.lam, ws.hblk, s)
+                                                : launch_rowhess_valu(h, B, Z, X0, ws.lam, ws.hblk, s);
+        }
         if (rc) return rc;
         if ((rc = launch_objective(h, B, Z, ws.f, ws.grad, s))) return rc;
-        // per-step Lagrangian blocks with the current multipliers (all zero on the first iterate: Gauss-Newton step)
-        rc = (h.variant != NEMPC_KERNEL_VALU && h.cfg.integrator != NEMPC_RK4)
-                 ? launch_rowhess_mfma(h, B, Z, X0, ws.lam, ws.hblk, s)
-                 : launch_rowhess_valu(h, B, Z, X0, ws.lam, ws.hblk, s);
-        if (rc) return rc;
         hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (B + a.ppw - 1) / a.ppw : (B + 63) / 64), dim3(64), lds_need,
                            s, a);
         NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, sizeof(int), s));
@@ -614,7 +619,8 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         for (int ls = 0; ls < o.max_linesearch; ++ls) {
             hipLaunchKernelGGL(solver_trial_kernel<T>, dim3(gBn), dim3(256), 0, s, B, n, (const T*)Z, (const T*)ws.dz,
                                (const T*)ws.alpha, (const int*)ws.lsdone, (T*)ws.Zt);
-            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, ws.Zt, X0, ws.gt, h.d_tiles_ws, s)
+            // the merit function needs the defects only: the matrix-core kernel skips its reverse sweeps (tiles = null)
+            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, ws.Zt, X0, ws.gt, nullptr, s)
                                                 : launch_rows_valu(h, B, ws.Zt, X0, ws.gt, h.d_tiles_ws, s);
             if (rc) return rc;
             if ((rc = launch_objective(h, B, ws.Zt, ws.ft, nullptr, s))) return rc;

@@ -84,9 +84,7 @@ class DeviceIntegrator(Integrator):
         assert len(x.shape) == 2 and len(u.shape) == 2, "x and u tensor must have dim 2"
         assert len(x0.shape) == 1, "x0 shape must have dim 1"
         eng = self.engine(1)
-        ex = self.model.gather_extra(self.H, p, tvp)
-        if ex is not None:
-            eng.bind_extra(eng.to_device(ex[None]))
+        self.model.bind_inputs(eng, p, tvp)
         z = np.concatenate([np.asarray(x, dtype=np.float64).reshape(-1), np.asarray(u, dtype=np.float64).reshape(-1)])
         return eng, eng.to_device(z[None, :]), eng.to_device(np.asarray(x0, dtype=np.float64)[None, :])
 
@@ -120,14 +118,16 @@ class DeviceIntegrator(Integrator):
         H, nx, nu = self.H, self.model.x_dim, self.model.u_dim
         n = H * (nx + nu)
         M = np.zeros((n, n))
+        w = int(getattr(self.model, "rolling_window", 1))
+        fwd = bool(getattr(self.model, "forward_rolling", True))
         for t in range(H):
-            uo = H * nx + t * nu
-            M[uo:uo + nu, uo:uo + nu] = 1.0
-            if t > 0:
-                xo = (t - 1) * nx
-                M[xo:xo + nx, xo:xo + nx] = 1.0
-                M[xo:xo + nx, uo:uo + nu] = 1.0
-                M[uo:uo + nu, xo:xo + nx] = 1.0
+            # variables step t reads: states x_{t-w} .. x_{t-1} (x0 and the history are data) and controls
+            # u_{t-w+1} .. u_t; every pair of them can couple
+            tau = t + (np.arange(w) - (w - 1) if fwd else -np.arange(w))
+            cols = [np.arange((k - 1) * nx, k * nx) for k in tau if k >= 1]
+            cols += [np.arange(H * nx + k * nu, H * nx + (k + 1) * nu) for k in tau if k >= 0]
+            cols = np.concatenate(cols)
+            M[np.ix_(cols, cols)] = 1.0
         return M
 
     # -- batched twins (device tensors) -------------------------------------------------------

@@ -10,5 +10,8 @@ class RK4Integrator(DeviceIntegrator):
     KIND = "rk4"
 
     def __init__(self, model, H, DT, cache_mode=False, cache_size=2):
+        if int(getattr(model, "rolling_window", 1)) > 1:
+            # same limit as the reference: its rolling models only pair with DiscretIntegrator / UnityIntegrator
+            raise NotImplementedError("RK4Integrator does not support rolling-window models")
         super().__init__(model, H, DT=DT)
         self.cache_mode = cache_mode

@@ -1,7 +1,9 @@
 # Links between user models and the solving system (reference: pyNeuralEMPC/model/__init__.py).
 from . import base
 from . import mlp
+from . import rolling
 from . import tensorflow
 from .base import Model
 from .mlp import MLPModel
-from .tensorflow import KerasTFModel
+from .rolling import MLPModelRollingInput
+from .tensorflow import KerasTFModel, KerasTFModelRollingInput

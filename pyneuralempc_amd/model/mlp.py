@@ -15,7 +15,7 @@ class MLPModel(Model):
     x_dim and the input width x_dim + u_dim (same checks as KerasTFModel.__init__)."""
 
     def __init__(self, weights, biases, x_dim, u_dim, p_dim=0, tvp_dim=0, dtype=torch.float64, device="cuda",
-                 kernel="auto"):
+                 kernel="auto", _input_width=None):
         p_dim, tvp_dim = int(p_dim or 0), int(tvp_dim or 0)
         weights = [np.asarray(w, dtype=np.float64) for w in weights]
         biases = [np.asarray(b, dtype=np.float64).reshape(-1) for b in biases]
@@ -24,7 +24,7 @@ class MLPModel(Model):
         if weights[-1].shape[1] != x_dim:
             raise ValueError("Your model do not provide a suitable output dim ! \n It must get the same dim as "
                              "the state dim.")
-        if weights[0].shape[0] != x_dim + u_dim + p_dim + tvp_dim:
+        if weights[0].shape[0] != (x_dim + u_dim + p_dim + tvp_dim if _input_width is None else _input_width):
             raise ValueError("Your model do not provide a suitable input dim ! \n It must get the same dim as the "
                              "sum of all input vars (x, u, p, tvp).")
         super().__init__(x_dim, u_dim, p_dim, tvp_dim)
@@ -62,6 +62,15 @@ class MLPModel(Model):
                 raise ValueError("this model has p_dim > 0: pass p (p_dim,)")
             parts.append(np.tile(np.asarray(p, dtype=np.float64).reshape(1, self.p_dim), (rows, 1)))
         return np.concatenate(parts, axis=1)
+
+    def bind_inputs(self, eng, p=None, tvp=None):
+        """Bind everything one problem's evaluation reads besides (z, x0) to `eng` (batch of one): the extra network
+        inputs here, plus the history for rolling-window models.  Returns True when something was (re)bound."""
+        ex = self.gather_extra(eng.H, p, tvp)
+        if ex is None:
+            return False
+        eng.bind_extra(eng.to_device(ex[None]))
+        return True
 
     def _rows(self, R):
         # H=1 UNITY problem per row: x_prev = X0[r], u = Z[r, nx:], and with the state slot of Z

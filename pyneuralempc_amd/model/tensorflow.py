@@ -7,6 +7,7 @@ activations and a linear output is rejected loudly."""
 import numpy as np
 
 from .mlp import MLPModel
+from .rolling import MLPModelRollingInput
 
 
 def _activation_name(layer):
@@ -50,3 +51,21 @@ class KerasTFModel(MLPModel):
                              "the sum of all input vars (x, u, p, tvp).")
         weights, biases = extract_dense_stack(model)
         super().__init__(weights, biases, x_dim, u_dim, p_dim, tvp_dim, **device_kwargs)
+
+
+class KerasTFModelRollingInput(MLPModelRollingInput):
+    """Drop-in for model/tensorflow.py:132-340: the Keras model reads rolling_window * (x_dim + u_dim + tvp_dim)
+    + p_dim inputs; set_prev_data supplies the history before each solve."""
+
+    def __init__(self, model, x_dim: int, u_dim: int, p_dim=0, tvp_dim=0, rolling_window=2, forward_rolling=True,
+                 standardScaler=None, **device_kwargs):
+        if standardScaler is not None:
+            raise NotImplementedError("This feature isn't supported yet !")
+        if model.output_shape[-1] != x_dim:
+            raise ValueError("Your Keras model do not provide a suitable output dim ! \n It must get the same dim "
+                             "as the state dim.")
+        if not isinstance(rolling_window, int) or rolling_window < 1:
+            raise ValueError("Your rolling windows need to be an integer gretter than 1.")
+        weights, biases = extract_dense_stack(model)
+        super().__init__(weights, biases, x_dim, u_dim, p_dim, tvp_dim, rolling_window=rolling_window,
+                         forward_rolling=forward_rolling, **device_kwargs)

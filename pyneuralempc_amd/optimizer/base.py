@@ -148,10 +148,9 @@ class _FusedEvaluator:
         self.n_device_evals = 0
 
     def set_parameters(self, p, tvp):
-        """Bind the problem's constant / time-varying parameters (extra network inputs) for the next evaluations."""
-        ex = self.model.gather_extra(self.engine.H, p, tvp)
-        if ex is not None:
-            self.engine.bind_extra(self.engine.to_device(ex[None]))
+        """Bind the problem's constant / time-varying parameters (extra network inputs; the history
+        of a rolling-window model) for the next evaluations."""
+        if self.model.bind_inputs(self.engine, p, tvp):
             self._key = None
 
     def evaluate(self, z, x0):

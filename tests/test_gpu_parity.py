@@ -122,10 +122,12 @@ def test_hessian_against_oracle_seeded(cfg):
 
 
 @pytest.mark.parametrize("cfg", [(6, 3, [128, 128, 128], 30, 0.1, 2), (3, 2, [48, 32], 7, 0.05, 5), (2, 1, [64, 64], 20, 0.5, 9),
-                                 (1, 1, [20], 3, 0.2, 4)])
+                                 (1, 1, [20], 3, 0.2, 4), (12, 4, [96, 96], 4, 0.2, 3)])
 def test_rk4_hessian_against_oracle(cfg):
     """RK4 Lagrangian Hessian for general dims (the reference's own RK4Integrator.hessian is hard-wired to
-    nx+nu = 3, rk4.py:246; the golden c2_rk4 case above pins that one, the oracle the rest)."""
+    nx+nu = 3, rk4.py:246; the golden c2_rk4 case above pins that one, the oracle the rest).  Matrix-core pipeline
+    (stage records -> stage multipliers -> contracted stage Hessians -> congruence sum, csrc/kernels_rk4hess.hip)
+    and the generic kernel."""
     from pyneuralempc_amd import CallbackEngine
     nx, nu, hidden, H, DT, B = cfg
     net = orc.MLP.random(nx + nu, hidden, nx, seed=3)
@@ -133,15 +135,38 @@ def test_rk4_hessian_against_oracle(cfg):
     Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=5)
     lamh = np.random.default_rng(6).normal(size=(B, prob.m))
     sigh = np.random.default_rng(7).uniform(0.0, 2.0, size=B)
-    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator="rk4", DT=DT, dtype=torch.float64, device="cuda:0",
-                         max_batch=B)
-    out = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lamh), eng.to_device(sigh),
-                   want=("hvals", "hdense"))
-    hd = out["hdense"].cpu().numpy()
-    assert np.array_equal(hd, np.transpose(hd, (0, 2, 1)))
-    for i in range(B):
-        np.testing.assert_allclose(hd[i], prob.lagrangian_hessian(Zh[i], X0h[i], lamh[i], sigh[i]),
-                                   rtol=1e-10, atol=1e-11)
+    dense = {}
+    for kernel in ("mfma", "valu"):
+        eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator="rk4", DT=DT, dtype=torch.float64, device="cuda:0",
+                             max_batch=B, kernel=kernel)
+        out = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lamh), eng.to_device(sigh),
+                       want=("hvals", "hdense"))
+        hd = dense[kernel] = out["hdense"].cpu().numpy()
+        assert np.array_equal(hd, np.transpose(hd, (0, 2, 1)))
+        for i in range(B):
+            np.testing.assert_allclose(hd[i], prob.lagrangian_hessian(Zh[i], X0h[i], lamh[i], sigh[i]),
+                                       rtol=1e-10, atol=1e-11)
+        # the evaluation callbacks are untouched by the Hessian pipeline's scratch use
+        res = eng.eval_numpy(Zh, X0h, want=("g", "jac_dense"))
+        np.testing.assert_allclose(res["jac_dense"][0], prob.jacobian(Zh[0], X0h[0]), **F64)
+    np.testing.assert_allclose(dense["mfma"], dense["valu"], rtol=1e-10, atol=1e-11)
+
+
+def test_rk4_hessian_fp32_c3_dims():
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, hidden, H, DT, B = 6, 3, [128, 128, 128], 30, 0.1, 5
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=3)
+    prob = orc.Problem(net, H, nx, nu, orc.RK4, DT)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=5)
+    lamh = np.random.default_rng(6).normal(size=(B, prob.m))
+    sigh = np.ones(B)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator="rk4", DT=DT, dtype=torch.float32, device="cuda:0",
+                         max_batch=B, kernel="mfma")
+    hd = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lamh), eng.to_device(sigh),
+                  want=("hdense",))["hdense"].cpu().numpy().astype(np.float64)
+    for i in (0, B - 1):
+        ref = prob.lagrangian_hessian(Zh[i], X0h[i], lamh[i], 1.0)
+        assert np.abs(hd[i] - ref).max() / max(1.0, np.abs(ref).max()) < 1e-4
 
 
 @pytest.mark.parametrize("kernel", ["valu", "mfma", "mfma_tile"])
@@ -274,3 +299,17 @@ def test_bound_launcher_tracks_input_contents():
     f, grad, g, jac = prob.eval_batch(Z2, X02)
     np.testing.assert_allclose(outs["jac_dense"].cpu().numpy(), jac, **F64)
     np.testing.assert_allclose(outs["f"].cpu().numpy(), f, **F64)
+
+
+@pytest.mark.parametrize("name", ["c2_discret", "c3_rk4", "c5_box", "odd_dims", "tvp_p_rk4"])
+def test_defect_only_evaluation_matches_full_evaluation(name):
+    """constraints() on its own: the matrix-core kernel runs forward only (no reverse sweeps, no tiles); the
+    defects must be the ones of the full evaluation, bit for bit on the same kernel family."""
+    d, W, b = load_case(name)
+    for kernel in ("mfma", "mfma_tile", "valu"):
+        eng = _engine(d, W, b, torch.float64, kernel)
+        only_g = eng.eval_numpy(d["Z"], d["X0"], want=("g",))["g"]
+        np.testing.assert_allclose(only_g, d["g"], **F64)
+        if kernel == "mfma_tile":
+            full = eng.eval_numpy(d["Z"], d["X0"], want=("g", "jac_tiles"))["g"]
+            assert np.array_equal(only_g, full)

@@ -158,3 +158,150 @@ def test_rolling_errors():
     eng.eval(Z, X0)
     with pytest.raises(NempcError, match="rolling-window"):
         eng.solve(X0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# reference-shaped plug-in surface: Model.set_prev_data / forward / jacobian / hessian, Integrator, IpoptProblem, NMPC
+# ---------------------------------------------------------------------------------------------------------------
+def _rolling_model(d, W, b):
+    import pyneuralempc_amd as nEMPC
+    return nEMPC.model.MLPModelRollingInput(W, b, int(d["nx"]), int(d["nu"]), p_dim=int(d["p_dim"]),
+                                            tvp_dim=int(d["tvp_dim"]), rolling_window=int(d["window"]),
+                                            forward_rolling=bool(int(d["forward_rolling"])), device="cuda:0")
+
+
+@pytest.mark.parametrize("name", ["roll2_discret", "roll3_unity_rev", "roll2_tvp_p", "roll4_wide"])
+def test_rolling_plugins_like_reference(name):
+    import pyneuralempc_amd as nEMPC
+    from pyneuralempc_amd.optimizer.ipopt import IpoptProblem
+    d, W, b = load_case(name)
+    H, nx, nu = int(d["H"]), int(d["nx"]), int(d["nu"])
+    model = _rolling_model(d, W, b)
+    integ = (nEMPC.integrator.discret.DiscretIntegrator(model, H) if int(d["kind"]) == orc.DISCRET
+             else nEMPC.integrator.unity.UnityIntegrator(model, H))
+    obj = nEMPC.objective.QuadraticObjective(Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"],
+                                             device="cuda:0")
+    ctrs = [nEMPC.constraints.BoxStateConstraint(d["box_lo"], d["box_hi"])] if int(d["has_box"]) else []
+    p = d["p"] if int(d["p_dim"]) else None
+    tvp = d["tvp"] if int(d["tvp_dim"]) else None
+    states = d["Z"][0][:H * nx].reshape(H, nx)
+    u = d["Z"][0][H * nx:].reshape(H, nu)
+    with pytest.raises(AssertionError, match="set_prev_data"):
+        integ.forward(states, u, d["X0"][0], p=p, tvp=tvp)
+    nh = H * nx
+    for i in range(d["Z"].shape[0]):
+        model.set_prev_data(d["hist_x"][i], d["hist_u"][i], tvp_prev=d.get("prev_tvp"))
+        z = d["Z"][i]
+        states, u = z[:nh].reshape(H, nx), z[nh:].reshape(H, nu)
+        np.testing.assert_allclose(integ.forward(states, u, d["X0"][i], p=p, tvp=tvp), d["g"][i][:nh], **F64)
+        np.testing.assert_allclose(integ.jacobian(states, u, d["X0"][i], p=p, tvp=tvp), d["jac"][i][:nh], **F64)
+        pb = IpoptProblem(d["X0"][i], obj, ctrs, integ, p=p, tvp=tvp)
+        assert pb._fused is not None
+        np.testing.assert_allclose(pb.objective(z), d["f"][i], **F64)
+        np.testing.assert_allclose(pb.gradient(z), d["grad"][i], **F64)
+        np.testing.assert_allclose(pb.constraints(z), d["g"][i], **F64)
+        np.testing.assert_allclose(pb.jacobian(z), d["jac"][i], **F64)
+        rows, cols = pb.hessianstructure()
+        np.testing.assert_allclose(pb.hessian(z, d["lam"][i], float(d["sigma"][i])), d["hdense"][i][rows, cols],
+                                   rtol=1e-11, atol=1e-12)
+    # integrator Hessian tensor and its structure map
+    ih = integ.hessian(states, u, d["X0"][i], p=p, tvp=tvp)
+    lam = d["lam"][i][:nh]
+    prob = oracle_problem(d, W, b, i)
+    np.testing.assert_allclose(np.einsum("i,ipq->pq", lam, ih), prob.lagrangian_hessian(z, d["X0"][i], np.concatenate(
+        [lam, np.zeros(prob.m - nh)]), 0.0), rtol=1e-11, atol=1e-12)
+    assert np.all((np.abs(ih).sum(axis=0) != 0) <= (integ.hessianstructure() != 0))
+
+
+@pytest.mark.parametrize("fwd", [True, False])
+def test_rolling_model_level_layouts(fwd):
+    """Model.forward / jacobian / hessian in the reference's [all x | all u] layout (tensorflow.py:236-340) against
+    the oracle network on the gathered windows and the selector of gen_jac_proj_mat (jax.py:8-21)."""
+    import pyneuralempc_amd as nEMPC
+    nx, nu, w, H = 2, 1, 3, 5
+    net = orc.MLP.random(w * (nx + nu), [24, 24], nx, seed=8)
+    model = nEMPC.model.MLPModelRollingInput(net.W, net.b, nx, nu, rolling_window=w, forward_rolling=fwd,
+                                             device="cuda:0")
+    rng = np.random.default_rng(2)
+    x, u = rng.normal(size=(H, nx)), rng.normal(size=(H, nu))
+    px, pu = rng.normal(size=(w - 1, nx)), rng.normal(size=(w - 1, nu))
+    model.set_prev_data(px, pu)
+    xr, ur = orc.rolling_rows(x, u, px, pu, w, fwd)
+    f, J, S = net.forward_jac_hess(np.concatenate([xr, ur], axis=1))
+    np.testing.assert_allclose(model.forward(x, u), f, **F64)
+    n = H * (nx + nu)
+    P = np.zeros((n, H, w * (nx + nu)))
+    for dim, vo, co in ((nx, 0, 0), (nu, H * nx, w * nx)):
+        for i in range(H):
+            for k in range(dim):
+                for o in range(i, min(H, i + w)):
+                    slot = (w - 1) - (o - i) if fwd else (o - i)
+                    P[vo + i * dim + k, o, co + slot * dim + k] = 1.0
+    np.testing.assert_allclose(model.jacobian(x, u), np.einsum("okc,voc->okv", J, P).reshape(H * nx, n), **F64)
+    np.testing.assert_allclose(model.hessian(x, u), np.einsum("aoc,okcd,bod->okab", P, S, P), rtol=1e-11, atol=1e-12)
+    with pytest.raises(AssertionError):
+        model.set_prev_data(px[:1], pu)
+
+
+def test_rolling_keras_dropin_and_rk4_rejection():
+    import pyneuralempc_amd as nEMPC
+
+    class _Layer:
+        def __init__(self, w, b, act):
+            self._w, self.activation = (w, b), act
+        def get_weights(self):
+            return list(self._w)
+
+    def tanh(x): return x
+    def linear(x): return x
+
+    nx, nu, w = 2, 1, 2
+    net = orc.MLP.random(w * (nx + nu), [16], nx, seed=0)
+
+    class _Keras:
+        layers = [_Layer(net.W[0], net.b[0], tanh), _Layer(net.W[1], net.b[1], linear)]
+        input_shape, output_shape = (None, w * (nx + nu)), (None, nx)
+
+    model = nEMPC.model.tensorflow.KerasTFModelRollingInput(_Keras(), nx, nu, rolling_window=w, device="cuda:0")
+    with pytest.raises(NotImplementedError):
+        nEMPC.integrator.rk4.RK4Integrator(model, 5, 0.1)
+    with pytest.raises(ValueError, match="rolling"):
+        nEMPC.model.tensorflow.KerasTFModelRollingInput(_Keras(), nx, nu, rolling_window=0, device="cuda:0")
+    with pytest.raises(ValueError, match="input dim"):
+        nEMPC.model.MLPModelRollingInput(net.W, net.b, nx, nu, rolling_window=3, device="cuda:0")
+
+
+def test_nmpc_next_with_rolling_model_slsqp():
+    """The reference's root test.py scenario (test.py:38-79: rolling model with window 2, DiscretIntegrator, H = 10,
+    cost sum((u-2)^2), unbounded domain, NMPC.next from x_past) with a tanh MLP in place of its polynomial fake
+    model: SLSQP on the CPU over the device callbacks; the result is feasible and a KKT point of the oracle's problem."""
+    import warnings
+    import pyneuralempc_amd as nEMPC
+    nx, nu, w, H = 2, 1, 2, 10
+    net = orc.MLP.random(w * (nx + nu), [24, 24], nx, seed=4)
+    net.W[-1] *= 0.2
+    net.b[-1] *= 0.2
+    model = nEMPC.model.MLPModelRollingInput(net.W, net.b, nx, nu, rolling_window=w, forward_rolling=True,
+                                             device="cuda:0")
+    x_past, u_past = np.array([[0.2, 0.1]]), np.array([[0.0]])
+    model.set_prev_data(x_past, u_past)
+    integ = nEMPC.integrator.discret.DiscretIntegrator(model, H)
+    obj = nEMPC.objective.QuadraticObjective(Q=np.zeros((nx, nx)), R=np.eye(nu), uref=2.0, device="cuda:0")
+    dom = nEMPC.constraints.DomainConstraint(states_constraint=[[-np.inf, np.inf]] * nx,
+                                             control_constraint=[[-np.inf, np.inf]])
+    opt = nEMPC.optimizer.Slsqp(max_iteration=300, tolerance=1e-11, verbose=0)
+    mpc = nEMPC.controller.NMPC(integ, obj, [dom], H, 1, optimizer=opt)
+    x0 = x_past.reshape(-1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pred, u = mpc.next(x0)
+    assert pred is not None and pred.shape == (H, nx) and u.shape == (H, nu)
+    prob = orc.Problem(net, H, nx, nu, orc.DISCRET, Q=np.zeros((nx, nx)), R=np.eye(nu), uref=2.0, window=w,
+                       hist_x=x_past, hist_u=u_past)
+    z = np.concatenate([pred.ravel(), u.ravel()])
+    assert np.abs(prob.constraints(z, x0)).max() < 1e-8
+    # the cost does not see the states: the minimiser is u = 2 with the states following the dynamics
+    np.testing.assert_allclose(u, 2.0, atol=1e-5)
+    J, gr = prob.jacobian(z, x0), prob.gradient(z)
+    lam = np.linalg.lstsq(J.T, -gr, rcond=None)[0]
+    assert np.abs(gr + J.T @ lam).max() < 1e-5
