@@ -28,7 +28,7 @@ namespace nempc {
 namespace {
 
 constexpr int INFO_LAM = 0, INFO_STEP = 1, INFO_AMAX = 2, INFO_G1 = 3, INFO_GINF = 4, INFO_D0 = 5, INFO_ZINF = 6,
-              INFO_N = 8;
+              INFO_RESTARTS = 7, INFO_N = 8;
 
 struct SolverArgs {
     int B, H, nx, nu, nin, n, m;
@@ -65,7 +65,7 @@ __device__ __forceinline__ void barrier_terms(T z, T lo, T hi, T mu, T& gadd, T&
 // NX, NU > 0: dimensions fixed at compile time -- every small loop unrolls and the temporaries live in registers
 // (2/1 and 6/3, the BASELINE shapes); NX = NU = 0: runtime dimensions, temporaries in LDS / global memory.
 template <typename T, int NX, int NU>
-__global__ __launch_bounds__(64) void solver_lq_kernel(SolverArgs a) {
+__global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T* lds = reinterpret_cast<T*>(lds_raw);
     const int lane = threadIdx.x;
@@ -78,21 +78,27 @@ __global__ __launch_bounds__(64) void solver_lq_kernel(SolverArgs a) {
     const int Lz = 0, Lgr = Lz + n, Lgc = Lgr + n, Ltl = Lgc + H * nx, LW = Ltl + H * nx * nin, LK = LW + H * nin * nin,
               Lk = LK + H * nu * nx, LP = Lk + H * nu, Lp = LP + H * nx * nx, Llam = Lp + H * nx, Ldz = Llam + H * nx,
               Ltmp = Ldz + n;
-    if (a.use_lds) {
-        for (int pp = 0; pp < ppw; ++pp) {
-            const int bp = blockIdx.x * ppw + pp;
-            if (bp >= a.B) break;
-            T* blk = lds + (size_t)pp * a.lds_stride;
-            const T* sz = (const T*)a.Z + (size_t)bp * n;
-            const T* sg = (const T*)a.grad + (size_t)bp * n;
-            const T* sc = (const T*)a.g + (size_t)bp * a.m;
-            const T* st = (const T*)a.tiles + (size_t)bp * H * nx * nin;
-            const T* sw = (const T*)a.hblk + (size_t)bp * H * nin * nin;
-            for (int i = lane; i < n; i += 64) { blk[Lz + i] = sz[i]; blk[Lgr + i] = sg[i]; }
-            for (int i = lane; i < H * nx; i += 64) blk[Lgc + i] = sc[i];
-            for (int i = lane; i < H * nx * nin; i += 64) blk[Ltl + i] = st[i];
-            for (int i = lane; i < H * nin * nin; i += 64) blk[LW + i] = sw[i];
+    // cooperative staging: one flat, unrolled loop per array over all the workgroup's problems (they are contiguous in
+    // global memory), all four waves loading -- many independent loads in flight instead of one dependent round
+    // trip per (problem, array)
+    const int b0 = blockIdx.x * ppw;
+    const int np = a.B - b0 < ppw ? a.B - b0 : ppw;
+    const int nthr = blockDim.x;
+    auto stage_in = [&](const T* __restrict__ src, int per, int src_stride, int loff) {
+        const int tot = np * per;
+        const T* base = src + (size_t)b0 * src_stride;
+#pragma unroll 4
+        for (int i = lane; i < tot; i += nthr) {
+            const int pp = i / per, e = i - pp * per;
+            lds[(size_t)pp * a.lds_stride + loff + e] = base[(size_t)pp * src_stride + e];
         }
+    };
+    if (a.use_lds) {
+        stage_in((const T*)a.Z, n, n, Lz);
+        stage_in((const T*)a.grad, n, n, Lgr);
+        stage_in((const T*)a.g, H * nx, a.m, Lgc);
+        stage_in((const T*)a.tiles, H * nx * nin, H * nx * nin, Ltl);
+        stage_in((const T*)a.hblk, H * nin * nin, H * nin * nin, LW);
         __syncthreads();
     }
     T* dzg = mine ? (T*)a.dz + (size_t)b * n : nullptr;
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(64) void solver_lq_kernel(SolverArgs a) {
     T* dz = a.use_lds ? blk + Ldz : dzg;
     const int uo = H * nx;
 
+    int restarts = 0;
     for (int attempt = 0; attempt < 14; ++attempt) {
     bool pd = true;
     // terminal value function: V_{H-1}(dx) = 1/2 dx' Hx dx + gx' dx
@@ -289,6 +296,7 @@ __global__ __launch_bounds__(64) void solver_lq_kernel(SolverArgs a) {
     }
     if (pd) break;
     reg = fmax(reg * T(10), T(1e-6));
+    ++restarts;
     }
     ((T*)a.reg)[b] = reg;
     T* lamn = a.use_lds ? blk + Llam : (T*)a.lamn + (size_t)b * a.m;
@@ -352,20 +360,21 @@ __global__ __launch_bounds__(64) void solver_lq_kernel(SolverArgs a) {
         }
     }
     info[INFO_LAM] = lam_inf; info[INFO_STEP] = step_inf; info[INFO_AMAX] = amax; info[INFO_G1] = g1;
-    info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf;
+    info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf; info[INFO_RESTARTS] = (T)restarts;
 #undef TMP
     }
     if (a.use_lds) {
         __syncthreads();
-        for (int pp = 0; pp < ppw; ++pp) {
-            const int bp = blockIdx.x * ppw + pp;
-            if (bp >= a.B) break;
-            const T* blk = lds + (size_t)pp * a.lds_stride;
-            T* dd = (T*)a.dz + (size_t)bp * n;
-            T* dl = (T*)a.lamn + (size_t)bp * a.m;
-            for (int i = lane; i < n; i += 64) dd[i] = blk[Ldz + i];
-            for (int i = lane; i < H * nx; i += 64) dl[i] = blk[Llam + i];
-        }
+        auto stage_out = [&](T* __restrict__ dst, int per, int dst_stride, int loff) {
+            const int tot = np * per;
+            T* base = dst + (size_t)b0 * dst_stride;
+            for (int i = lane; i < tot; i += nthr) {
+                const int pp = i / per, e = i - pp * per;
+                base[(size_t)pp * dst_stride + e] = lds[(size_t)pp * a.lds_stride + loff + e];
+            }
+        };
+        stage_out((T*)a.dz, n, n, Ldz);
+        stage_out((T*)a.lamn, H * nx, a.m, Llam);
     }
 }
 
@@ -450,7 +459,9 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, int mode
         T* lam = (T*)a.lam + (size_t)b * a.m;
         const T* lamn = (const T*)a.lamn + (size_t)b * a.m;
         for (int i = lane; i < H * nx; i += 64) lam[i] = fma(al, lamn[i] - lam[i], lam[i]);
-        if (lane == 0) { a.lsdone[b] = 1; reg[b] = fmax(reg[b] * T(0.1), T(1e-9)); }
+        // relax the damping only after a sweep that went through at the first attempt: a term that had to be raised
+        // this iteration would fail again right away and cost a full extra sweep
+        if (lane == 0) { a.lsdone[b] = 1; if (!(info[INFO_RESTARTS] > T(0))) reg[b] = fmax(reg[b] * T(0.1), T(1e-9)); }
     } else if (lane == 0) {
         alpha[b] = al * T(0.5);
         if (!last_ls) atomicAdd(a.n_active, 1);   // still searching: the host polls this to stop the backtracking early
@@ -577,6 +588,9 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     per_problem |= 1;   // odd stride: the ppw lanes of a sweep hit different LDS banks
     int ppw = (int)((size_t)150 * 1024 / ((size_t)per_problem * sizeof(T)));
     if (ppw > 16) ppw = 16;
+    // the sweep is one latency chain per lane whatever the number of active lanes: spread the batch over the CUs
+    const int spread = (B + 255) / 256;
+    if (ppw > spread) ppw = spread < 1 ? 1 : spread;
     a.use_lds = ppw >= 1;
     a.ppw = ppw;
     a.lds_stride = per_problem;
@@ -605,8 +619,9 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         }
         if (rc) return rc;
         if ((rc = launch_objective(h, B, Z, ws.f, ws.grad, s))) return rc;
-        hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (B + a.ppw - 1) / a.ppw : (B + 63) / 64), dim3(64), lds_need,
-                           s, a);
+        // LDS mode: four waves stage the working set, the first ppw lanes run the sweeps
+        hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (B + a.ppw - 1) / a.ppw : (B + 63) / 64), dim3(a.use_lds ? 256 : 64),
+                           lds_need, s, a);
         NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, sizeof(int), s));
         hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(B), dim3(64), 0, s, a, 0, (const T*)ws.f, (const T*)nullptr,
                            (const T*)nullptr, (const T*)nullptr, (T*)Z, 0);
