@@ -21,7 +21,7 @@ __device__ __forceinline__ T map_value(int32_t code, const T* __restrict__ tile)
 
 // one wave per problem; lanes stride over the horizon
 template <typename T>
-__device__ __forceinline__ void objective_body(int b, int H, int nx, int nu, const ObjOffsets& o,
+__device__ __forceinline__ void objective_body(int b, int lane, int H, int nx, int nu, const ObjOffsets& o,
                                                const T* __restrict__ P, const T* __restrict__ Z,
                                                T* __restrict__ f, T* __restrict__ grad) {
     const int n = H * (nx + nu);
@@ -29,7 +29,7 @@ __device__ __forceinline__ void objective_body(int b, int H, int nx, int nu, con
     const T *Q = P + o.Q, *Qs = P + o.Qs, *Rm = P + o.R, *Rs = P + o.Rs;
     const T *xref = P + o.xref, *uref = P + o.uref, *cx = P + o.cx, *cu = P + o.cu;
     double acc = 0.0;
-    for (int t = threadIdx.x; t < H; t += 64) {
+    for (int t = lane; t < H; t += 64) {
         const T* x = z + t * nx;
         const T* u = z + H * nx + t * nu;
         for (int i = 0; i < nx; ++i) {
@@ -57,14 +57,14 @@ __device__ __forceinline__ void objective_body(int b, int H, int nx, int nu, con
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    if (f && threadIdx.x == 0) f[b] = (T)acc;
+    if (f && lane == 0) f[b] = (T)acc;
 }
 
 template <typename T>
 __global__ __launch_bounds__(64) void objective_kernel(int B, int H, int nx, int nu, ObjOffsets o,
                                                        const T* __restrict__ P, const T* __restrict__ Z,
                                                        T* __restrict__ f, T* __restrict__ grad) {
-    if ((int)blockIdx.x < B) objective_body<T>(blockIdx.x, H, nx, nu, o, P, Z, f, grad);
+    if ((int)blockIdx.x < B) objective_body<T>(blockIdx.x, threadIdx.x, H, nx, nu, o, P, Z, f, grad);
 }
 
 // grid (ceil(m*n / (256 * kAsmVPT * 16/sizeof(T))), B)
@@ -125,8 +125,67 @@ __global__ __launch_bounds__(256) void post_kernel(int nb_asm, int mn, int tile_
     if ((int)blockIdx.x < nb_asm) {
         assemble_dense_body<T>(blockIdx.y, mn, tile_elems, map, tiles, jac);
     } else if (threadIdx.x < 64) {
-        objective_body<T>(blockIdx.y, H, nx, nu, o, P, Z, f, grad);
+        objective_body<T>(blockIdx.y, threadIdx.x, H, nx, nu, o, P, Z, f, grad);
     }
+}
+
+// Flat variant: the (B, m*n) output is ONE stream of 16-byte vectors cut into full blocks (a per-problem grid leaves
+// the last block of every problem mostly idle: m*n = 2400 is 1.17 blocks).  Needs m*n % (16/sizeof(T)) == 0 so that a
+// vector never straddles two problems.  Problem index of a vector: one exact division per block, then a
+// multiply-high by a host-checked reciprocal for the in-block offset.  Blocks >= nb_asm: objective, one problem per wave.
+template <typename T>
+__global__ __launch_bounds__(256) void post_flat_kernel(int nb_asm, int B, int mn, unsigned magic, int tile_elems,
+                                                        const int32_t* __restrict__ map, const T* __restrict__ tiles,
+                                                        T* __restrict__ jac, int H, int nx, int nu, ObjOffsets o,
+                                                        const T* __restrict__ P, const T* __restrict__ Z,
+                                                        T* __restrict__ f, T* __restrict__ grad) {
+    constexpr int NV = 16 / (int)sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(NV)));
+    typedef int32_t vecI __attribute__((ext_vector_type(NV)));
+    if ((int)blockIdx.x >= nb_asm) {
+        const int b = ((int)blockIdx.x - nb_asm) * 4 + (threadIdx.x >> 6);
+        if (b < B && (f || grad)) objective_body<T>(b, threadIdx.x & 63, H, nx, nu, o, P, Z, f, grad);
+        return;
+    }
+    const unsigned long long e_blk = (unsigned long long)blockIdx.x * (256 * kAsmVPT * NV);
+    const unsigned b_blk = (unsigned)(e_blk / (unsigned)mn);
+    const unsigned r_blk = (unsigned)(e_blk - (unsigned long long)b_blk * (unsigned)mn);
+    vecI code[kAsmVPT];
+    unsigned bb[kAsmVPT], ee[kAsmVPT];
+#pragma unroll
+    for (int u = 0; u < kAsmVPT; ++u) {
+        const unsigned numer = r_blk + (unsigned)(u * 256 + threadIdx.x) * NV;
+        const unsigned db = __umulhi(numer, magic);
+        ee[u] = numer - db * (unsigned)mn;
+        bb[u] = b_blk + db;
+        if (bb[u] < (unsigned)B) code[u] = *reinterpret_cast<const vecI*>(map + ee[u]);
+    }
+    vecT v[kAsmVPT];
+#pragma unroll
+    for (int u = 0; u < kAsmVPT; ++u) {
+        if (bb[u] < (unsigned)B) {
+            const T* tile = tiles + (size_t)bb[u] * tile_elems;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[u][k] = map_value<T>(code[u][k], tile);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kAsmVPT; ++u)
+        if (bb[u] < (unsigned)B) *reinterpret_cast<vecT*>(jac + (size_t)bb[u] * mn + ee[u]) = v[u];
+}
+
+// host side: can the flat kernel handle (B, mn)?  magic = ceil(2^32 / mn) is exact for numerators < 2^32 / (magic*mn - 2^32)
+inline bool flat_ok(const Handle& h, int B, const void* jac, unsigned* magic) {
+    const unsigned mn = (unsigned)h.m * (unsigned)h.n;
+    const unsigned NV = 16 / (unsigned)h.esz;
+    if (mn % NV != 0 || (reinterpret_cast<uintptr_t>(jac) & 15) != 0) return false;
+    if ((unsigned long long)B * mn >= (1ull << 32)) return false;
+    const unsigned long long mg = ((1ull << 32) + mn - 1) / mn;
+    const unsigned long long err = mg * mn - (1ull << 32);          // < mn
+    const unsigned long long max_numer = (unsigned long long)mn + 256ull * kAsmVPT * NV;
+    if (mg >= (1ull << 32) || err * max_numer >= (1ull << 32)) return false;
+    *magic = (unsigned)mg;
+    return true;
 }
 
 template <typename T>
@@ -170,7 +229,28 @@ int launch_objective(Handle& h, int B, const void* Z, void* f, void* grad, hipSt
     return NEMPC_OK;
 }
 
+template <typename T>
+int launch_post_flat(Handle& h, int B, unsigned magic, const void* tiles, void* jac, const void* Z, void* f, void* grad,
+                     hipStream_t s) {
+    const int mn = h.m * h.n;
+    const int te = h.cfg.H * h.cfg.nx * h.nin;
+    const int NV = 16 / (int)sizeof(T);
+    const long long total = (long long)B * mn;
+    const int nb_asm = (int)((total + 256LL * kAsmVPT * NV - 1) / (256LL * kAsmVPT * NV));
+    const int nb_obj = (f || grad) ? (B + 3) / 4 : 0;
+    ObjOffsets o = obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu);
+    hipLaunchKernelGGL(post_flat_kernel<T>, dim3((unsigned)(nb_asm + nb_obj)), dim3(256), 0, s, nb_asm, B, mn, magic, te,
+                       h.d_dense_map, (const T*)tiles, (T*)jac, h.cfg.H, h.cfg.nx, h.cfg.nu, o, (const T*)h.d_obj,
+                       (const T*)Z, (T*)f, (T*)grad);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
 int launch_assemble_dense(Handle& h, int B, const void* tiles, void* jac, hipStream_t s) {
+    unsigned magic = 0;
+    if (flat_ok(h, B, jac, &magic))
+        return h.cfg.dtype == NEMPC_F64 ? launch_post_flat<double>(h, B, magic, tiles, jac, nullptr, nullptr, nullptr, s)
+                                        : launch_post_flat<float>(h, B, magic, tiles, jac, nullptr, nullptr, nullptr, s);
     const int mn = h.m * h.n;
     const int te = h.cfg.H * h.cfg.nx * h.nin;
     const int per_block = 256 * kAsmVPT * (16 / (int)h.esz);
@@ -186,6 +266,10 @@ int launch_assemble_dense(Handle& h, int B, const void* tiles, void* jac, hipStr
 }
 
 int launch_post(Handle& h, int B, const void* tiles, void* jac, const void* Z, void* f, void* grad, hipStream_t s) {
+    unsigned magic = 0;
+    if (flat_ok(h, B, jac, &magic))
+        return h.cfg.dtype == NEMPC_F64 ? launch_post_flat<double>(h, B, magic, tiles, jac, Z, f, grad, s)
+                                        : launch_post_flat<float>(h, B, magic, tiles, jac, Z, f, grad, s);
     const int mn = h.m * h.n;
     const int te = h.cfg.H * h.cfg.nx * h.nin;
     const int per_block = 256 * kAsmVPT * (16 / (int)h.esz);
