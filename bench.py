@@ -289,13 +289,13 @@ def main():
                                         "eval_us_p10_median_p90": step_pcts},
         }
         # HBM bytes of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-        pmc_file = os.path.join(REPO, "profiles", "r01b_c2_b1024_pmc.json")
+        pmc_file = os.path.join(REPO, "profiles", "r01c_c2_b1024_pmc.json")
         if args.config == "c2" and B == 1024 and eng.kernel_variant == "mfma" and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             for k, v in pmc.items():
                 if k.startswith(str(eng.last_row_kernel)) and "hbm_traffic_bytes" in v:
                     out["roofline"]["traffic"] = v["hbm_traffic_bytes"]
-                    out["roofline"]["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch, profiles/r01b_c2_b1024_pmc.json; "
+                    out["roofline"]["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch, profiles/r01c_c2_b1024_pmc.json; "
                                                        "WRITE_SIZE of this kernel's 8-byte stores is uncalibrated "
                                                        "(algorithmic: 0.51 MB read, 1.3 MB written)")
         if solver_info:

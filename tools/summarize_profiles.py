@@ -28,7 +28,7 @@ for k, v in agg.items():
         m["hbm_read_bytes_corrected"] = m["FETCH_SIZE"] * 1024 * 2
         m["hbm_write_bytes"] = m["WRITE_SIZE"] * 1024
         m["hbm_traffic_bytes"] = m["hbm_read_bytes_corrected"] + m["hbm_write_bytes"]
-        m["write_size_calibrated"] = "post_kernel" in k or "assemble" in k   # 16-byte streaming stores only
+        m["write_size_calibrated"] = "post_" in k or "assemble" in k   # 16-byte streaming stores only
     res[k] = m
 json.dump(res, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1)[:1500])

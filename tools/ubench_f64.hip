@@ -91,8 +91,36 @@ __device__ __forceinline__ double fast_tanh(double x) {
     return copysign(t, x);
 }
 
+// table-driven variant: exp(y) = 2^(n/64) * exp(r), n = rint(y * 64/ln2), |r| <= ln2/128 -> degree-5 polynomial;
+// 2^(j/64) from a 64-entry LDS table (the lookup runs on the LDS pipe, not the shared DP pipe)
+__device__ double g_exp2_tab[64];
+template <int NEWTON>
+__device__ __forceinline__ double table_tanh(double x, const double* tab) {
+    const double ax = fmin(fabs(x), 20.0);
+    const double y = ax + ax;
+    const double n = rint(y * 92.332482616893656877);            // 64 / ln2
+    double r = fma(-n, 0.01083042469326756, y);                  // ln2/64 hi (21 trailing bits zero: n * hi exact)
+    r = fma(-n, 2.9815858269852933e-12, r);                      // ln2/64 lo
+    double p = 1.0 / 120.0;
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const int ni = (int)n;
+    const double e = ldexp(p * tab[ni & 63], ni >> 6);
+    const double d = e + 1.0;
+    double q = __builtin_amdgcn_rcp(d);
+    q = fma(fma(-d, q, 1.0), q, q);
+    if (NEWTON > 1) q = fma(fma(-d, q, 1.0), q, q);
+    return copysign(fma(-2.0, q, 1.0), x);
+}
+
 template <int MODE>
 __global__ void tanh_rate(const double* in, double* out, long long* cyc, int iters) {
+    __shared__ double tab[64];
+    if (threadIdx.x < 64) tab[threadIdx.x] = g_exp2_tab[threadIdx.x];
+    __syncthreads();
     double v[16];
     for (int i = 0; i < 16; ++i) v[i] = in[(blockIdx.x * blockDim.x + threadIdx.x) * 16 + i];
     long long t0 = clock64();
@@ -100,7 +128,9 @@ __global__ void tanh_rate(const double* in, double* out, long long* cyc, int ite
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if (MODE == 0) v[i] = tanh(v[i]) * 1.7;
-            else v[i] = fast_tanh(v[i]) * 1.7;
+            else if (MODE == 1) v[i] = fast_tanh(v[i]) * 1.7;
+            else if (MODE == 2) v[i] = table_tanh<2>(v[i], tab) * 1.7;
+            else v[i] = table_tanh<1>(v[i], tab) * 1.7;
         }
     }
     long long t1 = clock64();
@@ -108,11 +138,16 @@ __global__ void tanh_rate(const double* in, double* out, long long* cyc, int ite
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-__global__ void tanh_acc(const double* in, double* o_ref, double* o_fast, int n) {
+__global__ void tanh_acc(const double* in, double* o_ref, double* o_fast, double* o_t2, double* o_t1, int n) {
+    __shared__ double tab[64];
+    if (threadIdx.x < 64) tab[threadIdx.x] = g_exp2_tab[threadIdx.x];
+    __syncthreads();
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         o_ref[i] = tanh(in[i]);
         o_fast[i] = fast_tanh(in[i]);
+        o_t2[i] = table_tanh<2>(in[i], tab);
+        o_t1[i] = table_tanh<1>(in[i], tab);
     }
 }
 
@@ -223,8 +258,23 @@ int main() {
     CK(hipMalloc(&dref, sizeof(double) * n));
     CK(hipMalloc(&dfast, sizeof(double) * n));
     CK(hipMemcpy(din, hin.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    {
+        double htab[64];
+        for (int j = 0; j < 64; ++j) htab[j] = std::exp2(j / 64.0);
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_exp2_tab), htab, sizeof(htab)));
+    }
     const int titers = 50;
     for (int threads : {256, 512}) {
+        hipLaunchKernelGGL(tanh_rate<2>, dim3(blocks), dim3(threads), 0, 0, din, dout, dcyc, titers);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(cyc.data(), dcyc, sizeof(long long) * blocks, hipMemcpyDeviceToHost));
+        printf("table tanh, 2 Newton   waves/SIMD=%d  cycles per tanh (wave-instr) = %.1f\n", threads / 256,
+               median(cyc) / (titers * 16.0));
+        hipLaunchKernelGGL(tanh_rate<3>, dim3(blocks), dim3(threads), 0, 0, din, dout, dcyc, titers);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(cyc.data(), dcyc, sizeof(long long) * blocks, hipMemcpyDeviceToHost));
+        printf("table tanh, 1 Newton   waves/SIMD=%d  cycles per tanh (wave-instr) = %.1f\n", threads / 256,
+               median(cyc) / (titers * 16.0));
         hipLaunchKernelGGL(tanh_rate<0>, dim3(blocks), dim3(threads), 0, 0, din, dout, dcyc, titers);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(cyc.data(), dcyc, sizeof(long long) * blocks, hipMemcpyDeviceToHost));
@@ -236,16 +286,24 @@ int main() {
         printf("exp-based fast_tanh    waves/SIMD=%d  cycles per tanh (wave-instr) = %.1f\n", threads / 256,
                median(cyc) / (titers * 16.0));
     }
-    hipLaunchKernelGGL(tanh_acc, dim3((n + 255) / 256), dim3(256), 0, 0, din, dref, dfast, n);
-    std::vector<double> href(n), hfast(n);
+    double *dt2, *dt1;
+    CK(hipMalloc(&dt2, sizeof(double) * n));
+    CK(hipMalloc(&dt1, sizeof(double) * n));
+    hipLaunchKernelGGL(tanh_acc, dim3((n + 255) / 256), dim3(256), 0, 0, din, dref, dfast, dt2, dt1, n);
+    std::vector<double> href(n), hfast(n), ht2(n), ht1(n);
+    CK(hipMemcpy(ht2.data(), dt2, sizeof(double) * n, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(ht1.data(), dt1, sizeof(double) * n, hipMemcpyDeviceToHost));
     CK(hipMemcpy(href.data(), dref, sizeof(double) * n, hipMemcpyDeviceToHost));
     CK(hipMemcpy(hfast.data(), dfast, sizeof(double) * n, hipMemcpyDeviceToHost));
-    double e_ocml = 0, e_fast = 0;
+    double e_ocml = 0, e_fast = 0, e_t2 = 0, e_t1 = 0;
     for (int i = 0; i < n; ++i) {
         const double t = std::tanh(hin[i]);
         e_ocml = fmax(e_ocml, fabs(href[i] - t));
         e_fast = fmax(e_fast, fabs(hfast[i] - t));
+        e_t2 = fmax(e_t2, fabs(ht2[i] - t));
+        e_t1 = fmax(e_t1, fabs(ht1[i] - t));
     }
-    printf("max abs err vs host libm tanh: ocml %.3e, fast %.3e\n", e_ocml, e_fast);
+    printf("max abs err vs host libm tanh: ocml %.3e, fast %.3e, table(2 Newton) %.3e, table(1 Newton) %.3e\n", e_ocml, e_fast,
+           e_t2, e_t1);
     return 0;
 }
