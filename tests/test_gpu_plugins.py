@@ -225,3 +225,18 @@ def test_parameters_p_and_tvp_like_reference(name):
     net = orc.MLP(W, b)
     ex = np.concatenate([tvp, np.tile(p.reshape(1, -1), (H, 1))], axis=1)
     np.testing.assert_allclose(model.forward(states, u, p=p, tvp=tvp), net.forward(np.concatenate([states, u, ex], axis=1)), **F64)
+
+
+def test_lotka_volterra_example_runs():
+    """examples/lotka_volterra/run.py (counterpart of the reference's example script): a few closed-loop steps with
+    SLSQP on the device callbacks, and the batched on-device solve of the same problem family."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(GOLDEN), "..", "examples", "lotka_volterra", "run.py")
+    spec = importlib.util.spec_from_file_location("lv_example", os.path.abspath(path))
+    lv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lv)
+    traj = lv.main(steps=3, fit_iters=300, verbose=False)
+    assert traj.shape == (4, 2) and np.all(np.isfinite(traj))
+    assert traj[:, 0].max() <= lv.X_MAX + 0.05          # state limit respected up to the surrogate's model error
+    X = lv.main(steps=2, batch=16, fit_iters=300, verbose=False)
+    assert X.shape == (16, 2) and np.all(np.isfinite(X))
