@@ -468,7 +468,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams
     cx.NR = coop_nr<T>(p.nin);
     cx.jsz = 16 * p.nx * p.nin;
     cx.spt = p.scratch_per_wave;
-    cx.xt_off = 16 * p.nin + 2 * 16 * p.nx + 4 * cx.jsz;  // after the wave-tile kernel's carve-up
+    cx.xt_off = 16 * p.nin + 2 * 16 * p.nx + (p.kind == NEMPC_RK4 ? 4 : 1) * cx.jsz;  // after the wave-tile kernel's carve-up
     cx.ex_off = cx.xt_off + 16 * p.nx;                    // [16][ne] extra inputs
     cx.ne = p.ne;
     cx.extra = static_cast<const T*>(p.extra);

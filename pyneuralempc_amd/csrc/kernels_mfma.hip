@@ -37,7 +37,9 @@ MfmaOffsets make_offsets(int wp, int nh, int ks, int nx, int nin) {
 
 int scratch_elems(const Handle& h) {
     const int nx = h.cfg.nx, nin = h.nin;
-    return 16 * nin + 2 * 16 * nx + 4 * 16 * nx * nin + 16 * nx + 16 * h.ne;  // + x_t slot (cooperative kernel) + extra inputs
+    // xi0 | k | acck | J [| dk | accdk | dkn : RK4 chain only] | x_t slot (cooperative kernel) | extra inputs
+    const int njs = h.cfg.integrator == NEMPC_RK4 ? 4 : 1;
+    return 16 * nin + 2 * 16 * nx + njs * 16 * nx * nin + 16 * nx + 16 * h.ne;
 }
 
 }  // namespace

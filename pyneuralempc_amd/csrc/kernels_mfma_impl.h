@@ -250,7 +250,8 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
     T* s_dk = s_J + jsz;
     T* s_accdk = s_dk + jsz;
     T* s_dkn = s_accdk + jsz;
-    T* s_ex = s_dkn + jsz + 16 * nx;   // [16][ne] extra inputs (after the cooperative kernel's x_t slot)
+    T* s_ex = s_J + (rk4 ? 4 : 1) * jsz + 16 * nx;   // [16][ne] extra inputs (after the cooperative kernel's x_t slot);
+                                                     // the dk / accdk / dkn arrays exist for RK4 only
 
     for (int tile = blockIdx.x * nwaves + wave; tile < p.ntiles; tile += gridDim.x * nwaves) {
         const size_t row0 = (size_t)tile * 16;

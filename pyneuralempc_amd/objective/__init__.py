@@ -1,5 +1,7 @@
 # Objective functions (reference: pyNeuralEMPC/objective/__init__.py).
 from . import base
 from . import quadratic
+from . import autodiff
 from .base import ObjectiveFunc, ManualObjectifFunc
 from .quadratic import QuadraticObjective
+from .autodiff import TorchObjectifFunc

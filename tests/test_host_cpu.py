@@ -150,3 +150,41 @@ def test_quadratic_objective_host_side():
     assert np.array_equal(S != 0, Hm != 0)
     man = ManualObjectifFunc(lambda s, u, p, t: 1.0, lambda s, u, p, t: np.zeros(3), lambda s, u, p, t: np.eye(3))
     assert man.forward(None, None) == 1.0 and man.hessian(None, None).shape == (3, 3)
+
+
+def test_torch_objective_plugin_matches_closed_form_family():
+    """TorchObjectifFunc (the JAXObjectifFunc counterpart, objective/jax.py:16-90) on the reference's two cost
+    functions and on the general quadratic family, against the oracle's closed forms."""
+    import torch
+    from oracle import nempc_oracle as orc
+    from pyneuralempc_amd.objective import TorchObjectifFunc
+    H, nx, nu = 6, 2, 1
+    rng = np.random.default_rng(0)
+    Q = np.eye(nx) + 0.1 * rng.normal(size=(nx, nx))
+    R = np.array([[0.3]])
+    xref, uref, cu = rng.normal(size=(H, nx)), rng.normal(size=(H, nu)), rng.normal(size=(H, nu))
+    prob = orc.Problem(orc.MLP.random(nx + nu, [4], nx), H, nx, nu, Q=Q, R=R, xref=xref, uref=uref, cu=cu)
+    Qt, Rt, xr, ur, ct = (torch.tensor(a) for a in (Q, R, xref, uref, cu))
+
+    def cost(states, u, p=None, tvp=None):
+        dx, du = states - xr, u - ur
+        return torch.einsum("ti,ij,tj->", dx, Qt, dx) + torch.einsum("ti,ij,tj->", du, Rt, du) + torch.sum(ct * u)
+
+    obj = TorchObjectifFunc(cost, device="cpu")
+    states, u = rng.normal(size=(H, nx)), rng.normal(size=(H, nu))
+    z = np.concatenate([states.ravel(), u.ravel()])
+    np.testing.assert_allclose(obj.forward(states, u), prob.objective(z), rtol=1e-13)
+    np.testing.assert_allclose(obj.gradient(states, u), prob.gradient(z), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(obj.hessian(states, u), prob.objective_hessian(), rtol=1e-12, atol=1e-13)
+
+    class M:
+        x_dim, u_dim, p_dim, tvp_dim = nx, nu, 0, 0
+    m = M()
+    S = obj.hessianstructure(H, m)
+    assert np.array_equal(S != 0, prob.objective_hessian() != 0) and obj.hessianstructure(H, m) is S
+    # the reference's own two costs: sum(u * c) (run.py:89-90, gradient does not touch the states) and sum((u-2)^2)
+    lin = TorchObjectifFunc(lambda s, u, p=None, tvp=None: torch.sum(u.reshape(-1) * 1.1), device="cpu")
+    np.testing.assert_array_equal(lin.gradient(states, u), np.concatenate([np.zeros(H * nx), np.full(H * nu, 1.1)]))
+    assert not lin.hessian(states, u).any()
+    sq = TorchObjectifFunc(lambda s, u, p=None, tvp=None: torch.sum((u.reshape(-1) - 2.0) ** 2), device="cpu")
+    np.testing.assert_allclose(sq.gradient(states, u)[H * nx:], 2.0 * (u.ravel() - 2.0), rtol=1e-14)
