@@ -2,39 +2,42 @@
 import numpy as np
 
 
+def _bound_column(pairs, which, H):
+    """[b[which] for every (lower, upper) pair] repeated for the H steps of the horizon"""
+    return [pair[which] for pair in pairs] * H
+
+
 class DomainConstraint:
-    """Box bounds on the decision variables, consumed by the optimizer only (no rows in g)."""
+    """Box bounds on the decision variables z = [states | controls]; consumed by the optimizer as lb / ub
+    (optimizer/ipopt.py:153-154), they add no rows to g."""
 
     def __init__(self, states_constraint: list, control_constraint: list):
-        if len(states_constraint) == 0:
-            raise ValueError("States constraint empty !")
-        if len(control_constraint) == 0:
-            raise ValueError("Control constraint empty !")
-        for name, seq in (("states", states_constraint), ("control", control_constraint)):
-            if any(len(c) != 2 for c in seq):
-                raise ValueError(f"Your {name} constraint must be a list of bound couple  ! "
+        for pairs, empty_msg, label in ((states_constraint, "States constraint empty !", "states"),
+                                        (control_constraint, "Control constraint empty !", "control")):
+            if len(pairs) == 0:
+                raise ValueError(empty_msg)
+            if any(len(pair) != 2 for pair in pairs):
+                raise ValueError(f"Your {label} constraint must be a list of bound couple  ! "
                                  "[(lower_bound, upper_bound), ...]")
-        self.states_constraint = states_constraint
-        self.control_constraint = control_constraint
+        self.states_constraint, self.control_constraint = states_constraint, control_constraint
 
     def get_dim(self, H):
         return len(self.states_constraint), len(self.control_constraint)
 
     def get_lower_bounds(self, H):
-        return [c[0] for c in self.states_constraint] * H + [c[0] for c in self.control_constraint] * H
+        return _bound_column(self.states_constraint, 0, H) + _bound_column(self.control_constraint, 0, H)
 
     def get_upper_bounds(self, H):
-        return [c[1] for c in self.states_constraint] * H + [c[1] for c in self.control_constraint] * H
+        return _bound_column(self.states_constraint, 1, H) + _bound_column(self.control_constraint, 1, H)
 
     def get_type(self):
-        return Constraint.EQ_TYPE
+        return Constraint.EQ_TYPE     # meaningless for bounds and unused, as in the reference (constraints.py:32-33)
 
 
 class Constraint:
-    """Extra rows appended after the integrator defects (optimizer/ipopt.py:47-52,91-96)."""
-    EQ_TYPE = 0
-    INEQ_TYPE = 1
-    INTER_TYPE = 2
+    """Extra rows appended to g after the integrator defects (optimizer/ipopt.py:47-52,91-96).  A subclass gives
+    forward (k,), jacobian (k, n), get_dim(H) and the two bound vectors; the row type follows from the bounds."""
+    EQ_TYPE, INEQ_TYPE, INTER_TYPE = 0, 1, 2
 
     def forward(self, x, u, p=None, tvp=None):
         pass
@@ -43,9 +46,10 @@ class Constraint:
         pass
 
     def hessian(self, x, u, p=None, tvp=None):
-        """(k, n, n); called by the solver glue (ipopt.py:75). Linear rows: zeros."""
-        H = np.asarray(x).shape[0]
-        n = H * (np.asarray(x).shape[1] + np.asarray(u).shape[1])
+        """(k, n, n); called by the solver glue (ipopt.py:75) although the reference's base class does not declare
+        it.  Default: linear rows, all zeros."""
+        H, nx = np.asarray(x).shape
+        n = H * (nx + np.asarray(u).shape[1])
         return np.zeros((int(self.get_dim(H)), n, n))
 
     def get_dim(self, H):
@@ -58,15 +62,18 @@ class Constraint:
         raise NotImplementedError()
 
     def get_type(self, H=None):
-        lo, hi = np.asarray(self.get_lower_bounds(H)), np.asarray(self.get_upper_bounds(H))
-        if (hi == lo).all() and (lo == 0).all():
+        lo, hi = (np.asarray(v) for v in (self.get_lower_bounds(H), self.get_upper_bounds(H)))
+        if not (lo == 0).all():
+            return Constraint.INTER_TYPE
+        if (hi == 0).all():
             return Constraint.EQ_TYPE
-        if (hi == np.inf).all() and (lo == 0).all():
-            return Constraint.INEQ_TYPE
-        return Constraint.INTER_TYPE
+        return Constraint.INEQ_TYPE if (hi == np.inf).all() else Constraint.INTER_TYPE
 
 
-class EqualityConstraint(Constraint):
+class _ZeroLowerBound(Constraint):
+    """rows bounded below by zero; the two public flavours differ in the upper bound only"""
+    _upper = 0.0
+
     def forward(self, x, u, p=None, tvp=None):
         raise NotImplementedError()
 
@@ -77,21 +84,15 @@ class EqualityConstraint(Constraint):
         return np.zeros(int(self.get_dim(H)))
 
     def get_upper_bounds(self, H):
-        return np.zeros(int(self.get_dim(H)))
+        return np.full(int(self.get_dim(H)), self._upper)
 
 
-class InequalityConstraint(Constraint):
-    def forward(self, x, u, p=None, tvp=None):
-        raise NotImplementedError()
+class EqualityConstraint(_ZeroLowerBound):       # g(z) = 0
+    _upper = 0.0
 
-    def jacobian(self, x, u, p=None, tvp=None):
-        raise NotImplementedError()
 
-    def get_lower_bounds(self, H):
-        return np.zeros(int(self.get_dim(H)))
-
-    def get_upper_bounds(self, H):
-        return np.ones(int(self.get_dim(H))) * np.inf
+class InequalityConstraint(_ZeroLowerBound):     # g(z) >= 0
+    _upper = np.inf
 
 
 class BoxStateConstraint(Constraint):
