@@ -101,6 +101,7 @@ struct CoopCtx {
     size_t R;
     bool rk4;
     T DT;
+    RowGather gk;                   // where a row's window inputs come from (nempc_internal.h)
     long long* dbg;
 };
 
@@ -129,6 +130,8 @@ __device__ __forceinline__ void stage_load(const CoopCtx<T>& cx, int t0, int nro
             b = (int)((unsigned)r / (unsigned)cx.H);
             t = (int)((unsigned)r - (unsigned)b * (unsigned)cx.H);
             const T* z = cx.Z + (size_t)b * cx.n;
+            // plain models only (rolling windows stage directly, see the kernel body): keeps this early-issued
+            // path, whose registers stay live across the weight-slice loads, as small as it was
             if (col < cx.nx) v = (t == 0) ? cx.X0[(size_t)b * cx.nx + col] : z[(t - 1) * cx.nx + col];
             else if (col < cx.nin) v = z[cx.H * cx.nx + t * cx.nu + (col - cx.nx)];
             else if (col < cx.nin + cx.nx) v = z[t * cx.nx + (col - cx.nin)];
@@ -171,8 +174,7 @@ __device__ __forceinline__ void stage_direct(const CoopCtx<T>& cx, int t0, int n
             b = (int)((unsigned)r / (unsigned)cx.H);
             t = (int)((unsigned)r - (unsigned)b * (unsigned)cx.H);
             const T* z = cx.Z + (size_t)b * cx.n;
-            if (col < cx.nx) v = (t == 0) ? cx.X0[(size_t)b * cx.nx + col] : z[(t - 1) * cx.nx + col];
-            else if (col < cx.nin) v = z[cx.H * cx.nx + t * cx.nu + (col - cx.nx)];
+            if (col < cx.nin) v = gather_input<T>(cx.gk, z, cx.X0, b, t, col);   // [x_{t-1} | u_t] or the rolling window
             else if (col < cx.nin + cx.nx) v = z[t * cx.nx + (col - cx.nin)];
             else v = cx.extra[r * cx.ne + (col - cx.nin - cx.nx)];
         }
@@ -413,7 +415,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
         if (RI[2 * idx] >= 0) {
             const int i = (kd * cx.inv_nin) >> 16, d = kd - i * nin;
             const T* sj = SCR + (idx >> 4) * spt + 16 * nin + 2 * 16 * nx + (idx & 15) * jrow;
-            const T ident = (d == i && (rk4 || cx.kind == NEMPC_DISCRET)) ? T(1) : T(0);
+            const T ident = (d == cx.gk.xcur + i && (rk4 || cx.kind == NEMPC_DISCRET)) ? T(1) : T(0);
             cx.tiles[(size_t)t0 * 16 * jrow + item] = (rk4 ? s6 * sj[2 * jsz + kd] : sj[kd]) + ident;
         }
     }
@@ -425,7 +427,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
             const int cc = idx & 15;
             const T* s_xi0 = SCR + (idx >> 4) * spt;
             const T* sk = s_xi0 + 16 * nin;
-            const T xp = s_xi0[cc * nin + i];
+            const T xp = s_xi0[cc * nin + cx.gk.xcur + i];
             T phi;
             if (rk4) phi = xp + s6 * sk[16 * nx + cc * nx + i];
             else phi = (cx.kind == NEMPC_DISCRET ? xp : T(0)) + sk[cc * nx + i];
@@ -464,7 +466,8 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams
     cx.X0 = static_cast<const T*>(p.X0);
     cx.gout = static_cast<T*>(p.g);
     cx.tiles = static_cast<T*>(p.tiles);
-    cx.nx = p.nx; cx.nu = p.nu; cx.nin = p.nin; cx.H = p.H; cx.n = p.H * p.nin; cx.m = p.m;
+    cx.nx = p.nx; cx.nu = p.nu; cx.nin = p.nin; cx.H = p.H; cx.n = p.gk.n; cx.m = p.m;
+    cx.gk = p.gk;
     cx.NR = coop_nr<T>(p.nin);
     cx.jsz = 16 * p.nx * p.nin;
     cx.spt = p.scratch_per_wave;
@@ -490,7 +493,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams
     StageRegs<T, MT, TPW> sr;
     int t0 = t_begin;
     int nact = t_end - t0 < TPW ? t_end - t0 : TPW;
-    const bool early = (cx.nin + cx.nx + cx.ne) * TPW * 16 <= StageRegs<T, MT, TPW>::ITEMS * NTHREADS;
+    const bool early = cx.gk.w == 1 && (cx.nin + cx.nx + cx.ne) * TPW * 16 <= StageRegs<T, MT, TPW>::ITEMS * NTHREADS;
     if (early) stage_load<T, MT, TPW>(cx, t0, nact * 16, tid, sr);
     // small tables -> LDS ...
     copy_blob_to_lds<T>(gblob + p.off.w0f, lds + lay.w0f, p.ks * MT * 64, tid, NTHREADS);

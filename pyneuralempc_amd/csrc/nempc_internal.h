@@ -33,6 +33,7 @@ struct RowGather {
     int H, nx, nu, n;       // n = H*(nx+nu)
     int w, rev;             // window length, newest-first flag
     int xcur;               // tile column of the current state x_{t-1}, component 0 (where DISCRET adds its identity)
+    unsigned inv_nx, inv_nu; // ceil(2^32 / nx), ceil(2^32 / nu) (0 for a divisor of 1): d / nx == umulhi(d, inv_nx), exact while d * nx < 2^32
     const void* hx;         // (B, w-1, nx) states before x0, oldest first
     const void* hu;         // (B, w-1, nu) controls before u_0
 };
@@ -48,14 +49,14 @@ __device__ __forceinline__ T gather_input(const RowGather& gk, const T* __restri
     }
     const int wx = gk.w * nx, back = gk.w - 1;
     if (d < wx) {
-        const int j = d / nx, c = d - j * nx;
+        const int j = nx == 1 ? d : (int)__umulhi((unsigned)d, gk.inv_nx), c = d - j * nx;
         const int tau = t + (gk.rev ? -j : j - back);   // index into [x0 ; states]: 0 is x0
         if (tau >= 1) return z[(tau - 1) * nx + c];
         if (tau == 0) return X0[(size_t)b * nx + c];
         return static_cast<const T*>(gk.hx)[((size_t)b * back + (back + tau)) * nx + c];
     }
     d -= wx;
-    const int j = d / nu, c = d - j * nu;
+    const int j = nu == 1 ? d : (int)__umulhi((unsigned)d, gk.inv_nu), c = d - j * nu;
     const int tau = t + (gk.rev ? -j : j - back);
     if (tau >= 0) return z[gk.H * nx + tau * nu + c];
     return static_cast<const T*>(gk.hu)[((size_t)b * back + (back + tau)) * nu + c];
@@ -84,6 +85,8 @@ struct Handle {
         RowGather gk;
         gk.H = cfg.H; gk.nx = cfg.nx; gk.nu = cfg.nu; gk.n = n; gk.w = w; gk.rev = rev;
         gk.xcur = rev ? 0 : (w - 1) * cfg.nx;
+        gk.inv_nx = cfg.nx == 1 ? 0u : (unsigned)(((1ull << 32) + cfg.nx - 1) / (unsigned)cfg.nx);
+        gk.inv_nu = cfg.nu == 1 ? 0u : (unsigned)(((1ull << 32) + cfg.nu - 1) / (unsigned)cfg.nu);
         gk.hx = d_hist_x; gk.hu = d_hist_u;
         return gk;
     }

@@ -61,8 +61,12 @@ def test_rolling_golden_fp64(name):
         cl, cu = eng.constraint_bounds()
         np.testing.assert_array_equal(cl, d["cl"])
         np.testing.assert_array_equal(cu, d["cu_bound"])
-        if kernel != "valu":
-            assert eng.last_row_kernel == "rows_mfma_kernel"
+        # both matrix-core kernels serve rolling windows: "mfma" resolves to the cooperative one when it fits
+        expect = {"valu": "rows_valu_kernel", "mfma_tile": "rows_mfma_kernel"}.get(kernel)
+        if expect is not None:
+            assert eng.last_row_kernel == expect
+        else:
+            assert eng.last_row_kernel in ("rows_coop_kernel", "rows_mfma_kernel")
 
 
 @pytest.mark.parametrize("name", ROLLING_NAMES)
