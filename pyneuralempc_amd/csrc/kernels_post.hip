@@ -188,6 +188,26 @@ inline bool flat_ok(const Handle& h, int B, const void* jac, unsigned* magic) {
     return true;
 }
 
+// sparse contract in one launch: band-pattern values for all problems as one flat stream (blocks < nb_asm), objective
+// on the blocks after them (one problem per wave).  b = e / nnz by an exact 64-bit multiply-high.
+template <typename T>
+__global__ __launch_bounds__(256) void post_sparse_kernel(int nb_asm, int B, int nnz, unsigned long long magic64,
+                                                          int tile_elems, const int32_t* __restrict__ map,
+                                                          const T* __restrict__ tiles, T* __restrict__ vals, int H, int nx,
+                                                          int nu, ObjOffsets o, const T* __restrict__ P,
+                                                          const T* __restrict__ Z, T* __restrict__ f, T* __restrict__ grad) {
+    if ((int)blockIdx.x >= nb_asm) {
+        const int b = ((int)blockIdx.x - nb_asm) * 4 + (threadIdx.x >> 6);
+        if (b < B) objective_body<T>(b, threadIdx.x & 63, H, nx, nu, o, P, Z, f, grad);
+        return;
+    }
+    const unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (unsigned long long)B * nnz) return;
+    const unsigned b = (unsigned)__umul64hi(e, magic64);      // e / nnz, exact for e * nnz < 2^64
+    const unsigned k = (unsigned)(e - (unsigned long long)b * nnz);
+    vals[e] = map_value<T>(map[k], tiles + (size_t)b * tile_elems);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void assemble_sparse_kernel(int nnz, int tile_elems, const int32_t* __restrict__ map,
                                                               const T* __restrict__ tiles, T* __restrict__ vals) {
@@ -284,6 +304,27 @@ int launch_post(Handle& h, int B, const void* tiles, void* jac, const void* Z, v
         hipLaunchKernelGGL(post_kernel<float>, grid, block, 0, s, nb, mn, te, h.d_dense_map, (const float*)tiles,
                            (float*)jac, h.cfg.H, h.cfg.nx, h.cfg.nu, o, (const float*)h.d_obj, (const float*)Z,
                            (float*)f, (float*)grad);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
+int launch_post_sparse(Handle& h, int B, const void* tiles, void* vals, const void* Z, void* f, void* grad,
+                       hipStream_t s) {
+    const int nnz = (int)h.jac_rows.size();
+    const int te = h.cfg.H * h.cfg.nx * h.nin;
+    const unsigned long long total = (unsigned long long)B * nnz;
+    const int nb_asm = (int)((total + 255) / 256), nb_obj = (B + 3) / 4;
+    // ceil(2^64 / nnz): floor((2^64 - 1) / nnz) + 1 (nnz >= 2 always: every row has its -1 and a control column)
+    const unsigned long long magic = ~0ull / (unsigned long long)nnz + 1;
+    ObjOffsets o = obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu);
+    if (h.cfg.dtype == NEMPC_F64)
+        hipLaunchKernelGGL(post_sparse_kernel<double>, dim3((unsigned)(nb_asm + nb_obj)), dim3(256), 0, s, nb_asm, B, nnz,
+                           magic, te, h.d_sparse_map, (const double*)tiles, (double*)vals, h.cfg.H, h.cfg.nx, h.cfg.nu, o,
+                           (const double*)h.d_obj, (const double*)Z, (double*)f, (double*)grad);
+    else
+        hipLaunchKernelGGL(post_sparse_kernel<float>, dim3((unsigned)(nb_asm + nb_obj)), dim3(256), 0, s, nb_asm, B, nnz,
+                           magic, te, h.d_sparse_map, (const float*)tiles, (float*)vals, h.cfg.H, h.cfg.nx, h.cfg.nu, o,
+                           (const float*)h.d_obj, (const float*)Z, (float*)f, (float*)grad);
     NEMPC_HIP(hipGetLastError());
     return NEMPC_OK;
 }

@@ -486,6 +486,8 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
         rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, gout, tiles, s)
                                             : launch_rows_valu(h, B, Z, X0, gout, tiles, s);
         if (rc) return rc;
+        // sparse contract with the objective and without the dense matrix: one fused launch
+        if (jac_sparse && !jac_dense && (f || grad)) return launch_post_sparse(h, B, tiles, jac_sparse, Z, f, grad, s);
         if (jac_sparse && (rc = launch_assemble_sparse(h, B, tiles, jac_sparse, s))) return rc;
         if (jac_dense && (f || grad)) return launch_post(h, B, tiles, jac_dense, Z, f, grad, s);
         if (jac_dense && (rc = launch_assemble_dense(h, B, tiles, jac_dense, s))) return rc;

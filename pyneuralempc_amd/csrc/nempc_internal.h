@@ -176,6 +176,8 @@ int launch_objective(Handle& h, int B, const void* Z, void* f, void* grad, hipSt
 int launch_assemble_dense(Handle& h, int B, const void* tiles, void* jac, hipStream_t s);
 int launch_assemble_sparse(Handle& h, int B, const void* tiles, void* vals, hipStream_t s);
 int launch_post(Handle& h, int B, const void* tiles, void* jac, const void* Z, void* f, void* grad, hipStream_t s);
+int launch_post_sparse(Handle& h, int B, const void* tiles, void* vals, const void* Z, void* f, void* grad,
+                       hipStream_t s);
 int launch_assemble_hess(Handle& h, int B, const void* blocks, const void* sigma, void* hvals, void* hdense,
                          hipStream_t s);
 

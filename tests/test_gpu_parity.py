@@ -313,3 +313,23 @@ def test_defect_only_evaluation_matches_full_evaluation(name):
         if kernel == "mfma_tile":
             full = eng.eval_numpy(d["Z"], d["X0"], want=("g", "jac_tiles"))["g"]
             assert np.array_equal(only_g, full)
+
+
+@pytest.mark.parametrize("name", ["c2_discret", "c5_box", "odd_dims", "c3_rk4", "h1"])
+def test_sparse_contract_fused_launch(name):
+    """f, grad, g and the band-pattern Jacobian values without the dense matrix (one fused post launch)."""
+    d, W, b = load_case(name)
+    for dtype in (torch.float64, torch.float32):
+        eng = _engine(d, W, b, dtype, "auto")
+        res = eng.eval_numpy(d["Z"], d["X0"], want=("f", "grad", "g", "jac_sparse"))
+        rows, cols = eng.jac_structure()
+        if dtype == torch.float64:
+            np.testing.assert_allclose(res["f"], d["f"], **F64)
+            np.testing.assert_allclose(res["grad"], d["grad"], **F64)
+            np.testing.assert_allclose(res["g"], d["g"], **F64)
+            np.testing.assert_allclose(res["jac_sparse"], d["jac"][:, rows, cols], **F64)
+            full = eng.eval_numpy(d["Z"], d["X0"], want=ALL)
+            assert np.array_equal(res["jac_sparse"], full["jac_sparse"]) and np.array_equal(res["f"], full["f"])
+        else:
+            _f32_close(res["jac_sparse"], d["jac"][:, rows, cols], f"{name}/jac_sparse")
+            _f32_close(res["f"], d["f"], f"{name}/f")
