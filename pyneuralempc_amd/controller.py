@@ -75,17 +75,19 @@ class NMPC:
 
     def next_batch(self, X0, init_z=None, **solver_opts):
         """Solve B MPC problems at once on the device (no reference counterpart).  X0 (B,nx) NumPy
-        array or device tensor.  Needs the fused device path (device integrator + QuadraticObjective, no extra
-        constraint rows; state limits go into the DomainConstraint).  Returns (states (B,H,nx), u (B,H,nu),
+        array or device tensor.  Needs the fused device path (device integrator + QuadraticObjective; the only
+        extra rows accepted are BoxStateConstraint, which become bounds on the state variables).  Returns (states (B,H,nx), u (B,H,nu),
         status (B,) with Optimizer.SUCCESS / FAIL per problem) as NumPy arrays."""
         import torch
         from .optimizer.base import _FusedEvaluator
         from .objective.quadratic import QuadraticObjective
         from .integrator.base import DeviceIntegrator
+        from .constraints import BoxStateConstraint
+        boxes = [c for c in self.constraint_list if isinstance(c, BoxStateConstraint)]
         if not (isinstance(self.integrator, DeviceIntegrator) and isinstance(self.objective_func, QuadraticObjective)
-                and len(self.constraint_list) == 0):
+                and len(boxes) == len(self.constraint_list)):
             raise NotImplementedError("next_batch needs a device integrator, a QuadraticObjective and no extra "
-                                      "constraint rows")
+                                      "constraint rows other than BoxStateConstraint")
         key = (id(self.objective_func), None)
         cache = self.integrator._fused
         if key not in cache:
@@ -94,8 +96,13 @@ class NMPC:
         H = self.integrator.H
         X0t = X0 if isinstance(X0, torch.Tensor) else eng.to_device(np.atleast_2d(np.asarray(X0, dtype=np.float64)))
         Zi = None if init_z is None else (init_z if isinstance(init_z, torch.Tensor) else eng.to_device(init_z))
-        lb = np.asarray(self.domain_constraint.get_lower_bounds(H), dtype=np.float64)
-        ub = np.asarray(self.domain_constraint.get_upper_bounds(H), dtype=np.float64)
+        lb = np.asarray(self.domain_constraint.get_lower_bounds(H), dtype=np.float64).copy()
+        ub = np.asarray(self.domain_constraint.get_upper_bounds(H), dtype=np.float64).copy()
+        # box rows on the states are bounds on the state variables: intersect them with the domain
+        for box in boxes:
+            lo, hi = box._bounds(eng.nx)
+            lb[:H * eng.nx] = np.maximum(lb[:H * eng.nx], np.tile(lo, H))
+            ub[:H * eng.nx] = np.minimum(ub[:H * eng.nx], np.tile(hi, H))
         Z, status, iters = eng.solve(X0t.contiguous(), Zi, lb, ub, **solver_opts)
         self.last_batch_iterations = iters
         z = Z.to("cpu", torch.float64).numpy()

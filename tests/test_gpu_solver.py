@@ -107,3 +107,36 @@ def test_solver_argument_errors():
     eng.set_box_rows(-1.0, 1.0)
     with pytest.raises(NempcError):
         eng.solve(X0)
+
+
+def test_next_batch_turns_box_state_rows_into_state_bounds():
+    """BoxStateConstraint rows (BASELINE config 5 style) are bounds on the state variables for the batched solver:
+    same solution as the identical limits given through the DomainConstraint; other row constraints are refused."""
+    import pyneuralempc_amd as nEMPC
+    nx, nu, H, B = 2, 1, 12, 16
+    net = orc.MLP.random(nx + nu, [32, 32], nx, seed=2)
+    net.W[-1] *= 0.2
+    net.b[-1] *= 0.2
+    X0 = np.random.default_rng(3).uniform(-0.6, 0.6, size=(B, nx))
+
+    def controller(state_lim, extra):
+        model = nEMPC.model.MLPModel(net.W, net.b, nx, nu, device="cuda:0")
+        integ = nEMPC.integrator.discret.DiscretIntegrator(model, H)
+        obj = nEMPC.objective.QuadraticObjective(Q=np.eye(nx), R=0.05 * np.eye(nu), xref=np.full((H, nx), 1.0),
+                                                 device="cuda:0")
+        dom = nEMPC.constraints.DomainConstraint(states_constraint=[state_lim] * nx, control_constraint=[[-1.0, 1.0]])
+        return nEMPC.controller.NMPC(integ, obj, [dom] + extra, H, 1.0, optimizer=nEMPC.optimizer.Slsqp())
+
+    a = controller([-0.7, 0.7], [])
+    b = controller([-5.0, 5.0], [nEMPC.constraints.BoxStateConstraint(-0.7, 0.7, x_dim=nx)])
+    sa, ua, sta = a.next_batch(X0, max_iter=80)
+    sb, ub_, stb = b.next_batch(X0, max_iter=80)
+    assert (sta == 0).sum() >= B // 2 and np.array_equal(sta, stb)
+    assert np.array_equal(sa, sb) and np.array_equal(ua, ub_)
+    ok = sta == 0
+    assert sa[ok].max() <= 0.7 + 1e-9 and sa[ok].max() > 0.69  # the limit is active (xref = 1 pulls the states up)
+
+    class Rows(nEMPC.constraints.InequalityConstraint):
+        def get_dim(self, H): return H
+    with pytest.raises(NotImplementedError):
+        controller([-5.0, 5.0], [Rows()]).next_batch(X0)
