@@ -67,6 +67,21 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Cotangents swept together in the reverse pass: two when their accumulators are no bigger than those of a 2-tile
+// fp64 pass (fp64: single-tile passes; fp32: passes of <= 2 tiles).  Two independent MFMA chains per wave and half the
+// exchange barriers -- what the latency-bound cases (single-tile passes, 8-wave workgroups) lack.
+template <typename T>
+__host__ __device__ constexpr int coop_kg(int NT) {
+    return NT * (int)sizeof(T) <= 8 ? 2 : 1;   // three at a time for fp32 single-tile passes measured no better (576 vs 568 us at C3)
+}
+// exchange-buffer slots (16-row activation sets) a pass may publish at once
+template <typename T>
+__host__ __device__ constexpr int coop_slots(int TPW) {
+    int m = 0;
+    for (int nt = 1; nt <= TPW; ++nt) m = nt * coop_kg<T>(nt) > m ? nt * coop_kg<T>(nt) : m;
+    return m;
+}
+
 template <typename T>
 __host__ __device__ inline int coop_nr(int nin) {
     return sizeof(T) == 8 ? (nin + 3) / 4 : 4;
@@ -291,48 +306,65 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
             for (int j = 0; j < NT; ++j) a[l][j] = T(1) - a[l][j] * a[l][j];
 
         COOP_STAMP(6);
-        // ---- reverse sweep, one cotangent per network output
-        for (int k = 0; k < nx; ++k) {
-            V4 cv[NT];
-            {
+        // ---- reverse sweep: KG cotangents (network outputs) at a time; an odd leftover is swept twice, its second copy
+        //      is not stored
+        constexpr int KG = coop_kg<T>(NT);
+        for (int k0 = 0; k0 < nx; k0 += KG) {
+            V4 cv[KG][NT];
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                const int k = k0 + g < nx ? k0 + g : nx - 1;
                 const T* seed = cx.seed + k * MT * 16 + w * 16;
                 V4 sd;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sd[r] = seed[r * 4 + q];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) cv[j] = sd * a[NH - 1][j];
+                for (int j = 0; j < NT; ++j) cv[g][j] = sd * a[NH - 1][j];
             }
 #pragma unroll
             for (int l = NH - 1; l >= 1; --l) {
                 X = cx.X + (xsel & 1) * cx.xhalf;
                 ++xsel;
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
+                for (int g = 0; g < KG; ++g)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) X[((j * MT + w) * 4 + r) * 64 + lane] = cv[j][r];
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) X[(((g * NT + j) * MT + w) * 4 + r) * 64 + lane] = cv[g][j][r];
                 lds_barrier();
-                V4 cn[NT];
+                V4 cn[KG][NT];
 #pragma unroll
-                for (int j = 0; j < NT; ++j) cn[j] = V4{T(0), T(0), T(0), T(0)};
+                for (int g = 0; g < KG; ++g)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) cn[g][j] = V4{T(0), T(0), T(0), T(0)};
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            cn[j] = Ops::mma(W.wb[l - 1][mt * 4 + r], X[((j * MT + mt) * 4 + r) * 64 + lane], cn[j]);
+                        for (int g = 0; g < KG; ++g)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) cv[j] = cn[j] * a[l - 1][j];
+                            for (int j = 0; j < NT; ++j)
+                                cn[g][j] = Ops::mma(W.wb[l - 1][mt * 4 + r],
+                                                    X[(((g * NT + j) * MT + mt) * 4 + r) * 64 + lane], cn[g][j]);
+#pragma unroll
+                for (int g = 0; g < KG; ++g)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) cv[g][j] = cn[g][j] * a[l - 1][j];
             }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                V4 pj = V4{T(0), T(0), T(0), T(0)};
+            for (int g = 0; g < KG; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pj = Ops::mma(W.w0b[r], cv[j][r], pj);
+                for (int j = 0; j < NT; ++j) {
+                    V4 pj = V4{T(0), T(0), T(0), T(0)};
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < NR) PART[((((1 + k) * NT + j) * MT + w) * NR + r) * 64 + lane] = pj[r];
-            }
+                    for (int r = 0; r < 4; ++r) pj = Ops::mma(W.w0b[r], cv[g][j][r], pj);
+                    if (k0 + g < nx) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (r < NR) PART[((((1 + k0 + g) * NT + j) * MT + w) * NR + r) * 64 + lane] = pj[r];
+                    }
+                }
         }
         COOP_STAMP(7);
         lds_barrier();
