@@ -98,7 +98,8 @@ __device__ __forceinline__ double nempc_tanh(double x) {
     double q = __builtin_amdgcn_rcp(d);
     q = fma(fma(-d, q, 1.0), q, q);
     q = fma(fma(-d, q, 1.0), q, q);
-    return copysign(fma(-2.0, q, 1.0), x);
+    // fmin() above swallows a NaN argument; hand it back like libm does, so a diverged iterate stays visible
+    return x != x ? x : copysign(fma(-2.0, q, 1.0), x);
 }
 
 // fp32: hardware exp2 / rcp; abs error ~1e-7, inside the fp32 configs' 1e-4 tolerance
@@ -106,7 +107,7 @@ __device__ __forceinline__ float nempc_tanh(float x) {
     const float ax = fminf(fabsf(x), 10.0f);
     const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);  // exp(2|x|)
     const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    return copysignf(t, x);
+    return x != x ? x : copysignf(t, x);
 }
 
 template <typename T>

@@ -333,3 +333,24 @@ def test_sparse_contract_fused_launch(name):
         else:
             _f32_close(res["jac_sparse"], d["jac"][:, rows, cols], f"{name}/jac_sparse")
             _f32_close(res["f"], d["f"], f"{name}/f")
+
+
+@pytest.mark.parametrize("kernel", ["valu", "mfma", "mfma_tile"])
+def test_nan_inputs_stay_visible(kernel):
+    """A NaN in the iterate (diverged solver) must come out as NaN in exactly the rows that read it, like the
+    reference's NumPy / libm path -- not be clamped away by the fast tanh."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, H, B = 2, 1, 6, 3
+    net = orc.MLP.random(nx + nu, [32, 32], nx, seed=1)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=2)
+    Zh[1, H * nx + 2] = np.nan                      # control u_2 of problem 1
+    for integ, kind in (("unity", orc.UNITY), ("discret", orc.DISCRET)):
+        eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, device="cuda:0", max_batch=B, kernel=kernel)
+        res = eng.eval_numpy(Zh, X0h, want=("g", "jac_tiles"))
+        prob = orc.Problem(net, H, nx, nu, kind)
+        with np.errstate(invalid="ignore"):
+            gref = np.stack([prob.constraints(Zh[i], X0h[i]) for i in range(B)])
+        assert np.array_equal(np.isnan(res["g"]), np.isnan(gref))
+        assert np.isnan(res["g"][1, 2 * nx:3 * nx]).all() and np.isnan(res["jac_tiles"][1, 2]).all()
+        ok = ~np.isnan(gref)
+        np.testing.assert_allclose(res["g"][ok], gref[ok], **F64)
