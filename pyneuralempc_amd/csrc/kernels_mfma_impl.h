@@ -460,12 +460,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
 template <typename T, int WP, int NH, bool WLDS, int MAXWAVES>
 int launch_one(const MfmaParams& p, int waves, int grid, size_t lds_bytes, hipStream_t s) {
     auto kern = rows_mfma_kernel<T, WP, NH, WLDS, MAXWAVES>;
-    static thread_local size_t configured = 0;
-    if (lds_bytes > 65536 && lds_bytes > configured) {
-        NEMPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds_bytes));
-        configured = lds_bytes;
-    }
+    NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds_bytes, s, p);
     NEMPC_HIP(hipGetLastError());
     return NEMPC_OK;

@@ -3,7 +3,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <utility>
 
 #include "nempc_internal.h"
 
@@ -12,6 +15,21 @@ namespace nempc {
 static thread_local std::string g_last_error;
 
 void set_error(const std::string& msg) { g_last_error = msg; }
+
+hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 65536) return hipSuccess;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = done[{dev, kernel}];
+    if (bytes <= have) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 
 int hip_fail(hipError_t e, const char* what) {
     set_error(std::string(what) + ": " + hipGetErrorString(e));

@@ -147,6 +147,11 @@ inline ObjOffsets obj_offsets(int H, int nx, int nu) {
     return o;
 }
 
+// Dynamic LDS above 64 KiB needs hipFuncAttributeMaxDynamicSharedMemorySize, which is a per-device property of the
+// kernel: remember the largest size configured per (device, kernel) so the attribute call stays off the hot path.
+// Returns hipSuccess when nothing had to be done.
+hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
+
 // ---- kernels_valu.hip : generic thread-per-row kernel
 size_t valu_workspace_elems(const Handle& h);
 int launch_rows_valu(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s);
