@@ -354,3 +354,29 @@ def test_nan_inputs_stay_visible(kernel):
         assert np.isnan(res["g"][1, 2 * nx:3 * nx]).all() and np.isnan(res["jac_tiles"][1, 2]).all()
         ok = ~np.isnan(gref)
         np.testing.assert_allclose(res["g"][ok], gref[ok], **F64)
+
+
+@pytest.mark.parametrize("kind,DT", [(orc.DISCRET, 1.0), (orc.RK4, 0.2)])
+def test_linear_model_single_dense_layer(kind, DT):
+    """A network with no hidden layer (one Dense-linear): the generic kernel is the only path; values, Jacobian and
+    (zero-curvature) Hessian against the oracle."""
+    from pyneuralempc_amd import CallbackEngine
+    from pyneuralempc_amd._lib import NempcError
+    nx, nu, H, B = 3, 2, 5, 4
+    net = orc.MLP.random(nx + nu, [], nx, seed=9)
+    prob = orc.Problem(net, H, nx, nu, kind, DT)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=3)
+    integ = {orc.DISCRET: "discret", orc.RK4: "rk4"}[kind]
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, device="cuda:0", max_batch=B)
+    assert eng.kernel_variant == "valu"
+    with pytest.raises(NempcError):
+        CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, device="cuda:0", kernel="mfma")
+    res = eng.eval_numpy(Zh, X0h)
+    f, grad, g, jac = prob.eval_batch(Zh, X0h)
+    np.testing.assert_allclose(res["g"], g, **F64)
+    np.testing.assert_allclose(res["jac_dense"], jac, **F64)
+    lam = np.random.default_rng(1).normal(size=(B, prob.m))
+    hd = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lam), eng.to_device(np.ones(B)),
+                  want=("hdense",))["hdense"].cpu().numpy()
+    for i in range(B):
+        np.testing.assert_allclose(hd[i], prob.lagrangian_hessian(Zh[i], X0h[i], lam[i], 1.0), rtol=1e-11, atol=1e-12)
