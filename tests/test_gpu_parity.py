@@ -380,3 +380,23 @@ def test_linear_model_single_dense_layer(kind, DT):
                   want=("hdense",))["hdense"].cpu().numpy()
     for i in range(B):
         np.testing.assert_allclose(hd[i], prob.lagrangian_hessian(Zh[i], X0h[i], lam[i], 1.0), rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("hidden", [[8] * 7, [200], [17, 33, 5]])
+def test_shapes_outside_the_matrix_core_kernels(hidden):
+    """Deepest allowed stack (8 dense layers), a width beyond 128 and ragged widths: generic kernel (a ragged 3-hidden
+    stack pads to the matrix-core shape), against the oracle."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, H, B = 2, 2, 4, 5
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=4)
+    prob = orc.Problem(net, H, nx, nu, orc.RK4, 0.1)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=6)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator="rk4", DT=0.1, device="cuda:0", max_batch=B)
+    assert eng.kernel_variant == ("mfma" if hidden == [17, 33, 5] else "valu")
+    res = eng.eval_numpy(Zh, X0h)
+    f, grad, g, jac = prob.eval_batch(Zh, X0h)
+    np.testing.assert_allclose(res["g"], g, **F64)
+    np.testing.assert_allclose(res["jac_dense"], jac, rtol=1e-11, atol=1e-12)
+    with pytest.raises(ValueError, match="at most"):
+        deep = orc.MLP.random(nx + nu, [4] * 8, nx, seed=1)
+        CallbackEngine(deep.W, deep.b, H, nx, nu, device="cuda:0")
