@@ -117,6 +117,8 @@ struct CoopCtx {
     bool rk4;
     T DT;
     RowGather gk;                   // where a row's window inputs come from (nempc_internal.h)
+    T* stage_out;                   // RK4 Hessian pipeline: per (row, stage) record [xi_s | J_s | dk_{s-1}], else null
+    int stage_stride;
     long long* dbg;
 };
 
@@ -204,7 +206,7 @@ __device__ __forceinline__ void stage_direct(const CoopCtx<T>& cx, int t0, int n
 // One pass over NT (compile-time) tiles starting at tile t0.  NT is a template parameter on purpose:
 // with a runtime tile count every per-tile MFMA sat in its own basic block and hipcc copied the whole
 // accumulator set through AGPRs at each join (6,500 v_accvgpr_* moves, 10x slower reverse sweep).
-template <typename T, int WP, int NH, int NT>
+template <typename T, int WP, int NH, int NT, bool SR>
 __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeights<T, WP, NH>& W, int t0, int tid) {
     using Ops = MfmaOps<T>;
     using V4 = typename Ops::V4;
@@ -247,6 +249,9 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                     if (d < nin) {
                         v = s_xi0[c * nin + d];
                         if (stage > 0 && d < nx) v = fma(cdt, s_xi0[16 * nin + c * nx + d], v);
+                        // every wave forms the same stage input; wave 0 records it for the Hessian pipeline
+                        if (SR && w == 0 && RI[2 * (j * 16 + c)] >= 0)
+                            cx.stage_out[(((size_t)t0 + j) * 16 + c) * 4 * cx.stage_stride + (size_t)stage * cx.stage_stride + d] = v;
                     } else if (d < nin + cx.ne) {
                         v = s_xi0[cx.ex_off + c * cx.ne + (d - nin)];
                     }
@@ -392,6 +397,20 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
         }
         lds_barrier();
 
+        // stage record for the Hessian pipeline: this stage's Jacobian and the chain Jacobian it was entered with
+        if (SR) {
+            const int jn = nx * nin;
+            for (int e = tid; e < NT * jsz; e += NTHREADS) {
+                const int j = e / jsz, e2 = e - j * jsz;
+                const int cc = e2 / jn, rem2 = e2 - cc * jn;
+                if (RI[2 * (j * 16 + cc)] >= 0) {
+                    const T* sj = SCR + j * spt + 16 * nin + 2 * 16 * nx;
+                    T* rec = cx.stage_out + ((((size_t)t0 + j) * 16 + cc) * 4 + stage) * cx.stage_stride + nin;
+                    rec[rem2] = sj[e2];
+                    rec[jn + rem2] = stage > 0 ? sj[jsz + e2] : T(0);
+                }
+            }
+        }
         // ---- RK4 chain rule on the per-tile scratch (rk4.py:147-159)
         if (rk4) {
             if (stage == 0) {
@@ -472,7 +491,9 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
     COOP_STAMP(11);
 }
 
-template <typename T, int WP, int NH, int TPW>
+// SR: also write the per-(row, stage) records of the RK4 Hessian pipeline (its own instantiation: the extra stores and
+// their address arithmetic cost the plain kernel 0.3 - 0.9 us when they are only branched around)
+template <typename T, int WP, int NH, int TPW, bool SR = false>
 __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams p, CoopLayout lay) {
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
@@ -500,6 +521,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams
     cx.tiles = static_cast<T*>(p.tiles);
     cx.nx = p.nx; cx.nu = p.nu; cx.nin = p.nin; cx.H = p.H; cx.n = p.gk.n; cx.m = p.m;
     cx.gk = p.gk;
+    cx.stage_out = static_cast<T*>(p.stage_out); cx.stage_stride = p.stage_stride;
     cx.NR = coop_nr<T>(p.nin);
     cx.jsz = 16 * p.nx * p.nin;
     cx.spt = p.scratch_per_wave;
@@ -556,10 +578,10 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams
         if (early) stage_store<T, MT, TPW>(cx, nact * 16, tid, sr);
         else stage_direct<T, MT, TPW>(cx, t0, nact * 16, tid);
         lds_barrier();
-        if (nact == 1) coop_pass<T, WP, NH, 1>(cx, W, t0, tid);
-        if constexpr (TPW >= 2) { if (nact == 2) coop_pass<T, WP, NH, 2>(cx, W, t0, tid); }
-        if constexpr (TPW >= 3) { if (nact == 3) coop_pass<T, WP, NH, 3>(cx, W, t0, tid); }
-        if constexpr (TPW >= 4) { if (nact == 4) coop_pass<T, WP, NH, 4>(cx, W, t0, tid); }
+        if (nact == 1) coop_pass<T, WP, NH, 1, SR>(cx, W, t0, tid);
+        if constexpr (TPW >= 2) { if (nact == 2) coop_pass<T, WP, NH, 2, SR>(cx, W, t0, tid); }
+        if constexpr (TPW >= 3) { if (nact == 3) coop_pass<T, WP, NH, 3, SR>(cx, W, t0, tid); }
+        if constexpr (TPW >= 4) { if (nact == 4) coop_pass<T, WP, NH, 4, SR>(cx, W, t0, tid); }
         t0 += nact;
 #ifdef NEMPC_STAMPS
         cx.dbg = nullptr;   // diagnostic build: keep the FIRST pass's stamps
