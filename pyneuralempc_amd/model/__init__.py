@@ -2,6 +2,7 @@
 from . import base
 from . import mlp
 from . import rolling
+from . import jax
 from . import tensorflow
 from .base import Model
 from .mlp import MLPModel

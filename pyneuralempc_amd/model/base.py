@@ -28,3 +28,10 @@ class Model:
     def __init__(self, x_dim: int, u_dim: int, p_dim=None, tvp_dim=None):
         self.x_dim, self.u_dim = x_dim, u_dim
         self.p_dim, self.tvp_dim = p_dim, tvp_dim
+
+
+class ReOrderProxyModel(Model):
+    """Declared and unimplemented in the reference as well (model/base.py:26-28)."""
+
+    def __init__(self, model, order_list: list):
+        raise NotImplementedError("")

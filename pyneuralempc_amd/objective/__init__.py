@@ -2,6 +2,7 @@
 from . import base
 from . import quadratic
 from . import autodiff
+from . import jax
 from .base import ObjectiveFunc, ManualObjectifFunc
 from .quadratic import QuadraticObjective
 from .autodiff import TorchObjectifFunc

@@ -188,3 +188,15 @@ def test_torch_objective_plugin_matches_closed_form_family():
     assert not lin.hessian(states, u).any()
     sq = TorchObjectifFunc(lambda s, u, p=None, tvp=None: torch.sum((u.reshape(-1) - 2.0) ** 2), device="cpu")
     np.testing.assert_allclose(sq.gradient(states, u)[H * nx:], 2.0 * (u.ravel() - 2.0), rtol=1e-14)
+
+
+def test_reference_names_without_a_device_counterpart_explain_themselves():
+    import pyneuralempc_amd as nEMPC
+    with pytest.raises(NotImplementedError, match="TorchObjectifFunc"):
+        nEMPC.objective.jax.JAXObjectifFunc(lambda x, u, p=None, tvp=None: 0.0)
+    with pytest.raises(NotImplementedError, match="MLPModel"):
+        nEMPC.model.jax.DiffDiscretJaxModel(lambda x, u, p=None, tvp=None: x, 2, 1)
+    with pytest.raises(NotImplementedError, match="MLPModelRollingInput"):
+        nEMPC.model.jax.DiffDiscretJaxModelRollingWindow(lambda x, u, p=None, tvp=None: x, 2, 1, rolling_window=2)
+    with pytest.raises(NotImplementedError):
+        nEMPC.model.base.ReOrderProxyModel(None, [])
