@@ -169,7 +169,7 @@ typedef struct nempc_solver_opts {
     int32_t max_iter;        /* outer iterations, e.g. 200 */
     int32_t max_linesearch;  /* backtracking halvings per iteration, e.g. 6 */
     int32_t check_every;     /* host convergence poll period in iterations, e.g. 4 */
-    int32_t reserved;
+    int32_t lq_kernel;       /* Riccati sweep: 0 auto (by stage size), 1 one thread per problem, 2 one wave per problem */
     double tol_constraint;   /* max |defect| at convergence, e.g. 1e-8 */
     double tol_step;         /* max |dz| <= tol_step * (1 + max |z|), e.g. 1e-8 */
     double mu_init, mu_min, mu_factor; /* barrier schedule, e.g. 1e-1, 1e-9, 0.2 */

@@ -550,7 +550,7 @@ int nempc_solve(nempc_handle hh, int32_t B, const void* X0, void* Z, const doubl
     if (h.box) return fail(NEMPC_EUNSUPPORTED, "nempc_solve: box rows are not handled; pass state bounds as lb/ub");
     if (h.w > 1) return fail(NEMPC_EUNSUPPORTED, "nempc_solve: rolling-window models are not handled by the batched solver");
     if (opts->max_iter < 1 || opts->max_linesearch < 1 || !(opts->mu_factor > 0.0 && opts->mu_factor < 1.0) ||
-        !(opts->mu_init > 0.0) || !(opts->mu_min > 0.0))
+        !(opts->mu_init > 0.0) || !(opts->mu_min > 0.0) || opts->lq_kernel < 0 || opts->lq_kernel > 2)
         return fail(NEMPC_EINVAL, "nempc_solve: bad options");
     DeviceGuard dg(h.cfg.device);
     if (!dg.ok) return fail(NEMPC_EHIP, "nempc_solve: hipSetDevice failed");

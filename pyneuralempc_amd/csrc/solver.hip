@@ -19,6 +19,7 @@
 // Every problem carries its own mu, nu, step length and status; the batch advances in lock step and finished
 // problems idle.  All arithmetic is in kernels here; the callbacks are the handle's own row/objective kernels.
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 #include "nempc_internal.h"
@@ -378,6 +379,335 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     }
 }
 
+// Wave-per-problem variant of the LQ solve (LDS mode only): the same recursion, formulas and summation order as
+// solver_lq_kernel, but every small matrix operation of a stage is spread over the 64 lanes of the problem's wave
+// (entry per lane) with wave-level synchronisation between dependent operations.  A thread-per-problem sweep is one
+// serial chain of ~1000 FMAs per stage on 6/3-sized blocks with 4 of 64 lanes busy; here a stage is ~8 short phases.
+// NX, NU > 0: stage dimensions fixed at compile time (the entry loops unroll and their LDS loads overlap).
+template <typename T, int NX, int NU>
+__global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int H = a.H, nx = NX > 0 ? NX : a.nx, nu = NX > 0 ? NU : a.nu, nin = nx + nu, n = a.n;
+    const int ppw = a.ppw;                       // == waves per workgroup
+    const int b0 = blockIdx.x * ppw;
+    const int np = a.B - b0 < ppw ? a.B - b0 : ppw;
+    const int Lz = 0, Lgr = Lz + n, Lgc = Lgr + n, Ltl = Lgc + H * nx, LW = Ltl + H * nx * nin, LK = LW + H * nin * nin,
+              Lk = LK + H * nu * nx, LP = Lk + H * nu, Lp = LP + H * nx * nx, Llam = Lp + H * nx, Ldz = Llam + H * nx,
+              Ltmp = Ldz + n;
+    auto stage_in = [&](const T* __restrict__ src, int per, int src_stride, int loff) {
+        const int tot = np * per;
+        const T* base = src + (size_t)b0 * src_stride;
+#pragma unroll 4
+        for (int i = tid; i < tot; i += 256) {
+            const int pp = i / per, e = i - pp * per;
+            lds[(size_t)pp * a.lds_stride + loff + e] = base[(size_t)pp * src_stride + e];
+        }
+    };
+    stage_in((const T*)a.Z, n, n, Lz);
+    stage_in((const T*)a.grad, n, n, Lgr);
+    stage_in((const T*)a.g, H * nx, a.m, Lgc);
+    stage_in((const T*)a.tiles, H * nx * nin, H * nx * nin, Ltl);
+    stage_in((const T*)a.hblk, H * nin * nin, H * nin * nin, LW);
+    __syncthreads();
+
+    const int b = b0 + wv;
+    if (wv < np) {
+        T* blk = lds + (size_t)wv * a.lds_stride;
+        auto wsync = [] {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        if (a.status[b] >= 0) {
+            // finished problem: zero step, multipliers unchanged
+            for (int i = lane; i < n; i += 64) blk[Ldz + i] = T(0);
+            const T* lcur = (const T*)a.lam + (size_t)b * a.m;
+            for (int i = lane; i < H * nx; i += 64) blk[Llam + i] = lcur[i];
+        } else {
+            T* tb = blk + Ltmp;
+            int off = 0;
+            const int oP = off; off += nx * nx;
+            const int oPA = off; off += nx * nx;
+            const int oPn = off; off += nx * nx;
+            const int oPB = off; off += nx * nu;
+            const int oQux = off; off += nu * nx;
+            const int oK = off; off += nu * nx;
+            const int oQuu = off; off += nu * nu;
+            const int oPc = off; off += nx;
+            const int op = off; off += nx;
+            const int opn = off; off += nx;
+            const int odx = off; off += nx;
+            const int odxn = off; off += nx;
+            const int oqu = off; off += nu;
+            const int okv = off; off += nu;
+            const int odu = off; off += nu;
+            const int oflag = off;                 // 1 slot: Cholesky verdict of the stage
+            const T* z = blk + Lz;
+            const T* gr = blk + Lgr;
+            const T* gc = blk + Lgc;
+            const T* tl = blk + Ltl;
+            const T* Wb = blk + LW;
+            const T* Qs = (const T*)a.obj + a.oo.Qs;
+            const T* Rs = (const T*)a.obj + a.oo.Rs;
+            const T* lb = (const T*)a.lb;
+            const T* ub = (const T*)a.ub;
+            const T mu = ((const T*)a.mu)[b];
+            T reg = ((const T*)a.reg)[b];
+            T* Kst = blk + LK;
+            T* kst = blk + Lk;
+            T* Pst = blk + LP;
+            T* pst = blk + Lp;
+            T* dz = blk + Ldz;
+            T* lamn = blk + Llam;
+            const int uo = H * nx;
+            int restarts = 0;
+            for (int attempt = 0; attempt < 14; ++attempt) {
+                bool pd = true;
+                // terminal value function
+                for (int e = lane; e < nx * nx + nx; e += 64) {
+                    if (e < nx * nx) {
+                        const int i = e / nx, j = e - i * nx;
+                        T ga = T(0), ha = T(0);
+                        if (i == j) barrier_terms<T>(z[(H - 1) * nx + i], lb[(H - 1) * nx + i], ub[(H - 1) * nx + i], mu, ga, ha);
+                        tb[oP + e] = Qs[e] + (i == j ? ha : T(0));
+                    } else {
+                        const int i = e - nx * nx;
+                        T ga = T(0), ha = T(0);
+                        barrier_terms<T>(z[(H - 1) * nx + i], lb[(H - 1) * nx + i], ub[(H - 1) * nx + i], mu, ga, ha);
+                        tb[op + i] = gr[(H - 1) * nx + i] + ga;
+                    }
+                }
+                wsync();
+                for (int t = H - 1; t >= 0 && pd; --t) {
+                    const T* At = tl + (size_t)t * nx * nin;
+                    const T* Wt = Wb + (size_t)t * nin * nin;
+                    // store P_t, p_t; PA = P A, PB = P B, Pc = P c + p
+                    for (int e = lane; e < 2 * nx * nx + nx * nu + 2 * nx; e += 64) {
+                        int r = e;
+                        if (r < nx * nx) { Pst[(size_t)t * nx * nx + r] = tb[oP + r]; continue; }
+                        r -= nx * nx;
+                        if (r < nx) { pst[(size_t)t * nx + r] = tb[op + r]; continue; }
+                        r -= nx;
+                        if (r < nx * nx) {
+                            if (t > 0) {
+                                const int i = r / nx, j = r - i * nx;
+                                T v = T(0);
+                                for (int k = 0; k < nx; ++k) v = fma(tb[oP + i * nx + k], At[k * nin + j], v);
+                                tb[oPA + r] = v;
+                            }
+                            continue;
+                        }
+                        r -= nx * nx;
+                        if (r < nx * nu) {
+                            const int i = r / nu, j = r - i * nu;
+                            T v = T(0);
+                            for (int k = 0; k < nx; ++k) v = fma(tb[oP + i * nx + k], At[k * nin + nx + j], v);
+                            tb[oPB + r] = v;
+                            continue;
+                        }
+                        r -= nx * nu;
+                        T v = tb[op + r];
+                        for (int k = 0; k < nx; ++k) v = fma(tb[oP + r * nx + k], gc[t * nx + k], v);
+                        tb[oPc + r] = v;
+                    }
+                    wsync();
+                    // Quu, qu, Qux
+                    for (int e = lane; e < nu * nu + nu + nu * nx; e += 64) {
+                        int r = e;
+                        if (r < nu * nu) {
+                            const int i = r / nu, j = r - i * nu;
+                            T ga = T(0), ha = T(0);
+                            if (i == j) barrier_terms<T>(z[uo + t * nu + i], lb[uo + t * nu + i], ub[uo + t * nu + i], mu, ga, ha);
+                            T v = Rs[i * nu + j] + Wt[(nx + i) * nin + nx + j] + (i == j ? ha + reg : T(0));
+                            for (int k = 0; k < nx; ++k) v = fma(At[k * nin + nx + i], tb[oPB + k * nu + j], v);
+                            tb[oQuu + r] = v;
+                            continue;
+                        }
+                        r -= nu * nu;
+                        if (r < nu) {
+                            T ga = T(0), ha = T(0);
+                            barrier_terms<T>(z[uo + t * nu + r], lb[uo + t * nu + r], ub[uo + t * nu + r], mu, ga, ha);
+                            T v = gr[uo + t * nu + r] + ga;
+                            for (int k = 0; k < nx; ++k) v = fma(At[k * nin + nx + r], tb[oPc + k], v);
+                            tb[oqu + r] = v;
+                            continue;
+                        }
+                        r -= nu;
+                        if (t > 0) {
+                            const int i = r / nx, j = r - i * nx;
+                            T w = Wt[(nx + i) * nin + j];
+                            for (int k = 0; k < nx; ++k) w = fma(At[k * nin + nx + i], tb[oPA + k * nx + j], w);
+                            tb[oQux + r] = w;
+                        }
+                    }
+                    wsync();
+                    // Cholesky Quu = L L' (lower, in place): small and serial, one lane
+                    if (lane == 0) {
+                        T ok = T(1);
+                        for (int j = 0; j < nu && ok > T(0); ++j) {
+                            T d = tb[oQuu + j * nu + j];
+                            for (int k = 0; k < j; ++k) d -= tb[oQuu + j * nu + k] * tb[oQuu + j * nu + k];
+                            if (!(d > T(1e-12))) { ok = T(0); break; }
+                            d = sqrt(d);
+                            tb[oQuu + j * nu + j] = d;
+                            for (int i = j + 1; i < nu; ++i) {
+                                T v = tb[oQuu + i * nu + j];
+                                for (int k = 0; k < j; ++k) v -= tb[oQuu + i * nu + k] * tb[oQuu + j * nu + k];
+                                tb[oQuu + i * nu + j] = v / d;
+                            }
+                        }
+                        tb[oflag] = ok;
+                    }
+                    wsync();
+                    if (!(tb[oflag] > T(0))) { pd = false; break; }
+                    // kv = -Quu^-1 qu ; K = -Quu^-1 Qux: one right-hand side per lane (lane 0: qu, lane 1+col: Qux[:,col]);
+                    // the substitution runs in a per-lane strip of the du scratch (nu entries per column)
+                    const int ncolK = t > 0 ? nx : 0;
+                    if (lane <= ncolK) {
+                        const int col = lane - 1;
+                        T* y = tb + oflag + 1 + lane * nu;     // per-column work vector
+                        for (int i = 0; i < nu; ++i) {
+                            T v = (col < 0) ? tb[oqu + i] : tb[oQux + i * nx + col];
+                            for (int k = 0; k < i; ++k) v -= tb[oQuu + i * nu + k] * y[k];
+                            y[i] = v / tb[oQuu + i * nu + i];
+                        }
+                        for (int i = nu - 1; i >= 0; --i) {
+                            T v = y[i];
+                            for (int k = i + 1; k < nu; ++k) v -= tb[oQuu + k * nu + i] * y[k];
+                            v /= tb[oQuu + i * nu + i];
+                            y[i] = v;
+                        }
+                        for (int i = 0; i < nu; ++i) {
+                            if (col < 0) { tb[okv + i] = -y[i]; kst[(size_t)t * nu + i] = -y[i]; }
+                            else { tb[oK + i * nx + col] = -y[i]; Kst[(size_t)t * nu * nx + i * nx + col] = -y[i]; }
+                        }
+                    }
+                    wsync();
+                    if (t > 0) {
+                        for (int e = lane; e < nx * nx + nx; e += 64) {
+                            if (e < nx * nx) {
+                                const int i = e / nx, j = e - i * nx;
+                                T ga = T(0), ha = T(0);
+                                if (i == j) barrier_terms<T>(z[(t - 1) * nx + i], lb[(t - 1) * nx + i], ub[(t - 1) * nx + i], mu, ga, ha);
+                                T v = Qs[i * nx + j] + Wt[i * nin + j] + (i == j ? ha : T(0));
+                                for (int k = 0; k < nx; ++k) v = fma(At[k * nin + i], tb[oPA + k * nx + j], v);
+                                for (int k = 0; k < nu; ++k) v = fma(tb[oQux + k * nx + i], tb[oK + k * nx + j], v);
+                                tb[oPn + e] = v;
+                            } else {
+                                const int i = e - nx * nx;
+                                T ga = T(0), ha = T(0);
+                                barrier_terms<T>(z[(t - 1) * nx + i], lb[(t - 1) * nx + i], ub[(t - 1) * nx + i], mu, ga, ha);
+                                T v = gr[(t - 1) * nx + i] + ga;
+                                for (int k = 0; k < nx; ++k) v = fma(At[k * nin + i], tb[oPc + k], v);
+                                for (int k = 0; k < nu; ++k) v = fma(tb[oQux + k * nx + i], tb[okv + k], v);
+                                tb[opn + i] = v;
+                            }
+                        }
+                        wsync();
+                        for (int e = lane; e < nx * nx + nx; e += 64) {
+                            if (e < nx * nx) {
+                                const int i = e / nx, j = e - i * nx;
+                                tb[oP + e] = T(0.5) * (tb[oPn + i * nx + j] + tb[oPn + j * nx + i]);
+                            } else {
+                                tb[op + e - nx * nx] = tb[opn + e - nx * nx];
+                            }
+                        }
+                        wsync();
+                    }
+                }
+                if (pd) break;
+                reg = fmax(reg * T(10), T(1e-6));
+                ++restarts;
+            }
+            if (lane == 0) ((T*)a.reg)[b] = reg;
+            // forward sweep; the norms are accumulated per lane and reduced at the end
+            T lam_inf = T(0), step_inf = T(0), amax = T(1), D0 = T(0), g1 = T(0), ginf = T(0), zinf = T(0);
+            const T tau = T(0.995);
+            for (int i = lane; i < nx; i += 64) tb[odx + i] = T(0);
+            wsync();
+            for (int t = 0; t < H; ++t) {
+                const T* At = tl + (size_t)t * nx * nin;
+                for (int i = lane; i < nu; i += 64) {
+                    T v = kst[(size_t)t * nu + i];
+                    if (t > 0)
+                        for (int k = 0; k < nx; ++k) v = fma(Kst[(size_t)t * nu * nx + i * nx + k], tb[odx + k], v);
+                    tb[odu + i] = v;
+                }
+                wsync();
+                for (int i = lane; i < nx; i += 64) {
+                    T v = gc[t * nx + i];
+                    if (t > 0)
+                        for (int k = 0; k < nx; ++k) v = fma(At[i * nin + k], tb[odx + k], v);
+                    for (int k = 0; k < nu; ++k) v = fma(At[i * nin + nx + k], tb[odu + k], v);
+                    tb[odxn + i] = v;
+                }
+                wsync();
+                for (int i = lane; i < nx + nu; i += 64) {
+                    if (i < nx) {
+                        T lam = pst[(size_t)t * nx + i];
+                        for (int k = 0; k < nx; ++k) lam = fma(Pst[(size_t)t * nx * nx + i * nx + k], tb[odxn + k], lam);
+                        lam_inf = fmax(lam_inf, fabs(lam));
+                        lamn[t * nx + i] = lam;
+                        const T d = tb[odxn + i], zz = z[t * nx + i], lo = lb[t * nx + i], hi = ub[t * nx + i];
+                        dz[t * nx + i] = d;
+                        step_inf = fmax(step_inf, fabs(d));
+                        zinf = fmax(zinf, fabs(zz));
+                        T ga = T(0), ha = T(0);
+                        barrier_terms<T>(zz, lo, hi, mu, ga, ha);
+                        D0 = fma(gr[t * nx + i] + ga, d, D0);
+                        if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
+                        if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
+                        const T gv = fabs(gc[t * nx + i]);
+                        g1 += gv;
+                        ginf = fmax(ginf, gv);
+                    } else {
+                        const int j = i - nx;
+                        const T d = tb[odu + j], zz = z[uo + t * nu + j], lo = lb[uo + t * nu + j], hi = ub[uo + t * nu + j];
+                        dz[uo + t * nu + j] = d;
+                        step_inf = fmax(step_inf, fabs(d));
+                        zinf = fmax(zinf, fabs(zz));
+                        T ga = T(0), ha = T(0);
+                        barrier_terms<T>(zz, lo, hi, mu, ga, ha);
+                        D0 = fma(gr[uo + t * nu + j] + ga, d, D0);
+                        if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
+                        if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
+                    }
+                }
+                wsync();
+                for (int i = lane; i < nx; i += 64) tb[odx + i] = tb[odxn + i];
+                wsync();
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                lam_inf = fmax(lam_inf, __shfl_down(lam_inf, o, 64));
+                step_inf = fmax(step_inf, __shfl_down(step_inf, o, 64));
+                amax = fmin(amax, __shfl_down(amax, o, 64));
+                D0 += __shfl_down(D0, o, 64);
+                g1 += __shfl_down(g1, o, 64);
+                ginf = fmax(ginf, __shfl_down(ginf, o, 64));
+                zinf = fmax(zinf, __shfl_down(zinf, o, 64));
+            }
+            if (lane == 0) {
+                T* info = (T*)a.info + (size_t)b * INFO_N;
+                info[INFO_LAM] = lam_inf; info[INFO_STEP] = step_inf; info[INFO_AMAX] = amax; info[INFO_G1] = g1;
+                info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf; info[INFO_RESTARTS] = (T)restarts;
+            }
+        }
+    }
+    __syncthreads();
+    auto stage_out = [&](T* __restrict__ dst, int per, int dst_stride, int loff) {
+        const int tot = np * per;
+        T* base = dst + (size_t)b0 * dst_stride;
+        for (int i = tid; i < tot; i += 256) {
+            const int pp = i / per, e = i - pp * per;
+            base[(size_t)pp * dst_stride + e] = lds[(size_t)pp * a.lds_stride + loff + e];
+        }
+    };
+    stage_out((T*)a.dz, n, n, Ldz);
+    stage_out((T*)a.lamn, H * nx, a.m, Llam);
+}
+
 // log-barrier value of one problem's variables, summed by a wave
 template <typename T>
 __device__ __forceinline__ double barrier_value(const T* z, const T* lb, const T* ub, int n, T mu, int lane) {
@@ -512,7 +842,7 @@ struct SolverWs {
     int cap = 0;
 };
 
-int lq_tmp_elems(int nx, int nu) { return 3 * nx * nx + 3 * nx * nu + nu * nu + 5 * nx + 3 * nu; }
+int lq_tmp_elems(int nx, int nu) { return 3 * nx * nx + 3 * nx * nu + nu * nu + 5 * nx + 3 * nu + 1 + (nx + 1) * nu; }
 
 }  // namespace
 
@@ -591,15 +921,23 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     // the sweep is one latency chain per lane whatever the number of active lanes: spread the batch over the CUs
     const int spread = (B + 255) / 256;
     if (ppw > spread) ppw = spread < 1 ? 1 : spread;
+    // the wave-per-problem kernel runs one problem per wave of a 256-thread workgroup
+    const bool wave_wanted = o.lq_kernel != 1 && (o.lq_kernel == 2 || nx * (nx + nu) >= 12);
+    if (wave_wanted && ppw > 4) ppw = 4;
     a.use_lds = ppw >= 1;
     a.ppw = ppw;
     a.lds_stride = per_problem;
     const size_t lds_need = a.use_lds ? (size_t)ppw * per_problem * sizeof(T) : 0;
     a.tol_g = o.tol_constraint; a.tol_step = o.tol_step; a.mu_min = has_bounds ? o.mu_min : 0.0; a.mu_factor = o.mu_factor;
     auto lqk = (nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1> : ((nx == 6 && nu == 3) ? solver_lq_kernel<T, 6, 3> : solver_lq_kernel<T, 0, 0>);
-    if (a.use_lds && lds_need > 65536)
-        NEMPC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(lqk),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_need));
+    // wave-per-problem sweep when the working set is staged in LDS and a stage has enough entries to spread over a
+    // wave: 6/3 stages 6.5 k vs 5.0 k MPC solves/s at C3; 2/1 stages are 4 entries wide and stay on the
+    // thread-per-problem kernel (22.0 vs 23.1 ms per 40 iterations at C2).  nempc_solver_opts.lq_kernel forces one.
+    const bool lq_wave = a.use_lds && wave_wanted;
+    if (lq_wave)
+        lqk = (nx == 2 && nu == 1) ? solver_lqw_kernel<T, 2, 1>
+                                   : ((nx == 6 && nu == 3) ? solver_lqw_kernel<T, 6, 3> : solver_lqw_kernel<T, 0, 0>);
+    NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lqk), lds_need));
 
     int it = 0, rc;
     const int check = o.check_every > 0 ? o.check_every : 4;

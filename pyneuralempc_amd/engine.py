@@ -321,10 +321,11 @@ class CallbackEngine:
         return res
 
     def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=100, max_linesearch=6, check_every=2,
-              tol_constraint=1e-8, tol_step=1e-8, mu_init=1e-1, mu_min=1e-9, mu_factor=0.2, reg=1e-9):
+              tol_constraint=1e-8, tol_step=1e-8, mu_init=1e-1, mu_min=1e-9, mu_factor=0.2, reg=1e-9, lq_kernel="auto"):
         """Batched on-device solve (Gauss-Newton SQP, see csrc/solver.hip).  X0 (B,nx) device tensor; Z_init (B,n)
         or None for the reference's cold start [x0 tiled H ; zeros] (optimizer/ipopt.py:149); lb/ub (n) host
-        vectors as DomainConstraint produces them.  Returns (Z (B,n), status (B,) int32 [0 ok / 1 fail], iters)."""
+        vectors as DomainConstraint produces them; lq_kernel picks the Riccati sweep ("auto" | "thread" per problem | "wave"
+        per problem).  Returns (Z (B,n), status (B,) int32 [0 ok / 1 fail], iters)."""
         B = int(X0.shape[0])
         self._check_in(X0, (B, self.nx), "X0")
         self.reserve(B)
@@ -343,6 +344,7 @@ class CallbackEngine:
                 keep.append(a)
                 ptrs.append(p)
         opts = _lib.NempcSolverOpts(max_iter=max_iter, max_linesearch=max_linesearch, check_every=check_every,
+                                    lq_kernel={"auto": 0, "thread": 1, "wave": 2}[lq_kernel],
                                     tol_constraint=tol_constraint, tol_step=tol_step, mu_init=mu_init, mu_min=mu_min,
                                     mu_factor=mu_factor, reg=reg)
         status = torch.empty(B, dtype=torch.int32, device=self.device)

@@ -140,3 +140,27 @@ def test_next_batch_turns_box_state_rows_into_state_bounds():
         def get_dim(self, H): return H
     with pytest.raises(NotImplementedError):
         controller([-5.0, 5.0], [Rows()]).next_batch(X0)
+
+
+@pytest.mark.parametrize("dims", [(2, 1, [32, 32], 10, orc.DISCRET, 1.0), (3, 2, [24], 7, orc.DISCRET, 1.0),
+                                  (6, 3, [32, 32], 8, orc.RK4, 0.1)])
+def test_riccati_sweep_per_thread_and_per_wave_agree(dims):
+    """The two LQ kernels evaluate the same recursion in the same order: identical iterates, statuses and iteration
+    counts on bounded problems (compile-time 2/1 and 6/3 instantiations and the runtime-dimension one)."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, hidden, H, kind, DT = dims
+    B = 9
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=5)
+    net.W[-1] *= 0.2
+    net.b[-1] *= 0.2
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator={0: "discret", 2: "rk4"}[kind], DT=DT, device="cuda:0",
+                         max_batch=B)
+    X0 = eng.to_device(np.random.default_rng(2).uniform(-0.8, 0.8, size=(B, nx)))
+    lb = np.concatenate([np.full(H * nx, -2.0), np.full(H * nu, -0.3)])
+    out = {k: eng.solve(X0, lb=lb, ub=-lb, max_iter=60, lq_kernel=k) for k in ("thread", "wave", "auto")}
+    Zt, st, it = out["thread"]
+    Zw, sw, iw = out["wave"]
+    assert it == iw and torch.equal(st, sw)
+    np.testing.assert_allclose(Zw.cpu().numpy(), Zt.cpu().numpy(), rtol=0, atol=1e-12)
+    assert torch.equal(out["auto"][0], Zw if nx * (nx + nu) >= 12 else Zt)
+    assert int((st == 0).sum()) >= B - 2
