@@ -565,9 +565,9 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                     // kv = -Quu^-1 qu ; K = -Quu^-1 Qux: one right-hand side per lane (lane 0: qu, lane 1+col: Qux[:,col]);
                     // the substitution runs in a per-lane strip of the du scratch (nu entries per column)
                     const int ncolK = t > 0 ? nx : 0;
-                    if (lane <= ncolK) {
-                        const int col = lane - 1;
-                        T* y = tb + oflag + 1 + lane * nu;     // per-column work vector
+                    for (int c1 = lane; c1 <= ncolK; c1 += 64) {
+                        const int col = c1 - 1;
+                        T* y = tb + oflag + 1 + c1 * nu;       // per-column work vector
                         for (int i = 0; i < nu; ++i) {
                             T v = (col < 0) ? tb[oqu + i] : tb[oQux + i * nx + col];
                             for (int k = 0; k < i; ++k) v -= tb[oQuu + i * nu + k] * y[k];
