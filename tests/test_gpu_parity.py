@@ -400,3 +400,27 @@ def test_shapes_outside_the_matrix_core_kernels(hidden):
     with pytest.raises(ValueError, match="at most"):
         deep = orc.MLP.random(nx + nu, [4] * 8, nx, seed=1)
         CallbackEngine(deep.W, deep.b, H, nx, nu, device="cuda:0")
+
+
+def test_two_handles_on_two_streams():
+    """One handle per stream (nempc.h: a handle is not re-entrant): two engines with different networks evaluated
+    concurrently on their own HIP streams give the same numbers as when run alone."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, H, B = 2, 1, 20, 200
+    nets = [orc.MLP.random(nx + nu, [64, 64], nx, seed=s) for s in (1, 2)]
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=4)
+    engs = [CallbackEngine(n.W, n.b, H, nx, nu, device="cuda:0", max_batch=B) for n in nets]
+    Z, X0 = engs[0].to_device(Zh), engs[0].to_device(X0h)
+    alone = [{k: v.clone() for k, v in e.eval(Z, X0).items()} for e in engs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in engs]
+    outs = [None, None]
+    for rep in range(20):
+        for i, (e, st) in enumerate(zip(engs, streams)):
+            with torch.cuda.stream(st):
+                outs[i] = e.eval(Z, X0)
+    torch.cuda.synchronize()
+    for i in range(2):
+        for k in alone[i]:
+            assert torch.equal(outs[i][k], alone[i][k]), (i, k)
+    assert not torch.equal(outs[0]["g"], outs[1]["g"])
