@@ -424,3 +424,16 @@ def test_two_handles_on_two_streams():
         for k in alone[i]:
             assert torch.equal(outs[i][k], alone[i][k]), (i, k)
     assert not torch.equal(outs[0]["g"], outs[1]["g"])
+
+
+@pytest.mark.parametrize("kernel", ["mfma", "mfma_tile", "valu"])
+@pytest.mark.parametrize("name", ["c2_discret", "c5_box", "tvp_p_discret"])
+def test_golden_hessian_fp32(name, kernel):
+    """fp32 Lagrangian Hessian (cooperative, wave-per-tile and generic kernels) within 1e-4 of the fp64 golden."""
+    d, W, b = load_case(name)
+    eng = _engine(d, W, b, torch.float32, kernel)
+    out = eng.hess(eng.to_device(d["Z"]), eng.to_device(d["X0"]), eng.to_device(d["lam"]), eng.to_device(d["sigma"]),
+                   want=("hdense",))
+    hd = out["hdense"].cpu().numpy().astype(np.float64)
+    _f32_close(hd, d["hdense"], f"{name}/{kernel}/hdense")
+    assert np.array_equal(hd, np.transpose(hd, (0, 2, 1)))
