@@ -67,8 +67,9 @@ extern "C" {
 /* row-kernel implementation */
 #define NEMPC_KERNEL_AUTO 0
 #define NEMPC_KERNEL_VALU 1 /* generic thread-per-row kernel, any dims */
-#define NEMPC_KERNEL_MFMA 2 /* matrix-core kernels, padded hidden width in {32,64,128}, <=3 hidden layers:
-                               CU-cooperative kernel when the packed weights fit in LDS, else wave-per-tile */
+#define NEMPC_KERNEL_MFMA 2 /* matrix-core kernels, padded hidden width in {32,64,128}, <=3 hidden layers, nx <= 16,
+                               network inputs w*(nx+nu)+n_extra <= 32: CU-cooperative kernel when the weight slices
+                               fit the registers and the inputs <= 16, else wave-per-tile */
 #define NEMPC_KERNEL_MFMA_TILE 3 /* force the wave-per-tile matrix-core kernel (A/B measurements) */
 
 typedef struct nempc_handle_s* nempc_handle;

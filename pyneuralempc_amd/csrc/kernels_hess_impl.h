@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
         // ---- forward values
         V4 S1[NH][MT];  // holds a_l first, then 1 - a_l^2
         {
-            T xin[4];
+            T xin[kMaxKs];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < kMaxKs; ++ks) {
                 const int d = 4 * ks + q;
                 xin[ks] = (ks < p.ks && d < nin) ? s_xi0[c * nin + d]
                                                   : ((ks < p.ks && d < nin + p.ne) ? s_ex[c * p.ne + (d - nin)] : T(0));
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
                 for (int r = 0; r < 4; ++r) S1[0][mo][r] = bias[(mo * 4 + r) * 4 + q];
             const T* w = wsrc + p.off.w0f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < kMaxKs; ++ks) {
                 if (ks < p.ks) {
 #pragma unroll
                     for (int mo = 0; mo < MT; ++mo) S1[0][mo] = Ops::mma(w[(ks * MT + mo) * 64 + lane], xin[ks], S1[0][mo]);
@@ -205,12 +205,24 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) dcz[mt] = S1[l - 1][mt] * ddl[mt] + E[l - 1][mt] * da[l - 1][mt];
             }
-            V4 hcol[1] = {V4{T(0), T(0), T(0), T(0)}};
-            layer_mma<T, MT, 1, WLDS>(wsrc + p.off.w0b, lane, dcz, hcol);
+            if (p.mb == 1) {
+                V4 hcol[1] = {V4{T(0), T(0), T(0), T(0)}};
+                layer_mma<T, MT, 1, WLDS>(wsrc + p.off.w0b, lane, dcz, hcol);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int d = Ops::row(q, r);
-                if (d < nin) s_H[(c * nin + pd) * nin + d] = hcol[0][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int d = Ops::row(q, r);
+                    if (d < nin) s_H[(c * nin + pd) * nin + d] = hcol[0][r];
+                }
+            } else {   // 17..32 network inputs
+                V4 hcol[2] = {V4{T(0), T(0), T(0), T(0)}, V4{T(0), T(0), T(0), T(0)}};
+                layer_mma<T, MT, 2, WLDS>(wsrc + p.off.w0b, lane, dcz, hcol);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int d = 16 * mb + Ops::row(q, r);
+                        if (d < nin) s_H[(c * nin + pd) * nin + d] = hcol[mb][r];
+                    }
             }
         }
         wave_sync();

@@ -25,7 +25,7 @@ MfmaOffsets make_offsets(int wp, int nh, int ks, int nx, int nin) {
     for (int l = 1; l < nh; ++l) { o.wf[l] = p; p += MT * MT * 4 * 64; }
     o.wLf = p; p += MT * 4 * 64;
     for (int l = 1; l < nh; ++l) { o.wb[l] = p; p += MT * MT * 4 * 64; }
-    o.w0b = p; p += MT * 4 * 64;
+    o.w0b = p; p += MT * 4 * 64 * ((nin + 15) / 16);   // one fragment set per 16-row block of the input dimension
     o.p0tab = p; p += nin * MT * 16;
     o.wLb = p; p += ((nx + 3) / 4) * MT * 64;
     o.seed = p; p += nx * MT * 16;
@@ -47,7 +47,9 @@ int scratch_elems(const Handle& h) {
 bool mfma_supported(const Handle& h) {
     const int nh = h.nl - 1;
     if (nh < 1 || nh > 3) return false;
-    if (h.cfg.nx > 16 || h.nin + h.ne > 16) return false;
+    // network outputs on one 16-row block; inputs (window + extras) on up to kMaxKs k-steps, the window itself on up
+    // to two 16-row blocks of the last reverse step (wave-per-tile kernels; the cooperative ones take <= 16)
+    if (h.cfg.nx > 16 || h.nin + h.ne > 4 * kMaxKs || h.nin > 32) return false;
     return padded_width(h) != 0;
 }
 
@@ -66,6 +68,7 @@ int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b)
     const bool f64 = h.cfg.dtype == NEMPC_F64;
     auto row = [&](int q, int r) { return f64 ? MfmaOps<double>::row(q, r) : MfmaOps<float>::row(q, r); };
     const MfmaOffsets o = make_offsets(wp, nh, ks, nx, nin);
+    const int MB = (nin + 15) / 16;
     std::vector<double> blob((size_t)o.total, 0.0);
     auto Wat = [&](int l, int i, int j) -> double {
         return (i < h.din[l] && j < h.dout[l]) ? W[l][(size_t)i * h.dout[l] + j] : 0.0;
@@ -83,7 +86,8 @@ int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b)
                         blob[o.wb[l] + ((mt * 4 + r) * MT + mo) * 64 + lane] = Wat(l, 16 * mo + i16, kf);
                     }
                 blob[o.wLf + (mt * 4 + r) * 64 + lane] = (i16 < nx) ? Wat(L, kf, i16) : 0.0;
-                blob[o.w0b + (mt * 4 + r) * 64 + lane] = (i16 < nin) ? Wat(0, i16, kf) : 0.0;
+                for (int mb = 0; mb < MB; ++mb)
+                    blob[o.w0b + ((mt * 4 + r) * MB + mb) * 64 + lane] = (16 * mb + i16 < nin) ? Wat(0, 16 * mb + i16, kf) : 0.0;
             }
     }
     for (int lane = 0; lane < 64; ++lane) {   // W_L as an A operand with M = hidden unit, K = network output
@@ -135,7 +139,7 @@ int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, voi
     }
     MfmaParams p{};
     p.blob = h.mfma.blob;
-    p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4;
+    p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4; p.mb = (h.nin + 15) / 16;
     p.ne = h.ne; p.extra = h.d_extra;
     p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin);
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
@@ -163,7 +167,7 @@ int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, 
     HessParams hp{};
     MfmaParams& p = hp.base;
     p.blob = h.mfma.blob;
-    p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4;
+    p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4; p.mb = (h.nin + 15) / 16;
     p.ne = h.ne; p.extra = h.d_extra;
     p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin);
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;

@@ -24,6 +24,8 @@
 
 namespace nempc {
 
+constexpr int kMaxKs = 8;   // first-layer k-steps: network inputs (window + extras) up to 32
+
 struct MfmaOffsets {  // element offsets into the packed blob
     int w0f, wLf, w0b, seed, biasL;
     int p0tab, wLb;  // Hessian kernel tables: first-layer rows W_0[p,:], output-layer fragments for W_L lambda
@@ -34,7 +36,8 @@ struct MfmaOffsets {  // element offsets into the packed blob
 struct MfmaParams {
     const void* blob;
     MfmaOffsets off;
-    int nx, nu, nin, ks;  // ks = padded-input k-steps (ceil((nin+ne)/4))
+    int nx, nu, nin, ks;  // ks = padded-input k-steps (ceil((nin+ne)/4)) <= kMaxKs
+    int mb;               // 16-row blocks of the input dimension in the last reverse step: ceil(nin/16), 1 or 2
     int ne;               // extra network inputs per row (tvp, p); no Jacobian columns
     const void* extra;    // (B,H,ne) or null
     int kind;
@@ -279,9 +282,9 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
         for (int stage = 0; stage < nstages; ++stage) {
             const T cdt = (stage == 0) ? T(0) : ((stage == 3) ? DT : T(0.5) * DT);
             // ---- B operand of the first layer: xin[ks] = xi[4ks+q] of row c
-            T xin[4];
+            T xin[kMaxKs];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
+            for (int ks = 0; ks < kMaxKs; ++ks) {
                 const int d = 4 * ks + q;
                 T v = T(0);
                 if (ks < p.ks && d < nin) {
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
                     for (int r = 0; r < 4; ++r) a[0][mo][r] = bias[(mo * 4 + r) * 4 + q];
                 const T* w = wsrc + p.off.w0f;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
+                for (int ks = 0; ks < kMaxKs; ++ks) {
                     if (ks < p.ks) {
 #pragma unroll
                         for (int mo = 0; mo < MT; ++mo)
@@ -372,13 +375,25 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
 #pragma unroll
                     for (int mo = 0; mo < MT; ++mo) cv[mo] = cn[mo] * a[l - 1][mo];
                 }
-                V4 jk1[1] = {V4{T(0), T(0), T(0), T(0)}};
-                layer_mma<T, MT, 1, WLDS>(wsrc + p.off.w0b, lane, cv, jk1);
-                const V4 jk = jk1[0];
+                if (p.mb == 1) {
+                    V4 jk1[1] = {V4{T(0), T(0), T(0), T(0)}};
+                    layer_mma<T, MT, 1, WLDS>(wsrc + p.off.w0b, lane, cv, jk1);
+                    const V4 jk = jk1[0];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int d = Ops::row(q, r);
-                    if (d < nin) s_J[(c * nx + k) * nin + d] = jk[r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int d = Ops::row(q, r);
+                        if (d < nin) s_J[(c * nx + k) * nin + d] = jk[r];
+                    }
+                } else {   // 17..32 network inputs: two 16-row blocks of the input dimension
+                    V4 jk2[2] = {V4{T(0), T(0), T(0), T(0)}, V4{T(0), T(0), T(0), T(0)}};
+                    layer_mma<T, MT, 2, WLDS>(wsrc + p.off.w0b, lane, cv, jk2);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int d = 16 * mb + Ops::row(q, r);
+                            if (d < nin) s_J[(c * nx + k) * nin + d] = jk2[mb][r];
+                        }
                 }
             }
             wave_sync();

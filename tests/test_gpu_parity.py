@@ -97,7 +97,7 @@ def test_golden_hessian_fp64(name, kernel):
 
 
 @pytest.mark.parametrize("cfg", [(6, 3, [128, 128, 128], 30, 7), (3, 2, [48, 32], 7, 5), (12, 4, [96, 96], 4, 3),
-                                 (2, 1, [64, 64], 50, 40)])
+                                 (2, 1, [64, 64], 50, 40), (12, 9, [64, 64], 3, 6), (16, 16, [32], 2, 3)])
 def test_hessian_against_oracle_seeded(cfg):
     """Lagrangian-Hessian blocks of the matrix-core kernel vs the oracle (which carries no golden for these
     shapes: the reference's own integrator Hessian only exists for nx+nu = 3) and vs the generic kernel."""
@@ -178,7 +178,9 @@ def test_rk4_hessian_fp32_c3_dims():
     (4, 2, [32], 3, orc.UNITY, 1.0, None, 11),
     (3, 2, [48, 32], 7, orc.RK4, 0.05, None, 13),
     (1, 1, [20, 20, 20], 5, orc.DISCRET, 1.0, None, 7),
-    (16, 1, [64], 2, orc.DISCRET, 1.0, None, 3),     # nx at the MFMA-path limit... nin = 17 -> VALU only
+    (16, 1, [64], 2, orc.DISCRET, 1.0, None, 3),     # nx at the MFMA-path limit, nin = 17: two input blocks (tile kernel)
+    (10, 9, [64, 64], 3, orc.RK4, 0.1, None, 4),      # nin = 19, RK4 chain on two input blocks
+    (16, 16, [32], 2, orc.UNITY, 1.0, None, 2),       # nin = 32: widest matrix-core shape
     (12, 4, [96, 96], 4, orc.RK4, 0.2, None, 3),      # nin = 16: MFMA-path limit
 ])
 def test_against_oracle_seeded_fp64(cfg, kernel):
@@ -191,7 +193,7 @@ def test_against_oracle_seeded_fp64(cfg, kernel):
         eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=KIND_NAME[kind], DT=DT, dtype=torch.float64,
                              device="cuda:0", max_batch=B, kernel=kernel)
     except NempcError:
-        assert kernel.startswith("mfma") and nx + nu > 16   # documented shape gate of the matrix-core kernel
+        assert kernel.startswith("mfma") and nx + nu > 32   # documented shape gate of the matrix-core kernels
         return
     if box is not None:
         eng.set_box_rows(*box)

@@ -19,7 +19,7 @@ ALL = ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")
 def _kernels(d):
     tw = int(d["window"]) * (int(d["nx"]) + int(d["nu"]))
     ex = case_extra(d)
-    fits = tw + (0 if ex is None else ex.shape[1]) <= 16
+    fits = tw + (0 if ex is None else ex.shape[1]) <= 32 and tw <= 32     # matrix-core kernels: up to 32 network inputs
     return ["valu", "mfma", "mfma_tile"] if fits else ["valu"]
 
 
@@ -114,7 +114,7 @@ def test_rolling_seeded_batches_against_oracle(cfg):
     Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=5)
     lamh = rng.normal(size=(B, H * nx))
     sigh = rng.uniform(0.0, 2.0, size=B)
-    kernels = ["valu", "mfma"] if tw <= 16 else ["valu"]
+    kernels = ["valu", "mfma"] if tw <= 32 else ["valu"]
     for kernel in kernels:
         eng = CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B, kernel=kernel,
                              rolling_window=w, forward_rolling=fwd)
