@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define NEMPC_ABI_VERSION 3
+#define NEMPC_ABI_VERSION 4
 #define NEMPC_MAX_LAYERS 8 /* dense layers incl. the linear output layer */
 
 /* status codes */
@@ -107,6 +107,11 @@ int nempc_set_weights(nempc_handle h, const double* const* W, const double* cons
  * Q NULL = identity, R NULL = 0.1*identity, the SURVEY 8(d) defaults). Host doubles. */
 int nempc_set_objective(nempc_handle h, const double* Q, const double* R, const double* xref,
                         const double* uref, const double* cx, const double* cu);
+
+/* terminal cost: the last step's state term uses QT (nx,nx) instead of Q,
+ *   ... + (x_{H-1}-xref_{H-1})^T QT (x_{H-1}-xref_{H-1});   NULL = back to Q.  Kept across nempc_set_objective calls.
+ * (A member of the same family: JAXObjectifFunc takes any function of the whole trajectory, objective/jax.py:28-33.) */
+int nempc_set_terminal_weight(nempc_handle h, const double* QT);
 
 /* bind the extra network inputs for subsequent nempc_eval / nempc_hess / nempc_solve calls: E (B,H,n_extra) device,
  * dtype of the handle, row t of problem b = [tvp_t ; p] (time-varying parameters then constant parameters, the

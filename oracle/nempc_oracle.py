@@ -244,7 +244,8 @@ class Problem:
     """
 
     def __init__(self, net, H, nx, nu, kind=DISCRET, DT=1.0, Q=None, R=None, xref=None, uref=None,
-                 cx=None, cu=None, box=None, extra=None, window=1, forward_rolling=True, hist_x=None, hist_u=None):
+                 cx=None, cu=None, box=None, extra=None, window=1, forward_rolling=True, hist_x=None, hist_u=None,
+                 QT=None):
         self.extra = None if extra is None else np.asarray(extra, dtype=np.float64).reshape(H, -1)
         # rolling-window models (model/tensorflow.py:132, model/jax.py:93): tile width tw = window*(nx+nu)
         self.window, self.forward_rolling = int(window), bool(forward_rolling)
@@ -257,6 +258,8 @@ class Problem:
         self.n = H * (nx + nu)
         self.Q = np.eye(nx) if Q is None else np.asarray(Q, dtype=np.float64).reshape(nx, nx)
         self.R = 0.1 * np.eye(nu) if R is None else np.asarray(R, dtype=np.float64).reshape(nu, nu)
+        # terminal cost: the last step's state weight (a member of the same family; None = Q)
+        self.QT = self.Q if QT is None else np.asarray(QT, dtype=np.float64).reshape(nx, nx)
 
         def _tv(v, d):
             if v is None:
@@ -282,12 +285,13 @@ class Problem:
     def objective(self, z):
         x, u = self.split(z)
         dx, du = x - self.xref, u - self.uref
-        return float(np.einsum("ti,ij,tj->", dx, self.Q, dx) + np.einsum("ti,ij,tj->", du, self.R, du)
-                     + np.sum(self.cx * x) + np.sum(self.cu * u))
+        return float(np.einsum("ti,ij,tj->", dx[:-1], self.Q, dx[:-1]) + dx[-1] @ self.QT @ dx[-1]
+                     + np.einsum("ti,ij,tj->", du, self.R, du) + np.sum(self.cx * x) + np.sum(self.cu * u))
 
     def gradient(self, z):
         x, u = self.split(z)
         gx = (x - self.xref) @ (self.Q + self.Q.T).T + self.cx
+        gx[-1] = (x[-1] - self.xref[-1]) @ (self.QT + self.QT.T).T + self.cx[-1]
         gu = (u - self.uref) @ (self.R + self.R.T).T + self.cu
         return np.concatenate([gx.ravel(), gu.ravel()])
 
@@ -295,7 +299,8 @@ class Problem:
         n, H, nx, nu = self.n, self.H, self.nx, self.nu
         Hm = np.zeros((n, n))
         for t in range(H):
-            Hm[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx] = self.Q + self.Q.T
+            Qt = self.QT if t == H - 1 else self.Q
+            Hm[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx] = Qt + Qt.T
             o = H * nx + t * nu
             Hm[o:o + nu, o:o + nu] = self.R + self.R.T
         return Hm

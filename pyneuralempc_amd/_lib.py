@@ -6,7 +6,7 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libnempc.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LAYERS = 8
 F64, F32 = 0, 1
 DISCRET, UNITY, RK4 = 0, 1, 2
@@ -14,7 +14,7 @@ KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_TILE = 0, 1, 2, 3
 KERNEL_NAMES = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA, "mfma_tile": KERNEL_MFMA_TILE}
 INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
 
-EXPORTS = ["nempc_create", "nempc_destroy", "nempc_set_weights", "nempc_set_objective", "nempc_set_box_rows", "nempc_bind_extra", "nempc_bind_history",
+EXPORTS = ["nempc_create", "nempc_destroy", "nempc_set_weights", "nempc_set_objective", "nempc_set_terminal_weight", "nempc_set_box_rows", "nempc_bind_extra", "nempc_bind_history",
            "nempc_dims", "nempc_constraint_bounds", "nempc_jac_structure", "nempc_hess_structure", "nempc_eval",
            "nempc_hess", "nempc_solve", "nempc_sync", "nempc_kernel_variant", "nempc_last_row_kernel", "nempc_last_error", "nempc_abi_version"]
 
@@ -59,6 +59,7 @@ def load():
     lib.nempc_destroy.argtypes = [vp]
     lib.nempc_set_weights.argtypes = [vp, dpp, dpp]
     lib.nempc_set_objective.argtypes = [vp, dp, dp, dp, dp, dp, dp]
+    lib.nempc_set_terminal_weight.argtypes = [vp, dp]
     lib.nempc_set_box_rows.argtypes = [vp, ctypes.c_int, dp, dp]
     lib.nempc_bind_extra.argtypes = [vp, vp]
     lib.nempc_bind_history.argtypes = [vp, vp, vp]

@@ -26,10 +26,13 @@ __device__ __forceinline__ void objective_body(int b, int lane, int H, int nx, i
                                                T* __restrict__ f, T* __restrict__ grad) {
     const int n = H * (nx + nu);
     const T* z = Z + (size_t)b * n;
-    const T *Q = P + o.Q, *Qs = P + o.Qs, *Rm = P + o.R, *Rs = P + o.Rs;
+    const T *Rm = P + o.R, *Rs = P + o.Rs;
     const T *xref = P + o.xref, *uref = P + o.uref, *cx = P + o.cx, *cu = P + o.cu;
     double acc = 0.0;
     for (int t = lane; t < H; t += 64) {
+        // the last step may carry its own state weight (terminal cost)
+        const T* Q = t == H - 1 ? P + o.QT : P + o.Q;
+        const T* Qs = t == H - 1 ? P + o.QTs : P + o.Qs;
         const T* x = z + t * nx;
         const T* u = z + H * nx + t * nu;
         for (int i = 0; i < nx; ++i) {

@@ -101,10 +101,6 @@ int window_var(const Handle& h, int t, int d) {
     return tau >= 0 ? H * nx + tau * nu + c : -1;
 }
 
-struct ObjHost {
-    std::vector<double> Q, R, xref, uref, cx, cu;
-};
-
 int rebuild_structure(Handle& h) {
     const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu, nin = h.nin, n = h.n;
     h.m = H * nx + (h.box ? H * nx : 0);
@@ -150,12 +146,17 @@ int rebuild_structure(Handle& h) {
     return NEMPC_OK;
 }
 
-int upload_objective(Handle& h, const ObjHost& o) {
+int upload_objective(Handle& h, const ObjHost& o_in) {
+    h.obj_host = o_in;
+    const ObjHost& o = h.obj_host;
     const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu, n = h.n;
     ObjOffsets off = obj_offsets(H, nx, nu);
-    std::vector<double> Qs(nx * nx), Rs(nu * nu);
+    std::vector<double> Qs(nx * nx), Rs(nu * nu), QT(h.obj_QT.empty() ? o.Q : h.obj_QT), QTs(nx * nx);
     for (int i = 0; i < nx; ++i)
-        for (int j = 0; j < nx; ++j) Qs[i * nx + j] = o.Q[i * nx + j] + o.Q[j * nx + i];
+        for (int j = 0; j < nx; ++j) {
+            Qs[i * nx + j] = o.Q[i * nx + j] + o.Q[j * nx + i];
+            QTs[i * nx + j] = QT[i * nx + j] + QT[j * nx + i];
+        }
     for (int i = 0; i < nu; ++i)
         for (int j = 0; j < nu; ++j) Rs[i * nu + j] = o.R[i * nu + j] + o.R[j * nu + i];
 
@@ -174,7 +175,10 @@ int upload_objective(Handle& h, const ObjHost& o) {
     auto obj_const = [&](int r, int c, bool* structural) -> double {
         *structural = false;
         const bool rx = r < H * nx, cx = c < H * nx;
-        if (rx && cx && r / nx == c / nx) { *structural = true; return Qs[(r % nx) * nx + (c % nx)]; }
+        if (rx && cx && r / nx == c / nx) {
+            *structural = true;
+            return (r / nx == H - 1 ? QTs : Qs)[(r % nx) * nx + (c % nx)];
+        }
         if (!rx && !cx && (r - H * nx) / nu == (c - H * nx) / nu) {
             *structural = true;
             return Rs[((r - H * nx) % nu) * nu + ((c - H * nx) % nu)];
@@ -209,6 +213,8 @@ int upload_objective(Handle& h, const ObjHost& o) {
     std::vector<double> all((size_t)off.total);
     std::copy(o.Q.begin(), o.Q.end(), all.begin() + off.Q);
     std::copy(Qs.begin(), Qs.end(), all.begin() + off.Qs);
+    std::copy(QT.begin(), QT.end(), all.begin() + off.QT);
+    std::copy(QTs.begin(), QTs.end(), all.begin() + off.QTs);
     std::copy(o.R.begin(), o.R.end(), all.begin() + off.R);
     std::copy(Rs.begin(), Rs.end(), all.begin() + off.Rs);
     std::copy(o.xref.begin(), o.xref.end(), all.begin() + off.xref);
@@ -402,6 +408,17 @@ int nempc_set_objective(nempc_handle hh, const double* Q, const double* R, const
     if (cx) o.cx.assign(cx, cx + H * nx);
     if (cu) o.cu.assign(cu, cu + H * nu);
     return upload_objective(h, o);
+}
+
+int nempc_set_terminal_weight(nempc_handle hh, const double* QT) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_set_terminal_weight: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    DeviceGuard dg(h.cfg.device);
+    if (!dg.ok) return fail(NEMPC_EHIP, "nempc_set_terminal_weight: hipSetDevice failed");
+    const int nx = h.cfg.nx;
+    if (QT) h.obj_QT.assign(QT, QT + nx * nx); else h.obj_QT.clear();
+    const ObjHost keep = h.obj_host;
+    return upload_objective(h, keep);
 }
 
 int nempc_bind_extra(nempc_handle hh, const void* E) {

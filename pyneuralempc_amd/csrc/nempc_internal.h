@@ -72,6 +72,10 @@ struct MfmaNet {
     size_t blob_elems = 0;
 };
 
+struct ObjHost {   // host copy of the objective parameters (doubles), re-uploaded whenever one of them changes
+    std::vector<double> Q, R, xref, uref, cx, cu;
+};
+
 struct Handle {
     nempc_config cfg{};
     int n = 0, m = 0, nl = 0;
@@ -104,8 +108,10 @@ struct Handle {
     void* d_b[NEMPC_MAX_LAYERS]{};
     MfmaNet mfma;
 
-    // objective, dtype T: Q, Qs=Q+Q^T, R, Rs, xref, uref, cx, cu (one allocation)
+    // objective, dtype T: Q, Qs=Q+Q^T, R, Rs, xref, uref, cx, cu, QT, QTs (one allocation) + Hessian constants
     void* d_obj = nullptr;
+    ObjHost obj_host;            // last nempc_set_objective arguments (defaults filled in)
+    std::vector<double> obj_QT;  // terminal state weight (host copy; empty = same as Q), nempc_set_terminal_weight
     // bounds (host)
     std::vector<double> box_lo, box_hi;
 
@@ -130,7 +136,7 @@ struct Handle {
 };
 
 struct ObjOffsets {  // element offsets into Handle::d_obj
-    int Q, Qs, R, Rs, xref, uref, cx, cu, total;
+    int Q, Qs, R, Rs, xref, uref, cx, cu, QT, QTs, total;   // QT: weight of the last step (terminal cost), QTs = QT + QT^T
 };
 inline ObjOffsets obj_offsets(int H, int nx, int nu) {
     ObjOffsets o;
@@ -143,6 +149,8 @@ inline ObjOffsets obj_offsets(int H, int nx, int nu) {
     o.uref = p; p += H * nu;
     o.cx = p; p += H * nx;
     o.cu = p; p += H * nu;
+    o.QT = p; p += nx * nx;
+    o.QTs = p; p += nx * nx;
     o.total = p;
     return o;
 }

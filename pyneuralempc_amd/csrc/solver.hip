@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     const T* tl = a.use_lds ? blk + Ltl : (const T*)a.tiles + (size_t)b * H * nx * nin;
     const T* Wb = a.use_lds ? blk + LW : (const T*)a.hblk + (size_t)b * H * nin * nin;
     const T* Qs = (const T*)a.obj + a.oo.Qs;
+    const T* QTs = (const T*)a.obj + a.oo.QTs;
     const T* Rs = (const T*)a.obj + a.oo.Rs;
     const T* lb = (const T*)a.lb;
     const T* ub = (const T*)a.ub;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         T ga = T(0), ha = T(0);
         barrier_terms<T>(z[(H - 1) * nx + i], lb[(H - 1) * nx + i], ub[(H - 1) * nx + i], mu, ga, ha);
         #pragma unroll
-        for (int j = 0; j < nx; ++j) TMP(oP + i * nx + j) = Qs[i * nx + j] + (i == j ? ha : T(0));
+        for (int j = 0; j < nx; ++j) TMP(oP + i * nx + j) = QTs[i * nx + j] + (i == j ? ha : T(0));   // terminal weight
         TMP(op + i) = gr[(H - 1) * nx + i] + ga;
     }
     for (int t = H - 1; t >= 0 && pd; --t) {
@@ -450,6 +451,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
             const T* tl = blk + Ltl;
             const T* Wb = blk + LW;
             const T* Qs = (const T*)a.obj + a.oo.Qs;
+            const T* QTs = (const T*)a.obj + a.oo.QTs;
             const T* Rs = (const T*)a.obj + a.oo.Rs;
             const T* lb = (const T*)a.lb;
             const T* ub = (const T*)a.ub;
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                         const int i = e / nx, j = e - i * nx;
                         T ga = T(0), ha = T(0);
                         if (i == j) barrier_terms<T>(z[(H - 1) * nx + i], lb[(H - 1) * nx + i], ub[(H - 1) * nx + i], mu, ga, ha);
-                        tb[oP + e] = Qs[e] + (i == j ? ha : T(0));
+                        tb[oP + e] = QTs[e] + (i == j ? ha : T(0));   // terminal weight
                     } else {
                         const int i = e - nx * nx;
                         T ga = T(0), ha = T(0);

@@ -145,7 +145,8 @@ class CallbackEngine:
             self.lib.nempc_last_row_kernel(self._handle)]
 
     # ------------------------------------------------------------------ parameters
-    def set_objective(self, Q=None, R=None, xref=None, uref=None, cx=None, cu=None):
+    def set_objective(self, Q=None, R=None, xref=None, uref=None, cx=None, cu=None, QT=None):
+        """Quadratic + linear stage cost; QT (nx,nx) is the state weight of the last step (terminal cost), None = Q."""
         H, nx, nu = self.H, self.nx, self.nu
         keep, ptrs = [], []
         for v, shape in ((Q, (nx, nx)), (R, (nu, nu)), (xref, (H, nx)), (uref, (H, nu)), (cx, (H, nx)),
@@ -157,7 +158,12 @@ class CallbackEngine:
                 keep.append(a)
                 ptrs.append(p)
         _lib.check(self.lib.nempc_set_objective(self._handle, *ptrs))
-        self._objective = dict(Q=Q, R=R, xref=xref, uref=uref, cx=cx, cu=cu)
+        if QT is None:
+            _lib.check(self.lib.nempc_set_terminal_weight(self._handle, None))
+        else:
+            a, pt = _as_c_double(np.asarray(QT, dtype=np.float64).reshape(nx, nx))
+            _lib.check(self.lib.nempc_set_terminal_weight(self._handle, pt))
+        self._objective = dict(Q=Q, R=R, xref=xref, uref=uref, cx=cx, cu=cu, QT=QT)
         self._refresh_dims()
 
     def bind_extra(self, E):

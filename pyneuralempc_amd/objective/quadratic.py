@@ -7,6 +7,8 @@ kernel; the family below covers both objectives the reference's own scripts use
 
     f = sum_t (x_t - xref_t)^T Q (x_t - xref_t) + (u_t - uref_t)^T R (u_t - uref_t)
               + cx_t . x_t + cu_t . u_t
+
+with an optional terminal weight QT replacing Q in the last step (t = H-1).
 """
 import numpy as np
 import torch
@@ -16,9 +18,10 @@ from ..engine import CallbackEngine
 
 
 class QuadraticObjective(ObjectiveFunc):
-    def __init__(self, Q=None, R=None, xref=None, uref=None, cx=None, cu=None, dtype=torch.float64, device="cuda"):
+    def __init__(self, Q=None, R=None, xref=None, uref=None, cx=None, cu=None, QT=None, dtype=torch.float64,
+                 device="cuda"):
         super().__init__()
-        self.params = dict(Q=Q, R=R, xref=xref, uref=uref, cx=cx, cu=cu)
+        self.params = dict(Q=Q, R=R, xref=xref, uref=uref, cx=cx, cu=cu, QT=QT)
         self.dtype, self.device = dtype, device
         self._engines = {}
 
@@ -35,7 +38,9 @@ class QuadraticObjective(ObjectiveFunc):
 
         def tv(v, d):
             return np.zeros((H, d)) if v is None else np.broadcast_to(np.asarray(v, dtype=np.float64), (H, d)).copy()
-        return dict(Q=Q, R=R, xref=tv(p["xref"], nx), uref=tv(p["uref"], nu), cx=tv(p["cx"], nx), cu=tv(p["cu"], nu))
+        QT = None if p.get("QT") is None else np.asarray(p["QT"], dtype=np.float64).reshape(nx, nx)
+        return dict(Q=Q, R=R, xref=tv(p["xref"], nx), uref=tv(p["uref"], nu), cx=tv(p["cx"], nx), cu=tv(p["cu"], nu),
+                    QT=QT)
 
     def _engine(self, H, nx, nu):
         key = (H, nx, nu)

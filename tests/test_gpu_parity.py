@@ -439,3 +439,42 @@ def test_golden_hessian_fp32(name, kernel):
     hd = out["hdense"].cpu().numpy().astype(np.float64)
     _f32_close(hd, d["hdense"], f"{name}/{kernel}/hdense")
     assert np.array_equal(hd, np.transpose(hd, (0, 2, 1)))
+
+
+@pytest.mark.parametrize("kernel", ["mfma", "valu"])
+def test_terminal_weight(kernel):
+    """Terminal cost: the last step's state weight QT in f, grad f, the Lagrangian Hessian and the batched solver."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, H, B = 2, 1, 9, 6
+    net = orc.MLP.random(nx + nu, [32, 32], nx, seed=2)
+    net.W[-1] *= 0.2
+    net.b[-1] *= 0.2
+    rng = np.random.default_rng(5)
+    Q, R, QT = np.eye(nx) + 0.1 * rng.normal(size=(nx, nx)), 0.2 * np.eye(nu), 5.0 * np.eye(nx) + rng.normal(size=(nx, nx))
+    QT = QT @ QT.T / 4.0
+    xref = rng.normal(size=(H, nx)) * 0.2
+    prob = orc.Problem(net, H, nx, nu, orc.DISCRET, Q=Q, R=R, xref=xref, QT=QT)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=3)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, device="cuda:0", max_batch=B, kernel=kernel)
+    eng.set_objective(Q=Q, R=R, xref=xref, QT=QT)
+    res = eng.eval_numpy(Zh, X0h, want=("f", "grad"))
+    np.testing.assert_allclose(res["f"], [prob.objective(z) for z in Zh], **F64)
+    np.testing.assert_allclose(res["grad"], [prob.gradient(z) for z in Zh], **F64)
+    lam = rng.normal(size=(B, prob.m))
+    hd = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lam), eng.to_device(np.full(B, 0.7)),
+                  want=("hdense",))["hdense"].cpu().numpy()
+    for i in range(B):
+        np.testing.assert_allclose(hd[i], prob.lagrangian_hessian(Zh[i], X0h[i], lam[i], 0.7), rtol=1e-11, atol=1e-12)
+    # solver: KKT point of the oracle's problem with the terminal weight
+    Z, st, _ = eng.solve(eng.to_device(X0h), max_iter=80)
+    Z = Z.cpu().numpy()
+    assert int((st == 0).sum().item()) >= B - 1
+    for i in np.nonzero(st.cpu().numpy() == 0)[0][:3]:
+        assert np.abs(prob.constraints(Z[i], X0h[i])).max() < 1e-7
+        J, gr = prob.jacobian(Z[i], X0h[i]), prob.gradient(Z[i])
+        mult = np.linalg.lstsq(J.T, -gr, rcond=None)[0]
+        assert np.abs(gr + J.T @ mult).max() < 1e-5 * max(1.0, np.abs(gr).max())
+    # back to the plain family
+    eng.set_objective(Q=Q, R=R, xref=xref)
+    plain = orc.Problem(net, H, nx, nu, orc.DISCRET, Q=Q, R=R, xref=xref)
+    np.testing.assert_allclose(eng.eval_numpy(Zh, X0h, want=("f",))["f"], [plain.objective(z) for z in Zh], **F64)
