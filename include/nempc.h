@@ -163,8 +163,9 @@ int nempc_hess(nempc_handle h, int32_t B, const void* Z, const void* X0, const v
 /* Batched on-device solver (no reference counterpart: the reference hands ONE problem at a time to Ipopt /
  * SLSQP on the CPU, optimizer/ipopt.py:138-195, slsqp.py:143-197).  Solves the B problems
  *     min f(z)  s.t.  integrator defects = 0,  lb <= z <= ub
- * in lock step by Gauss-Newton SQP: per iterate one callback evaluation, one Riccati (block-tridiagonal KKT)
- * solve per problem, l1-merit backtracking; finite variable bounds through a log barrier.
+ * in lock step by SQP with the exact per-step Lagrangian blocks (Gauss-Newton on the first iterate): per iterate one
+ * callback + Hessian-block evaluation, one regularised Riccati (block-tridiagonal KKT) solve per problem, l1-merit
+ * backtracking on defect-only evaluations; finite variable bounds through a log barrier.
  *   X0 (B,nx) device; Z (B,n) device: initial guess in, solution out; lb/ub (n) HOST doubles (NULL = unbounded,
  *   +-INFINITY allowed; the vectors DomainConstraint.get_lower/upper_bounds produce, constraints.py:26-30);
  *   status (B) device int32 out: 0 converged (Optimizer.SUCCESS), 1 not converged (Optimizer.FAIL);
