@@ -88,7 +88,6 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     auto stage_in = [&](const T* __restrict__ src, int per, int src_stride, int loff) {
         const int tot = np * per;
         const T* base = src + (size_t)b0 * src_stride;
-#pragma unroll 4
         for (int i = lane; i < tot; i += nthr) {
             const int pp = i / per, e = i - pp * per;
             lds[(size_t)pp * a.lds_stride + loff + e] = base[(size_t)pp * src_stride + e];
@@ -400,7 +399,6 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
     auto stage_in = [&](const T* __restrict__ src, int per, int src_stride, int loff) {
         const int tot = np * per;
         const T* base = src + (size_t)b0 * src_stride;
-#pragma unroll 4
         for (int i = tid; i < tot; i += 256) {
             const int pp = i / per, e = i - pp * per;
             lds[(size_t)pp * a.lds_stride + loff + e] = base[(size_t)pp * src_stride + e];
