@@ -52,3 +52,46 @@ def allgather_u0(u0_local, total=None, group=None):
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
     return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
+class EvalPipeline:
+    """Keep several independent batches in flight on one GPU: `depth` handles, each on its own HIP stream, used in
+    rotation.  One evaluation's launch prologue and drain then run under another's full pass -- at C2 dims 35.9 k vs
+    33.2 k batch-evals/s for B=1024 and 88 k vs 53 k for B=256 (bench.py `pipelined_two_streams`).  A handle is not
+    re-entrant, hence one handle per slot; the batches must be independent (different MPC problem sets).
+
+        pipe = EvalPipeline(lambda: CallbackEngine(W, b, H, nx, nu, max_batch=B), depth=2)
+        t0 = pipe.submit(Z0, X00); t1 = pipe.submit(Z1, X01)       # asynchronous
+        out0 = pipe.wait(t0)                                         # dict of device tensors owned by slot 0
+    """
+
+    def __init__(self, make_engine, depth=2):
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.engines = [make_engine() for _ in range(depth)]
+        dev = self.engines[0].device
+        self.streams = [torch.cuda.Stream(dev) for _ in range(depth)]
+        self._next = 0
+
+    def submit(self, Z, X0, want=("f", "grad", "g", "jac_dense")):
+        """Launch on the next slot; returns a ticket.  The slot's output tensors are reused by its next submit, so wait
+        for (and consume) a ticket before `depth` further submits."""
+        i = self._next
+        self._next = (i + 1) % len(self.engines)
+        st = self.streams[i]
+        st.wait_stream(torch.cuda.current_stream(st.device))     # inputs produced on the caller's stream
+        with torch.cuda.stream(st):
+            out = self.engines[i].eval(Z, X0, want)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return (i, out, ev)
+
+    def wait(self, ticket, stream=None):
+        """Make `stream` (default: the current stream) wait for the ticket's evaluation; returns its outputs."""
+        _, out, ev = ticket
+        (stream or torch.cuda.current_stream(self.streams[0].device)).wait_event(ev)
+        return out
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()

@@ -478,3 +478,30 @@ def test_terminal_weight(kernel):
     eng.set_objective(Q=Q, R=R, xref=xref)
     plain = orc.Problem(net, H, nx, nu, orc.DISCRET, Q=Q, R=R, xref=xref)
     np.testing.assert_allclose(eng.eval_numpy(Zh, X0h, want=("f",))["f"], [plain.objective(z) for z in Zh], **F64)
+
+
+def test_eval_pipeline_keeps_independent_batches_in_flight():
+    from pyneuralempc_amd import CallbackEngine
+    from pyneuralempc_amd.parallel import EvalPipeline
+    nx, nu, H, B = 2, 1, 20, 64
+    net = orc.MLP.random(nx + nu, [64, 64], nx, seed=0)
+    make = lambda: CallbackEngine(net.W, net.b, H, nx, nu, device="cuda:0", max_batch=B)
+    ref = make()
+    pipe = EvalPipeline(make, depth=2)
+    batches = [tuple(ref.to_device(a) for a in orc.synthetic_inputs(B, H, nx, nu, seed=10 + k)) for k in range(6)]
+    expect = [{k: v.clone() for k, v in ref.eval(Z, X0).items()} for Z, X0 in batches]
+    tickets = []
+    for k, (Z, X0) in enumerate(batches):
+        if k >= 2:                                   # consume the slot's previous result before reusing it
+            out = pipe.wait(tickets[k - 2])
+            for name in out:
+                assert torch.equal(out[name], expect[k - 2][name])
+        tickets.append(pipe.submit(Z, X0))
+    for k in (4, 5):
+        out = pipe.wait(tickets[k])
+        torch.cuda.current_stream().synchronize()
+        for name in out:
+            assert torch.equal(out[name], expect[k][name])
+    pipe.synchronize()
+    with pytest.raises(ValueError):
+        EvalPipeline(make, depth=0)
