@@ -12,4 +12,5 @@ from . import integrator
 from . import optimizer
 from . import constraints
 from . import controller
+from . import parallel
 from .engine import CallbackEngine
