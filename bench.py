@@ -3,23 +3,28 @@
 "NLP callback evals/sec (f + grad f + g + jac g) at batch x H; Jacobian max-abs error vs CPU").
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus N ...            # spawns N ranks itself (one process per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 One "step" = one batched evaluation of all four callbacks (f, grad f, g, dense jac g) for the B problems
 a rank owns, inputs already resident in HBM.  `value` = problem-evals/s over the whole job
 (= n_gpus * B * steps / wall; one problem-eval = the four callbacks of ONE NLP instance at one iterate);
 `batch_evals_per_s` = value / B per GPU is the north-star reading "evaluations/sec on batch=1024".
-Ranks shard independent problems (weak scaling, no data-path collective); the only exchange is one
-all-gather of the first controls u0 per MPC step, issued once at the end of the timed region.
+Ranks shard independent problems (weak scaling, no data-path collective).  The only exchange is the all-gather of
+the first controls u0, once per MPC step: with N > 1 it is issued INSIDE the timed loop, through libnempc.so's own
+RCCL call (nempc_allgather_u0), once every `--evals-per-mpc-step` evaluations (an MPC step = one NLP solve = that
+many callback evaluations; default 10, the low end of what the batched solver needs).
+
+With `--gpus N > 1` and no WORLD_SIZE in the environment this process only launches the N ranks (before anything
+touches the GPU) and relays rank 0's JSON line; a failed rank makes the exit code non-zero.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
@@ -33,6 +38,10 @@ CONFIGS = {
                     label="configs[1]: batch=256, 2x1 MLP(2x64), H=20, Euler(Discret), fp64"),
     "c3": dict(nx=6, nu=3, hidden=[128, 128, 128], H=30, integrator="rk4", DT=0.1, dtype="f32", batch=1024, box=None,
                label="configs[2]: batch=1024, 6x3 MLP(3x128), H=30, RK4, fp32"),
+    # configs[3]: the C3 problem at a GLOBAL batch of 4096 sharded over the ranks (512 per GPU on 8 GPUs)
+    "c4": dict(nx=6, nu=3, hidden=[128, 128, 128], H=30, integrator="rk4", DT=0.1, dtype="f32", batch=None,
+               global_batch=4096, box=None,
+               label="configs[3]: batch=4096 sharded over the GPUs, 6x3 MLP(3x128), H=30, RK4, fp32, all-gather of u0"),
     "c5": dict(nx=2, nu=1, hidden=[64, 64], H=50, integrator="discret", DT=1.0, dtype="f64", batch=1024,
                box=(-2.0, 2.0), label="configs[4]: batch=1024, H=50, box state rows, dense jac, fp64"),
 }
@@ -40,6 +49,7 @@ CONFIGS = {
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F64_TFLOPS = 78.6         # MI355X FP64 vector = matrix peak (spec); v_mfma_f64_16x16x4_f64 at 32 FLOP/clk/SIMD
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: FP32 matrix (f32-in MFMA) = vector peak
+MALL_BYTES = 256 << 20         # Infinity Cache: an output that fits is not an HBM stream when rewritten in place
 
 
 def algorithmic_work(cfg, B, m, n):
@@ -77,13 +87,18 @@ def usable_cpus():
     return n
 
 
+def oracle_problem(cfg):
+    from oracle import nempc_oracle as orc
+    kind = {"discret": orc.DISCRET, "unity": orc.UNITY, "rk4": orc.RK4}[cfg["integrator"]]
+    net = orc.MLP.random(cfg["nx"] + cfg["nu"], cfg["hidden"], cfg["nx"], seed=0)
+    return net, orc.Problem(net, cfg["H"], cfg["nx"], cfg["nu"], kind, cfg["DT"], box=cfg["box"])
+
+
 def cpu_baseline(cfg, seconds=12.0):
     """C/OpenMP oracle (oracle/nempc_oracle.c) on the host cores this job may use, bounded sample of the same workload."""
     from oracle import nempc_oracle as orc
     from oracle.c_oracle import COracle
-    kind = {"discret": orc.DISCRET, "unity": orc.UNITY, "rk4": orc.RK4}[cfg["integrator"]]
-    net = orc.MLP.random(cfg["nx"] + cfg["nu"], cfg["hidden"], cfg["nx"], seed=0)
-    prob = orc.Problem(net, cfg["H"], cfg["nx"], cfg["nu"], kind, cfg["DT"], box=cfg["box"])
+    _, prob = oracle_problem(cfg)
     Bs = 512
     Z, X0 = orc.synthetic_inputs(Bs, cfg["H"], cfg["nx"], cfg["nu"], seed=1)
     co = COracle(prob)
@@ -106,7 +121,447 @@ def cpu_baseline(cfg, seconds=12.0):
             "sample": f"{reps} x {Bs} problem-evals of the same workload in {dt:.1f}s, C/OpenMP oracle "
                       f"(oracle/nempc_oracle.c) on {nthr} threads; host has {os.cpu_count()} logical cpus, "
                       f"{usable_cpus()} usable by this job (affinity / cgroup quota)",
-            "numpy_reference_shaped_1core": ref_rate}, prob
+            "numpy_reference_shaped_1core": ref_rate}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: `bench.py --gpus N` without a torchrun environment starts the N ranks itself
+# ------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n_gpus, argv):
+    """Start one child per GPU with the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), wait for all,
+    return the worst exit code.  Runs BEFORE this process has made any HIP / torch.cuda call: a process that has
+    touched the GPU must neither fork workers that use it nor be replaced by another program."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    worst = 0
+    deadline = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        codes = [p.poll() for p in procs]
+        if any(c not in (None, 0) for c in codes) and deadline is None:
+            deadline = time.time() + 30.0          # a rank died: give the others a moment, then stop them
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for r, p in enumerate(procs):
+        if p.returncode != 0:
+            print(f"bench.py: rank {r} exited with code {p.returncode}", file=sys.stderr)
+            worst = worst or (p.returncode if p.returncode > 0 else 1)
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------------------------
+class Rank:
+    def __init__(self, args):
+        import numpy as np
+        import torch
+        self.np, self.torch = np, torch
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if args.gpus != self.world:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; launch one rank per GPU "
+                             "(or drop WORLD_SIZE and let bench.py start the ranks)")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device; the product path has no CPU fallback")
+        # one process per GPU; NEMPC_BENCH_BACKEND=gloo is the one-GPU rehearsal mode (ranks share cuda:0, collectives
+        # through gloo) used to exercise this path where only one device exists
+        self.backend = os.environ.get("NEMPC_BENCH_BACKEND", "nccl")
+        ndev = torch.cuda.device_count()
+        if self.backend == "nccl" and self.world > ndev:
+            raise SystemExit(f"bench.py: {self.world} ranks but {ndev} visible GPU(s); RCCL needs one GPU per rank "
+                             "(NEMPC_BENCH_BACKEND=gloo rehearses the rank logic on fewer)")
+        dev_index = local_rank if self.backend == "nccl" else local_rank % max(ndev, 1)
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    # -------------------------------------------------------------------------------------------------------------
+    def make_engine(self, cfg, B, kernel="auto"):
+        from pyneuralempc_amd import CallbackEngine
+        torch = self.torch
+        net, _ = oracle_problem(cfg)                      # weights only: the oracle's generator defines the workload
+        tdtype = torch.float64 if cfg["dtype"] == "f64" else torch.float32
+        eng = CallbackEngine(net.W, net.b, cfg["H"], cfg["nx"], cfg["nu"], integrator=cfg["integrator"], DT=cfg["DT"],
+                             dtype=tdtype, device=self.dev, max_batch=B, kernel=kernel)
+        if cfg["box"] is not None:
+            eng.set_box_rows(*cfg["box"])
+        return eng
+
+    def timed_events(self, fn, reps):
+        """average seconds per call between two HIP events on the launch stream (torch's current stream is the one the
+        engine launches on)"""
+        torch = self.torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn(); torch.cuda.synchronize(self.dev)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(self.dev)
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    def per_step_us(self, fn, reps):
+        """one HIP event pair per evaluation -> (p10, median, p90) in microseconds (SURVEY 8d)"""
+        torch, np = self.torch, self.np
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        fn(); torch.cuda.synchronize(self.dev)
+        evs[0].record()
+        for i in range(reps):
+            fn()
+            evs[i + 1].record()
+        torch.cuda.synchronize(self.dev)
+        d = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(reps)]) * 1e3
+        return [float(np.percentile(d, q)) for q in (10, 50, 90)]
+
+    def check_against_oracle(self, cfg, outs, Zh, X0h):
+        """Max abs error of the outputs the TIMED launch left behind against the CPU oracle on three 16-problem slices
+        (first, middle, last) of the full batch -- no extra launch, the numbers checked are the numbers timed."""
+        np, torch = self.np, self.torch
+        _, prob = oracle_problem(cfg)
+        B = Zh.shape[0]
+        k = min(16, B)
+        starts = sorted({0, max(0, B // 2 - k // 2), B - k})
+        errs = {"f": 0.0, "grad": 0.0, "g": 0.0, "jac": 0.0}
+        scale = {"f": 0.0, "grad": 0.0, "g": 0.0, "jac": 0.0}
+        for s0 in starts:
+            sl = slice(s0, s0 + k)
+            f, grad, g, jac = prob.eval_batch(Zh[sl], X0h[sl])
+            for key, ref, name in (("f", f, "f"), ("grad", grad, "grad"), ("g", g, "g"), ("jac", jac, "jac_dense")):
+                got = outs[name][sl].to("cpu", torch.float64).numpy()
+                errs[key] = max(errs[key], float(np.abs(got - ref).max()))
+                scale[key] = max(scale[key], float(np.abs(ref).max()))
+        return errs, scale, [int(s) for s in starts]
+
+    # -------------------------------------------------------------------------------------------------------------
+    def run_config(self, name, steps, warmup, headline, kernel="auto"):
+        """Time one configuration on this rank.  headline=True: the barrier-bracketed wall-clock loop over all ranks
+        (the driver's contract) -> `value`; False: HIP-event timing only (the other configs of the default run)."""
+        np, torch = self.np, self.torch
+        from oracle import nempc_oracle as orc   # synthetic inputs + checker only (never the thing measured)
+        args = self.args
+        cfg = dict(CONFIGS[name])
+        if cfg.get("global_batch"):
+            if cfg["global_batch"] % self.world:
+                raise SystemExit(f"config {name}: global batch {cfg['global_batch']} does not divide over {self.world} ranks")
+            cfg["batch"] = cfg["global_batch"] // self.world
+        B = (args.batch if headline and args.batch else 0) or cfg["batch"]
+        eng = self.make_engine(cfg, B, kernel)
+        Zh, X0h = orc.synthetic_inputs(B, cfg["H"], cfg["nx"], cfg["nu"], seed=1 + self.rank)
+        Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+        want = ("f", "grad", "g", "jac_dense")
+        H, nx, nu = cfg["H"], cfg["nx"], cfg["nu"]
+        work = algorithmic_work(cfg, B, eng.m, eng.n)
+        w = 8 if cfg["dtype"] == "f64" else 4
+        jac_bytes = B * eng.m * eng.n * w
+
+        step, outs = eng.bind(Z, X0, want)           # one ctypes call per step: keeps the host out of the way
+        gather = None
+        gather_every = max(1, args.evals_per_mpc_step)
+        if self.dist is not None:
+            if self.backend == "nccl":
+                from pyneuralempc_amd.parallel import init_u0_comm
+                init_u0_comm(eng)                     # RCCL communicator owned by the handle (nempc_comm_init)
+                gather = lambda: eng.allgather_u0(Z=Z)                      # noqa: E731  nempc_allgather_u0
+            else:
+                from pyneuralempc_amd.parallel import allgather_u0, first_controls
+                gather = lambda: allgather_u0(first_controls(Z, H, nx, nu), total=self.world * B)   # noqa: E731
+        res = {"cfg": cfg, "B": B, "eng": eng}
+
+        if headline:
+            for i in range(warmup):
+                step()
+                if gather and (i + 1) % gather_every == 0:
+                    gather()
+            if gather:
+                gather()
+            self.barrier()
+            t0 = time.perf_counter()
+            n_gather = 0
+            for i in range(steps):
+                step()
+                if gather and (i + 1) % gather_every == 0:
+                    gathered = gather()
+                    n_gather += 1
+            self.barrier()
+            wall = time.perf_counter() - t0
+            wall = self.max_over_ranks(wall)
+            res["wall"] = wall
+            res["n_gather"] = n_gather
+            if gather and n_gather:
+                assert gathered.shape[0] == self.world * B
+                mine = gathered[self.rank * B:(self.rank + 1) * B]
+                assert torch.equal(mine, Z[:, H * nx:H * nx + nu]), "all-gather returned a wrong shard"
+        else:
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize(self.dev)
+
+        # accuracy of the launch just timed (the metric's second half)
+        errs, scale, starts = self.check_against_oracle(cfg, outs, Zh, X0h)
+        res["errs"], res["err_scale"], res["checked_slices"] = errs, scale, starts
+
+        reps = max(steps, 50)
+        t_rows = self.timed_events(eng.bind(Z, X0, ("g", "jac_tiles"))[0], reps)
+        row_kernel = eng.last_row_kernel
+        step, outs = eng.bind(Z, X0, want)
+        t_all = self.timed_events(step, reps)
+        res.update(t_rows=t_rows, t_all=t_all, row_kernel=row_kernel, work=work)
+        res["step_pcts"] = self.per_step_us(step, reps) if headline else None
+
+        # HBM-bound configs: the dense Jacobian rewritten in place stays in the 256 MB Infinity Cache when it fits.
+        # Rotate over enough output buffers that every store stream is larger than the cache -> an HBM rate.
+        res["t_all_rotating"] = None
+        if jac_bytes * 3 >= MALL_BYTES and jac_bytes >= (32 << 20):
+            nbuf = max(2, -(-2 * MALL_BYTES // jac_bytes))       # ring >= 2x the cache
+            ring = []
+            for _ in range(nbuf):
+                ring.append(eng.bind(Z, X0, want, out={"jac_dense": torch.empty_like(outs["jac_dense"])})[0])
+            k = [0]
+
+            def rot():
+                ring[k[0] % nbuf]()
+                k[0] += 1
+            res["t_all_rotating"] = self.timed_events(rot, reps)
+            res["rotation"] = {"buffers": nbuf, "bytes_each": jac_bytes}
+            del ring
+        return res
+
+    def roofline_of(self, res):
+        """the binding roofline of a configuration: MFMA for the row kernel unless the dense-contract bytes of the whole
+        evaluation sit above the ridge (C5), then HBM over the whole evaluation"""
+        cfg, work = res["cfg"], res["work"]
+        peak_tf = PEAK_F64_TFLOPS if cfg["dtype"] == "f64" else PEAK_F32_TFLOPS
+        ai = work["flops"] / work["dense_bytes"]
+        ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+        t_eval = res["t_all_rotating"] or res["t_all"]
+        mfma = {"bound": "mfma", "kernel": res["row_kernel"], "achieved": work["flops"] / res["t_rows"] / 1e12,
+                "peak": peak_tf, "unit": "TFLOP/s", "frac": work["flops"] / res["t_rows"] / 1e12 / peak_tf,
+                "traffic": None, "kernel_us": res["t_rows"] * 1e6, "flops_per_launch": work["flops"],
+                "arithmetic_intensity_dense": ai, "ridge": ridge}
+        hbm = {"bound": "hbm", "kernel": "whole evaluation (row kernel + post_flat_kernel)",
+               "achieved": work["dense_bytes"] / t_eval / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "frac": work["dense_bytes"] / t_eval / 1e9 / PEAK_HBM_GBS, "traffic": None,
+               "bytes_per_eval_dense_contract": work["dense_bytes"], "eval_us": t_eval * 1e6,
+               "eval_us_in_place": res["t_all"] * 1e6,
+               "note": ("dense Jacobian written to a ring of buffers larger than the 256 MB Infinity Cache"
+                        if res["t_all_rotating"] else "outputs rewritten in place (cache-resident when they fit 256 MB)")}
+        return (hbm, mfma) if ai < ridge else (mfma, hbm)
+
+    # -------------------------------------------------------------------------------------------------------------
+    def solver_leg(self, res):
+        """batched on-device solver + the all-gather of the SOLVED u0; throughput counts converged
+        problems only"""
+        np, torch = self.np, self.torch
+        cfg, B, eng = res["cfg"], res["B"], res["eng"]
+        H, nx, nu = cfg["H"], cfg["nx"], cfg["nu"]
+        lbv = np.concatenate([np.full(H * nx, -3.0), np.full(H * nu, -0.5)])
+        Xs = eng.to_device(np.random.default_rng(100 + self.rank).uniform(-0.5, 0.5, size=(B, nx)))
+        eng.solve(Xs, lb=lbv, ub=-lbv, max_iter=5)   # warm
+        self.barrier()
+        ts = time.perf_counter()
+        Zs, st, its = eng.solve(Xs, lb=lbv, ub=-lbv, max_iter=self.args.solver_iters)
+        torch.cuda.synchronize(self.dev)
+        t_solve = time.perf_counter() - ts
+        tg = time.perf_counter()
+        if eng.comm is not None:
+            allu0 = eng.allgather_u0(Z=Zs)
+        else:
+            from pyneuralempc_amd.parallel import allgather_u0, first_controls
+            allu0 = allgather_u0(first_controls(Zs, H, nx, nu), total=self.world * B)
+        torch.cuda.synchronize(self.dev)
+        t_gather = time.perf_counter() - tg
+        n_ok = self.sum_over_ranks(float((st == 0).sum().item()))
+        t_solve = self.max_over_ranks(t_solve)
+        total = self.world * B
+        return {"mpc_solved_per_s": n_ok / t_solve, "problems_per_s_incl_unconverged": total / t_solve,
+                "iterations": its, "converged_frac": n_ok / total, "solve_ms": t_solve * 1e3,
+                "allgather_u0_us": t_gather * 1e6, "gathered_rows": int(allu0.shape[0]),
+                "allgather_path": "nempc_allgather_u0 (RCCL)" if eng.comm is not None else
+                                  ("torch.distributed/" + self.backend if self.dist is not None else "single rank"),
+                "note": "SQP + Riccati, exact Lagrangian blocks, bounds |x|<=3 |u|<=0.5 via log barrier; "
+                        "mpc_solved_per_s counts status == 0 only"}
+
+    def gather_latency_us(self, res, reps=200):
+        """isolated latency of one u0 all-gather (stream-ordered, HIP events)"""
+        eng, cfg = res["eng"], res["cfg"]
+        if self.dist is None:
+            return None
+        torch = self.torch
+        B = res["B"]
+        Zd = torch.zeros(B, eng.n, dtype=eng.dtype, device=self.dev)
+        if eng.comm is not None:
+            fn = lambda: eng.allgather_u0(Z=Zd)                            # noqa: E731
+        else:
+            from pyneuralempc_amd.parallel import allgather_u0, first_controls
+            fn = lambda: allgather_u0(first_controls(Zd, cfg["H"], cfg["nx"], cfg["nu"]), total=self.world * B)  # noqa: E731
+        self.barrier()
+        t = self.timed_events(fn, reps)
+        return self.max_over_ranks(t) * 1e6
+
+    # -------------------------------------------------------------------------------------------------------------
+    def main(self):
+        np, torch = self.np, self.torch
+        args = self.args
+        res = self.run_config(args.config, args.steps, args.warmup, headline=True, kernel=args.kernel)
+        cfg, B, eng, wall = res["cfg"], res["B"], res["eng"], res["wall"]
+        primary, secondary = self.roofline_of(res)
+        out = {
+            "metric": "nlp_callback_evals_per_sec (f + grad f + g + dense jac g)",
+            "value": self.world * B * args.steps / wall,
+            "unit": "problem-evals/s",
+            "n_gpus": self.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": cfg["dtype"], "data": "synthetic",
+            "config": {"workload": cfg["label"], "batch_per_gpu": B, "H": cfg["H"], "nx": cfg["nx"], "nu": cfg["nu"],
+                       "hidden": cfg["hidden"], "integrator": cfg["integrator"], "n": eng.n, "m": eng.m,
+                       "row_kernel": eng.kernel_variant, "parallelism": f"problem-sharded x{self.world}"},
+            "batch_evals_per_s": args.steps / wall,
+            "jacobian_max_abs_err_vs_cpu": res["errs"]["jac"], "max_abs_err_vs_cpu": res["errs"],
+            "err_checked_on": f"outputs of the timed B={B} launch, problems {res['checked_slices']} (+16 each), rank {self.rank}",
+            "roofline": primary,
+            "roofline_" + secondary["bound"] + ("_whole_eval" if secondary["bound"] == "hbm" else "_row_kernel"): secondary,
+            "eval_us": {"timed_loop": wall / args.steps * 1e6, "event_loop": res["t_all"] * 1e6,
+                        "p10_median_p90": res["step_pcts"]},
+        }
+        if self.dist is not None:
+            out["allgather_u0"] = {
+                "per_mpc_step_every_n_evals": max(1, args.evals_per_mpc_step), "issued_in_timed_loop": res["n_gather"],
+                "path": "nempc_allgather_u0 (libnempc.so -> RCCL ncclAllGather)" if eng.comm is not None
+                        else "torch.distributed/" + self.backend,
+                "latency_us": self.gather_latency_us(res), "rows_gathered": self.world * B}
+        # HBM bytes of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+        pmc_file = os.path.join(REPO, "profiles", args.pmc_file)
+        if args.config == "c2" and B == 1024 and eng.kernel_variant == "mfma" and os.path.exists(pmc_file):
+            pmc = json.load(open(pmc_file))
+            for k, v in pmc.items():
+                if k.startswith(str(res["row_kernel"])) and "hbm_traffic_bytes" in v and out["roofline"]["bound"] == "mfma":
+                    out["roofline"]["traffic"] = v["hbm_traffic_bytes"]
+                    out["roofline"]["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch, profiles/" + args.pmc_file +
+                                                       " (algorithmic: 0.51 MB read, 1.3 MB written)")
+
+        if not args.only_eval:
+            # ---- two independent batches in flight (reported apart; `value` is the single-stream figure)
+            if self.rank == 0:
+                out["pipelined_two_streams"] = self.two_stream_leg(res)
+            # ---- batched solver + all-gather of the solved u0 (collective: every rank)
+            if cfg["box"] is None and (cfg["integrator"] != "rk4" or eng.kernel_variant != "valu"):
+                out["batched_solver"] = self.solver_leg(res)
+            if args.hessian and (cfg["integrator"] != "rk4" or eng.kernel_variant != "valu"):
+                out["hessian_callback"] = self.hessian_leg(res)
+            # ---- the other BASELINE configs under the same clock (HIP events; every rank runs them, rank 0 reports)
+            if args.config == "c2" and not args.batch and not args.no_other_configs:
+                others = {}
+                names = ["c2_b256", "c3", "c5"] + (["c4"] if self.world > 1 else [])
+                for nm in names:
+                    r2 = self.run_config(nm, 50, 5, headline=False)
+                    p2, s2 = self.roofline_of(r2)
+                    c2 = r2["cfg"]
+                    entry = {"workload": c2["label"], "batch_per_gpu": r2["B"], "dtype": c2["dtype"],
+                             "ms_per_step": r2["t_all"] * 1e3,
+                             "batch_evals_per_s_per_gpu": 1.0 / r2["t_all"],
+                             "problem_evals_per_s": self.world * r2["B"] / self.max_over_ranks(r2["t_all"]),
+                             "roofline": p2, "max_abs_err_vs_cpu": r2["errs"], "max_abs_ref": r2["err_scale"],
+                             "checked_slices": r2["checked_slices"]}
+                    if r2["t_all_rotating"]:
+                        entry["ms_per_step_rotating_outputs"] = r2["t_all_rotating"] * 1e3
+                        entry["rotation"] = r2["rotation"]
+                    if nm == "c4":
+                        entry["batched_solver"] = self.solver_leg(r2)
+                    others[nm] = entry
+                    del r2
+                out["other_configs"] = others
+            if self.world == 1 and not args.no_cpu:
+                out["cpu_baseline"] = cpu_baseline(cfg)
+        if self.rank == 0:
+            print(json.dumps(out), flush=True)
+        if self.dist is not None:
+            self.barrier()
+            self.dist.destroy_process_group()
+
+    def two_stream_leg(self, res):
+        torch = self.torch
+        from oracle import nempc_oracle as orc
+        cfg, B, eng = res["cfg"], res["B"], res["eng"]
+        want = ("f", "grad", "g", "jac_dense")
+        eng2 = self.make_engine(cfg, B, self.args.kernel)
+        Zh, X0h = orc.synthetic_inputs(B, cfg["H"], cfg["nx"], cfg["nu"], seed=1 + self.rank)
+        Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+        Zb, X0b = (eng2.to_device(a) for a in orc.synthetic_inputs(B, cfg["H"], cfg["nx"], cfg["nu"], seed=101 + self.rank))
+        sa, sb = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+        with torch.cuda.stream(sa):
+            step_a, _ = eng.bind(Z, X0, want)
+        with torch.cuda.stream(sb):
+            step_b, _ = eng2.bind(Zb, X0b, want)
+        torch.cuda.synchronize(self.dev)
+        for k in range(20):
+            (step_a if k % 2 == 0 else step_b)()
+        torch.cuda.synchronize(self.dev)
+        steps = self.args.steps
+        tp = time.perf_counter()
+        for k in range(steps):
+            (step_a if k % 2 == 0 else step_b)()
+        torch.cuda.synchronize(self.dev)
+        tp = (time.perf_counter() - tp) / steps
+        del eng2
+        return {"us_per_eval": tp * 1e6, "batch_evals_per_s": 1.0 / tp,
+                "note": "two handles on two HIP streams, independent batches alternating (this rank only)"}
+
+    def hessian_leg(self, res):
+        torch = self.torch
+        cfg, B, eng = res["cfg"], res["B"], res["eng"]
+        from oracle import nempc_oracle as orc
+        Zh, X0h = orc.synthetic_inputs(B, cfg["H"], cfg["nx"], cfg["nu"], seed=1 + self.rank)
+        Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+        lam = torch.randn(B, eng.m, dtype=eng.dtype, device=self.dev)
+        sig = torch.ones(B, dtype=eng.dtype, device=self.dev)
+        reps = max(self.args.steps // 4, 10)
+        t_h = self.timed_events(lambda: eng.hess(Z, X0, lam, sig), reps)
+        info = {"hess_us": t_h * 1e6, "nnz_hess": eng.nnz_hess, "hess_batch_evals_per_s": 1.0 / t_h}
+        if hasattr(eng, "hess_gn"):
+            wgt = torch.rand(B, cfg["H"] * cfg["nx"], dtype=eng.dtype, device=self.dev)
+            t_g = self.timed_events(lambda: eng.hess_gn(Z, X0, wgt, sig), reps)
+            info.update(gauss_newton_hess_us=t_g * 1e6, gauss_newton_batch_evals_per_s=1.0 / t_g)
+        return info
 
 
 def main():
@@ -118,227 +573,23 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU (default: the config's)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "valu", "mfma", "mfma_tile"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--hessian", action="store_true", help="also time the Lagrangian-Hessian callback (reported apart)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C2-B256 / C3 / C5 legs of the default run")
+    ap.add_argument("--only-eval", action="store_true",
+                    help="profiling mode: the timed loop, the row-kernel timing and the accuracy check of the timed "
+                         "launch only (no two-stream, solver, Hessian, other-config or CPU legs), so that a rocprofv3 "
+                         "kernel trace of this command averages the headline launch alone")
+    ap.add_argument("--hessian", action="store_true", help="also time the Hessian callbacks (reported apart)")
+    ap.add_argument("--evals-per-mpc-step", type=int, default=10,
+                    help="N > 1: one u0 all-gather per this many callback evaluations inside the timed loop")
+    ap.add_argument("--solver-iters", type=int, default=40)
+    ap.add_argument("--pmc-file", default="r02_c2_b1024_pmc.json")
     args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device; the product path has no CPU fallback")
-    # one process per GPU; NEMPC_BENCH_BACKEND=gloo is the one-GPU rehearsal mode (ranks share cuda:0, collectives
-    # through gloo) used to exercise this path where only one device exists
-    backend = os.environ.get("NEMPC_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    from oracle import nempc_oracle as orc   # synthetic inputs + checker only (never the thing measured)
-    from pyneuralempc_amd import CallbackEngine
-    from pyneuralempc_amd.parallel import allgather_u0
-
-    cfg = dict(CONFIGS[args.config])
-    B = args.batch or cfg["batch"]
-    tdtype = torch.float64 if cfg["dtype"] == "f64" else torch.float32
-    net = orc.MLP.random(cfg["nx"] + cfg["nu"], cfg["hidden"], cfg["nx"], seed=0)
-    eng = CallbackEngine(net.W, net.b, cfg["H"], cfg["nx"], cfg["nu"], integrator=cfg["integrator"], DT=cfg["DT"],
-                         dtype=tdtype, device=dev, max_batch=B, kernel=args.kernel)
-    if cfg["box"] is not None:
-        eng.set_box_rows(*cfg["box"])
-    Zh, X0h = orc.synthetic_inputs(B, cfg["H"], cfg["nx"], cfg["nu"], seed=1 + rank)
-    Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
-    want = ("f", "grad", "g", "jac_dense")
-    u0_off = cfg["H"] * cfg["nx"]
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    step, _outs = eng.bind(Z, X0, want)          # one ctypes call per step: keeps the host out of the way
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        allgather_u0(Z[:, u0_off:u0_off + cfg["nu"]].contiguous())
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if dist is not None:
-        gathered = allgather_u0(Z[:, u0_off:u0_off + cfg["nu"]].contiguous())
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        tw = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
-        assert gathered.shape[0] == world * B
-
-    # ---- per-kernel timing with HIP events on the launch stream (torch's current stream is the one the
-    # engine launches on): rows kernel alone, then the post kernels alone
-    def timed(fn, reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fn(); torch.cuda.synchronize(dev)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) * 1e-3 / reps
-
-    def per_step_us(fn, reps):
-        """one HIP event pair per evaluation -> (p10, median, p90) in microseconds (SURVEY 8d)"""
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-        fn(); torch.cuda.synchronize(dev)
-        evs[0].record()
-        for i in range(reps):
-            fn()
-            evs[i + 1].record()
-        torch.cuda.synchronize(dev)
-        d = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(reps)]) * 1e3
-        return [float(np.percentile(d, q)) for q in (10, 50, 90)]
-
-    reps = max(args.steps, 50)
-    t_rows = timed(eng.bind(Z, X0, ("g", "jac_tiles"))[0], reps)
-    step_pcts = per_step_us(step, reps)
-    t_all = timed(step, reps)
-    work = algorithmic_work(cfg, B, eng.m, eng.n)
-    peak_tf = PEAK_F64_TFLOPS if cfg["dtype"] == "f64" else PEAK_F32_TFLOPS
-    ach_tf = work["flops"] / t_rows / 1e12
-    t_step = wall / args.steps                      # the timed region itself (max over ranks)
-    ach_gbs = work["dense_bytes"] / t_step / 1e9
-    ai = work["flops"] / work["dense_bytes"]
-    ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
-
-    # ---- two independent batches in flight: a second handle on a second HIP stream, evaluations alternating.  The
-    # launch prologue / drain of one evaluation overlaps the other's full pass (reported apart; `value` above is the
-    # single-stream figure)
-    pipe_info = None
-    if rank == 0 or dist is None:
-        eng2 = CallbackEngine(net.W, net.b, cfg["H"], cfg["nx"], cfg["nu"], integrator=cfg["integrator"], DT=cfg["DT"],
-                              dtype=tdtype, device=dev, max_batch=B, kernel=args.kernel)
-        if cfg["box"] is not None:
-            eng2.set_box_rows(*cfg["box"])
-        Zb, X0b = (eng2.to_device(a) for a in orc.synthetic_inputs(B, cfg["H"], cfg["nx"], cfg["nu"], seed=101 + rank))
-        sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        with torch.cuda.stream(sa):
-            step_a, _ = eng.bind(Z, X0, want)
-        with torch.cuda.stream(sb):
-            step_b, _ = eng2.bind(Zb, X0b, want)
-        torch.cuda.synchronize(dev)
-        for k in range(20):
-            (step_a if k % 2 == 0 else step_b)()
-        torch.cuda.synchronize(dev)
-        tp = time.perf_counter()
-        for k in range(args.steps):
-            (step_a if k % 2 == 0 else step_b)()
-        torch.cuda.synchronize(dev)
-        tp = (time.perf_counter() - tp) / args.steps
-        pipe_info = {"us_per_eval": tp * 1e6, "batch_evals_per_s": 1.0 / tp,
-                     "note": "two handles on two HIP streams, independent batches alternating (this rank only)"}
-        del eng2
-        step, _outs = eng.bind(Z, X0, want)      # rebind the first handle to the default stream
-
-    # ---- batched on-device solver (SURVEY 8f-1) + the one collective of the design: all-gather of the solved u0
-    solver_info = None
-    # (RK4 Lagrangian blocks on the generic kernel take minutes at C3 dims: only with the matrix-core pipeline)
-    if cfg["box"] is None and (cfg["integrator"] != "rk4" or eng.kernel_variant != "valu"):
-        lbv = np.concatenate([np.full(cfg["H"] * cfg["nx"], -3.0), np.full(cfg["H"] * cfg["nu"], -0.5)])
-        Xs = eng.to_device(np.random.default_rng(100 + rank).uniform(-0.5, 0.5, size=(B, cfg["nx"])))
-        # fp32 configs: tolerances an fp32 iterate can reach
-        tols = {} if cfg["dtype"] == "f64" else dict(tol_constraint=1e-4, tol_step=1e-4, mu_min=1e-5, reg=1e-6)
-        eng.solve(Xs, lb=lbv, ub=-lbv, max_iter=5, **tols)   # warm
-        barrier()
-        ts = time.perf_counter()
-        Zs, st, its = eng.solve(Xs, lb=lbv, ub=-lbv, max_iter=40, **tols)
-        torch.cuda.synchronize(dev)
-        t_solve = time.perf_counter() - ts
-        u0 = Zs[:, u0_off:u0_off + cfg["nu"]].contiguous()
-        tg = time.perf_counter()
-        allu0 = allgather_u0(u0)
-        torch.cuda.synchronize(dev)
-        t_gather = time.perf_counter() - tg
-        conv = torch.tensor([float((st == 0).sum().item()), t_solve], dtype=torch.float64, device=dev)
-        if dist is not None:
-            c2 = conv.clone()
-            dist.all_reduce(c2[0:1], op=dist.ReduceOp.SUM)
-            dist.all_reduce(c2[1:2], op=dist.ReduceOp.MAX)
-            conv = c2
-        solver_info = {"mpc_solves_per_s": world * B / float(conv[1].item()), "iterations": its,
-                       "converged_frac": float(conv[0].item()) / (world * B), "solve_ms": float(conv[1].item()) * 1e3,
-                       "allgather_u0_us": t_gather * 1e6, "gathered_rows": int(allu0.shape[0]),
-                       "note": "SQP + Riccati, exact Lagrangian blocks, bounds |x|<=3 |u|<=0.5 via log barrier, <=40 iterations"}
-
-    hess_info = None
-    if args.hessian and (cfg["integrator"] != "rk4" or eng.kernel_variant != "valu"):
-        lam = torch.randn(B, eng.m, dtype=tdtype, device=dev)
-        sig = torch.ones(B, dtype=tdtype, device=dev)
-        t_h = timed(lambda: eng.hess(Z, X0, lam, sig), max(args.steps // 4, 10))
-        hess_info = {"hess_us": t_h * 1e6, "nnz_hess": eng.nnz_hess, "hess_batch_evals_per_s": 1.0 / t_h}
-
-    # ---- accuracy vs the CPU oracle on a sample (the metric's second half)
-    res = eng.eval(Z[:32].contiguous(), X0[:32].contiguous(), want)
-    res = {k: v.to("cpu", torch.float64).numpy() for k, v in res.items()}
-    kind = {"discret": orc.DISCRET, "unity": orc.UNITY, "rk4": orc.RK4}[cfg["integrator"]]
-    prob = orc.Problem(net, cfg["H"], cfg["nx"], cfg["nu"], kind, cfg["DT"], box=cfg["box"])
-    f, grad, g, jac = prob.eval_batch(Zh[:32], X0h[:32])
-    errs = {"f": float(np.abs(res["f"] - f).max()), "grad": float(np.abs(res["grad"] - grad).max()),
-            "g": float(np.abs(res["g"] - g).max()), "jac": float(np.abs(res["jac_dense"] - jac).max())}
-
-    if rank == 0:
-        out = {
-            "metric": "nlp_callback_evals_per_sec (f + grad f + g + dense jac g)",
-            "value": world * B * args.steps / wall,
-            "unit": "problem-evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": cfg["dtype"], "data": "synthetic",
-            "config": {"workload": cfg["label"], "batch_per_gpu": B, "H": cfg["H"], "nx": cfg["nx"], "nu": cfg["nu"],
-                       "hidden": cfg["hidden"], "integrator": cfg["integrator"], "n": eng.n, "m": eng.m,
-                       "row_kernel": eng.kernel_variant, "parallelism": f"problem-sharded x{world}"},
-            "batch_evals_per_s": args.steps / wall,
-            "jacobian_max_abs_err_vs_cpu": errs["jac"], "max_abs_err_vs_cpu": errs,
-            "roofline": {"bound": "mfma", "kernel": eng.last_row_kernel, "achieved": ach_tf,
-                         "peak": peak_tf, "unit": "TFLOP/s", "frac": ach_tf / peak_tf, "traffic": None,
-                         "kernel_us": t_rows * 1e6, "flops_per_launch": work["flops"],
-                         "arithmetic_intensity_dense": ai, "ridge": ridge},
-            "roofline_hbm_whole_eval": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                        "frac": ach_gbs / PEAK_HBM_GBS, "bytes_per_eval_dense_contract":
-                                            work["dense_bytes"], "eval_us": t_step * 1e6, "eval_us_event_loop": t_all * 1e6,
-                                        "eval_us_p10_median_p90": step_pcts},
-        }
-        # HBM bytes of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-        pmc_file = os.path.join(REPO, "profiles", "r01c_c2_b1024_pmc.json")
-        if args.config == "c2" and B == 1024 and eng.kernel_variant == "mfma" and os.path.exists(pmc_file):
-            pmc = json.load(open(pmc_file))
-            for k, v in pmc.items():
-                if k.startswith(str(eng.last_row_kernel)) and "hbm_traffic_bytes" in v:
-                    out["roofline"]["traffic"] = v["hbm_traffic_bytes"]
-                    out["roofline"]["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch, profiles/r01c_c2_b1024_pmc.json; "
-                                                       "WRITE_SIZE of this kernel's 8-byte stores is uncalibrated "
-                                                       "(algorithmic: 0.51 MB read, 1.3 MB written)")
-        if pipe_info:
-            out["pipelined_two_streams"] = pipe_info
-        if solver_info:
-            out["batched_solver"] = solver_info
-        if hess_info:
-            out["hessian_callback"] = hess_info
-        if world == 1 and not args.no_cpu:
-            cb, _ = cpu_baseline(cfg)
-            out["cpu_baseline"] = cb
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launcher role: nothing above this line has touched HIP (torch is not even imported yet)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    Rank(args).main()
 
 
 if __name__ == "__main__":

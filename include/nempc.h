@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define NEMPC_ABI_VERSION 4
+#define NEMPC_ABI_VERSION 5
 #define NEMPC_MAX_LAYERS 8 /* dense layers incl. the linear output layer */
 
 /* status codes */
@@ -97,6 +97,10 @@ typedef struct nempc_config {
 int nempc_create(const nempc_config* cfg, nempc_handle* out);
 int nempc_destroy(nempc_handle h);
 
+/* grow the workspaces to hold max_batch problems per call (no-op when they already do).  Everything else the handle
+ * owns -- weights, objective, structure, bindings, communicator -- is kept.  Synchronises the device. */
+int nempc_reserve(nempc_handle h, int32_t max_batch);
+
 /* network weights: W[l] is (in_l, out_l) row-major -- the Keras `kernel` layout used by
  * KerasTFModel (model/tensorflow.py:8-51); b[l] is (out_l). Host doubles. */
 int nempc_set_weights(nempc_handle h, const double* const* W, const double* const* b);
@@ -116,13 +120,15 @@ int nempc_set_terminal_weight(nempc_handle h, const double* QT);
 /* bind the extra network inputs for subsequent nempc_eval / nempc_hess / nempc_solve calls: E (B,H,n_extra) device,
  * dtype of the handle, row t of problem b = [tvp_t ; p] (time-varying parameters then constant parameters, the
  * concatenation order of KerasTFModel._gather_input).  The pointer is stored, not copied; required when
- * n_extra > 0.  */
-int nempc_bind_extra(nempc_handle h, const void* E);
+ * n_extra > 0.  B = problems the tensor covers: a later evaluation of more problems than that is refused
+ * (NEMPC_EINVAL) instead of reading past the end.  */
+int nempc_bind_extra(nempc_handle h, const void* E, int32_t B);
 
 /* history of a rolling-window model for subsequent calls (set_prev_data, model/tensorflow.py:178-189):
  * hist_x (B, w-1, nx) = the w-1 states BEFORE x0, oldest first; hist_u (B, w-1, nu) = the w-1 controls before u_0.
- * Device pointers of the handle's dtype, stored not copied; required when rolling_window > 1. */
-int nempc_bind_history(nempc_handle h, const void* hist_x, const void* hist_u);
+ * Device pointers of the handle's dtype, stored not copied; required when rolling_window > 1.  B = problems the
+ * tensors cover (evaluations of more problems are refused). */
+int nempc_bind_history(nempc_handle h, const void* hist_x, const void* hist_u, int32_t B);
 
 /* extra constraint rows g_box = states.ravel() (a Constraint in the sense of constraints.py:36-63
  * with constant selector Jacobian); lo/hi (nx) host doubles are only reported back through
@@ -187,6 +193,27 @@ int nempc_solve(nempc_handle h, int32_t B, const void* X0, void* Z, const double
                 const nempc_solver_opts* opts, int32_t* status, int32_t* iters, void* stream);
 
 int nempc_sync(nempc_handle h, void* stream);
+
+/* Multi-GPU (no reference counterpart -- the reference has no distributed code).  Ranks own disjoint
+ * shards of the problem batch, one process per GPU; nothing on the callback path communicates.  The single exchange
+ * is an all-gather of the solved first controls u0 = z[H*nx : H*nx+nu] of every problem, once per MPC step, issued on
+ * RCCL (ncclAllGather over xGMI) by the library itself:
+ *   nempc_comm_unique_id   rank 0 only: fills id (NEMPC_COMM_ID_BYTES host bytes = an ncclUniqueId); the host side
+ *                          hands it to the other ranks (torch.distributed broadcast in pyneuralempc_amd/parallel.py)
+ *   nempc_comm_init        every rank, collectively: builds the handle's communicator on the handle's device
+ *   nempc_allgather_u0     every rank, collectively, asynchronous on `stream`: packs this rank's u0 -- taken from
+ *                          Z (B,n) (what nempc_solve returns), or from u0 (B,nu) when Z is NULL -- into its slot of
+ *                          gathered (nranks*rows_per_rank, nu) and all-gathers in place.  rows_per_rank >= B is the
+ *                          common slot size (the largest shard when shards are ragged; the pad rows are zero).
+ *   nempc_comm_size        nranks / rank of the handle's communicator (0 / -1 when there is none)
+ * RCCL is bound at run time on the first of these calls (dlopen librccl.so.1; NEMPC_EUNSUPPORTED when absent). */
+#define NEMPC_COMM_ID_BYTES 128
+int nempc_comm_unique_id(void* id);
+int nempc_comm_init(nempc_handle h, int32_t nranks, int32_t rank, const void* id);
+int nempc_allgather_u0(nempc_handle h, int32_t B, int32_t rows_per_rank, const void* Z, const void* u0,
+                       void* gathered, void* stream);
+int nempc_comm_size(nempc_handle h, int32_t* nranks, int32_t* rank);
+int nempc_comm_destroy(nempc_handle h);
 
 /* which row kernel the handle resolved to (NEMPC_KERNEL_VALU | NEMPC_KERNEL_MFMA | NEMPC_KERNEL_MFMA_TILE) */
 int nempc_kernel_variant(nempc_handle h);

@@ -11,7 +11,7 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libnempc.so")
 SOURCES = ["nempc_api.hip", "kernels_valu.hip", "kernels_post.hip", "kernels_mfma.hip",
-           "kernels_mfma_f64.hip", "kernels_mfma_f32.hip", "kernels_rk4hess.hip", "solver.hip"]
+           "kernels_mfma_f64.hip", "kernels_mfma_f32.hip", "kernels_rk4hess.hip", "solver.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
 
@@ -58,7 +58,7 @@ def build(force=False, verbose=True):
                     print(f"[nempc build] compiled {os.path.basename(s)}", file=sys.stderr)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

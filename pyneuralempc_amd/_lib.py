@@ -6,7 +6,8 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "libnempc.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
+COMM_ID_BYTES = 128
 MAX_LAYERS = 8
 F64, F32 = 0, 1
 DISCRET, UNITY, RK4 = 0, 1, 2
@@ -14,9 +15,10 @@ KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_TILE = 0, 1, 2, 3
 KERNEL_NAMES = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA, "mfma_tile": KERNEL_MFMA_TILE}
 INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
 
-EXPORTS = ["nempc_create", "nempc_destroy", "nempc_set_weights", "nempc_set_objective", "nempc_set_terminal_weight", "nempc_set_box_rows", "nempc_bind_extra", "nempc_bind_history",
+EXPORTS = ["nempc_create", "nempc_destroy", "nempc_reserve", "nempc_set_weights", "nempc_set_objective", "nempc_set_terminal_weight", "nempc_set_box_rows", "nempc_bind_extra", "nempc_bind_history",
            "nempc_dims", "nempc_constraint_bounds", "nempc_jac_structure", "nempc_hess_structure", "nempc_eval",
-           "nempc_hess", "nempc_solve", "nempc_sync", "nempc_kernel_variant", "nempc_last_row_kernel", "nempc_last_error", "nempc_abi_version"]
+           "nempc_hess", "nempc_solve", "nempc_sync", "nempc_kernel_variant", "nempc_last_row_kernel", "nempc_last_error", "nempc_abi_version",
+           "nempc_comm_unique_id", "nempc_comm_init", "nempc_allgather_u0", "nempc_comm_size", "nempc_comm_destroy"]
 
 
 class NempcError(RuntimeError):
@@ -57,12 +59,13 @@ def load():
     dpp = ctypes.POINTER(dp)
     lib.nempc_create.argtypes = [ctypes.POINTER(NempcConfig), ctypes.POINTER(vp)]
     lib.nempc_destroy.argtypes = [vp]
+    lib.nempc_reserve.argtypes = [vp, i32]
     lib.nempc_set_weights.argtypes = [vp, dpp, dpp]
     lib.nempc_set_objective.argtypes = [vp, dp, dp, dp, dp, dp, dp]
     lib.nempc_set_terminal_weight.argtypes = [vp, dp]
     lib.nempc_set_box_rows.argtypes = [vp, ctypes.c_int, dp, dp]
-    lib.nempc_bind_extra.argtypes = [vp, vp]
-    lib.nempc_bind_history.argtypes = [vp, vp, vp]
+    lib.nempc_bind_extra.argtypes = [vp, vp, i32]
+    lib.nempc_bind_history.argtypes = [vp, vp, vp, i32]
     lib.nempc_dims.argtypes = [vp, ip, ip, ip, ip]
     lib.nempc_constraint_bounds.argtypes = [vp, dp, dp]
     lib.nempc_jac_structure.argtypes = [vp, ip, ip]
@@ -73,6 +76,11 @@ def load():
     lib.nempc_sync.argtypes = [vp, vp]
     lib.nempc_kernel_variant.argtypes = [vp]
     lib.nempc_last_row_kernel.argtypes = [vp]
+    lib.nempc_comm_unique_id.argtypes = [vp]
+    lib.nempc_comm_init.argtypes = [vp, i32, i32, vp]
+    lib.nempc_allgather_u0.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    lib.nempc_comm_size.argtypes = [vp, ip, ip]
+    lib.nempc_comm_destroy.argtypes = [vp]
     lib.nempc_last_error.argtypes = []
     lib.nempc_last_error.restype = ctypes.c_char_p
     lib.nempc_abi_version.argtypes = []

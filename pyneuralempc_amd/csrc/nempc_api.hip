@@ -245,6 +245,7 @@ void destroy_impl(Handle* h) {
     mfma_free(*h);
     rk4hess_free(*h);
     solver_free(*h);
+    comm_free(*h);
     dev_free(h->d_obj);
     void* p = h->d_dense_map; dev_free(p); h->d_dense_map = nullptr;
     p = h->d_sparse_map; dev_free(p); h->d_sparse_map = nullptr;
@@ -359,6 +360,32 @@ int nempc_destroy(nempc_handle hh) {
     return NEMPC_OK;
 }
 
+int nempc_reserve(nempc_handle hh, int32_t max_batch) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_reserve: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    if (max_batch < 1) return fail(NEMPC_EINVAL, "nempc_reserve: max_batch must be >= 1");
+    if (max_batch <= h.cfg.max_batch) return NEMPC_OK;
+    DeviceGuard dg(h.cfg.device);
+    if (!dg.ok) return fail(NEMPC_EHIP, "nempc_reserve: hipSetDevice failed");
+    // an evaluation may still be running out of the old workspaces on some stream
+    NEMPC_HIP(hipDeviceSynchronize());
+    h.cfg.max_batch = max_batch;
+    const size_t Bm = (size_t)max_batch;
+    rk4hess_free(h);      // sized lazily from max_batch on their next use
+    solver_free(h);
+    dev_free(h.d_tiles_ws); dev_free(h.d_valu_ws); dev_free(h.d_hess_ws); dev_free(h.d_g_ws);
+    int rc = NEMPC_OK;
+    do {
+        if ((rc = dev_alloc(&h.d_tiles_ws, Bm * h.cfg.H * h.cfg.nx * h.nin * h.esz))) break;
+        h.valu_ws_elems = valu_workspace_elems(h);
+        if ((rc = dev_alloc(&h.d_valu_ws, h.valu_ws_elems * h.esz))) break;
+        if ((rc = dev_alloc(&h.d_hess_ws, Bm * h.cfg.H * h.nin * h.nin * h.esz))) break;
+        if ((rc = dev_alloc(&h.d_g_ws, Bm * h.m * h.esz))) break;
+    } while (0);
+    if (rc) h.cfg.max_batch = 0;   // workspaces are gone: every evaluation is refused until a reserve succeeds
+    return rc;
+}
+
 int nempc_set_weights(nempc_handle hh, const double* const* W, const double* const* b) {
     if (!hh || !W || !b) return fail(NEMPC_EINVAL, "nempc_set_weights: null argument");
     Handle& h = *reinterpret_cast<Handle*>(hh);
@@ -421,22 +448,26 @@ int nempc_set_terminal_weight(nempc_handle hh, const double* QT) {
     return upload_objective(h, keep);
 }
 
-int nempc_bind_extra(nempc_handle hh, const void* E) {
+int nempc_bind_extra(nempc_handle hh, const void* E, int32_t B) {
     if (!hh) return fail(NEMPC_EINVAL, "nempc_bind_extra: null handle");
     Handle& h = *reinterpret_cast<Handle*>(hh);
     if (h.ne == 0 && E) return fail(NEMPC_EINVAL, "nempc_bind_extra: the handle was created with n_extra = 0");
+    if (E && B < 1) return fail(NEMPC_EINVAL, "nempc_bind_extra: B (problems the tensor covers) must be >= 1");
     h.d_extra = E;
+    h.extra_B = E ? B : 0;
     return NEMPC_OK;
 }
 
-int nempc_bind_history(nempc_handle hh, const void* hist_x, const void* hist_u) {
+int nempc_bind_history(nempc_handle hh, const void* hist_x, const void* hist_u, int32_t B) {
     if (!hh) return fail(NEMPC_EINVAL, "nempc_bind_history: null handle");
     Handle& h = *reinterpret_cast<Handle*>(hh);
     if (h.w == 1 && (hist_x || hist_u))
         return fail(NEMPC_EINVAL, "nempc_bind_history: the handle was created with rolling_window = 1");
     if (h.w > 1 && (!hist_x != !hist_u)) return fail(NEMPC_EINVAL, "nempc_bind_history: bind both histories or neither");
+    if (hist_x && B < 1) return fail(NEMPC_EINVAL, "nempc_bind_history: B (problems the tensors cover) must be >= 1");
     h.d_hist_x = hist_x;
     h.d_hist_u = hist_u;
+    h.hist_B = hist_x ? B : 0;
     return NEMPC_OK;
 }
 
@@ -509,6 +540,8 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
     if (need_rows && h.ne > 0 && !h.d_extra) return fail(NEMPC_ESTATE, "nempc_eval: n_extra > 0 but nempc_bind_extra was not called");
     if (need_rows && h.w > 1 && !h.d_hist_x)
         return fail(NEMPC_ESTATE, "nempc_eval: rolling_window > 1 but nempc_bind_history was not called");
+    if (need_rows && ((h.ne > 0 && B > h.extra_B) || (h.w > 1 && B > h.hist_B)))
+        return fail(NEMPC_EINVAL, "nempc_eval: B exceeds the batch the bound extras / history cover");
     DeviceGuard dg(h.cfg.device);
     if (!dg.ok) return fail(NEMPC_EHIP, "nempc_eval: hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -542,6 +575,8 @@ int nempc_hess(nempc_handle hh, int32_t B, const void* Z, const void* X0, const 
     if (h.ne > 0 && !h.d_extra) return fail(NEMPC_ESTATE, "nempc_hess: n_extra > 0 but nempc_bind_extra was not called");
     if (h.w > 1 && !h.d_hist_x)
         return fail(NEMPC_ESTATE, "nempc_hess: rolling_window > 1 but nempc_bind_history was not called");
+    if ((h.ne > 0 && B > h.extra_B) || (h.w > 1 && B > h.hist_B))
+        return fail(NEMPC_EINVAL, "nempc_hess: B exceeds the batch the bound extras / history cover");
     DeviceGuard dg(h.cfg.device);
     if (!dg.ok) return fail(NEMPC_EHIP, "nempc_hess: hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -564,6 +599,7 @@ int nempc_solve(nempc_handle hh, int32_t B, const void* X0, void* Z, const doubl
     if (!X0 || !Z || !opts || !status) return fail(NEMPC_EINVAL, "nempc_solve: null argument");
     if (!h.have_weights) return fail(NEMPC_ESTATE, "nempc_solve: call nempc_set_weights first");
     if (h.ne > 0 && !h.d_extra) return fail(NEMPC_ESTATE, "nempc_solve: n_extra > 0 but nempc_bind_extra was not called");
+    if (h.ne > 0 && B > h.extra_B) return fail(NEMPC_EINVAL, "nempc_solve: B exceeds the batch the bound extras cover");
     if (h.box) return fail(NEMPC_EUNSUPPORTED, "nempc_solve: box rows are not handled; pass state bounds as lb/ub");
     if (h.w > 1) return fail(NEMPC_EUNSUPPORTED, "nempc_solve: rolling-window models are not handled by the batched solver");
     if (opts->max_iter < 1 || opts->max_linesearch < 1 || !(opts->mu_factor > 0.0 && opts->mu_factor < 1.0) ||

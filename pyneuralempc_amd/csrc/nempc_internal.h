@@ -82,6 +82,8 @@ struct Handle {
     int nin = 0;                 // tile width = decision inputs one row's network reads: w*(nx+nu)
     int ne = 0;                  // extra network inputs (tvp + p); the network's input width is nin + ne
     const void* d_extra = nullptr;  // bound by nempc_bind_extra, (B,H,ne)
+    int extra_B = 0;                // problems the bound extras cover
+    int hist_B = 0;                 // problems the bound history covers
     int w = 1, rev = 0;          // rolling window (1 = plain model), newest-first flag
     const void* d_hist_x = nullptr;  // bound by nempc_bind_history
     const void* d_hist_u = nullptr;
@@ -132,6 +134,7 @@ struct Handle {
     void* d_rk4_ht = nullptr;    //   (Bmax*H, 4, nin, nin) contracted stage Hessians
     long long* d_dbg = nullptr;  // diagnostic builds only
     void* solver_ws = nullptr;   // solver.hip
+    void* comm = nullptr;        // comm.hip: RCCL communicator of the u0 all-gather
     mutable int last_row_kernel = 0;  // 1 valu, 2 coop, 3 wave-tile
 };
 
@@ -198,5 +201,8 @@ int launch_assemble_hess(Handle& h, int B, const void* blocks, const void* sigma
 int solver_run(Handle& h, int B, const void* X0, void* Z, const double* lb, const double* ub,
                const nempc_solver_opts& o, int32_t* status_dev, int32_t* iters_host, hipStream_t s);
 void solver_free(Handle& h);
+
+// ---- comm.hip : RCCL all-gather of the first controls
+void comm_free(Handle& h);
 
 }  // namespace nempc

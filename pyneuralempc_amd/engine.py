@@ -102,7 +102,8 @@ class CallbackEngine:
         if self._box is not None:
             self.set_box_rows(*self._box)
         if self._extra is not None:
-            _lib.check(self.lib.nempc_bind_extra(self._handle, ctypes.c_void_p(self._extra.data_ptr())))
+            _lib.check(self.lib.nempc_bind_extra(self._handle, ctypes.c_void_p(self._extra.data_ptr()),
+                                                 int(self._extra.shape[0])))
         if self._history is not None:
             self.bind_history(*self._history)
         self._refresh_dims()
@@ -129,9 +130,12 @@ class CallbackEngine:
         self.n, self.m, self.nnz_jac, self.nnz_hess = n.value, m.value, nj.value, nh.value
 
     def reserve(self, B):
-        """Grow the handle's workspaces to hold B problems (recreates the handle)."""
+        """Grow the handle's workspaces to hold B problems (nempc_reserve: the handle, its bindings and its
+        communicator are kept)."""
         if B > self.max_batch:
-            self._create(int(B))
+            _lib.check(self.lib.nempc_reserve(self._handle, int(B)))
+            self.max_batch = int(B)
+            self._buffers = {}
 
     @property
     def kernel_variant(self):
@@ -174,7 +178,8 @@ class CallbackEngine:
         if E.device != self.device or E.dtype != self.dtype or E.dim() != 3 or tuple(E.shape[1:]) != (self.H, self.n_extra):
             raise ValueError(f"extra inputs must be a {self.dtype} tensor (B,{self.H},{self.n_extra}) on {self.device}")
         self._extra = E.contiguous()
-        _lib.check(self.lib.nempc_bind_extra(self._handle, ctypes.c_void_p(self._extra.data_ptr())))
+        _lib.check(self.lib.nempc_bind_extra(self._handle, ctypes.c_void_p(self._extra.data_ptr()),
+                                             int(self._extra.shape[0])))
 
     def bind_history(self, hist_x, hist_u):
         """Bind the history of a rolling-window model: hist_x (B, w-1, nx) states before x0 (oldest first), hist_u
@@ -190,7 +195,8 @@ class CallbackEngine:
             raise ValueError("hist_x and hist_u must cover the same batch")
         self._history = (hist_x.contiguous(), hist_u.contiguous())
         _lib.check(self.lib.nempc_bind_history(self._handle, ctypes.c_void_p(self._history[0].data_ptr()),
-                                               ctypes.c_void_p(self._history[1].data_ptr())))
+                                               ctypes.c_void_p(self._history[1].data_ptr()),
+                                               int(self._history[0].shape[0])))
 
     def _check_extra(self, B):
         if self.n_extra and (self._extra is None or self._extra.shape[0] < B):
@@ -279,13 +285,13 @@ class CallbackEngine:
                                            ptr["jac_dense"], ptr["jac_tiles"], ptr["jac_sparse"], self._stream()))
         return res
 
-    def bind(self, Z, X0, want=("f", "grad", "g", "jac_dense")):
+    def bind(self, Z, X0, want=("f", "grad", "g", "jac_dense"), out=None):
         """Pre-validated evaluation for hot loops: returns (launch, outputs) where launch() re-evaluates the
-        callbacks at the CURRENT contents of Z / X0 into the fixed `outputs` tensors with one ctypes call (no
-        per-call allocation or checking).  Valid while Z, X0 and the outputs stay alive and the handle is not
-        re-created (reserve / set_box_rows)."""
+        callbacks at the CURRENT contents of Z / X0 into the fixed `outputs` tensors (caller-supplied through `out`,
+        else the engine's reusable buffers) with one ctypes call (no per-call allocation or checking).  Valid while
+        Z, X0 and the outputs stay alive and the workspaces are not re-sized (reserve / set_box_rows)."""
         B = int(Z.shape[0])
-        res = self.eval(Z, X0, want)                      # validates, allocates outputs, warms the kernels
+        res = self.eval(Z, X0, want, out=out)             # validates, allocates outputs, warms the kernels
         ptr = {k: (ctypes.c_void_p(res[k].data_ptr()) if k in res else None)
                for k in ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")}
         handle, fn = self._handle, self.lib.nempc_eval
@@ -327,14 +333,21 @@ class CallbackEngine:
         return res
 
     def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=100, max_linesearch=6, check_every=2,
-              tol_constraint=1e-8, tol_step=1e-8, mu_init=1e-1, mu_min=1e-9, mu_factor=0.2, reg=1e-9, lq_kernel="auto"):
+              tol_constraint=None, tol_step=None, mu_init=1e-1, mu_min=None, mu_factor=0.2, reg=None, lq_kernel="auto"):
         """Batched on-device solve (Gauss-Newton SQP, see csrc/solver.hip).  X0 (B,nx) device tensor; Z_init (B,n)
         or None for the reference's cold start [x0 tiled H ; zeros] (optimizer/ipopt.py:149); lb/ub (n) host
-        vectors as DomainConstraint produces them; lq_kernel picks the Riccati sweep ("auto" | "thread" per problem | "wave"
+        vectors as DomainConstraint produces them; tolerances default by dtype (fp64 1e-8, fp32 1e-4); lq_kernel picks the Riccati sweep ("auto" | "thread" per problem | "wave"
         per problem).  Returns (Z (B,n), status (B,) int32 [0 ok / 1 fail], iters)."""
         B = int(X0.shape[0])
         self._check_in(X0, (B, self.nx), "X0")
+        self._check_extra(B)
         self.reserve(B)
+        # tolerances an iterate of the handle's precision can reach (fp32 stalls near 1e-5 relative)
+        f64 = self.dtype == torch.float64
+        tol_constraint = (1e-8 if f64 else 1e-4) if tol_constraint is None else tol_constraint
+        tol_step = (1e-8 if f64 else 1e-4) if tol_step is None else tol_step
+        mu_min = (1e-9 if f64 else 1e-5) if mu_min is None else mu_min
+        reg = (1e-9 if f64 else 1e-6) if reg is None else reg
         if Z_init is None:
             Z = torch.cat([X0.repeat(1, self.H), torch.zeros(B, self.H * self.nu, dtype=self.dtype, device=self.device)],
                           dim=1).contiguous()
@@ -363,6 +376,51 @@ class CallbackEngine:
 
     def sync(self):
         _lib.check(self.lib.nempc_sync(self._handle, self._stream()))
+
+    # ------------------------------------------------------------------ multi-GPU: the u0 all-gather on RCCL
+    def comm_init(self, nranks, rank, unique_id):
+        """Collective over the ranks: build this handle's RCCL communicator from the 128-byte id rank 0 obtained
+        with `CallbackEngine.comm_unique_id()` (parallel.init_u0_comm moves it over torch.distributed)."""
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {_lib.COMM_ID_BYTES} bytes")
+        buf = (ctypes.c_char * _lib.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nempc_comm_init(self._handle, int(nranks), int(rank), ctypes.cast(buf, ctypes.c_void_p)))
+        self._comm = (int(nranks), int(rank))
+
+    @staticmethod
+    def comm_unique_id():
+        buf = (ctypes.c_char * _lib.COMM_ID_BYTES)()
+        _lib.check(_lib.load().nempc_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return bytes(buf)
+
+    @property
+    def comm(self):
+        """(nranks, rank) of the handle's communicator, or None."""
+        return getattr(self, "_comm", None)
+
+    def allgather_u0(self, Z=None, u0=None, rows_per_rank=None, out=None):
+        """nempc_allgather_u0: first controls of this rank's B problems -- read from Z (B,n) or given as u0 (B,nu) --
+        gathered over the communicator into (nranks*rows_per_rank, nu), rank-major; asynchronous on the current
+        stream.  rows_per_rank defaults to B (equal shards); ragged shards pass the largest shard size."""
+        if self.comm is None:
+            raise RuntimeError("allgather_u0: call comm_init first")
+        if (Z is None) == (u0 is None):
+            raise ValueError("pass exactly one of Z and u0")
+        src = Z if Z is not None else u0
+        B = int(src.shape[0])
+        self._check_in(src, (B, self.n if Z is not None else self.nu), "Z" if Z is not None else "u0")
+        rows = B if rows_per_rank is None else int(rows_per_rank)
+        shape = (self.comm[0] * rows, self.nu)
+        if out is None:
+            out = self._out("u0_gathered", shape)
+        self._check_in(out, shape, "out")
+        zp = ctypes.c_void_p(Z.data_ptr()) if Z is not None else None
+        up = ctypes.c_void_p(u0.data_ptr()) if u0 is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nempc_allgather_u0(self._handle, B, rows, zp, up, ctypes.c_void_p(out.data_ptr()),
+                                                   self._stream()))
+        return out
 
     # ------------------------------------------------------------------ host convenience (B=1 drop-in path)
     def to_device(self, a):

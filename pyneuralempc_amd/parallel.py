@@ -20,33 +20,66 @@ def first_controls(Z, H, nx, nu):
     return Z[:, H * nx:H * nx + nu].contiguous()
 
 
-def allgather_u0(u0_local, total=None, group=None):
-    """Gather (b_r, nu) per rank into (sum_r b_r, nu), rank-major.  Equal shards use one
-    all_gather_into_tensor on a persistent-sized buffer; ragged shards pad to the largest."""
+def init_u0_comm(engine, group=None):
+    """Collective: give `engine`'s handle an RCCL communicator spanning the ranks of `group` (nempc_comm_init).  Rank 0
+    draws the ncclUniqueId (nempc_comm_unique_id) and torch.distributed carries its 128 bytes to the other ranks --
+    the process group is only the bootstrap channel; the all-gather itself is issued by libnempc.so on RCCL."""
+    if not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError("init_u0_comm needs an initialised torch.distributed process group")
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    on_device = dist.get_backend(group) == "nccl"
+    raw = type(engine).comm_unique_id() if rank == 0 else bytes(128)
+    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+    if on_device:
+        t = t.to(engine.device)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    engine.comm_init(world, rank, bytes(t.cpu().numpy().tobytes()))
+    return engine.comm
+
+
+def _shard_counts(b, device, total, world, rank, group):
+    if total is not None:
+        counts = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
+        if counts[rank] != b:
+            raise ValueError("local shard size does not match shard_bounds(total, rank, world)")
+        return counts
+    sizes = torch.tensor([b], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    return [int(s.item()) for s in all_sizes]
+
+
+def allgather_u0(u0_local, total=None, group=None, engine=None):
+    """Gather (b_r, nu) per rank into (sum_r b_r, nu), rank-major.
+
+    With `engine` holding a communicator (init_u0_comm) the exchange is libnempc.so's own nempc_allgather_u0 --
+    ncclAllGather on RCCL, in place on a persistent buffer; pass `total` (the global problem count) so that no size
+    exchange precedes it.  Otherwise it goes through torch.distributed (backend "nccl" = RCCL on a GPU node, "gloo" in
+    the CPU tests).  Ragged shards pad to the largest shard."""
     if not (dist.is_available() and dist.is_initialized()):
         return u0_local
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     b, nu = u0_local.shape
-    if total is None:
-        sizes = torch.tensor([b], dtype=torch.int64, device=u0_local.device)
-        all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-        dist.all_gather(all_sizes, sizes, group=group)
-        counts = [int(s.item()) for s in all_sizes]
-    else:
-        counts = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
-        if counts[rank] != b:
-            raise ValueError("local shard size does not match shard_bounds(total, rank, world)")
+    counts = _shard_counts(b, u0_local.device, total, world, rank, group)
     bmax = max(counts)
-    if all(c == bmax for c in counts):
-        out = torch.empty(world * b, nu, dtype=u0_local.dtype, device=u0_local.device)
-        try:
+    equal = all(c == bmax for c in counts)
+    if engine is not None and engine.comm is not None:
+        if engine.comm != (world, rank):
+            raise ValueError("the engine's communicator does not span this process group")
+        out = engine.allgather_u0(u0=u0_local.contiguous(), rows_per_rank=bmax)
+        if equal:
+            return out
+        return torch.cat([out[r * bmax:r * bmax + c] for r, c in enumerate(counts)], dim=0)
+    fused = dist.get_backend(group) == "nccl"      # all_gather_into_tensor: a capability of the backend, not a try
+    if equal:
+        if fused:
+            out = torch.empty(world * b, nu, dtype=u0_local.dtype, device=u0_local.device)
             dist.all_gather_into_tensor(out, u0_local.contiguous(), group=group)
-        except (RuntimeError, NotImplementedError):  # backend without the fused form
-            parts = [torch.empty_like(u0_local) for _ in range(world)]
-            dist.all_gather(parts, u0_local.contiguous(), group=group)
-            out = torch.cat(parts, dim=0)
-        return out
+            return out
+        parts = [torch.empty_like(u0_local) for _ in range(world)]
+        dist.all_gather(parts, u0_local.contiguous(), group=group)
+        return torch.cat(parts, dim=0)
     padded = torch.zeros(bmax, nu, dtype=u0_local.dtype, device=u0_local.device)
     padded[:b] = u0_local
     parts = [torch.empty_like(padded) for _ in range(world)]
@@ -75,11 +108,17 @@ class EvalPipeline:
 
     def submit(self, Z, X0, want=("f", "grad", "g", "jac_dense")):
         """Launch on the next slot; returns a ticket.  The slot's output tensors are reused by its next submit, so wait
-        for (and consume) a ticket before `depth` further submits."""
+        for (and consume) a ticket before `depth` further submits.  Z / X0 must not be modified in place until the
+        ticket has been waited for."""
         i = self._next
         self._next = (i + 1) % len(self.engines)
         st = self.streams[i]
         st.wait_stream(torch.cuda.current_stream(st.device))     # inputs produced on the caller's stream
+        # the side stream reads Z / X0 after this call returns: tell the caching allocator, so a caller that drops
+        # them does not get the memory handed out again under the running kernel.  Overwriting them IN PLACE before
+        # wait(ticket) is still a race the caller must avoid (wait first, or submit a copy).
+        Z.record_stream(st)
+        X0.record_stream(st)
         with torch.cuda.stream(st):
             out = self.engines[i].eval(Z, X0, want)
             ev = torch.cuda.Event()

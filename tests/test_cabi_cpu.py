@@ -66,6 +66,18 @@ def test_create_validates_before_touching_the_device_and_fails_loudly_without_gp
     assert lib.nempc_eval(None, 1, None, None, None, None, None, None, None, None, None) == -1
 
 
+def test_comm_entry_points_validate_without_a_device():
+    """the RCCL entry points reject bad arguments before they bind RCCL or touch a device"""
+    from pyneuralempc_amd import _lib
+    lib = _lib.load()
+    assert lib.nempc_comm_unique_id(None) == -1
+    assert lib.nempc_comm_init(None, 2, 0, None) == -1
+    assert lib.nempc_allgather_u0(None, 1, 1, None, None, None, None) == -1
+    assert lib.nempc_comm_destroy(None) == -1
+    assert lib.nempc_reserve(None, 4) == -1
+    assert _lib.COMM_ID_BYTES == 128
+
+
 def test_engine_has_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

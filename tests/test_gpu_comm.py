@@ -1,0 +1,108 @@
+"""GPU: the library's own RCCL entry points (nempc_comm_*, nempc_allgather_u0) on a one-rank communicator -- the only
+size a one-GPU box can build (RCCL refuses two ranks on one device) -- plus nempc_reserve and the bound-batch checks.
+The N-rank form is exercised by `bench.py --gpus N` on a multi-GPU node and by the gloo tests in
+test_parallel_cpu.py for the sharding logic."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nempc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(B, dtype=torch.float64, **kw):
+    from pyneuralempc_amd import CallbackEngine
+    net = orc.MLP.random(3 + kw.get("n_extra", 0), [32, 32], 2, seed=3)
+    return CallbackEngine(net.W, net.b, 6, 2, 1, dtype=dtype, device="cuda:0", max_batch=B, **kw), net
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_allgather_u0_single_rank_rccl(dtype):
+    from pyneuralempc_amd import CallbackEngine
+    B = 37
+    eng, _ = _engine(B, dtype)
+    assert eng.comm is None
+    with pytest.raises(RuntimeError, match="comm_init"):
+        eng.allgather_u0(Z=torch.zeros(B, eng.n, dtype=dtype, device="cuda:0"))
+    eng.comm_init(1, 0, CallbackEngine.comm_unique_id())
+    assert eng.comm == (1, 0)
+    Z = torch.randn(B, eng.n, dtype=dtype, device="cuda:0")
+    got = eng.allgather_u0(Z=Z)
+    torch.cuda.synchronize()
+    assert got.shape == (B, 1) and torch.equal(got, Z[:, 12:13])
+    # explicit u0, padded slot (ragged shards pad to the largest): pad rows are zero
+    u0 = torch.randn(B, 1, dtype=dtype, device="cuda:0")
+    got = eng.allgather_u0(u0=u0, rows_per_rank=B + 3)
+    torch.cuda.synchronize()
+    assert got.shape == (B + 3, 1) and torch.equal(got[:B], u0) and not got[B:].any()
+    with pytest.raises(ValueError):
+        eng.allgather_u0(Z=Z, u0=u0)
+    # growing the workspaces keeps the communicator (nempc_reserve does not re-create the handle)
+    eng.reserve(4 * B)
+    assert eng.max_batch == 4 * B
+    Z2 = torch.randn(4 * B, eng.n, dtype=dtype, device="cuda:0")
+    assert torch.equal(eng.allgather_u0(Z=Z2), Z2[:, 12:13])
+
+
+def test_parallel_helper_uses_the_engine_comm_single_process_group():
+    """init_u0_comm + allgather_u0(engine=...) through a one-rank torch.distributed group (nccl = RCCL)"""
+    import os
+    import socket
+    import torch.distributed as dist
+    from pyneuralempc_amd.parallel import allgather_u0, init_u0_comm
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        eng, _ = _engine(16)
+        assert init_u0_comm(eng) == (1, 0)
+        u0 = torch.randn(16, 1, dtype=torch.float64, device="cuda:0")
+        assert torch.equal(allgather_u0(u0, total=16, engine=eng), u0)
+        assert torch.equal(allgather_u0(u0, total=16), u0)          # torch.distributed path, same answer
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reserve_keeps_weights_objective_and_results():
+    eng, net = _engine(4)
+    eng.set_objective(Q=np.diag([2.0, 3.0]), R=[[0.5]])
+    eng.set_box_rows(-1.0, 1.0)
+    Zh, X0h = orc.synthetic_inputs(40, 6, 2, 1, seed=5)
+    small = eng.eval_numpy(Zh[:4], X0h[:4])
+    big = eng.eval_numpy(Zh, X0h)              # grows through nempc_reserve
+    assert eng.max_batch == 40
+    for k in small:
+        assert np.array_equal(small[k], big[k][:4]), k
+    prob = orc.Problem(net, 6, 2, 1, orc.DISCRET, Q=np.diag([2.0, 3.0]), R=np.array([[0.5]]), box=(-1.0, 1.0))
+    f, grad, g, jac = prob.eval_batch(Zh, X0h)
+    np.testing.assert_allclose(big["f"], f, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(big["jac_dense"], jac, rtol=1e-12, atol=1e-12)
+    lam = torch.randn(40, eng.m, dtype=torch.float64, device="cuda:0")
+    sig = torch.ones(40, dtype=torch.float64, device="cuda:0")
+    hv = eng.hess(eng.to_device(Zh), eng.to_device(X0h), lam, sig)["hvals"].cpu().numpy()
+    ref = np.stack([prob.hessian_values(Zh[i], X0h[i], lam[i].cpu().numpy(), 1.0) for i in range(40)])
+    np.testing.assert_allclose(hv, ref, rtol=1e-11, atol=1e-11)
+
+
+def test_bound_extras_smaller_than_the_batch_are_refused():
+    """a (1,H,ne) extras tensor left bound by a B=1 call must not be read for B problems"""
+    from pyneuralempc_amd._lib import NempcError
+    eng, _ = _engine(8, n_extra=2)
+    Zh, X0h = orc.synthetic_inputs(8, 6, 2, 1, seed=2)
+    Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+    eng.bind_extra(torch.zeros(1, 6, 2, dtype=torch.float64, device="cuda:0"))
+    eng.eval(Z[:1].contiguous(), X0[:1].contiguous())
+    with pytest.raises(ValueError, match="bind_extra"):
+        eng.eval(Z, X0)
+    with pytest.raises(ValueError, match="bind_extra"):
+        eng.solve(X0)
+    # and the C ABI itself refuses it even when the Python check is bypassed
+    import ctypes
+    rc = eng.lib.nempc_eval(eng._handle, 8, ctypes.c_void_p(Z.data_ptr()), ctypes.c_void_p(X0.data_ptr()), None, None,
+                            ctypes.c_void_p(eng._out("g", (8, eng.m)).data_ptr()), None, None, None, None)
+    assert rc == -1 and b"bound extras" in eng.lib.nempc_last_error()
+    eng.bind_extra(torch.zeros(8, 6, 2, dtype=torch.float64, device="cuda:0"))
+    eng.eval(Z, X0)

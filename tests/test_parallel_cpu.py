@@ -58,3 +58,51 @@ def test_allgather_u0_world2_gloo(tmp_path, B):
 def test_allgather_is_identity_without_process_group():
     u = torch.ones(3, 2)
     assert allgather_u0(u) is u
+
+
+def test_bench_launcher_spawns_ranks_before_touching_the_gpu(tmp_path):
+    """`bench.py --gpus N` without WORLD_SIZE is only a launcher: it must start the N ranks with the torchrun
+    environment without importing torch (hence without any HIP call) in the parent, and report a failed rank."""
+    import subprocess
+    import sys
+    from conftest import REPO
+    probe = r'''
+import os, sys
+sys.path.insert(0, %r)
+os.environ.pop("WORLD_SIZE", None)
+import bench
+started = []
+class FakeProc:
+    def __init__(self, cmd, env=None):
+        started.append((cmd, {k: env[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+        self.returncode = 3 if env["RANK"] == "1" else 0
+    def poll(self):
+        return self.returncode
+    def kill(self):
+        pass
+bench.subprocess.Popen = FakeProc
+sys.argv = ["bench.py", "--gpus", "2", "--steps", "3"]
+try:
+    bench.main()
+except SystemExit as e:
+    code = e.code
+assert "torch" not in sys.modules, "the launcher imported torch"
+assert len(started) == 2 and [s[1]["RANK"] for s in started] == ["0", "1"]
+assert all(s[1]["WORLD_SIZE"] == "2" and s[1]["MASTER_ADDR"] == "127.0.0.1" for s in started)
+assert started[0][1]["MASTER_PORT"] == started[1][1]["MASTER_PORT"]
+assert started[0][0][-4:] == ["--gpus", "2", "--steps", "3"]
+assert code == 3, code
+print("launcher-ok")
+''' % REPO
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "launcher-ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_rank_refuses_mismatched_world(tmp_path):
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
