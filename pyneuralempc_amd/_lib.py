@@ -4,7 +4,8 @@ import ctypes
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libnempc.so")
+# NEMPC_LIB: an alternative build of the same library (A/B kernel experiments, tools/build_variant.py)
+LIB_PATH = os.environ.get("NEMPC_LIB") or os.path.join(PKG, "libnempc.so")
 
 ABI_VERSION = 5
 COMM_ID_BYTES = 128

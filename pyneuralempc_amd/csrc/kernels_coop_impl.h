@@ -43,10 +43,57 @@ namespace nempc {
         __builtin_amdgcn_sched_barrier(0);                                                \
         if (cx.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) cx.dbg[(threadIdx.x >> 6) * 64 + (idx)] = (long long)_t; \
     } while (0)
+// per-workgroup timeline (wave 0, lane 0 of EVERY workgroup): word idx of the workgroup's 16-word record = shader
+// clock (s_memtime: local and cheap; s_memrealtime goes out to the chip's timestamp unit and costs the wave ~1 us per
+// read, which is why it is taken once, at exit, into word 13 to put the workgroups on a common axis);
+// word 15 = XCC id << 32 | HW_ID
+#define COOP_WGSTAMP(dbgp, idx)                                                              \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if ((dbgp) && threadIdx.x == 0 && blockIdx.x < 4096)                                 \
+            (dbgp)[1024 + blockIdx.x * 16 + (idx)] = (long long)__builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#define COOP_WGSTAMP_REAL(dbgp, idx)                                                         \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if ((dbgp) && threadIdx.x == 0 && blockIdx.x < 4096)                                 \
+            (dbgp)[1024 + blockIdx.x * 16 + (idx)] = (long long)__builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
 #else
 #define COOP_STAMP(idx) \
     do {                \
     } while (0)
+#define COOP_WGSTAMP(dbgp, idx) \
+    do {                        \
+    } while (0)
+#define COOP_WGSTAMP_REAL(dbgp, idx) \
+    do {                             \
+    } while (0)
+#endif
+
+#ifdef NEMPC_STAMPS
+#define NEMPC_STAMP_A(idx)                                                                 \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        unsigned long long _t;                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");         \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (a.dbg && blockIdx.x == 0 && (threadIdx.x & 63) == 0) a.dbg[(threadIdx.x >> 6) * 64 + (idx)] = (long long)_t; \
+    } while (0)
+#else
+#define NEMPC_STAMP_A(idx) \
+    do {                   \
+    } while (0)
+#endif
+
+// A/B switches of the prologue / pass-boundary experiments (tools/build_variant.py -D...)
+#ifndef NEMPC_COOP_PROLOGUE_BARRIER
+#define NEMPC_COOP_PROLOGUE_BARRIER 0
+#endif
+#ifndef NEMPC_COOP_MIDSTAGE
+#define NEMPC_COOP_MIDSTAGE 1
 #endif
 
 struct CoopLayout {  // element offsets inside dynamic LDS
@@ -72,6 +119,9 @@ __device__ __forceinline__ void lds_barrier() {
 // exchange barriers -- what the latency-bound cases (single-tile passes, 8-wave workgroups) lack.
 template <typename T>
 __host__ __device__ constexpr int coop_kg(int NT) {
+#ifdef NEMPC_EXP_KG1
+    return 1;
+#endif
     return NT * (int)sizeof(T) <= 8 ? 2 : 1;   // three at a time for fp32 single-tile passes measured no better (576 vs 568 us at C3)
 }
 // exchange-buffer slots (16-row activation sets) a pass may publish at once
@@ -113,6 +163,7 @@ struct CoopCtx {
     const T* extra;
     unsigned inv32_jrow, inv32_nx;
     int xhalf;                      // elements per half of the double-buffered exchange area  // ceil(2^32 / d) for d >= 2: item / d == umulhi(item, inv32) while item * d < 2^32
+    unsigned invH;                  // ceil(2^32 / H) (0 for H == 1): row / H == umulhi(row, invH)
     size_t R;
     bool rk4;
     T DT;
@@ -144,7 +195,7 @@ __device__ __forceinline__ void stage_load(const CoopCtx<T>& cx, int t0, int nro
         int b = -1, t = 0;
         const size_t r = (size_t)t0 * 16 + idx;
         if (col < ncol && idx < nrows && r < cx.R) {
-            b = (int)((unsigned)r / (unsigned)cx.H);
+            b = cx.invH ? (int)__umulhi((unsigned)r, cx.invH) : (int)r;
             t = (int)((unsigned)r - (unsigned)b * (unsigned)cx.H);
             const T* z = cx.Z + (size_t)b * cx.n;
             // plain models only (rolling windows stage directly, see the kernel body): keeps this early-issued
@@ -159,7 +210,8 @@ __device__ __forceinline__ void stage_load(const CoopCtx<T>& cx, int t0, int nro
 }
 
 template <typename T, int MT, int TPW>
-__device__ __forceinline__ void stage_store(const CoopCtx<T>& cx, int nrows, int tid, const StageRegs<T, MT, TPW>& sr) {
+__device__ __forceinline__ void stage_store(const CoopCtx<T>& cx, T* SCRdst, int* RIdst, int nrows, int tid,
+                                            const StageRegs<T, MT, TPW>& sr) {
     constexpr int ROWS = TPW * 16, NTHREADS = MT * 64;
     const int ncol = cx.nin + cx.nx + cx.ne;
 #pragma unroll
@@ -167,11 +219,11 @@ __device__ __forceinline__ void stage_store(const CoopCtx<T>& cx, int nrows, int
         const int item = tid + it * NTHREADS;
         const int col = item / ROWS, idx = item - col * ROWS;
         if (col < ncol && idx < nrows) {
-            T* tile = cx.SCR + (idx >> 4) * cx.spt;
+            T* tile = SCRdst + (idx >> 4) * cx.spt;
             if (col < cx.nin) tile[(idx & 15) * cx.nin + col] = sr.v[it];
             else if (col < cx.nin + cx.nx) tile[cx.xt_off + (idx & 15) * cx.nx + (col - cx.nin)] = sr.v[it];
             else tile[cx.ex_off + (idx & 15) * cx.ne + (col - cx.nin - cx.nx)] = sr.v[it];
-            if (col == 0) { cx.RI[2 * idx] = sr.b[it]; cx.RI[2 * idx + 1] = sr.t[it]; }
+            if (col == 0) { RIdst[2 * idx] = sr.b[it]; RIdst[2 * idx + 1] = sr.t[it]; }
         }
     }
 }
@@ -188,7 +240,7 @@ __device__ __forceinline__ void stage_direct(const CoopCtx<T>& cx, int t0, int n
         int b = -1, t = 0;
         const size_t r = (size_t)t0 * 16 + idx;
         if (r < cx.R) {
-            b = (int)((unsigned)r / (unsigned)cx.H);
+            b = cx.invH ? (int)__umulhi((unsigned)r, cx.invH) : (int)r;
             t = (int)((unsigned)r - (unsigned)b * (unsigned)cx.H);
             const T* z = cx.Z + (size_t)b * cx.n;
             if (col < cx.nin) v = gather_input<T>(cx.gk, z, cx.X0, b, t, col);   // [x_{t-1} | u_t] or the rolling window
@@ -206,8 +258,14 @@ __device__ __forceinline__ void stage_direct(const CoopCtx<T>& cx, int t0, int n
 // One pass over NT (compile-time) tiles starting at tile t0.  NT is a template parameter on purpose:
 // with a runtime tile count every per-tile MFMA sat in its own basic block and hipcc copied the whole
 // accumulator set through AGPRs at each join (6,500 v_accvgpr_* moves, 10x slower reverse sweep).
-template <typename T, int WP, int NH, int NT, bool SR>
-__device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeights<T, WP, NH>& W, int t0, int tid) {
+// `nxt` (valid when has_nxt): the NEXT pass's inputs, already fetched into registers; they are written to the other scratch
+// buffer (SCRnext / RInext) just before this pass's first global store.  Placed there for the vmcnt counter: stores
+// count in it too and retire in order, so a wait for those loads issued after the epilogue's (runtime-many) stores
+// degenerates to vmcnt(0) and sat out the stores' acknowledgement, 1.4 us per pass boundary.
+template <typename T, int WP, int NH, int NT, bool SR, int TPW>
+__device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeights<T, WP, NH>& W, int t0, int tid,
+                                          const StageRegs<T, WP / 16, TPW>& nxt, bool has_nxt, T* SCRnext, int* RInext,
+                                          int nrows_next) {
     using Ops = MfmaOps<T>;
     using V4 = typename Ops::V4;
     constexpr int MT = WP / 16;
@@ -457,6 +515,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
     }
 
     COOP_STAMP(9);
+    if (has_nxt) stage_store<T, WP / 16, TPW>(cx, SCRnext, RInext, nrows_next, tid, nxt);
     // ---- outputs: compact tiles (16 rows contiguous in memory) and defects
     const T s6 = DT / T(6);
     // tiles: the pass's NT*16 rows are contiguous in memory -> lanes run over the flat element index (coalesced)
@@ -491,107 +550,214 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
     COOP_STAMP(11);
 }
 
+// Everything the kernel needs, prepared on the host (try_launch_coop): the kernel itself does no setup arithmetic.
+// The first version derived its constants in the kernel -- three 64-bit scalar divisions, a dozen dependent
+// s_load round trips into a 100-SGPR budget -- and spent 1.7 us between wave start and its first vector load
+// (tools/diag_stamps.py); now the fields the first loads need come first and the rest arrives in their shadow.
+struct CoopArgs {
+    // ---- needed by the first vector loads
+    const void* Z;
+    const void* X0;
+    const void* small;      // blob + off.coop_small: [w0f | seed | bias_l | biasL]
+    const void* wslice;     // blob + off.coop_slices: per-wave register slices, 16-byte lane vectors
+    const void* extra;
+    int tiles_per_wg, tiles_rem;
+    unsigned R;             // rows = B*H
+    unsigned invH;          // ceil(2^32 / H), 0 for H == 1: r / H == umulhi(r, invH) while r*H < 2^32 (checked by the host)
+    int H, n, nx, nu, nin, ne;
+    int small_vecs;         // 16-byte vectors in `small`
+    int nload;              // 16-byte loads per lane of a wave's slice
+    int early;              // first-pass inputs through registers (plain models whose columns fit StageRegs)
+    // ---- LDS carve-up (element offsets) and table offsets inside the LDS copy of `small`
+    int l_w0f, l_tail, l_x, l_xhalf, l_part, l_scratch, l_scratch2, l_rowinfo, l_rowinfo2;   // *2: the second buffer
+    int bias_off[3], biasL_off;
+    // ---- the rest of CoopCtx
+    void* g;
+    void* tiles;
+    void* stage_out;
+    long long* dbg;
+    int m, NR, jsz, spt, nstages, ks, kind, box, xt_off, ex_off, inv_nin, rk4, stage_stride;
+    unsigned inv32_jrow, inv32_nx;
+    double DT;
+    RowGather gk;
+};
+
 // SR: also write the per-(row, stage) records of the RK4 Hessian pipeline (its own instantiation: the extra stores and
 // their address arithmetic cost the plain kernel 0.3 - 0.9 us when they are only branched around)
-template <typename T, int WP, int NH, int TPW, bool SR = false>
-__global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coop_kernel(MfmaParams p, CoopLayout lay) {
+// OCC: waves per SIMD the register allocation must allow (workgroups per CU = OCC * 4 / MT)
+template <typename T, int WP, int NH, int TPW, bool SR = false, int OCC = 2>
+__global__ __launch_bounds__((WP / 16) * 64, OCC) void rows_coop_kernel(CoopArgs a) {
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T* lds = reinterpret_cast<T*>(lds_raw);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    const T* __restrict__ gblob = static_cast<const T*>(p.blob);
-    NEMPC_STAMP(0);
+    NEMPC_STAMP_A(0);
+    COOP_WGSTAMP(a.dbg, 0);
+#ifdef NEMPC_STAMPS
+    if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096)
+        a.dbg[1024 + blockIdx.x * 16 + 15] = ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+#endif
 
     CoopCtx<T> cx;
-    cx.w0f = lds + lay.w0f;
-    cx.seed = lds + lay.tail;
-    for (int l = 0; l < 3; ++l) cx.bias_off[l] = p.off.bias[l] - p.off.seed;
-    cx.biasL_off = p.off.biasL - p.off.seed;
-    cx.X = lds + lay.x;
-    cx.xhalf = lay.xhalf;
-    cx.PART = lds + lay.part;
-    cx.SCR = lds + lay.scratch;
-    cx.RI = reinterpret_cast<int*>(lds + lay.rowinfo);
-    cx.Z = static_cast<const T*>(p.Z);
-    cx.X0 = static_cast<const T*>(p.X0);
-    cx.gout = static_cast<T*>(p.g);
-    cx.tiles = static_cast<T*>(p.tiles);
-    cx.nx = p.nx; cx.nu = p.nu; cx.nin = p.nin; cx.H = p.H; cx.n = p.gk.n; cx.m = p.m;
-    cx.gk = p.gk;
-    cx.stage_out = static_cast<T*>(p.stage_out); cx.stage_stride = p.stage_stride;
-    cx.NR = coop_nr<T>(p.nin);
-    cx.jsz = 16 * p.nx * p.nin;
-    cx.spt = p.scratch_per_wave;
-    cx.xt_off = 16 * p.nin + 2 * 16 * p.nx + (p.kind == NEMPC_RK4 ? 4 : 1) * cx.jsz;  // after the wave-tile kernel's carve-up
-    cx.ex_off = cx.xt_off + 16 * p.nx;                    // [16][ne] extra inputs
-    cx.ne = p.ne;
-    cx.extra = static_cast<const T*>(p.extra);
-    cx.inv32_jrow = (unsigned)((0x100000000ull + (unsigned)(p.nx * p.nin) - 1) / (unsigned)(p.nx * p.nin));
-    cx.inv32_nx = (unsigned)((0x100000000ull + (unsigned)p.nx - 1) / (unsigned)p.nx);
-    cx.inv_nin = (65536 + p.nin - 1) / p.nin;              // kd / nin == (kd * inv_nin) >> 16 for kd < 256
-    cx.rk4 = p.kind == NEMPC_RK4;
-    cx.nstages = cx.rk4 ? 4 : 1;
-    cx.ks = p.ks; cx.kind = p.kind; cx.box = p.box;
-    cx.R = (size_t)p.B * p.H;
-    cx.DT = (T)p.DT;
-    cx.dbg = p.dbg;
+    cx.Z = static_cast<const T*>(a.Z);
+    cx.X0 = static_cast<const T*>(a.X0);
+    cx.extra = static_cast<const T*>(a.extra);
+    cx.nx = a.nx; cx.nu = a.nu; cx.nin = a.nin; cx.H = a.H; cx.n = a.n; cx.ne = a.ne;
+    cx.R = a.R; cx.invH = a.invH;
 
     // contiguous, balanced range of tiles for this workgroup (quotient / remainder computed on the host)
-    const int t_begin = blockIdx.x * p.tiles_per_wg + ((int)blockIdx.x < p.tiles_rem ? (int)blockIdx.x : p.tiles_rem);
-    const int t_end = t_begin + p.tiles_per_wg + ((int)blockIdx.x < p.tiles_rem ? 1 : 0);
+    const int t_begin = blockIdx.x * a.tiles_per_wg + ((int)blockIdx.x < a.tiles_rem ? (int)blockIdx.x : a.tiles_rem);
+    const int t_end = t_begin + a.tiles_per_wg + ((int)blockIdx.x < a.tiles_rem ? 1 : 0);
 
-    // first pass's inputs: loads issued BEFORE the weight-slice loads, consumed (LDS stores) after them
+    // ---- every global load of the prologue is issued before anything waits (VMEM returns in order):
+    //      1. the first pass's inputs, 2. the small tables, 3. this wave's weight slices.
     StageRegs<T, MT, TPW> sr;
     int t0 = t_begin;
     int nact = t_end - t0 < TPW ? t_end - t0 : TPW;
-    const bool early = cx.gk.w == 1 && (cx.nin + cx.nx + cx.ne) * TPW * 16 <= StageRegs<T, MT, TPW>::ITEMS * NTHREADS;
-    if (early) stage_load<T, MT, TPW>(cx, t0, nact * 16, tid, sr);
-    // small tables -> LDS ...
-    copy_blob_to_lds<T>(gblob + p.off.w0f, lds + lay.w0f, p.ks * MT * 64, tid, NTHREADS);
-    copy_blob_to_lds<T>(gblob + p.off.seed, lds + lay.tail, p.off.total - p.off.seed, tid, NTHREADS);
-    // ... then this wave's weight slices -> registers (kept for every pass); first needed by hidden layer 1,
-    // so their latency hides under layer 0 of the first pass
-    CoopWeights<T, WP, NH> W;
-#pragma unroll
-    for (int l = 1; l < NH; ++l)
-#pragma unroll
-        for (int i = 0; i < MT * 4; ++i) {
-#ifdef NEMPC_EXP_NOWEIGHTS   // timing experiment only: how much of the prologue is the weight fetch
-            W.wf[l - 1][i] = T(1e-3) * T(lane + i);
-            W.wb[l - 1][i] = T(1e-3) * T(lane - i);
+    const bool early = a.early != 0;
+#ifdef NEMPC_EXP_NOSTAGE   // timing experiment only
+    for (int it = 0; it < StageRegs<T, MT, TPW>::ITEMS; ++it) { sr.v[it] = T(0.01) * T(tid & 15); sr.b[it] = tid & 7; sr.t[it] = tid & 3; }
 #else
-            W.wf[l - 1][i] = gblob[p.off.wf[l] + (i * MT + w) * 64 + lane];
-            W.wb[l - 1][i] = gblob[p.off.wb[l] + (i * MT + w) * 64 + lane];
+    if (early) stage_load<T, MT, TPW>(cx, t0, nact * 16, tid, sr);
+#endif
+    COOP_WGSTAMP(a.dbg, 1);
+    constexpr int SMALL_PER_THREAD = 4;     // covers 4 * NTHREADS 16-byte vectors; larger tables loop below
+    vecT sm[SMALL_PER_THREAD];
+    {
+        const vecT* __restrict__ gs = static_cast<const vecT*>(a.small);
+#pragma unroll
+        for (int u = 0; u < SMALL_PER_THREAD; ++u) {
+            const int idx = tid + u * NTHREADS;
+#ifdef NEMPC_EXP_NOSMALL   // timing experiment only
+            for (int e = 0; e < VEC; ++e) sm[u][e] = T(1e-3) * T(idx + e);
+#else
+            if (idx < a.small_vecs) sm[u] = gs[idx];
 #endif
         }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        W.wL[r] = gblob[p.off.wLf + (w * 4 + r) * 64 + lane];
-        W.w0b[r] = gblob[p.off.w0b + (w * 4 + r) * 64 + lane];
     }
-    NEMPC_STAMP(1);
-
-    while (t0 < t_end) {
-        if (early) stage_store<T, MT, TPW>(cx, nact * 16, tid, sr);
-        else stage_direct<T, MT, TPW>(cx, t0, nact * 16, tid);
-        lds_barrier();
-        if (nact == 1) coop_pass<T, WP, NH, 1, SR>(cx, W, t0, tid);
-        if constexpr (TPW >= 2) { if (nact == 2) coop_pass<T, WP, NH, 2, SR>(cx, W, t0, tid); }
-        if constexpr (TPW >= 3) { if (nact == 3) coop_pass<T, WP, NH, 3, SR>(cx, W, t0, tid); }
-        if constexpr (TPW >= 4) { if (nact == 4) coop_pass<T, WP, NH, 4, SR>(cx, W, t0, tid); }
-        t0 += nact;
-#ifdef NEMPC_STAMPS
-        cx.dbg = nullptr;   // diagnostic build: keep the FIRST pass's stamps
+    COOP_WGSTAMP(a.dbg, 2);
+    // The CU's texture path moves 64 B/clk and serves requests in arrival order: the two workgroups' slices are
+    // 160 KB = 1.1 us of it.  Hold the slice loads back until every wave of the workgroup has queued its inputs and
+    // tables, or the late waves' inputs wait behind the early waves' slices (first pass 1.9 us later, measured).
+#if NEMPC_COOP_PROLOGUE_BARRIER
+    __builtin_amdgcn_s_barrier();
 #endif
+    // this wave's weight slices -> registers (kept for every pass): nload fully coalesced 1-KB loads off one base;
+    // first needed by hidden layer 1, so their latency hides under layer 0 of the first pass
+    constexpr int NFRAG = (NH - 1) * 2 * MT * 4 + 8;
+    constexpr int NLOAD = (NFRAG + VEC - 1) / VEC;
+    vecT wv[NLOAD];
+    {
+        const vecT* __restrict__ ws = static_cast<const vecT*>(a.wslice) + (size_t)w * NLOAD * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) {
+#ifdef NEMPC_EXP_NOWEIGHTS   // timing experiment only: how much of the prologue is the weight fetch
+            for (int e = 0; e < VEC; ++e) wv[k][e] = T(1e-3) * T(lane + k + e);
+#else
+            wv[k] = ws[k * 64];
+#endif
+        }
+    }
+    NEMPC_STAMP_A(1);
+    COOP_WGSTAMP(a.dbg, 3);
+
+    // ---- the rest of the context (scalar loads in the shadow of the vector loads above)
+    cx.w0f = lds + a.l_w0f;
+    cx.seed = lds + a.l_tail;
+    for (int l = 0; l < 3; ++l) cx.bias_off[l] = a.bias_off[l];
+    cx.biasL_off = a.biasL_off;
+    cx.X = lds + a.l_x;
+    cx.xhalf = a.l_xhalf;
+    cx.PART = lds + a.l_part;
+    // scratch and row info are double-buffered: pass k works in buffer k & 1 while the inputs of pass k + 1 land in
+    // the other one
+    T* const scr_base = lds + a.l_scratch;
+    int* const ri_base = reinterpret_cast<int*>(lds + a.l_rowinfo);
+    const int scr_sz = a.l_scratch2 - a.l_scratch, ri_sz = (a.l_rowinfo2 - a.l_rowinfo) * (int)(sizeof(T) / sizeof(int));
+    cx.SCR = scr_base;
+    cx.RI = ri_base;
+    cx.gout = static_cast<T*>(a.g);
+    cx.tiles = static_cast<T*>(a.tiles);
+    cx.m = a.m;
+    cx.gk = a.gk;
+    cx.stage_out = static_cast<T*>(a.stage_out); cx.stage_stride = a.stage_stride;
+    cx.NR = a.NR; cx.jsz = a.jsz; cx.spt = a.spt; cx.xt_off = a.xt_off; cx.ex_off = a.ex_off;
+    cx.inv32_jrow = a.inv32_jrow; cx.inv32_nx = a.inv32_nx; cx.inv_nin = a.inv_nin;
+    cx.rk4 = a.rk4 != 0; cx.nstages = a.nstages; cx.ks = a.ks; cx.kind = a.kind; cx.box = a.box;
+    cx.DT = (T)a.DT;
+    cx.dbg = a.dbg;
+
+    // small tables -> LDS (waits for the inputs and the tables only; the weight slices are still in flight)
+    {
+        vecT* ls = reinterpret_cast<vecT*>(lds + a.l_w0f);
+#pragma unroll
+        for (int u = 0; u < SMALL_PER_THREAD; ++u) {
+            const int idx = tid + u * NTHREADS;
+            if (idx < a.small_vecs) ls[idx] = sm[u];
+        }
+        const vecT* __restrict__ gs = static_cast<const vecT*>(a.small);
+        for (int idx = tid + SMALL_PER_THREAD * NTHREADS; idx < a.small_vecs; idx += NTHREADS) ls[idx] = gs[idx];
+    }
+    CoopWeights<T, WP, NH> W;
+    {
+        int f = 0;
+#pragma unroll
+        for (int l = 1; l < NH; ++l) {
+#pragma unroll
+            for (int i = 0; i < MT * 4; ++i, ++f) W.wf[l - 1][i] = wv[f / VEC][f % VEC];
+#pragma unroll
+            for (int i = 0; i < MT * 4; ++i, ++f) W.wb[l - 1][i] = wv[f / VEC][f % VEC];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r, ++f) W.wL[r] = wv[f / VEC][f % VEC];
+#pragma unroll
+        for (int r = 0; r < 4; ++r, ++f) W.w0b[r] = wv[f / VEC][f % VEC];
+    }
+#ifdef NEMPC_STAMPS
+    int npass = 0;
+#endif
+
+    int parity = 0;
+    if (early) stage_store<T, MT, TPW>(cx, cx.SCR, cx.RI, nact * 16, tid, sr);
+    while (t0 < t_end) {
+        const int t_cur = t0, n_cur = nact;
+        if (!early) stage_direct<T, MT, TPW>(cx, t_cur, n_cur * 16, tid);
+        // the NEXT pass's inputs are fetched now, under this pass (their registers are free again): without it every
+        // pass boundary exposed a full global round trip (2 us at B=1024 with both workgroups of the CU loading)
+        t0 += n_cur;
+        const bool pf = NEMPC_COOP_MIDSTAGE && early && t0 < t_end;
         if (t0 < t_end) {
             nact = t_end - t0 < TPW ? t_end - t0 : TPW;
             if (early) stage_load<T, MT, TPW>(cx, t0, nact * 16, tid, sr);
         }
+        lds_barrier();
+#ifdef NEMPC_STAMPS
+        if (npass < 4) COOP_WGSTAMP(a.dbg, 4 + 2 * npass);
+#endif
+        T* const scr_n = scr_base + (parity ^ 1) * scr_sz;
+        int* const ri_n = ri_base + (parity ^ 1) * ri_sz;
+        if (n_cur == 1) coop_pass<T, WP, NH, 1, SR, TPW>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16);
+        if constexpr (TPW >= 2) { if (n_cur == 2) coop_pass<T, WP, NH, 2, SR, TPW>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
+        if constexpr (TPW >= 3) { if (n_cur == 3) coop_pass<T, WP, NH, 3, SR, TPW>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
+        if constexpr (TPW >= 4) { if (n_cur == 4) coop_pass<T, WP, NH, 4, SR, TPW>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
+        if (!NEMPC_COOP_MIDSTAGE && early && t0 < t_end) stage_store<T, MT, TPW>(cx, scr_n, ri_n, nact * 16, tid, sr);
+        parity ^= 1;
+        cx.SCR = scr_n;
+        cx.RI = ri_n;
+#ifdef NEMPC_STAMPS
+        cx.dbg = nullptr;   // diagnostic build: keep the FIRST pass's stamps
+        if (npass < 4) COOP_WGSTAMP(a.dbg, 5 + 2 * npass);
+        ++npass;
+#endif
     }
-    NEMPC_STAMP(12);
+    NEMPC_STAMP_A(12);
+    COOP_WGSTAMP(a.dbg, 14);
+    COOP_WGSTAMP_REAL(a.dbg, 13);
 }
 
 }  // namespace nempc

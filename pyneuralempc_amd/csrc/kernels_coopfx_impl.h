@@ -1,0 +1,384 @@
+// Fixed-shape cooperative row kernel (gfx950): the CU-cooperative matrix-core kernel of kernels_coop_impl.h with the
+// problem shape (nx, nu) as template parameters, for plain models (window 1, no extra inputs) under the Discret / Unity
+// transcriptions -- BASELINE configs[1] and configs[4] (2 states, 1 control, MLP 2x64).
+//
+// Why a second instantiation family.  Per-wave stamps of the generic kernel (tools/diag_stamps.py) put ~55 % of a pass
+// in work that is not arithmetic: index arithmetic on runtime dims, scalar-register spills (100 SGPRs, 88 v_readlane per
+// pass), a separate reduction phase with its two barriers and a 4.5k-cycle epilogue for three stores per thread.  Two
+// waves share a SIMD; when both are in such phases the double-precision pipe idles (measured busy share 52 %).  With the
+// dims fixed every index folds to a constant, the LDS carve-up is a compile-time table, the K-split partials are summed
+// by the epilogue itself (no reduction phase), and row -> (problem, step) is two multiply-highs instead of an LDS table.
+//
+// Same math, same operand-layout trick and the same packed weights as the generic kernel (see kernels_mfma_impl.h and
+// kernels_coop_impl.h); results agree with it to rounding (the K-split partial sums are added in the same order).
+#pragma once
+
+#include "kernels_coop_impl.h"
+
+namespace nempc {
+
+template <typename T, int WP, int NH, int TPW, int NX, int NU>
+struct FxLayout {   // element offsets inside dynamic LDS, all compile-time
+    static constexpr int MT = WP / 16;
+    static constexpr int NIN = NX + NU;
+    static constexpr int KS = (NIN + 3) / 4;
+    static constexpr int NR = sizeof(T) == 8 ? (NIN + 3) / 4 : 4;   // accumulator registers holding the NIN input rows
+    static constexpr int NRO = sizeof(T) == 8 ? (NX + 3) / 4 : 4;   // ... the NX output rows
+    static constexpr int JROW = NX * NIN;
+    // small tables, copied flat from off.fx_small: [w0f | seed | bias_0..NH-1 | biasL]
+    static constexpr int W0F = 0;
+    static constexpr int SEED = W0F + KS * MT * 64;
+    static constexpr int BIAS = SEED + NX * MT * 16;
+    static constexpr int BIASL = BIAS + NH * MT * 16;
+    static constexpr int SMALL_END = BIASL + 16;
+    // exchange buffer: two halves of TPW activation sets (one cotangent per sweep)
+    static constexpr int XH = TPW * MT * 256;
+    static constexpr int X = (SMALL_END + 15) & ~15;
+    // K-split partials: slot 0 = network output, slots 1..NX = Jacobian row k; per (slot, tile, wave): NR x 64 lanes
+    static constexpr int PART = X + 2 * XH;
+    static constexpr int PART_SZ = (NRO + NX * NR) * TPW * MT * 64;
+    // inputs, double-buffered: per tile xi[16][NIN] then xt[16][NX]
+    static constexpr int IN_TILE = 16 * (NIN + NX);
+    static constexpr int IN = PART + PART_SZ;
+    static constexpr int IN_SZ = (TPW * IN_TILE + 15) & ~15;
+    static constexpr int TOTAL = IN + 2 * IN_SZ;
+};
+
+struct FxArgs {   // host-prepared; the fields the first loads need come first
+    const void* Z;
+    const void* X0;
+    const void* small;      // blob + off.fx_small
+    const void* wslice;     // blob + off.coop_slices
+    int tiles_per_wg, tiles_rem;
+    unsigned R;             // rows = B*H
+    unsigned invH;          // ceil(2^32 / H), 0 for H == 1
+    int H, n, m;
+    int ident;              // 1: Discret (Phi = x + f), 0: Unity
+    int box;
+    int small_vecs;
+    void* g;
+    void* tiles;
+};
+
+template <typename T, int WP, int NH, int TPW, int NX, int NU>
+struct FxCtx {
+    using L = FxLayout<T, WP, NH, TPW, NX, NU>;
+    T* lds;
+    const T* __restrict__ Z;
+    const T* __restrict__ X0;
+    T* __restrict__ gout;
+    T* __restrict__ tiles;
+    unsigned R, invH;
+    int H, n, m, ident, box;
+};
+
+// inputs of a pass: item = (column, row); columns = NIN network inputs then the NX current states x_t
+template <typename T, int NT, int NTHREADS, int NCOL>
+struct FxStage {
+    static constexpr int ROWS = NT * 16;
+    static constexpr int ITEMS = (NCOL * ROWS + NTHREADS - 1) / NTHREADS;
+    T v[ITEMS];
+};
+
+template <typename T, int WP, int NH, int TPW, int NX, int NU, int NT>
+__device__ __forceinline__ void fx_stage_load(const FxCtx<T, WP, NH, TPW, NX, NU>& cx, int t0, int tid,
+                                              FxStage<T, NT, (WP / 16) * 64, NX + NU + NX>& sr) {
+    constexpr int NIN = NX + NU, NCOL = NIN + NX, ROWS = NT * 16, NTHREADS = (WP / 16) * 64;
+#pragma unroll
+    for (int it = 0; it < FxStage<T, NT, NTHREADS, NCOL>::ITEMS; ++it) {
+        const int item = tid + it * NTHREADS;
+        const int col = item / ROWS, idx = item - col * ROWS;      // compile-time divisor
+        T v = T(0);
+        const unsigned r = (unsigned)t0 * 16u + (unsigned)idx;
+        if (col < NCOL && r < cx.R) {
+            const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
+            const int t = (int)(r - b * (unsigned)cx.H);
+            const T* z = cx.Z + (size_t)b * cx.n;
+            if (col < NX) v = (t == 0) ? cx.X0[(size_t)b * NX + col] : z[(t - 1) * NX + col];
+            else if (col < NIN) v = z[cx.H * NX + t * NU + (col - NX)];
+            else v = z[t * NX + (col - NIN)];
+        }
+        sr.v[it] = v;
+    }
+}
+
+template <typename T, int WP, int NH, int TPW, int NX, int NU, int NT>
+__device__ __forceinline__ void fx_stage_store(T* in, int tid, const FxStage<T, NT, (WP / 16) * 64, NX + NU + NX>& sr) {
+    constexpr int NIN = NX + NU, NCOL = NIN + NX, ROWS = NT * 16, NTHREADS = (WP / 16) * 64;
+    using L = FxLayout<T, WP, NH, TPW, NX, NU>;
+#pragma unroll
+    for (int it = 0; it < FxStage<T, NT, NTHREADS, NCOL>::ITEMS; ++it) {
+        const int item = tid + it * NTHREADS;
+        const int col = item / ROWS, idx = item - col * ROWS;
+        if (col < NCOL) {
+            T* tile = in + (idx >> 4) * L::IN_TILE;
+            if (col < NIN) tile[(idx & 15) * NIN + col] = sr.v[it];
+            else tile[16 * NIN + (idx & 15) * NX + (col - NIN)] = sr.v[it];
+        }
+    }
+}
+
+// One pass over NT tiles starting at tile t0, inputs in `in`.
+template <typename T, int WP, int NH, int TPW, int NX, int NU, int NT>
+__device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx, const CoopWeights<T, WP, NH>& W,
+                                        const T* in, int t0, int tid, int& xsel) {
+    using Ops = MfmaOps<T>;
+    using V4 = typename Ops::V4;
+    using L = FxLayout<T, WP, NH, TPW, NX, NU>;
+    constexpr int MT = WP / 16, NTHREADS = MT * 64, NIN = NX + NU, KS = L::KS, NR = L::NR, NRO = L::NRO, JROW = L::JROW;
+    const int lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    T* const lds = cx.lds;
+    T* const PART = lds + L::PART;
+
+    V4 a[NH][NT];
+    // ---- layer 0, this wave's feature block
+    {
+        const T* bias = lds + L::BIAS + w * 16;
+        V4 b0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b0[r] = bias[r * 4 + q];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) a[0][j] = b0;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const T wfrag = lds[L::W0F + (ks * MT + w) * 64 + lane];
+            const int d = 4 * ks + q;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const T v = d < NIN ? in[j * L::IN_TILE + c * NIN + d] : T(0);
+                a[0][j] = Ops::mma(wfrag, v, a[0][j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[0][j][r] = Ops::tanh_(a[0][j][r]);
+    }
+    // ---- hidden-to-hidden layers through the double-buffered exchange area (see kernels_coop_impl.h)
+#pragma unroll
+    for (int l = 1; l < NH; ++l) {
+        T* X = lds + L::X + (xsel & 1) * L::XH;
+        ++xsel;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[((j * MT + w) * 4 + r) * 64 + lane] = a[l - 1][j][r];
+        lds_barrier();
+        const T* bias = lds + L::BIAS + l * MT * 16 + w * 16;
+        V4 b0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b0[r] = bias[r * 4 + q];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) a[l][j] = b0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    a[l][j] = Ops::mma(W.wf[l - 1][mt * 4 + r], X[((j * MT + mt) * 4 + r) * 64 + lane], a[l][j]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[l][j][r] = Ops::tanh_(a[l][j][r]);
+    }
+    // ---- network output: K-split partial over this wave's block
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        V4 pf = V4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf = Ops::mma(W.wL[r], a[NH - 1][j][r], pf);
+#pragma unroll
+        for (int r = 0; r < NRO; ++r) PART[((j * MT + w) * NRO + r) * 64 + lane] = pf[r];
+    }
+#pragma unroll
+    for (int l = 0; l < NH; ++l)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) a[l][j] = T(1) - a[l][j] * a[l][j];
+
+    // ---- reverse sweep, one cotangent (network output) at a time
+    T* const PJ = PART + NRO * TPW * MT * 64;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        V4 cv[NT];
+        {
+            const T* seed = lds + L::SEED + k * MT * 16 + w * 16;
+            V4 sd;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sd[r] = seed[r * 4 + q];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) cv[j] = sd * a[NH - 1][j];
+        }
+#pragma unroll
+        for (int l = NH - 1; l >= 1; --l) {
+            T* X = lds + L::X + (xsel & 1) * L::XH;
+            ++xsel;
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[((j * MT + w) * 4 + r) * 64 + lane] = cv[j][r];
+            lds_barrier();
+            V4 cn[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) cn[j] = V4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        cn[j] = Ops::mma(W.wb[l - 1][mt * 4 + r], X[((j * MT + mt) * 4 + r) * 64 + lane], cn[j]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) cv[j] = cn[j] * a[l - 1][j];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            V4 pj = V4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pj = Ops::mma(W.w0b[r], cv[j][r], pj);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) PJ[(((k * TPW + j) * MT + w) * NR + r) * 64 + lane] = pj[r];
+        }
+    }
+    lds_barrier();
+
+    // ---- outputs straight from the partials (no reduction phase): the sum over the MT waves is taken here, in wave
+    //      order like the generic kernel's reduction
+    // tiles: the pass's NT*16 rows are contiguous in memory -> lanes run over the flat element index (coalesced)
+#pragma unroll
+    for (int it = 0; it < (NT * 16 * JROW + NTHREADS - 1) / NTHREADS; ++it) {
+        const int item = tid + it * NTHREADS;
+        const int idx = item / JROW, kd = item - idx * JROW;     // compile-time divisors
+        const int k = kd / NIN, d = kd - k * NIN;
+        const unsigned r = (unsigned)t0 * 16u + (unsigned)idx;
+        if (item < NT * 16 * JROW && r < cx.R) {
+            const int j = idx >> 4, cc = idx & 15;
+            const int qq = sizeof(T) == 8 ? (d & 3) : (d >> 2), rr = sizeof(T) == 8 ? (d >> 2) : (d & 3);
+            T v = T(0);
+#pragma unroll
+            for (int ww = 0; ww < MT; ++ww) v += PJ[(((k * TPW + j) * MT + ww) * NR + rr) * 64 + qq * 16 + cc];
+            if (cx.ident && d == k) v += T(1);
+            cx.tiles[(size_t)t0 * (16 * JROW) + item] = v;
+        }
+    }
+    // defects: lanes run over (row, state) with the state fastest -> contiguous inside a problem
+#pragma unroll
+    for (int it = 0; it < (NT * 16 * NX + NTHREADS - 1) / NTHREADS; ++it) {
+        const int item = tid + it * NTHREADS;
+        const int idx = item / NX, i = item - idx * NX;
+        const unsigned r = (unsigned)t0 * 16u + (unsigned)idx;
+        if (item < NT * 16 * NX && r < cx.R) {
+            const int j = idx >> 4, cc = idx & 15;
+            const int qq = sizeof(T) == 8 ? (i & 3) : (i >> 2), rr = sizeof(T) == 8 ? (i >> 2) : (i & 3);
+            T f = lds[L::BIASL + rr * 4 + qq];
+#pragma unroll
+            for (int ww = 0; ww < MT; ++ww) f += PART[((j * MT + ww) * NRO + rr) * 64 + qq * 16 + cc];
+            const T* tin = in + j * L::IN_TILE;
+            const T xp = tin[cc * NIN + i];
+            const T xt = tin[16 * NIN + cc * NX + i];
+            const T phi = (cx.ident ? xp : T(0)) + f;
+            const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
+            const int t = (int)(r - b * (unsigned)cx.H);
+            T* gp = cx.gout + (size_t)b * cx.m + t * NX + i;
+            gp[0] = phi - xt;
+            if (cx.box) gp[(size_t)cx.H * NX] = xt;
+        }
+    }
+    lds_barrier();
+}
+
+template <typename T, int WP, int NH, int TPW, int NX, int NU>
+__global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a) {
+    using L = FxLayout<T, WP, NH, TPW, NX, NU>;
+    constexpr int MT = WP / 16;
+    constexpr int NTHREADS = MT * 64;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    constexpr int NCOL = NX + NU + NX;
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T* lds = reinterpret_cast<T*>(lds_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+
+    FxCtx<T, WP, NH, TPW, NX, NU> cx;
+    cx.lds = lds;
+    cx.Z = static_cast<const T*>(a.Z);
+    cx.X0 = static_cast<const T*>(a.X0);
+    cx.R = a.R; cx.invH = a.invH; cx.H = a.H; cx.n = a.n;
+
+    const int t_begin = blockIdx.x * a.tiles_per_wg + ((int)blockIdx.x < a.tiles_rem ? (int)blockIdx.x : a.tiles_rem);
+    const int t_end = t_begin + a.tiles_per_wg + ((int)blockIdx.x < a.tiles_rem ? 1 : 0);
+
+    // ---- every global load of the prologue is issued before anything waits: inputs, small tables, weight slices.
+    //      The staging registers always cover a full TPW-tile pass; a shorter pass just leaves rows unused.
+    FxStage<T, TPW, NTHREADS, NCOL> sr;
+    int t0 = t_begin;
+    fx_stage_load<T, WP, NH, TPW, NX, NU, TPW>(cx, t0, tid, sr);
+    constexpr int SMALL_VECS = (L::SMALL_END + VEC - 1) / VEC;
+    constexpr int SMALL_PER_THREAD = (SMALL_VECS + NTHREADS - 1) / NTHREADS;
+    vecT sm[SMALL_PER_THREAD];
+    {
+        const vecT* __restrict__ gs = static_cast<const vecT*>(a.small);
+#pragma unroll
+        for (int u = 0; u < SMALL_PER_THREAD; ++u) {
+            const int idx = tid + u * NTHREADS;
+            if (idx < SMALL_VECS) sm[u] = gs[idx];
+        }
+    }
+    constexpr int NFRAG = (NH - 1) * 2 * MT * 4 + 8;
+    constexpr int NLOAD = (NFRAG + VEC - 1) / VEC;
+    vecT wv[NLOAD];
+    {
+        const vecT* __restrict__ ws = static_cast<const vecT*>(a.wslice) + (size_t)w * NLOAD * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) wv[k] = ws[k * 64];
+    }
+    cx.gout = static_cast<T*>(a.g);
+    cx.tiles = static_cast<T*>(a.tiles);
+    cx.m = a.m; cx.ident = a.ident; cx.box = a.box;
+    {
+        vecT* ls = reinterpret_cast<vecT*>(lds + L::W0F);
+#pragma unroll
+        for (int u = 0; u < SMALL_PER_THREAD; ++u) {
+            const int idx = tid + u * NTHREADS;
+            if (idx < SMALL_VECS) ls[idx] = sm[u];
+        }
+    }
+    CoopWeights<T, WP, NH> W;
+    {
+        int f = 0;
+#pragma unroll
+        for (int l = 1; l < NH; ++l) {
+#pragma unroll
+            for (int i = 0; i < MT * 4; ++i, ++f) W.wf[l - 1][i] = wv[f / VEC][f % VEC];
+#pragma unroll
+            for (int i = 0; i < MT * 4; ++i, ++f) W.wb[l - 1][i] = wv[f / VEC][f % VEC];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r, ++f) W.wL[r] = wv[f / VEC][f % VEC];
+#pragma unroll
+        for (int r = 0; r < 4; ++r, ++f) W.w0b[r] = wv[f / VEC][f % VEC];
+    }
+
+    int parity = 0, xsel = 0;
+    T* const in_base = lds + L::IN;
+    fx_stage_store<T, WP, NH, TPW, NX, NU, TPW>(in_base, tid, sr);
+    while (t0 < t_end) {
+        const int t_cur = t0;
+        const int n_cur = t_end - t0 < TPW ? t_end - t0 : TPW;
+        t0 += n_cur;
+        const bool more = t0 < t_end;
+        if (more) fx_stage_load<T, WP, NH, TPW, NX, NU, TPW>(cx, t0, tid, sr);   // next pass's inputs, under this pass
+        lds_barrier();
+        const T* in = in_base + parity * L::IN_SZ;
+        if (n_cur == 1) fx_pass<T, WP, NH, TPW, NX, NU, 1>(cx, W, in, t_cur, tid, xsel);
+        if constexpr (TPW >= 2) { if (n_cur == 2) fx_pass<T, WP, NH, TPW, NX, NU, 2>(cx, W, in, t_cur, tid, xsel); }
+        if constexpr (TPW >= 3) { if (n_cur == 3) fx_pass<T, WP, NH, TPW, NX, NU, 3>(cx, W, in, t_cur, tid, xsel); }
+        parity ^= 1;
+        if (more) fx_stage_store<T, WP, NH, TPW, NX, NU, TPW>(in_base + parity * L::IN_SZ, tid, sr);
+    }
+}
+
+}  // namespace nempc

@@ -17,7 +17,7 @@ int padded_width(const Handle& h) {
     return 0;
 }
 
-MfmaOffsets make_offsets(int wp, int nh, int ks, int nx, int nin) {
+MfmaOffsets make_offsets(int wp, int nh, int ks, int nx, int nin, int esz) {
     const int MT = wp / 16;
     MfmaOffsets o{};
     int p = 0;
@@ -32,6 +32,16 @@ MfmaOffsets make_offsets(int wp, int nh, int ks, int nx, int nin) {
     for (int l = 0; l < nh; ++l) { o.bias[l] = p; p += MT * 16; }
     o.biasL = p; p += 16;
     o.total = p;
+    // cooperative-kernel copies (16-byte aligned: every size above is a multiple of 16 elements)
+    const int vec = 16 / esz;
+    const int nfrag = (nh - 1) * 2 * MT * 4 + 8;
+    o.coop_small = p;
+    o.coop_small_elems = ks * MT * 64 + (o.total - o.seed);
+    p += (o.coop_small_elems + 15) & ~15;
+    o.coop_nload = (nfrag + vec - 1) / vec;
+    o.coop_slices = p;
+    p += MT * o.coop_nload * 64 * vec;
+    o.grand_total = p;
     return o;
 }
 
@@ -67,9 +77,9 @@ int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b)
     const int nx = h.cfg.nx, nin = h.nin, ks = (nin + h.ne + 3) / 4, L = h.nl - 1;
     const bool f64 = h.cfg.dtype == NEMPC_F64;
     auto row = [&](int q, int r) { return f64 ? MfmaOps<double>::row(q, r) : MfmaOps<float>::row(q, r); };
-    const MfmaOffsets o = make_offsets(wp, nh, ks, nx, nin);
+    const MfmaOffsets o = make_offsets(wp, nh, ks, nx, nin, (int)h.esz);
     const int MB = (nin + 15) / 16;
-    std::vector<double> blob((size_t)o.total, 0.0);
+    std::vector<double> blob((size_t)o.grand_total, 0.0);
     auto Wat = [&](int l, int i, int j) -> double {
         return (i < h.din[l] && j < h.dout[l]) ? W[l][(size_t)i * h.dout[l] + j] : 0.0;
     };
@@ -108,6 +118,27 @@ int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b)
             blob[o.biasL + r * 4 + q] = (oo < nx) ? b[L][oo] : 0.0;
         }
 
+    // cooperative-kernel copies (only meaningful when the last reverse step has one 16-row block, MB == 1)
+    {
+        const int vec = 16 / (int)h.esz;
+        for (int i = 0; i < ks * MT * 64; ++i) blob[o.coop_small + i] = blob[o.w0f + i];
+        for (int i = 0; i < o.total - o.seed; ++i) blob[o.coop_small + ks * MT * 64 + i] = blob[o.seed + i];
+        for (int w = 0; w < MT; ++w)
+            for (int lane = 0; lane < 64; ++lane) {
+                int fidx = 0;
+                auto put = [&](double v) {
+                    blob[o.coop_slices + ((size_t)(w * o.coop_nload + fidx / vec) * 64 + lane) * vec + fidx % vec] = v;
+                    ++fidx;
+                };
+                for (int l = 1; l < nh; ++l) {
+                    for (int i = 0; i < MT * 4; ++i) put(blob[o.wf[l] + (i * MT + w) * 64 + lane]);
+                    for (int i = 0; i < MT * 4; ++i) put(blob[o.wb[l] + (i * MT + w) * 64 + lane]);
+                }
+                for (int r = 0; r < 4; ++r) put(blob[o.wLf + (w * 4 + r) * 64 + lane]);
+                for (int r = 0; r < 4; ++r) put(blob[o.w0b + ((w * 4 + r) * MB) * 64 + lane]);
+            }
+    }
+
     mfma_free(h);
     hipError_t e = hipMalloc(&h.mfma.blob, blob.size() * h.esz);
     if (e != hipSuccess) {
@@ -141,7 +172,7 @@ int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, voi
     p.blob = h.mfma.blob;
     p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4; p.mb = (h.nin + 15) / 16;
     p.ne = h.ne; p.extra = h.d_extra;
-    p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin);
+    p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin, (int)h.esz);
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
     p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
@@ -169,7 +200,7 @@ int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, 
     p.blob = h.mfma.blob;
     p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4; p.mb = (h.nin + 15) / 16;
     p.ne = h.ne; p.extra = h.d_extra;
-    p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin);
+    p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin, (int)h.esz);
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
     p.Z = Z; p.X0 = X0; p.g = nullptr; p.tiles = nullptr;

@@ -31,6 +31,12 @@ struct MfmaOffsets {  // element offsets into the packed blob
     int p0tab, wLb;  // Hessian kernel tables: first-layer rows W_0[p,:], output-layer fragments for W_L lambda
     int wf[3], wb[3], bias[3];
     int total;
+    // cooperative row kernel: the same numbers once more, laid out for its prologue (kernels_coop_impl.h) --
+    //   coop_small   [w0f | seed | bias_l | biasL] contiguous (one flat copy to LDS),
+    //   coop_slices  per wave: its register-resident fragments (wf, wb per hidden layer, wL, w0b) as 16-byte
+    //                lane vectors, load k of lane = element ((wave * coop_nload + k) * 64 + lane) * VEC
+    int coop_small, coop_small_elems, coop_slices, coop_nload;
+    int grand_total;
 };
 
 struct MfmaParams {

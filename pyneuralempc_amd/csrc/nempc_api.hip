@@ -619,17 +619,19 @@ int nempc_sync(nempc_handle hh, void* stream) {
 }
 
 #ifdef NEMPC_STAMPS
-// diagnostic library only (tools/diag_stamps.py): allocate / read the stamp buffer (16 waves x 64 stamps)
+// diagnostic library only (tools/diag_stamps.py): allocate / read the stamp buffer: 16 waves x 64 phase stamps of
+// workgroup 0, then 16 words per workgroup (timeline of every workgroup, 4096 workgroups at most)
+#define NEMPC_DBG_WORDS (1024 + 4096 * 16)
 int nempc_debug_stamps(nempc_handle hh, long long* host_out) {
     Handle& h = *reinterpret_cast<Handle*>(hh);
     DeviceGuard dg(h.cfg.device);
     if (!h.d_dbg) {
-        NEMPC_HIP(hipMalloc((void**)&h.d_dbg, sizeof(long long) * 1024));
-        NEMPC_HIP(hipMemset(h.d_dbg, 0, sizeof(long long) * 1024));
+        NEMPC_HIP(hipMalloc((void**)&h.d_dbg, sizeof(long long) * NEMPC_DBG_WORDS));
+        NEMPC_HIP(hipMemset(h.d_dbg, 0, sizeof(long long) * NEMPC_DBG_WORDS));
         return NEMPC_OK;
     }
     NEMPC_HIP(hipDeviceSynchronize());
-    NEMPC_HIP(hipMemcpy(host_out, h.d_dbg, sizeof(long long) * 1024, hipMemcpyDeviceToHost));
+    NEMPC_HIP(hipMemcpy(host_out, h.d_dbg, sizeof(long long) * NEMPC_DBG_WORDS, hipMemcpyDeviceToHost));
     return NEMPC_OK;
 }
 #endif

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Build a variant of libnempc.so with extra -D flags into pyneuralempc_amd/build_<tag>/libnempc_<tag>.so (A/B kernel
+experiments; run with NEMPC_LIB=<that path>).   python tools/build_variant.py <tag> [-DNAME=VALUE ...] [--only a.hip,b.hip]"""
+import os, subprocess, sys
+from concurrent.futures import ThreadPoolExecutor
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from pyneuralempc_amd import _build
+
+def main():
+    tag = sys.argv[1]
+    defs = [a for a in sys.argv[2:] if a.startswith("-D")]
+    out = os.path.join(_build.PKG, f"build_{tag}")
+    os.makedirs(out, exist_ok=True)
+    # only the translation units that see the kernels are rebuilt with the flags; the rest come from the main build
+    kern = {"kernels_mfma_f64.hip", "kernels_mfma_f32.hip"} if "--all" not in sys.argv else set(_build.SOURCES)
+    _build.build(verbose=False)
+    def one(src):
+        if src in kern:
+            o = os.path.join(out, src.replace(".hip", ".o"))
+            subprocess.run([_build._hipcc()] + _build.FLAGS + defs + ["-c", os.path.join(_build.CSRC, src), "-o", o], check=True)
+            return o
+        return os.path.join(_build.PKG, "build", src.replace(".hip", ".o"))
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, _build.SOURCES))
+    lib = os.path.join(out, f"libnempc_{tag}.so")
+    subprocess.run([_build._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"], check=True)
+    print(lib)
+
+if __name__ == "__main__":
+    main()

@@ -40,10 +40,61 @@ if __name__ == "__main__":
     want = ("g", "jac_dense") if (len(sys.argv) > 3 and sys.argv[3] == "dense") else ("g", "jac_tiles")
     for _ in range(3):
         eng.eval(Z, X0, want)
-    buf = np.zeros(1024, dtype=np.int64)
+    buf = np.zeros(1024 + 4096 * 16, dtype=np.int64)
     eng.lib.nempc_debug_stamps(eng._handle, buf.ctypes.data_as(ctypes.c_void_p))
-    st = buf.reshape(16, 64)
+    st = buf[:1024].reshape(16, 64)
+    # ---- timeline of every workgroup (100 MHz ticks -> us), last evaluation
+    wg = buf[1024:].reshape(4096, 16)
+    live = wg[:, 0] != 0
+    wg = wg[live]
+    # shader-clock stamps; the one real-time stamp (word 13, taken right after the exit stamp, word 14) puts the
+    # workgroups on a common axis: t(event) = real_exit - (clk_exit - clk_event) / f
+    span_clk = (wg[:, 14] - wg[:, 0]).astype(np.float64)
+    f_mhz = float(os.environ.get("NEMPC_CLK_MHZ", "0")) or None
+    if f_mhz is None:
+        # clock from the spread of exits: among workgroups of one XCD the shader counter is common
+        f_mhz = 2250.0
+    real_exit_us = wg[:, 13] / 100.0
+    T = np.zeros(wg.shape, dtype=np.float64)            # every stamp of every workgroup on the common axis, us
+    for i in range(15):
+        T[:, i] = real_exit_us - (wg[:, 14] - wg[:, i]) / f_mhz
+    T -= T[:, 0].min()
+    T[wg == 0] = np.nan
+    hw = wg[:, 15]
+    xcc = (hw >> 32) & 0xF
+    hwid = hw & 0xFFFFFFFF
+    cu = (hwid >> 8) & 0xF
+    sh = (hwid >> 12) & 0x1
+    se = (hwid >> 13) & 0x7
+    cukey = xcc * 1000 + se * 100 + sh * 10 + cu
+    print(f"workgroups {len(wg)}, distinct CUs {len(set(cukey.tolist()))}, XCCs {sorted(set(xcc.tolist()))}")
+    print(f"kernel span (first entry -> last exit): {np.nanmax(T[:, 14]):.2f} us   [shader clock assumed {f_mhz:.0f} MHz; "
+          f"median workgroup lifetime {np.median(span_clk):.0f} cycles]")
+    names = ["entry", "stage_ld issued", "blob->LDS", "weights issued", "p1 staged", "p1 done", "p2 staged", "p2 done",
+             "p3 staged", "p3 done"]
+    for lo, hi, label in ((0, 256, "wg 0..255 (one tile more)"), (256, 512, "wg 256..511")):
+        sel = wg[lo:hi]
+        if not len(sel): continue
+        print(label)
+        for i, nm in enumerate(names):
+            col = sel[:, i]
+            ok = col != 0
+            if ok.any():
+                v = T[lo:hi, i][ok]
+                print(f"   {nm:>16s}: min {v.min():6.2f}  median {np.median(v):6.2f}  max {v.max():6.2f} us   (n={ok.sum()})")
+        v = T[lo:hi, 14]
+        print(f"   {'exit':>16s}: min {v.min():6.2f}  median {np.median(v):6.2f}  max {v.max():6.2f} us")
+    # per-CU occupancy: how many workgroups per CU, and whether the two of a CU overlap
+    from collections import defaultdict
+    per = defaultdict(list)
+    for i in range(len(wg)):
+        per[int(cukey[i])].append(i)
+    cnt = defaultdict(int)
+    for k, v in per.items(): cnt[len(v)] += 1
+    print("workgroups per CU histogram:", dict(cnt))
+    np.save(os.path.join(REPO, "gpurun_out", "wg_timeline.npy"), wg)
     for w in range(8):
         s = st[w][:13]
         if s[0] == 0: continue
-        print(f"wave {w}: " + " ".join(f"{i}:{int(s[i + 1] - s[i]):>6d}" for i in range(12) if s[i] and s[i + 1]) + f"   total {int(s[12]-s[0])}")
+        idx = [i for i in range(13) if s[i]]
+        print(f"wave {w}: " + " ".join(f"{a}>{b}:{int(s[b] - s[a]):>6d}" for a, b in zip(idx[:-1], idx[1:])) + f"   total {int(s[12]-s[0])}")
