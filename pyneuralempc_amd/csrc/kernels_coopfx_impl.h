@@ -14,6 +14,7 @@
 #pragma once
 
 #include "kernels_coop_impl.h"
+#include "kernels_obj_impl.h"
 
 namespace nempc {
 
@@ -57,7 +58,15 @@ struct FxArgs {   // host-prepared; the fields the first loads need come first
     int box;
     int small_vecs;
     void* g;
-    void* tiles;
+    void* tiles;            // may be null in the fused evaluation (nobody asked for the compact tiles)
+    // ---- fused evaluation (FUSE instantiation): the dense Jacobian rows and the objective of the workgroup's
+    //      problems leave from the same launch; the separate assembly launch and its boundary disappear
+    void* jac;              // (B, m, n) dense, 16-byte aligned, n a multiple of the vector width
+    void* f;                // (B) or null
+    void* grad;             // (B, n) or null
+    const void* P;          // objective table (Handle::d_obj), copied to LDS behind the layout
+    int p_elems;
+    ObjOffsets oo;
 };
 
 template <typename T, int WP, int NH, int TPW, int NX, int NU>
@@ -70,6 +79,7 @@ struct FxCtx {
     T* __restrict__ tiles;
     unsigned R, invH;
     int H, n, m, ident, box;
+    T* __restrict__ jac;
 };
 
 // inputs of a pass: item = (column, row); columns = NIN network inputs then the NX current states x_t
@@ -119,9 +129,13 @@ __device__ __forceinline__ void fx_stage_store(T* in, int tid, const FxStage<T, 
 }
 
 // One pass over NT tiles starting at tile t0, inputs in `in`.
-template <typename T, int WP, int NH, int TPW, int NX, int NU, int NT>
+// `nxt` / `in_next` (when has_next): the NEXT pass's inputs, already in registers; they go to the other input buffer
+// BEFORE this pass's global stores are issued -- vmcnt counts stores too and retires in order, so a wait for those loads
+// placed after the stores would sit out the stores' acknowledgement (with the dense rows fused in: the whole HBM time).
+template <typename T, int WP, int NH, int TPW, int NX, int NU, int NT, bool FUSE>
 __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx, const CoopWeights<T, WP, NH>& W,
-                                        const T* in, int t0, int tid, int& xsel) {
+                                        const T* in, int t0, int tid, int& xsel,
+                                        const FxStage<T, TPW, (WP / 16) * 64, NX + NU + NX>& nxt, bool has_next, T* in_next) {
     using Ops = MfmaOps<T>;
     using V4 = typename Ops::V4;
     using L = FxLayout<T, WP, NH, TPW, NX, NU>;
@@ -242,10 +256,13 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
         }
     }
     lds_barrier();
+    if (has_next) fx_stage_store<T, WP, NH, TPW, NX, NU, TPW>(in_next, tid, nxt);
 
     // ---- outputs straight from the partials (no reduction phase): the sum over the MT waves is taken here, in wave
     //      order like the generic kernel's reduction
-    // tiles: the pass's NT*16 rows are contiguous in memory -> lanes run over the flat element index (coalesced)
+    // tiles: the pass's NT*16 rows are contiguous in memory -> lanes run over the flat element index (coalesced).
+    // The fused evaluation also keeps them in LDS (TS, on the now idle exchange area) for the dense rows below.
+    T* const TS = lds + L::X;
 #pragma unroll
     for (int it = 0; it < (NT * 16 * JROW + NTHREADS - 1) / NTHREADS; ++it) {
         const int item = tid + it * NTHREADS;
@@ -259,7 +276,8 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
             for (int ww = 0; ww < MT; ++ww) v += PJ[(((k * TPW + j) * MT + ww) * NR + rr) * 64 + qq * 16 + cc];
             if (cx.ident && d == k) v += T(1);
-            cx.tiles[(size_t)t0 * (16 * JROW) + item] = v;
+            if (!FUSE || cx.tiles) cx.tiles[(size_t)t0 * (16 * JROW) + item] = v;
+            if (FUSE) TS[item] = v;
         }
     }
     // defects: lanes run over (row, state) with the state fastest -> contiguous inside a problem
@@ -285,10 +303,70 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             if (cx.box) gp[(size_t)cx.H * NX] = xt;
         }
     }
+    if constexpr (FUSE) {
+        // ---- dense Jacobian rows of the pass (integrator/discret.py:38-56, unity.py:38-56; ipopt.py:88-96): row (t, i)
+        //      of problem b holds -1 at x_t[i], the tile's state block at x_{t-1} (t >= 1), its control block at u_t,
+        //      zeros elsewhere.  32 lanes stream one row as 16-byte vectors (lane -> column pair is fixed, so the
+        //      column classification is hoisted), 8 rows per sweep of the workgroup; box rows (+1 selectors) follow.
+        lds_barrier();
+        constexpr int VEC = 16 / (int)sizeof(T);
+        typedef T vecT __attribute__((ext_vector_type(VEC)));
+        constexpr int LPR = 32, RPS = NTHREADS / LPR;          // lanes per row, rows per sweep
+        const int HNX = cx.H * NX, nvec = cx.n / VEC;
+        const int lsub = tid & (LPR - 1), rsub = tid / LPR;
+        for (int ch = 0; ch * LPR < nvec; ++ch) {
+            const int cvx = lsub + ch * LPR;
+            const int col0 = cvx * VEC;
+            // per column of this lane's vector: which step's state / control it is
+            int tc[VEC], ic[VEC];
+            bool isx[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int col = col0 + e;
+                isx[e] = col < HNX;
+                const int cu = col - HNX;
+                tc[e] = isx[e] ? col / NX : cu / NU;
+                ic[e] = isx[e] ? col - tc[e] * NX : NX + (cu - tc[e] * NU);     // tile column d when the step matches
+            }
+            if (cvx < nvec) {
+#pragma unroll
+                for (int sw = 0; sw < (NT * 16 * NX + RPS - 1) / RPS; ++sw) {
+                    const int lr = sw * RPS + rsub;                    // dense row of the pass: (local row, state i)
+                    const int lrow = lr / NX, i = lr - lrow * NX;
+                    const unsigned r = (unsigned)t0 * 16u + (unsigned)lrow;
+                    if (lr < NT * 16 * NX && r < cx.R) {
+                        const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
+                        const int t = (int)(r - b * (unsigned)cx.H);
+                        const T* ts = TS + lrow * JROW + i * NIN;
+                        vecT v;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            // state column of step t-1 / control column of step t -> tile entry; x_t[i] -> -1
+                            const bool hit = isx[e] ? (tc[e] == t - 1) : (tc[e] == t);
+                            T val = hit ? ts[ic[e]] : T(0);
+                            if (isx[e] && tc[e] == t && ic[e] == i) val = T(-1);
+                            v[e] = val;
+                        }
+                        T* row = cx.jac + ((size_t)b * cx.m + t * NX + i) * cx.n;
+                        // write-through (sc0 sc1): the rows go out to memory as they are issued instead of sitting dirty in
+                        // L2 until the end-of-kernel write-back (C2, B=1024: whole evaluation 21.9 -> 20.3 us)
+                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(row + col0), "v"(v) : "memory");
+                        if (cx.box) {
+                            vecT o1;
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) o1[e] = (isx[e] && tc[e] == t && ic[e] == i) ? T(1) : T(0);
+                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(row + (size_t)HNX * cx.n + col0), "v"(o1) : "memory");
+                        }
+                    }
+                }
+            }
+        }
+    }
     lds_barrier();
 }
 
-template <typename T, int WP, int NH, int TPW, int NX, int NU>
+// FUSE: the whole hessian-free evaluation in this launch -- g, [tiles,] dense jac, f, grad
+template <typename T, int WP, int NH, int TPW, int NX, int NU, bool FUSE = false>
 __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a) {
     using L = FxLayout<T, WP, NH, TPW, NX, NU>;
     constexpr int MT = WP / 16;
@@ -327,6 +405,18 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a
             if (idx < SMALL_VECS) sm[u] = gs[idx];
         }
     }
+    // fused evaluation: the objective table rides along (-> LDS behind the layout, read at the very end); tables
+    // beyond PV_PER_THREAD * NTHREADS elements (horizons past ~80 steps) are completed just before they are used
+    constexpr int PV_PER_THREAD = 2;
+    T pv[PV_PER_THREAD];
+    if constexpr (FUSE) {
+        const T* __restrict__ gp = static_cast<const T*>(a.P);
+#pragma unroll
+        for (int u = 0; u < PV_PER_THREAD; ++u) {
+            const int idx = tid + u * NTHREADS;
+            pv[u] = idx < a.p_elems ? gp[idx] : T(0);
+        }
+    }
     constexpr int NFRAG = (NH - 1) * 2 * MT * 4 + 8;
     constexpr int NLOAD = (NFRAG + VEC - 1) / VEC;
     vecT wv[NLOAD];
@@ -337,6 +427,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a
     }
     cx.gout = static_cast<T*>(a.g);
     cx.tiles = static_cast<T*>(a.tiles);
+    cx.jac = static_cast<T*>(a.jac);
     cx.m = a.m; cx.ident = a.ident; cx.box = a.box;
     {
         vecT* ls = reinterpret_cast<vecT*>(lds + L::W0F);
@@ -344,6 +435,13 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a
         for (int u = 0; u < SMALL_PER_THREAD; ++u) {
             const int idx = tid + u * NTHREADS;
             if (idx < SMALL_VECS) ls[idx] = sm[u];
+        }
+    }
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int u = 0; u < PV_PER_THREAD; ++u) {
+            const int idx = tid + u * NTHREADS;
+            if (idx < a.p_elems) lds[L::TOTAL + idx] = pv[u];
         }
     }
     CoopWeights<T, WP, NH> W;
@@ -373,11 +471,30 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a
         if (more) fx_stage_load<T, WP, NH, TPW, NX, NU, TPW>(cx, t0, tid, sr);   // next pass's inputs, under this pass
         lds_barrier();
         const T* in = in_base + parity * L::IN_SZ;
-        if (n_cur == 1) fx_pass<T, WP, NH, TPW, NX, NU, 1>(cx, W, in, t_cur, tid, xsel);
-        if constexpr (TPW >= 2) { if (n_cur == 2) fx_pass<T, WP, NH, TPW, NX, NU, 2>(cx, W, in, t_cur, tid, xsel); }
-        if constexpr (TPW >= 3) { if (n_cur == 3) fx_pass<T, WP, NH, TPW, NX, NU, 3>(cx, W, in, t_cur, tid, xsel); }
+        T* const in_next = in_base + (parity ^ 1) * L::IN_SZ;
+        if (n_cur == 1) fx_pass<T, WP, NH, TPW, NX, NU, 1, FUSE>(cx, W, in, t_cur, tid, xsel, sr, more, in_next);
+        if constexpr (TPW >= 2) { if (n_cur == 2) fx_pass<T, WP, NH, TPW, NX, NU, 2, FUSE>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
+        if constexpr (TPW >= 3) { if (n_cur == 3) fx_pass<T, WP, NH, TPW, NX, NU, 3, FUSE>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
         parity ^= 1;
-        if (more) fx_stage_store<T, WP, NH, TPW, NX, NU, TPW>(in_base + parity * L::IN_SZ, tid, sr);
+    }
+    if constexpr (FUSE) {
+        // ---- objective of the problems whose first row lies in this workgroup's tile range, one problem per wave
+        //      at a time (same routine, hence the same bits, as the assembly kernels' objective blocks)
+        if (a.f || a.grad) {
+            if (a.p_elems > PV_PER_THREAD * NTHREADS) {
+                const T* __restrict__ gp = static_cast<const T*>(a.P);
+                for (int i = tid + PV_PER_THREAD * NTHREADS; i < a.p_elems; i += NTHREADS) lds[L::TOTAL + i] = gp[i];
+                __syncthreads();
+            }
+            const unsigned r_lo = (unsigned)t_begin * 16u;
+            unsigned r_hi = (unsigned)t_end * 16u;
+            if (r_hi > a.R) r_hi = a.R;
+            const unsigned H = (unsigned)a.H;
+            const unsigned b_lo = (r_lo + H - 1) / H, b_hi = (r_hi + H - 1) / H;    // problems b_lo .. b_hi - 1
+            for (unsigned b = b_lo + (unsigned)w; b < b_hi; b += MT)
+                objective_body<T>((int)b, lane, a.H, NX, NU, a.oo, lds + L::TOTAL, cx.Z, static_cast<T*>(a.f),
+                                  static_cast<T*>(a.grad));
+        }
     }
 }
 

@@ -162,6 +162,34 @@ int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, v
     return launch_rows_mfma_stages(h, B, Z, X0, g, tiles, nullptr, 0, s);
 }
 
+static MfmaParams base_params(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles) {
+    MfmaParams p{};
+    p.blob = h.mfma.blob;
+    p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4; p.mb = (h.nin + 15) / 16;
+    p.ne = h.ne; p.extra = h.d_extra;
+    p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin, (int)h.esz);
+    p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
+    p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
+    p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
+    p.gk = h.gather();
+    p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
+    p.scratch_per_wave = (scratch_elems(h) + 1) & ~1;
+    p.dbg = h.d_dbg;
+    return p;
+}
+
+// Whole hessian-free evaluation (g, dense jac, f, grad [, tiles]) in ONE launch where a fixed-shape kernel covers the
+// problem; NEMPC_EUNSUPPORTED (no error message, nothing launched) tells nempc_eval to take the two-launch path.
+int launch_eval_fused(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, void* f,
+                      void* grad, hipStream_t s) {
+    if (!h.mfma.blob || !jac || !h.d_obj) return NEMPC_EUNSUPPORTED;
+    MfmaParams p = base_params(h, B, Z, X0, g, tiles);
+    p.fuse_jac = jac; p.fuse_f = f; p.fuse_grad = grad;
+    p.obj = h.d_obj;
+    p.oo = obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu);
+    return h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+}
+
 int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* stage_out,
                             int stage_stride, hipStream_t s) {
     if (!h.mfma.blob) {

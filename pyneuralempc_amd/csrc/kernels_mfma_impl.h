@@ -60,6 +60,12 @@ struct MfmaParams {
     void* stage_out;       // RK4 Hessian pipeline only: per (row, stage) record [xi_s (nin) | J_s (nx*nin) | dk_{s-1} (nx*nin)]
     int stage_stride;      // elements per record = nin + 2*nx*nin
     long long* dbg;        // diagnostic builds only (-DNEMPC_STAMPS): per-wave phase stamps of workgroup 0
+    // fused evaluation (fixed-shape kernel only): dense Jacobian and objective from the same launch
+    void* fuse_jac;
+    void* fuse_f;
+    void* fuse_grad;
+    const void* obj;
+    ObjOffsets oo;
 };
 
 // In-kernel stamps exist only in the diagnostic library built by tools/diag_stamps.py; the shipped

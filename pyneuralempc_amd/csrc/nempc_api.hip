@@ -551,6 +551,11 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
         const bool need_tiles = jac_dense || jac_tiles || jac_sparse || h.variant == NEMPC_KERNEL_VALU;
         void* tiles = jac_tiles ? jac_tiles : (need_tiles ? h.d_tiles_ws : nullptr);
         void* gout = g ? g : h.d_g_ws;
+        // dense contract on a compiled shape: rows, dense assembly and objective in ONE launch
+        if (jac_dense && !jac_sparse && h.variant == NEMPC_KERNEL_MFMA) {
+            rc = launch_eval_fused(h, B, Z, X0, gout, jac_tiles, jac_dense, f, grad, s);
+            if (rc != NEMPC_EUNSUPPORTED) return rc;
+        }
         rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, gout, tiles, s)
                                             : launch_rows_valu(h, B, Z, X0, gout, tiles, s);
         if (rc) return rc;
