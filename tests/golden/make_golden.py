@@ -72,6 +72,14 @@ def import_reference():
     opt = sys.modules["pyNeuralEMPC.optimizer"]
     opt.Ipopt, opt.Optimizer, opt.Slsqp = ref.ipopt.Ipopt, ref.opt_base.Optimizer, ref.slsqp.Slsqp
     ref.controller = _load("pyNeuralEMPC.controller", f"{REF}/controller.py")
+    # model/jax.py: its window -> variable projection gen_jac_proj_mat (jax.py:8-20) is plain NumPy; the module's
+    # top-level `import jax` / `import jax.numpy` only bind names used inside the JAX model classes, so attribute-less
+    # placeholders (as for cyipopt above) are enough to import it.  Nothing of JAX is called.
+    if "jax" not in sys.modules:
+        jax_ph = types.ModuleType("jax")
+        jax_ph.numpy = types.ModuleType("jax.numpy")
+        sys.modules["jax"], sys.modules["jax.numpy"] = jax_ph, jax_ph.numpy
+    ref.model_jax = _load("pyNeuralEMPC.model.jax", f"{REF}/model/jax.py")
     return ref
 
 
@@ -152,8 +160,9 @@ def make_plugins(ref):
                 parts.append(np.tile(np.asarray(p).reshape(1, -1), (x.shape[0], 1)))
             return np.concatenate(parts, axis=1)
 
-        def _proj(self, T, dim):
-            # (T*dim variables, T steps, w*dim window slots) 0/1 selector, cf. gen_jac_proj_mat
+        def _proj_written(self, T, dim):
+            # (T*dim variables, T steps, w*dim window slots) 0/1 selector, this file's reading of gen_jac_proj_mat,
+            # extended to forward_rolling=False (which the reference leaves as a TODO, jax.py:186)
             w = self.rolling_window
             P = np.zeros((T * dim, T, w * dim))
             for i in range(T):
@@ -161,6 +170,16 @@ def make_plugins(ref):
                     for o in range(i, min(T, i + w)):
                         slot = (w - 1) - (o - i) if self.forward_rolling else (o - i)
                         P[i * dim + k, o, slot * dim + k] = 1.0
+            return P
+
+        def _proj(self, T, dim):
+            """Forward order: the reference's OWN gen_jac_proj_mat (model/jax.py:8-20), imported and called here, so the
+            rolling fixtures pin the band against that function itself; the hand-written form must agree with it.
+            Reverse order (no reference implementation): the hand-written form."""
+            if not self.forward_rolling:
+                return self._proj_written(T, dim)
+            P = ref.model_jax.gen_jac_proj_mat(T, dim, self.rolling_window).reshape(T * dim, T, self.rolling_window * dim)
+            assert np.array_equal(P, self._proj_written(T, dim)), "hand-written projection != gen_jac_proj_mat"
             return P
 
         def forward(self, x, u, p=None, tvp=None):
@@ -251,11 +270,40 @@ CASES = {
 }
 
 
+def check_network_derivatives_by_ad(net, n_in, seed=11, rows=3, with_hess=True):
+    """The one piece of every fixture that does not come from reference arithmetic -- the per-row derivative of the
+    network, which the reference obtains from TensorFlow / JAX autodiff -- is cross-checked HERE, while the fixtures are
+    made, against an independent autodiff (torch.func jacrev / hessian, fp64), so a fixture can never be written from
+    a network derivative that only the oracle believes in."""
+    import torch
+    Wt = [torch.tensor(w, dtype=torch.float64) for w in net.W]
+    bt = [torch.tensor(b, dtype=torch.float64) for b in net.b]
+
+    def f(xi):
+        a = xi
+        for w, b in zip(Wt[:-1], bt[:-1]):
+            a = torch.tanh(a @ w + b)
+        return a @ Wt[-1] + bt[-1]
+
+    xi = np.random.default_rng(seed).normal(size=(rows, n_in))
+    fo, Jo, So = net.forward_jac_hess(xi)
+    _, Jr = net.forward_jac(xi)
+    for r in range(rows):
+        x = torch.tensor(xi[r], dtype=torch.float64)
+        Ja = torch.func.jacrev(f)(x).numpy()
+        assert np.abs(Ja - Jo[r]).max() < 1e-12 and np.abs(Ja - Jr[r]).max() < 1e-12, "network Jacobian != torch AD"
+        assert np.abs(f(x).numpy() - fo[r]).max() < 1e-13
+        if with_hess:
+            Ha = torch.func.hessian(f)(x).numpy()
+            assert np.abs(Ha - So[r]).max() < 1e-11, "network Hessian != torch AD"
+
+
 def build_case(ref, plugins, name, spec):
     NumpyMLPModel, QuadObjective, BoxStateRows = plugins[:3]
     nx, nu, hidden, H, kind, DT, box, B, with_h = spec[:9]
     p_dim, tvp_dim = (spec[9], spec[10]) if len(spec) > 9 else (0, 0)
     net = orc.MLP.random(nx + nu + p_dim + tvp_dim, hidden, nx, seed=0)
+    check_network_derivatives_by_ad(net, nx + nu + p_dim + tvp_dim, with_hess=max(hidden) <= 64)
     rng = np.random.default_rng(7)
     xref = rng.normal(size=(H, nx)) * 0.3
     uref = rng.normal(size=(H, nu)) * 0.3
@@ -345,6 +393,7 @@ def build_rolling_case(ref, plugins, name, c):
     nx, nu, H, kind, w, fwd, box, B = c["nx"], c["nu"], c["H"], c["kind"], c["window"], c["forward"], c["box"], c["B"]
     p_dim, tvp_dim = c.get("p_dim", 0), c.get("tvp_dim", 0)
     net = orc.MLP.random(w * (nx + nu) + w * tvp_dim + p_dim, c["hidden"], nx, seed=0)
+    check_network_derivatives_by_ad(net, w * (nx + nu) + w * tvp_dim + p_dim, with_hess=max(c["hidden"]) <= 64)
     rng = np.random.default_rng(7)
     xref = rng.normal(size=(H, nx)) * 0.3
     uref = rng.normal(size=(H, nu)) * 0.3

@@ -1,0 +1,155 @@
+"""GPU parity at the sizes the performance numbers are quoted on (BASELINE configs[1] dims at B=1024, configs[2],
+configs[4]): the FULL launch is checked against the CPU oracle on three 16-problem slices (first, middle, last),
+structural zeros must be exact zeros, and the kernel families must agree with each other.  Grid / tile-range /
+row -> (problem, step) arithmetic only shows its bugs at these sizes and at ragged batch sizes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nempc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+F64 = dict(rtol=1e-12, atol=1e-12)
+DEFAULT = ("f", "grad", "g", "jac_dense")
+ALL = ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")
+
+
+def _slices(B, k=16):
+    k = min(k, B)
+    return [slice(s, s + k) for s in sorted({0, max(0, B // 2 - k // 2), B - k})]
+
+
+def _engine(net, H, nx, nu, B, kernel="auto", integrator="discret", DT=1.0, dtype=torch.float64, box=None):
+    from pyneuralempc_amd import CallbackEngine
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integrator, DT=DT, dtype=dtype, device="cuda:0",
+                         max_batch=B, kernel=kernel)
+    if box is not None:
+        eng.set_box_rows(*box)
+    return eng
+
+
+@pytest.mark.parametrize("B", [1024, 1000, 37, 1])
+def test_c2_fused_evaluation_full_size(B):
+    """configs[1] dims: the one-launch evaluation (rows + dense Jacobian + objective, rows_coopfx_kernel) against the
+    oracle and, bit for bit, against the unfused launch sequence of the same handle."""
+    H, nx, nu = 20, 2, 1
+    net = orc.MLP.random(3, [64, 64], 2, seed=0)
+    eng = _engine(net, H, nx, nu, B)
+    eng.set_objective(Q=[[1.0, 0.2], [0.1, 0.7]], R=[[0.3]], xref=np.linspace(-1, 1, H * nx).reshape(H, nx),
+                      uref=0.1, cx=0.05, cu=-0.2, QT=[[2.0, 0.0], [0.3, 1.5]])
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=4)
+    Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+    fused = {k: v.clone() for k, v in eng.eval(Z, X0, DEFAULT).items()}
+    assert eng.last_row_kernel == "rows_coopfx_kernel"
+    unf = {k: v.clone() for k, v in eng.eval(Z, X0, ALL).items()}       # sparse requested -> separate assembly launches
+    for k in DEFAULT:
+        assert torch.equal(fused[k], unf[k]), k
+    prob = orc.Problem(net, H, nx, nu, Q=np.array([[1.0, 0.2], [0.1, 0.7]]), R=np.array([[0.3]]),
+                       xref=np.linspace(-1, 1, H * nx).reshape(H, nx), uref=np.full((H, nu), 0.1),
+                       cx=np.full((H, nx), 0.05), cu=np.full((H, nu), -0.2), QT=np.array([[2.0, 0.0], [0.3, 1.5]]))
+    rows, cols = eng.jac_structure()
+    mask = np.zeros((eng.m, eng.n), dtype=bool)
+    mask[rows, cols] = True
+    jac = fused["jac_dense"].cpu().numpy()
+    assert np.all(jac[:, ~mask] == 0.0)
+    for sl in _slices(B):
+        f, grad, g, J = prob.eval_batch(Zh[sl], X0h[sl])
+        np.testing.assert_allclose(fused["f"][sl].cpu().numpy(), f, **F64)
+        np.testing.assert_allclose(fused["grad"][sl].cpu().numpy(), grad, **F64)
+        np.testing.assert_allclose(fused["g"][sl].cpu().numpy(), g, **F64)
+        np.testing.assert_allclose(jac[sl], J, **F64)
+    # g only / without the objective / with the compact tiles: every output subset of the fused launch
+    only = eng.eval(Z, X0, ("g", "jac_dense"))
+    assert torch.equal(only["jac_dense"], fused["jac_dense"]) and torch.equal(only["g"], fused["g"])
+    wt = eng.eval(Z, X0, ("f", "g", "jac_dense", "jac_tiles"))
+    assert torch.equal(wt["jac_tiles"], unf["jac_tiles"]) and torch.equal(wt["f"], fused["f"])
+
+
+def test_c2_unity_and_odd_horizon_take_the_right_path():
+    """Unity on the fixed-shape kernel; an odd n (H odd, 3 variables per step) cannot be streamed as 16-byte vectors and
+    must fall back to the two-launch path with identical results."""
+    net = orc.MLP.random(3, [64, 64], 2, seed=1)
+    for H, integ in ((20, "unity"), (7, "discret"), (64, "discret")):
+        B = 130
+        eng = _engine(net, H, 2, 1, B, integrator=integ)
+        Zh, X0h = orc.synthetic_inputs(B, H, 2, 1, seed=9)
+        res = eng.eval_numpy(Zh, X0h)
+        prob = orc.Problem(net, H, 2, 1, orc.UNITY if integ == "unity" else orc.DISCRET)
+        f, grad, g, J = prob.eval_batch(Zh, X0h)
+        np.testing.assert_allclose(res["jac_dense"], J, **F64)
+        np.testing.assert_allclose(res["g"], g, **F64)
+        np.testing.assert_allclose(res["f"], f, **F64)
+        np.testing.assert_allclose(res["grad"], grad, **F64)
+
+
+def test_c5_full_size_box_rows_and_hessian():
+    """configs[4]: B=1024, H=50, box state rows in g / jac (m = 200), fp64, incl. the Lagrangian Hessian callback."""
+    B, H, nx, nu = 1024, 50, 2, 1
+    net = orc.MLP.random(3, [64, 64], 2, seed=0)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=1)
+    prob = orc.Problem(net, H, nx, nu, box=(-2.0, 2.0))
+    out = {}
+    for kern in ("mfma", "mfma_tile"):
+        eng = _engine(net, H, nx, nu, B, kernel=kern, box=(-2.0, 2.0))
+        assert eng.m == 200 and eng.n == 150
+        Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+        res = eng.eval(Z, X0, DEFAULT)
+        out[kern] = {k: v.cpu().numpy() for k, v in res.items()}
+        if kern == "mfma":
+            assert eng.last_row_kernel == "rows_coopfx_kernel"
+            rows, cols = eng.jac_structure()
+            mask = np.zeros((eng.m, eng.n), dtype=bool)
+            mask[rows, cols] = True
+            assert np.all(out[kern]["jac_dense"][:, ~mask] == 0.0)
+            lam = torch.randn(B, eng.m, dtype=torch.float64, device="cuda:0", generator=torch.Generator("cuda:0").manual_seed(3))
+            sig = torch.full((B,), 0.7, dtype=torch.float64, device="cuda:0")
+            hv = eng.hess(Z, X0, lam, sig)["hvals"].cpu().numpy()
+            lam_h = lam.cpu().numpy()
+            for sl in _slices(B, 4):
+                ref = np.stack([prob.hessian_values(Zh[i], X0h[i], lam_h[i], 0.7) for i in range(sl.start, sl.stop)])
+                np.testing.assert_allclose(hv[sl], ref, rtol=1e-11, atol=1e-11)
+        del eng, res
+    for k in DEFAULT:
+        np.testing.assert_allclose(out["mfma"][k], out["mfma_tile"][k], **F64)
+    for sl in _slices(B):
+        f, grad, g, J = prob.eval_batch(Zh[sl], X0h[sl])
+        np.testing.assert_allclose(out["mfma"]["f"][sl], f, **F64)
+        np.testing.assert_allclose(out["mfma"]["grad"][sl], grad, **F64)
+        np.testing.assert_allclose(out["mfma"]["g"][sl], g, **F64)
+        np.testing.assert_allclose(out["mfma"]["jac_dense"][sl], J, **F64)
+
+
+def test_c3_full_size_rk4_fp32():
+    """configs[2]: B=1024, H=30, 6 states / 3 controls, MLP 3x128, RK4, fp32 (tolerance 1e-4 relative to the fp64
+    oracle): 30,720 rows on the cooperative matrix-core kernel and on the wave-per-tile one."""
+    B, H, nx, nu, DT = 1024, 30, 6, 3, 0.1
+    net = orc.MLP.random(9, [128, 128, 128], 6, seed=0)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=1)
+    prob = orc.Problem(net, H, nx, nu, orc.RK4, DT)
+    out = {}
+    for kern in ("mfma", "mfma_tile"):
+        eng = _engine(net, H, nx, nu, B, kernel=kern, integrator="rk4", DT=DT, dtype=torch.float32)
+        res = eng.eval(eng.to_device(Zh), eng.to_device(X0h), DEFAULT)
+        out[kern] = {k: v.to("cpu", torch.float64).numpy() for k, v in res.items()}
+        if kern == "mfma":
+            assert eng.last_row_kernel == "rows_coop_kernel"
+            rows, cols = eng.jac_structure()
+            mask = np.zeros((eng.m, eng.n), dtype=bool)
+            mask[rows, cols] = True
+            assert np.all(out[kern]["jac_dense"][:, ~mask] == 0.0)
+        del eng, res
+
+    def close(a, b, what):
+        err = np.abs(a - b).max() / max(1.0, np.abs(b).max())
+        assert err < 1e-4, f"{what}: max rel err {err:.2e}"
+
+    for k in DEFAULT:
+        close(out["mfma"][k], out["mfma_tile"][k], f"coop vs wave-tile {k}")
+    for sl in _slices(B):
+        f, grad, g, J = prob.eval_batch(Zh[sl], X0h[sl])
+        for kern in out:
+            close(out[kern]["f"][sl], f, "f")
+            close(out[kern]["grad"][sl], grad, "grad")
+            close(out[kern]["g"][sl], g, "g")
+            close(out[kern]["jac_dense"][sl], J, "jac")
