@@ -166,6 +166,16 @@ int nempc_eval(nempc_handle h, int32_t B, const void* Z, const void* X0, void* f
 int nempc_hess(nempc_handle h, int32_t B, const void* Z, const void* X0, const void* lambda,
                const void* sigma, void* hvals, void* hdense, void* hblocks, void* stream);
 
+/* Gauss-Newton Hessian callback (BASELINE.json north_star; no reference counterpart -- the reference's Hessian,
+ * ipopt.py:66-86, is the exact one above):
+ *   hvals (B,nnz_hess) = (sigma_b * d2f + sum_t T_t^T diag(w_{b,t}) T_t)[rows, cols],   T_t = jac tile of step t
+ * in the SAME pattern as nempc_hess (nempc_hess_structure): the per-step blocks take the place of the Lagrangian
+ * blocks, built from the row kernel's first-order tiles alone (no second-order sweep: one row-kernel launch, one block
+ * kernel, one assembly).  w (B, H*nx) positive weights per defect row, NULL = ones; sigma (B).  Positive semidefinite
+ * for w >= 0 and a convex objective.  Optional hdense (B,n,n), hblocks (B,H,w*(nx+nu),w*(nx+nu)) as in nempc_hess. */
+int nempc_hess_gn(nempc_handle h, int32_t B, const void* Z, const void* X0, const void* w, const void* sigma,
+                  void* hvals, void* hdense, void* hblocks, void* stream);
+
 /* Batched on-device solver (no reference counterpart: the reference hands ONE problem at a time to Ipopt /
  * SLSQP on the CPU, optimizer/ipopt.py:138-195, slsqp.py:143-197).  Solves the B problems
  *     min f(z)  s.t.  integrator defects = 0,  lb <= z <= ub

@@ -387,6 +387,29 @@ class Problem:
             Hm[np.ix_(cols[keep], cols[keep])] += blk[np.ix_(keep, keep)]
         return Hm
 
+    def gauss_newton_hessian(self, z, x0, w, sigma):
+        """sigma * d2f + sum_t T_t^T diag(w_t) T_t, dense (n,n), T_t = d Phi / d[x_{t-1} | u_t] the row's Jacobian tile.
+
+        No reference counterpart: the reference's own Hessian callback is the EXACT Lagrangian Hessian above
+        (optimizer/ipopt.py:66-86); BASELINE.json's north_star names the Gauss-Newton variant -- the first-order model
+        of how a weight w_t on step t's successor state curves the problem in (x_{t-1}, u_t), i.e. what remains of
+        lagrangian_hessian when the network's second derivatives are dropped and the multipliers are replaced by a
+        positive weighting.  Same block placement, hence the same sparsity pattern, as the exact one."""
+        H, nx, n = self.H, self.nx, self.n
+        w = np.ones(H * nx) if w is None else np.asarray(w, dtype=np.float64)
+        J = self.tiles(z, x0)[2]
+        Hm = sigma * self.objective_hessian()
+        for t in range(H):
+            blk = np.einsum("k,kp,kq->pq", w[t * nx:(t + 1) * nx], J[t], J[t])
+            cols = self.tile_columns(t)
+            keep = np.nonzero(cols >= 0)[0]
+            Hm[np.ix_(cols[keep], cols[keep])] += blk[np.ix_(keep, keep)]
+        return Hm
+
+    def gauss_newton_values(self, z, x0, w, sigma):
+        r, c = self.hessian_structure()
+        return self.gauss_newton_hessian(z, x0, w, sigma)[r, c]
+
     def hessian_structure(self):
         """Exact structural lower-triangular pattern, row-major ordered like
         np.nonzero(np.tril(.)) in optimizer/ipopt.py:55-62.  (The reference samples three random

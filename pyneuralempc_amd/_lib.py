@@ -18,7 +18,7 @@ INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
 
 EXPORTS = ["nempc_create", "nempc_destroy", "nempc_reserve", "nempc_set_weights", "nempc_set_objective", "nempc_set_terminal_weight", "nempc_set_box_rows", "nempc_bind_extra", "nempc_bind_history",
            "nempc_dims", "nempc_constraint_bounds", "nempc_jac_structure", "nempc_hess_structure", "nempc_eval",
-           "nempc_hess", "nempc_solve", "nempc_sync", "nempc_kernel_variant", "nempc_last_row_kernel", "nempc_last_error", "nempc_abi_version",
+           "nempc_hess", "nempc_hess_gn", "nempc_solve", "nempc_sync", "nempc_kernel_variant", "nempc_last_row_kernel", "nempc_last_error", "nempc_abi_version",
            "nempc_comm_unique_id", "nempc_comm_init", "nempc_allgather_u0", "nempc_comm_size", "nempc_comm_destroy"]
 
 
@@ -73,6 +73,7 @@ def load():
     lib.nempc_hess_structure.argtypes = [vp, ip, ip]
     lib.nempc_eval.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.nempc_hess.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.nempc_hess_gn.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.nempc_solve.argtypes = [vp, i32, vp, vp, dp, dp, ctypes.POINTER(NempcSolverOpts), vp, ip, vp]
     lib.nempc_sync.argtypes = [vp, vp]
     lib.nempc_kernel_variant.argtypes = [vp]

@@ -73,13 +73,15 @@ class NMPC:
         return z[:nxh].reshape(self.integrator.H, -1), z[nxh:].reshape(self.integrator.H, -1)
 
 
-    def next_batch(self, X0, init_z=None, **solver_opts):
+    def next_batch(self, X0, init_z=None, p=None, tvp=None, **solver_opts):
         """Solve B MPC problems at once on the device (no reference counterpart).  X0 (B,nx) NumPy
         array or device tensor.  Needs the fused device path (device integrator + QuadraticObjective; the only
-        extra rows accepted are BoxStateConstraint, which become bounds on the state variables).  Returns (states (B,H,nx), u (B,H,nu),
+        extra rows accepted are BoxStateConstraint, which become bounds on the state variables).  Models with
+        parameters take p (p_dim,) or (B,p_dim) and tvp (H,tvp_dim) or (B,H,tvp_dim) -- one set for all problems or one
+        per problem (the batched form of NMPC.next's p / tvp, controller.py:65).  Returns (states (B,H,nx), u (B,H,nu),
         status (B,) with Optimizer.SUCCESS / FAIL per problem) as NumPy arrays."""
         import torch
-        from .optimizer.base import _FusedEvaluator
+        from .optimizer.base import fused_evaluator
         from .objective.quadratic import QuadraticObjective
         from .integrator.base import DeviceIntegrator
         from .constraints import BoxStateConstraint
@@ -88,13 +90,30 @@ class NMPC:
                 and len(boxes) == len(self.constraint_list)):
             raise NotImplementedError("next_batch needs a device integrator, a QuadraticObjective and no extra "
                                       "constraint rows other than BoxStateConstraint")
-        key = (id(self.objective_func), None)
-        cache = self.integrator._fused
-        if key not in cache:
-            cache[key] = _FusedEvaluator(self.integrator, self.objective_func, None)
-        eng = cache[key].engine
+        eng = fused_evaluator(self.integrator, self.objective_func, None).engine
         H = self.integrator.H
         X0t = X0 if isinstance(X0, torch.Tensor) else eng.to_device(np.atleast_2d(np.asarray(X0, dtype=np.float64)))
+        B = int(X0t.shape[0])
+        model = self.integrator.model
+        if model.p_dim + model.tvp_dim:
+            # extra network inputs of every problem: (B, H, tvp_dim + p_dim) = [tvp_t | p], the reference's
+            # concatenation order (model/tensorflow.py:39-47); a (1, ...) binding left by NMPC.next never serves B > 1
+            parts = []
+            if model.tvp_dim:
+                if tvp is None:
+                    raise ValueError("this model has tvp_dim > 0: pass tvp (H, tvp_dim) or (B, H, tvp_dim)")
+                tv = np.asarray(tvp, dtype=np.float64)
+                tv = np.broadcast_to(tv if tv.ndim == 3 else tv[None], (B, H, model.tvp_dim))
+                parts.append(tv)
+            if model.p_dim:
+                if p is None:
+                    raise ValueError("this model has p_dim > 0: pass p (p_dim,) or (B, p_dim)")
+                pv = np.asarray(p, dtype=np.float64)
+                pv = np.broadcast_to(pv if pv.ndim == 2 else pv[None], (B, model.p_dim))
+                parts.append(np.broadcast_to(pv[:, None, :], (B, H, model.p_dim)))
+            eng.bind_extra(eng.to_device(np.concatenate(parts, axis=2)))
+        elif p is not None or tvp is not None:
+            raise ValueError("this model takes no p / tvp")
         Zi = None if init_z is None else (init_z if isinstance(init_z, torch.Tensor) else eng.to_device(init_z))
         lb = np.asarray(self.domain_constraint.get_lower_bounds(H), dtype=np.float64).copy()
         ub = np.asarray(self.domain_constraint.get_upper_bounds(H), dtype=np.float64).copy()

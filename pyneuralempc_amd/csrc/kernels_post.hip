@@ -303,6 +303,38 @@ int launch_assemble_sparse(Handle& h, int B, const void* tiles, void* vals, hipS
     return NEMPC_OK;
 }
 
+// Gauss-Newton blocks: blocks[r][p][q] = sum_k w[r][k] * T[r][k][p] * T[r][k][q] from the row kernel's tiles T (R, nx, nin);
+// w == null means unit weights.  The product T_p * T_q is formed first, so the block is symmetric to the last bit.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_blocks_kernel(size_t total, int nx, int nin, const T* __restrict__ tiles,
+                                                        const T* __restrict__ w, T* __restrict__ blocks) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int nn = nin * nin;
+    const size_t r = idx / nn;
+    const int pq = (int)(idx - r * nn), p = pq / nin, q = pq - p * nin;
+    const T* t = tiles + r * (size_t)(nx * nin);
+    T s = T(0);
+    for (int k = 0; k < nx; ++k) {
+        const T tt = t[k * nin + p] * t[k * nin + q];
+        s = fma(w ? w[r * nx + k] : T(1), tt, s);
+    }
+    blocks[idx] = s;
+}
+
+int launch_gn_blocks(Handle& h, int B, const void* tiles, const void* w, void* blocks, hipStream_t s) {
+    const size_t total = (size_t)B * h.cfg.H * h.nin * h.nin;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (h.cfg.dtype == NEMPC_F64)
+        hipLaunchKernelGGL(gn_blocks_kernel<double>, grid, block, 0, s, total, h.cfg.nx, h.nin, (const double*)tiles,
+                           (const double*)w, (double*)blocks);
+    else
+        hipLaunchKernelGGL(gn_blocks_kernel<float>, grid, block, 0, s, total, h.cfg.nx, h.nin, (const float*)tiles,
+                           (const float*)w, (float*)blocks);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
 // d_hess_map layout (w codes per entry): [0,nnz) tril map | [nnz, nnz+n*n) dense map ; objc follows the same split in d_hess_objc
 int launch_assemble_hess(Handle& h, int B, const void* blocks, const void* sigma, void* hvals, void* hdense,
                          hipStream_t s) {

@@ -595,6 +595,32 @@ int nempc_hess(nempc_handle hh, int32_t B, const void* Z, const void* X0, const 
     return launch_assemble_hess(h, B, blocks, sigma, hvals, hdense, s);
 }
 
+int nempc_hess_gn(nempc_handle hh, int32_t B, const void* Z, const void* X0, const void* w, const void* sigma,
+                  void* hvals, void* hdense, void* hblocks, void* stream) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_hess_gn: null handle");
+    Handle& h = *reinterpret_cast<Handle*>(hh);
+    if (B < 0 || B > h.cfg.max_batch) return fail(NEMPC_EINVAL, "nempc_hess_gn: B outside [0, max_batch]");
+    if (B == 0) return NEMPC_OK;
+    if (!Z || !X0 || !sigma) return fail(NEMPC_EINVAL, "nempc_hess_gn: null input");
+    if (!h.have_weights) return fail(NEMPC_ESTATE, "nempc_hess_gn: call nempc_set_weights first");
+    if (h.ne > 0 && !h.d_extra) return fail(NEMPC_ESTATE, "nempc_hess_gn: n_extra > 0 but nempc_bind_extra was not called");
+    if (h.w > 1 && !h.d_hist_x)
+        return fail(NEMPC_ESTATE, "nempc_hess_gn: rolling_window > 1 but nempc_bind_history was not called");
+    if ((h.ne > 0 && B > h.extra_B) || (h.w > 1 && B > h.hist_B))
+        return fail(NEMPC_EINVAL, "nempc_hess_gn: B exceeds the batch the bound extras / history cover");
+    DeviceGuard dg(h.cfg.device);
+    if (!dg.ok) return fail(NEMPC_EHIP, "nempc_hess_gn: hipSetDevice failed");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // first-order model only: the row kernel's tiles (no second-order sweep), then the same assembly as nempc_hess
+    int rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, h.d_g_ws, h.d_tiles_ws, s)
+                                            : launch_rows_valu(h, B, Z, X0, h.d_g_ws, h.d_tiles_ws, s);
+    if (rc) return rc;
+    void* blocks = hblocks ? hblocks : h.d_hess_ws;
+    if ((rc = launch_gn_blocks(h, B, h.d_tiles_ws, w, blocks, s))) return rc;
+    if (!hvals && !hdense) return NEMPC_OK;
+    return launch_assemble_hess(h, B, blocks, sigma, hvals, hdense, s);
+}
+
 int nempc_solve(nempc_handle hh, int32_t B, const void* X0, void* Z, const double* lb, const double* ub,
                 const nempc_solver_opts* opts, int32_t* status, int32_t* iters, void* stream) {
     if (!hh) return fail(NEMPC_EINVAL, "nempc_solve: null handle");

@@ -198,6 +198,7 @@ int launch_post_sparse(Handle& h, int B, const void* tiles, void* vals, const vo
                        hipStream_t s);
 int launch_assemble_hess(Handle& h, int B, const void* blocks, const void* sigma, void* hvals, void* hdense,
                          hipStream_t s);
+int launch_gn_blocks(Handle& h, int B, const void* tiles, const void* w, void* blocks, hipStream_t s);
 
 // ---- solver.hip : batched Gauss-Newton SQP
 int solver_run(Handle& h, int B, const void* X0, void* Z, const double* lb, const double* ub,

@@ -332,6 +332,36 @@ class CallbackEngine:
                                            ptr["hblocks"], self._stream()))
         return res
 
+    def hess_gn(self, Z, X0, w=None, sigma=None, want=("hvals",)):
+        """Gauss-Newton Hessian (nempc_hess_gn): sigma * d2f + sum_t T_t^T diag(w_t) T_t in hess_structure() order, from
+        the first-order tiles only.  w (B, H*nx) weights per defect row (None = ones), sigma (B,) (None = ones)."""
+        B = int(Z.shape[0])
+        self._check_in(Z, (B, self.n), "Z")
+        self._check_in(X0, (B, self.nx), "X0")
+        if w is not None:
+            self._check_in(w, (B, self.H * self.nx), "w")
+        if sigma is None:
+            sigma = torch.ones(B, dtype=self.dtype, device=self.device)
+        self._check_in(sigma, (B,), "sigma")
+        self._check_extra(B)
+        self.reserve(B)
+        shapes = {"hvals": (B, self.nnz_hess), "hdense": (B, self.n, self.n),
+                  "hblocks": (B, self.H, self.nin, self.nin)}
+        res, ptr = {}, {}
+        for k in shapes:
+            if k in want:
+                res[k] = self._out("gn_" + k, shapes[k])
+                ptr[k] = ctypes.c_void_p(res[k].data_ptr())
+            else:
+                ptr[k] = None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nempc_hess_gn(self._handle, B, ctypes.c_void_p(Z.data_ptr()),
+                                              ctypes.c_void_p(X0.data_ptr()),
+                                              None if w is None else ctypes.c_void_p(w.data_ptr()),
+                                              ctypes.c_void_p(sigma.data_ptr()), ptr["hvals"], ptr["hdense"],
+                                              ptr["hblocks"], self._stream()))
+        return res
+
     def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=100, max_linesearch=6, check_every=2,
               tol_constraint=None, tol_step=None, mu_init=1e-1, mu_min=None, mu_factor=0.2, reg=None, lq_kernel="auto"):
         """Batched on-device solve (Gauss-Newton SQP, see csrc/solver.hip).  X0 (B,nx) device tensor; Z_init (B,n)

@@ -42,16 +42,28 @@ class QuadraticObjective(ObjectiveFunc):
         return dict(Q=Q, R=R, xref=tv(p["xref"], nx), uref=tv(p["uref"], nu), cx=tv(p["cx"], nx), cu=tv(p["cu"], nu),
                     QT=QT)
 
+    def fingerprint(self, H, nx, nu):
+        """Bytes of the resolved parameters: what a device handle compares to notice that `params` was changed after
+        the objective was uploaded (a moving xref / uref in tracking MPC)."""
+        r = self.resolved(H, nx, nu)
+        return b"".join(np.ascontiguousarray(r[k]).tobytes() if r[k] is not None else b"-"
+                        for k in ("Q", "R", "xref", "uref", "cx", "cu", "QT"))
+
     def _engine(self, H, nx, nu):
         key = (H, nx, nu)
-        eng = self._engines.get(key)
-        if eng is None:
+        ent = self._engines.get(key)
+        fp = self.fingerprint(H, nx, nu)
+        if ent is None:
             # objective-only handle: a one-layer placeholder network (never evaluated)
             eng = CallbackEngine([np.zeros((nx + nu, nx))], [np.zeros(nx)], H, nx, nu, integrator="unity",
                                  dtype=self.dtype, device=self.device, max_batch=1, kernel="valu")
             eng.set_objective(**self.resolved(H, nx, nu))
-            self._engines[key] = eng
-        return eng
+            self._engines[key] = [eng, fp]
+            return eng
+        if ent[1] != fp:            # parameters were edited since the upload: the reference re-reads them every call
+            ent[0].set_objective(**self.resolved(H, nx, nu))
+            ent[1] = fp
+        return ent[0]
 
     def _z(self, states, u):
         states, u = np.asarray(states, dtype=np.float64), np.asarray(u, dtype=np.float64)
@@ -74,7 +86,8 @@ class QuadraticObjective(ObjectiveFunc):
         n = H * (nx + nu)
         Hm = np.zeros((n, n))
         for t in range(H):
-            Hm[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx] = r["Q"] + r["Q"].T
+            Qt = r["QT"] if (t == H - 1 and r["QT"] is not None) else r["Q"]
+            Hm[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx] = Qt + Qt.T
             o = H * nx + t * nu
             Hm[o:o + nu, o:o + nu] = r["R"] + r["R"].T
         return Hm

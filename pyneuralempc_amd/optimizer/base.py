@@ -130,6 +130,34 @@ def warm_start_shift(prev, H, x_dim, u_dim):
     return np.concatenate([xs[1:].ravel(), xs[-1], us[1:].ravel(), us[-1]])
 
 
+_FUSED_CACHE_SIZE = 4   # evaluators an integrator keeps alive (each owns a device handle and its workspaces)
+
+
+def fused_evaluator(integrator, objective, box):
+    """The integrator's evaluator for (objective, box), created on first use and REFRESHED on every use: the cache is
+    keyed on the objects themselves (weak references, so a new objective allocated at a recycled id() cannot hit a stale
+    entry) and the uploaded parameters are compared with the objects' current ones, because the caller may edit
+    QuadraticObjective.params / the box bounds between solves and the reference re-reads them on every call.  At most
+    _FUSED_CACHE_SIZE entries; the least recently used one is dropped (with its device handle)."""
+    import weakref
+    cache = integrator._fused
+    key = (id(objective), id(box) if box is not None else None)
+    ent = cache.get(key)
+    if ent is not None and (ent[0]() is not objective or (box is not None and ent[1]() is not box)):
+        del cache[key]          # a dead object's id was recycled
+        ent = None
+    if ent is None:
+        ev = _FusedEvaluator(integrator, objective, box)
+        ent = (weakref.ref(objective), weakref.ref(box) if box is not None else None, ev)
+    else:
+        del cache[key]          # re-inserted below: dict order = recency
+    cache[key] = ent
+    while len(cache) > _FUSED_CACHE_SIZE:
+        cache.pop(next(iter(cache)))
+    ent[2].refresh(objective, box)
+    return ent[2]
+
+
 class _FusedEvaluator:
     """integrator + QuadraticObjective [+ BoxStateConstraint] on ONE engine: a single device call
     yields f, grad f, g, dense jac g for an iterate; results are cached per (z, x0) because the
@@ -138,14 +166,29 @@ class _FusedEvaluator:
     def __init__(self, integrator, objective, box):
         model = integrator.model
         self.model = model
+        self.H, self.nx, self.nu = integrator.H, model.x_dim, model.u_dim
         self.engine = model.make_engine(integrator.H, integrator.KIND, DT=integrator.DT, max_batch=1)
-        self.engine.set_objective(**objective.resolved(integrator.H, model.x_dim, model.u_dim))
-        if box is not None:
-            lo, hi = box._bounds(model.x_dim)
-            self.engine.set_box_rows(lo, hi)
+        self._obj_fp = None
+        self._box_fp = None
         self._key = None
         self._val = None
         self.n_device_evals = 0
+        self.refresh(objective, box)
+
+    def refresh(self, objective, box):
+        """Re-upload the objective / box bounds when they differ from what the handle holds."""
+        fp = objective.fingerprint(self.H, self.nx, self.nu)
+        if fp != self._obj_fp:
+            self.engine.set_objective(**objective.resolved(self.H, self.nx, self.nu))
+            self._obj_fp = fp
+            self._key = None
+        if box is not None:
+            lo, hi = box._bounds(self.nx)
+            bfp = np.asarray(lo, dtype=np.float64).tobytes() + np.asarray(hi, dtype=np.float64).tobytes()
+            if bfp != self._box_fp:
+                self.engine.set_box_rows(lo, hi)
+                self._box_fp = bfp
+                self._key = None
 
     def set_parameters(self, p, tvp):
         """Bind the problem's constant / time-varying parameters (extra network inputs; the history
@@ -190,11 +233,7 @@ class _CallbackGlue:
         boxes = [c for c in constraints if isinstance(c, BoxStateConstraint)]
         if (isinstance(integrator, DeviceIntegrator) and isinstance(objective_func, QuadraticObjective)
                 and len(boxes) == len(constraints) and len(boxes) <= 1):
-            key = (id(objective_func), id(boxes[0]) if boxes else None)
-            cache = integrator._fused
-            if key not in cache:
-                cache[key] = _FusedEvaluator(integrator, objective_func, boxes[0] if boxes else None)
-            self._fused = cache[key]
+            self._fused = fused_evaluator(integrator, objective_func, boxes[0] if boxes else None)
             self._fused.set_parameters(p, tvp)
 
     def _split(self, x):

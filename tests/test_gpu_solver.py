@@ -164,3 +164,79 @@ def test_riccati_sweep_per_thread_and_per_wave_agree(dims):
     np.testing.assert_allclose(Zw.cpu().numpy(), Zt.cpu().numpy(), rtol=0, atol=1e-12)
     assert torch.equal(out["auto"][0], Zw if nx * (nx + nu) >= 12 else Zt)
     assert int((st == 0).sum()) >= B - 2
+
+
+def test_next_batch_with_p_and_tvp_binds_per_problem_parameters():
+    """Models with constant / time-varying parameters: next_batch takes p / tvp per problem (or one set for all) and
+    never evaluates B problems against the (1, H, n_extra) binding a previous NMPC.next left behind."""
+    import pyneuralempc_amd as nEMPC
+    nx, nu, H, B, pd, td = 2, 1, 8, 5, 1, 2
+    net = orc.MLP.random(nx + nu + td + pd, [32, 32], nx, seed=5)
+    net.W[-1] *= 0.2
+    net.b[-1] *= 0.2
+    rng = np.random.default_rng(8)
+    X0 = rng.uniform(-0.5, 0.5, size=(B, nx))
+    P = rng.normal(size=(B, pd))
+    TV = rng.normal(size=(B, H, td))
+    model = nEMPC.model.MLPModel(net.W, net.b, nx, nu, p_dim=pd, tvp_dim=td, device="cuda:0")
+    integ = nEMPC.integrator.discret.DiscretIntegrator(model, H)
+    obj = nEMPC.objective.QuadraticObjective(Q=np.eye(nx), R=0.05 * np.eye(nu), xref=np.full((H, nx), 0.3), device="cuda:0")
+    dom = nEMPC.constraints.DomainConstraint(states_constraint=[[-3.0, 3.0]] * nx, control_constraint=[[-1.0, 1.0]])
+    ctl = nEMPC.controller.NMPC(integ, obj, [dom], H, 1.0, optimizer=nEMPC.optimizer.Slsqp())
+    # a single-problem solve first: leaves a one-problem parameter binding on the shared handle
+    s1, u1 = ctl.next(X0[0], p=P[0], tvp=TV[0])
+    assert s1 is not None
+    with pytest.raises(ValueError, match="p_dim"):
+        ctl.next_batch(X0, tvp=TV)
+    S, U, st = ctl.next_batch(X0, p=P, tvp=TV, max_iter=80)
+    assert (st == 0).all()
+    # every problem solved with ITS parameters: the defects of the returned trajectories vanish under the oracle
+    for b in range(B):
+        extra = np.concatenate([TV[b], np.tile(P[b].reshape(1, -1), (H, 1))], axis=1)
+        prob = orc.Problem(net, H, nx, nu, extra=extra)
+        z = np.concatenate([S[b].ravel(), U[b].ravel()])
+        assert np.abs(prob.constraints(z, X0[b])).max() < 1e-7
+    # problem 0 agrees with the single-problem SLSQP solve of the same data
+    np.testing.assert_allclose(S[0], s1, atol=5e-4)   # SLSQP stops at its own ftol
+    # one parameter set for all problems == that set repeated
+    Sa, Ua, _ = ctl.next_batch(X0, p=P[1], tvp=TV[1], max_iter=80)
+    Sb, Ub, _ = ctl.next_batch(X0, p=np.tile(P[1], (B, 1)), tvp=np.tile(TV[1][None], (B, 1, 1)), max_iter=80)
+    assert np.array_equal(Sa, Sb) and np.array_equal(Ua, Ub)
+
+
+def test_objective_edits_between_solves_reach_the_device():
+    """QuadraticObjective.params edited after the first solve (a moving reference in tracking MPC): the fused
+    evaluator, the objective's own engine and next_batch all see the new values (the cache was keyed by id()
+    and uploaded once)."""
+    import pyneuralempc_amd as nEMPC
+    from pyneuralempc_amd.optimizer.ipopt import IpoptProblem
+    nx, nu, H = 2, 1, 6
+    net = orc.MLP.random(nx + nu, [16], nx, seed=1)
+    model = nEMPC.model.MLPModel(net.W, net.b, nx, nu, device="cuda:0")
+    integ = nEMPC.integrator.discret.DiscretIntegrator(model, H)
+    obj = nEMPC.objective.QuadraticObjective(Q=np.eye(nx), R=0.1 * np.eye(nu), xref=np.zeros((H, nx)), device="cuda:0")
+    box = nEMPC.constraints.BoxStateConstraint(-1.0, 1.0, x_dim=nx)
+    Z, X0 = orc.synthetic_inputs(1, H, nx, nu, seed=3)
+    z, x0 = Z[0], X0[0]
+    pb = IpoptProblem(x0, obj, [box], integ)
+    f0 = pb.objective(z)
+    np.testing.assert_allclose(f0, orc.Problem(net, H, nx, nu).objective(z), rtol=1e-12)
+    obj.params["xref"] = np.full((H, nx), 0.5)
+    obj.params["QT"] = 3.0 * np.eye(nx)
+    ref = orc.Problem(net, H, nx, nu, xref=np.full((H, nx), 0.5), QT=3.0 * np.eye(nx))
+    pb2 = IpoptProblem(x0, obj, [box], integ)
+    assert pb2._fused is pb._fused                      # same handle, refreshed parameters
+    np.testing.assert_allclose(pb2.objective(z), ref.objective(z), rtol=1e-12)
+    np.testing.assert_allclose(pb2.gradient(z), ref.gradient(z), rtol=1e-12, atol=1e-12)
+    st, u = z[:H * nx].reshape(H, nx), z[H * nx:].reshape(H, nu)
+    np.testing.assert_allclose(obj.forward(st, u), ref.objective(z), rtol=1e-12)
+    np.testing.assert_allclose(obj.hessian(st, u), ref.objective_hessian(), rtol=1e-12)
+    # the box bounds are re-read as well
+    box.lo, box.hi = np.full(nx, -0.25), np.full(nx, 0.25)
+    pb3 = IpoptProblem(x0, obj, [box], integ)
+    assert np.allclose(pb3.get_constraint_lower_bounds()[H * nx:], -0.25)
+    # the evaluator cache is bounded
+    for k in range(8):
+        o = nEMPC.objective.QuadraticObjective(xref=np.full((H, nx), 0.1 * k), device="cuda:0")
+        IpoptProblem(x0, o, [], integ)
+    assert len(integ._fused) <= 4

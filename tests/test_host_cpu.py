@@ -148,6 +148,12 @@ def test_quadratic_objective_host_side():
     assert Hm.shape == (9, 9) and np.allclose(Hm[:2, :2], [[2.0, 0.5], [0.5, 4.0]]) and np.isclose(Hm[6, 6], 0.6)
     S = q.hessianstructure(3, M())
     assert np.array_equal(S != 0, Hm != 0)
+    # terminal weight: the last state block carries QT + QT^T, and a parameter edit changes the fingerprint
+    fp = q.fingerprint(3, 2, 1)
+    q.params["QT"] = [[5.0, 0.0], [1.0, 7.0]]
+    Ht = q.hessian(np.zeros((3, 2)), np.zeros((3, 1)))
+    assert np.allclose(Ht[4:6, 4:6], [[10.0, 1.0], [1.0, 14.0]]) and np.allclose(Ht[:4, :4], Hm[:4, :4])
+    assert q.fingerprint(3, 2, 1) != fp
     man = ManualObjectifFunc(lambda s, u, p, t: 1.0, lambda s, u, p, t: np.zeros(3), lambda s, u, p, t: np.eye(3))
     assert man.forward(None, None) == 1.0 and man.hessian(None, None).shape == (3, 3)
 

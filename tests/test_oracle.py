@@ -195,3 +195,39 @@ def test_c_oracle_matches_numpy_oracle(name):
     np.testing.assert_allclose(cgrad, grad, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(cg, g, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(cjac, jac, rtol=1e-11, atol=1e-12)
+
+
+def test_gauss_newton_hessian_is_the_first_order_part_of_the_exact_one():
+    """oracle.gauss_newton_hessian: (a) its per-step blocks are T^T diag(w) T with T checked by central finite
+    differences of the step map; (b) for a network without hidden layer (zero second derivative) the exact Lagrangian
+    Hessian has no constraint curvature at all, and with w = 0 both reduce to sigma * d2f; (c) PSD for w >= 0."""
+    H, nx, nu = 5, 2, 1
+    net = orc.MLP.random(nx + nu, [12, 9], nx, seed=4)
+    prob = orc.Problem(net, H, nx, nu, orc.RK4, 0.2, Q=np.diag([1.0, 2.0]), R=np.array([[0.3]]))
+    Z, X0 = orc.synthetic_inputs(1, H, nx, nu, seed=2)
+    z, x0 = Z[0], X0[0]
+    w = np.random.default_rng(5).uniform(0.2, 1.5, size=H * nx)
+    G = prob.gauss_newton_hessian(z, x0, w, 0.8)
+    eps = 1e-6
+    Jfd = np.zeros((H * nx, prob.n))
+    for j in range(prob.n):
+        e = np.zeros(prob.n); e[j] = eps
+        Jfd[:, j] = (prob.constraints(z + e, x0) - prob.constraints(z - e, x0)) / (2 * eps)
+    ref = 0.8 * prob.objective_hessian()
+    for t in range(H):
+        cols = prob.tile_columns(t)
+        keep = cols[cols >= 0]
+        T = Jfd[t * nx:(t + 1) * nx][:, keep].copy()
+        # the defect's own -x_t column is not part of the tile; tile columns are x_{t-1} and u_t only
+        ref[np.ix_(keep, keep)] += T.T @ np.diag(w[t * nx:(t + 1) * nx]) @ T
+    assert np.abs(G - ref).max() < 1e-7
+    assert np.array_equal(G, G.T) or np.abs(G - G.T).max() < 1e-15
+    assert np.linalg.eigvalsh(0.5 * (G + G.T)).min() > -1e-12
+    lin = orc.MLP([np.random.default_rng(1).normal(size=(nx + nu, nx))], [np.zeros(nx)])
+    pl = orc.Problem(lin, H, nx, nu, orc.DISCRET)
+    lam = np.random.default_rng(2).normal(size=pl.m)
+    np.testing.assert_allclose(pl.lagrangian_hessian(z, x0, lam, 0.8), pl.gauss_newton_hessian(z, x0, np.zeros(H * nx), 0.8),
+                               atol=1e-14)
+    r, c = prob.hessian_structure()
+    mask = np.zeros((prob.n, prob.n), dtype=bool); mask[r, c] = True; mask |= mask.T
+    assert np.all(G[~mask] == 0.0)       # same pattern as the exact callback
