@@ -186,7 +186,9 @@ int nempc_hess_gn(nempc_handle h, int32_t B, const void* Z, const void* X0, cons
  *   +-INFINITY allowed; the vectors DomainConstraint.get_lower/upper_bounds produce, constraints.py:26-30);
  *   status (B) device int32 out: 0 converged (Optimizer.SUCCESS), 1 not converged (Optimizer.FAIL);
  *   *iters (host, optional) outer iterations run.  Synchronises the stream internally (convergence polls).
- *   Box ROWS (nempc_set_box_rows) are not handled here -- express state bounds as variable bounds.
+ *   Box ROWS (nempc_set_box_rows) are state limits: they are intersected with lb / ub on the state variables (what the
+ *   reference's glue would hand Ipopt as constraint rows, optimizer/ipopt.py:44-52, is a bound here).
+ *   lb[i] == ub[i] (a fixed variable) is NEMPC_EINVAL: the log barrier needs an interior.
  *   rolling_window > 1 is NEMPC_EUNSUPPORTED (the stage structure the Riccati sweep relies on is gone). */
 typedef struct nempc_solver_opts {
     int32_t max_iter;        /* outer iterations, e.g. 200 */
@@ -197,6 +199,12 @@ typedef struct nempc_solver_opts {
     double tol_step;         /* max |dz| <= tol_step * (1 + max |z|), e.g. 1e-8 */
     double mu_init, mu_min, mu_factor; /* barrier schedule, e.g. 1e-1, 1e-9, 0.2 */
     double reg;              /* initial Levenberg term on the control Hessian, e.g. 1e-9 */
+    int32_t compact;         /* 1: whenever a quarter of the still-active problems has converged (checked every check_every
+                                iterations) gather the unconverged ones to the front and launch only over them -- the
+                                stragglers then stop costing batch-wide launches; 0: lock step over all B to the end.
+                                Results are identical either way (per-problem arithmetic does not depend on the slot). */
+    int32_t reserved;        /* 0 */
+    int32_t* iters_out;      /* optional device int32 (B): iteration at which each problem converged (0 = did not) */
 } nempc_solver_opts;
 
 int nempc_solve(nempc_handle h, int32_t B, const void* X0, void* Z, const double* lb, const double* ub,

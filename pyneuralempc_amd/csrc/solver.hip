@@ -19,6 +19,7 @@
 // Every problem carries its own mu, nu, step length and status; the batch advances in lock step and finished
 // problems idle.  All arithmetic is in kernels here; the callbacks are the handle's own row/objective kernels.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <limits>
 
@@ -40,6 +41,7 @@ struct SolverArgs {
     const void* lb; const void* ub;                                      // (n) device, dtype T, +-inf allowed
     void* mu; void* pen; void* reg; void* alpha; void* phi0; void* dir;  // (B) per problem (pen = l1 penalty)
     int* status; int* lsdone; int* n_active;
+    int* iters_done; int cur_it;                                         // per problem: iteration at which it converged
     void* dz; void* info;                                                // (B,n), (B,INFO_N)
     void* Kst; void* kst; void* Pst; void* pst;                          // Riccati storage per problem
     void* tmp; size_t tmp_stride;                                        // global temporaries when LDS is too small
@@ -47,6 +49,7 @@ struct SolverArgs {
     int ppw;                                                             // problems per workgroup (LDS mode)
     int lds_stride;                                                      // elements per problem in LDS (odd)
     double tol_g, tol_step, mu_min, mu_factor;
+    double armijo_slack;                                                 // relative slack of the Armijo test (see merit kernel)
 };
 
 template <typename T>
@@ -754,10 +757,12 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, int mode
             if (!last_mu) {
                 // superlinear decrease: mu <- max(mu_min, min(mu_factor * mu, mu^1.5))
                 if (lane == 0) mu[b] = fmax(fmin(mu[b] * (T)a.mu_factor, mu[b] * sqrt(mu[b])), (T)a.mu_min);
-                // new sub-problem: skip this step (direction was computed for the old mu)
+                // new sub-problem: skip this step (direction was computed for the old mu).  (Lowering mu one iteration
+                // late instead, from the previous iteration's norms, so that no iteration is skipped, was measured:
+                // same median iteration count, slightly fewer problems converged within 40 / 80 / 160 iterations.)
                 if (lane == 0) { a.lsdone[b] = 1; atomicAdd(a.n_active, 1); }
             } else {
-                if (lane == 0) { a.status[b] = 0; a.lsdone[b] = 1; }
+                if (lane == 0) { a.status[b] = 0; a.lsdone[b] = 1; a.iters_done[b] = a.cur_it + 1; }
             }
             return;
         }
@@ -783,7 +788,10 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, int mode
     const T phit = (T)((double)ft[b] + bar + (double)nu[b] * g1);
     const T al = alpha[b];
     // Armijo on the l1 merit; the directional derivative is negative for a descent direction
-    const bool ok = (phit == phit) && phit <= phi0[b] + T(1e-4) * al * fmin(dir[b], T(0)) + T(1e-12) * fabs(phi0[b]);
+    // the slack absorbs the rounding of the merit value itself (f is a sum of ~n terms in T): without a dtype-sized one
+    // an fp32 iterate close to its solution fails the test on noise, halves its step six times and gets damped
+    const T slack = (T)a.armijo_slack;
+    const bool ok = (phit == phit) && phit <= phi0[b] + T(1e-4) * al * fmin(dir[b], T(0)) + slack * fabs(phi0[b]);
     if (ok) {
         for (int i = lane; i < a.n; i += 64) Zcur[(size_t)b * a.n + i] = zt[i];
         T* lam = (T*)a.lam + (size_t)b * a.m;
@@ -813,9 +821,14 @@ __global__ __launch_bounds__(256) void solver_trial_kernel(int B, int n, const T
 template <typename T>
 __global__ __launch_bounds__(256) void solver_init_kernel(int B, int n, T* __restrict__ Z, const T* __restrict__ lb,
                                                           const T* __restrict__ ub, T* mu, T* nu, T* reg, int* status,
-                                                          T mu0, T reg0, int has_bounds) {
+                                                          int* orig, int* iters_done, T* info, T mu0, T reg0,
+                                                          int has_bounds) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (size_t)B) { mu[i] = has_bounds ? mu0 : T(0); nu[i] = T(1); reg[i] = reg0; status[i] = -1; }
+    if (i < (size_t)B) {
+        mu[i] = has_bounds ? mu0 : T(0); nu[i] = T(1); reg[i] = reg0; status[i] = -1;
+        orig[i] = (int)i; iters_done[i] = 0;
+        for (int k = 0; k < INFO_N; ++k) info[i * INFO_N + k] = std::numeric_limits<T>::max();   // "no previous step"
+    }
     if (i >= (size_t)B * n) return;
     const int k = (int)(i % n);
     const T lo = lb[k], hi = ub[k];
@@ -828,18 +841,84 @@ __global__ __launch_bounds__(256) void solver_init_kernel(int B, int n, T* __res
     Z[i] = z;
 }
 
-__global__ void solver_finalize_kernel(int B, int* status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B && status[b] < 0) status[b] = 1;
+// ---- compaction of the unconverged problems (the lock-step batch would otherwise launch every kernel B wide for a
+// handful of stragglers).  One workgroup computes the stable partition of slots [0, Bact): perm[new slot] = old slot,
+// unconverged first; the rows of every per-problem array that lives across iterations are then gathered into the
+// second buffer set.
+__global__ __launch_bounds__(1024) void solver_partition_kernel(int Bact, const int* __restrict__ status,
+                                                                int* __restrict__ perm, int* __restrict__ count) {
+    __shared__ int s_cnt[1024];
+    __shared__ int s_tot;
+    const int tid = threadIdx.x;
+    const int per = (Bact + 1023) / 1024;
+    const int lo = tid * per, hi = min(Bact, lo + per);
+    int c = 0;
+    for (int b = lo; b < hi; ++b) c += status[b] < 0 ? 1 : 0;
+    s_cnt[tid] = c;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 1024; ++i) { const int v = s_cnt[i]; s_cnt[i] = run; run += v; }
+        s_tot = run;
+        *count = run;
+    }
+    __syncthreads();
+    int pa = s_cnt[tid], pi = s_tot + (lo - s_cnt[tid]);     // next active / inactive slot of this thread's range
+    for (int b = lo; b < hi; ++b) {
+        if (status[b] < 0) perm[pa++] = b; else perm[pi++] = b;
+    }
+}
+
+struct CompactArrays {   // (src, dst, elements per problem, bytes per element); up to 12 arrays
+    const void* src[12];
+    void* dst[12];
+    int per[12];
+    int esz[12];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void solver_gather_kernel(int Bact, const int* __restrict__ perm, CompactArrays ca) {
+    const int slot = blockIdx.x;
+    if (slot >= Bact) return;
+    const int from = perm[slot];
+    for (int k = 0; k < ca.n; ++k) {
+        const int words = ca.per[k] * ca.esz[k] / 4;          // every array is a multiple of 4 bytes per problem
+        const unsigned* s = (const unsigned*)ca.src[k] + (size_t)from * words;
+        unsigned* d = (unsigned*)ca.dst[k] + (size_t)slot * words;
+        for (int i = threadIdx.x; i < words; i += 256) d[i] = s[i];
+    }
+}
+
+// results back in the caller's order: Z_out[orig[slot]] = Z[slot]; unfinished problems are FAIL (1)
+template <typename T>
+__global__ __launch_bounds__(256) void solver_scatter_kernel(int B, int n, const T* __restrict__ Zc,
+                                                             const int* __restrict__ status_c,
+                                                             const int* __restrict__ orig,
+                                                             const int* __restrict__ iters_c, T* __restrict__ Zout,
+                                                             int* __restrict__ status_out, int* __restrict__ iters_out) {
+    const int slot = blockIdx.x;
+    if (slot >= B) return;
+    const int o = orig[slot];
+    for (int i = threadIdx.x; i < n; i += 256) Zout[(size_t)o * n + i] = Zc[(size_t)slot * n + i];
+    if (threadIdx.x == 0) {
+        status_out[o] = status_c[slot] == 0 ? 0 : 1;
+        if (iters_out) iters_out[o] = iters_c[slot];
+    }
 }
 
 struct SolverWs {
     void *Zt = nullptr, *f = nullptr, *ft = nullptr, *grad = nullptr, *g = nullptr, *gt = nullptr, *tiles = nullptr;
     void *lb = nullptr, *ub = nullptr, *mu = nullptr, *nu = nullptr, *reg = nullptr, *alpha = nullptr, *phi0 = nullptr,
-         *dir = nullptr, *hblk = nullptr, *lam = nullptr, *lamn = nullptr, *sig = nullptr, *dz = nullptr, *info = nullptr, *Kst = nullptr, *kst = nullptr, *Pst = nullptr, *pst = nullptr,
-         *tmp = nullptr;
+         *dir = nullptr, *hblk = nullptr, *lam = nullptr, *lamn = nullptr, *sig = nullptr, *dz = nullptr, *Kst = nullptr, *kst = nullptr, *Pst = nullptr, *pst = nullptr,
+         *tmp = nullptr;   // (info lives in infoc: it is read across iterations)
     int *lsdone = nullptr, *n_active = nullptr;
+    // state that lives across iterations, in two buffer sets (compaction gathers from one into the other)
+    void *Zc[2] = {nullptr, nullptr}, *X0c[2] = {nullptr, nullptr}, *lamc[2] = {nullptr, nullptr}, *muc[2] = {nullptr, nullptr},
+         *nuc[2] = {nullptr, nullptr}, *regc[2] = {nullptr, nullptr}, *exc[2] = {nullptr, nullptr}, *infoc[2] = {nullptr, nullptr};
+    int *stc[2] = {nullptr, nullptr}, *orig[2] = {nullptr, nullptr}, *itc[2] = {nullptr, nullptr};
+    int *perm = nullptr, *count = nullptr;
     int cap = 0;
+    size_t ex_per = 0;
 };
 
 int lq_tmp_elems(int nx, int nu) { return 3 * nx * nx + 3 * nx * nu + nu * nu + 5 * nx + 3 * nu + 1 + (nx + 1) * nu; }
@@ -850,47 +929,90 @@ void solver_free(Handle& h) {
     SolverWs* w = static_cast<SolverWs*>(h.solver_ws);
     if (!w) return;
     void** ptrs[] = {&w->Zt, &w->f, &w->ft, &w->grad, &w->g, &w->gt, &w->tiles, &w->lb, &w->ub, &w->mu, &w->nu, &w->reg,
-                     &w->alpha, &w->phi0, &w->dir, &w->hblk, &w->lam, &w->lamn, &w->sig, &w->dz, &w->info, &w->Kst, &w->kst, &w->Pst, &w->pst, &w->tmp};
+                     &w->alpha, &w->phi0, &w->dir, &w->hblk, &w->lam, &w->lamn, &w->sig, &w->dz, &w->Kst, &w->kst, &w->Pst, &w->pst, &w->tmp};
     for (void** p : ptrs)
         if (*p) (void)hipFree(*p);
     if (w->lsdone) (void)hipFree(w->lsdone);
     if (w->n_active) (void)hipFree(w->n_active);
+    for (int k = 0; k < 2; ++k) {
+        void* ps[] = {w->Zc[k], w->X0c[k], w->lamc[k], w->muc[k], w->nuc[k], w->regc[k], w->exc[k], w->infoc[k], w->stc[k],
+                      w->orig[k], w->itc[k]};
+        for (void* p : ps)
+            if (p) (void)hipFree(p);
+    }
+    if (w->perm) (void)hipFree(w->perm);
+    if (w->count) (void)hipFree(w->count);
     delete w;
     h.solver_ws = nullptr;
 }
+
+namespace {
+// the handle's extras binding is pointed at the compacted copy while the solve runs; put back on every exit path
+struct ExtraBindingGuard {
+    Handle& h;
+    const void* saved;
+    int saved_B;
+    explicit ExtraBindingGuard(Handle& hh) : h(hh), saved(hh.d_extra), saved_B(hh.extra_B) {}
+    ~ExtraBindingGuard() { h.d_extra = saved; h.extra_B = saved_B; }
+};
+}  // namespace
 
 template <typename T>
 static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* lb, const double* ub,
                        const nempc_solver_opts& o, int32_t* status_dev, int32_t* iters_host, hipStream_t s) {
     const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu, nin = h.nin, n = h.n, m = h.m;
+    const size_t ex_per = (size_t)H * h.ne;
     if (!h.solver_ws) h.solver_ws = new SolverWs();
-    SolverWs& w = *static_cast<SolverWs*>(h.solver_ws);
-    if (w.cap < B) {
-        solver_free(h);
-        h.solver_ws = new SolverWs();
-        SolverWs& w2 = *static_cast<SolverWs*>(h.solver_ws);
-        const size_t e = sizeof(T), Bn = (size_t)B;
-        struct { void** p; size_t bytes; } al[] = {
-            {&w2.Zt, Bn * n * e}, {&w2.f, Bn * e}, {&w2.ft, Bn * e}, {&w2.grad, Bn * n * e}, {&w2.g, Bn * m * e},
-            {&w2.gt, Bn * m * e}, {&w2.tiles, Bn * H * nx * nin * e}, {&w2.lb, (size_t)n * e}, {&w2.ub, (size_t)n * e},
-            {&w2.mu, Bn * e}, {&w2.nu, Bn * e}, {&w2.reg, Bn * e}, {&w2.alpha, Bn * e}, {&w2.phi0, Bn * e},
-            {&w2.dir, Bn * e}, {&w2.hblk, Bn * H * nin * nin * e}, {&w2.lam, Bn * m * e}, {&w2.lamn, Bn * m * e},
-            {&w2.sig, Bn * e}, {&w2.dz, Bn * n * e}, {&w2.info, Bn * INFO_N * e}, {&w2.Kst, Bn * H * nu * nx * e},
-            {&w2.kst, Bn * H * nu * e}, {&w2.Pst, Bn * H * nx * nx * e}, {&w2.pst, Bn * H * nx * e},
-            {&w2.tmp, Bn * lq_tmp_elems(nx, nu) * e}};
-        for (auto& x : al) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
-        NEMPC_HIP(hipMalloc((void**)&w2.lsdone, Bn * sizeof(int)));
-        NEMPC_HIP(hipMalloc((void**)&w2.n_active, sizeof(int)));
-        w2.cap = B;
+    {
+        SolverWs& w = *static_cast<SolverWs*>(h.solver_ws);
+        if (w.cap < B || w.ex_per != ex_per) {
+            solver_free(h);
+            h.solver_ws = new SolverWs();
+            SolverWs& w2 = *static_cast<SolverWs*>(h.solver_ws);
+            const size_t e = sizeof(T), Bn = (size_t)B;
+            struct { void** p; size_t bytes; } al[] = {
+                {&w2.Zt, Bn * n * e}, {&w2.f, Bn * e}, {&w2.ft, Bn * e}, {&w2.grad, Bn * n * e}, {&w2.g, Bn * m * e},
+                {&w2.gt, Bn * m * e}, {&w2.tiles, Bn * H * nx * nin * e}, {&w2.lb, (size_t)n * e}, {&w2.ub, (size_t)n * e},
+                {&w2.alpha, Bn * e}, {&w2.phi0, Bn * e},
+                {&w2.dir, Bn * e}, {&w2.hblk, Bn * H * nin * nin * e}, {&w2.lamn, Bn * m * e},
+                {&w2.sig, Bn * e}, {&w2.dz, Bn * n * e}, {&w2.Kst, Bn * H * nu * nx * e},
+                {&w2.kst, Bn * H * nu * e}, {&w2.Pst, Bn * H * nx * nx * e}, {&w2.pst, Bn * H * nx * e},
+                {&w2.tmp, Bn * lq_tmp_elems(nx, nu) * e}};
+            for (auto& x : al) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
+            for (int k = 0; k < 2; ++k) {
+                struct { void** p; size_t bytes; } al2[] = {
+                    {&w2.Zc[k], Bn * n * e}, {&w2.X0c[k], Bn * nx * e}, {&w2.lamc[k], Bn * m * e}, {&w2.muc[k], Bn * e},
+                    {&w2.nuc[k], Bn * e}, {&w2.regc[k], Bn * e}, {&w2.exc[k], Bn * ex_per * e}, {&w2.infoc[k], Bn * INFO_N * e},
+                    {(void**)&w2.stc[k], Bn * sizeof(int)}, {(void**)&w2.orig[k], Bn * sizeof(int)},
+                    {(void**)&w2.itc[k], Bn * sizeof(int)}};
+                for (auto& x : al2) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
+            }
+            NEMPC_HIP(hipMalloc((void**)&w2.lsdone, Bn * sizeof(int)));
+            NEMPC_HIP(hipMalloc((void**)&w2.n_active, sizeof(int)));
+            NEMPC_HIP(hipMalloc((void**)&w2.perm, Bn * sizeof(int)));
+            NEMPC_HIP(hipMalloc((void**)&w2.count, sizeof(int)));
+            w2.cap = B;
+            w2.ex_per = ex_per;
+        }
     }
     SolverWs& ws = *static_cast<SolverWs*>(h.solver_ws);
-    // bounds -> device (dtype T); +-inf become +-max so that comparisons stay exact
+    // bounds -> device (dtype T); +-inf become +-max so that comparisons stay exact.  Box ROWS on the states
+    // (nempc_set_box_rows; a Constraint's rows in the reference's glue, optimizer/ipopt.py:44-52) are bounds on the
+    // state variables for this solver: intersected here, what controller.py:101-105 of this package does on the host.
     std::vector<T> hl(n), hu(n);
     bool has_bounds = false;
     const T big = std::numeric_limits<T>::max();
     for (int i = 0; i < n; ++i) {
-        const double lo = lb ? lb[i] : -INFINITY, hi = ub ? ub[i] : INFINITY;
+        double lo = lb ? lb[i] : -INFINITY, hi = ub ? ub[i] : INFINITY;
+        if (h.box && i < H * nx) {
+            lo = std::max(lo, h.box_lo[i % nx]);
+            hi = std::min(hi, h.box_hi[i % nx]);
+        }
         if (lo > hi) { set_error("nempc_solve: lb > ub"); return NEMPC_EINVAL; }
+        if (lo == hi) {
+            set_error("nempc_solve: lb == ub (a fixed variable has no interior for the barrier); eliminate it from the problem");
+            return NEMPC_EINVAL;
+        }
         hl[i] = std::isfinite(lo) ? (T)lo : -big;
         hu[i] = std::isfinite(hi) ? (T)hi : big;
         has_bounds = has_bounds || std::isfinite(lo) || std::isfinite(hi);
@@ -899,36 +1021,59 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     NEMPC_HIP(hipMemcpyAsync(ws.ub, hu.data(), n * sizeof(T), hipMemcpyHostToDevice, s));
     NEMPC_HIP(hipStreamSynchronize(s));   // hl / hu are stack-owned
 
+    // ---- working copies in buffer set `cur`; the caller's Z / status are written once, at the end, in the caller's order
+    int cur = 0;
+    ExtraBindingGuard extra_guard(h);
+    NEMPC_HIP(hipMemcpyAsync(ws.Zc[0], Z, (size_t)B * n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    NEMPC_HIP(hipMemcpyAsync(ws.X0c[0], X0, (size_t)B * nx * sizeof(T), hipMemcpyDeviceToDevice, s));
+    if (ex_per) {
+        NEMPC_HIP(hipMemcpyAsync(ws.exc[0], h.d_extra, (size_t)B * ex_per * sizeof(T), hipMemcpyDeviceToDevice, s));
+        h.d_extra = ws.exc[0];
+        h.extra_B = B;
+    }
     const unsigned gBn = (unsigned)(((size_t)B * n + 255) / 256);
-    hipLaunchKernelGGL(solver_init_kernel<T>, dim3(gBn), dim3(256), 0, s, B, n, (T*)Z, (const T*)ws.lb, (const T*)ws.ub,
-                       (T*)ws.mu, (T*)ws.nu, (T*)ws.reg, status_dev, (T)o.mu_init, (T)o.reg, has_bounds ? 1 : 0);
+    hipLaunchKernelGGL(solver_init_kernel<T>, dim3(gBn), dim3(256), 0, s, B, n, (T*)ws.Zc[0], (const T*)ws.lb,
+                       (const T*)ws.ub, (T*)ws.muc[0], (T*)ws.nuc[0], (T*)ws.regc[0], ws.stc[0], ws.orig[0], ws.itc[0],
+                       (T*)ws.infoc[0], (T)o.mu_init, (T)o.reg, has_bounds ? 1 : 0);
+    NEMPC_HIP(hipMemsetAsync(ws.lamc[0], 0, (size_t)B * m * sizeof(T), s));
 
     SolverArgs a{};
-    a.B = B; a.H = H; a.nx = nx; a.nu = nu; a.nin = nin; a.n = n; a.m = m;
-    a.Z = Z; a.grad = ws.grad; a.g = ws.g; a.tiles = ws.tiles;
-    a.hblk = ws.hblk; a.lam = ws.lam; a.lamn = ws.lamn;
-    NEMPC_HIP(hipMemsetAsync(ws.lam, 0, (size_t)B * m * sizeof(T), s));
+    a.H = H; a.nx = nx; a.nu = nu; a.nin = nin; a.n = n; a.m = m;
+    a.grad = ws.grad; a.g = ws.g; a.tiles = ws.tiles;
+    a.hblk = ws.hblk; a.lamn = ws.lamn;
     a.obj = h.d_obj; a.oo = obj_offsets(H, nx, nu);
-    a.lb = ws.lb; a.ub = ws.ub; a.mu = ws.mu; a.pen = ws.nu; a.reg = ws.reg; a.alpha = ws.alpha; a.phi0 = ws.phi0;
-    a.dir = ws.dir; a.status = status_dev; a.lsdone = ws.lsdone; a.n_active = ws.n_active;
-    a.dz = ws.dz; a.info = ws.info; a.Kst = ws.Kst; a.kst = ws.kst; a.Pst = ws.Pst; a.pst = ws.pst;
+    a.lb = ws.lb; a.ub = ws.ub; a.alpha = ws.alpha; a.phi0 = ws.phi0;
+    a.dir = ws.dir; a.lsdone = ws.lsdone; a.n_active = ws.n_active;
+    a.dz = ws.dz; a.Kst = ws.Kst; a.kst = ws.kst; a.Pst = ws.Pst; a.pst = ws.pst;
     a.tmp = ws.tmp; a.tmp_stride = (size_t)B;
+    auto point_at = [&](int k) {
+        a.Z = ws.Zc[k]; a.lam = ws.lamc[k]; a.mu = ws.muc[k]; a.pen = ws.nuc[k]; a.reg = ws.regc[k];
+        a.status = ws.stc[k]; a.iters_done = ws.itc[k]; a.info = ws.infoc[k];
+        if (ex_per) h.d_extra = ws.exc[k];
+    };
+    point_at(0);
     int per_problem = 2 * n + 2 * H * nx + H * nx * nin + H * nin * nin + H * nu * nx + H * nu + H * nx * nx + H * nx + n +
                       lq_tmp_elems(nx, nu);
     per_problem |= 1;   // odd stride: the ppw lanes of a sweep hit different LDS banks
-    int ppw = (int)((size_t)150 * 1024 / ((size_t)per_problem * sizeof(T)));
-    if (ppw > 16) ppw = 16;
-    // the sweep is one latency chain per lane whatever the number of active lanes: spread the batch over the CUs
-    const int spread = (B + 255) / 256;
-    if (ppw > spread) ppw = spread < 1 ? 1 : spread;
-    // the wave-per-problem kernel runs one problem per wave of a 256-thread workgroup
     const bool wave_wanted = o.lq_kernel != 1 && (o.lq_kernel == 2 || nx * (nx + nu) >= 12);
-    if (wave_wanted && ppw > 4) ppw = 4;
-    a.use_lds = ppw >= 1;
-    a.ppw = ppw;
+    auto pick_ppw = [&](int Bact) {
+        int ppw = (int)((size_t)150 * 1024 / ((size_t)per_problem * sizeof(T)));
+        if (ppw > 16) ppw = 16;
+        // the sweep is one latency chain per lane whatever the number of active lanes: spread the batch over the CUs
+        const int spread = (Bact + 255) / 256;
+        if (ppw > spread) ppw = spread < 1 ? 1 : spread;
+        // the wave-per-problem kernel runs one problem per wave of a 256-thread workgroup
+        if (wave_wanted && ppw > 4) ppw = 4;
+        return ppw;
+    };
+    a.ppw = pick_ppw(B);
+    a.use_lds = a.ppw >= 1;
     a.lds_stride = per_problem;
-    const size_t lds_need = a.use_lds ? (size_t)ppw * per_problem * sizeof(T) : 0;
     a.tol_g = o.tol_constraint; a.tol_step = o.tol_step; a.mu_min = has_bounds ? o.mu_min : 0.0; a.mu_factor = o.mu_factor;
+    {
+        static const double slack_eps = [] { const char* e = getenv("NEMPC_SOLVER_SLACK_EPS"); return e ? atof(e) : 0.0; }();
+        a.armijo_slack = std::max(1e-12, slack_eps * (double)std::numeric_limits<T>::epsilon());
+    }
     auto lqk = (nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1> : ((nx == 6 && nu == 3) ? solver_lq_kernel<T, 6, 3> : solver_lq_kernel<T, 0, 0>);
     // wave-per-problem sweep when the working set is staged in LDS and a stage has enough entries to spread over a
     // wave: 6/3 stages 6.5 k vs 5.0 k MPC solves/s at C3; 2/1 stages are 4 entries wide and stay on the
@@ -937,49 +1082,65 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     if (lq_wave)
         lqk = (nx == 2 && nu == 1) ? solver_lqw_kernel<T, 2, 1>
                                    : ((nx == 6 && nu == 3) ? solver_lqw_kernel<T, 6, 3> : solver_lqw_kernel<T, 0, 0>);
-    NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lqk), lds_need));
+    {
+        const int ppw_max = (int)((size_t)150 * 1024 / ((size_t)per_problem * sizeof(T)));
+        const size_t lds_max = a.use_lds ? (size_t)std::min(std::max(ppw_max, 1), 16) * per_problem * sizeof(T) : 0;
+        NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lqk), lds_max));
+    }
 
+    int Bact = B;                 // slots [0, Bact) may still be unconverged; compaction keeps them in front
     int it = 0, rc;
     const int check = o.check_every > 0 ? o.check_every : 4;
+    static const int trace_slot = [] { const char* e = getenv("NEMPC_SOLVER_TRACE"); return e ? atoi(e) : -1; }();
+    const bool trace = trace_slot >= 0 && trace_slot < B;
+    const bool compact = o.compact != 0 && !trace;
     for (; it < o.max_iter; ++it) {
+        a.B = Bact;
+        a.cur_it = it;
+        const size_t lds_need = a.use_lds ? (size_t)a.ppw * per_problem * sizeof(T) : 0;
+        const unsigned gAn = (unsigned)(((size_t)Bact * n + 255) / 256);
+        void* Zc = ws.Zc[cur];
+        const void* X0c = ws.X0c[cur];
         // callbacks at the iterate: defects + tiles (row kernel), f + grad (objective kernel)
         // and the per-step Lagrangian blocks with the current multipliers (all zero on the first iterate:
         // Gauss-Newton step).  The RK4 matrix-core pipeline produces defects, tiles and blocks from one row launch.
         const bool rk4_pipeline = h.variant != NEMPC_KERNEL_VALU && h.cfg.integrator == NEMPC_RK4;
         if (rk4_pipeline) {
-            rc = launch_rowhess_rk4_mfma(h, B, Z, X0, ws.lam, ws.hblk, s, ws.g, ws.tiles);
+            rc = launch_rowhess_rk4_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s, ws.g, ws.tiles);
         } else {
-            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, ws.g, ws.tiles, s)
-                                                : launch_rows_valu(h, B, Z, X0, ws.g, ws.tiles, s);
+            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, Bact, Zc, X0c, ws.g, ws.tiles, s)
+                                                : launch_rows_valu(h, Bact, Zc, X0c, ws.g, ws.tiles, s);
             if (rc) return rc;
-            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rowhess_mfma(h, B, Z, X0, ws.lam, ws.hblk, s)
-                                                : launch_rowhess_valu(h, B, Z, X0, ws.lam, ws.hblk, s);
+            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rowhess_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s)
+                                                : launch_rowhess_valu(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s);
         }
         if (rc) return rc;
-        if ((rc = launch_objective(h, B, Z, ws.f, ws.grad, s))) return rc;
+        if ((rc = launch_objective(h, Bact, Zc, ws.f, ws.grad, s))) return rc;
         // LDS mode: four waves stage the working set, the first ppw lanes run the sweeps
-        hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (B + a.ppw - 1) / a.ppw : (B + 63) / 64), dim3(a.use_lds ? 256 : 64),
+        hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (Bact + a.ppw - 1) / a.ppw : (Bact + 63) / 64), dim3(a.use_lds ? 256 : 64),
                            lds_need, s, a);
         NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, sizeof(int), s));
-        hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(B), dim3(64), 0, s, a, 0, (const T*)ws.f, (const T*)nullptr,
-                           (const T*)nullptr, (const T*)nullptr, (T*)Z, 0);
+        hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(Bact), dim3(64), 0, s, a, 0, (const T*)ws.f, (const T*)nullptr,
+                           (const T*)nullptr, (const T*)nullptr, (T*)Zc, 0);
+        bool polled = false;
+        int nact = Bact;
         if ((it + 1) % check == 0 || it + 1 == o.max_iter) {
-            int nact = 0;
             NEMPC_HIP(hipMemcpyAsync(&nact, ws.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
             NEMPC_HIP(hipStreamSynchronize(s));
+            polled = true;
             if (nact == 0) { ++it; break; }
         }
         for (int ls = 0; ls < o.max_linesearch; ++ls) {
-            hipLaunchKernelGGL(solver_trial_kernel<T>, dim3(gBn), dim3(256), 0, s, B, n, (const T*)Z, (const T*)ws.dz,
+            hipLaunchKernelGGL(solver_trial_kernel<T>, dim3(gAn), dim3(256), 0, s, Bact, n, (const T*)Zc, (const T*)ws.dz,
                                (const T*)ws.alpha, (const int*)ws.lsdone, (T*)ws.Zt);
             // the merit function needs the defects only: the matrix-core kernel skips its reverse sweeps (tiles = null)
-            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, ws.Zt, X0, ws.gt, nullptr, s)
-                                                : launch_rows_valu(h, B, ws.Zt, X0, ws.gt, h.d_tiles_ws, s);
+            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, Bact, ws.Zt, X0c, ws.gt, nullptr, s)
+                                                : launch_rows_valu(h, Bact, ws.Zt, X0c, ws.gt, h.d_tiles_ws, s);
             if (rc) return rc;
-            if ((rc = launch_objective(h, B, ws.Zt, ws.ft, nullptr, s))) return rc;
+            if ((rc = launch_objective(h, Bact, ws.Zt, ws.ft, nullptr, s))) return rc;
             NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, sizeof(int), s));
-            hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(B), dim3(64), 0, s, a, 1, (const T*)ws.f, (const T*)ws.Zt,
-                               (const T*)ws.gt, (const T*)ws.ft, (T*)Z, ls + 1 == o.max_linesearch ? 1 : 0);
+            hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(Bact), dim3(64), 0, s, a, 1, (const T*)ws.f, (const T*)ws.Zt,
+                               (const T*)ws.gt, (const T*)ws.ft, (T*)Zc, ls + 1 == o.max_linesearch ? 1 : 0);
             // most iterations accept the first trial for every problem: one small poll saves the remaining
             // max_linesearch-1 callback evaluations
             int pending = 0;
@@ -987,8 +1148,65 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             NEMPC_HIP(hipStreamSynchronize(s));
             if (pending == 0) break;
         }
+        if (trace) {   // NEMPC_SOLVER_TRACE=<slot>: one line per iteration for that slot (diagnostic, synchronises)
+            T inf[INFO_N], muv, alv, regv, penv; int st, lsd;
+            NEMPC_HIP(hipStreamSynchronize(s));
+            NEMPC_HIP(hipMemcpy(inf, (const T*)a.info + (size_t)trace_slot * INFO_N, sizeof(inf), hipMemcpyDeviceToHost));
+            NEMPC_HIP(hipMemcpy(&muv, (const T*)a.mu + trace_slot, sizeof(T), hipMemcpyDeviceToHost));
+            NEMPC_HIP(hipMemcpy(&alv, (const T*)a.alpha + trace_slot, sizeof(T), hipMemcpyDeviceToHost));
+            NEMPC_HIP(hipMemcpy(&regv, (const T*)a.reg + trace_slot, sizeof(T), hipMemcpyDeviceToHost));
+            NEMPC_HIP(hipMemcpy(&penv, (const T*)a.pen + trace_slot, sizeof(T), hipMemcpyDeviceToHost));
+            NEMPC_HIP(hipMemcpy(&st, a.status + trace_slot, sizeof(int), hipMemcpyDeviceToHost));
+            NEMPC_HIP(hipMemcpy(&lsd, a.lsdone + trace_slot, sizeof(int), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[solver it %3d slot %d] mu %.2e step %.2e ginf %.2e lam %.2e amax %.2e alpha %.2e reg %.1e pen %.2e restarts %.0f status %d lsdone %d\n",
+                    it, trace_slot, (double)muv, (double)inf[INFO_STEP], (double)inf[INFO_GINF], (double)inf[INFO_LAM],
+                    (double)inf[INFO_AMAX], (double)alv, (double)regv, (double)penv, (double)inf[INFO_RESTARTS], st, lsd);
+        }
+        // ---- compaction: once a quarter of the active slots has finished, gather the unconverged problems to the
+        //      front of the other buffer set and shrink every launch to them
+        if (compact && polled && nact < Bact - Bact / 4 && Bact > 64) {
+            const int nxt = cur ^ 1;
+            hipLaunchKernelGGL(solver_partition_kernel, dim3(1), dim3(1024), 0, s, Bact, (const int*)ws.stc[cur], ws.perm,
+                               ws.count);
+            CompactArrays ca{};
+            int k = 0;
+            auto add = [&](const void* src, void* dst, int per, int esz) {
+                ca.src[k] = src; ca.dst[k] = dst; ca.per[k] = per; ca.esz[k] = esz; ++k;
+            };
+            add(ws.Zc[cur], ws.Zc[nxt], n, sizeof(T));
+            add(ws.X0c[cur], ws.X0c[nxt], nx, sizeof(T));
+            add(ws.lamc[cur], ws.lamc[nxt], m, sizeof(T));
+            add(ws.muc[cur], ws.muc[nxt], 1, sizeof(T));
+            add(ws.nuc[cur], ws.nuc[nxt], 1, sizeof(T));
+            add(ws.regc[cur], ws.regc[nxt], 1, sizeof(T));
+            add(ws.stc[cur], ws.stc[nxt], 1, sizeof(int));
+            add(ws.orig[cur], ws.orig[nxt], 1, sizeof(int));
+            add(ws.itc[cur], ws.itc[nxt], 1, sizeof(int));
+            add(ws.infoc[cur], ws.infoc[nxt], INFO_N, sizeof(T));
+            if (ex_per) add(ws.exc[cur], ws.exc[nxt], (int)ex_per, sizeof(T));
+            ca.n = k;
+            hipLaunchKernelGGL(solver_gather_kernel, dim3(Bact), dim3(256), 0, s, Bact, (const int*)ws.perm, ca);
+            // slots [Bact, B) hold problems that finished before earlier compactions: carry them over unchanged
+            if (Bact < B) {
+                const size_t rest = (size_t)(B - Bact);
+                NEMPC_HIP(hipMemcpyAsync((T*)ws.Zc[nxt] + (size_t)Bact * n, (const T*)ws.Zc[cur] + (size_t)Bact * n,
+                                         rest * n * sizeof(T), hipMemcpyDeviceToDevice, s));
+                NEMPC_HIP(hipMemcpyAsync(ws.stc[nxt] + Bact, ws.stc[cur] + Bact, rest * sizeof(int), hipMemcpyDeviceToDevice, s));
+                NEMPC_HIP(hipMemcpyAsync(ws.orig[nxt] + Bact, ws.orig[cur] + Bact, rest * sizeof(int), hipMemcpyDeviceToDevice, s));
+                NEMPC_HIP(hipMemcpyAsync(ws.itc[nxt] + Bact, ws.itc[cur] + Bact, rest * sizeof(int), hipMemcpyDeviceToDevice, s));
+            }
+            int cnt = 0;
+            NEMPC_HIP(hipMemcpyAsync(&cnt, ws.count, sizeof(int), hipMemcpyDeviceToHost, s));
+            NEMPC_HIP(hipStreamSynchronize(s));
+            cur = nxt;
+            point_at(cur);
+            Bact = cnt > 0 ? cnt : 1;
+            a.ppw = pick_ppw(Bact);
+        }
     }
-    hipLaunchKernelGGL(solver_finalize_kernel, dim3((B + 255) / 256), dim3(256), 0, s, B, status_dev);
+    hipLaunchKernelGGL(solver_scatter_kernel<T>, dim3(B), dim3(256), 0, s, B, n, (const T*)ws.Zc[cur],
+                       (const int*)ws.stc[cur], (const int*)ws.orig[cur], (const int*)ws.itc[cur], (T*)Z, status_dev,
+                       (int*)o.iters_out);
     NEMPC_HIP(hipGetLastError());
     NEMPC_HIP(hipStreamSynchronize(s));
     if (iters_host) *iters_host = it;

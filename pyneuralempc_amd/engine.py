@@ -363,11 +363,14 @@ class CallbackEngine:
         return res
 
     def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=100, max_linesearch=6, check_every=2,
-              tol_constraint=None, tol_step=None, mu_init=1e-1, mu_min=None, mu_factor=0.2, reg=None, lq_kernel="auto"):
+              tol_constraint=None, tol_step=None, mu_init=1e-1, mu_min=None, mu_factor=0.2, reg=None, lq_kernel="auto",
+              compact=True, return_iterations=False):
         """Batched on-device solve (Gauss-Newton SQP, see csrc/solver.hip).  X0 (B,nx) device tensor; Z_init (B,n)
         or None for the reference's cold start [x0 tiled H ; zeros] (optimizer/ipopt.py:149); lb/ub (n) host
         vectors as DomainConstraint produces them; tolerances default by dtype (fp64 1e-8, fp32 1e-4); lq_kernel picks the Riccati sweep ("auto" | "thread" per problem | "wave"
-        per problem).  Returns (Z (B,n), status (B,) int32 [0 ok / 1 fail], iters)."""
+        per problem); compact=True gathers the unconverged problems to the front as the batch converges (same results,
+        shorter launches).  Returns (Z (B,n), status (B,) int32 [0 ok / 1 fail], iters) [+ per-problem convergence
+        iteration (B,) int32 with return_iterations=True]."""
         B = int(X0.shape[0])
         self._check_in(X0, (B, self.nx), "X0")
         self._check_extra(B)
@@ -392,16 +395,20 @@ class CallbackEngine:
                 a, p = _as_c_double(np.broadcast_to(np.asarray(v, dtype=np.float64), (self.n,)))
                 keep.append(a)
                 ptrs.append(p)
+        its_dev = torch.zeros(B, dtype=torch.int32, device=self.device) if return_iterations else None
         opts = _lib.NempcSolverOpts(max_iter=max_iter, max_linesearch=max_linesearch, check_every=check_every,
                                     lq_kernel={"auto": 0, "thread": 1, "wave": 2}[lq_kernel],
                                     tol_constraint=tol_constraint, tol_step=tol_step, mu_init=mu_init, mu_min=mu_min,
-                                    mu_factor=mu_factor, reg=reg)
+                                    mu_factor=mu_factor, reg=reg, compact=1 if compact else 0, reserved=0,
+                                    iters_out=None if its_dev is None else its_dev.data_ptr())
         status = torch.empty(B, dtype=torch.int32, device=self.device)
         iters = ctypes.c_int32(0)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.nempc_solve(self._handle, B, ctypes.c_void_p(X0.data_ptr()), ctypes.c_void_p(Z.data_ptr()),
                                             ptrs[0], ptrs[1], ctypes.byref(opts), ctypes.c_void_p(status.data_ptr()),
                                             ctypes.byref(iters), self._stream()))
+        if return_iterations:
+            return Z, status, iters.value, its_dev
         return Z, status, iters.value
 
     def sync(self):
