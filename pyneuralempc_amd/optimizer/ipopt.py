@@ -57,7 +57,12 @@ class _SparseJacobianView:
 
     def __init__(self, core, with_hessian):
         self.core = core
-        self.objective, self.gradient, self.constraints = core.objective, core.gradient, core.constraints
+        if getattr(core, "_fused", None) is not None:
+            self.objective = lambda x: float(self._ev(x)["f"])
+            self.gradient = lambda x: self._ev(x)["grad"].copy()
+            self.constraints = lambda x: self._ev(x)["g"].copy()
+        else:
+            self.objective, self.gradient, self.constraints = core.objective, core.gradient, core.constraints
         self.rows, self.cols = core.jacobianstructure()
         if with_hessian:
             self.hessian, self.hessianstructure = core.hessian, core.hessianstructure
@@ -66,7 +71,16 @@ class _SparseJacobianView:
         return self.rows, self.cols
 
     def jacobian(self, x):
+        # the band values come from the device in jac_structure() order (fused sparse launch): the dense (m,n) matrix
+        # is neither assembled nor copied
+        fused = getattr(self.core, "_fused", None)
+        if fused is not None:
+            return fused.evaluate(x, self.core.x0, sparse=True)["jac_sparse"].copy()
         return self.core.jacobian(x)[self.rows, self.cols]
+
+    # with the sparse view every callback of an iterate shares the sparse evaluation (one device call per iterate)
+    def _ev(self, x):
+        return self.core._fused.evaluate(x, self.core.x0, sparse=True)
 
 
 class IpoptProblemFactory(ProblemFactory):

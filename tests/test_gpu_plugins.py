@@ -268,3 +268,35 @@ def test_torch_objective_through_the_unfused_glue():
     rows, cols = pb.hessianstructure()
     hv = pb.hessian(z, d["lam"][0], float(d["sigma"][0]))
     np.testing.assert_allclose(hv, d["hdense"][0][rows, cols], rtol=1e-10, atol=1e-11)
+
+
+def test_b1_fast_path_and_sparse_view_match_the_engine():
+    """The B=1 callback path (pinned, device-mapped staging; optimizer/base.py:_FusedEvaluator) returns what a plain
+    batched evaluation returns, for the dense and for the sparse-Jacobian view (band values straight from the device:
+    Ipopt(sparse_jacobian=True) never builds or copies the dense matrix), incl. the Hessian callback."""
+    import pyneuralempc_amd as nEMPC
+    from pyneuralempc_amd.optimizer.ipopt import IpoptProblem, _SparseJacobianView
+    d, W, b = load_case("c5_box")
+    H, nx, nu = int(d["H"]), int(d["nx"]), int(d["nu"])
+    model = nEMPC.model.MLPModel(W, b, nx, nu, device="cuda:0")
+    integ = nEMPC.integrator.discret.DiscretIntegrator(model, H)
+    obj = nEMPC.objective.QuadraticObjective(Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"], device="cuda:0")
+    box = nEMPC.constraints.BoxStateConstraint(d["box_lo"], d["box_hi"])
+    for i in range(d["Z"].shape[0]):
+        z, x0 = d["Z"][i], d["X0"][i]
+        pb = IpoptProblem(x0, obj, [box], integ)
+        assert pb._fused is not None
+        n_before = pb._fused.n_device_evals
+        np.testing.assert_allclose(pb.objective(z), d["f"][i], **F64)
+        np.testing.assert_allclose(pb.gradient(z), d["grad"][i], **F64)
+        np.testing.assert_allclose(pb.constraints(z), d["g"][i], **F64)
+        np.testing.assert_allclose(pb.jacobian(z), d["jac"][i], **F64)
+        assert pb._fused.n_device_evals == n_before + 1             # four callbacks, one device evaluation
+        sv = _SparseJacobianView(pb, True)
+        rows, cols = sv.jacobianstructure()
+        vals = sv.jacobian(z)
+        assert np.array_equal(vals, d["jac"][i][rows, cols]) or np.allclose(vals, d["jac"][i][rows, cols], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(sv.constraints(z), d["g"][i], **F64)
+        np.testing.assert_allclose(sv.objective(z), d["f"][i], **F64)
+        hr, hc = pb.hessianstructure()
+        np.testing.assert_allclose(pb.hessian(z, d["lam"][i], float(d["sigma"][i])), d["hdense"][i][hr, hc], rtol=1e-11, atol=1e-12)

@@ -31,4 +31,18 @@ with warnings.catch_warnings():
         pb._fused._key = None
         pb.constraints(z + 1e-9 * i)
     te = (time.perf_counter() - t1) / 200
+    from pyneuralempc_amd.optimizer.ipopt import IpoptProblem, _SparseJacobianView
+    ip = IpoptProblem(x, obj, [], integ)
+    sv = _SparseJacobianView(ip, True)
+    t2 = time.perf_counter()
+    for i in range(200):
+        ip._fused._key = None
+        sv.jacobian(z + 1e-9 * i)
+    ts = (time.perf_counter() - t2) / 200
+    lam = np.ones(ip._fused.engine.m)
+    t3 = time.perf_counter()
+    for i in range(200):
+        ip.hessian(z + 1e-9 * i, lam, 1.0)
+    th = (time.perf_counter() - t3) / 200
+print(f"sparse-Jacobian callback (band values from the device): {ts * 1e6:.0f} us; Lagrangian-Hessian callback: {th * 1e6:.0f} us")
 print(f"NMPC.next (warm-started SLSQP): {dt / steps * 1e3:.2f} ms per MPC step; fused callback evaluation incl. host copies: {te * 1e6:.0f} us")
