@@ -474,15 +474,21 @@ class Rank:
                 "path": "nempc_allgather_u0 (libnempc.so -> RCCL ncclAllGather)" if eng.comm is not None
                         else "torch.distributed/" + self.backend,
                 "latency_us": self.gather_latency_us(res), "rows_gathered": self.world * B}
-        # HBM bytes of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+        # HBM bytes of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py):
+        # FETCH_SIZE * 2 (gfx950 correction) + WRITE_SIZE per launch, tools/summarize_profiles.py
         pmc_file = os.path.join(REPO, "profiles", args.pmc_file)
         if args.config == "c2" and B == 1024 and eng.kernel_variant == "mfma" and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             for k, v in pmc.items():
-                if k.startswith(str(res["row_kernel"])) and "hbm_traffic_bytes" in v and out["roofline"]["bound"] == "mfma":
-                    out["roofline"]["traffic"] = v["hbm_traffic_bytes"]
-                    out["roofline"]["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch, profiles/" + args.pmc_file +
-                                                       " (algorithmic: 0.51 MB read, 1.3 MB written)")
+                if not k.startswith(str(res["row_kernel"])) or "hbm_traffic_bytes" not in v:
+                    continue
+                fused = k.rstrip().endswith("true>")
+                for rf in (out["roofline"], secondary):
+                    if rf["bound"] == ("hbm" if fused else "mfma"):
+                        rf["traffic"] = v["hbm_traffic_bytes"]
+                        rf["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch of " + k + ", profiles/" + args.pmc_file +
+                                              (" (the fused evaluation: algorithmic 0.5 MB read, 20.5 MB written)" if fused else
+                                               " (algorithmic: 0.51 MB read, 1.3 MB written)"))
 
         if not args.only_eval:
             # ---- two independent batches in flight (reported apart; `value` is the single-stream figure)

@@ -32,3 +32,15 @@ for k, v in agg.items():
     res[k] = m
 json.dump(res, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1)[:1500])
+# pipe-utilisation / instruction-mix passes (<src>_pipe1, <src>_pipe2) -> <tag>_pipe.json
+pagg = collections.defaultdict(lambda: collections.defaultdict(list))
+for kind in ("pipe1", "pipe2"):
+    for f in glob.glob(f"{src}_{kind}/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("nempc::", "")
+            if name.startswith(("rows_", "post_", "rowhess", "assemble")):
+                pagg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if pagg:
+    pres = {k: dict({c: sum(x) / len(x) for c, x in v.items()}, launches_sampled=max(len(x) for x in v.values()))
+            for k, v in pagg.items()}
+    json.dump(pres, open(os.path.join(out, f"{tag}_pipe.json"), "w"), indent=1)
