@@ -350,12 +350,12 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
                         T* row = cx.jac + ((size_t)b * cx.m + t * NX + i) * cx.n;
                         // write-through (sc0 sc1): the rows go out to memory as they are issued instead of sitting dirty in
                         // L2 until the end-of-kernel write-back (C2, B=1024: whole evaluation 21.9 -> 20.3 us)
-                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(row + col0), "v"(v) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(row + col0), "v"(v) );
                         if (cx.box) {
                             vecT o1;
 #pragma unroll
                             for (int e = 0; e < VEC; ++e) o1[e] = (isx[e] && tc[e] == t && ic[e] == i) ? T(1) : T(0);
-                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(row + (size_t)HNX * cx.n + col0), "v"(o1) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(row + (size_t)HNX * cx.n + col0), "v"(o1) );
                         }
                     }
                 }
@@ -394,6 +394,53 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a
     FxStage<T, TPW, NTHREADS, NCOL> sr;
     int t0 = t_begin;
     fx_stage_load<T, WP, NH, TPW, NX, NU, TPW>(cx, t0, tid, sr);
+    // fused evaluation: the objective of this workgroup's problems (those whose first row lies in its tile range) is one
+    // problem per wave, one step per lane.  Its inputs are fetched HERE, with the first loads, and it is evaluated while
+    // the weight slices stream in; done at the end of the kernel it added its own global round trip to every
+    // workgroup's tail (1.3 us of the launch).  Horizons beyond 64 steps and problems beyond the first MT take the tail path.
+    unsigned ob_lo = 0, ob_hi = 0;
+    bool ob_pro = false;
+    T ox[NX], ou[NU], oxr[NX], our[NU], ocx[NX], ocu[NU], oQ[NX * NX], oQs[NX * NX], oR[NU * NU], oRs[NU * NU];
+    if constexpr (FUSE) {
+        if (a.f || a.grad) {
+            const unsigned r_lo = (unsigned)t_begin * 16u;
+            unsigned r_hi = (unsigned)t_end * 16u;
+            if (r_hi > a.R) r_hi = a.R;
+            const unsigned Hh = (unsigned)a.H;
+            ob_lo = (r_lo + Hh - 1) / Hh;
+            ob_hi = (r_hi + Hh - 1) / Hh;                 // problems ob_lo .. ob_hi - 1
+            ob_pro = a.H <= 64;
+            const unsigned bw = ob_lo + (unsigned)w;
+            if (ob_pro && bw < ob_hi) {
+                const T* __restrict__ P = static_cast<const T*>(a.P);
+                const int t = lane < a.H ? lane : 0;
+                const T* z = cx.Z + (size_t)bw * a.n;
+                const bool last = t == a.H - 1;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    ox[i] = z[t * NX + i];
+                    oxr[i] = P[a.oo.xref + t * NX + i];
+                    ocx[i] = P[a.oo.cx + t * NX + i];
+                }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    ou[i] = z[a.H * NX + t * NU + i];
+                    our[i] = P[a.oo.uref + t * NU + i];
+                    ocu[i] = P[a.oo.cu + t * NU + i];
+                }
+#pragma unroll
+                for (int i = 0; i < NX * NX; ++i) {
+                    oQ[i] = P[(last ? a.oo.QT : a.oo.Q) + i];
+                    oQs[i] = P[(last ? a.oo.QTs : a.oo.Qs) + i];
+                }
+#pragma unroll
+                for (int i = 0; i < NU * NU; ++i) {
+                    oR[i] = P[a.oo.R + i];
+                    oRs[i] = P[a.oo.Rs + i];
+                }
+            }
+        }
+    }
     constexpr int SMALL_VECS = (L::SMALL_END + VEC - 1) / VEC;
     constexpr int SMALL_PER_THREAD = (SMALL_VECS + NTHREADS - 1) / NTHREADS;
     vecT sm[SMALL_PER_THREAD];
@@ -444,6 +491,45 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a
             if (idx < a.p_elems) lds[L::TOTAL + idx] = pv[u];
         }
     }
+    if constexpr (FUSE) {
+        const unsigned bw = ob_lo + (unsigned)w;
+        if (ob_pro && bw < ob_hi) {
+            // same operations in the same order as objective_body (kernels_obj_impl.h): same bits
+            double acc = 0.0;
+            if (lane < a.H) {
+                T* grad = static_cast<T*>(a.grad);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const T dxi = ox[i] - oxr[i];
+                    T qd = T(0), qsd = T(0);
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) {
+                        const T dxj = ox[j] - oxr[j];
+                        qd = fma(oQ[i * NX + j], dxj, qd);
+                        qsd = fma(oQs[i * NX + j], dxj, qsd);
+                    }
+                    acc += (double)(dxi * qd + ocx[i] * ox[i]);
+                    if (grad) grad[(size_t)bw * a.n + lane * NX + i] = qsd + ocx[i];
+                }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    const T dui = ou[i] - our[i];
+                    T rd = T(0), rsd = T(0);
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) {
+                        const T duj = ou[j] - our[j];
+                        rd = fma(oR[i * NU + j], duj, rd);
+                        rsd = fma(oRs[i * NU + j], duj, rsd);
+                    }
+                    acc += (double)(dui * rd + ocu[i] * ou[i]);
+                    if (grad) grad[(size_t)bw * a.n + a.H * NX + lane * NU + i] = rsd + ocu[i];
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+            if (a.f && lane == 0) static_cast<T*>(a.f)[bw] = (T)acc;
+        }
+    }
     CoopWeights<T, WP, NH> W;
     {
         int f = 0;
@@ -486,12 +572,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a
                 for (int i = tid + PV_PER_THREAD * NTHREADS; i < a.p_elems; i += NTHREADS) lds[L::TOTAL + i] = gp[i];
                 __syncthreads();
             }
-            const unsigned r_lo = (unsigned)t_begin * 16u;
-            unsigned r_hi = (unsigned)t_end * 16u;
-            if (r_hi > a.R) r_hi = a.R;
-            const unsigned H = (unsigned)a.H;
-            const unsigned b_lo = (r_lo + H - 1) / H, b_hi = (r_hi + H - 1) / H;    // problems b_lo .. b_hi - 1
-            for (unsigned b = b_lo + (unsigned)w; b < b_hi; b += MT)
+            for (unsigned b = ob_lo + (unsigned)w + (ob_pro ? MT : 0); b < ob_hi; b += MT)
                 objective_body<T>((int)b, lane, a.H, NX, NU, a.oo, lds + L::TOTAL, cx.Z, static_cast<T*>(a.f),
                                   static_cast<T*>(a.grad));
         }
