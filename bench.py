@@ -297,9 +297,23 @@ class Rank:
         gather = None
         gather_every = max(1, args.evals_per_mpc_step)
         if self.dist is not None:
+            comm_ok = False
             if self.backend == "nccl":
+                # the library's own RCCL call (nempc_comm_init / nempc_allgather_u0).  Should the communicator not come
+                # up on some node, the run continues on torch.distributed's all_gather -- the same RCCL underneath -- and
+                # the line says so (`allgather_u0.path`, `allgather_u0.cabi_error`); every rank must take the same path.
                 from pyneuralempc_amd.parallel import init_u0_comm
-                init_u0_comm(eng)                     # RCCL communicator owned by the handle (nempc_comm_init)
+                try:
+                    init_u0_comm(eng)                 # RCCL communicator owned by the handle
+                    ok = 1.0
+                except Exception as e:                # noqa: BLE001
+                    self.comm_error = f"{type(e).__name__}: {e}"
+                    ok = 0.0
+                comm_ok = self.sum_over_ranks(ok) == float(self.world)
+                if not comm_ok and eng.comm is not None:
+                    eng.lib.nempc_comm_destroy(eng._handle)
+                    eng._comm = None
+            if comm_ok:
                 gather = lambda: eng.allgather_u0(Z=Z)                      # noqa: E731  nempc_allgather_u0
             else:
                 from pyneuralempc_amd.parallel import allgather_u0, first_controls
@@ -474,6 +488,8 @@ class Rank:
                 "path": "nempc_allgather_u0 (libnempc.so -> RCCL ncclAllGather)" if eng.comm is not None
                         else "torch.distributed/" + self.backend,
                 "latency_us": self.gather_latency_us(res), "rows_gathered": self.world * B}
+            if getattr(self, "comm_error", None):
+                out["allgather_u0"]["cabi_error"] = self.comm_error
         # HBM bytes of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py):
         # FETCH_SIZE * 2 (gfx950 correction) + WRITE_SIZE per launch, tools/summarize_profiles.py
         pmc_file = os.path.join(REPO, "profiles", args.pmc_file)

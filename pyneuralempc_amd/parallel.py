@@ -28,12 +28,23 @@ def init_u0_comm(engine, group=None):
         raise RuntimeError("init_u0_comm needs an initialised torch.distributed process group")
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     on_device = dist.get_backend(group) == "nccl"
-    raw = type(engine).comm_unique_id() if rank == 0 else bytes(128)
+    # byte 0 = "rank 0 obtained an id": if it could not (RCCL missing), EVERY rank raises instead of the others waiting
+    # in the broadcast for an id that never comes
+    raw, err = bytes(129), None
+    if rank == 0:
+        try:
+            raw = b"\x01" + type(engine).comm_unique_id()
+        except Exception as e:      # noqa: BLE001  (reported below, on every rank)
+            err = e
     t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
     if on_device:
         t = t.to(engine.device)
     dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    engine.comm_init(world, rank, bytes(t.cpu().numpy().tobytes()))
+    got = bytes(t.cpu().numpy().tobytes())
+    if got[0] != 1:
+        raise RuntimeError(f"init_u0_comm: rank 0 could not create an RCCL unique id ({err})" if rank == 0 else
+                           "init_u0_comm: rank 0 could not create an RCCL unique id")
+    engine.comm_init(world, rank, got[1:])
     return engine.comm
 
 
