@@ -26,18 +26,21 @@ struct FxLayout {   // element offsets inside dynamic LDS, all compile-time
     static constexpr int NR = sizeof(T) == 8 ? (NIN + 3) / 4 : 4;   // accumulator registers holding the NIN input rows
     static constexpr int NRO = sizeof(T) == 8 ? (NX + 3) / 4 : 4;   // ... the NX output rows
     static constexpr int JROW = NX * NIN;
-    // small tables, copied flat from off.fx_small: [w0f | seed | bias_0..NH-1 | biasL]
+    // small tables, copied flat from off.fx_small: [w0f | seed | bias_0..NH-1 | biasL | p0tab]
     static constexpr int W0F = 0;
     static constexpr int SEED = W0F + KS * MT * 64;
     static constexpr int BIAS = SEED + NX * MT * 16;
     static constexpr int BIASL = BIAS + NH * MT * 16;
-    static constexpr int SMALL_END = BIASL + 16;
+    static constexpr int P0 = BIASL + 16;                            // first-layer rows per lane: [d][MT*16]
+    static constexpr int SMALL_END = P0 + NIN * MT * 16;
     // exchange buffer: two halves of TPW activation sets (one cotangent per sweep)
     static constexpr int XH = TPW * MT * 256;
     static constexpr int X = (SMALL_END + 15) & ~15;
-    // K-split partials: slot 0 = network output, slots 1..NX = Jacobian row k; per (slot, tile, wave): NR x 64 lanes
+    // K-split partials, one value per (tile, wave, quantity, row): network outputs PF[j][w][k][16], Jacobian rows
+    // PJ[k][j][w][d][16]
     static constexpr int PART = X + 2 * XH;
-    static constexpr int PART_SZ = (NRO + NX * NR) * TPW * MT * 64;
+    static constexpr int PF_SZ = TPW * MT * NX * 16;
+    static constexpr int PART_SZ = PF_SZ + NX * TPW * MT * NIN * 16;
     // inputs, double-buffered: per tile xi[16][NIN] then xt[16][NX]
     static constexpr int IN_TILE = 16 * (NIN + NX);
     static constexpr int IN = PART + PART_SZ;
@@ -129,6 +132,28 @@ __device__ __forceinline__ void fx_stage_store(T* in, int tid, const FxStage<T, 
 }
 
 // One pass over NT tiles starting at tile t0, inputs in `in`.
+// Sum of a per-lane value over the four 16-lane rows of the wave (the K index q of the accumulator layout), left in every
+// lane: gfx950's v_permlane16_swap / v_permlane32_swap exchange rows inside the vector unit (no LDS round trip); with both
+// operands equal, swap + add folds rows {0,1},{2,3} and then the two halves.  Fixed order ((r0+r1)+(r2+r3)).
+__device__ __forceinline__ double fx_qsum(double s) {
+    unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
+    auto l16 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto h16 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    s = __hiloint2double((int)h16[0], (int)l16[0]) + __hiloint2double((int)h16[1], (int)l16[1]);
+    lo = (unsigned)__double2loint(s); hi = (unsigned)__double2hiint(s);
+    auto l32 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto h32 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)h32[0], (int)l32[0]) + __hiloint2double((int)h32[1], (int)l32[1]);
+}
+__device__ __forceinline__ float fx_qsum(float s) {
+    unsigned v = __float_as_uint(s);
+    auto a16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    s = __uint_as_float(a16[0]) + __uint_as_float(a16[1]);
+    v = __float_as_uint(s);
+    auto a32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return __uint_as_float(a32[0]) + __uint_as_float(a32[1]);
+}
+
 // `nxt` / `in_next` (when has_next): the NEXT pass's inputs, already in registers; they go to the other input buffer
 // BEFORE this pass's global stores are issued -- vmcnt counts stores too and retires in order, so a wait for those loads
 // placed after the stores would sit out the stores' acknowledgement (with the dense rows fused in: the whole HBM time).
@@ -139,7 +164,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
     using Ops = MfmaOps<T>;
     using V4 = typename Ops::V4;
     using L = FxLayout<T, WP, NH, TPW, NX, NU>;
-    constexpr int MT = WP / 16, NTHREADS = MT * 64, NIN = NX + NU, KS = L::KS, NR = L::NR, NRO = L::NRO, JROW = L::JROW;
+    constexpr int MT = WP / 16, NTHREADS = MT * 64, NIN = NX + NU, KS = L::KS, JROW = L::JROW;
     const int lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
     T* const lds = cx.lds;
@@ -197,33 +222,39 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[l][j][r] = Ops::tanh_(a[l][j][r]);
     }
-    // ---- network output: K-split partial over this wave's block
+    // ---- network output: K-split partial over this wave's 16 hidden units.  The two skinny layers (NX outputs here,
+    //      NIN inputs at the end of the reverse sweep) used to be MFMAs that compute 16 output rows for the 2-3 that
+    //      exist -- 12 of a tile-wave's 61 matrix instructions, on the pipe that bounds the kernel.  On the vector unit
+    //      they are 4 FMAs per value and lane plus the row sum above: a fifth of the double-precision pipe time.
+    V4 wl[NX];      // W_L[f(q,r)][k] for this lane's four features (the reverse sweep's seed is the same numbers)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        V4 pf = V4{T(0), T(0), T(0), T(0)};
+    for (int k = 0; k < NX; ++k) {
+        const T* seed = lds + L::SEED + k * MT * 16 + w * 16;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pf = Ops::mma(W.wL[r], a[NH - 1][j][r], pf);
-#pragma unroll
-        for (int r = 0; r < NRO; ++r) PART[((j * MT + w) * NRO + r) * 64 + lane] = pf[r];
+        for (int r = 0; r < 4; ++r) wl[k][r] = seed[r * 4 + q];
     }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            T sv = a[NH - 1][j][0] * wl[k][0];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) sv = fma(a[NH - 1][j][r], wl[k][r], sv);
+            sv = fx_qsum(sv);
+            if (q == 0) PART[((j * MT + w) * NX + k) * 16 + c] = sv;
+        }
 #pragma unroll
     for (int l = 0; l < NH; ++l)
 #pragma unroll
         for (int j = 0; j < NT; ++j) a[l][j] = T(1) - a[l][j] * a[l][j];
 
     // ---- reverse sweep, one cotangent (network output) at a time
-    T* const PJ = PART + NRO * TPW * MT * 64;
+    T* const PJ = PART + L::PF_SZ;
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
         V4 cv[NT];
-        {
-            const T* seed = lds + L::SEED + k * MT * 16 + w * 16;
-            V4 sd;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sd[r] = seed[r * 4 + q];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) cv[j] = sd * a[NH - 1][j];
-        }
+        for (int j = 0; j < NT; ++j) cv[j] = wl[k] * a[NH - 1][j];
 #pragma unroll
         for (int l = NH - 1; l >= 1; --l) {
             T* X = lds + L::X + (xsel & 1) * L::XH;
@@ -246,13 +277,21 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
             for (int j = 0; j < NT; ++j) cv[j] = cn[j] * a[l - 1][j];
         }
+        // last reverse step onto the NIN inputs, on the vector unit: J[k][d] partial = sum_r cv_r * W0[d][f(q,r)]
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            V4 pj = V4{T(0), T(0), T(0), T(0)};
+        for (int d = 0; d < NIN; ++d) {
+            const T* p0 = lds + L::P0 + d * MT * 16 + w * 16;
+            V4 w0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) pj = Ops::mma(W.w0b[r], cv[j][r], pj);
+            for (int r = 0; r < 4; ++r) w0[r] = p0[r * 4 + q];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) PJ[(((k * TPW + j) * MT + w) * NR + r) * 64 + lane] = pj[r];
+            for (int j = 0; j < NT; ++j) {
+                T sv = cv[j][0] * w0[0];
+#pragma unroll
+                for (int r = 1; r < 4; ++r) sv = fma(cv[j][r], w0[r], sv);
+                sv = fx_qsum(sv);
+                if (q == 0) PJ[(((k * TPW + j) * MT + w) * NIN + d) * 16 + c] = sv;
+            }
         }
     }
     lds_barrier();
@@ -271,10 +310,9 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
         const unsigned r = (unsigned)t0 * 16u + (unsigned)idx;
         if (item < NT * 16 * JROW && r < cx.R) {
             const int j = idx >> 4, cc = idx & 15;
-            const int qq = sizeof(T) == 8 ? (d & 3) : (d >> 2), rr = sizeof(T) == 8 ? (d >> 2) : (d & 3);
             T v = T(0);
 #pragma unroll
-            for (int ww = 0; ww < MT; ++ww) v += PJ[(((k * TPW + j) * MT + ww) * NR + rr) * 64 + qq * 16 + cc];
+            for (int ww = 0; ww < MT; ++ww) v += PJ[(((k * TPW + j) * MT + ww) * NIN + d) * 16 + cc];
             if (cx.ident && d == k) v += T(1);
             if (!FUSE || cx.tiles) cx.tiles[(size_t)t0 * (16 * JROW) + item] = v;
             if (FUSE) TS[item] = v;
@@ -291,7 +329,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             const int qq = sizeof(T) == 8 ? (i & 3) : (i >> 2), rr = sizeof(T) == 8 ? (i >> 2) : (i & 3);
             T f = lds[L::BIASL + rr * 4 + qq];
 #pragma unroll
-            for (int ww = 0; ww < MT; ++ww) f += PART[((j * MT + ww) * NRO + rr) * 64 + qq * 16 + cc];
+            for (int ww = 0; ww < MT; ++ww) f += PART[((j * MT + ww) * NX + i) * 16 + cc];
             const T* tin = in + j * L::IN_TILE;
             const T xp = tin[cc * NIN + i];
             const T xt = tin[16 * NIN + cc * NX + i];

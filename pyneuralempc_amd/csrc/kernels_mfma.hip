@@ -41,6 +41,9 @@ MfmaOffsets make_offsets(int wp, int nh, int ks, int nx, int nin, int esz) {
     o.coop_nload = (nfrag + vec - 1) / vec;
     o.coop_slices = p;
     p += MT * o.coop_nload * 64 * vec;
+    o.fx_small = p;
+    o.fx_small_elems = o.coop_small_elems + nin * MT * 16;
+    p += (o.fx_small_elems + 15) & ~15;
     o.grand_total = p;
     return o;
 }
@@ -138,6 +141,9 @@ int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b)
                 for (int r = 0; r < 4; ++r) put(blob[o.w0b + ((w * 4 + r) * MB) * 64 + lane]);
             }
     }
+
+    for (int i = 0; i < o.coop_small_elems; ++i) blob[o.fx_small + i] = blob[o.coop_small + i];
+    for (int i = 0; i < nin * MT * 16; ++i) blob[o.fx_small + o.coop_small_elems + i] = blob[o.p0tab + i];
 
     mfma_free(h);
     hipError_t e = hipMalloc(&h.mfma.blob, blob.size() * h.esz);

@@ -36,6 +36,9 @@ struct MfmaOffsets {  // element offsets into the packed blob
     //   coop_slices  per wave: its register-resident fragments (wf, wb per hidden layer, wL, w0b) as 16-byte
     //                lane vectors, load k of lane = element ((wave * coop_nload + k) * 64 + lane) * VEC
     int coop_small, coop_small_elems, coop_slices, coop_nload;
+    //   fx_small     [w0f | seed | bias_l | biasL | p0tab]: the fixed-shape kernel's tables (p0tab = first-layer rows per
+    //                lane, for its vector-unit skinny layers)
+    int fx_small, fx_small_elems;
     int grand_total;
 };
 
