@@ -314,7 +314,15 @@ class Rank:
                     eng.lib.nempc_comm_destroy(eng._handle)
                     eng._comm = None
             if comm_ok:
-                gather = lambda: eng.allgather_u0(Z=Z)                      # noqa: E731  nempc_allgather_u0
+                # the exchange runs on its own HIP stream: it only reads Z (the solver's output of the previous MPC step),
+                # nothing on the callback path waits for it, so the next evaluations proceed under it (xGMI latency is
+                # hidden instead of being added to every MPC step); the timed region ends with both streams drained
+                comm_stream = torch.cuda.Stream(self.dev)
+
+                def gather():
+                    comm_stream.wait_stream(torch.cuda.current_stream(self.dev))
+                    with torch.cuda.stream(comm_stream):
+                        return eng.allgather_u0(Z=Z)
             else:
                 from pyneuralempc_amd.parallel import allgather_u0, first_controls
                 gather = lambda: allgather_u0(first_controls(Z, H, nx, nu), total=self.world * B)   # noqa: E731
@@ -485,7 +493,7 @@ class Rank:
         if self.dist is not None:
             out["allgather_u0"] = {
                 "per_mpc_step_every_n_evals": max(1, args.evals_per_mpc_step), "issued_in_timed_loop": res["n_gather"],
-                "path": "nempc_allgather_u0 (libnempc.so -> RCCL ncclAllGather)" if eng.comm is not None
+                "path": "nempc_allgather_u0 (libnempc.so -> RCCL ncclAllGather), on its own HIP stream" if eng.comm is not None
                         else "torch.distributed/" + self.backend,
                 "latency_us": self.gather_latency_us(res), "rows_gathered": self.world * B}
             if getattr(self, "comm_error", None):
