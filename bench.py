@@ -186,9 +186,12 @@ class Rank:
         torch.cuda.set_device(dev_index)
         self.dev = torch.device("cuda", dev_index)
         self.dist = None
-        if self.world > 1:
+        # NEMPC_BENCH_FORCE_DIST=1: bring the process group (and with it the RCCL paths) up even for one rank -- the only
+        # way to execute the N > 1 code on a one-GPU box
+        if self.world > 1 or os.environ.get("NEMPC_BENCH_FORCE_DIST"):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
             if self.backend == "nccl":
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
             else:
@@ -318,11 +321,14 @@ class Rank:
                 # nothing on the callback path waits for it, so the next evaluations proceed under it (xGMI latency is
                 # hidden instead of being added to every MPC step); the timed region ends with both streams drained
                 comm_stream = torch.cuda.Stream(self.dev)
+                torch.cuda.synchronize(self.dev)
+                launch_gather, gathered_buf = eng.bind_allgather_u0(Z, stream=comm_stream)
+                main_stream = torch.cuda.current_stream(self.dev)
 
                 def gather():
-                    comm_stream.wait_stream(torch.cuda.current_stream(self.dev))
-                    with torch.cuda.stream(comm_stream):
-                        return eng.allgather_u0(Z=Z)
+                    comm_stream.wait_stream(main_stream)
+                    launch_gather()
+                    return gathered_buf
             else:
                 from pyneuralempc_amd.parallel import allgather_u0, first_controls
                 gather = lambda: allgather_u0(first_controls(Z, H, nx, nu), total=self.world * B)   # noqa: E731
@@ -548,7 +554,10 @@ class Rank:
             if self.world == 1 and not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(cfg)
         if self.rank == 0:
+            sys.stdout.flush()
+            os.dup2(self.saved_stdout, 1)
             print(json.dumps(out), flush=True)
+            os.dup2(2, 1)
         if self.dist is not None:
             self.barrier()
             self.dist.destroy_process_group()
@@ -624,7 +633,14 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launcher role: nothing above this line has touched HIP (torch is not even imported yet)
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
-    Rank(args).main()
+    # stdout carries exactly one JSON line: libraries that print banners while they initialise (RCCL does, to stdout) are
+    # sent to stderr by pointing fd 1 there until the line is ready
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    rank = Rank(args)
+    rank.saved_stdout = saved_stdout
+    rank.main()
 
 
 if __name__ == "__main__":

@@ -459,6 +459,23 @@ class CallbackEngine:
                                                    self._stream()))
         return out
 
+    def bind_allgather_u0(self, Z, stream=None, rows_per_rank=None):
+        """Pre-validated all-gather for hot loops (the counterpart of `bind`): returns (launch, gathered) where launch()
+        re-issues nempc_allgather_u0 on `stream` (a torch.cuda.Stream; default: the current one) at the CURRENT contents
+        of Z with one ctypes call."""
+        out = self.allgather_u0(Z=Z, rows_per_rank=rows_per_rank)          # validates, allocates, warms
+        B = int(Z.shape[0])
+        rows = B if rows_per_rank is None else int(rows_per_rank)
+        st = ctypes.c_void_p((stream or torch.cuda.current_stream(self.device)).cuda_stream)
+        args = (self._handle, B, rows, ctypes.c_void_p(Z.data_ptr()), None, ctypes.c_void_p(out.data_ptr()), st)
+        fn = self.lib.nempc_allgather_u0
+
+        def launch():
+            rc = fn(*args)
+            if rc:
+                _lib.check(rc)
+        return launch, out
+
     # ------------------------------------------------------------------ host convenience (B=1 drop-in path)
     def to_device(self, a):
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device, self.dtype)
