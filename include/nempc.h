@@ -181,7 +181,8 @@ int nempc_hess_gn(nempc_handle h, int32_t B, const void* Z, const void* X0, cons
  *     min f(z)  s.t.  integrator defects = 0,  lb <= z <= ub
  * in lock step by SQP with the exact per-step Lagrangian blocks (Gauss-Newton on the first iterate): per iterate one
  * callback + Hessian-block evaluation, one regularised Riccati (block-tridiagonal KKT) solve per problem, l1-merit
- * backtracking on defect-only evaluations; finite variable bounds through a log barrier.
+ * backtracking on defect-only evaluations; finite variable bounds by a primal-dual interior point (barrier parameter
+ * mu, multipliers of the bounds updated with their own step length).
  *   X0 (B,nx) device; Z (B,n) device: initial guess in, solution out; lb/ub (n) HOST doubles (NULL = unbounded,
  *   +-INFINITY allowed; the vectors DomainConstraint.get_lower/upper_bounds produce, constraints.py:26-30);
  *   status (B) device int32 out: 0 converged (Optimizer.SUCCESS), 1 not converged (Optimizer.FAIL);
@@ -203,7 +204,8 @@ typedef struct nempc_solver_opts {
                                 iterations) gather the unconverged ones to the front and launch only over them -- the
                                 stragglers then stop costing batch-wide launches; 0: lock step over all B to the end.
                                 Results are identical either way (per-problem arithmetic does not depend on the slot). */
-    int32_t reserved;        /* 0 */
+    int32_t barrier;         /* bounds: 0 primal-dual interior point (multipliers of the bounds carried along; default),
+                                1 primal log barrier (the round-1 method; kept for A/B) */
     int32_t* iters_out;      /* optional device int32 (B): iteration at which each problem converged (0 = did not) */
 } nempc_solver_opts;
 

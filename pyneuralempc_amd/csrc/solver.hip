@@ -42,6 +42,10 @@ struct SolverArgs {
     void* mu; void* pen; void* reg; void* alpha; void* phi0; void* dir;  // (B) per problem (pen = l1 penalty)
     int* status; int* lsdone; int* n_active;
     int* iters_done; int cur_it;                                         // per problem: iteration at which it converged
+    // bounds, primal-dual: zl / zu (B,n) multipliers of z >= lb / z <= ub, their steps, and the barrier diagonal the LQ
+    // model adds to the Hessian (zl/(z-lb) + zu/(ub-z)); the barrier gradient -mu/(z-lb) + mu/(ub-z) is folded into grad
+    void* zl; void* zu; void* dzl; void* dzu; void* alz; void* bh;
+    int primal_dual;
     void* dz; void* info;                                                // (B,n), (B,INFO_N)
     void* Kst; void* kst; void* Pst; void* pst;                          // Riccati storage per problem
     void* tmp; size_t tmp_stride;                                        // global temporaries when LDS is too small
@@ -52,12 +56,66 @@ struct SolverArgs {
     double armijo_slack;                                                 // relative slack of the Armijo test (see merit kernel)
 };
 
+// ---- bounds by a PRIMAL-DUAL interior point (round 2; the first version was the primal log barrier, Hessian term
+// mu/d^2).  With multipliers zl, zu of z >= lb, z <= ub the Newton system of the perturbed KKT conditions, reduced to
+// the primal step, has  Hessian + diag(zl/dl + zu/du)  and gradient  grad f - mu/dl + mu/du  (dl = z-lb, du = ub-z);
+// the dual steps follow from the primal one,  dzl = mu/dl - zl - (zl/dl) dz,  dzu = mu/du - zu + (zu/du) dz,  and are
+// taken to their own fraction-to-the-boundary length.  The diagonal zl/dl stays moderate on a variable that sits at its
+// bound with a small multiplier, where mu/dl^2 explodes -- the stragglers of the primal version were exactly the
+// problems whose steps kept being cut by the boundary (NEMPC_SOLVER_TRACE).  Both terms keep the LQ structure.
+// Runs before the LQ kernel: writes the diagonal bh and folds the barrier gradient into grad.
 template <typename T>
-__device__ __forceinline__ void barrier_terms(T z, T lo, T hi, T mu, T& gadd, T& hadd) {
-    if (mu > T(0)) {
-        if (lo > -std::numeric_limits<T>::max()) { const T d = z - lo; gadd -= mu / d; hadd += mu / (d * d); }
-        if (hi < std::numeric_limits<T>::max()) { const T d = hi - z; gadd += mu / d; hadd += mu / (d * d); }
+__global__ __launch_bounds__(256) void solver_barrier_kernel(SolverArgs a) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)a.B * a.n) return;
+    const int b = (int)(idx / a.n), i = (int)(idx - (size_t)b * a.n);
+    T ga = T(0), ha = T(0);
+    const T mu = ((const T*)a.mu)[b];
+    if (mu > T(0) && a.status[b] < 0) {
+        const T z = ((const T*)a.Z)[idx], lo = ((const T*)a.lb)[i], hi = ((const T*)a.ub)[i];
+        if (lo > -std::numeric_limits<T>::max()) {
+            const T d = z - lo;
+            ga -= mu / d;
+            ha += a.primal_dual ? ((const T*)a.zl)[idx] / d : mu / (d * d);
+        }
+        if (hi < std::numeric_limits<T>::max()) {
+            const T d = hi - z;
+            ga += mu / d;
+            ha += a.primal_dual ? ((const T*)a.zu)[idx] / d : mu / (d * d);
+        }
     }
+    ((T*)a.bh)[idx] = ha;
+    ((T*)a.grad)[idx] += ga;
+}
+
+// after the LQ solve: dual steps and their fraction-to-the-boundary length (one wave per problem)
+template <typename T>
+__global__ __launch_bounds__(64) void solver_dual_kernel(SolverArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= a.B || !a.primal_dual) return;
+    const T mu = ((const T*)a.mu)[b];
+    const T tau = T(0.995);
+    T amax = T(1);
+    if (mu > T(0) && a.status[b] < 0)
+        for (int i = lane; i < a.n; i += 64) {
+            const size_t idx = (size_t)b * a.n + i;
+            const T z = ((const T*)a.Z)[idx], d = ((const T*)a.dz)[idx], lo = ((const T*)a.lb)[i], hi = ((const T*)a.ub)[i];
+            T sl = T(0), su = T(0);
+            if (lo > -std::numeric_limits<T>::max()) {
+                const T dl = z - lo, zl = ((const T*)a.zl)[idx];
+                sl = mu / dl - zl - (zl / dl) * d;
+                if (sl < T(0)) amax = fmin(amax, -tau * zl / sl);
+            }
+            if (hi < std::numeric_limits<T>::max()) {
+                const T du = hi - z, zu = ((const T*)a.zu)[idx];
+                su = mu / du - zu + (zu / du) * d;
+                if (su < T(0)) amax = fmin(amax, -tau * zu / su);
+            }
+            ((T*)a.dzl)[idx] = sl;
+            ((T*)a.dzu)[idx] = su;
+        }
+    for (int o = 32; o > 0; o >>= 1) amax = fmin(amax, __shfl_down(amax, o, 64));
+    if (lane == 0) ((T*)a.alz)[b] = amax;
 }
 
 // One thread per problem.  The sweep is a long chain of tiny dependent matrix products: straight from global
@@ -81,7 +139,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     // element offsets of the per-problem LDS block
     const int Lz = 0, Lgr = Lz + n, Lgc = Lgr + n, Ltl = Lgc + H * nx, LW = Ltl + H * nx * nin, LK = LW + H * nin * nin,
               Lk = LK + H * nu * nx, LP = Lk + H * nu, Lp = LP + H * nx * nx, Llam = Lp + H * nx, Ldz = Llam + H * nx,
-              Ltmp = Ldz + n;
+              Lbh = Ldz + n, Ltmp = Lbh + n;
     // cooperative staging: one flat, unrolled loop per array over all the workgroup's problems (they are contiguous in
     // global memory), all four waves loading -- many independent loads in flight instead of one dependent round
     // trip per (problem, array)
@@ -102,6 +160,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         stage_in((const T*)a.g, H * nx, a.m, Lgc);
         stage_in((const T*)a.tiles, H * nx * nin, H * nx * nin, Ltl);
         stage_in((const T*)a.hblk, H * nin * nin, H * nin * nin, LW);
+        stage_in((const T*)a.bh, n, n, Lbh);
         __syncthreads();
     }
     T* dzg = mine ? (T*)a.dz + (size_t)b * n : nullptr;
@@ -148,7 +207,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     const T* Rs = (const T*)a.obj + a.oo.Rs;
     const T* lb = (const T*)a.lb;
     const T* ub = (const T*)a.ub;
-    const T mu = ((const T*)a.mu)[b];
+    const T* bh = a.use_lds ? blk + Lbh : (const T*)a.bh + (size_t)b * n;   // barrier diagonal (solver_barrier_kernel)
     T reg = ((const T*)a.reg)[b];
     T* Kst = a.use_lds ? blk + LK : (T*)a.Kst + (size_t)b * H * nu * nx;
     T* kst = a.use_lds ? blk + Lk : (T*)a.kst + (size_t)b * H * nu;
@@ -164,7 +223,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     #pragma unroll
     for (int i = 0; i < nx; ++i) {
         T ga = T(0), ha = T(0);
-        barrier_terms<T>(z[(H - 1) * nx + i], lb[(H - 1) * nx + i], ub[(H - 1) * nx + i], mu, ga, ha);
+        ha = bh[(H - 1) * nx + i];
         #pragma unroll
         for (int j = 0; j < nx; ++j) TMP(oP + i * nx + j) = QTs[i * nx + j] + (i == j ? ha : T(0));   // terminal weight
         TMP(op + i) = gr[(H - 1) * nx + i] + ga;
@@ -205,7 +264,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         #pragma unroll
         for (int i = 0; i < nu; ++i) {
             T ga = T(0), ha = T(0);
-            barrier_terms<T>(z[uo + t * nu + i], lb[uo + t * nu + i], ub[uo + t * nu + i], mu, ga, ha);
+            ha = bh[uo + t * nu + i];
             #pragma unroll
             for (int j = 0; j < nu; ++j) {
                 T v = Rs[i * nu + j] + Wt[(nx + i) * nin + nx + j] + (i == j ? ha + reg : T(0));
@@ -273,7 +332,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             #pragma unroll
             for (int i = 0; i < nx; ++i) {
                 T ga = T(0), ha = T(0);
-                barrier_terms<T>(z[(t - 1) * nx + i], lb[(t - 1) * nx + i], ub[(t - 1) * nx + i], mu, ga, ha);
+                ha = bh[(t - 1) * nx + i];
                 #pragma unroll
                 for (int j = 0; j < nx; ++j) {
                     T v = Qs[i * nx + j] + Wt[i * nin + j] + (i == j ? ha : T(0));
@@ -341,7 +400,6 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             step_inf = fmax(step_inf, fabs(d));
             zinf = fmax(zinf, fabs(zz));
             T ga = T(0), ha = T(0);
-            barrier_terms<T>(zz, lo, hi, mu, ga, ha);
             D0 = fma(gr[t * nx + i] + ga, d, D0);
             if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
             if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
@@ -357,7 +415,6 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             step_inf = fmax(step_inf, fabs(d));
             zinf = fmax(zinf, fabs(zz));
             T ga = T(0), ha = T(0);
-            barrier_terms<T>(zz, lo, hi, mu, ga, ha);
             D0 = fma(gr[uo + t * nu + i] + ga, d, D0);
             if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
             if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
@@ -398,7 +455,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
     const int np = a.B - b0 < ppw ? a.B - b0 : ppw;
     const int Lz = 0, Lgr = Lz + n, Lgc = Lgr + n, Ltl = Lgc + H * nx, LW = Ltl + H * nx * nin, LK = LW + H * nin * nin,
               Lk = LK + H * nu * nx, LP = Lk + H * nu, Lp = LP + H * nx * nx, Llam = Lp + H * nx, Ldz = Llam + H * nx,
-              Ltmp = Ldz + n;
+              Lbh = Ldz + n, Ltmp = Lbh + n;
     auto stage_in = [&](const T* __restrict__ src, int per, int src_stride, int loff) {
         const int tot = np * per;
         const T* base = src + (size_t)b0 * src_stride;
@@ -412,6 +469,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
     stage_in((const T*)a.g, H * nx, a.m, Lgc);
     stage_in((const T*)a.tiles, H * nx * nin, H * nx * nin, Ltl);
     stage_in((const T*)a.hblk, H * nin * nin, H * nin * nin, LW);
+    stage_in((const T*)a.bh, n, n, Lbh);
     __syncthreads();
 
     const int b = b0 + wv;
@@ -456,7 +514,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
             const T* Rs = (const T*)a.obj + a.oo.Rs;
             const T* lb = (const T*)a.lb;
             const T* ub = (const T*)a.ub;
-            const T mu = ((const T*)a.mu)[b];
+            const T* bh = blk + Lbh;                                             // barrier diagonal (solver_barrier_kernel)
             T reg = ((const T*)a.reg)[b];
             T* Kst = blk + LK;
             T* kst = blk + Lk;
@@ -473,12 +531,12 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                     if (e < nx * nx) {
                         const int i = e / nx, j = e - i * nx;
                         T ga = T(0), ha = T(0);
-                        if (i == j) barrier_terms<T>(z[(H - 1) * nx + i], lb[(H - 1) * nx + i], ub[(H - 1) * nx + i], mu, ga, ha);
+                        if (i == j) ha = bh[(H - 1) * nx + i];
                         tb[oP + e] = QTs[e] + (i == j ? ha : T(0));   // terminal weight
                     } else {
                         const int i = e - nx * nx;
                         T ga = T(0), ha = T(0);
-                        barrier_terms<T>(z[(H - 1) * nx + i], lb[(H - 1) * nx + i], ub[(H - 1) * nx + i], mu, ga, ha);
+                        ha = bh[(H - 1) * nx + i];
                         tb[op + i] = gr[(H - 1) * nx + i] + ga;
                     }
                 }
@@ -522,7 +580,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                         if (r < nu * nu) {
                             const int i = r / nu, j = r - i * nu;
                             T ga = T(0), ha = T(0);
-                            if (i == j) barrier_terms<T>(z[uo + t * nu + i], lb[uo + t * nu + i], ub[uo + t * nu + i], mu, ga, ha);
+                            if (i == j) ha = bh[uo + t * nu + i];
                             T v = Rs[i * nu + j] + Wt[(nx + i) * nin + nx + j] + (i == j ? ha + reg : T(0));
                             for (int k = 0; k < nx; ++k) v = fma(At[k * nin + nx + i], tb[oPB + k * nu + j], v);
                             tb[oQuu + r] = v;
@@ -531,7 +589,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                         r -= nu * nu;
                         if (r < nu) {
                             T ga = T(0), ha = T(0);
-                            barrier_terms<T>(z[uo + t * nu + r], lb[uo + t * nu + r], ub[uo + t * nu + r], mu, ga, ha);
+                            ha = bh[uo + t * nu + r];
                             T v = gr[uo + t * nu + r] + ga;
                             for (int k = 0; k < nx; ++k) v = fma(At[k * nin + nx + r], tb[oPc + k], v);
                             tb[oqu + r] = v;
@@ -593,7 +651,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                             if (e < nx * nx) {
                                 const int i = e / nx, j = e - i * nx;
                                 T ga = T(0), ha = T(0);
-                                if (i == j) barrier_terms<T>(z[(t - 1) * nx + i], lb[(t - 1) * nx + i], ub[(t - 1) * nx + i], mu, ga, ha);
+                                if (i == j) ha = bh[(t - 1) * nx + i];
                                 T v = Qs[i * nx + j] + Wt[i * nin + j] + (i == j ? ha : T(0));
                                 for (int k = 0; k < nx; ++k) v = fma(At[k * nin + i], tb[oPA + k * nx + j], v);
                                 for (int k = 0; k < nu; ++k) v = fma(tb[oQux + k * nx + i], tb[oK + k * nx + j], v);
@@ -601,7 +659,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                             } else {
                                 const int i = e - nx * nx;
                                 T ga = T(0), ha = T(0);
-                                barrier_terms<T>(z[(t - 1) * nx + i], lb[(t - 1) * nx + i], ub[(t - 1) * nx + i], mu, ga, ha);
+                                ha = bh[(t - 1) * nx + i];
                                 T v = gr[(t - 1) * nx + i] + ga;
                                 for (int k = 0; k < nx; ++k) v = fma(At[k * nin + i], tb[oPc + k], v);
                                 for (int k = 0; k < nu; ++k) v = fma(tb[oQux + k * nx + i], tb[okv + k], v);
@@ -658,8 +716,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                         step_inf = fmax(step_inf, fabs(d));
                         zinf = fmax(zinf, fabs(zz));
                         T ga = T(0), ha = T(0);
-                        barrier_terms<T>(zz, lo, hi, mu, ga, ha);
-                        D0 = fma(gr[t * nx + i] + ga, d, D0);
+                                    D0 = fma(gr[t * nx + i] + ga, d, D0);
                         if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
                         if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
                         const T gv = fabs(gc[t * nx + i]);
@@ -672,8 +729,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                         step_inf = fmax(step_inf, fabs(d));
                         zinf = fmax(zinf, fabs(zz));
                         T ga = T(0), ha = T(0);
-                        barrier_terms<T>(zz, lo, hi, mu, ga, ha);
-                        D0 = fma(gr[uo + t * nu + j] + ga, d, D0);
+                                    D0 = fma(gr[uo + t * nu + j] + ga, d, D0);
                         if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
                         if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
                     }
@@ -797,6 +853,25 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, int mode
         T* lam = (T*)a.lam + (size_t)b * a.m;
         const T* lamn = (const T*)a.lamn + (size_t)b * a.m;
         for (int i = lane; i < H * nx; i += 64) lam[i] = fma(al, lamn[i] - lam[i], lam[i]);
+        if (a.primal_dual && mu[b] > T(0)) {
+            // bound multipliers: their own step length, then kept within a factor kappa of mu / slack at the new point
+            // (the safeguard of primal-dual interior-point codes: a multiplier far from the central path is pulled back)
+            const T az = ((const T*)a.alz)[b], kap = T(1e10);
+            T* zl = (T*)a.zl + (size_t)b * a.n;
+            T* zu = (T*)a.zu + (size_t)b * a.n;
+            const T* dzl = (const T*)a.dzl + (size_t)b * a.n;
+            const T* dzu = (const T*)a.dzu + (size_t)b * a.n;
+            for (int i = lane; i < a.n; i += 64) {
+                if (lb[i] > -std::numeric_limits<T>::max()) {
+                    const T c = mu[b] / (zt[i] - lb[i]);
+                    zl[i] = fmin(fmax(fma(az, dzl[i], zl[i]), c / kap), c * kap);
+                }
+                if (ub[i] < std::numeric_limits<T>::max()) {
+                    const T c = mu[b] / (ub[i] - zt[i]);
+                    zu[i] = fmin(fmax(fma(az, dzu[i], zu[i]), c / kap), c * kap);
+                }
+            }
+        }
         // relax the damping only after a sweep that went through at the first attempt: a term that had to be raised
         // this iteration would fail again right away and cost a full extra sweep
         if (lane == 0) { a.lsdone[b] = 1; if (!(info[INFO_RESTARTS] > T(0))) reg[b] = fmax(reg[b] * T(0.1), T(1e-9)); }
@@ -821,8 +896,8 @@ __global__ __launch_bounds__(256) void solver_trial_kernel(int B, int n, const T
 template <typename T>
 __global__ __launch_bounds__(256) void solver_init_kernel(int B, int n, T* __restrict__ Z, const T* __restrict__ lb,
                                                           const T* __restrict__ ub, T* mu, T* nu, T* reg, int* status,
-                                                          int* orig, int* iters_done, T* info, T mu0, T reg0,
-                                                          int has_bounds) {
+                                                          int* orig, int* iters_done, T* info, T* zl, T* zu, T mu0,
+                                                          T reg0, int has_bounds) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (size_t)B) {
         mu[i] = has_bounds ? mu0 : T(0); nu[i] = T(1); reg[i] = reg0; status[i] = -1;
@@ -839,6 +914,10 @@ __global__ __launch_bounds__(256) void solver_init_kernel(int B, int n, T* __res
     if (flo) z = fmax(z, lo + marg);
     if (fhi) z = fmin(z, hi - marg);
     Z[i] = z;
+    if (zl) {   // bound multipliers on the central path of the first barrier parameter
+        zl[i] = flo ? mu0 / (z - lo) : T(0);
+        zu[i] = fhi ? mu0 / (hi - z) : T(0);
+    }
 }
 
 // ---- compaction of the unconverged problems (the lock-step batch would otherwise launch every kernel B wide for a
@@ -869,11 +948,11 @@ __global__ __launch_bounds__(1024) void solver_partition_kernel(int Bact, const 
     }
 }
 
-struct CompactArrays {   // (src, dst, elements per problem, bytes per element); up to 12 arrays
-    const void* src[12];
-    void* dst[12];
-    int per[12];
-    int esz[12];
+struct CompactArrays {   // (src, dst, elements per problem, bytes per element); up to 14 arrays
+    const void* src[14];
+    void* dst[14];
+    int per[14];
+    int esz[14];
     int n;
 };
 
@@ -914,7 +993,9 @@ struct SolverWs {
     int *lsdone = nullptr, *n_active = nullptr;
     // state that lives across iterations, in two buffer sets (compaction gathers from one into the other)
     void *Zc[2] = {nullptr, nullptr}, *X0c[2] = {nullptr, nullptr}, *lamc[2] = {nullptr, nullptr}, *muc[2] = {nullptr, nullptr},
-         *nuc[2] = {nullptr, nullptr}, *regc[2] = {nullptr, nullptr}, *exc[2] = {nullptr, nullptr}, *infoc[2] = {nullptr, nullptr};
+         *nuc[2] = {nullptr, nullptr}, *regc[2] = {nullptr, nullptr}, *exc[2] = {nullptr, nullptr}, *infoc[2] = {nullptr, nullptr},
+         *zlc[2] = {nullptr, nullptr}, *zuc[2] = {nullptr, nullptr};
+    void *dzl = nullptr, *dzu = nullptr, *alz = nullptr, *bh = nullptr;
     int *stc[2] = {nullptr, nullptr}, *orig[2] = {nullptr, nullptr}, *itc[2] = {nullptr, nullptr};
     int *perm = nullptr, *count = nullptr;
     int cap = 0;
@@ -936,10 +1017,12 @@ void solver_free(Handle& h) {
     if (w->n_active) (void)hipFree(w->n_active);
     for (int k = 0; k < 2; ++k) {
         void* ps[] = {w->Zc[k], w->X0c[k], w->lamc[k], w->muc[k], w->nuc[k], w->regc[k], w->exc[k], w->infoc[k], w->stc[k],
-                      w->orig[k], w->itc[k]};
+                      w->orig[k], w->itc[k], w->zlc[k], w->zuc[k]};
         for (void* p : ps)
             if (p) (void)hipFree(p);
     }
+    for (void* p : {w->dzl, w->dzu, w->alz, w->bh})
+        if (p) (void)hipFree(p);
     if (w->perm) (void)hipFree(w->perm);
     if (w->count) (void)hipFree(w->count);
     delete w;
@@ -977,12 +1060,14 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                 {&w2.dir, Bn * e}, {&w2.hblk, Bn * H * nin * nin * e}, {&w2.lamn, Bn * m * e},
                 {&w2.sig, Bn * e}, {&w2.dz, Bn * n * e}, {&w2.Kst, Bn * H * nu * nx * e},
                 {&w2.kst, Bn * H * nu * e}, {&w2.Pst, Bn * H * nx * nx * e}, {&w2.pst, Bn * H * nx * e},
-                {&w2.tmp, Bn * lq_tmp_elems(nx, nu) * e}};
+                {&w2.tmp, Bn * lq_tmp_elems(nx, nu) * e}, {&w2.dzl, Bn * n * e}, {&w2.dzu, Bn * n * e}, {&w2.alz, Bn * e},
+                {&w2.bh, Bn * n * e}};
             for (auto& x : al) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
             for (int k = 0; k < 2; ++k) {
                 struct { void** p; size_t bytes; } al2[] = {
                     {&w2.Zc[k], Bn * n * e}, {&w2.X0c[k], Bn * nx * e}, {&w2.lamc[k], Bn * m * e}, {&w2.muc[k], Bn * e},
                     {&w2.nuc[k], Bn * e}, {&w2.regc[k], Bn * e}, {&w2.exc[k], Bn * ex_per * e}, {&w2.infoc[k], Bn * INFO_N * e},
+                    {&w2.zlc[k], Bn * n * e}, {&w2.zuc[k], Bn * n * e},
                     {(void**)&w2.stc[k], Bn * sizeof(int)}, {(void**)&w2.orig[k], Bn * sizeof(int)},
                     {(void**)&w2.itc[k], Bn * sizeof(int)}};
                 for (auto& x : al2) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
@@ -1034,7 +1119,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     const unsigned gBn = (unsigned)(((size_t)B * n + 255) / 256);
     hipLaunchKernelGGL(solver_init_kernel<T>, dim3(gBn), dim3(256), 0, s, B, n, (T*)ws.Zc[0], (const T*)ws.lb,
                        (const T*)ws.ub, (T*)ws.muc[0], (T*)ws.nuc[0], (T*)ws.regc[0], ws.stc[0], ws.orig[0], ws.itc[0],
-                       (T*)ws.infoc[0], (T)o.mu_init, (T)o.reg, has_bounds ? 1 : 0);
+                       (T*)ws.infoc[0], (T*)ws.zlc[0], (T*)ws.zuc[0], (T)o.mu_init, (T)o.reg, has_bounds ? 1 : 0);
     NEMPC_HIP(hipMemsetAsync(ws.lamc[0], 0, (size_t)B * m * sizeof(T), s));
 
     SolverArgs a{};
@@ -1044,15 +1129,17 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     a.obj = h.d_obj; a.oo = obj_offsets(H, nx, nu);
     a.lb = ws.lb; a.ub = ws.ub; a.alpha = ws.alpha; a.phi0 = ws.phi0;
     a.dir = ws.dir; a.lsdone = ws.lsdone; a.n_active = ws.n_active;
-    a.dz = ws.dz; a.Kst = ws.Kst; a.kst = ws.kst; a.Pst = ws.Pst; a.pst = ws.pst;
+    a.dz = ws.dz; a.Kst = ws.Kst;
+    a.dzl = ws.dzl; a.dzu = ws.dzu; a.alz = ws.alz; a.bh = ws.bh;
+    a.primal_dual = (has_bounds && o.barrier != 1) ? 1 : 0; a.kst = ws.kst; a.Pst = ws.Pst; a.pst = ws.pst;
     a.tmp = ws.tmp; a.tmp_stride = (size_t)B;
     auto point_at = [&](int k) {
         a.Z = ws.Zc[k]; a.lam = ws.lamc[k]; a.mu = ws.muc[k]; a.pen = ws.nuc[k]; a.reg = ws.regc[k];
-        a.status = ws.stc[k]; a.iters_done = ws.itc[k]; a.info = ws.infoc[k];
+        a.status = ws.stc[k]; a.iters_done = ws.itc[k]; a.info = ws.infoc[k]; a.zl = ws.zlc[k]; a.zu = ws.zuc[k];
         if (ex_per) h.d_extra = ws.exc[k];
     };
     point_at(0);
-    int per_problem = 2 * n + 2 * H * nx + H * nx * nin + H * nin * nin + H * nu * nx + H * nu + H * nx * nx + H * nx + n +
+    int per_problem = 2 * n + 2 * H * nx + H * nx * nin + H * nin * nin + H * nu * nx + H * nu + H * nx * nx + H * nx + n + n +
                       lq_tmp_elems(nx, nu);
     per_problem |= 1;   // odd stride: the ppw lanes of a sweep hit different LDS banks
     const bool wave_wanted = o.lq_kernel != 1 && (o.lq_kernel == 2 || nx * (nx + nu) >= 12);
@@ -1116,9 +1203,12 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         }
         if (rc) return rc;
         if ((rc = launch_objective(h, Bact, Zc, ws.f, ws.grad, s))) return rc;
+        // bounds: barrier diagonal for the LQ model, barrier gradient folded into grad
+        hipLaunchKernelGGL(solver_barrier_kernel<T>, dim3(gAn), dim3(256), 0, s, a);
         // LDS mode: four waves stage the working set, the first ppw lanes run the sweeps
         hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (Bact + a.ppw - 1) / a.ppw : (Bact + 63) / 64), dim3(a.use_lds ? 256 : 64),
                            lds_need, s, a);
+        if (a.primal_dual) hipLaunchKernelGGL(solver_dual_kernel<T>, dim3(Bact), dim3(64), 0, s, a);
         NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, sizeof(int), s));
         hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(Bact), dim3(64), 0, s, a, 0, (const T*)ws.f, (const T*)nullptr,
                            (const T*)nullptr, (const T*)nullptr, (T*)Zc, 0);
@@ -1183,6 +1273,8 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             add(ws.orig[cur], ws.orig[nxt], 1, sizeof(int));
             add(ws.itc[cur], ws.itc[nxt], 1, sizeof(int));
             add(ws.infoc[cur], ws.infoc[nxt], INFO_N, sizeof(T));
+            add(ws.zlc[cur], ws.zlc[nxt], n, sizeof(T));
+            add(ws.zuc[cur], ws.zuc[nxt], n, sizeof(T));
             if (ex_per) add(ws.exc[cur], ws.exc[nxt], (int)ex_per, sizeof(T));
             ca.n = k;
             hipLaunchKernelGGL(solver_gather_kernel, dim3(Bact), dim3(256), 0, s, Bact, (const int*)ws.perm, ca);

@@ -364,7 +364,7 @@ class CallbackEngine:
 
     def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=100, max_linesearch=6, check_every=2,
               tol_constraint=None, tol_step=None, mu_init=1e-1, mu_min=None, mu_factor=0.2, reg=None, lq_kernel="auto",
-              compact=True, return_iterations=False):
+              compact=True, return_iterations=False, barrier="primal-dual"):
         """Batched on-device solve (Gauss-Newton SQP, see csrc/solver.hip).  X0 (B,nx) device tensor; Z_init (B,n)
         or None for the reference's cold start [x0 tiled H ; zeros] (optimizer/ipopt.py:149); lb/ub (n) host
         vectors as DomainConstraint produces them; tolerances default by dtype (fp64 1e-8, fp32 1e-4); lq_kernel picks the Riccati sweep ("auto" | "thread" per problem | "wave"
@@ -399,7 +399,8 @@ class CallbackEngine:
         opts = _lib.NempcSolverOpts(max_iter=max_iter, max_linesearch=max_linesearch, check_every=check_every,
                                     lq_kernel={"auto": 0, "thread": 1, "wave": 2}[lq_kernel],
                                     tol_constraint=tol_constraint, tol_step=tol_step, mu_init=mu_init, mu_min=mu_min,
-                                    mu_factor=mu_factor, reg=reg, compact=1 if compact else 0, reserved=0,
+                                    mu_factor=mu_factor, reg=reg, compact=1 if compact else 0,
+                                    barrier={"primal-dual": 0, "primal": 1}[barrier],
                                     iters_out=None if its_dev is None else its_dev.data_ptr())
         status = torch.empty(B, dtype=torch.int32, device=self.device)
         iters = ctypes.c_int32(0)
