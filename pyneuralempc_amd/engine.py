@@ -362,14 +362,17 @@ class CallbackEngine:
                                               ptr["hblocks"], self._stream()))
         return res
 
-    def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=100, max_linesearch=6, check_every=2,
+    def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=200, max_linesearch=6, check_every=2,
               tol_constraint=None, tol_step=None, mu_init=1e-1, mu_min=None, mu_factor=0.2, reg=None, lq_kernel="auto",
-              compact=True, return_iterations=False, barrier="primal-dual"):
+              compact=True, return_iterations=False, barrier="primal-dual", linesearch="auto"):
         """Batched on-device solve (Gauss-Newton SQP, see csrc/solver.hip).  X0 (B,nx) device tensor; Z_init (B,n)
         or None for the reference's cold start [x0 tiled H ; zeros] (optimizer/ipopt.py:149); lb/ub (n) host
         vectors as DomainConstraint produces them; tolerances default by dtype (fp64 1e-8, fp32 1e-4); lq_kernel picks the Riccati sweep ("auto" | "thread" per problem | "wave"
         per problem); compact=True gathers the unconverged problems to the front as the batch converges (same results,
-        shorter launches).  Returns (Z (B,n), status (B,) int32 [0 ok / 1 fail], iters) [+ per-problem convergence
+        shorter launches); linesearch "loop" backtracks inside an iteration (every problem waits for the slowest search),
+        "deferred" tries one step length per iteration and lets a rejected problem retry at half the length in the next one
+        (about half the time per iteration at the 2/1 shape, more iterations for hard problems), "auto" defers for small
+        stages and loops for matrix-core-bound ones.  Returns (Z (B,n), status (B,) int32 [0 ok / 1 fail], iters) [+ per-problem convergence
         iteration (B,) int32 with return_iterations=True]."""
         B = int(X0.shape[0])
         self._check_in(X0, (B, self.nx), "X0")
@@ -401,7 +404,8 @@ class CallbackEngine:
                                     tol_constraint=tol_constraint, tol_step=tol_step, mu_init=mu_init, mu_min=mu_min,
                                     mu_factor=mu_factor, reg=reg, compact=1 if compact else 0,
                                     barrier={"primal-dual": 0, "primal": 1}[barrier],
-                                    iters_out=None if its_dev is None else its_dev.data_ptr())
+                                    iters_out=None if its_dev is None else its_dev.data_ptr(),
+                                    linesearch={"auto": 0, "loop": 1, "deferred": 2}[linesearch], reserved=0)
         status = torch.empty(B, dtype=torch.int32, device=self.device)
         iters = ctypes.c_int32(0)
         with torch.cuda.device(self.device):

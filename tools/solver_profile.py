@@ -16,16 +16,17 @@ net = orc.MLP.random(nx + nu, hidden, nx, seed=0)
 eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=kind, DT=DT, dtype=dt, device="cuda:0", max_batch=B)
 X0 = eng.to_device(np.random.default_rng(100).uniform(-0.5, 0.5, size=(B, nx)))
 lb = np.concatenate([np.full(H * nx, -3.0), np.full(H * nu, -0.5)])
-modes = [("primal-dual", True), ("primal", True), ("primal-dual", False)]
-for mi in (40, 80, 160):
-    for barrier, compact in modes:
+modes = [("primal-dual", True, "auto"), ("primal-dual", True, "deferred"), ("primal-dual", True, "loop"), ("primal", True, "loop")]
+for mi in (40, 60, 80, 160):
+    for barrier, compact, lsm in modes:
         eng.solve(X0, lb=lb, ub=-lb, max_iter=3)
         torch.cuda.synchronize(); t = time.perf_counter()
-        Z, st, it, per = eng.solve(X0, lb=lb, ub=-lb, max_iter=mi, compact=compact, return_iterations=True, barrier=barrier)
+        Z, st, it, per = eng.solve(X0, lb=lb, ub=-lb, max_iter=mi, compact=compact, return_iterations=True, barrier=barrier,
+                                   linesearch=lsm)
         torch.cuda.synchronize(); dtm = time.perf_counter() - t
         ok = (st == 0)
         p = per[ok].cpu().numpy()
         q = np.percentile(p, [50, 90, 95, 99]) if len(p) else [0] * 4
-        print(f"{cfgname} B={B} max_iter={mi:3d} {barrier:11s} compact={int(compact)}: {dtm*1e3:7.2f} ms, {it:3d} iterations, {int(ok.sum()):5d}/{B} "
+        print(f"{cfgname} B={B} max_iter={mi:3d} {barrier:11s} ls={lsm:8s} compact={int(compact)}: {dtm*1e3:7.2f} ms, {it:3d} iterations, {int(ok.sum()):5d}/{B} "
               f"converged ({int(ok.sum())/dtm:9.0f} solved/s); iterations to converge p50/p90/p95/p99 = "
               f"{q[0]:.0f}/{q[1]:.0f}/{q[2]:.0f}/{q[3]:.0f}")
