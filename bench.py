@@ -432,6 +432,18 @@ class Rank:
         done = per[st == 0].to("cpu").numpy()
         # iterations after which 95 % of the batch had converged (None: fewer than 95 % did within the budget)
         it95 = int(np.sort(done)[int(np.ceil(0.95 * B)) - 1]) if len(done) >= int(np.ceil(0.95 * B)) else None
+        # the same batch at other iteration budgets (this rank only): convergence is a function of the budget
+        budgets = {}
+        for mi in (40, 160):
+            if mi == self.args.solver_iters:
+                continue
+            torch.cuda.synchronize(self.dev)
+            tb = time.perf_counter()
+            _, stb, _ = eng.solve(Xs, lb=lbv, ub=-lbv, max_iter=mi)
+            torch.cuda.synchronize(self.dev)
+            tb = time.perf_counter() - tb
+            okb = int((stb == 0).sum().item())
+            budgets[str(mi)] = {"solve_ms": tb * 1e3, "converged_frac": okb / B, "mpc_solved_per_s": okb / tb}
         tg = time.perf_counter()
         if eng.comm is not None:
             allu0 = eng.allgather_u0(Z=Zs)
@@ -449,9 +461,11 @@ class Rank:
                 "allgather_u0_us": t_gather * 1e6, "gathered_rows": int(allu0.shape[0]),
                 "allgather_path": "nempc_allgather_u0 (RCCL)" if eng.comm is not None else
                                   ("torch.distributed/" + self.backend if self.dist is not None else "single rank"),
-                "note": "SQP + Riccati, exact Lagrangian blocks, bounds |x|<=3 |u|<=0.5 via log barrier, unconverged "
-                        "problems compacted to the front as the batch converges; mpc_solved_per_s counts status == 0 only "
-                        "(this rank's iteration statistics)"}
+                "other_budgets_this_rank": budgets,
+                "note": "SQP + Riccati, exact Lagrangian blocks, bounds |x|<=3 |u|<=0.5 by a primal-dual interior point, "
+                        "deferred backtracking (one trial evaluation per iteration), unconverged problems compacted to the "
+                        "front as the batch converges; mpc_solved_per_s counts status == 0 only (this rank's iteration "
+                        "statistics)"}
 
     def gather_latency_us(self, res, reps=200):
         """isolated latency of one u0 all-gather (stream-ordered, HIP events)"""
@@ -625,7 +639,7 @@ def main():
     ap.add_argument("--hessian", action="store_true", help="also time the Hessian callbacks (reported apart)")
     ap.add_argument("--evals-per-mpc-step", type=int, default=10,
                     help="N > 1: one u0 all-gather per this many callback evaluations inside the timed loop")
-    ap.add_argument("--solver-iters", type=int, default=40)
+    ap.add_argument("--solver-iters", type=int, default=64)
     ap.add_argument("--pmc-file", default="r02_c2_b1024_pmc.json")
     args = ap.parse_args()
     if args.gpus < 1:

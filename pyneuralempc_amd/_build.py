@@ -16,6 +16,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=o
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
 
 
+# per-source extra flags.  Kernel-argument preload: the leading 16 dwords of a kernel's plain arguments are placed in
+# scalar registers by the dispatcher (the fixed-shape row kernel lists what its first loads need there)
+EXTRA_FLAGS = {"kernels_mfma_f64.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
+
+
 def _hipcc():
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -45,7 +50,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s}:\n{r.stdout}\n{r.stderr}")

@@ -36,6 +36,9 @@ struct FxLayout {   // element offsets inside dynamic LDS, all compile-time
     // exchange buffer: two halves of TPW activation sets (one cotangent per sweep)
     static constexpr int XH = TPW * MT * 256;
     static constexpr int X = (SMALL_END + 15) & ~15;
+    // fused evaluation, epilogue: the exchange area is reused as [row buffer RB_CAP | tiles of the pass TS_SZ]
+    static constexpr int TS_SZ = (TPW * 16 * JROW + 15) & ~15;
+    static constexpr int RB_CAP = 2 * XH - TS_SZ;
     // K-split partials, one value per (tile, wave, quantity, row): network outputs PF[j][w][k][16], Jacobian rows
     // PJ[k][j][w][d][16]
     static constexpr int PART = X + 2 * XH;
@@ -69,6 +72,8 @@ struct FxArgs {   // host-prepared; the fields the first loads need come first
     void* grad;             // (B, n) or null
     const void* P;          // objective table (Handle::d_obj), copied to LDS behind the layout
     int p_elems;
+    int rb_rows;            // dense rows per chunk of the LDS row buffer (FxLayout::RB_CAP / n, at least 1)
+    unsigned inv_nvec;      // ceil(2^32 / (n / VEC)): flat vector index -> row by multiply-high
     ObjOffsets oo;
 };
 
@@ -83,6 +88,8 @@ struct FxCtx {
     unsigned R, invH;
     int H, n, m, ident, box;
     T* __restrict__ jac;
+    int rb_rows;            // dense rows the LDS row buffer holds (RB_CAP / n)
+    unsigned inv_nvec;      // ceil(2^32 / (n / VEC)), 0 for one vector per row
 };
 
 // inputs of a pass: item = (column, row); columns = NIN network inputs then the NX current states x_t
@@ -300,8 +307,8 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
     // ---- outputs straight from the partials (no reduction phase): the sum over the MT waves is taken here, in wave
     //      order like the generic kernel's reduction
     // tiles: the pass's NT*16 rows are contiguous in memory -> lanes run over the flat element index (coalesced).
-    // The fused evaluation also keeps them in LDS (TS, on the now idle exchange area) for the dense rows below.
-    T* const TS = lds + L::X;
+    // The fused evaluation also keeps them in LDS (TS, at the end of the now idle exchange area) for the dense rows below.
+    T* const TS = lds + L::X + L::RB_CAP;
 #pragma unroll
     for (int it = 0; it < (NT * 16 * JROW + NTHREADS - 1) / NTHREADS; ++it) {
         const int item = tid + it * NTHREADS;
@@ -344,56 +351,108 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
     if constexpr (FUSE) {
         // ---- dense Jacobian rows of the pass (integrator/discret.py:38-56, unity.py:38-56; ipopt.py:88-96): row (t, i)
         //      of problem b holds -1 at x_t[i], the tile's state block at x_{t-1} (t >= 1), its control block at u_t,
-        //      zeros elsewhere.  32 lanes stream one row as 16-byte vectors (lane -> column pair is fixed, so the
-        //      column classification is hoisted), 8 rows per sweep of the workgroup; box rows (+1 selectors) follow.
-        lds_barrier();
+        //      zeros elsewhere; box rows (+1 selectors) follow the defect rows of each problem.
+        //      Every vector instruction costs the matrix pipe four cycles (tools/ubench_dpops.hip), so the rows are NOT
+        //      computed per output vector (classify the column, compare with the row's step, select: ~66 vector
+        //      instructions per store, 1.3 M per launch = 2.3 us at B=1024).  They are assembled in LDS -- the idle
+        //      exchange area, zero-filled, then the 4 non-zeros per row dropped in by one lane per row -- and streamed out
+        //      as a flat copy: one ds_read_b128 and one 1 KB-per-wave store per vector, addressing on the scalar unit.
         constexpr int VEC = 16 / (int)sizeof(T);
         typedef T vecT __attribute__((ext_vector_type(VEC)));
-        constexpr int LPR = 32, RPS = NTHREADS / LPR;          // lanes per row, rows per sweep
-        const int HNX = cx.H * NX, nvec = cx.n / VEC;
-        const int lsub = tid & (LPR - 1), rsub = tid / LPR;
-        for (int ch = 0; ch * LPR < nvec; ++ch) {
-            const int cvx = lsub + ch * LPR;
-            const int col0 = cvx * VEC;
-            // per column of this lane's vector: which step's state / control it is
-            int tc[VEC], ic[VEC];
-            bool isx[VEC];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const int col = col0 + e;
-                isx[e] = col < HNX;
-                const int cu = col - HNX;
-                tc[e] = isx[e] ? col / NX : cu / NU;
-                ic[e] = isx[e] ? col - tc[e] * NX : NX + (cu - tc[e] * NU);     // tile column d when the step matches
-            }
-            if (cvx < nvec) {
-#pragma unroll
-                for (int sw = 0; sw < (NT * 16 * NX + RPS - 1) / RPS; ++sw) {
-                    const int lr = sw * RPS + rsub;                    // dense row of the pass: (local row, state i)
+        constexpr int DR = NT * 16 * NX;                                 // dense rows of a full pass
+        T* const RB = lds + L::X;
+        vecT* const RBv = reinterpret_cast<vecT*>(RB);
+        const int n = cx.n, nvec = n / VEC;
+        const unsigned r0 = (unsigned)t0 * 16u;
+        const int drv = r0 + NT * 16u <= cx.R ? DR : (int)(cx.R - r0) * NX;     // rows of the pass that exist
+        const int rpc = drv < cx.rb_rows ? drv : cx.rb_rows;            // rows per chunk of the LDS row buffer
+        const unsigned b0 = cx.invH ? __umulhi(r0, cx.invH) : r0;       // first problem of the pass (uniform)
+        const vecT zero = {};
+#ifdef NEMPC_EXP_NODENSE      // timing experiment only
+        const int nkind = 0;
+#else
+        const int nkind = cx.box ? 2 : 1;
+#endif
+        for (int kind = 0; kind < nkind; ++kind) {
+            for (int c0 = 0; c0 < drv; c0 += rpc) {
+                const int nr = drv - c0 < rpc ? drv - c0 : rpc;
+                lds_barrier();                 // TS complete; the previous chunk has left the buffer
+                // each wave owns a run of rows: zero them, then one lane per row drops the non-zeros in (the LDS
+                // executes one wave's operations in order, so no barrier between the two)
+                const int rpw = (nr + MT - 1) / MT;
+                const int lo = w * rpw, hi = lo + rpw < nr ? lo + rpw : nr;
+                for (int v = lo * nvec + lane; v < hi * nvec; v += 64) RBv[v] = zero;
+                asm volatile("" ::: "memory");
+                if (lo + lane < hi) {
+                    const int lr = c0 + lo + lane;
                     const int lrow = lr / NX, i = lr - lrow * NX;
-                    const unsigned r = (unsigned)t0 * 16u + (unsigned)lrow;
-                    if (lr < NT * 16 * NX && r < cx.R) {
-                        const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
-                        const int t = (int)(r - b * (unsigned)cx.H);
+                    const unsigned r = r0 + (unsigned)lrow;
+                    const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
+                    const int t = (int)(r - b * (unsigned)cx.H);
+                    T* row = RB + (lo + lane) * n;
+                    if (kind == 0) {
                         const T* ts = TS + lrow * JROW + i * NIN;
-                        vecT v;
+                        if (t >= 1) {
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            // state column of step t-1 / control column of step t -> tile entry; x_t[i] -> -1
-                            const bool hit = isx[e] ? (tc[e] == t - 1) : (tc[e] == t);
-                            T val = hit ? ts[ic[e]] : T(0);
-                            if (isx[e] && tc[e] == t && ic[e] == i) val = T(-1);
-                            v[e] = val;
+                            for (int jj = 0; jj < NX; ++jj) row[(t - 1) * NX + jj] = ts[jj];
                         }
-                        T* row = cx.jac + ((size_t)b * cx.m + t * NX + i) * cx.n;
-                        // write-through (sc0 sc1): the rows go out to memory as they are issued instead of sitting dirty in
-                        // L2 until the end-of-kernel write-back (C2, B=1024: whole evaluation 21.9 -> 20.3 us)
-                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(row + col0), "v"(v) );
-                        if (cx.box) {
-                            vecT o1;
+                        row[t * NX + i] = T(-1);
 #pragma unroll
-                            for (int e = 0; e < VEC; ++e) o1[e] = (isx[e] && tc[e] == t && ic[e] == i) ? T(1) : T(0);
-                            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(row + (size_t)HNX * cx.n + col0), "v"(o1) );
+                        for (int jj = 0; jj < NU; ++jj) row[cx.H * NX + t * NU + jj] = ts[NX + jj];
+                    } else {
+                        row[t * NX + i] = T(1);
+                    }
+                }
+                lds_barrier();
+                const int nvc = nr * nvec;
+                // write-through stores (sc0 sc1): the rows go out to memory as they are issued instead of sitting dirty
+                // in L2 until the end-of-kernel write-back (C2, B=1024: whole evaluation 21.9 -> 20.3 us)
+                if (!cx.box) {
+                    // without box rows m = H*NX: dense row (r, i) is row r*NX + i of one (R*NX, n) matrix, the chunk is
+                    // one contiguous block of memory
+                    const char* base = reinterpret_cast<const char*>(cx.jac) +
+                                       ((size_t)r0 * NX + (size_t)c0) * (size_t)n * sizeof(T);
+                    // reads of a batch are all in flight before the first store waits for its data
+                    constexpr int UB = 4;
+                    for (int f0 = tid; f0 < nvc; f0 += UB * NTHREADS) {
+                        vecT v[UB];
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            const int fv = f0 + u * NTHREADS;
+                            if (fv < nvc) v[u] = RBv[fv];
+                        }
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            const int fv = f0 + u * NTHREADS;
+#ifdef NEMPC_EXP_NODENSE_STORE   // timing experiment only
+                            if (v[u][0] == T(123.456))
+#endif
+                            if (fv < nvc) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(v[u]), "s"(base));
+                        }
+                    }
+                } else {
+                    const char* base = reinterpret_cast<const char*>(cx.jac) + (size_t)b0 * cx.m * (size_t)n * sizeof(T);
+                    constexpr int UB = 4;
+                    for (int f0 = tid; f0 < nvc; f0 += UB * NTHREADS) {
+                        vecT v[UB];
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            const int fv = f0 + u * NTHREADS;
+                            if (fv < nvc) v[u] = RBv[fv];
+                        }
+#pragma unroll
+                        for (int u = 0; u < UB; ++u) {
+                            const int fv = f0 + u * NTHREADS;
+                            const int lrr = cx.inv_nvec ? (int)__umulhi((unsigned)fv, cx.inv_nvec) : fv;
+                            const int cv = fv - lrr * nvec;
+                            const int lr = c0 + lrr;
+                            const int lrow = lr / NX, i = lr - lrow * NX;
+                            const unsigned r = r0 + (unsigned)lrow;
+                            const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
+                            const int t = (int)(r - b * (unsigned)cx.H);
+                            const int rowidx = (int)(b - b0) * cx.m + (kind ? cx.H * NX : 0) + t * NX + i;
+                            const int voff = (rowidx * n + cv * VEC) * (int)sizeof(T);
+                            if (fv < nvc) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v[u]), "s"(base));
                         }
                     }
                 }
@@ -405,7 +464,13 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 
 // FUSE: the whole hessian-free evaluation in this launch -- g, [tiles,] dense jac, f, grad
 template <typename T, int WP, int NH, int TPW, int NX, int NU, bool FUSE = false>
-__global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a) {
+__global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
+    // the 16 dwords the first vector loads depend on, as plain arguments: with -amdgpu-kernarg-preload-count=16 they are
+    // in scalar registers when the wave starts instead of behind a scalar-load round trip (the struct repeats them)
+    const void* pZ, const void* pX0, const void* psmall, const void* pwslice, int ptiles_per_wg, int ptiles_rem,
+    unsigned pR, unsigned pinvH, int pH, int pn, int pm, int pident, FxArgs a) {
+    a.Z = pZ; a.X0 = pX0; a.small = psmall; a.wslice = pwslice; a.tiles_per_wg = ptiles_per_wg; a.tiles_rem = ptiles_rem;
+    a.R = pR; a.invH = pinvH; a.H = pH; a.n = pn; a.m = pm; a.ident = pident;
     using L = FxLayout<T, WP, NH, TPW, NX, NU>;
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
@@ -439,6 +504,9 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a
     unsigned ob_lo = 0, ob_hi = 0;
     bool ob_pro = false;
     T ox[NX], ou[NU], oxr[NX], our[NU], ocx[NX], ocu[NU], oQ[NX * NX], oQs[NX * NX], oR[NU * NU], oRs[NU * NU];
+#ifdef NEMPC_EXP_NOOBJ   // timing experiment only
+    a.f = nullptr; a.grad = nullptr;
+#endif
     if constexpr (FUSE) {
         if (a.f || a.grad) {
             const unsigned r_lo = (unsigned)t_begin * 16u;
@@ -514,6 +582,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(FxArgs a
     cx.tiles = static_cast<T*>(a.tiles);
     cx.jac = static_cast<T*>(a.jac);
     cx.m = a.m; cx.ident = a.ident; cx.box = a.box;
+    cx.rb_rows = a.rb_rows; cx.inv_nvec = a.inv_nvec;
     {
         vecT* ls = reinterpret_cast<vecT*>(lds + L::W0F);
 #pragma unroll

@@ -88,36 +88,43 @@ struct MfmaParams {
     } while (0)
 #endif
 
-// tanh for the row kernels.  ocml's tanh(double) costs ~670 cycles per wave-instruction on gfx950
-// (tools/ubench_f64.hip); the form below, t = 1 - 2 / (exp(2|x|) + 1) with a degree-13 polynomial
-// exp and a Newton-refined v_rcp_f64, costs ~145 and has the same 2.2e-16 max abs error against
-// libm on [-30, 30] (absolute accuracy is what the 1 - a^2 derivative factors need).
+// tanh for the row kernels: t = 1 - 2 / (exp(2|x|) + 1), sign restored.  ocml's tanh(double) costs ~670 cycles per
+// wave-instruction on gfx950.  On this chip every vector instruction -- double, single or integer -- takes the same 4
+// issue cycles (v_rcp_f64: 16) and a v_mfma_f64 holds the vector pipe for all of its 64 (tools/ubench_dpops.hip: MFMA
+// waves and vector waves on one SIMD serialise whatever the vector instruction is), so what a tanh costs the matrix
+// kernels is its instruction COUNT.  25 issue slots here against 33 for the straightforward form (degree-13 Taylor,
+// v_rndne + v_cvt_i32, two Newton steps, NaN select), same 2.2e-16 max abs error against tanhl on [-30, 30]
+// (tools/ubench_tanh.hip; absolute accuracy is what the 1 - a^2 derivative factors need):
+//  * |x| is clamped at 20 (tanh(20) rounds to 1) on its HIGH dword only: one compare, one select.  A NaN fails the
+//    compare and flows through every later operation, so a diverged iterate stays visible without a select at the end
+//  * n = rint(|x| * 2/ln2) by the 1.5*2^52 shift: one fma and one subtract, and the integer n is the low dword of
+//    the shifted value (no v_rndne_f64, no v_cvt_i32_f64)
+//  * exp(2s) on |s| <= ln2/4 by a degree-11 Chebyshev fit (relative error 1.7e-17 with the rounded coefficients)
+//  * 1/d from v_rcp_f64 and ONE cubic step (three fmas)
 __device__ __forceinline__ double nempc_tanh(double x) {
-    const double ax = fmin(fabs(x), 20.0);  // tanh(20) rounds to 1
-    const double y = ax + ax;
-    const double n = rint(y * 1.4426950408889634);
-    double r = fma(-n, 6.93147180369123816490e-01, y);
-    r = fma(-n, 1.90821492927058770002e-10, r);
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    const double d = ldexp(p, (int)n) + 1.0;
+    const double a = __hiloint2double(fabs(x) > 20.0 ? 0x40340000 : __double2hiint(x), __double2loint(x));
+    const double SHIFT = 6755399441055744.0;
+    const double t = fma(fabs(a), 2.8853900817779268, SHIFT);
+    const double nf = t - SHIFT;
+    double s = fma(-nf, 0.5 * 6.93147180369123816490e-01, fabs(a));
+    s = fma(-nf, 0.5 * 1.90821492927058770002e-10, s);
+    double p = 5.1425357017013815e-05;
+    p = fma(p, s, 0.00028295822990378013);
+    p = fma(p, s, 0.0014109307350312432);
+    p = fma(p, s, 0.0063491802834760944);
+    p = fma(p, s, 0.025396825459260305);
+    p = fma(p, s, 0.08888888929481456);
+    p = fma(p, s, 0.26666666666622724);
+    p = fma(p, s, 0.6666666666638096);
+    p = fma(p, s, 1.3333333333333344);
+    p = fma(p, s, 2.0000000000000075);
+    p = fma(p, s, 2.0);
+    p = fma(p, s, 1.0);
+    const double d = ldexp(p, __double2loint(t)) + 1.0;
     double q = __builtin_amdgcn_rcp(d);
-    q = fma(fma(-d, q, 1.0), q, q);
-    q = fma(fma(-d, q, 1.0), q, q);
-    // fmin() above swallows a NaN argument; hand it back like libm does, so a diverged iterate stays visible
-    return x != x ? x : copysign(fma(-2.0, q, 1.0), x);
+    const double e = fma(-d, q, 1.0);
+    q = fma(fma(e, e, e), q, q);
+    return copysign(fma(-2.0, q, 1.0), x);
 }
 
 // fp32: hardware exp2 / rcp; abs error ~1e-7, inside the fp32 configs' 1e-4 tolerance

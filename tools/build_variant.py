@@ -18,7 +18,7 @@ def main():
     def one(src):
         if src in kern:
             o = os.path.join(out, src.replace(".hip", ".o"))
-            subprocess.run([_build._hipcc()] + _build.FLAGS + defs + ["-c", os.path.join(_build.CSRC, src), "-o", o], check=True)
+            subprocess.run([_build._hipcc()] + _build.FLAGS + (_build.EXTRA_FLAGS.get(src, []) if "--no-extra" not in sys.argv else []) + defs + ["-c", os.path.join(_build.CSRC, src), "-o", o], check=True)
             return o
         return os.path.join(_build.PKG, "build", src.replace(".hip", ".o"))
     with ThreadPoolExecutor(max_workers=4) as ex:
