@@ -16,6 +16,16 @@
 #include "kernels_coop_impl.h"
 #include "kernels_obj_impl.h"
 
+// diagnostic builds only (tools/diag_stamps.py): the per-workgroup timeline has 13 event slots; -DNEMPC_STAMPS_PRO spends
+// them on the prologue instead of the pass
+#ifdef NEMPC_STAMPS_PRO
+#define FX_STAMP_PASS(p, i) do { } while (0)
+#define FX_STAMP_PRO(p, i) COOP_WGSTAMP(p, i)
+#else
+#define FX_STAMP_PASS(p, i) COOP_WGSTAMP(p, i)
+#define FX_STAMP_PRO(p, i) do { } while (0)
+#endif
+
 namespace nempc {
 
 template <typename T, int WP, int NH, int TPW, int NX, int NU>
@@ -36,11 +46,10 @@ struct FxLayout {   // element offsets inside dynamic LDS, all compile-time
     // exchange buffer: two halves of TPW activation sets (one cotangent per sweep)
     static constexpr int XH = TPW * MT * 256;
     static constexpr int X = (SMALL_END + 15) & ~15;
-    // fused evaluation, epilogue: the exchange area is reused as [row buffer RB_CAP | tiles of the pass TS_SZ]
-    static constexpr int TS_SZ = (TPW * 16 * JROW + 15) & ~15;
-    static constexpr int RB_CAP = 2 * XH - TS_SZ;
-    // K-split partials, one value per (tile, wave, quantity, row): network outputs PF[j][w][k][16], Jacobian rows
-    // PJ[k][j][w][d][16]
+    // fused evaluation, epilogue: the exchange area is reused as the buffer the dense rows are assembled in
+    static constexpr int RB_CAP = 2 * XH;
+    // K-split partials, one value per (wave, tile, quantity, row): network outputs PF[w][j][k][16], Jacobian rows
+    // PJ[k][w][j][d][16] (value-major inside a wave's block: fx_rowsums_store writes four values per store)
     static constexpr int PART = X + 2 * XH;
     static constexpr int PF_SZ = TPW * MT * NX * 16;
     static constexpr int PART_SZ = PF_SZ + NX * TPW * MT * NIN * 16;
@@ -50,6 +59,8 @@ struct FxLayout {   // element offsets inside dynamic LDS, all compile-time
     static constexpr int IN_SZ = (TPW * IN_TILE + 15) & ~15;
     static constexpr int TOTAL = IN + 2 * IN_SZ;
 };
+
+constexpr int FX_ZCOPY = 512;   // elements of Z (the workgroup's problems) parked in LDS for the objective: 2 per thread
 
 struct FxArgs {   // host-prepared; the fields the first loads need come first
     const void* Z;
@@ -72,10 +83,26 @@ struct FxArgs {   // host-prepared; the fields the first loads need come first
     void* grad;             // (B, n) or null
     const void* P;          // objective table (Handle::d_obj), copied to LDS behind the layout
     int p_elems;
+    int zp_max;             // problems whose variables fit the LDS copy (FX_ZCOPY / n; 0 when the table itself is too long)
     int rb_rows;            // dense rows per chunk of the LDS row buffer (FxLayout::RB_CAP / n, at least 1)
     unsigned inv_nvec;      // ceil(2^32 / (n / VEC)): flat vector index -> row by multiply-high
+    long long* dbg;         // diagnostic builds only
     ObjOffsets oo;
 };
+
+// The argument block proper, read where it is needed.  Kernel arguments are fetched by scalar loads that the compiler
+// issues at the top of the kernel, and with ~100 scalar registers live it then waits for them at once to spill them
+// into vector lanes: a cold round trip (0.3-0.5 us) in front of the very first vector load.  What the prologue needs
+// travels in the preloaded leading arguments; the rest -- output pointers, m, box, ... -- is only used by a pass's
+// epilogue and is read THERE through the kernarg segment pointer (the empty asm pins the earliest point).
+constexpr int FX_ARGS_KERNARG_OFFSET = 56;      // five pointers and four dwords precede the FxArgs argument
+typedef const FxArgs __attribute__((address_space(4)))* FxArgsK;
+__device__ __forceinline__ FxArgsK fx_late_args() {
+    const char __attribute__((address_space(4)))* kp =
+        (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return (FxArgsK)(kp + FX_ARGS_KERNARG_OFFSET);
+}
 
 template <typename T, int WP, int NH, int TPW, int NX, int NU>
 struct FxCtx {
@@ -83,13 +110,9 @@ struct FxCtx {
     T* lds;
     const T* __restrict__ Z;
     const T* __restrict__ X0;
-    T* __restrict__ gout;
-    T* __restrict__ tiles;
     unsigned R, invH;
-    int H, n, m, ident, box;
-    T* __restrict__ jac;
-    int rb_rows;            // dense rows the LDS row buffer holds (RB_CAP / n)
-    unsigned inv_nvec;      // ceil(2^32 / (n / VEC)), 0 for one vector per row
+    int H, n;
+    long long* dbg;         // diagnostic builds only (-DNEMPC_STAMPS, tools/diag_stamps.py): per-workgroup timeline
 };
 
 // inputs of a pass: item = (column, row); columns = NIN network inputs then the NX current states x_t
@@ -161,6 +184,59 @@ __device__ __forceinline__ float fx_qsum(float s) {
     return __uint_as_float(a32[0]) + __uint_as_float(a32[1]);
 }
 
+// A pointer the whole wave agrees on, pinned to scalar registers (the "s" operand of the stores below must not be left to
+// the compiler's uniformity analysis)
+__device__ __forceinline__ const char* fx_uniform_ptr(const char* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+// Several row sums at once.  v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the
+// second; fed two DIFFERENT values a, b it leaves [a0 b0 a2 b2] and [a1 b1 a3 b3], whose sum holds a0+a1 and a2+a3 in rows
+// 0 / 2 and b0+b1, b2+b3 in rows 1 / 3: one swap pair and one add take two values through a stage (fx_qsum spends that
+// on one).  v_permlane32_swap then folds two such registers, and row q of the result is the full sum of value q -- four
+// values for 9 instructions instead of 24, each summed in fx_qsum's order ((r0 + r1) + (r2 + r3)).
+__device__ __forceinline__ double fx_swap16_add(double a, double b) {
+    auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ double fx_swap32_add(double a, double b) {
+    auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+__device__ __forceinline__ float fx_swap16_add(float a, float b) {
+    auto v = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(v[0]) + __uint_as_float(v[1]);
+}
+__device__ __forceinline__ float fx_swap32_add(float a, float b) {
+    auto v = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(v[0]) + __uint_as_float(v[1]);
+}
+// Row sums of NV per-lane values -> dst[v * 16 + c] (value-major, 16 row entries each): groups of four leave through one
+// lane-linear store (lane = q*16 + c holds value 4g + q), the remainder through the narrower forms.
+template <typename T, int NV>
+__device__ __forceinline__ void fx_rowsums_store(const T (&s)[NV], T* dst, int lane) {
+    const int q = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < NV / 4; ++g)
+        dst[g * 64 + lane] = fx_swap32_add(fx_swap16_add(s[4 * g], s[4 * g + 1]), fx_swap16_add(s[4 * g + 2], s[4 * g + 3]));
+    constexpr int G = NV / 4, REM = NV % 4;
+    if constexpr (REM == 1) {
+        const T v = fx_qsum(s[4 * G]);
+        if (q == 0) dst[G * 64 + lane] = v;
+    } else if constexpr (REM == 2) {
+        const T p = fx_swap16_add(s[4 * G], s[4 * G + 1]);
+        const T v = fx_swap32_add(p, p);                      // rows [a b a b]
+        if (q < 2) dst[G * 64 + lane] = v;
+    } else if constexpr (REM == 3) {
+        const T v = fx_swap32_add(fx_swap16_add(s[4 * G], s[4 * G + 1]), fx_swap16_add(s[4 * G + 2], s[4 * G + 2]));
+        if (q < 3) dst[G * 64 + lane] = v;
+    }
+}
+
 // `nxt` / `in_next` (when has_next): the NEXT pass's inputs, already in registers; they go to the other input buffer
 // BEFORE this pass's global stores are issued -- vmcnt counts stores too and retires in order, so a wait for those loads
 // placed after the stores would sit out the stores' acknowledgement (with the dense rows fused in: the whole HBM time).
@@ -201,6 +277,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[0][j][r] = Ops::tanh_(a[0][j][r]);
     }
+    FX_STAMP_PRO(cx.dbg, 10);
     // ---- hidden-to-hidden layers through the double-buffered exchange area (see kernels_coop_impl.h)
 #pragma unroll
     for (int l = 1; l < NH; ++l) {
@@ -229,6 +306,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
             for (int r = 0; r < 4; ++r) a[l][j][r] = Ops::tanh_(a[l][j][r]);
     }
+    FX_STAMP_PRO(cx.dbg, 11);
     // ---- network output: K-split partial over this wave's 16 hidden units.  The two skinny layers (NX outputs here,
     //      NIN inputs at the end of the reverse sweep) used to be MFMAs that compute 16 output rows for the 2-3 that
     //      exist -- 12 of a tile-wave's 61 matrix instructions, on the pipe that bounds the kernel.  On the vector unit
@@ -240,16 +318,20 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
         for (int r = 0; r < 4; ++r) wl[k][r] = seed[r * 4 + q];
     }
+    {
+        T sv[NT * NX];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            T sv = a[NH - 1][j][0] * wl[k][0];
+            for (int k = 0; k < NX; ++k) {
+                T v = a[NH - 1][j][0] * wl[k][0];
 #pragma unroll
-            for (int r = 1; r < 4; ++r) sv = fma(a[NH - 1][j][r], wl[k][r], sv);
-            sv = fx_qsum(sv);
-            if (q == 0) PART[((j * MT + w) * NX + k) * 16 + c] = sv;
-        }
+                for (int r = 1; r < 4; ++r) v = fma(a[NH - 1][j][r], wl[k][r], v);
+                sv[j * NX + k] = v;
+            }
+        fx_rowsums_store<T, NT * NX>(sv, PART + w * (TPW * NX) * 16, lane);
+    }
+    FX_STAMP_PASS(cx.dbg, 5);
 #pragma unroll
     for (int l = 0; l < NH; ++l)
 #pragma unroll
@@ -285,32 +367,42 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             for (int j = 0; j < NT; ++j) cv[j] = cn[j] * a[l - 1][j];
         }
         // last reverse step onto the NIN inputs, on the vector unit: J[k][d] partial = sum_r cv_r * W0[d][f(q,r)]
+        {
+            T sv[NT * NIN];
 #pragma unroll
-        for (int d = 0; d < NIN; ++d) {
-            const T* p0 = lds + L::P0 + d * MT * 16 + w * 16;
-            V4 w0;
+            for (int d = 0; d < NIN; ++d) {
+                const T* p0 = lds + L::P0 + d * MT * 16 + w * 16;
+                V4 w0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) w0[r] = p0[r * 4 + q];
+                for (int r = 0; r < 4; ++r) w0[r] = p0[r * 4 + q];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                T sv = cv[j][0] * w0[0];
+                for (int j = 0; j < NT; ++j) {
+                    T v = cv[j][0] * w0[0];
 #pragma unroll
-                for (int r = 1; r < 4; ++r) sv = fma(cv[j][r], w0[r], sv);
-                sv = fx_qsum(sv);
-                if (q == 0) PJ[(((k * TPW + j) * MT + w) * NIN + d) * 16 + c] = sv;
+                    for (int r = 1; r < 4; ++r) v = fma(cv[j][r], w0[r], v);
+                    sv[j * NIN + d] = v;
+                }
             }
+            fx_rowsums_store<T, NT * NIN>(sv, PJ + (k * MT + w) * (TPW * NIN) * 16, lane);
         }
     }
+    FX_STAMP_PASS(cx.dbg, 6);
+    FX_STAMP_PRO(cx.dbg, 12);
+    // what only the epilogue needs, fetched now: the barrier below covers the scalar loads
+    const FxArgsK ka = fx_late_args();
+    T* const o_tiles = static_cast<T*>(ka->tiles);
+    T* const o_g = static_cast<T*>(ka->g);
+    const int a_ident = ka->ident, a_box = ka->box, a_m = ka->m;
     lds_barrier();
     if (has_next) fx_stage_store<T, WP, NH, TPW, NX, NU, TPW>(in_next, tid, nxt);
+    FX_STAMP_PASS(cx.dbg, 7);
 
     // ---- outputs straight from the partials (no reduction phase): the sum over the MT waves is taken here, in wave
     //      order like the generic kernel's reduction
     // tiles: the pass's NT*16 rows are contiguous in memory -> lanes run over the flat element index (coalesced).
-    // The fused evaluation also keeps them in LDS (TS, at the end of the now idle exchange area) for the dense rows below.
-    T* const TS = lds + L::X + L::RB_CAP;
+    // (The fused evaluation sums them where it places them into the dense rows, below.)
 #pragma unroll
-    for (int it = 0; it < (NT * 16 * JROW + NTHREADS - 1) / NTHREADS; ++it) {
+    for (int it = 0; it < (FUSE ? 0 : (NT * 16 * JROW + NTHREADS - 1) / NTHREADS); ++it) {
         const int item = tid + it * NTHREADS;
         const int idx = item / JROW, kd = item - idx * JROW;     // compile-time divisors
         const int k = kd / NIN, d = kd - k * NIN;
@@ -319,10 +411,9 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             const int j = idx >> 4, cc = idx & 15;
             T v = T(0);
 #pragma unroll
-            for (int ww = 0; ww < MT; ++ww) v += PJ[(((k * TPW + j) * MT + ww) * NIN + d) * 16 + cc];
-            if (cx.ident && d == k) v += T(1);
-            if (!FUSE || cx.tiles) cx.tiles[(size_t)t0 * (16 * JROW) + item] = v;
-            if (FUSE) TS[item] = v;
+            for (int ww = 0; ww < MT; ++ww) v += PJ[((k * MT + ww) * (TPW * NIN) + j * NIN + d) * 16 + cc];
+            if (a_ident && d == k) v += T(1);
+            o_tiles[(size_t)t0 * (16 * JROW) + item] = v;
         }
     }
     // defects: lanes run over (row, state) with the state fastest -> contiguous inside a problem
@@ -336,18 +427,19 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             const int qq = sizeof(T) == 8 ? (i & 3) : (i >> 2), rr = sizeof(T) == 8 ? (i >> 2) : (i & 3);
             T f = lds[L::BIASL + rr * 4 + qq];
 #pragma unroll
-            for (int ww = 0; ww < MT; ++ww) f += PART[((j * MT + ww) * NX + i) * 16 + cc];
+            for (int ww = 0; ww < MT; ++ww) f += PART[(ww * (TPW * NX) + j * NX + i) * 16 + cc];
             const T* tin = in + j * L::IN_TILE;
             const T xp = tin[cc * NIN + i];
             const T xt = tin[16 * NIN + cc * NX + i];
-            const T phi = (cx.ident ? xp : T(0)) + f;
+            const T phi = (a_ident ? xp : T(0)) + f;
             const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
             const int t = (int)(r - b * (unsigned)cx.H);
-            T* gp = cx.gout + (size_t)b * cx.m + t * NX + i;
+            T* gp = o_g + (size_t)b * a_m + t * NX + i;
             gp[0] = phi - xt;
-            if (cx.box) gp[(size_t)cx.H * NX] = xt;
+            if (a_box) gp[(size_t)cx.H * NX] = xt;
         }
     }
+    FX_STAMP_PASS(cx.dbg, 8);
     if constexpr (FUSE) {
         // ---- dense Jacobian rows of the pass (integrator/discret.py:38-56, unity.py:38-56; ipopt.py:88-96): row (t, i)
         //      of problem b holds -1 at x_t[i], the tile's state block at x_{t-1} (t >= 1), its control block at u_t,
@@ -355,33 +447,39 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
         //      Every vector instruction costs the matrix pipe four cycles (tools/ubench_dpops.hip), so the rows are NOT
         //      computed per output vector (classify the column, compare with the row's step, select: ~66 vector
         //      instructions per store, 1.3 M per launch = 2.3 us at B=1024).  They are assembled in LDS -- the idle
-        //      exchange area, zero-filled, then the 4 non-zeros per row dropped in by one lane per row -- and streamed out
-        //      as a flat copy: one ds_read_b128 and one 1 KB-per-wave store per vector, addressing on the scalar unit.
+        //      exchange area, zero-filled, then the 4 non-zeros per row dropped in by one lane per row, which sums them
+        //      from the K-split partials on the spot -- and streamed out as a flat copy: one ds_read_b128 and one
+        //      1 KB-per-wave store per vector, addressing on the scalar unit.
         constexpr int VEC = 16 / (int)sizeof(T);
         typedef T vecT __attribute__((ext_vector_type(VEC)));
         constexpr int DR = NT * 16 * NX;                                 // dense rows of a full pass
+        T* const o_jac = static_cast<T*>(ka->jac);
+        const int a_rb_rows = ka->rb_rows;
+        const unsigned a_inv_nvec = ka->inv_nvec;
         T* const RB = lds + L::X;
         vecT* const RBv = reinterpret_cast<vecT*>(RB);
         const int n = cx.n, nvec = n / VEC;
         const unsigned r0 = (unsigned)t0 * 16u;
         const int drv = r0 + NT * 16u <= cx.R ? DR : (int)(cx.R - r0) * NX;     // rows of the pass that exist
-        const int rpc = drv < cx.rb_rows ? drv : cx.rb_rows;            // rows per chunk of the LDS row buffer
+        const int rpc = drv < a_rb_rows ? drv : a_rb_rows;            // rows per chunk of the LDS row buffer
         const unsigned b0 = cx.invH ? __umulhi(r0, cx.invH) : r0;       // first problem of the pass (uniform)
         const vecT zero = {};
 #ifdef NEMPC_EXP_NODENSE      // timing experiment only
         const int nkind = 0;
 #else
-        const int nkind = cx.box ? 2 : 1;
+        const int nkind = a_box ? 2 : 1;
 #endif
         for (int kind = 0; kind < nkind; ++kind) {
             for (int c0 = 0; c0 < drv; c0 += rpc) {
                 const int nr = drv - c0 < rpc ? drv - c0 : rpc;
-                lds_barrier();                 // TS complete; the previous chunk has left the buffer
+                if (kind + c0 > 0) lds_barrier();      // the previous chunk has left the buffer
                 // each wave owns a run of rows: zero them, then one lane per row drops the non-zeros in (the LDS
                 // executes one wave's operations in order, so no barrier between the two)
                 const int rpw = (nr + MT - 1) / MT;
                 const int lo = w * rpw, hi = lo + rpw < nr ? lo + rpw : nr;
+#ifndef NEMPC_EXP_NOZEROFILL   // timing experiment only
                 for (int v = lo * nvec + lane; v < hi * nvec; v += 64) RBv[v] = zero;
+#endif
                 asm volatile("" ::: "memory");
                 if (lo + lane < hi) {
                     const int lr = c0 + lo + lane;
@@ -391,7 +489,21 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
                     const int t = (int)(r - b * (unsigned)cx.H);
                     T* row = RB + (lo + lane) * n;
                     if (kind == 0) {
-                        const T* ts = TS + lrow * JROW + i * NIN;
+                        // the row's tile entries: K-split partials summed in wave order (the unfused kernel's loop above)
+                        const int j = lrow >> 4, cc = lrow & 15;
+                        T ts[NIN];
+#pragma unroll
+                        for (int d = 0; d < NIN; ++d) {
+                            T v = T(0);
+#pragma unroll
+                            for (int ww = 0; ww < MT; ++ww) v += PJ[((i * MT + ww) * (TPW * NIN) + j * NIN + d) * 16 + cc];
+                            if (a_ident && d == i) v += T(1);
+                            ts[d] = v;
+                        }
+                        if (o_tiles) {
+#pragma unroll
+                            for (int d = 0; d < NIN; ++d) o_tiles[(size_t)r * JROW + i * NIN + d] = ts[d];
+                        }
                         if (t >= 1) {
 #pragma unroll
                             for (int jj = 0; jj < NX; ++jj) row[(t - 1) * NX + jj] = ts[jj];
@@ -403,15 +515,17 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
                         row[t * NX + i] = T(1);
                     }
                 }
+                FX_STAMP_PASS(cx.dbg, 9);
                 lds_barrier();
+                FX_STAMP_PASS(cx.dbg, 10);
                 const int nvc = nr * nvec;
                 // write-through stores (sc0 sc1): the rows go out to memory as they are issued instead of sitting dirty
                 // in L2 until the end-of-kernel write-back (C2, B=1024: whole evaluation 21.9 -> 20.3 us)
-                if (!cx.box) {
+                if (!a_box) {
                     // without box rows m = H*NX: dense row (r, i) is row r*NX + i of one (R*NX, n) matrix, the chunk is
                     // one contiguous block of memory
-                    const char* base = reinterpret_cast<const char*>(cx.jac) +
-                                       ((size_t)r0 * NX + (size_t)c0) * (size_t)n * sizeof(T);
+                    const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) +
+                                                      ((size_t)r0 * NX + (size_t)c0) * (size_t)n * sizeof(T));
                     // reads of a batch are all in flight before the first store waits for its data
                     constexpr int UB = 4;
                     for (int f0 = tid; f0 < nvc; f0 += UB * NTHREADS) {
@@ -419,7 +533,11 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
                             const int fv = f0 + u * NTHREADS;
+#ifdef NEMPC_EXP_NOSTREAMREAD   // timing experiment only
+                            v[u] = zero;
+#else
                             if (fv < nvc) v[u] = RBv[fv];
+#endif
                         }
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
@@ -431,7 +549,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
                         }
                     }
                 } else {
-                    const char* base = reinterpret_cast<const char*>(cx.jac) + (size_t)b0 * cx.m * (size_t)n * sizeof(T);
+                    const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) + (size_t)b0 * a_m * (size_t)n * sizeof(T));
                     constexpr int UB = 4;
                     for (int f0 = tid; f0 < nvc; f0 += UB * NTHREADS) {
                         vecT v[UB];
@@ -443,14 +561,14 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
                             const int fv = f0 + u * NTHREADS;
-                            const int lrr = cx.inv_nvec ? (int)__umulhi((unsigned)fv, cx.inv_nvec) : fv;
+                            const int lrr = a_inv_nvec ? (int)__umulhi((unsigned)fv, a_inv_nvec) : fv;
                             const int cv = fv - lrr * nvec;
                             const int lr = c0 + lrr;
                             const int lrow = lr / NX, i = lr - lrow * NX;
                             const unsigned r = r0 + (unsigned)lrow;
                             const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
                             const int t = (int)(r - b * (unsigned)cx.H);
-                            const int rowidx = (int)(b - b0) * cx.m + (kind ? cx.H * NX : 0) + t * NX + i;
+                            const int rowidx = (int)(b - b0) * a_m + (kind ? cx.H * NX : 0) + t * NX + i;
                             const int voff = (rowidx * n + cv * VEC) * (int)sizeof(T);
                             if (fv < nvc) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v[u]), "s"(base));
                         }
@@ -458,19 +576,50 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
                 }
             }
         }
+        FX_STAMP_PASS(cx.dbg, 11);
     }
     lds_barrier();
+    FX_STAMP_PASS(cx.dbg, 12);
 }
 
 // FUSE: the whole hessian-free evaluation in this launch -- g, [tiles,] dense jac, f, grad
 template <typename T, int WP, int NH, int TPW, int NX, int NU, bool FUSE = false>
 __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
-    // the 16 dwords the first vector loads depend on, as plain arguments: with -amdgpu-kernarg-preload-count=16 they are
-    // in scalar registers when the wave starts instead of behind a scalar-load round trip (the struct repeats them)
-    const void* pZ, const void* pX0, const void* psmall, const void* pwslice, int ptiles_per_wg, int ptiles_rem,
-    unsigned pR, unsigned pinvH, int pH, int pn, int pm, int pident, FxArgs a) {
-    a.Z = pZ; a.X0 = pX0; a.small = psmall; a.wslice = pwslice; a.tiles_per_wg = ptiles_per_wg; a.tiles_rem = ptiles_rem;
-    a.R = pR; a.invH = pinvH; a.H = pH; a.n = pn; a.m = pm; a.ident = pident;
+    // what the prologue's loads depend on, as plain arguments: with -amdgpu-kernarg-preload-count the leading 14 dwords are
+    // in scalar registers when the wave starts instead of behind a scalar-load round trip (the struct carries the rest;
+    // n and the objective table's offsets follow from H and the compiled shape)
+    const void* pZ, const void* pX0, const void* psmall, const void* pwslice, const void* pP, unsigned ppack, unsigned pR,
+    unsigned pinvH, int pH, FxArgs a) {
+    // `a` itself is never read here (see fx_late_args); a local block holds what the preloaded arguments say
+    struct {
+        const void *Z, *X0, *small, *wslice, *P;
+        int tiles_per_wg, tiles_rem, zp_max, H, n, p_elems;
+        unsigned R, invH;
+        ObjOffsets oo;
+        long long* dbg;
+    } pa;
+    pa.Z = pZ; pa.X0 = pX0; pa.small = psmall; pa.wslice = pwslice; pa.P = pP;
+    pa.tiles_per_wg = (int)(ppack & 0xffu); pa.tiles_rem = (int)((ppack >> 8) & 0x3ffu);
+    pa.zp_max = (int)((ppack >> 18) & 0x3ffu);
+#ifdef NEMPC_EXP_NOOBJ   // timing experiment only
+    const bool want_obj = false;
+#else
+    const bool want_obj = ((ppack >> 28) & 3u) != 0;     // f or grad asked for
+#endif
+    pa.R = pR; pa.invH = pinvH; pa.H = pH; pa.n = pH * (NX + NU);
+    pa.oo = obj_offsets(pH, NX, NU);
+    pa.p_elems = FUSE ? pa.oo.total : 0;
+#ifdef NEMPC_STAMPS
+    pa.dbg = a.dbg;
+#else
+    pa.dbg = nullptr;
+    (void)a;
+#endif
+    COOP_WGSTAMP(pa.dbg, 0);
+#ifdef NEMPC_STAMPS
+    if (pa.dbg && threadIdx.x == 0 && blockIdx.x < 4096)
+        pa.dbg[1024 + blockIdx.x * 16 + 15] = ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+#endif
     using L = FxLayout<T, WP, NH, TPW, NX, NU>;
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
@@ -485,77 +634,56 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
 
     FxCtx<T, WP, NH, TPW, NX, NU> cx;
     cx.lds = lds;
-    cx.Z = static_cast<const T*>(a.Z);
-    cx.X0 = static_cast<const T*>(a.X0);
-    cx.R = a.R; cx.invH = a.invH; cx.H = a.H; cx.n = a.n;
+    cx.Z = static_cast<const T*>(pa.Z);
+    cx.X0 = static_cast<const T*>(pa.X0);
+    cx.R = pa.R; cx.invH = pa.invH; cx.H = pa.H; cx.n = pa.n;
 
-    const int t_begin = blockIdx.x * a.tiles_per_wg + ((int)blockIdx.x < a.tiles_rem ? (int)blockIdx.x : a.tiles_rem);
-    const int t_end = t_begin + a.tiles_per_wg + ((int)blockIdx.x < a.tiles_rem ? 1 : 0);
+    const int t_begin = blockIdx.x * pa.tiles_per_wg + ((int)blockIdx.x < pa.tiles_rem ? (int)blockIdx.x : pa.tiles_rem);
+    const int t_end = t_begin + pa.tiles_per_wg + ((int)blockIdx.x < pa.tiles_rem ? 1 : 0);
 
     // ---- every global load of the prologue is issued before anything waits: inputs, small tables, weight slices.
     //      The staging registers always cover a full TPW-tile pass; a shorter pass just leaves rows unused.
     FxStage<T, TPW, NTHREADS, NCOL> sr;
     int t0 = t_begin;
     fx_stage_load<T, WP, NH, TPW, NX, NU, TPW>(cx, t0, tid, sr);
-    // fused evaluation: the objective of this workgroup's problems (those whose first row lies in its tile range) is one
-    // problem per wave, one step per lane.  Its inputs are fetched HERE, with the first loads, and it is evaluated while
-    // the weight slices stream in; done at the end of the kernel it added its own global round trip to every
-    // workgroup's tail (1.3 us of the launch).  Horizons beyond 64 steps and problems beyond the first MT take the tail path.
-    unsigned ob_lo = 0, ob_hi = 0;
-    bool ob_pro = false;
-    T ox[NX], ou[NU], oxr[NX], our[NU], ocx[NX], ocu[NU], oQ[NX * NX], oQs[NX * NX], oR[NU * NU], oRs[NU * NU];
-#ifdef NEMPC_EXP_NOOBJ   // timing experiment only
-    a.f = nullptr; a.grad = nullptr;
-#endif
-    if constexpr (FUSE) {
-        if (a.f || a.grad) {
-            const unsigned r_lo = (unsigned)t_begin * 16u;
-            unsigned r_hi = (unsigned)t_end * 16u;
-            if (r_hi > a.R) r_hi = a.R;
-            const unsigned Hh = (unsigned)a.H;
-            ob_lo = (r_lo + Hh - 1) / Hh;
-            ob_hi = (r_hi + Hh - 1) / Hh;                 // problems ob_lo .. ob_hi - 1
-            ob_pro = a.H <= 64;
-            const unsigned bw = ob_lo + (unsigned)w;
-            if (ob_pro && bw < ob_hi) {
-                const T* __restrict__ P = static_cast<const T*>(a.P);
-                const int t = lane < a.H ? lane : 0;
-                const T* z = cx.Z + (size_t)bw * a.n;
-                const bool last = t == a.H - 1;
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    ox[i] = z[t * NX + i];
-                    oxr[i] = P[a.oo.xref + t * NX + i];
-                    ocx[i] = P[a.oo.cx + t * NX + i];
-                }
-#pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    ou[i] = z[a.H * NX + t * NU + i];
-                    our[i] = P[a.oo.uref + t * NU + i];
-                    ocu[i] = P[a.oo.cu + t * NU + i];
-                }
-#pragma unroll
-                for (int i = 0; i < NX * NX; ++i) {
-                    oQ[i] = P[(last ? a.oo.QT : a.oo.Q) + i];
-                    oQs[i] = P[(last ? a.oo.QTs : a.oo.Qs) + i];
-                }
-#pragma unroll
-                for (int i = 0; i < NU * NU; ++i) {
-                    oR[i] = P[a.oo.R + i];
-                    oRs[i] = P[a.oo.Rs + i];
-                }
-            }
-        }
-    }
+    FX_STAMP_PRO(pa.dbg, 1);
     constexpr int SMALL_VECS = (L::SMALL_END + VEC - 1) / VEC;
     constexpr int SMALL_PER_THREAD = (SMALL_VECS + NTHREADS - 1) / NTHREADS;
     vecT sm[SMALL_PER_THREAD];
     {
-        const vecT* __restrict__ gs = static_cast<const vecT*>(a.small);
+        const vecT* __restrict__ gs = static_cast<const vecT*>(pa.small);
 #pragma unroll
         for (int u = 0; u < SMALL_PER_THREAD; ++u) {
             const int idx = tid + u * NTHREADS;
             if (idx < SMALL_VECS) sm[u] = gs[idx];
+        }
+    }
+    FX_STAMP_PRO(pa.dbg, 2);
+    // fused evaluation: the objective of this workgroup's problems (those whose first row lies in its tile range).  Their
+    // variables -- one contiguous piece of Z -- are fetched in the prologue and parked in LDS next to the
+    // objective's table; the first pass evaluates them from there, one problem per wave.  Evaluated from global memory it
+    // cost a round trip of its own wherever it stood (at the end of the kernel 1.3 us; in the prologue, 19 loads per lane
+    // ahead of the weight slices in the in-order return queue, about the same).  Everything these loads need is
+    // among the preloaded arguments, so they go out without waiting for the argument block.
+    unsigned ob_lo = 0, ob_hi = 0;
+    int ob_n = 0;                       // problems whose variables fit the LDS copy
+    constexpr int ZV_PER_THREAD = 2;
+    T zv[ZV_PER_THREAD];
+    if constexpr (FUSE) {
+        if (want_obj) {
+            const unsigned r_lo = (unsigned)t_begin * 16u;
+            unsigned r_hi = (unsigned)t_end * 16u;
+            if (r_hi > pa.R) r_hi = pa.R;
+            const unsigned Hh = (unsigned)pa.H;
+            ob_lo = pa.invH ? __umulhi(r_lo + Hh - 1, pa.invH) : r_lo;
+            ob_hi = pa.invH ? __umulhi(r_hi + Hh - 1, pa.invH) : r_hi;      // problems ob_lo .. ob_hi - 1
+            ob_n = (int)(ob_hi - ob_lo) < pa.zp_max ? (int)(ob_hi - ob_lo) : pa.zp_max;
+            const T* __restrict__ zsrc = cx.Z + (size_t)ob_lo * pa.n;
+#pragma unroll
+            for (int u = 0; u < ZV_PER_THREAD; ++u) {
+                const int idx = tid + u * NTHREADS;
+                zv[u] = idx < ob_n * pa.n ? zsrc[idx] : T(0);
+            }
         }
     }
     // fused evaluation: the objective table rides along (-> LDS behind the layout, read at the very end); tables
@@ -563,26 +691,25 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     constexpr int PV_PER_THREAD = 2;
     T pv[PV_PER_THREAD];
     if constexpr (FUSE) {
-        const T* __restrict__ gp = static_cast<const T*>(a.P);
+        const T* __restrict__ gp = static_cast<const T*>(pa.P);
 #pragma unroll
         for (int u = 0; u < PV_PER_THREAD; ++u) {
             const int idx = tid + u * NTHREADS;
-            pv[u] = idx < a.p_elems ? gp[idx] : T(0);
+            pv[u] = idx < pa.p_elems ? gp[idx] : T(0);
         }
     }
+    FX_STAMP_PRO(pa.dbg, 3);
     constexpr int NFRAG = (NH - 1) * 2 * MT * 4 + 8;
     constexpr int NLOAD = (NFRAG + VEC - 1) / VEC;
     vecT wv[NLOAD];
     {
-        const vecT* __restrict__ ws = static_cast<const vecT*>(a.wslice) + (size_t)w * NLOAD * 64 + lane;
+        const vecT* __restrict__ ws = static_cast<const vecT*>(pa.wslice) + (size_t)w * NLOAD * 64 + lane;
 #pragma unroll
         for (int k = 0; k < NLOAD; ++k) wv[k] = ws[k * 64];
     }
-    cx.gout = static_cast<T*>(a.g);
-    cx.tiles = static_cast<T*>(a.tiles);
-    cx.jac = static_cast<T*>(a.jac);
-    cx.m = a.m; cx.ident = a.ident; cx.box = a.box;
-    cx.rb_rows = a.rb_rows; cx.inv_nvec = a.inv_nvec;
+    FX_STAMP_PASS(pa.dbg, 1);
+    FX_STAMP_PRO(pa.dbg, 4);
+    cx.dbg = pa.dbg;
     {
         vecT* ls = reinterpret_cast<vecT*>(lds + L::W0F);
 #pragma unroll
@@ -591,52 +718,24 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
             if (idx < SMALL_VECS) ls[idx] = sm[u];
         }
     }
+    FX_STAMP_PRO(pa.dbg, 5);
     if constexpr (FUSE) {
 #pragma unroll
         for (int u = 0; u < PV_PER_THREAD; ++u) {
             const int idx = tid + u * NTHREADS;
-            if (idx < a.p_elems) lds[L::TOTAL + idx] = pv[u];
+            if (idx < pa.p_elems) lds[L::TOTAL + idx] = pv[u];
         }
     }
+    const int p_pad = (pa.p_elems + 15) & ~15;
     if constexpr (FUSE) {
-        const unsigned bw = ob_lo + (unsigned)w;
-        if (ob_pro && bw < ob_hi) {
-            // same operations in the same order as objective_body (kernels_obj_impl.h): same bits
-            double acc = 0.0;
-            if (lane < a.H) {
-                T* grad = static_cast<T*>(a.grad);
 #pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    const T dxi = ox[i] - oxr[i];
-                    T qd = T(0), qsd = T(0);
-#pragma unroll
-                    for (int j = 0; j < NX; ++j) {
-                        const T dxj = ox[j] - oxr[j];
-                        qd = fma(oQ[i * NX + j], dxj, qd);
-                        qsd = fma(oQs[i * NX + j], dxj, qsd);
-                    }
-                    acc += (double)(dxi * qd + ocx[i] * ox[i]);
-                    if (grad) grad[(size_t)bw * a.n + lane * NX + i] = qsd + ocx[i];
-                }
-#pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    const T dui = ou[i] - our[i];
-                    T rd = T(0), rsd = T(0);
-#pragma unroll
-                    for (int j = 0; j < NU; ++j) {
-                        const T duj = ou[j] - our[j];
-                        rd = fma(oR[i * NU + j], duj, rd);
-                        rsd = fma(oRs[i * NU + j], duj, rsd);
-                    }
-                    acc += (double)(dui * rd + ocu[i] * ou[i]);
-                    if (grad) grad[(size_t)bw * a.n + a.H * NX + lane * NU + i] = rsd + ocu[i];
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-            if (a.f && lane == 0) static_cast<T*>(a.f)[bw] = (T)acc;
+        for (int u = 0; u < ZV_PER_THREAD; ++u) {
+            const int idx = tid + u * NTHREADS;
+            if (idx < ob_n * pa.n) lds[L::TOTAL + p_pad + idx] = zv[u];
         }
     }
+    FX_STAMP_PASS(pa.dbg, 2);
+    FX_STAMP_PRO(pa.dbg, 6);
     CoopWeights<T, WP, NH> W;
     {
         int f = 0;
@@ -653,9 +752,11 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         for (int r = 0; r < 4; ++r, ++f) W.w0b[r] = wv[f / VEC][f % VEC];
     }
 
+    FX_STAMP_PASS(pa.dbg, 3);
     int parity = 0, xsel = 0;
     T* const in_base = lds + L::IN;
     fx_stage_store<T, WP, NH, TPW, NX, NU, TPW>(in_base, tid, sr);
+    FX_STAMP_PRO(pa.dbg, 7);
     while (t0 < t_end) {
         const int t_cur = t0;
         const int n_cur = t_end - t0 < TPW ? t_end - t0 : TPW;
@@ -663,6 +764,19 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         const bool more = t0 < t_end;
         if (more) fx_stage_load<T, WP, NH, TPW, NX, NU, TPW>(cx, t0, tid, sr);   // next pass's inputs, under this pass
         lds_barrier();
+        FX_STAMP_PASS(pa.dbg, 4);
+        FX_STAMP_PRO(pa.dbg, 8);
+        if constexpr (FUSE) {
+            if (t_cur == t_begin && ob_n > 0) {
+                const FxArgsK ka = fx_late_args();
+                T* const o_f = static_cast<T*>(ka->f);
+                T* const o_grad = static_cast<T*>(ka->grad);
+                for (int k = w; k < ob_n; k += MT)
+                    objective_row<T>((int)ob_lo + k, lane, pa.H, NX, NU, pa.oo, lds + L::TOTAL, lds + L::TOTAL + p_pad + k * pa.n,
+                                     o_f, o_grad);
+            }
+        }
+        FX_STAMP_PRO(pa.dbg, 9);
         const T* in = in_base + parity * L::IN_SZ;
         T* const in_next = in_base + (parity ^ 1) * L::IN_SZ;
         if (n_cur == 1) fx_pass<T, WP, NH, TPW, NX, NU, 1, FUSE>(cx, W, in, t_cur, tid, xsel, sr, more, in_next);
@@ -671,19 +785,22 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         parity ^= 1;
     }
     if constexpr (FUSE) {
-        // ---- objective of the problems whose first row lies in this workgroup's tile range, one problem per wave
-        //      at a time (same routine, hence the same bits, as the assembly kernels' objective blocks)
-        if (a.f || a.grad) {
-            if (a.p_elems > PV_PER_THREAD * NTHREADS) {
-                const T* __restrict__ gp = static_cast<const T*>(a.P);
-                for (int i = tid + PV_PER_THREAD * NTHREADS; i < a.p_elems; i += NTHREADS) lds[L::TOTAL + i] = gp[i];
+        // ---- problems beyond the LDS copy (long horizons, many problems per workgroup): from global memory, one
+        //      problem per wave at a time (same routine, hence the same bits)
+        if (want_obj && ob_lo + (unsigned)ob_n < ob_hi) {
+            const FxArgsK ka = fx_late_args();
+            if (pa.p_elems > PV_PER_THREAD * NTHREADS) {
+                const T* __restrict__ gp = static_cast<const T*>(pa.P);
+                for (int i = tid + PV_PER_THREAD * NTHREADS; i < pa.p_elems; i += NTHREADS) lds[L::TOTAL + i] = gp[i];
                 __syncthreads();
             }
-            for (unsigned b = ob_lo + (unsigned)w + (ob_pro ? MT : 0); b < ob_hi; b += MT)
-                objective_body<T>((int)b, lane, a.H, NX, NU, a.oo, lds + L::TOTAL, cx.Z, static_cast<T*>(a.f),
-                                  static_cast<T*>(a.grad));
+            for (unsigned b = ob_lo + (unsigned)ob_n + (unsigned)w; b < ob_hi; b += MT)
+                objective_body<T>((int)b, lane, pa.H, NX, NU, pa.oo, lds + L::TOTAL, cx.Z, static_cast<T*>(ka->f),
+                                  static_cast<T*>(ka->grad));
         }
     }
+    COOP_WGSTAMP(pa.dbg, 14);
+    COOP_WGSTAMP_REAL(pa.dbg, 13);
 }
 
 }  // namespace nempc

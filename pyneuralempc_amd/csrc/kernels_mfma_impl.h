@@ -92,13 +92,16 @@ struct MfmaParams {
 // wave-instruction on gfx950.  On this chip every vector instruction -- double, single or integer -- takes the same 4
 // issue cycles (v_rcp_f64: 16) and a v_mfma_f64 holds the vector pipe for all of its 64 (tools/ubench_dpops.hip: MFMA
 // waves and vector waves on one SIMD serialise whatever the vector instruction is), so what a tanh costs the matrix
-// kernels is its instruction COUNT.  25 issue slots here against 33 for the straightforward form (degree-13 Taylor,
+// kernels is its instruction COUNT.  24 issue slots here against 33 for the straightforward form (degree-13 Taylor,
 // v_rndne + v_cvt_i32, two Newton steps, NaN select), same 2.2e-16 max abs error against tanhl on [-30, 30]
 // (tools/ubench_tanh.hip; absolute accuracy is what the 1 - a^2 derivative factors need):
 //  * |x| is clamped at 20 (tanh(20) rounds to 1) on its HIGH dword only: one compare, one select.  A NaN fails the
 //    compare and flows through every later operation, so a diverged iterate stays visible without a select at the end
 //  * n = rint(|x| * 2/ln2) by the 1.5*2^52 shift: one fma and one subtract, and the integer n is the low dword of
 //    the shifted value (no v_rndne_f64, no v_cvt_i32_f64)
+//  * s = |x| - n ln2/2 with ln2/2 as ONE double: its rounding error (1.9e-17) times n is an error of 2.2 n 1.9e-17 in
+//    exp(2s), which reaches tanh scaled by 2e/(e+1)^2 ~ 2^(1-n): at most 2.4e-17 absolute (n = 2), so the second
+//    Cody-Waite step buys nothing here
 //  * exp(2s) on |s| <= ln2/4 by a degree-11 Chebyshev fit (relative error 1.7e-17 with the rounded coefficients)
 //  * 1/d from v_rcp_f64 and ONE cubic step (three fmas)
 __device__ __forceinline__ double nempc_tanh(double x) {
@@ -106,8 +109,7 @@ __device__ __forceinline__ double nempc_tanh(double x) {
     const double SHIFT = 6755399441055744.0;
     const double t = fma(fabs(a), 2.8853900817779268, SHIFT);
     const double nf = t - SHIFT;
-    double s = fma(-nf, 0.5 * 6.93147180369123816490e-01, fabs(a));
-    s = fma(-nf, 0.5 * 1.90821492927058770002e-10, s);
+    const double s = fma(-nf, 0.34657359027997264, fabs(a));      // ln2/2 in one piece, see above
     double p = 5.1425357017013815e-05;
     p = fma(p, s, 0.00028295822990378013);
     p = fma(p, s, 0.0014109307350312432);

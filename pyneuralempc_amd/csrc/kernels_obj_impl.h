@@ -6,13 +6,41 @@
 
 namespace nempc {
 
-// one wave per problem; lanes stride over the horizon
+// Sum over the wave, valid in lane 0, in the pairing order of the shuffle tree (offsets 32, 16, 8, 4, 2, 1; lane i adds
+// lane i + offset) -- on the vector unit alone: gfx950's row swaps for the two wide steps, DPP row shifts for the four
+// narrow ones.  The ds_bpermute tree it replaces is six dependent LDS round trips.
+template <int N>
+__device__ __forceinline__ double row_shl_add(double s) {
+    const int lo = __double2loint(s), hi = __double2hiint(s);
+    // row_shl:N -- lane i reads lane i + N of its 16-lane row; lanes whose source is outside the row read 0
+    const int l2 = __builtin_amdgcn_update_dpp(0, lo, 0x100 + N, 0xf, 0xf, false);
+    const int h2 = __builtin_amdgcn_update_dpp(0, hi, 0x100 + N, 0xf, 0xf, false);
+    return s + __hiloint2double(h2, l2);
+}
+__device__ __forceinline__ double wave_sum_lane0(double s) {
+    {
+        auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(s), (unsigned)__double2loint(s), false, false);
+        auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(s), (unsigned)__double2hiint(s), false, false);
+        s = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);     // lane i < 32: s_i + s_{i+32}
+    }
+    {
+        auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(s), (unsigned)__double2loint(s), false, false);
+        auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(s), (unsigned)__double2hiint(s), false, false);
+        s = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);     // lane i < 16: + lane i + 16
+    }
+    s = row_shl_add<8>(s);
+    s = row_shl_add<4>(s);
+    s = row_shl_add<2>(s);
+    s = row_shl_add<1>(s);
+    return s;
+}
+
+// one wave per problem; lanes stride over the horizon.  z: the problem's variables (global memory, or a copy in LDS)
 template <typename T>
-__device__ __forceinline__ void objective_body(int b, int lane, int H, int nx, int nu, const ObjOffsets& o,
-                                               const T* __restrict__ P, const T* __restrict__ Z,
-                                               T* __restrict__ f, T* __restrict__ grad) {
+__device__ __forceinline__ void objective_row(int b, int lane, int H, int nx, int nu, const ObjOffsets& o,
+                                              const T* __restrict__ P, const T* __restrict__ z,
+                                              T* __restrict__ f, T* __restrict__ grad) {
     const int n = H * (nx + nu);
-    const T* z = Z + (size_t)b * n;
     const T *Rm = P + o.R, *Rs = P + o.Rs;
     const T *xref = P + o.xref, *uref = P + o.uref, *cx = P + o.cx, *cu = P + o.cu;
     double acc = 0.0;
@@ -45,10 +73,15 @@ __device__ __forceinline__ void objective_body(int b, int lane, int H, int nx, i
             if (grad) grad[(size_t)b * n + H * nx + t * nu + i] = rsd + cu[t * nu + i];
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    acc = wave_sum_lane0(acc);
     if (f && lane == 0) f[b] = (T)acc;
 }
 
+template <typename T>
+__device__ __forceinline__ void objective_body(int b, int lane, int H, int nx, int nu, const ObjOffsets& o,
+                                               const T* __restrict__ P, const T* __restrict__ Z,
+                                               T* __restrict__ f, T* __restrict__ grad) {
+    objective_row<T>(b, lane, H, nx, nu, o, P, Z + (size_t)b * (H * (nx + nu)), f, grad);
+}
 
 }  // namespace nempc

@@ -141,7 +141,7 @@ struct Handle {
 struct ObjOffsets {  // element offsets into Handle::d_obj
     int Q, Qs, R, Rs, xref, uref, cx, cu, QT, QTs, total;   // QT: weight of the last step (terminal cost), QTs = QT + QT^T
 };
-inline ObjOffsets obj_offsets(int H, int nx, int nu) {
+__host__ __device__ inline ObjOffsets obj_offsets(int H, int nx, int nu) {
     ObjOffsets o;
     int p = 0;
     o.Q = p; p += nx * nx;

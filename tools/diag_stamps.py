@@ -37,7 +37,10 @@ if __name__ == "__main__":
     eng.lib.nempc_debug_stamps(eng._handle, None)
     Z, X0 = orc.synthetic_inputs(B, 20, 2, 1, seed=1)
     Z, X0 = eng.to_device(Z), eng.to_device(X0)
-    want = ("g", "jac_dense") if (len(sys.argv) > 3 and sys.argv[3] == "dense") else ("g", "jac_tiles")
+    mode = sys.argv[3] if len(sys.argv) > 3 else "tiles"
+    want = {"dense": ("g", "jac_dense"), "fused": ("f", "grad", "g", "jac_dense")}.get(mode, ("g", "jac_tiles"))
+    if mode == "fused":
+        eng.set_objective(Q=np.eye(2), R=np.eye(1))
     for _ in range(3):
         eng.eval(Z, X0, want)
     buf = np.zeros(1024 + 4096 * 16, dtype=np.int64)
@@ -72,6 +75,14 @@ if __name__ == "__main__":
           f"median workgroup lifetime {np.median(span_clk):.0f} cycles]")
     names = ["entry", "stage_ld issued", "blob->LDS", "weights issued", "p1 staged", "p1 done", "p2 staged", "p2 done",
              "p3 staged", "p3 done"]
+    if eng.last_row_kernel == "rows_coopfx_kernel":      # fixed-shape kernel: stamps of the LAST pass of each workgroup
+        names = ["entry", "loads issued", "tables in LDS", "weights arrived", "first barrier", "forward done",
+                 "reverse done", "partials barrier", "tiles + g out", "rows assembled", "rows barrier", "rows issued",
+                 "pass end"]
+        if any(f == "-DNEMPC_STAMPS_PRO" for f in sys.argv) or os.environ.get("NEMPC_STAMPS_PRO"):
+            names = ["entry", "inputs issued", "tables issued", "objective loads issued", "weights issued",
+                     "tables in LDS", "objective data in LDS", "inputs in LDS", "first barrier", "objective done",
+                     "layer 0 done", "hidden forward done", "reverse done"]
     for lo, hi, label in ((0, 256, "wg 0..255 (one tile more)"), (256, 512, "wg 256..511")):
         sel = wg[lo:hi]
         if not len(sel): continue

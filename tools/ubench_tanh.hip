@@ -53,8 +53,7 @@ __device__ __forceinline__ double tanh_lean(double x) {
     const double SHIFT = 6755399441055744.0;                                   // 1.5 * 2^52
     const double t = fma(fabs(a), 2.8853900817779268, SHIFT);                  // 2/ln2
     const double nf = t - SHIFT;
-    double s = fma(-nf, 0.5 * 6.93147180369123816490e-01, fabs(a));
-    s = fma(-nf, 0.5 * 1.90821492927058770002e-10, s);
+    const double s = fma(-nf, 0.34657359027997264, fabs(a));      // ln2/2 in one piece: its rounding error matters only where tanh is flat
     double p;
     if (DEG == 11) {
         p = 5.1425357017013815e-05;
