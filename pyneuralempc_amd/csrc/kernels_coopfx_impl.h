@@ -455,14 +455,12 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
         constexpr int DR = NT * 16 * NX;                                 // dense rows of a full pass
         T* const o_jac = static_cast<T*>(ka->jac);
         const int a_rb_rows = ka->rb_rows;
-        const unsigned a_inv_nvec = ka->inv_nvec;
         T* const RB = lds + L::X;
         vecT* const RBv = reinterpret_cast<vecT*>(RB);
         const int n = cx.n, nvec = n / VEC;
         const unsigned r0 = (unsigned)t0 * 16u;
         const int drv = r0 + NT * 16u <= cx.R ? DR : (int)(cx.R - r0) * NX;     // rows of the pass that exist
         const int rpc = drv < a_rb_rows ? drv : a_rb_rows;            // rows per chunk of the LDS row buffer
-        const unsigned b0 = cx.invH ? __umulhi(r0, cx.invH) : r0;       // first problem of the pass (uniform)
         const vecT zero = {};
 #ifdef NEMPC_EXP_NODENSE      // timing experiment only
         const int nkind = 0;
@@ -549,29 +547,38 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
                         }
                     }
                 } else {
-                    const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) + (size_t)b0 * a_m * (size_t)n * sizeof(T));
-                    constexpr int UB = 4;
-                    for (int f0 = tid; f0 < nvc; f0 += UB * NTHREADS) {
-                        vecT v[UB];
+                    // with box rows a problem's defect rows and its box rows are two separate contiguous blocks: the chunk is
+                    // cut where the problem changes (scalar arithmetic, at most a few pieces) and every piece is a flat copy
+                    // like the one above -- no per-vector address arithmetic
+                    const int HNXr = cx.H * NX;
+                    for (int s0 = 0; s0 < nr;) {
+                        const int lr = c0 + s0;                                  // first dense row of the piece
+                        const unsigned r = r0 + (unsigned)(lr / NX);
+                        const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
+                        const int k = (int)(r - b * (unsigned)cx.H) * NX + (lr - (lr / NX) * NX);   // its row within the block
+                        const int len = nr - s0 < HNXr - k ? nr - s0 : HNXr - k;  // rows up to the end of the problem / chunk
+                        const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) +
+                                                          ((size_t)b * a_m + (kind ? HNXr : 0) + k) * (size_t)n * sizeof(T));
+                        const vecT* src = RBv + s0 * nvec;
+                        const int nv = len * nvec;
+                        constexpr int UB = 4;
+                        for (int f0 = tid; f0 < nv; f0 += UB * NTHREADS) {
+                            vecT v[UB];
 #pragma unroll
-                        for (int u = 0; u < UB; ++u) {
-                            const int fv = f0 + u * NTHREADS;
-                            if (fv < nvc) v[u] = RBv[fv];
-                        }
+                            for (int u = 0; u < UB; ++u) {
+                                const int fv = f0 + u * NTHREADS;
+                                if (fv < nv) v[u] = src[fv];
+                            }
 #pragma unroll
-                        for (int u = 0; u < UB; ++u) {
-                            const int fv = f0 + u * NTHREADS;
-                            const int lrr = a_inv_nvec ? (int)__umulhi((unsigned)fv, a_inv_nvec) : fv;
-                            const int cv = fv - lrr * nvec;
-                            const int lr = c0 + lrr;
-                            const int lrow = lr / NX, i = lr - lrow * NX;
-                            const unsigned r = r0 + (unsigned)lrow;
-                            const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
-                            const int t = (int)(r - b * (unsigned)cx.H);
-                            const int rowidx = (int)(b - b0) * a_m + (kind ? cx.H * NX : 0) + t * NX + i;
-                            const int voff = (rowidx * n + cv * VEC) * (int)sizeof(T);
-                            if (fv < nvc) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v[u]), "s"(base));
+                            for (int u = 0; u < UB; ++u) {
+                                const int fv = f0 + u * NTHREADS;
+#ifdef NEMPC_EXP_NODENSE_STORE   // timing experiment only
+                                if (v[u][0] == T(123.456))
+#endif
+                                if (fv < nv) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(v[u]), "s"(base));
+                            }
                         }
+                        s0 += len;
                     }
                 }
             }

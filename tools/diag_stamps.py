@@ -32,10 +32,13 @@ if __name__ == "__main__":
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     kernel = sys.argv[2] if len(sys.argv) > 2 else "mfma"
     net = orc.MLP.random(3, [64, 64], 2, seed=0)
-    eng = CallbackEngine(net.W, net.b, 20, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=B, kernel=kernel)
+    Hd = int(os.environ.get("NEMPC_DIAG_H", "20"))
+    eng = CallbackEngine(net.W, net.b, Hd, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=B, kernel=kernel)
+    if os.environ.get("NEMPC_DIAG_BOX"):
+        eng.set_box_rows(-2.0, 2.0)
     eng.lib.nempc_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     eng.lib.nempc_debug_stamps(eng._handle, None)
-    Z, X0 = orc.synthetic_inputs(B, 20, 2, 1, seed=1)
+    Z, X0 = orc.synthetic_inputs(B, Hd, 2, 1, seed=1)
     Z, X0 = eng.to_device(Z), eng.to_device(X0)
     mode = sys.argv[3] if len(sys.argv) > 3 else "tiles"
     want = {"dense": ("g", "jac_dense"), "fused": ("f", "grad", "g", "jac_dense")}.get(mode, ("g", "jac_tiles"))
