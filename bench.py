@@ -405,7 +405,9 @@ class Rank:
                 "peak": peak_tf, "unit": "TFLOP/s", "frac": work["flops"] / res["t_rows"] / 1e12 / peak_tf,
                 "traffic": None, "kernel_us": res["t_rows"] * 1e6, "flops_per_launch": work["flops"],
                 "arithmetic_intensity_dense": ai, "ridge": ridge}
-        hbm = {"bound": "hbm", "kernel": "whole evaluation (row kernel + post_flat_kernel)",
+        fused = res["row_kernel"] == "rows_coopfx_kernel"
+        hbm = {"bound": "hbm", "kernel": ("whole evaluation: one launch, rows_coopfx_kernel<..., FUSE = true>" if fused else
+                                           "whole evaluation (row kernel + post_flat_kernel)"),
                "achieved": work["dense_bytes"] / t_eval / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                "frac": work["dense_bytes"] / t_eval / 1e9 / PEAK_HBM_GBS, "traffic": None,
                "bytes_per_eval_dense_contract": work["dense_bytes"], "eval_us": t_eval * 1e6,
