@@ -291,3 +291,46 @@ def test_box_rows_are_state_bounds_for_the_batched_solver():
     assert ok.sum() >= B // 2
     zs = Za.cpu().numpy()[ok][:, :H * nx]
     assert zs.max() <= 0.7 + 1e-9 and zs.max() > 0.69        # the row limit is active
+
+
+def test_backtracking_modes_reach_the_same_solutions_and_barrier_kinds_agree():
+    """nempc_solver_opts.linesearch / .barrier: deferred backtracking (one trial evaluation per iteration; a rejected
+    problem retries at half the length next iteration) and the inner loop are different schedules of the same search --
+    on problems both converge, to the same KKT points; the primal-dual interior point and the primal log barrier end at
+    the same bounded minimisers.  Deferral may spend more iterations, never fewer converged problems at a generous budget."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, H, B = 2, 1, 20, 256
+    net = orc.MLP.random(nx + nu, [64, 64], nx, seed=0)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B)
+    X0 = eng.to_device(np.random.default_rng(100).uniform(-0.5, 0.5, size=(B, nx)))
+    lb = np.concatenate([np.full(H * nx, -3.0), np.full(H * nu, -0.5)])
+    out = {}
+    for key, kw in (("loop", dict(linesearch="loop")), ("deferred", dict(linesearch="deferred")),
+                    ("primal", dict(linesearch="loop", barrier="primal"))):
+        Z, st, it, per = eng.solve(X0, lb=lb, ub=-lb, max_iter=400, return_iterations=True, **kw)
+        out[key] = (Z.cpu().numpy(), st.cpu().numpy(), it, per.cpu().numpy())
+    ok_l, ok_d, ok_p = (out[k][1] == 0 for k in ("loop", "deferred", "primal"))
+    assert ok_l.mean() > 0.97 and ok_d.mean() > 0.97 and ok_p.mean() > 0.9
+    both = ok_l & ok_d
+    # same local solution unless the two schedules fell into different basins (rare; bounded here)
+    diff = np.abs(out["loop"][0][both] - out["deferred"][0][both]).max(axis=1)
+    assert (diff < 1e-5).mean() > 0.97
+    bothp = ok_l & ok_p
+    diffp = np.abs(out["loop"][0][bothp] - out["primal"][0][bothp]).max(axis=1)
+    assert (diffp < 1e-4).mean() > 0.95
+    # bounds hold at every returned iterate
+    for k in out:
+        assert (out[k][0] >= lb - 1e-12).all() and (out[k][0] <= -lb + 1e-12).all()
+    # a deferred problem spends an iteration per trial
+    assert np.median(out["deferred"][3][both]) >= np.median(out["loop"][3][both])
+
+
+def test_solver_refuses_unknown_option_values():
+    from pyneuralempc_amd import CallbackEngine
+    net = orc.MLP.random(3, [16], 2, seed=1)
+    eng = CallbackEngine(net.W, net.b, 5, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=4)
+    X0 = eng.to_device(np.zeros((4, 2)))
+    with pytest.raises(KeyError):
+        eng.solve(X0, linesearch="sometimes")
+    with pytest.raises(KeyError):
+        eng.solve(X0, barrier="dual")
