@@ -13,7 +13,12 @@ a rank owns, inputs already resident in HBM.  `value` = problem-evals/s over the
 Ranks shard independent problems (weak scaling, no data-path collective).  The only exchange is the all-gather of
 the first controls u0, once per MPC step: with N > 1 it is issued INSIDE the timed loop, through libnempc.so's own
 RCCL call (nempc_allgather_u0), once every `--evals-per-mpc-step` evaluations (an MPC step = one NLP solve = that
-many callback evaluations; default 10, the low end of what the batched solver needs).
+many callback evaluations; default 17, the median number of iterations the batched solver needs on this workload --
+`batched_solver.iters_to_converge_p50` -- each of which evaluates the callbacks at least once).
+
+Timing: the device is first brought to its sustained clock by `--prime-ms` (default 40) of the same step, untimed and
+reported (`clock_priming`); then W warm-up steps; then a barrier and a device synchronize, exactly K steps, a device
+synchronize that stops the rank's clock, a barrier, and the MAX over ranks.
 
 With `--gpus N > 1` and no WORLD_SIZE in the environment this process only launches the N ranks (before anything
 touches the GPU) and relays rank 0's JSON line; a failed rank makes the exit code non-zero.
@@ -229,12 +234,26 @@ class Rank:
             eng.set_box_rows(*cfg["box"])
         return eng
 
-    def timed_events(self, fn, reps):
+    def prime(self, fn, ms=None):
+        """untimed run of `fn` for --prime-ms (at least one call), device drained afterwards: every timing of this file
+        starts from the sustained clock, not from whatever the idle time before it left"""
+        ms = self.args.prime_ms if ms is None else ms
+        tp = time.perf_counter()
+        fn()
+        while (time.perf_counter() - tp) * 1e3 < ms:
+            for _ in range(16):
+                fn()
+            self.torch.cuda.synchronize(self.dev)
+        self.torch.cuda.synchronize(self.dev)
+        return (time.perf_counter() - tp) * 1e3
+
+    def timed_events(self, fn, reps, prime_ms=None):
         """average seconds per call between two HIP events on the launch stream (torch's current stream is the one the
-        engine launches on)"""
+        engine launches on).  prime_ms=0 for a `fn` that contains a collective: the priming loop is time-based, and ranks
+        must issue the same number of collectives."""
         torch = self.torch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fn(); torch.cuda.synchronize(self.dev)
+        self.prime(fn, prime_ms)
         e0.record()
         for _ in range(reps):
             fn()
@@ -246,7 +265,7 @@ class Rank:
         """one HIP event pair per evaluation -> (p10, median, p90) in microseconds"""
         torch, np = self.torch, self.np
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-        fn(); torch.cuda.synchronize(self.dev)
+        self.prime(fn)
         evs[0].record()
         for i in range(reps):
             fn()
@@ -320,7 +339,8 @@ class Rank:
                 # the exchange runs on its own HIP stream: it only reads Z (the solver's output of the previous MPC step),
                 # nothing on the callback path waits for it, so the next evaluations proceed under it (xGMI latency is
                 # hidden instead of being added to every MPC step); the timed region ends with both streams drained
-                comm_stream = torch.cuda.Stream(self.dev)
+                comm_stream = (torch.cuda.current_stream(self.dev) if os.environ.get("NEMPC_BENCH_GATHER_STREAM") == "main"
+                               else torch.cuda.Stream(self.dev))          # A/B knob: same stream = serialised exchange
                 torch.cuda.synchronize(self.dev)
                 launch_gather, gathered_buf = eng.bind_allgather_u0(Z, stream=comm_stream)
                 main_stream = torch.cuda.current_stream(self.dev)
@@ -335,13 +355,22 @@ class Rank:
         res = {"cfg": cfg, "B": B, "eng": eng}
 
         if headline:
+            # A GPU that has been idle (process start-up, allocation, the barrier) runs its first milliseconds below its
+            # sustained clock: the same launch takes 19.9 us in a cold 20-step region and 17.3 us after ~30 ms of load
+            # (tools/host_launch_cost.py).  The metric is a sustained rate, so the device is brought to it first --
+            # `--prime-ms` of this same step, untimed, reported in the line -- then the W warm-up steps, then the K timed ones.
+            res["primed_ms"] = self.prime(step) if args.prime_ms > 0 else 0.0
             for i in range(warmup):
                 step()
                 if gather and (i + 1) % gather_every == 0:
                     gather()
             if gather:
                 gather()
+            # exactly `steps` steps between two (barrier + device synchronize) brackets; the closing synchronize drains both
+            # streams and stops this rank's clock, the closing barrier and the MAX over ranks follow -- the slowest rank sets
+            # the time, the latency of the barrier collective itself (0.1-0.3 ms, as long as a short timed region) does not
             self.barrier()
+            torch.cuda.synchronize(self.dev)
             t0 = time.perf_counter()
             n_gather = 0
             for i in range(steps):
@@ -349,8 +378,9 @@ class Rank:
                 if gather and (i + 1) % gather_every == 0:
                     gathered = gather()
                     n_gather += 1
-            self.barrier()
+            torch.cuda.synchronize(self.dev)
             wall = time.perf_counter() - t0
+            self.barrier()
             wall = self.max_over_ranks(wall)
             res["wall"] = wall
             res["n_gather"] = n_gather
@@ -483,7 +513,7 @@ class Rank:
             from pyneuralempc_amd.parallel import allgather_u0, first_controls
             fn = lambda: allgather_u0(first_controls(Zd, cfg["H"], cfg["nx"], cfg["nu"]), total=self.world * B)  # noqa: E731
         self.barrier()
-        t = self.timed_events(fn, reps)
+        t = self.timed_events(fn, reps, prime_ms=0)
         return self.max_over_ranks(t) * 1e6
 
     # -------------------------------------------------------------------------------------------------------------
@@ -511,6 +541,9 @@ class Rank:
             "roofline_" + secondary["bound"] + ("_whole_eval" if secondary["bound"] == "hbm" else "_row_kernel"): secondary,
             "eval_us": {"timed_loop": wall / args.steps * 1e6, "event_loop": res["t_all"] * 1e6,
                         "p10_median_p90": res["step_pcts"]},
+            "clock_priming": {"ms": res.get("primed_ms", 0.0),
+                              "note": "untimed run of the same step before the W warm-up steps: an idle GPU starts below its "
+                                      "sustained clock (--prime-ms 0 measures from cold)"},
         }
         if self.dist is not None:
             out["allgather_u0"] = {
@@ -639,8 +672,10 @@ def main():
                          "launch only (no two-stream, solver, Hessian, other-config or CPU legs), so that a rocprofv3 "
                          "kernel trace of this command averages the headline launch alone")
     ap.add_argument("--hessian", action="store_true", help="also time the Hessian callbacks (reported apart)")
-    ap.add_argument("--evals-per-mpc-step", type=int, default=10,
+    ap.add_argument("--evals-per-mpc-step", type=int, default=17,
                     help="N > 1: one u0 all-gather per this many callback evaluations inside the timed loop")
+    ap.add_argument("--prime-ms", type=float, default=40.0,
+                    help="untimed run of the headline step before the warm-up steps, to reach the sustained clock (0: off)")
     ap.add_argument("--solver-iters", type=int, default=64)
     ap.add_argument("--pmc-file", default="r02_c2_b1024_pmc.json")
     args = ap.parse_args()

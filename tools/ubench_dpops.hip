@@ -50,6 +50,41 @@ OP32(mov, "v_mov_b32 %0, %0")
 // Does a vector instruction of kind KIND co-issue with v_mfma_f64_16x16x4_f64 of another wave on the same SIMD?
 // 512 threads = 2 waves per SIMD; waves 0-3 run MFMAs, waves 4-7 the vector instruction (mode 0 both, 1 MFMA only, 2 vector only)
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+// same question for the single-precision matrix instruction (v_mfma_f32_16x16x4_f32, 32 cycles)
+template <int KIND>
+__global__ void coexec32(double* out, int iters, int mode) {
+    const int wave = threadIdx.x >> 6;
+    const bool mf = wave < 4;
+    f4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = f4{0, 0, 0, 0};
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    double v[8];
+    float f[8];
+    for (int i = 0; i < 8; ++i) { v[i] = a + i; f[i] = a + i; }
+    if (mf && mode != 2) {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);   // 8 x 32 cycles
+    } else if (!mf && mode != 1) {
+        for (int it = 0; it < iters; ++it)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (KIND == 0) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(v[i]));
+                    if (KIND == 1) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f[i]));
+                    if (KIND == 2) asm volatile("v_add_u32 %0, %0, %0" : "+v"(f[i]));
+                }
+    }
+    double s = 0;
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < 8; ++i) s += v[i] + f[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <int KIND>
 __global__ void coexec(double* out, int iters, int mode) {
     const int wave = threadIdx.x >> 6;
@@ -122,5 +157,18 @@ int main() {
         printf("coexec f64 MFMA with %-10s [%-17s]: wall %.3f ms\n", kinds[K], modes[mode], ms);   \
     }
     CO(0) CO(1) CO(2) CO(3)
+#define CO32(K)                                                                                    \
+    for (int mode = 0; mode < 3; ++mode) {                                                         \
+        hipEvent_t e0, e1;                                                                         \
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));                                          \
+        hipLaunchKernelGGL(coexec32<K>, dim3(blocks), dim3(512), 0, 0, dout, 100, mode);           \
+        CK(hipEventRecord(e0));                                                                    \
+        hipLaunchKernelGGL(coexec32<K>, dim3(blocks), dim3(512), 0, 0, dout, 4000, mode);          \
+        CK(hipEventRecord(e1));                                                                    \
+        CK(hipEventSynchronize(e1));                                                               \
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));                                            \
+        printf("coexec f32 MFMA with %-10s [%-17s]: wall %.3f ms\n", kinds[K], modes[mode], ms);   \
+    }
+    CO32(0) CO32(1) CO32(2)
     return 0;
 }
