@@ -29,7 +29,7 @@ def _engine(net, H, nx, nu, B, kernel="auto", integrator="discret", DT=1.0, dtyp
     return eng
 
 
-@pytest.mark.parametrize("B", [1024, 1000, 37, 1])
+@pytest.mark.parametrize("B", [1024, 1000, 37, 1, 2600])
 def test_c2_fused_evaluation_full_size(B):
     """configs[1] dims: the one-launch evaluation (rows + dense Jacobian + objective, rows_coopfx_kernel) against the
     oracle and, bit for bit, against the unfused launch sequence of the same handle."""
@@ -70,7 +70,9 @@ def test_c2_unity_and_odd_horizon_take_the_right_path():
     """Unity on the fixed-shape kernel; an odd n (H odd, 3 variables per step) cannot be streamed as 16-byte vectors and
     must fall back to the two-launch path with identical results."""
     net = orc.MLP.random(3, [64, 64], 2, seed=1)
-    for H, integ in ((20, "unity"), (7, "discret"), (64, "discret")):
+    # H = 100 / 150: the objective's table no longer fits the prologue copy (its problems take the kernel's tail path from
+    # global memory) and the dense rows go through the LDS row buffer in several chunks per pass
+    for H, integ in ((20, "unity"), (7, "discret"), (64, "discret"), (100, "discret"), (150, "unity")):
         B = 130
         eng = _engine(net, H, 2, 1, B, integrator=integ)
         Zh, X0h = orc.synthetic_inputs(B, H, 2, 1, seed=9)
