@@ -43,7 +43,7 @@ struct SolverArgs {
     const void* obj;  ObjOffsets oo;                                     // Qs, Rs live in the objective block
     const void* lb; const void* ub;                                      // (n) device, dtype T, +-inf allowed
     void* mu; void* pen; void* reg; void* alpha; void* phi0; void* dir;  // (B) per problem (pen = l1 penalty)
-    int* status; int* lsdone; int* n_active;
+    int* status; int* lsdone; int* n_active; int* n_pending;   // counters the host polls: unconverged problems / problems still backtracking
     int* iters_done; int cur_it;                                         // per problem: iteration at which it converged
     // bounds, primal-dual: zl / zu (B,n) multipliers of z >= lb / z <= ub, their steps, and the barrier diagonal the LQ
     // model adds to the Hessian (zl/(z-lb) + zu/(ub-z)); the barrier gradient -mu/(z-lb) + mu/(ub-z) is folded into grad
@@ -71,6 +71,7 @@ struct SolverArgs {
 template <typename T>
 __global__ __launch_bounds__(256) void solver_barrier_kernel(SolverArgs a) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) *a.n_active = 0;      // counter of the convergence test that follows the LQ solve (a memset launch before)
     if (idx >= (size_t)a.B * a.n) return;
     const int b = (int)(idx / a.n), i = (int)(idx - (size_t)b * a.n);
     T ga = T(0), ha = T(0);
@@ -94,9 +95,8 @@ __global__ __launch_bounds__(256) void solver_barrier_kernel(SolverArgs a) {
 
 // after the LQ solve: dual steps and their fraction-to-the-boundary length (one wave per problem)
 template <typename T>
-__global__ __launch_bounds__(64) void solver_dual_kernel(SolverArgs a) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    if (b >= a.B || !a.primal_dual) return;
+__device__ __forceinline__ void solver_dual_body(const SolverArgs& a, int b, int lane) {
+    if (!a.primal_dual) return;
     const T mu = ((const T*)a.mu)[b];
     const T tau = T(0.995);
     T amax = T(1);
@@ -296,14 +296,16 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             #pragma unroll
             for (int k = 0; k < j; ++k) d -= TMP(oQuu + j * nu + k) * TMP(oQuu + j * nu + k);
             if (!(d > T(1e-12))) { pd = false; break; }   // not positive definite: restart with more damping
-            d = sqrt(d);
+            // the diagonal of L is only ever divided by: its INVERSE is kept in its place (one division per pivot instead
+            // of one per use -- seven per stage at 2/1 -- in a sweep whose time is its instruction count)
+            d = T(1) / sqrt(d);
             TMP(oQuu + j * nu + j) = d;
             #pragma unroll
             for (int i = j + 1; i < nu; ++i) {
                 T v = TMP(oQuu + i * nu + j);
                 #pragma unroll
                 for (int k = 0; k < j; ++k) v -= TMP(oQuu + i * nu + k) * TMP(oQuu + j * nu + k);
-                TMP(oQuu + i * nu + j) = v / d;
+                TMP(oQuu + i * nu + j) = v * d;
             }
         }
         if (!pd) break;
@@ -315,14 +317,14 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                 T v = (col < 0) ? TMP(oqu + i) : TMP(oQux + i * nx + col);
                 #pragma unroll
                 for (int k = 0; k < i; ++k) v -= TMP(oQuu + i * nu + k) * TMP(odu + k);
-                TMP(odu + i) = v / TMP(oQuu + i * nu + i);
+                TMP(odu + i) = v * TMP(oQuu + i * nu + i);
             }
             #pragma unroll
             for (int i = nu - 1; i >= 0; --i) {
                 T v = TMP(odu + i);
                 #pragma unroll
                 for (int k = i + 1; k < nu; ++k) v -= TMP(oQuu + k * nu + i) * TMP(odu + k);
-                v /= TMP(oQuu + i * nu + i);
+                v *= TMP(oQuu + i * nu + i);
                 TMP(odu + i) = v;
             }
             #pragma unroll
@@ -615,12 +617,12 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                             T d = tb[oQuu + j * nu + j];
                             for (int k = 0; k < j; ++k) d -= tb[oQuu + j * nu + k] * tb[oQuu + j * nu + k];
                             if (!(d > T(1e-12))) { ok = T(0); break; }
-                            d = sqrt(d);
+                            d = T(1) / sqrt(d);               // inverse diagonal, as in the thread-per-problem kernel
                             tb[oQuu + j * nu + j] = d;
                             for (int i = j + 1; i < nu; ++i) {
                                 T v = tb[oQuu + i * nu + j];
                                 for (int k = 0; k < j; ++k) v -= tb[oQuu + i * nu + k] * tb[oQuu + j * nu + k];
-                                tb[oQuu + i * nu + j] = v / d;
+                                tb[oQuu + i * nu + j] = v * d;
                             }
                         }
                         tb[oflag] = ok;
@@ -636,12 +638,12 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                         for (int i = 0; i < nu; ++i) {
                             T v = (col < 0) ? tb[oqu + i] : tb[oQux + i * nx + col];
                             for (int k = 0; k < i; ++k) v -= tb[oQuu + i * nu + k] * y[k];
-                            y[i] = v / tb[oQuu + i * nu + i];
+                            y[i] = v * tb[oQuu + i * nu + i];
                         }
                         for (int i = nu - 1; i >= 0; --i) {
                             T v = y[i];
                             for (int k = i + 1; k < nu; ++k) v -= tb[oQuu + k * nu + i] * y[k];
-                            v /= tb[oQuu + i * nu + i];
+                            v *= tb[oQuu + i * nu + i];
                             y[i] = v;
                         }
                         for (int i = 0; i < nu; ++i) {
@@ -794,9 +796,83 @@ __device__ __forceinline__ double l1_norm(const T* g, int m, int lane) {
 
 // mode 0: after the LQ solve -- convergence / barrier update, penalty update, merit at the iterate, first step length
 // mode 1: after evaluating the trial point -- Armijo test, accept (copy) or halve
+// Convergence test, barrier update and merit at the iterate (after the LQ solve), one wave per problem.  Returns, the same
+// in every lane, whether the problem takes no step this iteration (`lsd`) and the step length of its first trial (`al`).
 template <typename T>
-__global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, int mode, const T* __restrict__ f,
-                                                          const T* __restrict__ Zt, const T* __restrict__ gt,
+__device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, int lane, const T* __restrict__ f,
+                                                   const T* __restrict__ Zcur, int& lsd, T& al) {
+    T* mu = (T*)a.mu; T* nu = (T*)a.pen; T* alpha = (T*)a.alpha; T* phi0 = (T*)a.phi0; T* dir = (T*)a.dir;
+    const T* info = (const T*)a.info + (size_t)b * INFO_N;
+    const T* lb = (const T*)a.lb;
+    const T* ub = (const T*)a.ub;
+    const int H = a.H, nx = a.nx;
+    lsd = 1;
+    al = T(0);
+    if (a.status[b] >= 0) { if (lane == 0) a.lsdone[b] = 1; return; }
+    // converged for the current barrier parameter?  Sub-problems with mu above its floor are only solved to
+    // an accuracy proportional to mu (kappa = 10); the last one to the requested tolerances.
+    const T mub = mu[b];
+    const bool last_mu = !(mub > (T)a.mu_min * T(1.0001));
+    const T tg = last_mu ? (T)a.tol_g : fmax((T)a.tol_g, T(10) * mub);
+    const T tsx = last_mu ? (T)a.tol_step * (T(1) + info[INFO_ZINF]) : fmax((T)a.tol_step, T(10) * mub) * (T(1) + info[INFO_ZINF]);
+    const bool conv = info[INFO_GINF] <= tg && info[INFO_STEP] <= tsx;
+    if (conv) {
+        if (!last_mu) {
+            // superlinear decrease: mu <- max(mu_min, min(mu_factor * mu, mu^1.5))
+            if (lane == 0) mu[b] = fmax(fmin(mub * (T)a.mu_factor, mub * sqrt(mub)), (T)a.mu_min);
+            // new sub-problem: skip this step (direction was computed for the old mu).  (Lowering mu one iteration
+            // late instead, from the previous iteration's norms, so that no iteration is skipped, was measured:
+            // same median iteration count, slightly fewer problems converged within 40 / 80 / 160 iterations.)
+            if (lane == 0) { a.lsdone[b] = 1; atomicAdd(a.n_active, 1); }
+        } else {
+            if (lane == 0) { a.status[b] = 0; a.lsdone[b] = 1; a.iters_done[b] = a.cur_it + 1; }
+        }
+        return;
+    }
+    const T* z = Zcur + (size_t)b * a.n;
+    const T* g = (const T*)a.g + (size_t)b * a.m;
+    const double bar = barrier_value<T>(z, lb, ub, a.n, mub, lane);
+    const double g1 = l1_norm<T>(g, H * nx, lane);
+    // deferred backtracking: a problem whose last trial was rejected stands where it stood; this iteration
+    // recomputed the same direction and tries it at half the rejected length
+    lsd = 0;
+    al = info[INFO_LSK] > T(0) ? fmin(info[INFO_AMAX], info[INFO_LSA]) : info[INFO_AMAX];
+    if (lane == 0) {
+        const T nun = fmax(nu[b], T(1.5) * info[INFO_LAM] + T(1e-3));
+        nu[b] = nun;
+        phi0[b] = (T)((double)f[b] + bar + (double)nun * g1);
+        dir[b] = info[INFO_D0] - nun * (T)g1;
+        alpha[b] = al;
+        // a retry iteration re-solves with the damping the opening iteration had to raise, so its own restart count
+        // is zero: remember the opening one, or the accept below relaxes a term that was only just raised
+        T* infw = (T*)a.info + (size_t)b * INFO_N;
+        infw[INFO_LSR] = info[INFO_LSK] > T(0) ? fmax(infw[INFO_LSR], info[INFO_RESTARTS]) : info[INFO_RESTARTS];
+        a.lsdone[b] = 0;
+        atomicAdd(a.n_active, 1);
+    }
+}
+
+// After the LQ solve, ONE launch per iteration (three before: dual steps, merit at the iterate, first trial point): the
+// dual steps of the bounds and their step length, the convergence test / barrier update / merit value, and the first
+// trial point Zt = Z + alpha dz of the problems that take a step.  One wave per problem.
+template <typename T>
+__global__ __launch_bounds__(64) void solver_step_kernel(SolverArgs a, const T* __restrict__ f, const T* __restrict__ Zcur,
+                                                         T* __restrict__ Zt) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b == 0 && lane == 0) *a.n_pending = 0;          // counted by the trial's acceptance test (solver_merit_kernel)
+    if (b >= a.B) return;
+    solver_dual_body<T>(a, b, lane);
+    int lsd;
+    T al;
+    solver_merit0_body<T>(a, b, lane, f, Zcur, lsd, al);
+    const T* z = Zcur + (size_t)b * a.n;
+    const T* dz = (const T*)a.dz + (size_t)b * a.n;
+    for (int i = lane; i < a.n; i += 64) Zt[(size_t)b * a.n + i] = lsd ? z[i] : fma(al, dz[i], z[i]);
+}
+
+// Acceptance test of a trial point (Armijo on the l1 merit), one wave per problem
+template <typename T>
+__global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T* __restrict__ Zt, const T* __restrict__ gt,
                                                           const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls) {
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= a.B) return;
@@ -805,48 +881,6 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, int mode
     const T* lb = (const T*)a.lb;
     const T* ub = (const T*)a.ub;
     const int H = a.H, nx = a.nx;
-    if (mode == 0) {
-        if (a.status[b] >= 0) { if (lane == 0) a.lsdone[b] = 1; return; }
-        // converged for the current barrier parameter?  Sub-problems with mu above its floor are only solved to
-        // an accuracy proportional to mu (kappa = 10); the last one to the requested tolerances.
-        const bool last_mu = !(mu[b] > (T)a.mu_min * T(1.0001));
-        const T tg = last_mu ? (T)a.tol_g : fmax((T)a.tol_g, T(10) * mu[b]);
-        const T tsx = last_mu ? (T)a.tol_step * (T(1) + info[INFO_ZINF]) : fmax((T)a.tol_step, T(10) * mu[b]) * (T(1) + info[INFO_ZINF]);
-        const bool conv = info[INFO_GINF] <= tg && info[INFO_STEP] <= tsx;
-        if (conv) {
-            if (!last_mu) {
-                // superlinear decrease: mu <- max(mu_min, min(mu_factor * mu, mu^1.5))
-                if (lane == 0) mu[b] = fmax(fmin(mu[b] * (T)a.mu_factor, mu[b] * sqrt(mu[b])), (T)a.mu_min);
-                // new sub-problem: skip this step (direction was computed for the old mu).  (Lowering mu one iteration
-                // late instead, from the previous iteration's norms, so that no iteration is skipped, was measured:
-                // same median iteration count, slightly fewer problems converged within 40 / 80 / 160 iterations.)
-                if (lane == 0) { a.lsdone[b] = 1; atomicAdd(a.n_active, 1); }
-            } else {
-                if (lane == 0) { a.status[b] = 0; a.lsdone[b] = 1; a.iters_done[b] = a.cur_it + 1; }
-            }
-            return;
-        }
-        const T* z = Zcur + (size_t)b * a.n;
-        const T* g = (const T*)a.g + (size_t)b * a.m;
-        const double bar = barrier_value<T>(z, lb, ub, a.n, mu[b], lane);
-        const double g1 = l1_norm<T>(g, H * nx, lane);
-        if (lane == 0) {
-            const T nun = fmax(nu[b], T(1.5) * info[INFO_LAM] + T(1e-3));
-            nu[b] = nun;
-            phi0[b] = (T)((double)f[b] + bar + (double)nun * g1);
-            dir[b] = info[INFO_D0] - nun * (T)g1;
-            // deferred backtracking: a problem whose last trial was rejected stands where it stood; this iteration
-            // recomputed the same direction and tries it at half the rejected length
-            alpha[b] = info[INFO_LSK] > T(0) ? fmin(info[INFO_AMAX], info[INFO_LSA]) : info[INFO_AMAX];
-            // a retry iteration re-solves with the damping the opening iteration had to raise, so its own restart count
-            // is zero: remember the opening one, or the accept below relaxes a term that was only just raised
-            T* infw = (T*)a.info + (size_t)b * INFO_N;
-            infw[INFO_LSR] = info[INFO_LSK] > T(0) ? fmax(infw[INFO_LSR], info[INFO_RESTARTS]) : info[INFO_RESTARTS];
-            a.lsdone[b] = 0;
-            atomicAdd(a.n_active, 1);
-        }
-        return;
-    }
     if (a.lsdone[b]) return;
     const T* zt = Zt + (size_t)b * a.n;
     const double bar = barrier_value<T>(zt, lb, ub, a.n, mu[b], lane);
@@ -902,7 +936,7 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, int mode
             if (k >= (T)a.max_ls) { inf[INFO_LSK] = T(0); reg[b] = fmin(fmax(reg[b] * T(100), T(1e-6)), T(1e8)); }
             else { inf[INFO_LSK] = k; inf[INFO_LSA] = al * T(0.5); }
         } else {
-            if (!last_ls) atomicAdd(a.n_active, 1);   // still searching: the host polls this to stop the backtracking early
+            if (!last_ls) atomicAdd(a.n_pending, 1);  // still searching: the host polls this to stop the backtracking early
             if (last_ls) {   // no progress: damp the next LQ solve
                 a.lsdone[b] = 1;
                 reg[b] = fmin(fmax(reg[b] * T(100), T(1e-6)), T(1e8));
@@ -929,8 +963,9 @@ __global__ __launch_bounds__(256) void solver_defer_kernel(SolverArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256) void solver_trial_kernel(int B, int n, const T* __restrict__ Z, const T* __restrict__ dz,
                                                            const T* __restrict__ alpha, const int* __restrict__ lsdone,
-                                                           T* __restrict__ Zt) {
+                                                           T* __restrict__ Zt, int* __restrict__ n_pending) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *n_pending = 0;         // counter of the problems still searching after this trial
     if (i >= (size_t)B * n) return;
     const int b = (int)(i / n);
     Zt[i] = lsdone[b] ? Z[i] : fma(alpha[b], dz[i], Z[i]);
@@ -1119,7 +1154,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                 for (auto& x : al2) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
             }
             NEMPC_HIP(hipMalloc((void**)&w2.lsdone, Bn * sizeof(int)));
-            NEMPC_HIP(hipMalloc((void**)&w2.n_active, sizeof(int)));
+            NEMPC_HIP(hipMalloc((void**)&w2.n_active, 2 * sizeof(int)));   // [unconverged, still backtracking]
             NEMPC_HIP(hipMalloc((void**)&w2.perm, Bn * sizeof(int)));
             NEMPC_HIP(hipMalloc((void**)&w2.count, sizeof(int)));
             w2.cap = B;
@@ -1174,7 +1209,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     a.hblk = ws.hblk; a.lamn = ws.lamn;
     a.obj = h.d_obj; a.oo = obj_offsets(H, nx, nu);
     a.lb = ws.lb; a.ub = ws.ub; a.alpha = ws.alpha; a.phi0 = ws.phi0;
-    a.dir = ws.dir; a.lsdone = ws.lsdone; a.n_active = ws.n_active;
+    a.dir = ws.dir; a.lsdone = ws.lsdone; a.n_active = ws.n_active; a.n_pending = ws.n_active + 1;
     a.dz = ws.dz; a.Kst = ws.Kst;
     a.dzl = ws.dzl; a.dzu = ws.dzu; a.alz = ws.alz; a.bh = ws.bh;
     a.primal_dual = (has_bounds && o.barrier != 1) ? 1 : 0; a.kst = ws.kst; a.Pst = ws.Pst; a.pst = ws.pst;
@@ -1256,10 +1291,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         // LDS mode: four waves stage the working set, the first ppw lanes run the sweeps
         hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (Bact + a.ppw - 1) / a.ppw : (Bact + 63) / 64), dim3(a.use_lds ? 256 : 64),
                            lds_need, s, a);
-        if (a.primal_dual) hipLaunchKernelGGL(solver_dual_kernel<T>, dim3(Bact), dim3(64), 0, s, a);
-        NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, sizeof(int), s));
-        hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(Bact), dim3(64), 0, s, a, 0, (const T*)ws.f, (const T*)nullptr,
-                           (const T*)nullptr, (const T*)nullptr, (T*)Zc, 0);
+        hipLaunchKernelGGL(solver_step_kernel<T>, dim3(Bact), dim3(64), 0, s, a, (const T*)ws.f, (const T*)Zc, (T*)ws.Zt);
         bool polled = false;
         int nact = Bact;
         if ((it + 1) % check == 0 || it + 1 == o.max_iter) {
@@ -1281,22 +1313,23 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         // (a retry is an iteration), so max_iter budgets are larger than with the inner loop.
         const int lsm = o.linesearch == 0 ? (wave_wanted ? 1 : 2) : o.linesearch;
         for (int ls = 0; ls < o.max_linesearch; ++ls) {
-            hipLaunchKernelGGL(solver_trial_kernel<T>, dim3(gAn), dim3(256), 0, s, Bact, n, (const T*)Zc, (const T*)ws.dz,
-                               (const T*)ws.alpha, (const int*)ws.lsdone, (T*)ws.Zt);
+            // the first trial point comes from solver_step_kernel; later ones (inner-loop backtracking) from here
+            if (ls > 0)
+                hipLaunchKernelGGL(solver_trial_kernel<T>, dim3(gAn), dim3(256), 0, s, Bact, n, (const T*)Zc, (const T*)ws.dz,
+                                   (const T*)ws.alpha, (const int*)ws.lsdone, (T*)ws.Zt, a.n_pending);
             // the merit function needs the defects only: the matrix-core kernel skips its reverse sweeps (tiles = null)
             rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, Bact, ws.Zt, X0c, ws.gt, nullptr, s)
                                                 : launch_rows_valu(h, Bact, ws.Zt, X0c, ws.gt, h.d_tiles_ws, s);
             if (rc) return rc;
             if ((rc = launch_objective(h, Bact, ws.Zt, ws.ft, nullptr, s))) return rc;
-            NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, sizeof(int), s));
-            hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(Bact), dim3(64), 0, s, a, 1, (const T*)ws.f, (const T*)ws.Zt,
+            hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(Bact), dim3(64), 0, s, a, (const T*)ws.Zt,
                                (const T*)ws.gt, (const T*)ws.ft, (T*)Zc,
                                lsm == 2 ? 2 : (ls + 1 == o.max_linesearch ? 1 : 0));
             if (lsm == 2) break;          // one trial per outer iteration: nothing to poll
             // most iterations accept the first trial for every problem: one small poll saves the remaining
             // max_linesearch-1 callback evaluations
             int pending = 0;
-            NEMPC_HIP(hipMemcpyAsync(&pending, ws.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+            NEMPC_HIP(hipMemcpyAsync(&pending, a.n_pending, sizeof(int), hipMemcpyDeviceToHost, s));
             NEMPC_HIP(hipStreamSynchronize(s));
             if (pending == 0) break;
             if (lsm == 3 && ls == 0 && pending * 4 <= std::min(Bact, last_nact)) {
