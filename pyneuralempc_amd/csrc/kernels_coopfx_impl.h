@@ -760,6 +760,15 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     }
 
     FX_STAMP_PASS(pa.dbg, 3);
+    // When the objective is evaluated.  The two workgroups of a CU do not interleave: the one dispatched first (the first
+    // half of the grid) runs its passes at nearly full speed and is done ~1.5 us before the other, which fills gaps and
+    // finishes last (tools/diag_stamps.py).  So the first has slack at its END and the second at its START: the objective
+    // (0.6 us of one wave's time, LDS-resident by then either way) goes where the slack is.
+#ifdef NEMPC_EXP_OBJ_FIRST   // timing experiment only
+    const bool obj_last = false;
+#else
+    const bool obj_last = 2 * blockIdx.x < gridDim.x;
+#endif
     int parity = 0, xsel = 0;
     T* const in_base = lds + L::IN;
     fx_stage_store<T, WP, NH, TPW, NX, NU, TPW>(in_base, tid, sr);
@@ -774,7 +783,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         FX_STAMP_PASS(pa.dbg, 4);
         FX_STAMP_PRO(pa.dbg, 8);
         if constexpr (FUSE) {
-            if (t_cur == t_begin && ob_n > 0) {
+            if (t_cur == t_begin && ob_n > 0 && !obj_last) {
                 const FxArgsK ka = fx_late_args();
                 T* const o_f = static_cast<T*>(ka->f);
                 T* const o_grad = static_cast<T*>(ka->grad);
@@ -792,6 +801,14 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         parity ^= 1;
     }
     if constexpr (FUSE) {
+        if (ob_n > 0 && obj_last) {
+            const FxArgsK ka = fx_late_args();
+            T* const o_f = static_cast<T*>(ka->f);
+            T* const o_grad = static_cast<T*>(ka->grad);
+            for (int k = w; k < ob_n; k += MT)
+                objective_row<T>((int)ob_lo + k, lane, pa.H, NX, NU, pa.oo, lds + L::TOTAL, lds + L::TOTAL + p_pad + k * pa.n,
+                                 o_f, o_grad);
+        }
         // ---- problems beyond the LDS copy (long horizons, many problems per workgroup): from global memory, one
         //      problem per wave at a time (same routine, hence the same bits)
         if (want_obj && ob_lo + (unsigned)ob_n < ob_hi) {
