@@ -112,6 +112,7 @@ struct FxCtx {
     const T* __restrict__ X0;
     unsigned R, invH;
     int H, n;
+    bool rev;               // reverse sweeps wanted (tiles or dense rows asked for); false: defects [+ objective] only
     long long* dbg;         // diagnostic builds only (-DNEMPC_STAMPS, tools/diag_stamps.py): per-workgroup timeline
 };
 
@@ -332,13 +333,15 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
         fx_rowsums_store<T, NT * NX>(sv, PART + w * (TPW * NX) * 16, lane);
     }
     FX_STAMP_PASS(cx.dbg, 5);
+    T* const PJ = PART + L::PF_SZ;
+    // a defect-only evaluation (a line-search trial of the batched solver: g and f, no derivatives) ends the arithmetic here
+    if (cx.rev) {
 #pragma unroll
     for (int l = 0; l < NH; ++l)
 #pragma unroll
         for (int j = 0; j < NT; ++j) a[l][j] = T(1) - a[l][j] * a[l][j];
 
     // ---- reverse sweep, one cotangent (network output) at a time
-    T* const PJ = PART + L::PF_SZ;
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
         V4 cv[NT];
@@ -386,6 +389,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             fx_rowsums_store<T, NT * NIN>(sv, PJ + (k * MT + w) * (TPW * NIN) * 16, lane);
         }
     }
+    }   // cx.rev
     FX_STAMP_PASS(cx.dbg, 6);
     FX_STAMP_PRO(cx.dbg, 12);
     // what only the epilogue needs, fetched now: the barrier below covers the scalar loads
@@ -400,9 +404,10 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
     // ---- outputs straight from the partials (no reduction phase): the sum over the MT waves is taken here, in wave
     //      order like the generic kernel's reduction
     // tiles: the pass's NT*16 rows are contiguous in memory -> lanes run over the flat element index (coalesced).
-    // (The fused evaluation sums them where it places them into the dense rows, below.)
+    // (The fused evaluation with the dense matrix sums them where it places them into the dense rows, below.)
+    if (cx.rev && o_tiles && (!FUSE || !ka->jac))
 #pragma unroll
-    for (int it = 0; it < (FUSE ? 0 : (NT * 16 * JROW + NTHREADS - 1) / NTHREADS); ++it) {
+    for (int it = 0; it < (NT * 16 * JROW + NTHREADS - 1) / NTHREADS; ++it) {
         const int item = tid + it * NTHREADS;
         const int idx = item / JROW, kd = item - idx * JROW;     // compile-time divisors
         const int k = kd / NIN, d = kd - k * NIN;
@@ -465,7 +470,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #ifdef NEMPC_EXP_NODENSE      // timing experiment only
         const int nkind = 0;
 #else
-        const int nkind = a_box ? 2 : 1;
+        const int nkind = o_jac ? (a_box ? 2 : 1) : 0;       // fused objective without the dense matrix: nothing to assemble
 #endif
         for (int kind = 0; kind < nkind; ++kind) {
             for (int c0 = 0; c0 < drv; c0 += rpc) {
@@ -613,6 +618,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
 #else
     const bool want_obj = ((ppack >> 28) & 3u) != 0;     // f or grad asked for
 #endif
+    const bool want_rev = (ppack >> 30) & 1u;            // tiles or dense rows asked for
     pa.R = pR; pa.invH = pinvH; pa.H = pH; pa.n = pH * (NX + NU);
     pa.oo = obj_offsets(pH, NX, NU);
     pa.p_elems = FUSE ? pa.oo.total : 0;
@@ -643,7 +649,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     cx.lds = lds;
     cx.Z = static_cast<const T*>(pa.Z);
     cx.X0 = static_cast<const T*>(pa.X0);
-    cx.R = pa.R; cx.invH = pa.invH; cx.H = pa.H; cx.n = pa.n;
+    cx.R = pa.R; cx.invH = pa.invH; cx.H = pa.H; cx.n = pa.n; cx.rev = want_rev;
 
     const int t_begin = blockIdx.x * pa.tiles_per_wg + ((int)blockIdx.x < pa.tiles_rem ? (int)blockIdx.x : pa.tiles_rem);
     const int t_end = t_begin + pa.tiles_per_wg + ((int)blockIdx.x < pa.tiles_rem ? 1 : 0);

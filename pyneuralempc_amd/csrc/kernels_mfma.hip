@@ -188,8 +188,9 @@ static MfmaParams base_params(Handle& h, int B, const void* Z, const void* X0, v
 // problem; NEMPC_EUNSUPPORTED (no error message, nothing launched) tells nempc_eval to take the two-launch path.
 int launch_eval_fused(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, void* f,
                       void* grad, hipStream_t s) {
-    if (!h.mfma.blob || !jac || !h.d_obj) return NEMPC_EUNSUPPORTED;
+    if (!h.mfma.blob || !h.d_obj || (!jac && !f && !grad)) return NEMPC_EUNSUPPORTED;
     MfmaParams p = base_params(h, B, Z, X0, g, tiles);
+    p.fuse_obj = true;
     p.fuse_jac = jac; p.fuse_f = f; p.fuse_grad = grad;
     p.obj = h.d_obj;
     p.oo = obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu);

@@ -64,6 +64,7 @@ struct MfmaParams {
     int stage_stride;      // elements per record = nin + 2*nx*nin
     long long* dbg;        // diagnostic builds only (-DNEMPC_STAMPS): per-wave phase stamps of workgroup 0
     // fused evaluation (fixed-shape kernel only): dense Jacobian and objective from the same launch
+    bool fuse_obj;         // one-launch evaluation asked for (launch_eval_fused); fuse_jac may be null (no dense matrix)
     void* fuse_jac;
     void* fuse_f;
     void* fuse_grad;

@@ -551,8 +551,9 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
         const bool need_tiles = jac_dense || jac_tiles || jac_sparse || h.variant == NEMPC_KERNEL_VALU;
         void* tiles = jac_tiles ? jac_tiles : (need_tiles ? h.d_tiles_ws : nullptr);
         void* gout = g ? g : h.d_g_ws;
-        // dense contract on a compiled shape: rows, dense assembly and objective in ONE launch
-        if (jac_dense && !jac_sparse && h.variant == NEMPC_KERNEL_MFMA) {
+        // compiled shape: rows, objective and (dense contract) the dense assembly in ONE launch; without a derivative
+        // output (g with f / grad: what a line-search trial needs) the same launch runs its forward passes only
+        if (!jac_sparse && (jac_dense || f || grad) && h.variant == NEMPC_KERNEL_MFMA) {
             rc = launch_eval_fused(h, B, Z, X0, gout, jac_tiles, jac_dense, f, grad, s);
             if (rc != NEMPC_EUNSUPPORTED) return rc;
         }

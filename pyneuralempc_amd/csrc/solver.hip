@@ -1284,17 +1284,22 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         // and the per-step Lagrangian blocks with the current multipliers (all zero on the first iterate:
         // Gauss-Newton step).  The RK4 matrix-core pipeline produces defects, tiles and blocks from one row launch.
         const bool rk4_pipeline = h.variant != NEMPC_KERNEL_VALU && h.cfg.integrator == NEMPC_RK4;
+        bool fused_eval = false;
         if (rk4_pipeline) {
             rc = launch_rowhess_rk4_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s, ws.g, ws.tiles);
         } else {
-            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, Bact, Zc, X0c, ws.g, ws.tiles, s)
-                                                : launch_rows_valu(h, Bact, Zc, X0c, ws.g, ws.tiles, s);
+            // compiled shapes: defects, tiles, f and grad from one launch
+            fused_eval = h.variant == NEMPC_KERNEL_MFMA &&
+                         (rc = launch_eval_fused(h, Bact, Zc, X0c, ws.g, ws.tiles, nullptr, ws.f, ws.grad, s)) != NEMPC_EUNSUPPORTED;
+            if (!fused_eval)
+                rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, Bact, Zc, X0c, ws.g, ws.tiles, s)
+                                                    : launch_rows_valu(h, Bact, Zc, X0c, ws.g, ws.tiles, s);
             if (rc) return rc;
             rc = h.variant != NEMPC_KERNEL_VALU ? launch_rowhess_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s)
                                                 : launch_rowhess_valu(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s);
         }
         if (rc) return rc;
-        if ((rc = launch_objective(h, Bact, Zc, ws.f, ws.grad, s))) return rc;
+        if (!fused_eval && (rc = launch_objective(h, Bact, Zc, ws.f, ws.grad, s))) return rc;
         // bounds: barrier diagonal for the LQ model, barrier gradient folded into grad
         hipLaunchKernelGGL(solver_barrier_kernel<T>, dim3(gAn), dim3(256), 0, s, a);
         // LDS mode: four waves stage the working set, the first ppw lanes run the sweeps
@@ -1327,10 +1332,14 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                 hipLaunchKernelGGL(solver_trial_kernel<T>, dim3(gAn), dim3(256), 0, s, Bact, n, (const T*)Zc, (const T*)ws.dz,
                                    (const T*)ws.alpha, (const int*)ws.lsdone, (T*)ws.Zt, a.n_pending);
             // the merit function needs the defects only: the matrix-core kernel skips its reverse sweeps (tiles = null)
-            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, Bact, ws.Zt, X0c, ws.gt, nullptr, s)
-                                                : launch_rows_valu(h, Bact, ws.Zt, X0c, ws.gt, h.d_tiles_ws, s);
+            // (compiled shapes: defects and f of the trial point from one forward-only launch)
+            const bool fused_trial = h.variant == NEMPC_KERNEL_MFMA &&
+                (rc = launch_eval_fused(h, Bact, ws.Zt, X0c, ws.gt, nullptr, nullptr, ws.ft, nullptr, s)) != NEMPC_EUNSUPPORTED;
+            if (!fused_trial)
+                rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, Bact, ws.Zt, X0c, ws.gt, nullptr, s)
+                                                    : launch_rows_valu(h, Bact, ws.Zt, X0c, ws.gt, h.d_tiles_ws, s);
             if (rc) return rc;
-            if ((rc = launch_objective(h, Bact, ws.Zt, ws.ft, nullptr, s))) return rc;
+            if (!fused_trial && (rc = launch_objective(h, Bact, ws.Zt, ws.ft, nullptr, s))) return rc;
             hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(Bact), dim3(64), 0, s, a, (const T*)ws.Zt,
                                (const T*)ws.gt, (const T*)ws.ft, (T*)Zc,
                                lsm == 2 ? 2 : (ls + 1 == o.max_linesearch ? 1 : 0));

@@ -64,6 +64,15 @@ def test_c2_fused_evaluation_full_size(B):
     assert torch.equal(only["jac_dense"], fused["jac_dense"]) and torch.equal(only["g"], fused["g"])
     wt = eng.eval(Z, X0, ("f", "g", "jac_dense", "jac_tiles"))
     assert torch.equal(wt["jac_tiles"], unf["jac_tiles"]) and torch.equal(wt["f"], fused["f"])
+    # the same launch without the dense matrix: objective + compact tiles, and forward passes only (what a line-search
+    # trial of the batched solver asks for)
+    ct = {k: v.clone() for k, v in eng.eval(Z, X0, ("f", "grad", "g", "jac_tiles")).items()}
+    assert eng.last_row_kernel == "rows_coopfx_kernel"
+    for k in ("f", "grad", "g"):
+        assert torch.equal(ct[k], fused[k]), k
+    assert torch.equal(ct["jac_tiles"], unf["jac_tiles"])
+    fo = {k: v.clone() for k, v in eng.eval(Z, X0, ("f", "g")).items()}
+    assert torch.equal(fo["f"], fused["f"]) and torch.equal(fo["g"], fused["g"])
 
 
 def test_c2_unity_and_odd_horizon_take_the_right_path():
