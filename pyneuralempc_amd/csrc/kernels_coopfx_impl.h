@@ -480,9 +480,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
                 // executes one wave's operations in order, so no barrier between the two)
                 const int rpw = (nr + MT - 1) / MT;
                 const int lo = w * rpw, hi = lo + rpw < nr ? lo + rpw : nr;
-#ifndef NEMPC_EXP_NOZEROFILL   // timing experiment only
                 for (int v = lo * nvec + lane; v < hi * nvec; v += 64) RBv[v] = zero;
-#endif
                 asm volatile("" ::: "memory");
                 if (lo + lane < hi) {
                     const int lr = c0 + lo + lane;
@@ -536,18 +534,11 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
                             const int fv = f0 + u * NTHREADS;
-#ifdef NEMPC_EXP_NOSTREAMREAD   // timing experiment only
-                            v[u] = zero;
-#else
                             if (fv < nvc) v[u] = RBv[fv];
-#endif
                         }
 #pragma unroll
                         for (int u = 0; u < UB; ++u) {
                             const int fv = f0 + u * NTHREADS;
-#ifdef NEMPC_EXP_NODENSE_STORE   // timing experiment only
-                            if (v[u][0] == T(123.456))
-#endif
                             if (fv < nvc) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(v[u]), "s"(base));
                         }
                     }
@@ -577,9 +568,6 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
                             for (int u = 0; u < UB; ++u) {
                                 const int fv = f0 + u * NTHREADS;
-#ifdef NEMPC_EXP_NODENSE_STORE   // timing experiment only
-                                if (v[u][0] == T(123.456))
-#endif
                                 if (fv < nv) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(v[u]), "s"(base));
                             }
                         }
@@ -770,11 +758,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     // half of the grid) runs its passes at nearly full speed and is done ~1.5 us before the other, which fills gaps and
     // finishes last (tools/diag_stamps.py).  So the first has slack at its END and the second at its START: the objective
     // (0.6 us of one wave's time, LDS-resident by then either way) goes where the slack is.
-#ifdef NEMPC_EXP_OBJ_FIRST   // timing experiment only
-    const bool obj_last = false;
-#else
     const bool obj_last = 2 * blockIdx.x < gridDim.x;
-#endif
     int parity = 0, xsel = 0;
     T* const in_base = lds + L::IN;
     fx_stage_store<T, WP, NH, TPW, NX, NU, TPW>(in_base, tid, sr);
