@@ -362,7 +362,7 @@ class CallbackEngine:
                                               ptr["hblocks"], self._stream()))
         return res
 
-    def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=200, max_linesearch=6, check_every=2,
+    def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=200, max_linesearch=6, check_every=4,
               tol_constraint=None, tol_step=None, mu_init=1e-1, mu_min=None, mu_factor=0.2, reg=None, lq_kernel="auto",
               compact=True, return_iterations=False, barrier="primal-dual", linesearch="auto"):
         """Batched on-device solve (Gauss-Newton SQP, see csrc/solver.hip).  X0 (B,nx) device tensor; Z_init (B,n)
