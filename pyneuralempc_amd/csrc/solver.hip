@@ -379,6 +379,11 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     ((T*)a.reg)[b] = reg;
     T* lamn = a.use_lds ? blk + Llam : (T*)a.lamn + (size_t)b * a.m;
     // forward sweep
+    // The norms, the directional derivative and the fraction-to-the-boundary length of the step are NOT part of the
+    // recursion: in LDS mode a wave per problem computes them from the staged arrays after the sweeps (below), with its
+    // 64 lanes over the elements -- in the sweep they were 60 % of the forward pass's instructions (three divisions per
+    // stage among them), issued one per ~10 cycles by a lone lane (kernel 37 -> 22 us clean)
+    const bool norms_here = !a.use_lds;
     T lam_inf = T(0), step_inf = T(0), amax = T(1), D0 = T(0), g1 = T(0), ginf = T(0), zinf = T(0);
     const T tau = T(0.995);
     #pragma unroll
@@ -408,39 +413,87 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             T lam = pst[(size_t)t * nx + i];
             #pragma unroll
             for (int k = 0; k < nx; ++k) lam = fma(Pst[(size_t)t * nx * nx + i * nx + k], TMP(odxn + k), lam);
-            lam_inf = fmax(lam_inf, fabs(lam));
             lamn[t * nx + i] = lam;
-            const T d = TMP(odxn + i), zz = z[t * nx + i], lo = lb[t * nx + i], hi = ub[t * nx + i];
+            const T d = TMP(odxn + i);
             dz[t * nx + i] = d;
-            step_inf = fmax(step_inf, fabs(d));
-            zinf = fmax(zinf, fabs(zz));
-            T ga = T(0), ha = T(0);
-            D0 = fma(gr[t * nx + i] + ga, d, D0);
-            if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
-            if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
-            const T gv = fabs(gc[t * nx + i]);
-            g1 += gv;
-            ginf = fmax(ginf, gv);
             TMP(odx + i) = d;
+            if (norms_here) {
+                const T zz = z[t * nx + i], lo = lb[t * nx + i], hi = ub[t * nx + i];
+                lam_inf = fmax(lam_inf, fabs(lam));
+                step_inf = fmax(step_inf, fabs(d));
+                zinf = fmax(zinf, fabs(zz));
+                D0 = fma(gr[t * nx + i], d, D0);
+                if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
+                if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
+                const T gv = fabs(gc[t * nx + i]);
+                g1 += gv;
+                ginf = fmax(ginf, gv);
+            }
         }
         #pragma unroll
         for (int i = 0; i < nu; ++i) {
-            const T d = TMP(odu + i), zz = z[uo + t * nu + i], lo = lb[uo + t * nu + i], hi = ub[uo + t * nu + i];
+            const T d = TMP(odu + i);
             dz[uo + t * nu + i] = d;
-            step_inf = fmax(step_inf, fabs(d));
-            zinf = fmax(zinf, fabs(zz));
-            T ga = T(0), ha = T(0);
-            D0 = fma(gr[uo + t * nu + i] + ga, d, D0);
-            if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
-            if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
+            if (norms_here) {
+                const T zz = z[uo + t * nu + i], lo = lb[uo + t * nu + i], hi = ub[uo + t * nu + i];
+                step_inf = fmax(step_inf, fabs(d));
+                zinf = fmax(zinf, fabs(zz));
+                D0 = fma(gr[uo + t * nu + i], d, D0);
+                if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
+                if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
+            }
         }
     }
-    info[INFO_LAM] = lam_inf; info[INFO_STEP] = step_inf; info[INFO_AMAX] = amax; info[INFO_G1] = g1;
-    info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf; info[INFO_RESTARTS] = (T)restarts;
+    if (norms_here) {
+        info[INFO_LAM] = lam_inf; info[INFO_STEP] = step_inf; info[INFO_AMAX] = amax; info[INFO_G1] = g1;
+        info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf;
+    }
+    info[INFO_RESTARTS] = (T)restarts;
 #undef TMP
     }
     if (a.use_lds) {
         __syncthreads();
+        {
+            // norms of the steps just computed: wave w takes problems w, w + #waves, ...
+            const int wv = lane >> 6, ln = lane & 63, nwv = nthr >> 6;
+            const T* lb = (const T*)a.lb;
+            const T* ub = (const T*)a.ub;
+            const T tau = T(0.995);
+            for (int pp = wv; pp < np; pp += nwv) {
+                const int bp = b0 + pp;
+                if (a.status[bp] >= 0) continue;
+                const T* blk = lds + (size_t)pp * a.lds_stride;
+                T lam_inf = T(0), step_inf = T(0), amax = T(1), D0 = T(0), g1 = T(0), ginf = T(0), zinf = T(0);
+                for (int i = ln; i < n; i += 64) {
+                    const T d = blk[Ldz + i], zz = blk[Lz + i], lo = lb[i], hi = ub[i];
+                    step_inf = fmax(step_inf, fabs(d));
+                    zinf = fmax(zinf, fabs(zz));
+                    D0 = fma(blk[Lgr + i], d, D0);
+                    if (d < T(0) && lo > -std::numeric_limits<T>::max()) amax = fmin(amax, tau * (zz - lo) / (-d));
+                    if (d > T(0) && hi < std::numeric_limits<T>::max()) amax = fmin(amax, tau * (hi - zz) / d);
+                }
+                for (int i = ln; i < H * nx; i += 64) {
+                    lam_inf = fmax(lam_inf, fabs(blk[Llam + i]));
+                    const T gv = fabs(blk[Lgc + i]);
+                    g1 += gv;
+                    ginf = fmax(ginf, gv);
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    lam_inf = fmax(lam_inf, __shfl_down(lam_inf, o, 64));
+                    step_inf = fmax(step_inf, __shfl_down(step_inf, o, 64));
+                    amax = fmin(amax, __shfl_down(amax, o, 64));
+                    D0 += __shfl_down(D0, o, 64);
+                    g1 += __shfl_down(g1, o, 64);
+                    ginf = fmax(ginf, __shfl_down(ginf, o, 64));
+                    zinf = fmax(zinf, __shfl_down(zinf, o, 64));
+                }
+                if (ln == 0) {
+                    T* info = (T*)a.info + (size_t)bp * INFO_N;
+                    info[INFO_LAM] = lam_inf; info[INFO_STEP] = step_inf; info[INFO_AMAX] = amax; info[INFO_G1] = g1;
+                    info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf;
+                }
+            }
+        }
         auto stage_out = [&](T* __restrict__ dst, int per, int dst_stride, int loff) {
             const int tot = np * per;
             T* base = dst + (size_t)b0 * dst_stride;
