@@ -47,6 +47,7 @@ struct SolverArgs {
     const void* obj;  ObjOffsets oo;                                     // Qs, Rs live in the objective block
     const void* lb; const void* ub;                                      // (n) device, dtype T, +-inf allowed
     void* mu; void* pen; void* reg; void* alpha; void* phi0; void* dir;  // (B) per problem (pen = l1 penalty)
+    int lq_attempts;      // Riccati sweeps a problem may try per iteration before it sits the iteration out
     int* status; int* lsdone; int* n_active; int* n_pending;   // counters the host polls: unconverged problems / problems still backtracking
     int* iters_done; int cur_it;                                         // per problem: iteration at which it converged
     // bounds, primal-dual: zl / zu (B,n) multipliers of z >= lb / z <= ub, their steps, and the barrier diagonal the LQ
@@ -225,7 +226,8 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     const int uo = H * nx;
 
     int restarts = 0;
-    for (int attempt = 0; attempt < 14; ++attempt) {
+    bool solved = false;
+    for (int attempt = 0; attempt < a.lq_attempts; ++attempt) {
     bool pd = true;
     // terminal value function: V_{H-1}(dx) = 1/2 dx' Hx dx + gx' dx
     #pragma unroll
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             }
         }
     }
-    if (pd) break;
+    if (pd) { solved = true; break; }
     // decade steps from a floor of 1e-3: whenever a sweep of this problem family fails, the damping that lets it through
     // is 0.1 .. 100 (NEMPC_SOLVER_STATS), and the whole launch waits for the one problem in hundreds that climbs there --
     // nine attempts from the relaxed value with a floor of 1e-6, six from 1e-3 (the kernel runs 37 us clean, 10 us more
@@ -378,6 +380,17 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     }
     ((T*)a.reg)[b] = reg;
     T* lamn = a.use_lds ? blk + Llam : (T*)a.lamn + (size_t)b * a.m;
+    if (!solved) {
+        // Out of attempts for this iteration.  The launch waits for its slowest problem, and the one problem in hundreds
+        // that needs five or six decades of damping made every other one wait ~50 us for it: it now keeps the damping it
+        // has climbed to, takes NO step this iteration (zero step, multipliers unchanged, marked by a negative restart
+        // count) and goes on climbing in the next one.
+        for (int i = 0; i < n; ++i) dz[i] = T(0);
+        const T* lcur = (const T*)a.lam + (size_t)b * a.m;
+        for (int i = 0; i < H * nx; ++i) lamn[i] = lcur[i];
+        info[INFO_STEP] = std::numeric_limits<T>::max();
+        info[INFO_RESTARTS] = (T)(-restarts);
+    } else {
     // forward sweep
     // The norms, the directional derivative and the fraction-to-the-boundary length of the step are NOT part of the
     // recursion: in LDS mode a wave per problem computes them from the staged arrays after the sweeps (below), with its
@@ -449,6 +462,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf;
     }
     info[INFO_RESTARTS] = (T)restarts;
+    }   // solved
 #undef TMP
     }
     if (a.use_lds) {
@@ -489,7 +503,9 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                 }
                 if (ln == 0) {
                     T* info = (T*)a.info + (size_t)bp * INFO_N;
-                    info[INFO_LAM] = lam_inf; info[INFO_STEP] = step_inf; info[INFO_AMAX] = amax; info[INFO_G1] = g1;
+                    const bool sat_out = info[INFO_RESTARTS] < T(0);       // no step this iteration: keep the sentinel
+                    info[INFO_LAM] = lam_inf; info[INFO_STEP] = sat_out ? std::numeric_limits<T>::max() : step_inf;
+                    info[INFO_AMAX] = amax; info[INFO_G1] = g1;
                     info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf;
                 }
             }
@@ -592,7 +608,8 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
             T* lamn = blk + Llam;
             const int uo = H * nx;
             int restarts = 0;
-            for (int attempt = 0; attempt < 14; ++attempt) {
+            bool solved = false;
+            for (int attempt = 0; attempt < a.lq_attempts; ++attempt) {
                 bool pd = true;
                 // terminal value function
                 for (int e = lane; e < nx * nx + nx; e += 64) {
@@ -746,11 +763,22 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                         wsync();
                     }
                 }
-                if (pd) break;
+                if (pd) { solved = true; break; }
                 reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));     // as in the thread-per-problem kernel
                 ++restarts;
             }
             if (lane == 0) ((T*)a.reg)[b] = reg;
+            if (!solved) {
+                // out of attempts: no step this iteration (see the thread-per-problem kernel)
+                for (int i = lane; i < n; i += 64) dz[i] = T(0);
+                const T* lcur = (const T*)a.lam + (size_t)b * a.m;
+                for (int i = lane; i < H * nx; i += 64) lamn[i] = lcur[i];
+                if (lane == 0) {
+                    T* info = (T*)a.info + (size_t)b * INFO_N;
+                    info[INFO_STEP] = std::numeric_limits<T>::max();
+                    info[INFO_RESTARTS] = (T)(-restarts);
+                }
+            } else {
             // forward sweep; the norms are accumulated per lane and reduced at the end
             T lam_inf = T(0), step_inf = T(0), amax = T(1), D0 = T(0), g1 = T(0), ginf = T(0), zinf = T(0);
             const T tau = T(0.995);
@@ -820,6 +848,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                 info[INFO_LAM] = lam_inf; info[INFO_STEP] = step_inf; info[INFO_AMAX] = amax; info[INFO_G1] = g1;
                 info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf; info[INFO_RESTARTS] = (T)restarts;
             }
+            }   // solved
         }
     }
     __syncthreads();
@@ -871,6 +900,10 @@ __device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, i
     lsd = 1;
     al = T(0);
     if (a.status[b] >= 0) { if (lane == 0) a.lsdone[b] = 1; return; }
+    if (info[INFO_RESTARTS] < T(0)) {    // the Riccati sweep ran out of attempts: no step this iteration, still unconverged
+        if (lane == 0) { a.lsdone[b] = 1; atomicAdd(a.n_active, 1); }
+        return;
+    }
     // converged for the current barrier parameter?  Sub-problems with mu above its floor are only solved to
     // an accuracy proportional to mu (kappa = 10); the last one to the requested tolerances.
     const T mub = mu[b];
@@ -1305,6 +1338,8 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         a.armijo_slack = std::max(1e-12, slack_eps * (double)std::numeric_limits<T>::epsilon());
     }
     a.max_ls = o.max_linesearch;
+    static const int lq_attempts = [] { const char* e = getenv("NEMPC_LQ_ATTEMPTS"); return e ? atoi(e) : 3; }();
+    a.lq_attempts = lq_attempts > 0 ? lq_attempts : 3;
     auto lqk = (nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1> : ((nx == 6 && nu == 3) ? solver_lq_kernel<T, 6, 3> : solver_lq_kernel<T, 0, 0>);
     // wave-per-problem sweep when the working set is staged in LDS and a stage has enough entries to spread over a
     // wave: 6/3 stages 6.5 k vs 5.0 k MPC solves/s at C3; 2/1 stages are 4 entries wide and stay on the
@@ -1417,7 +1452,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             NEMPC_HIP(hipMemcpy(rg.data(), a.reg, rg.size() * sizeof(T), hipMemcpyDeviceToHost));
             double sum = 0, mx = 0, rmx = 0; int nz = 0;
             for (int i = 0; i < Bact; ++i) {
-                const double r = (double)inf[(size_t)i * INFO_N + INFO_RESTARTS];
+                const double r = std::fabs((double)inf[(size_t)i * INFO_N + INFO_RESTARTS]);
                 sum += r; if (r > mx) mx = r; if (r > 0) ++nz; if ((double)rg[i] > rmx) rmx = (double)rg[i];
             }
             fprintf(stderr, "[solver it %3d] active slots %4d  restarts: max %.0f mean %.2f  problems restarting %d  max damping %.1e\n",
