@@ -164,3 +164,38 @@ def test_c3_full_size_rk4_fp32():
             close(out[kern]["grad"][sl], grad, "grad")
             close(out[kern]["g"][sl], g, "g")
             close(out[kern]["jac_dense"][sl], J, "jac")
+
+
+@pytest.mark.parametrize("box", [None, (-1.5, 1.5)])
+def test_fused_launch_sweep_of_small_shapes(box):
+    """The one-launch evaluation over horizons and batch sizes around its internal boundaries (one vector per row side,
+    rows that straddle problems inside a tile, a single tile, several passes per workgroup), with and without box rows,
+    every output subset that takes the fused kernel -- against the oracle."""
+    net = orc.MLP.random(3, [64, 64], 2, seed=3)
+    for H in (2, 4, 6, 10, 16, 32):
+        for B in (1, 3, 17, 700):
+            eng = _engine(net, H, 2, 1, B, box=box)
+            eng.set_objective(Q=[[1.0, 0.1], [0.1, 0.5]], R=[[0.2]], cx=0.03, cu=-0.1)
+            Zh, X0h = orc.synthetic_inputs(B, H, 2, 1, seed=H + B)
+            Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+            prob = orc.Problem(net, H, 2, 1, Q=np.array([[1.0, 0.1], [0.1, 0.5]]), R=np.array([[0.2]]),
+                               cx=np.full((H, 2), 0.03), cu=np.full((H, 1), -0.1), box=box)
+            f, grad, g, J = prob.eval_batch(Zh, X0h)
+            res = {k: v.cpu().numpy() for k, v in eng.eval(Z, X0, DEFAULT).items()}
+            assert eng.last_row_kernel == "rows_coopfx_kernel", (H, B)
+            np.testing.assert_allclose(res["f"], f, **F64)
+            np.testing.assert_allclose(res["grad"], grad, **F64)
+            np.testing.assert_allclose(res["g"], g, **F64)
+            np.testing.assert_allclose(res["jac_dense"], J, **F64)
+            sub = {k: v.cpu().numpy() for k, v in eng.eval(Z, X0, ("f", "g")).items()}
+            np.testing.assert_allclose(sub["f"], f, **F64)
+            np.testing.assert_allclose(sub["g"], g, **F64)
+            ct = {k: v.cpu().numpy() for k, v in eng.eval(Z, X0, ("grad", "g", "jac_tiles")).items()}
+            np.testing.assert_allclose(ct["grad"], grad, **F64)
+            # the compact tiles against the dense matrix they are the blocks of
+            T = ct["jac_tiles"]                       # (B, H, nx, nx + nu)
+            for t in range(H):
+                np.testing.assert_allclose(T[:, t, :, 2:], J[:, 2 * t:2 * t + 2, 2 * H + t:2 * H + t + 1], **F64)
+                if t >= 1:
+                    np.testing.assert_allclose(T[:, t, :, :2], J[:, 2 * t:2 * t + 2, 2 * (t - 1):2 * t], **F64)
+            del eng
