@@ -14,8 +14,11 @@ for cfg in c3 c5; do
   python3 bench.py --config $cfg --hessian --steps 100 --warmup 10 --no-cpu > $O/${TAG}_bench_${cfg}.json 2> $O/${TAG}_bench_${cfg}.err
   echo "bench $cfg done"
 done
+# enough timed steps that the clock-priming launches of bench.py (40 ms per timing loop, in synchronised batches of 16)
+# are a small share of the per-kernel averages
 for cfg in c2 c3 c5; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_${cfg}_trace -- python3 bench.py --config $cfg --only-eval --steps 200 --warmup 20 > $O/${TAG}_${cfg}_trace.json 2> $O/${TAG}_${cfg}_trace.err
+  case $cfg in c2) ST=4000;; c5) ST=1500;; *) ST=200;; esac
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_${cfg}_trace -- python3 bench.py --config $cfg --only-eval --steps $ST --warmup 20 > $O/${TAG}_${cfg}_trace.json 2> $O/${TAG}_${cfg}_trace.err
   echo "trace $cfg done"
 done
 for cfg in c2 c5; do
