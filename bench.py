@@ -336,17 +336,20 @@ class Rank:
                     eng.lib.nempc_comm_destroy(eng._handle)
                     eng._comm = None
             if comm_ok:
-                # the exchange runs on its own HIP stream: it only reads Z (the solver's output of the previous MPC step),
-                # nothing on the callback path waits for it, so the next evaluations proceed under it (xGMI latency is
-                # hidden instead of being added to every MPC step); the timed region ends with both streams drained
-                comm_stream = (torch.cuda.current_stream(self.dev) if os.environ.get("NEMPC_BENCH_GATHER_STREAM") == "main"
-                               else torch.cuda.Stream(self.dev))          # A/B knob: same stream = serialised exchange
+                # the exchange is issued on the launch stream, between two evaluations.  On a stream of its own it could run
+                # under the next evaluations (it only reads Z) -- measured, that costs MORE: the cross-stream event pair, a
+                # second stream to drain and a co-running kernel that takes a workgroup slot from an evaluation sized to fill
+                # the chip exactly (one rank, 20-step region: 22.6 us per step against 19.5 serialised; 19.3 against 18.6 over
+                # 200 steps).  NEMPC_BENCH_GATHER_STREAM=own keeps the other arrangement for A/B.
+                comm_stream = (torch.cuda.Stream(self.dev) if os.environ.get("NEMPC_BENCH_GATHER_STREAM") == "own"
+                               else torch.cuda.current_stream(self.dev))
                 torch.cuda.synchronize(self.dev)
                 launch_gather, gathered_buf = eng.bind_allgather_u0(Z, stream=comm_stream)
                 main_stream = torch.cuda.current_stream(self.dev)
 
                 def gather():
-                    comm_stream.wait_stream(main_stream)
+                    if comm_stream != main_stream:
+                        comm_stream.wait_stream(main_stream)
                     launch_gather()
                     return gathered_buf
             else:
@@ -548,7 +551,7 @@ class Rank:
         if self.dist is not None:
             out["allgather_u0"] = {
                 "per_mpc_step_every_n_evals": max(1, args.evals_per_mpc_step), "issued_in_timed_loop": res["n_gather"],
-                "path": "nempc_allgather_u0 (libnempc.so -> RCCL ncclAllGather), on its own HIP stream" if eng.comm is not None
+                "path": "nempc_allgather_u0 (libnempc.so -> RCCL ncclAllGather), on the launch stream" if eng.comm is not None
                         else "torch.distributed/" + self.backend,
                 "latency_us": self.gather_latency_us(res), "rows_gathered": self.world * B}
             if getattr(self, "comm_error", None):
