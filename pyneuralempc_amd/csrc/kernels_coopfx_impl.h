@@ -472,15 +472,39 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #else
         const int nkind = o_jac ? (a_box ? 2 : 1) : 0;       // fused objective without the dense matrix: nothing to assemble
 #endif
+        // each wave owns a fixed run of the buffer's row slots: it zeroes them once per pass, and from the second chunk on
+        // only takes back the few entries the previous chunk's row left in a slot before one lane per row drops the new
+        // row's non-zeros in (the LDS executes one wave's operations in order, so no barrier in between; zero-filling the
+        // buffer per chunk was a fifth of the dense phase's instructions at 150 columns with box rows)
+        const int rpw = (rpc + MT - 1) / MT;
+        const int lo = w * rpw;
+        int pc0 = -1, pnr = 0, pkind = 0;
         for (int kind = 0; kind < nkind; ++kind) {
             for (int c0 = 0; c0 < drv; c0 += rpc) {
                 const int nr = drv - c0 < rpc ? drv - c0 : rpc;
                 if (kind + c0 > 0) lds_barrier();      // the previous chunk has left the buffer
-                // each wave owns a run of rows: zero them, then one lane per row drops the non-zeros in (the LDS
-                // executes one wave's operations in order, so no barrier between the two)
-                const int rpw = (nr + MT - 1) / MT;
-                const int lo = w * rpw, hi = lo + rpw < nr ? lo + rpw : nr;
-                for (int v = lo * nvec + lane; v < hi * nvec; v += 64) RBv[v] = zero;
+                const int hi = lo + rpw < nr ? lo + rpw : nr;
+                if (pc0 < 0) {
+                    const int zhi = lo + rpw < rpc ? lo + rpw : rpc;
+                    for (int v = lo * nvec + lane; v < zhi * nvec; v += 64) RBv[v] = zero;
+                } else if (lo + lane < (lo + rpw < pnr ? lo + rpw : pnr)) {
+                    const int lr = pc0 + lo + lane;
+                    const int lrow = lr / NX, i = lr - lrow * NX;
+                    const unsigned r = r0 + (unsigned)lrow;
+                    const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
+                    const int t = (int)(r - b * (unsigned)cx.H);
+                    T* row = RB + (lo + lane) * n;
+                    row[t * NX + i] = T(0);
+                    if (pkind == 0) {
+                        if (t >= 1) {
+#pragma unroll
+                            for (int jj = 0; jj < NX; ++jj) row[(t - 1) * NX + jj] = T(0);
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < NU; ++jj) row[cx.H * NX + t * NU + jj] = T(0);
+                    }
+                }
+                pc0 = c0; pnr = nr; pkind = kind;
                 asm volatile("" ::: "memory");
                 if (lo + lane < hi) {
                     const int lr = c0 + lo + lane;
