@@ -9,13 +9,20 @@ src, tag = sys.argv[1], sys.argv[2]          # e.g. gpurun_out/prof2  r01_c2_b10
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(REPO, "profiles")
 os.makedirs(out, exist_ok=True)
-for f in glob.glob(f"{src}_trace/*/*_kernel_stats.csv"):
+def newest(pattern):
+    """gpurun merges every call's output into the local gpurun_out/, so a directory can hold several runs: take the
+    latest file only"""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
+for f in newest(f"{src}_trace/*/*_kernel_stats.csv"):
     shutil.copy(f, os.path.join(out, f"{tag}_kernel_stats.csv"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for kind in ("fetch", "write", "mfma"):
     if not glob.glob(f"{src}_{kind}"):
         continue
-    for f in glob.glob(f"{src}_{kind}/*/*_counter_collection.csv"):
+    for f in newest(f"{src}_{kind}/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("nempc::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
@@ -35,7 +42,7 @@ print(json.dumps(res, indent=1)[:1500])
 # pipe-utilisation / instruction-mix passes (<src>_pipe1, <src>_pipe2) -> <tag>_pipe.json
 pagg = collections.defaultdict(lambda: collections.defaultdict(list))
 for kind in ("pipe1", "pipe2"):
-    for f in glob.glob(f"{src}_{kind}/*/*_counter_collection.csv"):
+    for f in newest(f"{src}_{kind}/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("nempc::", "")
             if name.startswith(("rows_", "post_", "rowhess", "assemble")):
