@@ -1362,6 +1362,8 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     }
 
     int poll_pending = -1;        // slot of the convergence-counter copy that is in flight, -1: none
+    int poll_it[2] = {0, 0};      // iteration at which each slot's copy was issued
+    const bool lagged_polls = !wave_wanted;     // small stages: iterations are chains of latency-bound launches
     int Bact = B;                 // slots [0, Bact) may still be unconverged; compaction keeps them in front
     int last_nact = B;            // unconverged problems at the last convergence poll
     int it = 0, rc;
@@ -1409,17 +1411,31 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         bool polled = false;
         int nact = Bact;
         if ((it + 1) % check == 0 || it + 1 == o.max_iter) {
-            if (poll_pending >= 0) {
-                NEMPC_HIP(hipEventSynchronize(ws.pev[poll_pending]));
-                nact = ws.hpoll[poll_pending];
+            if (!lagged_polls) {
+                // matrix-core-bound stages: an iteration is milliseconds, a drained stream costs nothing next to four
+                // iterations at a stale batch size
+                NEMPC_HIP(hipMemcpyAsync(ws.hpoll, ws.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+                NEMPC_HIP(hipStreamSynchronize(s));
+                nact = ws.hpoll[0];
                 polled = true;
                 last_nact = nact;
                 if (nact == 0) { ++it; break; }
+            } else {
+                if (poll_pending >= 0) {
+                    NEMPC_HIP(hipEventSynchronize(ws.pev[poll_pending]));
+                    nact = ws.hpoll[poll_pending];
+                    polled = true;
+                    last_nact = nact;
+                    // every problem had converged when that copy was issued: report THAT iteration count (the iterations
+                    // launched since found nothing to do)
+                    if (nact == 0) { it = poll_it[poll_pending] + 1; break; }
+                }
+                const int slot = poll_pending < 0 ? 0 : poll_pending ^ 1;
+                NEMPC_HIP(hipMemcpyAsync(ws.hpoll + slot, ws.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+                NEMPC_HIP(hipEventRecord(ws.pev[slot], s));
+                poll_pending = slot;
+                poll_it[slot] = it;
             }
-            const int slot = poll_pending < 0 ? 0 : poll_pending ^ 1;
-            NEMPC_HIP(hipMemcpyAsync(ws.hpoll + slot, ws.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
-            NEMPC_HIP(hipEventRecord(ws.pev[slot], s));
-            poll_pending = slot;
         }
         // Backtracking in a lock-step batch.  An inner loop makes every problem pay for the one that needs six halvings
         // (measured: 5.7 trial evaluations per iteration at B=1024, C2 dims, 70 % of the solve time).  DEFERRED (2): one
@@ -1525,12 +1541,19 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                 NEMPC_HIP(hipMemcpyAsync(ws.orig[nxt] + Bact, ws.orig[cur] + Bact, rest * sizeof(int), hipMemcpyDeviceToDevice, s));
                 NEMPC_HIP(hipMemcpyAsync(ws.itc[nxt] + Bact, ws.itc[cur] + Bact, rest * sizeof(int), hipMemcpyDeviceToDevice, s));
             }
-            int cnt = 0;
-            NEMPC_HIP(hipMemcpyAsync(&cnt, ws.count, sizeof(int), hipMemcpyDeviceToHost, s));
-            NEMPC_HIP(hipStreamSynchronize(s));
+            // the unconverged problems now sit in front.  Their exact number is on the device; the host shrinks the
+            // launches to the counter it has just read -- taken a period earlier, so an upper bound (problems only ever
+            // leave the active set): a few finished problems ride along in the active prefix and are skipped by every
+            // kernel, and no stream synchronisation is needed to learn the exact count
             cur = nxt;
             point_at(cur);
-            Bact = cnt > 0 ? cnt : 1;
+            if (lagged_polls) {
+                Bact = nact > 0 ? (nact < Bact ? nact : Bact) : 1;
+            } else {
+                NEMPC_HIP(hipMemcpyAsync(ws.hpoll, ws.count, sizeof(int), hipMemcpyDeviceToHost, s));
+                NEMPC_HIP(hipStreamSynchronize(s));
+                Bact = ws.hpoll[0] > 0 ? ws.hpoll[0] : 1;
+            }
             a.ppw = pick_ppw(Bact);
         }
     }
