@@ -318,7 +318,8 @@ class Rank:
         step, outs = eng.bind(Z, X0, want)           # one ctypes call per step: keeps the host out of the way
         gather = None
         gather_every = max(1, args.evals_per_mpc_step)
-        if self.dist is not None:
+        # a communicator only where a gather follows: the headline loop and the sharded configs[3] solve
+        if self.dist is not None and (headline or name == "c4"):
             comm_ok = False
             if self.backend == "nccl":
                 # the library's own RCCL call (nempc_comm_init / nempc_allgather_u0).  Should the communicator not come
