@@ -16,9 +16,10 @@ RCCL call (nempc_allgather_u0), once every `--evals-per-mpc-step` evaluations (a
 many callback evaluations; default 17, the median number of iterations the batched solver needs on this workload --
 `batched_solver.iters_to_converge_p50` -- each of which evaluates the callbacks at least once).
 
-Timing: the device is first brought to its sustained clock by `--prime-ms` (default 40) of the same step, untimed and
-reported (`clock_priming`); then W warm-up steps; then a barrier and a device synchronize, exactly K steps, a device
-synchronize that stops the rank's clock, a barrier, and the MAX over ranks.
+Timing: W warm-up steps; a barrier and a device synchronize, exactly K steps, a device synchronize that stops the rank's
+clock, a barrier, and the MAX over ranks.  That region is run twice: once as the process finds the GPU
+(`value_from_cold_gpu`), and once after the device has been brought to its sustained clock by `--prime-ms` (default 40)
+of the same step, untimed and reported (`clock_priming`) -- `value`.  `--prime-ms 0` runs the cold region only.
 
 With `--gpus N > 1` and no WORLD_SIZE in the environment this process only launches the N ranks (before anything
 touches the GPU) and relays rank 0's JSON line; a failed rank makes the exit code non-zero.
@@ -363,29 +364,36 @@ class Rank:
             # sustained clock: the same launch takes 19.9 us in a cold 20-step region and 17.3 us after ~30 ms of load
             # (tools/host_launch_cost.py).  The metric is a sustained rate, so the device is brought to it first --
             # `--prime-ms` of this same step, untimed, reported in the line -- then the W warm-up steps, then the K timed ones.
-            res["primed_ms"] = self.prime(step) if args.prime_ms > 0 else 0.0
-            for i in range(warmup):
-                step()
-                if gather and (i + 1) % gather_every == 0:
+            def timed_region():
+                """W warm-up steps, then exactly `steps` steps between two (barrier + device synchronize) brackets; the
+                closing synchronize drains the stream and stops this rank's clock, the closing barrier and the MAX over
+                ranks follow -- the slowest rank sets the time, the latency of the barrier collective itself (0.1-0.3 ms,
+                as long as a short timed region) does not"""
+                for i in range(warmup):
+                    step()
+                    if gather and (i + 1) % gather_every == 0:
+                        gather()
+                if gather:
                     gather()
-            if gather:
-                gather()
-            # exactly `steps` steps between two (barrier + device synchronize) brackets; the closing synchronize drains both
-            # streams and stops this rank's clock, the closing barrier and the MAX over ranks follow -- the slowest rank sets
-            # the time, the latency of the barrier collective itself (0.1-0.3 ms, as long as a short timed region) does not
-            self.barrier()
-            torch.cuda.synchronize(self.dev)
-            t0 = time.perf_counter()
-            n_gather = 0
-            for i in range(steps):
-                step()
-                if gather and (i + 1) % gather_every == 0:
-                    gathered = gather()
-                    n_gather += 1
-            torch.cuda.synchronize(self.dev)
-            wall = time.perf_counter() - t0
-            self.barrier()
-            wall = self.max_over_ranks(wall)
+                self.barrier()
+                torch.cuda.synchronize(self.dev)
+                t0 = time.perf_counter()
+                ng, last = 0, None
+                for i in range(steps):
+                    step()
+                    if gather and (i + 1) % gather_every == 0:
+                        last = gather()
+                        ng += 1
+                torch.cuda.synchronize(self.dev)
+                w_ = time.perf_counter() - t0
+                self.barrier()
+                return self.max_over_ranks(w_), ng, last
+
+            # the same region twice: as the process finds the GPU (cold, reported next to the headline), then -- the metric
+            # is a sustained rate -- after the priming run
+            res["wall_cold"] = timed_region()[0] if args.prime_ms > 0 else None
+            res["primed_ms"] = self.prime(step) if args.prime_ms > 0 else 0.0
+            wall, n_gather, gathered = timed_region()
             res["wall"] = wall
             res["n_gather"] = n_gather
             if gather and n_gather:
@@ -545,6 +553,7 @@ class Rank:
             "roofline_" + secondary["bound"] + ("_whole_eval" if secondary["bound"] == "hbm" else "_row_kernel"): secondary,
             "eval_us": {"timed_loop": wall / args.steps * 1e6, "event_loop": res["t_all"] * 1e6,
                         "p10_median_p90": res["step_pcts"]},
+            "value_from_cold_gpu": (self.world * B * args.steps / res["wall_cold"]) if res.get("wall_cold") else None,
             "clock_priming": {"ms": res.get("primed_ms", 0.0),
                               "note": "untimed run of the same step before the W warm-up steps: an idle GPU starts below its "
                                       "sustained clock (--prime-ms 0 measures from cold)"},
