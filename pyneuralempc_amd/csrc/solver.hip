@@ -127,6 +127,29 @@ __device__ __forceinline__ void solver_dual_body(const SolverArgs& a, int b, int
     if (lane == 0) ((T*)a.alz)[b] = amax;
 }
 
+// The barrier terms of variable i of problem b at the iterate -- what solver_barrier_kernel writes, for the LQ kernels
+// that stage their working set in LDS and fold it in while staging (one launch less per iteration): ga joins the
+// gradient, ha is the diagonal of the LQ model
+template <typename T>
+__device__ __forceinline__ void solver_barrier_terms(const SolverArgs& a, int b, int i, T& ga, T& ha) {
+    ga = T(0); ha = T(0);
+    const T mu = ((const T*)a.mu)[b];
+    if (mu > T(0) && a.status[b] < 0) {
+        const size_t idx = (size_t)b * a.n + i;
+        const T z = ((const T*)a.Z)[idx], lo = ((const T*)a.lb)[i], hi = ((const T*)a.ub)[i];
+        if (lo > -std::numeric_limits<T>::max()) {
+            const T d = z - lo;
+            ga -= mu / d;
+            ha += a.primal_dual ? ((const T*)a.zl)[idx] / d : mu / (d * d);
+        }
+        if (hi < std::numeric_limits<T>::max()) {
+            const T d = hi - z;
+            ga += mu / d;
+            ha += a.primal_dual ? ((const T*)a.zu)[idx] / d : mu / (d * d);
+        }
+    }
+}
+
 // One thread per problem.  The sweep is a long chain of tiny dependent matrix products: straight from global
 // memory every operand costs a ~600-cycle round trip (measured 720 us per call at B=1024, 2/1, H=20).  So a
 // workgroup first copies the whole working set of its `ppw` problems (iterate, gradient, defects, tiles,
@@ -164,12 +187,22 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         }
     };
     if (a.use_lds) {
+        if (blockIdx.x == 0 && lane == 0) *a.n_active = 0;   // counter of the convergence test that follows this kernel
         stage_in((const T*)a.Z, n, n, Lz);
-        stage_in((const T*)a.grad, n, n, Lgr);
+        // gradient + barrier gradient, barrier diagonal: computed while staging (no solver_barrier_kernel launch)
+        for (int i = lane; i < np * n; i += nthr) {
+            const int pp = i / n, e = i - pp * n;
+            T ga, ha;
+            solver_barrier_terms<T>(a, b0 + pp, e, ga, ha);
+            T* blkp = lds + (size_t)pp * a.lds_stride;
+            T gv = ((const T*)a.grad)[(size_t)(b0 + pp) * n + e];
+            gv += ga;
+            blkp[Lgr + e] = gv;
+            blkp[Lbh + e] = ha;
+        }
         stage_in((const T*)a.g, H * nx, a.m, Lgc);
         stage_in((const T*)a.tiles, H * nx * nin, H * nx * nin, Ltl);
         stage_in((const T*)a.hblk, H * nin * nin, H * nin * nin, LW);
-        stage_in((const T*)a.bh, n, n, Lbh);
         __syncthreads();
     }
     T* dzg = mine ? (T*)a.dz + (size_t)b * n : nullptr;
@@ -548,12 +581,21 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
             lds[(size_t)pp * a.lds_stride + loff + e] = base[(size_t)pp * src_stride + e];
         }
     };
+    if (blockIdx.x == 0 && tid == 0) *a.n_active = 0;       // counter of the convergence test that follows this kernel
     stage_in((const T*)a.Z, n, n, Lz);
-    stage_in((const T*)a.grad, n, n, Lgr);
+    for (int i = tid; i < np * n; i += 256) {               // gradient + barrier gradient, barrier diagonal
+        const int pp = i / n, e = i - pp * n;
+        T ga, ha;
+        solver_barrier_terms<T>(a, b0 + pp, e, ga, ha);
+        T* blkp = lds + (size_t)pp * a.lds_stride;
+        T gv = ((const T*)a.grad)[(size_t)(b0 + pp) * n + e];
+        gv += ga;
+        blkp[Lgr + e] = gv;
+        blkp[Lbh + e] = ha;
+    }
     stage_in((const T*)a.g, H * nx, a.m, Lgc);
     stage_in((const T*)a.tiles, H * nx * nin, H * nx * nin, Ltl);
     stage_in((const T*)a.hblk, H * nin * nin, H * nin * nin, LW);
-    stage_in((const T*)a.bh, n, n, Lbh);
     __syncthreads();
 
     const int b = b0 + wv;
@@ -1399,7 +1441,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         if (rc) return rc;
         if (!fused_eval && (rc = launch_objective(h, Bact, Zc, ws.f, ws.grad, s))) return rc;
         // bounds: barrier diagonal for the LQ model, barrier gradient folded into grad
-        hipLaunchKernelGGL(solver_barrier_kernel<T>, dim3(gAn), dim3(256), 0, s, a);
+        if (!a.use_lds) hipLaunchKernelGGL(solver_barrier_kernel<T>, dim3(gAn), dim3(256), 0, s, a);
         // LDS mode: four waves stage the working set, the first ppw lanes run the sweeps
         hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (Bact + a.ppw - 1) / a.ppw : (Bact + 63) / 64), dim3(a.use_lds ? 256 : 64),
                            lds_need, s, a);
