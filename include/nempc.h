@@ -214,7 +214,8 @@ typedef struct nempc_solver_opts {
                                 every problem pay for the one that needs six halvings (measured: 5.7 trial evaluations per
                                 iteration at B=1024, 70 % of the solve time; at configs[2] dims a trial is 5 % of an iteration and
                                 the inner loop converges more problems per second).  1: inner backtracking loop (round 1). */
-    int32_t reserved;        /* 0 */
+    int32_t lq_attempts;     /* Riccati sweeps a problem may try per iteration (each restart damps ten times harder) before it
+                                keeps its damping and sits the iteration out; 0 = default (3) */
 } nempc_solver_opts;
 
 int nempc_solve(nempc_handle h, int32_t B, const void* X0, void* Z, const double* lb, const double* ub,

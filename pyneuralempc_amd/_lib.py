@@ -41,7 +41,7 @@ class NempcSolverOpts(ctypes.Structure):
                 ("lq_kernel", ctypes.c_int32), ("tol_constraint", ctypes.c_double), ("tol_step", ctypes.c_double),
                 ("mu_init", ctypes.c_double), ("mu_min", ctypes.c_double), ("mu_factor", ctypes.c_double),
                 ("reg", ctypes.c_double), ("compact", ctypes.c_int32), ("barrier", ctypes.c_int32),
-                ("iters_out", ctypes.c_void_p), ("linesearch", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("iters_out", ctypes.c_void_p), ("linesearch", ctypes.c_int32), ("lq_attempts", ctypes.c_int32)]
 
 
 _lib = None

@@ -1387,8 +1387,8 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         a.armijo_slack = std::max(1e-12, slack_eps * (double)std::numeric_limits<T>::epsilon());
     }
     a.max_ls = o.max_linesearch;
-    static const int lq_attempts = [] { const char* e = getenv("NEMPC_LQ_ATTEMPTS"); return e ? atoi(e) : 3; }();
-    a.lq_attempts = lq_attempts > 0 ? lq_attempts : 3;
+    static const int lq_attempts_env = [] { const char* e = getenv("NEMPC_LQ_ATTEMPTS"); return e ? atoi(e) : 0; }();   // A/B knob
+    a.lq_attempts = o.lq_attempts > 0 ? o.lq_attempts : (lq_attempts_env > 0 ? lq_attempts_env : 3);
     auto lqk = (nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1> : ((nx == 6 && nu == 3) ? solver_lq_kernel<T, 6, 3> : solver_lq_kernel<T, 0, 0>);
     // wave-per-problem sweep when the working set is staged in LDS and a stage has enough entries to spread over a
     // wave: 6/3 stages 6.5 k vs 5.0 k MPC solves/s at C3; 2/1 stages are 4 entries wide and stay on the

@@ -364,7 +364,7 @@ class CallbackEngine:
 
     def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=200, max_linesearch=6, check_every=4,
               tol_constraint=None, tol_step=None, mu_init=1e-1, mu_min=None, mu_factor=0.2, reg=None, lq_kernel="auto",
-              compact=True, return_iterations=False, barrier="primal-dual", linesearch="auto"):
+              compact=True, return_iterations=False, barrier="primal-dual", linesearch="auto", lq_attempts=0):
         """Batched on-device solve (Gauss-Newton SQP, see csrc/solver.hip).  X0 (B,nx) device tensor; Z_init (B,n)
         or None for the reference's cold start [x0 tiled H ; zeros] (optimizer/ipopt.py:149); lb/ub (n) host
         vectors as DomainConstraint produces them; tolerances default by dtype (fp64 1e-8, fp32 1e-4); lq_kernel picks the Riccati sweep ("auto" | "thread" per problem | "wave"
@@ -372,7 +372,8 @@ class CallbackEngine:
         shorter launches); linesearch "loop" backtracks inside an iteration (every problem waits for the slowest search),
         "deferred" tries one step length per iteration and lets a rejected problem retry at half the length in the next one
         (about half the time per iteration at the 2/1 shape, more iterations for hard problems), "auto" defers for small
-        stages and loops for matrix-core-bound ones.  Returns (Z (B,n), status (B,) int32 [0 ok / 1 fail], iters) [+ per-problem convergence
+        stages and loops for matrix-core-bound ones; lq_attempts bounds the Riccati sweeps a problem may try per iteration
+        (0: the library's default of 3).  Returns (Z (B,n), status (B,) int32 [0 ok / 1 fail], iters) [+ per-problem convergence
         iteration (B,) int32 with return_iterations=True]."""
         B = int(X0.shape[0])
         self._check_in(X0, (B, self.nx), "X0")
@@ -405,7 +406,7 @@ class CallbackEngine:
                                     mu_factor=mu_factor, reg=reg, compact=1 if compact else 0,
                                     barrier={"primal-dual": 0, "primal": 1}[barrier],
                                     iters_out=None if its_dev is None else its_dev.data_ptr(),
-                                    linesearch={"auto": 0, "loop": 1, "deferred": 2}[linesearch], reserved=0)
+                                    linesearch={"auto": 0, "loop": 1, "deferred": 2}[linesearch], lq_attempts=int(lq_attempts))
         status = torch.empty(B, dtype=torch.int32, device=self.device)
         iters = ctypes.c_int32(0)
         with torch.cuda.device(self.device):
