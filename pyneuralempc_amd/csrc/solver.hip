@@ -11,13 +11,21 @@
 //   couple only (x_{t-1}, u_t), so every QP is still an LQ problem in the linearised dynamics
 //   dx_t = A_t dx_{t-1} + B_t du_t + g_t, solved exactly by one backward Riccati sweep and one forward sweep per
 //   problem (block-tridiagonal KKT, O(H (nx+nu)^3)).  Indefinite control Hessians Quu are handled the DDP way:
-//   the sweep restarts with a larger Levenberg term.  Multipliers = Riccati costates of the previous step;
-// * variable bounds (DomainConstraint, constraints.py:3-33) enter as a log barrier whose diagonal terms keep the
-//   LQ structure; mu is decreased per problem once its barrier sub-problem has converged;
+//   the sweep restarts with a larger Levenberg term (decade steps from 1e-3, at most lq_attempts sweeps per
+//   iteration: a problem still indefinite then keeps its damping and sits the iteration out, so that the launch does
+//   not wait for it).  Multipliers = Riccati costates of the previous step;
+// * variable bounds (DomainConstraint, constraints.py:3-33): primal-dual interior point -- the multipliers of the
+//   bounds are iterates with their own step length; their diagonal terms keep the LQ structure (the primal log
+//   barrier of round 1 stays as an option); mu is decreased per problem once its sub-problem has converged;
 // * globalisation: l1 merit f_mu + nu |g|_1 with nu tracking the Riccati costates, backtracking from the
-//   fraction-to-the-boundary step.
-// Every problem carries its own mu, nu, step length and status; the batch advances in lock step and finished
-// problems idle.  All arithmetic is in kernels here; the callbacks are the handle's own row/objective kernels.
+//   fraction-to-the-boundary step -- one trial per iteration for small stages (a rejected problem stands still and
+//   retries the same direction at half the length next iteration), an inner loop for matrix-core-bound ones.
+// Every problem carries its own mu, nu, step length, damping and status; the batch advances in lock step, the
+// unconverged problems are compacted to the front as it converges.  All arithmetic is in kernels here; the callbacks
+// are the handle's own row/objective kernels (one fused launch per iterate and one forward-only launch per trial on the
+// compiled shapes).  Per iteration and small stage: fused evaluation, Hessian blocks, Riccati (+ barrier terms while
+// staging, + step norms by a wave per problem), step kernel (dual steps, convergence test / merit, first trial point),
+// trial evaluation, acceptance test -- six launches; the host reads the convergence counter one period late.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
