@@ -56,6 +56,8 @@ struct SolverArgs {
     const void* lb; const void* ub;                                      // (n) device, dtype T, +-inf allowed
     void* mu; void* pen; void* reg; void* alpha; void* phi0; void* dir;  // (B) per problem (pen = l1 penalty)
     int lq_attempts;      // Riccati sweeps a problem may try per iteration before it sits the iteration out
+    int fuse_step;        // thread-per-problem Riccati kernel in LDS mode: it also does solver_step_kernel's work
+    const void* f_it; void* Zt_it;   // ... with the iterate's objective values (B) and the trial-point buffer (B,n)
     int* status; int* lsdone; int* n_active; int* n_pending;   // counters the host polls: unconverged problems / problems still backtracking
     int* iters_done; int cur_it;                                         // per problem: iteration at which it converged
     // bounds, primal-dual: zl / zu (B,n) multipliers of z >= lb / z <= ub, their steps, and the barrier diagonal the LQ
@@ -108,7 +110,9 @@ __global__ __launch_bounds__(256) void solver_barrier_kernel(SolverArgs a) {
 
 // after the LQ solve: dual steps and their fraction-to-the-boundary length (one wave per problem)
 template <typename T>
-__device__ __forceinline__ void solver_dual_body(const SolverArgs& a, int b, int lane) {
+__device__ __forceinline__ void solver_dual_body(const SolverArgs& a, int b, int lane, const T* __restrict__ zp,
+                                                 const T* __restrict__ dzp) {
+    // zp / dzp: the problem's iterate and step (global memory, or the Riccati kernel's LDS copies)
     if (!a.primal_dual) return;
     const T mu = ((const T*)a.mu)[b];
     const T tau = T(0.995);
@@ -116,7 +120,7 @@ __device__ __forceinline__ void solver_dual_body(const SolverArgs& a, int b, int
     if (mu > T(0) && a.status[b] < 0)
         for (int i = lane; i < a.n; i += 64) {
             const size_t idx = (size_t)b * a.n + i;
-            const T z = ((const T*)a.Z)[idx], d = ((const T*)a.dz)[idx], lo = ((const T*)a.lb)[i], hi = ((const T*)a.ub)[i];
+            const T z = zp[i], d = dzp[i], lo = ((const T*)a.lb)[i], hi = ((const T*)a.ub)[i];
             T sl = T(0), su = T(0);
             if (lo > -std::numeric_limits<T>::max()) {
                 const T dl = z - lo, zl = ((const T*)a.zl)[idx];
@@ -158,6 +162,15 @@ __device__ __forceinline__ void solver_barrier_terms(const SolverArgs& a, int b,
     }
 }
 
+template <typename T>
+struct StepInfo {   // what the Riccati kernel leaves in the info row (read from there, or handed over in registers)
+    T ginf, step, zinf, lam, d0, amax, lsk, lsa, restarts;
+};
+template <typename T>
+__device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, int lane, const T* __restrict__ f,
+                                                   const T* __restrict__ zp, const T* __restrict__ gp, const StepInfo<T>& si,
+                                                   int& lsd, T& al);
+
 // One thread per problem.  The sweep is a long chain of tiny dependent matrix products: straight from global
 // memory every operand costs a ~600-cycle round trip (measured 720 us per call at B=1024, 2/1, H=20).  So a
 // workgroup first copies the whole working set of its `ppw` problems (iterate, gradient, defects, tiles,
@@ -195,7 +208,11 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         }
     };
     if (a.use_lds) {
-        if (blockIdx.x == 0 && lane == 0) *a.n_active = 0;   // counter of the convergence test that follows this kernel
+        // counters of the convergence test (zeroed here unless the test runs inside this kernel: then the previous
+        // iteration's acceptance kernel did it) and of the trial's acceptance test
+        if (blockIdx.x == 0 && lane == 0) {
+            if (a.fuse_step) *a.n_pending = 0; else *a.n_active = 0;
+        }
         stage_in((const T*)a.Z, n, n, Lz);
         // gradient + barrier gradient, barrier diagonal: computed while staging (no solver_barrier_kernel launch)
         for (int i = lane; i < np * n; i += nthr) {
@@ -431,6 +448,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         for (int i = 0; i < H * nx; ++i) lamn[i] = lcur[i];
         info[INFO_STEP] = std::numeric_limits<T>::max();
         info[INFO_RESTARTS] = (T)(-restarts);
+        if (a.use_lds) blk[Lbh] = (T)(-restarts);          // (the barrier diagonal is no longer needed: slot for the post-pass)
     } else {
     // forward sweep
     // The norms, the directional derivative and the fraction-to-the-boundary length of the step are NOT part of the
@@ -503,6 +521,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf;
     }
     info[INFO_RESTARTS] = (T)restarts;
+    if (a.use_lds) blk[Lbh] = (T)restarts;
     }   // solved
 #undef TMP
     }
@@ -516,8 +535,15 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             const T tau = T(0.995);
             for (int pp = wv; pp < np; pp += nwv) {
                 const int bp = b0 + pp;
-                if (a.status[bp] >= 0) continue;
                 const T* blk = lds + (size_t)pp * a.lds_stride;
+                if (a.status[bp] >= 0) {
+                    if (a.fuse_step) {      // finished problem: no step, its trial point is the iterate
+                        if (ln == 0) a.lsdone[bp] = 1;
+                        T* zt = (T*)a.Zt_it + (size_t)bp * n;
+                        for (int i = ln; i < n; i += 64) zt[i] = blk[Lz + i];
+                    }
+                    continue;
+                }
                 T lam_inf = T(0), step_inf = T(0), amax = T(1), D0 = T(0), g1 = T(0), ginf = T(0), zinf = T(0);
                 for (int i = ln; i < n; i += 64) {
                     const T d = blk[Ldz + i], zz = blk[Lz + i], lo = lb[i], hi = ub[i];
@@ -542,12 +568,29 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                     ginf = fmax(ginf, __shfl_down(ginf, o, 64));
                     zinf = fmax(zinf, __shfl_down(zinf, o, 64));
                 }
+                const T rst = blk[Lbh];                    // restart count left by the sweeping lane (negative: sat out)
+                const bool sat_out = rst < T(0);           // no step this iteration: keep the sentinel
                 if (ln == 0) {
                     T* info = (T*)a.info + (size_t)bp * INFO_N;
-                    const bool sat_out = info[INFO_RESTARTS] < T(0);       // no step this iteration: keep the sentinel
                     info[INFO_LAM] = lam_inf; info[INFO_STEP] = sat_out ? std::numeric_limits<T>::max() : step_inf;
                     info[INFO_AMAX] = amax; info[INFO_G1] = g1;
                     info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf;
+                }
+                if (a.fuse_step) {
+                    // what solver_step_kernel does, from the LDS copies and the norms still in registers: dual steps of the
+                    // bounds, convergence test / barrier update / merit at the iterate, first trial point
+                    const T* infg = (const T*)a.info + (size_t)bp * INFO_N;
+                    StepInfo<T> si;
+                    si.ginf = __shfl(ginf, 0, 64); si.zinf = __shfl(zinf, 0, 64); si.lam = __shfl(lam_inf, 0, 64);
+                    si.d0 = __shfl(D0, 0, 64); si.amax = __shfl(amax, 0, 64);
+                    si.step = sat_out ? std::numeric_limits<T>::max() : __shfl(step_inf, 0, 64);
+                    si.lsk = infg[INFO_LSK]; si.lsa = infg[INFO_LSA]; si.restarts = rst;
+                    solver_dual_body<T>(a, bp, ln, blk + Lz, blk + Ldz);
+                    int lsd;
+                    T al;
+                    solver_merit0_body<T>(a, bp, ln, (const T*)a.f_it, blk + Lz, blk + Lgc, si, lsd, al);
+                    T* zt = (T*)a.Zt_it + (size_t)bp * n;
+                    for (int i = ln; i < n; i += 64) zt[i] = lsd ? blk[Lz + i] : fma(al, blk[Ldz + i], blk[Lz + i]);
                 }
             }
         }
@@ -940,17 +983,23 @@ __device__ __forceinline__ double l1_norm(const T* g, int m, int lane) {
 // Convergence test, barrier update and merit at the iterate (after the LQ solve), one wave per problem.  Returns, the same
 // in every lane, whether the problem takes no step this iteration (`lsd`) and the step length of its first trial (`al`).
 template <typename T>
+__device__ __forceinline__ StepInfo<T> step_info_from(const T* info) {
+    return StepInfo<T>{info[INFO_GINF], info[INFO_STEP], info[INFO_ZINF], info[INFO_LAM], info[INFO_D0], info[INFO_AMAX],
+                       info[INFO_LSK], info[INFO_LSA], info[INFO_RESTARTS]};
+}
+// zp, gp: the problem's iterate and defects (global memory, or the Riccati kernel's LDS copies)
+template <typename T>
 __device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, int lane, const T* __restrict__ f,
-                                                   const T* __restrict__ Zcur, int& lsd, T& al) {
+                                                   const T* __restrict__ zp, const T* __restrict__ gp, const StepInfo<T>& si,
+                                                   int& lsd, T& al) {
     T* mu = (T*)a.mu; T* nu = (T*)a.pen; T* alpha = (T*)a.alpha; T* phi0 = (T*)a.phi0; T* dir = (T*)a.dir;
-    const T* info = (const T*)a.info + (size_t)b * INFO_N;
     const T* lb = (const T*)a.lb;
     const T* ub = (const T*)a.ub;
     const int H = a.H, nx = a.nx;
     lsd = 1;
     al = T(0);
     if (a.status[b] >= 0) { if (lane == 0) a.lsdone[b] = 1; return; }
-    if (info[INFO_RESTARTS] < T(0)) {    // the Riccati sweep ran out of attempts: no step this iteration, still unconverged
+    if (si.restarts < T(0)) {    // the Riccati sweep ran out of attempts: no step this iteration, still unconverged
         if (lane == 0) { a.lsdone[b] = 1; atomicAdd(a.n_active, 1); }
         return;
     }
@@ -959,8 +1008,8 @@ __device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, i
     const T mub = mu[b];
     const bool last_mu = !(mub > (T)a.mu_min * T(1.0001));
     const T tg = last_mu ? (T)a.tol_g : fmax((T)a.tol_g, T(10) * mub);
-    const T tsx = last_mu ? (T)a.tol_step * (T(1) + info[INFO_ZINF]) : fmax((T)a.tol_step, T(10) * mub) * (T(1) + info[INFO_ZINF]);
-    const bool conv = info[INFO_GINF] <= tg && info[INFO_STEP] <= tsx;
+    const T tsx = last_mu ? (T)a.tol_step * (T(1) + si.zinf) : fmax((T)a.tol_step, T(10) * mub) * (T(1) + si.zinf);
+    const bool conv = si.ginf <= tg && si.step <= tsx;
     if (conv) {
         if (!last_mu) {
             // superlinear decrease: mu <- max(mu_min, min(mu_factor * mu, mu^1.5))
@@ -974,24 +1023,22 @@ __device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, i
         }
         return;
     }
-    const T* z = Zcur + (size_t)b * a.n;
-    const T* g = (const T*)a.g + (size_t)b * a.m;
-    const double bar = barrier_value<T>(z, lb, ub, a.n, mub, lane);
-    const double g1 = l1_norm<T>(g, H * nx, lane);
+    const double bar = barrier_value<T>(zp, lb, ub, a.n, mub, lane);
+    const double g1 = l1_norm<T>(gp, H * nx, lane);
     // deferred backtracking: a problem whose last trial was rejected stands where it stood; this iteration
     // recomputed the same direction and tries it at half the rejected length
     lsd = 0;
-    al = info[INFO_LSK] > T(0) ? fmin(info[INFO_AMAX], info[INFO_LSA]) : info[INFO_AMAX];
+    al = si.lsk > T(0) ? fmin(si.amax, si.lsa) : si.amax;
     if (lane == 0) {
-        const T nun = fmax(nu[b], T(1.5) * info[INFO_LAM] + T(1e-3));
+        const T nun = fmax(nu[b], T(1.5) * si.lam + T(1e-3));
         nu[b] = nun;
         phi0[b] = (T)((double)f[b] + bar + (double)nun * g1);
-        dir[b] = info[INFO_D0] - nun * (T)g1;
+        dir[b] = si.d0 - nun * (T)g1;
         alpha[b] = al;
         // a retry iteration re-solves with the damping the opening iteration had to raise, so its own restart count
         // is zero: remember the opening one, or the accept below relaxes a term that was only just raised
         T* infw = (T*)a.info + (size_t)b * INFO_N;
-        infw[INFO_LSR] = info[INFO_LSK] > T(0) ? fmax(infw[INFO_LSR], info[INFO_RESTARTS]) : info[INFO_RESTARTS];
+        infw[INFO_LSR] = si.lsk > T(0) ? fmax(infw[INFO_LSR], si.restarts) : si.restarts;
         a.lsdone[b] = 0;
         atomicAdd(a.n_active, 1);
     }
@@ -1006,12 +1053,13 @@ __global__ __launch_bounds__(64) void solver_step_kernel(SolverArgs a, const T* 
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b == 0 && lane == 0) *a.n_pending = 0;          // counted by the trial's acceptance test (solver_merit_kernel)
     if (b >= a.B) return;
-    solver_dual_body<T>(a, b, lane);
-    int lsd;
-    T al;
-    solver_merit0_body<T>(a, b, lane, f, Zcur, lsd, al);
     const T* z = Zcur + (size_t)b * a.n;
     const T* dz = (const T*)a.dz + (size_t)b * a.n;
+    solver_dual_body<T>(a, b, lane, z, dz);
+    int lsd;
+    T al;
+    const StepInfo<T> si = step_info_from<T>((const T*)a.info + (size_t)b * INFO_N);
+    solver_merit0_body<T>(a, b, lane, f, z, (const T*)a.g + (size_t)b * a.m, si, lsd, al);
     for (int i = lane; i < a.n; i += 64) Zt[(size_t)b * a.n + i] = lsd ? z[i] : fma(al, dz[i], z[i]);
 }
 
@@ -1020,6 +1068,9 @@ template <typename T>
 __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T* __restrict__ Zt, const T* __restrict__ gt,
                                                           const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls) {
     const int b = blockIdx.x, lane = threadIdx.x;
+    // the convergence counter of the NEXT iteration, when its test runs inside the Riccati kernel (the host's copy of this
+    // iteration's count was issued before this launch)
+    if (b == 0 && lane == 0 && a.fuse_step) *a.n_active = 0;
     if (b >= a.B) return;
     T* mu = (T*)a.mu; T* nu = (T*)a.pen; T* reg = (T*)a.reg; T* alpha = (T*)a.alpha; T* phi0 = (T*)a.phi0; T* dir = (T*)a.dir;
     const T* info = (const T*)a.info + (size_t)b * INFO_N;
@@ -1402,6 +1453,10 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     // wave: 6/3 stages 6.5 k vs 5.0 k MPC solves/s at C3; 2/1 stages are 4 entries wide and stay on the
     // thread-per-problem kernel (22.0 vs 23.1 ms per 40 iterations at C2).  nempc_solver_opts.lq_kernel forces one.
     const bool lq_wave = a.use_lds && wave_wanted;
+    static const int no_fuse_step = [] { const char* e = getenv("NEMPC_SOLVER_NO_FUSE_STEP"); return e ? atoi(e) : 0; }();
+    a.fuse_step = a.use_lds && !lq_wave && !no_fuse_step;
+    a.f_it = ws.f; a.Zt_it = ws.Zt;
+    if (a.fuse_step) NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, 2 * sizeof(int), s));
     if (lq_wave)
         lqk = (nx == 2 && nu == 1) ? solver_lqw_kernel<T, 2, 1>
                                    : ((nx == 6 && nu == 3) ? solver_lqw_kernel<T, 6, 3> : solver_lqw_kernel<T, 0, 0>);
@@ -1453,7 +1508,8 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         // LDS mode: four waves stage the working set, the first ppw lanes run the sweeps
         hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (Bact + a.ppw - 1) / a.ppw : (Bact + 63) / 64), dim3(a.use_lds ? 256 : 64),
                            lds_need, s, a);
-        hipLaunchKernelGGL(solver_step_kernel<T>, dim3(Bact), dim3(64), 0, s, a, (const T*)ws.f, (const T*)Zc, (T*)ws.Zt);
+        if (!a.fuse_step)
+            hipLaunchKernelGGL(solver_step_kernel<T>, dim3(Bact), dim3(64), 0, s, a, (const T*)ws.f, (const T*)Zc, (T*)ws.Zt);
         // Convergence poll, one period late: the counter of THIS iteration is copied to a pinned slot behind an event and the
         // host goes on issuing the next iterations; what it reads here is the copy issued a period ago, long complete.  A
         // blocking poll drains the stream every time (10 polls of ~25 us in a 5.5 ms solve); the price of the lag is up to
