@@ -70,6 +70,8 @@ struct SolverArgs {
     int use_lds;                                                         // 1: per-problem working set staged in LDS
     int ppw;                                                             // problems per workgroup (LDS mode)
     int lds_stride;                                                      // elements per problem in LDS (odd)
+    int spec, att_elems;   // thread-per-problem sweep: damping levels tried side by side (lanes per problem), elements of
+                           // one attempt's region (gains, value function, temporaries) in the problem's LDS block
     double tol_g, tol_step, mu_min, mu_factor;
     double armijo_slack;                                                 // relative slack of the Armijo test (see merit kernel)
     int max_ls;                                                          // halvings before the next LQ solve is damped
@@ -187,12 +189,15 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     constexpr bool FIX = NX > 0;
     const int H = a.H, nx = FIX ? NX : a.nx, nu = FIX ? NU : a.nu, nin = nx + nu, n = a.n;
     const int ppw = a.use_lds ? a.ppw : 64;
-    const int b = blockIdx.x * ppw + lane;
-    const bool mine = lane < ppw && b < a.B;
-    // element offsets of the per-problem LDS block
-    const int Lz = 0, Lgr = Lz + n, Lgc = Lgr + n, Ltl = Lgc + H * nx, LW = Ltl + H * nx * nin, LK = LW + H * nin * nin,
-              Lk = LK + H * nu * nx, LP = Lk + H * nu, Lp = LP + H * nx * nx, Llam = Lp + H * nx, Ldz = Llam + H * nx,
-              Lbh = Ldz + n, Ltmp = Lbh + n;
+    const int spec = a.use_lds ? a.spec : 1;
+    const int aj0 = lane < ppw * spec ? lane / ppw : 0;      // which of the side-by-side damping levels this lane sweeps
+    const int pl = lane < ppw * spec ? lane - aj0 * ppw : lane;   // its problem's slot in the workgroup
+    // element offsets of the per-problem LDS block: the arrays every attempt reads, the results, then one region per attempt
+    const int Lz = 0, Lgr = Lz + n, Lgc = Lgr + n, Ltl = Lgc + H * nx, LW = Ltl + H * nx * nin, Llam = LW + H * nin * nin,
+              Ldz = Llam + H * nx, Lbh = Ldz + n, Latt = Lbh + n + aj0 * a.att_elems, LK = Latt, Lk = LK + H * nu * nx,
+              LP = Lk + H * nu, Lp = LP + H * nx * nx, Ltmp = Lp + H * nx;
+    const int b = blockIdx.x * ppw + pl;
+    const bool mine = lane < ppw * spec && b < a.B;
     // cooperative staging: one flat, unrolled loop per array over all the workgroup's problems (they are contiguous in
     // global memory), all four waves loading -- many independent loads in flight instead of one dependent round
     // trip per (problem, array)
@@ -233,16 +238,18 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     T* dzg = mine ? (T*)a.dz + (size_t)b * n : nullptr;
     if (mine && a.status[b] >= 0) {
         // finished problem: zero step (written through the copy-out below in LDS mode)
-        T* dzp = a.use_lds ? lds + (size_t)lane * a.lds_stride + Ldz : dzg;
-        for (int i = 0; i < n; ++i) dzp[i] = T(0);
-        if (a.use_lds) {
-            T* lp = lds + (size_t)lane * a.lds_stride + Llam;
-            const T* lcur = (const T*)a.lam + (size_t)b * a.m;
-            for (int i = 0; i < H * nx; ++i) lp[i] = lcur[i];
+        if (aj0 == 0) {
+            T* dzp = a.use_lds ? lds + (size_t)pl * a.lds_stride + Ldz : dzg;
+            for (int i = 0; i < n; ++i) dzp[i] = T(0);
+            if (a.use_lds) {
+                T* lp = lds + (size_t)pl * a.lds_stride + Llam;
+                const T* lcur = (const T*)a.lam + (size_t)b * a.m;
+                for (int i = 0; i < H * nx; ++i) lp[i] = lcur[i];
+            }
         }
     } else if (mine) {
     T* info = (T*)a.info + (size_t)b * INFO_N;
-    T* blk = lds + (size_t)lane * a.lds_stride;
+    T* blk = lds + (size_t)pl * a.lds_stride;
     T* tb = a.use_lds ? blk + Ltmp : (T*)a.tmp + b;
     const size_t ts = a.use_lds ? 1 : a.tmp_stride;
     T tmpv[FIX ? (3 * NX * NX + 3 * NX * NU + NU * NU + 5 * NX + 3 * NU) : 1];
@@ -283,10 +290,19 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     T* dz = a.use_lds ? blk + Ldz : dzg;
     const int uo = H * nx;
 
+    // Damping levels side by side: a sweep that meets an indefinite pivot has to be repeated with more damping, and the
+    // launch waited for the problem in hundreds that needs the third attempt (one sweep is a ~20 us latency chain of one
+    // lane; the levels are known beforehand: decade steps).  `spec` lanes per problem now run the levels of a round at the
+    // same time, each into its own region of the problem's block; the FIRST level that goes through is the one used, so
+    // the result is what the sequential attempts gave.
     int restarts = 0;
-    bool solved = false;
-    for (int attempt = 0; attempt < a.lq_attempts; ++attempt) {
-    bool pd = true;
+    bool solved = false, any = false;
+    const T reg_in = reg;
+    for (int base = 0; base < a.lq_attempts && !any; base += spec) {
+    const int aj = base + aj0;
+    reg = reg_in;
+    for (int k = 0; k < aj; ++k) reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));
+    bool pd = aj < a.lq_attempts;
     // terminal value function: V_{H-1}(dx) = 1/2 dx' Hx dx + gx' dx
     #pragma unroll
     for (int i = 0; i < nx; ++i) {
@@ -427,18 +443,29 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             }
         }
     }
-    if (pd) { solved = true; break; }
+    {
+        const unsigned long long ok = __ballot(pd);
+        int win = -1;
+        for (int jj = spec - 1; jj >= 0; --jj)
+            if ((ok >> (jj * ppw + pl)) & 1ull) win = jj;
+        if (win >= 0) { any = true; solved = win == aj0; restarts = base + win; }
+    }
     // decade steps from a floor of 1e-3: whenever a sweep of this problem family fails, the damping that lets it through
     // is 0.1 .. 100 (NEMPC_SOLVER_STATS), and the whole launch waits for the one problem in hundreds that climbs there --
     // nine attempts from the relaxed value with a floor of 1e-6, six from 1e-3 (the kernel runs 37 us clean, 10 us more
     // per attempt).  Remembering per problem the level that worked last time did not help: the restarting problems are
     // mostly first-timers.
-    reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));
-    ++restarts;
     }
-    ((T*)a.reg)[b] = reg;
+    if (!any) {
+        restarts = a.lq_attempts;
+        reg = reg_in;
+        for (int k = 0; k < a.lq_attempts; ++k) reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));
+    }
+    if (solved || (!any && aj0 == 0)) ((T*)a.reg)[b] = reg;
     T* lamn = a.use_lds ? blk + Llam : (T*)a.lamn + (size_t)b * a.m;
-    if (!solved) {
+    if (!solved && (any || aj0 != 0)) {
+        // another lane of this problem holds the level that is used (or reports that none went through)
+    } else if (!solved) {
         // Out of attempts for this iteration.  The launch waits for its slowest problem, and the one problem in hundreds
         // that needs five or six decades of damping made every other one wait ~50 us for it: it now keeps the damping it
         // has climbed to, takes NO step this iteration (zero step, multipliers unchanged, marked by a negative restart
@@ -621,9 +648,9 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
     const int ppw = a.ppw;                       // == waves per workgroup
     const int b0 = blockIdx.x * ppw;
     const int np = a.B - b0 < ppw ? a.B - b0 : ppw;
-    const int Lz = 0, Lgr = Lz + n, Lgc = Lgr + n, Ltl = Lgc + H * nx, LW = Ltl + H * nx * nin, LK = LW + H * nin * nin,
-              Lk = LK + H * nu * nx, LP = Lk + H * nu, Lp = LP + H * nx * nx, Llam = Lp + H * nx, Ldz = Llam + H * nx,
-              Lbh = Ldz + n, Ltmp = Lbh + n;
+    const int Lz = 0, Lgr = Lz + n, Lgc = Lgr + n, Ltl = Lgc + H * nx, LW = Ltl + H * nx * nin, Llam = LW + H * nin * nin,
+              Ldz = Llam + H * nx, Lbh = Ldz + n, LK = Lbh + n, Lk = LK + H * nu * nx, LP = Lk + H * nu, Lp = LP + H * nx * nx,
+              Ltmp = Lp + H * nx;
     auto stage_in = [&](const T* __restrict__ src, int per, int src_stride, int loff) {
         const int tot = np * per;
         const T* base = src + (size_t)b0 * src_stride;
@@ -1423,13 +1450,23 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         if (ex_per) h.d_extra = ws.exc[k];
     };
     point_at(0);
-    int per_problem = 2 * n + 2 * H * nx + H * nx * nin + H * nin * nin + H * nu * nx + H * nu + H * nx * nx + H * nx + n + n +
-                      lq_tmp_elems(nx, nu);
-    per_problem |= 1;   // odd stride: the ppw lanes of a sweep hit different LDS banks
+    static const int lq_attempts_env = [] { const char* e = getenv("NEMPC_LQ_ATTEMPTS"); return e ? atoi(e) : 0; }();   // A/B knob
+    a.lq_attempts = o.lq_attempts > 0 ? o.lq_attempts : (lq_attempts_env > 0 ? lq_attempts_env : 3);
     const bool wave_wanted = o.lq_kernel != 1 && (o.lq_kernel == 2 || nx * (nx + nu) >= 12);
+    // thread-per-problem sweep: up to three damping levels side by side (lanes and LDS regions per problem)
+    static const int lq_spec_env = [] { const char* e = getenv("NEMPC_LQ_SPEC"); return e ? atoi(e) : 0; }();           // A/B knob
+    a.spec = wave_wanted ? 1 : std::max(1, std::min(std::min(a.lq_attempts, lq_spec_env > 0 ? lq_spec_env : 3), 8));
+    a.att_elems = H * nu * nx + H * nu + H * nx * nx + H * nx + lq_tmp_elems(nx, nu);
+    int per_problem;
+    for (;; --a.spec) {
+        per_problem = 2 * n + 2 * H * nx + H * nx * nin + H * nin * nin + n + n + a.spec * a.att_elems;
+        per_problem |= 1;   // odd stride: the ppw lanes of a sweep hit different LDS banks
+        if (a.spec == 1 || (size_t)per_problem * sizeof(T) <= (size_t)150 * 1024) break;   // (levels one after the other if not)
+    }
     auto pick_ppw = [&](int Bact) {
         int ppw = (int)((size_t)150 * 1024 / ((size_t)per_problem * sizeof(T)));
         if (ppw > 16) ppw = 16;
+        if (ppw * a.spec > 64) ppw = 64 / a.spec;       // the sweeping lanes are one wave
         // the sweep is one latency chain per lane whatever the number of active lanes: spread the batch over the CUs
         const int spread = (Bact + 255) / 256;
         if (ppw > spread) ppw = spread < 1 ? 1 : spread;
@@ -1446,8 +1483,6 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         a.armijo_slack = std::max(1e-12, slack_eps * (double)std::numeric_limits<T>::epsilon());
     }
     a.max_ls = o.max_linesearch;
-    static const int lq_attempts_env = [] { const char* e = getenv("NEMPC_LQ_ATTEMPTS"); return e ? atoi(e) : 0; }();   // A/B knob
-    a.lq_attempts = o.lq_attempts > 0 ? o.lq_attempts : (lq_attempts_env > 0 ? lq_attempts_env : 3);
     auto lqk = (nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1> : ((nx == 6 && nu == 3) ? solver_lq_kernel<T, 6, 3> : solver_lq_kernel<T, 0, 0>);
     // wave-per-problem sweep when the working set is staged in LDS and a stage has enough entries to spread over a
     // wave: 6/3 stages 6.5 k vs 5.0 k MPC solves/s at C3; 2/1 stages are 4 entries wide and stay on the
