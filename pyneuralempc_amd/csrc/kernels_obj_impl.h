@@ -35,6 +35,43 @@ __device__ __forceinline__ double wave_sum_lane0(double s) {
     return s;
 }
 
+// Maximum / minimum over the wave, valid in lane 0, same tree: lanes without a partner inside their row keep their own
+// value (idempotent operations need no neutral element).
+template <int N, bool MAX>
+__device__ __forceinline__ double row_shl_ext(double s) {
+    const int lo = __double2loint(s), hi = __double2hiint(s);
+    const int l2 = __builtin_amdgcn_update_dpp(lo, lo, 0x100 + N, 0xf, 0xf, false);
+    const int h2 = __builtin_amdgcn_update_dpp(hi, hi, 0x100 + N, 0xf, 0xf, false);
+    const double o = __hiloint2double(h2, l2);
+    return MAX ? fmax(s, o) : fmin(s, o);
+}
+template <bool MAX>
+__device__ __forceinline__ double wave_ext_lane0(double s) {
+    {
+        auto l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(s), (unsigned)__double2loint(s), false, false);
+        auto h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(s), (unsigned)__double2hiint(s), false, false);
+        const double x = __hiloint2double((int)h[0], (int)l[0]), y = __hiloint2double((int)h[1], (int)l[1]);
+        s = MAX ? fmax(x, y) : fmin(x, y);
+    }
+    {
+        auto l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(s), (unsigned)__double2loint(s), false, false);
+        auto h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(s), (unsigned)__double2hiint(s), false, false);
+        const double x = __hiloint2double((int)h[0], (int)l[0]), y = __hiloint2double((int)h[1], (int)l[1]);
+        s = MAX ? fmax(x, y) : fmin(x, y);
+    }
+    s = row_shl_ext<8, MAX>(s);
+    s = row_shl_ext<4, MAX>(s);
+    s = row_shl_ext<2, MAX>(s);
+    s = row_shl_ext<1, MAX>(s);
+    return s;
+}
+__device__ __forceinline__ double wave_max_lane0(double s) { return wave_ext_lane0<true>(s); }
+__device__ __forceinline__ double wave_min_lane0(double s) { return wave_ext_lane0<false>(s); }
+// lane 0's value in every lane (a scalar register; all lanes of the wave must be active)
+__device__ __forceinline__ double wave_bcast_lane0(double s) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(s)), __builtin_amdgcn_readfirstlane(__double2loint(s)));
+}
+
 // one wave per problem; lanes stride over the horizon.  z: the problem's variables (global memory, or a copy in LDS)
 template <typename T>
 __device__ __forceinline__ void objective_row(int b, int lane, int H, int nx, int nu, const ObjOffsets& o,

@@ -32,6 +32,7 @@
 #include <limits>
 
 #include "nempc_internal.h"
+#include "kernels_obj_impl.h"
 
 #ifndef NEMPC_REG_FLOOR
 #define NEMPC_REG_FLOOR 1e-3      // first damping level of a restarted Riccati sweep (see solver_lq_kernel)
@@ -113,13 +114,12 @@ __global__ __launch_bounds__(256) void solver_barrier_kernel(SolverArgs a) {
 // after the LQ solve: dual steps and their fraction-to-the-boundary length (one wave per problem)
 template <typename T>
 __device__ __forceinline__ void solver_dual_body(const SolverArgs& a, int b, int lane, const T* __restrict__ zp,
-                                                 const T* __restrict__ dzp) {
+                                                 const T* __restrict__ dzp, T mu, int status) {
     // zp / dzp: the problem's iterate and step (global memory, or the Riccati kernel's LDS copies)
     if (!a.primal_dual) return;
-    const T mu = ((const T*)a.mu)[b];
     const T tau = T(0.995);
     T amax = T(1);
-    if (mu > T(0) && a.status[b] < 0)
+    if (mu > T(0) && status < 0)
         for (int i = lane; i < a.n; i += 64) {
             const size_t idx = (size_t)b * a.n + i;
             const T z = zp[i], d = dzp[i], lo = ((const T*)a.lb)[i], hi = ((const T*)a.ub)[i];
@@ -137,7 +137,7 @@ __device__ __forceinline__ void solver_dual_body(const SolverArgs& a, int b, int
             ((T*)a.dzl)[idx] = sl;
             ((T*)a.dzu)[idx] = su;
         }
-    for (int o = 32; o > 0; o >>= 1) amax = fmin(amax, __shfl_down(amax, o, 64));
+    amax = (T)wave_min_lane0((double)amax);
     if (lane == 0) ((T*)a.alz)[b] = amax;
 }
 
@@ -145,33 +145,71 @@ __device__ __forceinline__ void solver_dual_body(const SolverArgs& a, int b, int
 // that stage their working set in LDS and fold it in while staging (one launch less per iteration): ga joins the
 // gradient, ha is the diagonal of the LQ model
 template <typename T>
-__device__ __forceinline__ void solver_barrier_terms(const SolverArgs& a, int b, int i, T& ga, T& ha) {
+__device__ __forceinline__ void barrier_terms_of(bool primal_dual, T mu, int status, T z, T lo, T hi, T zl, T zu, T& ga, T& ha) {
     ga = T(0); ha = T(0);
-    const T mu = ((const T*)a.mu)[b];
-    if (mu > T(0) && a.status[b] < 0) {
-        const size_t idx = (size_t)b * a.n + i;
-        const T z = ((const T*)a.Z)[idx], lo = ((const T*)a.lb)[i], hi = ((const T*)a.ub)[i];
+    if (mu > T(0) && status < 0) {
         if (lo > -std::numeric_limits<T>::max()) {
             const T d = z - lo;
             ga -= mu / d;
-            ha += a.primal_dual ? ((const T*)a.zl)[idx] / d : mu / (d * d);
+            ha += primal_dual ? zl / d : mu / (d * d);
         }
         if (hi < std::numeric_limits<T>::max()) {
             const T d = hi - z;
             ga += mu / d;
-            ha += a.primal_dual ? ((const T*)a.zu)[idx] / d : mu / (d * d);
+            ha += primal_dual ? zu / d : mu / (d * d);
         }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void solver_barrier_terms(const SolverArgs& a, int b, int i, T& ga, T& ha) {
+    ga = T(0); ha = T(0);
+    const T mu = ((const T*)a.mu)[b];
+    const int status = a.status[b];
+    if (mu > T(0) && status < 0) {
+        const size_t idx = (size_t)b * a.n + i;
+        const T z = ((const T*)a.Z)[idx], lo = ((const T*)a.lb)[i], hi = ((const T*)a.ub)[i];
+        const bool lof = lo > -std::numeric_limits<T>::max(), hif = hi < std::numeric_limits<T>::max();
+        barrier_terms_of<T>(a.primal_dual, mu, status, z, lo, hi, a.primal_dual && lof ? ((const T*)a.zl)[idx] : T(0),
+                            a.primal_dual && hif ? ((const T*)a.zu)[idx] : T(0), ga, ha);
     }
 }
 
 template <typename T>
-struct StepInfo {   // what the Riccati kernel leaves in the info row (read from there, or handed over in registers)
+struct StepInfo {   // what the Riccati kernel leaves in the info row (read from there, or handed over in registers) ...
     T ginf, step, zinf, lam, d0, amax, lsk, lsa, restarts;
+    // ... and the problem's scalars, loaded in one go ahead of their use (each was a dependent global round trip)
+    T lsr, mu, nu, f;
+    int status;
 };
 template <typename T>
 __device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, int lane, const T* __restrict__ f,
                                                    const T* __restrict__ zp, const T* __restrict__ gp, const StepInfo<T>& si,
                                                    int& lsd, T& al);
+
+#ifdef NEMPC_LQ_STAMPS
+__device__ long long nempc_lq_stamps[16];
+#define LQ_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) nempc_lq_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define LQ_STAMP(i) do { } while (0)
+#endif
+
+// 1 / sqrt(d) for a pivot d > 1e-12: hardware estimate + two coupled Newton steps (double; ~1 ulp) or one (float).  The
+// IEEE sqrt followed by the IEEE division is ~32 instructions of a chain that a lone lane issues one per ~10 cycles.
+__device__ __forceinline__ double inv_sqrt_pos(double d) {
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+    double r = fma(-g, h, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-g, h, 0.5);
+    h = fma(h, r, h);
+    return h + h;
+}
+__device__ __forceinline__ float inv_sqrt_pos(float d) {
+    const float y = __builtin_amdgcn_rsqf(d);
+    const float r = fmaf(-d * y, y, 1.0f);
+    return fmaf(0.5f * y, r, y);
+}
 
 // One thread per problem.  The sweep is a long chain of tiny dependent matrix products: straight from global
 // memory every operand costs a ~600-cycle round trip (measured 720 us per call at B=1024, 2/1, H=20).  So a
@@ -181,15 +219,15 @@ __device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, i
 // Problems whose working set does not fit in LDS fall back to global temporaries (ppw = 64, use_lds = 0).
 // NX, NU > 0: dimensions fixed at compile time -- every small loop unrolls and the temporaries live in registers
 // (2/1 and 6/3, the BASELINE shapes); NX = NU = 0: runtime dimensions, temporaries in LDS / global memory.
-template <typename T, int NX, int NU>
+template <typename T, int NX, int NU, bool LDS>
 __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T* lds = reinterpret_cast<T*>(lds_raw);
     const int lane = threadIdx.x;
     constexpr bool FIX = NX > 0;
     const int H = a.H, nx = FIX ? NX : a.nx, nu = FIX ? NU : a.nu, nin = nx + nu, n = a.n;
-    const int ppw = a.use_lds ? a.ppw : 64;
-    const int spec = a.use_lds ? a.spec : 1;
+    const int ppw = LDS ? a.ppw : 64;
+    const int spec = LDS ? a.spec : 1;
     const int aj0 = lane < ppw * spec ? lane / ppw : 0;      // which of the side-by-side damping levels this lane sweeps
     const int pl = lane < ppw * spec ? lane - aj0 * ppw : lane;   // its problem's slot in the workgroup
     // element offsets of the per-problem LDS block: the arrays every attempt reads, the results, then one region per attempt
@@ -198,50 +236,95 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
               LP = Lk + H * nu, Lp = LP + H * nx * nx, Ltmp = Lp + H * nx;
     const int b = blockIdx.x * ppw + pl;
     const bool mine = lane < ppw * spec && b < a.B;
-    // cooperative staging: one flat, unrolled loop per array over all the workgroup's problems (they are contiguous in
-    // global memory), all four waves loading -- many independent loads in flight instead of one dependent round
-    // trip per (problem, array)
+    // cooperative staging, all four waves loading: a wave takes a problem (with fewer than three problems in the
+    // workgroup, two or all four waves share one), its lanes the elements -- index arithmetic without divisions (a flat
+    // index over problems x elements cost a ~40-instruction integer division per element, in a phase that a wave runs
+    // once, at one instruction per ~10 cycles)
     const int b0 = blockIdx.x * ppw;
     const int np = a.B - b0 < ppw ? a.B - b0 : ppw;
     const int nthr = blockDim.x;
+    const int wvu = __builtin_amdgcn_readfirstlane(lane >> 6);
+    const int lgw = np >= 3 ? 0 : (np == 2 ? 1 : 2);                 // log2(waves per problem), 4 waves
+    const int st_p0 = wvu >> lgw, st_pstep = 4 >> lgw, st_e0 = ((wvu & ((1 << lgw) - 1)) << 6) + (lane & 63), st_estep = 64 << lgw;
     auto stage_in = [&](const T* __restrict__ src, int per, int src_stride, int loff) {
-        const int tot = np * per;
-        const T* base = src + (size_t)b0 * src_stride;
-        for (int i = lane; i < tot; i += nthr) {
-            const int pp = i / per, e = i - pp * per;
-            lds[(size_t)pp * a.lds_stride + loff + e] = base[(size_t)pp * src_stride + e];
+        for (int pp = st_p0; pp < np; pp += st_pstep) {
+            const T* sp = src + (size_t)(b0 + pp) * src_stride;
+            T* dp = lds + (size_t)pp * a.lds_stride + loff;
+            for (int e = st_e0; e < per; e += st_estep) dp[e] = sp[e];
         }
     };
-    if (a.use_lds) {
+    LQ_STAMP(0);
+    if (LDS) {
         // counters of the convergence test (zeroed here unless the test runs inside this kernel: then the previous
         // iteration's acceptance kernel did it) and of the trial's acceptance test
         if (blockIdx.x == 0 && lane == 0) {
             if (a.fuse_step) *a.n_pending = 0; else *a.n_active = 0;
         }
+        // Small stages (every array a few wavefuls: the BASELINE 2/1 shapes): ALL loads of a problem are issued before the
+        // first LDS write, one global round trip instead of one per array and three inside the barrier terms
+        const int Ntl = H * nx * nin, NW = H * nin * nin;
+        const bool one_shot = n <= st_estep && Ntl <= 2 * st_estep && NW <= 3 * st_estep;
+        if (one_shot) {
+            for (int pp = st_p0; pp < np; pp += st_pstep) {
+                const int bq = b0 + pp, e = st_e0, e1 = e + st_estep, e2 = e1 + st_estep;
+                const bool in_n = e < n, pdl = a.primal_dual != 0;
+                const T mu_q = ((const T*)a.mu)[bq];
+                const int st_q = a.status[bq];
+                const T vz = in_n ? ((const T*)a.Z)[(size_t)bq * n + e] : T(0);
+                const T vgr = in_n ? ((const T*)a.grad)[(size_t)bq * n + e] : T(0);
+                const T vlo = in_n ? ((const T*)a.lb)[e] : -std::numeric_limits<T>::max();
+                const T vhi = in_n ? ((const T*)a.ub)[e] : std::numeric_limits<T>::max();
+                const T vzl = in_n && pdl ? ((const T*)a.zl)[(size_t)bq * n + e] : T(0);
+                const T vzu = in_n && pdl ? ((const T*)a.zu)[(size_t)bq * n + e] : T(0);
+                const T vgc = e < H * nx ? ((const T*)a.g)[(size_t)bq * a.m + e] : T(0);
+                const T* tq = (const T*)a.tiles + (size_t)bq * Ntl;
+                const T* wq = (const T*)a.hblk + (size_t)bq * NW;
+                const T vt0 = e < Ntl ? tq[e] : T(0), vt1 = e1 < Ntl ? tq[e1] : T(0);
+                const T vw0 = e < NW ? wq[e] : T(0), vw1 = e1 < NW ? wq[e1] : T(0), vw2 = e2 < NW ? wq[e2] : T(0);
+                T* blkp = lds + (size_t)pp * a.lds_stride;
+                if (e < Ntl) blkp[Ltl + e] = vt0;
+                if (e1 < Ntl) blkp[Ltl + e1] = vt1;
+                if (e < NW) blkp[LW + e] = vw0;
+                if (e1 < NW) blkp[LW + e1] = vw1;
+                if (e2 < NW) blkp[LW + e2] = vw2;
+                if (e < H * nx) blkp[Lgc + e] = vgc;
+                if (in_n) {
+                    T ga, ha;
+                    barrier_terms_of<T>(pdl, mu_q, st_q, vz, vlo, vhi, vzl, vzu, ga, ha);
+                    blkp[Lz + e] = vz;
+                    blkp[Lgr + e] = vgr + ga;
+                    blkp[Lbh + e] = ha;
+                }
+            }
+            __syncthreads();
+        } else {
         stage_in((const T*)a.Z, n, n, Lz);
         // gradient + barrier gradient, barrier diagonal: computed while staging (no solver_barrier_kernel launch)
-        for (int i = lane; i < np * n; i += nthr) {
-            const int pp = i / n, e = i - pp * n;
-            T ga, ha;
-            solver_barrier_terms<T>(a, b0 + pp, e, ga, ha);
+        for (int pp = st_p0; pp < np; pp += st_pstep) {
             T* blkp = lds + (size_t)pp * a.lds_stride;
-            T gv = ((const T*)a.grad)[(size_t)(b0 + pp) * n + e];
-            gv += ga;
-            blkp[Lgr + e] = gv;
-            blkp[Lbh + e] = ha;
+            for (int e = st_e0; e < n; e += st_estep) {
+                T ga, ha;
+                solver_barrier_terms<T>(a, b0 + pp, e, ga, ha);
+                T gv = ((const T*)a.grad)[(size_t)(b0 + pp) * n + e];
+                gv += ga;
+                blkp[Lgr + e] = gv;
+                blkp[Lbh + e] = ha;
+            }
         }
         stage_in((const T*)a.g, H * nx, a.m, Lgc);
         stage_in((const T*)a.tiles, H * nx * nin, H * nx * nin, Ltl);
         stage_in((const T*)a.hblk, H * nin * nin, H * nin * nin, LW);
         __syncthreads();
+        }
     }
+    LQ_STAMP(1);
     T* dzg = mine ? (T*)a.dz + (size_t)b * n : nullptr;
     if (mine && a.status[b] >= 0) {
         // finished problem: zero step (written through the copy-out below in LDS mode)
         if (aj0 == 0) {
-            T* dzp = a.use_lds ? lds + (size_t)pl * a.lds_stride + Ldz : dzg;
+            T* dzp = LDS ? lds + (size_t)pl * a.lds_stride + Ldz : dzg;
             for (int i = 0; i < n; ++i) dzp[i] = T(0);
-            if (a.use_lds) {
+            if (LDS) {
                 T* lp = lds + (size_t)pl * a.lds_stride + Llam;
                 const T* lcur = (const T*)a.lam + (size_t)b * a.m;
                 for (int i = 0; i < H * nx; ++i) lp[i] = lcur[i];
@@ -250,8 +333,8 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     } else if (mine) {
     T* info = (T*)a.info + (size_t)b * INFO_N;
     T* blk = lds + (size_t)pl * a.lds_stride;
-    T* tb = a.use_lds ? blk + Ltmp : (T*)a.tmp + b;
-    const size_t ts = a.use_lds ? 1 : a.tmp_stride;
+    T* tb = LDS ? blk + Ltmp : (T*)a.tmp + b;
+    const size_t ts = LDS ? 1 : a.tmp_stride;
     T tmpv[FIX ? (3 * NX * NX + 3 * NX * NU + NU * NU + 5 * NX + 3 * NU) : 1];
 #define TMP(e) (*(FIX ? &tmpv[FIX ? (e) : 0] : &tb[(size_t)(e) * ts]))
     int off = 0;
@@ -271,23 +354,35 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     const int okv = off; off += nu;
     const int odu = off; off += nu;
 
-    const T* z = a.use_lds ? blk + Lz : (const T*)a.Z + (size_t)b * n;
-    const T* gr = a.use_lds ? blk + Lgr : (const T*)a.grad + (size_t)b * n;
-    const T* gc = a.use_lds ? blk + Lgc : (const T*)a.g + (size_t)b * a.m;
-    const T* tl = a.use_lds ? blk + Ltl : (const T*)a.tiles + (size_t)b * H * nx * nin;
-    const T* Wb = a.use_lds ? blk + LW : (const T*)a.hblk + (size_t)b * H * nin * nin;
+    const T* z = LDS ? blk + Lz : (const T*)a.Z + (size_t)b * n;
+    const T* gr = LDS ? blk + Lgr : (const T*)a.grad + (size_t)b * n;
+    const T* gc = LDS ? blk + Lgc : (const T*)a.g + (size_t)b * a.m;
+    const T* tl = LDS ? blk + Ltl : (const T*)a.tiles + (size_t)b * H * nx * nin;
+    const T* Wb = LDS ? blk + LW : (const T*)a.hblk + (size_t)b * H * nin * nin;
     const T* Qs = (const T*)a.obj + a.oo.Qs;
     const T* QTs = (const T*)a.obj + a.oo.QTs;
     const T* Rs = (const T*)a.obj + a.oo.Rs;
+    // small stages: the objective's weights live in registers for the sweeps (read from global memory inside the stage
+    // loop they were two ~500-cycle waits per stage: the stores of the sweep keep the compiler from hoisting them)
+    constexpr bool REGTAB = FIX && NX * NX + NU * NU <= 16;
+    T Qr[REGTAB ? NX * NX : 1], Rr[REGTAB ? NU * NU : 1];
+    if (REGTAB) {
+        #pragma unroll
+        for (int e = 0; e < NX * NX; ++e) Qr[REGTAB ? e : 0] = Qs[e];
+        #pragma unroll
+        for (int e = 0; e < NU * NU; ++e) Rr[REGTAB ? e : 0] = Rs[e];
+    }
+#define QS(e) (REGTAB ? Qr[REGTAB ? (e) : 0] : Qs[e])
+#define RS(e) (REGTAB ? Rr[REGTAB ? (e) : 0] : Rs[e])
     const T* lb = (const T*)a.lb;
     const T* ub = (const T*)a.ub;
-    const T* bh = a.use_lds ? blk + Lbh : (const T*)a.bh + (size_t)b * n;   // barrier diagonal (solver_barrier_kernel)
+    const T* bh = LDS ? blk + Lbh : (const T*)a.bh + (size_t)b * n;   // barrier diagonal (solver_barrier_kernel)
     T reg = ((const T*)a.reg)[b];
-    T* Kst = a.use_lds ? blk + LK : (T*)a.Kst + (size_t)b * H * nu * nx;
-    T* kst = a.use_lds ? blk + Lk : (T*)a.kst + (size_t)b * H * nu;
-    T* Pst = a.use_lds ? blk + LP : (T*)a.Pst + (size_t)b * H * nx * nx;
-    T* pst = a.use_lds ? blk + Lp : (T*)a.pst + (size_t)b * H * nx;
-    T* dz = a.use_lds ? blk + Ldz : dzg;
+    T* Kst = LDS ? blk + LK : (T*)a.Kst + (size_t)b * H * nu * nx;
+    T* kst = LDS ? blk + Lk : (T*)a.kst + (size_t)b * H * nu;
+    T* Pst = LDS ? blk + LP : (T*)a.Pst + (size_t)b * H * nx * nx;
+    T* pst = LDS ? blk + Lp : (T*)a.pst + (size_t)b * H * nx;
+    T* dz = LDS ? blk + Ldz : dzg;
     const int uo = H * nx;
 
     // Damping levels side by side: a sweep that meets an indefinite pivot has to be repeated with more damping, and the
@@ -312,7 +407,11 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         for (int j = 0; j < nx; ++j) TMP(oP + i * nx + j) = QTs[i * nx + j] + (i == j ? ha : T(0));   // terminal weight
         TMP(op + i) = gr[(H - 1) * nx + i] + ga;
     }
+#ifdef NEMPC_LQ_EXP_NOBACK
+    for (int t = H - 1; t >= H - 1 && pd; --t) {
+#else
     for (int t = H - 1; t >= 0 && pd; --t) {
+#endif
         const T* At = tl + (size_t)t * nx * nin;   // [i][0:nx] = A, [i][nx:] = B
         const T* Wt = Wb + (size_t)t * nin * nin;  // Lagrangian block over (x_{t-1}, u_t)
         #pragma unroll
@@ -351,7 +450,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             ha = bh[uo + t * nu + i];
             #pragma unroll
             for (int j = 0; j < nu; ++j) {
-                T v = Rs[i * nu + j] + Wt[(nx + i) * nin + nx + j] + (i == j ? ha + reg : T(0));
+                T v = RS(i * nu + j) + Wt[(nx + i) * nin + nx + j] + (i == j ? ha + reg : T(0));
                 #pragma unroll
                 for (int k = 0; k < nx; ++k) v = fma(At[k * nin + nx + i], TMP(oPB + k * nu + j), v);
                 TMP(oQuu + i * nu + j) = v;
@@ -378,7 +477,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             if (!(d > T(1e-12))) { pd = false; break; }   // not positive definite: restart with more damping
             // the diagonal of L is only ever divided by: its INVERSE is kept in its place (one division per pivot instead
             // of one per use -- seven per stage at 2/1 -- in a sweep whose time is its instruction count)
-            d = T(1) / sqrt(d);
+            d = inv_sqrt_pos(d);
             TMP(oQuu + j * nu + j) = d;
             #pragma unroll
             for (int i = j + 1; i < nu; ++i) {
@@ -421,7 +520,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                 ha = bh[(t - 1) * nx + i];
                 #pragma unroll
                 for (int j = 0; j < nx; ++j) {
-                    T v = Qs[i * nx + j] + Wt[i * nin + j] + (i == j ? ha : T(0));
+                    T v = QS(i * nx + j) + Wt[i * nin + j] + (i == j ? ha : T(0));
                     #pragma unroll
                     for (int k = 0; k < nx; ++k) v = fma(At[k * nin + i], TMP(oPA + k * nx + j), v);
                     #pragma unroll
@@ -462,7 +561,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         for (int k = 0; k < a.lq_attempts; ++k) reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));
     }
     if (solved || (!any && aj0 == 0)) ((T*)a.reg)[b] = reg;
-    T* lamn = a.use_lds ? blk + Llam : (T*)a.lamn + (size_t)b * a.m;
+    T* lamn = LDS ? blk + Llam : (T*)a.lamn + (size_t)b * a.m;
     if (!solved && (any || aj0 != 0)) {
         // another lane of this problem holds the level that is used (or reports that none went through)
     } else if (!solved) {
@@ -475,19 +574,23 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         for (int i = 0; i < H * nx; ++i) lamn[i] = lcur[i];
         info[INFO_STEP] = std::numeric_limits<T>::max();
         info[INFO_RESTARTS] = (T)(-restarts);
-        if (a.use_lds) blk[Lbh] = (T)(-restarts);          // (the barrier diagonal is no longer needed: slot for the post-pass)
+        if (LDS) blk[Lbh] = (T)(-restarts);          // (the barrier diagonal is no longer needed: slot for the post-pass)
     } else {
     // forward sweep
     // The norms, the directional derivative and the fraction-to-the-boundary length of the step are NOT part of the
     // recursion: in LDS mode a wave per problem computes them from the staged arrays after the sweeps (below), with its
     // 64 lanes over the elements -- in the sweep they were 60 % of the forward pass's instructions (three divisions per
     // stage among them), issued one per ~10 cycles by a lone lane (kernel 37 -> 22 us clean)
-    const bool norms_here = !a.use_lds;
+    const bool norms_here = !LDS;
     T lam_inf = T(0), step_inf = T(0), amax = T(1), D0 = T(0), g1 = T(0), ginf = T(0), zinf = T(0);
     const T tau = T(0.995);
     #pragma unroll
     for (int i = 0; i < nx; ++i) TMP(odx + i) = T(0);
+#ifdef NEMPC_LQ_EXP_NOFWD
+    for (int t = 0; t < 1; ++t) {
+#else
     for (int t = 0; t < H; ++t) {
+#endif
         const T* At = tl + (size_t)t * nx * nin;
         #pragma unroll
         for (int i = 0; i < nu; ++i) {
@@ -548,12 +651,16 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf;
     }
     info[INFO_RESTARTS] = (T)restarts;
-    if (a.use_lds) blk[Lbh] = (T)restarts;
+    if (LDS) blk[Lbh] = (T)restarts;
     }   // solved
 #undef TMP
+#undef QS
+#undef RS
     }
-    if (a.use_lds) {
+    LQ_STAMP(2);
+    if (LDS) {
         __syncthreads();
+        LQ_STAMP(3);
         {
             // norms of the steps just computed: wave w takes problems w, w + #waves, ...
             const int wv = lane >> 6, ln = lane & 63, nwv = nthr >> 6;
@@ -563,7 +670,15 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             for (int pp = wv; pp < np; pp += nwv) {
                 const int bp = b0 + pp;
                 const T* blk = lds + (size_t)pp * a.lds_stride;
-                if (a.status[bp] >= 0) {
+                // the problem's scalars for the step part below: all requested now, used after the norms
+                const T* infg = (const T*)a.info + (size_t)bp * INFO_N;
+                StepInfo<T> si;
+                si.status = a.status[bp];
+                if (a.fuse_step) {
+                    si.mu = ((const T*)a.mu)[bp]; si.nu = ((const T*)a.pen)[bp]; si.f = ((const T*)a.f_it)[bp];
+                    si.lsk = infg[INFO_LSK]; si.lsa = infg[INFO_LSA]; si.lsr = infg[INFO_LSR];
+                }
+                if (si.status >= 0) {
                     if (a.fuse_step) {      // finished problem: no step, its trial point is the iterate
                         if (ln == 0) a.lsdone[bp] = 1;
                         T* zt = (T*)a.Zt_it + (size_t)bp * n;
@@ -586,15 +701,15 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                     g1 += gv;
                     ginf = fmax(ginf, gv);
                 }
-                for (int o = 32; o > 0; o >>= 1) {
-                    lam_inf = fmax(lam_inf, __shfl_down(lam_inf, o, 64));
-                    step_inf = fmax(step_inf, __shfl_down(step_inf, o, 64));
-                    amax = fmin(amax, __shfl_down(amax, o, 64));
-                    D0 += __shfl_down(D0, o, 64);
-                    g1 += __shfl_down(g1, o, 64);
-                    ginf = fmax(ginf, __shfl_down(ginf, o, 64));
-                    zinf = fmax(zinf, __shfl_down(zinf, o, 64));
-                }
+                // (on the vector unit alone: each shuffle tree was six dependent LDS round trips of a lone wave)
+                lam_inf = (T)wave_max_lane0((double)lam_inf);
+                step_inf = (T)wave_max_lane0((double)step_inf);
+                amax = (T)wave_min_lane0((double)amax);
+                D0 = (T)wave_sum_lane0((double)D0);
+                g1 = (T)wave_sum_lane0((double)g1);
+                ginf = (T)wave_max_lane0((double)ginf);
+                zinf = (T)wave_max_lane0((double)zinf);
+                LQ_STAMP(4);
                 const T rst = blk[Lbh];                    // restart count left by the sweeping lane (negative: sat out)
                 const bool sat_out = rst < T(0);           // no step this iteration: keep the sentinel
                 if (ln == 0) {
@@ -603,35 +718,41 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                     info[INFO_AMAX] = amax; info[INFO_G1] = g1;
                     info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf;
                 }
+#ifdef NEMPC_LQ_EXP_NOPOST
+                if (false) {
+#else
                 if (a.fuse_step) {
+#endif
                     // what solver_step_kernel does, from the LDS copies and the norms still in registers: dual steps of the
                     // bounds, convergence test / barrier update / merit at the iterate, first trial point
-                    const T* infg = (const T*)a.info + (size_t)bp * INFO_N;
-                    StepInfo<T> si;
-                    si.ginf = __shfl(ginf, 0, 64); si.zinf = __shfl(zinf, 0, 64); si.lam = __shfl(lam_inf, 0, 64);
-                    si.d0 = __shfl(D0, 0, 64); si.amax = __shfl(amax, 0, 64);
-                    si.step = sat_out ? std::numeric_limits<T>::max() : __shfl(step_inf, 0, 64);
-                    si.lsk = infg[INFO_LSK]; si.lsa = infg[INFO_LSA]; si.restarts = rst;
-                    solver_dual_body<T>(a, bp, ln, blk + Lz, blk + Ldz);
+                    si.ginf = (T)wave_bcast_lane0((double)ginf); si.zinf = (T)wave_bcast_lane0((double)zinf);
+                    si.lam = (T)wave_bcast_lane0((double)lam_inf);
+                    si.d0 = (T)wave_bcast_lane0((double)D0); si.amax = (T)wave_bcast_lane0((double)amax);
+                    si.step = sat_out ? std::numeric_limits<T>::max() : (T)wave_bcast_lane0((double)step_inf);
+                    si.restarts = rst;
+                    solver_dual_body<T>(a, bp, ln, blk + Lz, blk + Ldz, si.mu, si.status);
+                    LQ_STAMP(5);
                     int lsd;
                     T al;
                     solver_merit0_body<T>(a, bp, ln, (const T*)a.f_it, blk + Lz, blk + Lgc, si, lsd, al);
+                    LQ_STAMP(6);
                     T* zt = (T*)a.Zt_it + (size_t)bp * n;
                     for (int i = ln; i < n; i += 64) zt[i] = lsd ? blk[Lz + i] : fma(al, blk[Ldz + i], blk[Lz + i]);
                 }
             }
         }
+        LQ_STAMP(7);
         auto stage_out = [&](T* __restrict__ dst, int per, int dst_stride, int loff) {
-            const int tot = np * per;
-            T* base = dst + (size_t)b0 * dst_stride;
-            for (int i = lane; i < tot; i += nthr) {
-                const int pp = i / per, e = i - pp * per;
-                base[(size_t)pp * dst_stride + e] = lds[(size_t)pp * a.lds_stride + loff + e];
+            for (int pp = st_p0; pp < np; pp += st_pstep) {
+                T* dp = dst + (size_t)(b0 + pp) * dst_stride;
+                const T* sp = lds + (size_t)pp * a.lds_stride + loff;
+                for (int e = st_e0; e < per; e += st_estep) dp[e] = sp[e];
             }
         };
         stage_out((T*)a.dz, n, n, Ldz);
         stage_out((T*)a.lamn, H * nx, a.m, Llam);
     }
+    LQ_STAMP(8);
 }
 
 // Wave-per-problem variant of the LQ solve (LDS mode only): the same recursion, formulas and summation order as
@@ -816,7 +937,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                             T d = tb[oQuu + j * nu + j];
                             for (int k = 0; k < j; ++k) d -= tb[oQuu + j * nu + k] * tb[oQuu + j * nu + k];
                             if (!(d > T(1e-12))) { ok = T(0); break; }
-                            d = T(1) / sqrt(d);               // inverse diagonal, as in the thread-per-problem kernel
+                            d = inv_sqrt_pos(d);              // inverse diagonal, as in the thread-per-problem kernel
                             tb[oQuu + j * nu + j] = d;
                             for (int i = j + 1; i < nu; ++i) {
                                 T v = tb[oQuu + i * nu + j];
@@ -993,16 +1114,14 @@ __device__ __forceinline__ double barrier_value(const T* z, const T* lb, const T
             if (lb[i] > -std::numeric_limits<T>::max()) acc -= (double)mu * log((double)(z[i] - lb[i]));
             if (ub[i] < std::numeric_limits<T>::max()) acc -= (double)mu * log((double)(ub[i] - z[i]));
         }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    return __shfl(acc, 0, 64);
+    return wave_bcast_lane0(wave_sum_lane0(acc));
 }
 
 template <typename T>
 __device__ __forceinline__ double l1_norm(const T* g, int m, int lane) {
     double acc = 0.0;
     for (int i = lane; i < m; i += 64) acc += fabs((double)g[i]);
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    return __shfl(acc, 0, 64);
+    return wave_bcast_lane0(wave_sum_lane0(acc));
 }
 
 // mode 0: after the LQ solve -- convergence / barrier update, penalty update, merit at the iterate, first step length
@@ -1010,9 +1129,11 @@ __device__ __forceinline__ double l1_norm(const T* g, int m, int lane) {
 // Convergence test, barrier update and merit at the iterate (after the LQ solve), one wave per problem.  Returns, the same
 // in every lane, whether the problem takes no step this iteration (`lsd`) and the step length of its first trial (`al`).
 template <typename T>
-__device__ __forceinline__ StepInfo<T> step_info_from(const T* info) {
+__device__ __forceinline__ StepInfo<T> step_info_from(const SolverArgs& a, int b, const T* __restrict__ f) {
+    const T* info = (const T*)a.info + (size_t)b * INFO_N;
     return StepInfo<T>{info[INFO_GINF], info[INFO_STEP], info[INFO_ZINF], info[INFO_LAM], info[INFO_D0], info[INFO_AMAX],
-                       info[INFO_LSK], info[INFO_LSA], info[INFO_RESTARTS]};
+                       info[INFO_LSK], info[INFO_LSA], info[INFO_RESTARTS], info[INFO_LSR],
+                       ((const T*)a.mu)[b], ((const T*)a.pen)[b], f[b], a.status[b]};
 }
 // zp, gp: the problem's iterate and defects (global memory, or the Riccati kernel's LDS copies)
 template <typename T>
@@ -1025,14 +1146,14 @@ __device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, i
     const int H = a.H, nx = a.nx;
     lsd = 1;
     al = T(0);
-    if (a.status[b] >= 0) { if (lane == 0) a.lsdone[b] = 1; return; }
+    if (si.status >= 0) { if (lane == 0) a.lsdone[b] = 1; return; }
     if (si.restarts < T(0)) {    // the Riccati sweep ran out of attempts: no step this iteration, still unconverged
         if (lane == 0) { a.lsdone[b] = 1; atomicAdd(a.n_active, 1); }
         return;
     }
     // converged for the current barrier parameter?  Sub-problems with mu above its floor are only solved to
     // an accuracy proportional to mu (kappa = 10); the last one to the requested tolerances.
-    const T mub = mu[b];
+    const T mub = si.mu;
     const bool last_mu = !(mub > (T)a.mu_min * T(1.0001));
     const T tg = last_mu ? (T)a.tol_g : fmax((T)a.tol_g, T(10) * mub);
     const T tsx = last_mu ? (T)a.tol_step * (T(1) + si.zinf) : fmax((T)a.tol_step, T(10) * mub) * (T(1) + si.zinf);
@@ -1057,15 +1178,15 @@ __device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, i
     lsd = 0;
     al = si.lsk > T(0) ? fmin(si.amax, si.lsa) : si.amax;
     if (lane == 0) {
-        const T nun = fmax(nu[b], T(1.5) * si.lam + T(1e-3));
+        const T nun = fmax(si.nu, T(1.5) * si.lam + T(1e-3));
         nu[b] = nun;
-        phi0[b] = (T)((double)f[b] + bar + (double)nun * g1);
+        phi0[b] = (T)((double)si.f + bar + (double)nun * g1);
         dir[b] = si.d0 - nun * (T)g1;
         alpha[b] = al;
         // a retry iteration re-solves with the damping the opening iteration had to raise, so its own restart count
         // is zero: remember the opening one, or the accept below relaxes a term that was only just raised
         T* infw = (T*)a.info + (size_t)b * INFO_N;
-        infw[INFO_LSR] = si.lsk > T(0) ? fmax(infw[INFO_LSR], si.restarts) : si.restarts;
+        infw[INFO_LSR] = si.lsk > T(0) ? fmax(si.lsr, si.restarts) : si.restarts;
         a.lsdone[b] = 0;
         atomicAdd(a.n_active, 1);
     }
@@ -1082,10 +1203,10 @@ __global__ __launch_bounds__(64) void solver_step_kernel(SolverArgs a, const T* 
     if (b >= a.B) return;
     const T* z = Zcur + (size_t)b * a.n;
     const T* dz = (const T*)a.dz + (size_t)b * a.n;
-    solver_dual_body<T>(a, b, lane, z, dz);
+    const StepInfo<T> si = step_info_from<T>(a, b, f);
+    solver_dual_body<T>(a, b, lane, z, dz, si.mu, si.status);
     int lsd;
     T al;
-    const StepInfo<T> si = step_info_from<T>((const T*)a.info + (size_t)b * INFO_N);
     solver_merit0_body<T>(a, b, lane, f, z, (const T*)a.g + (size_t)b * a.m, si, lsd, al);
     for (int i = lane; i < a.n; i += 64) Zt[(size_t)b * a.n + i] = lsd ? z[i] : fma(al, dz[i], z[i]);
 }
@@ -1483,7 +1604,10 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         a.armijo_slack = std::max(1e-12, slack_eps * (double)std::numeric_limits<T>::epsilon());
     }
     a.max_ls = o.max_linesearch;
-    auto lqk = (nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1> : ((nx == 6 && nu == 3) ? solver_lq_kernel<T, 6, 3> : solver_lq_kernel<T, 0, 0>);
+    auto lqk = a.use_lds ? ((nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1, true>
+                                                  : ((nx == 6 && nu == 3) ? solver_lq_kernel<T, 6, 3, true> : solver_lq_kernel<T, 0, 0, true>))
+                         : ((nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1, false>
+                                                  : ((nx == 6 && nu == 3) ? solver_lq_kernel<T, 6, 3, false> : solver_lq_kernel<T, 0, 0, false>));
     // wave-per-problem sweep when the working set is staged in LDS and a stage has enough entries to spread over a
     // wave: 6/3 stages 6.5 k vs 5.0 k MPC solves/s at C3; 2/1 stages are 4 entries wide and stay on the
     // thread-per-problem kernel (22.0 vs 23.1 ms per 40 iterations at C2).  nempc_solver_opts.lq_kernel forces one.
@@ -1543,6 +1667,16 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         // LDS mode: four waves stage the working set, the first ppw lanes run the sweeps
         hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (Bact + a.ppw - 1) / a.ppw : (Bact + 63) / 64), dim3(a.use_lds ? 256 : 64),
                            lds_need, s, a);
+#ifdef NEMPC_LQ_STAMPS
+        if (it == 3) {
+            long long st[16];
+            hipStreamSynchronize(s);
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(nempc_lq_stamps), sizeof(st));
+            fprintf(stderr, "lq stamps (cycles since start):");
+            for (int i = 1; i <= 8; ++i) fprintf(stderr, " %lld", st[i] - st[0]);
+            fprintf(stderr, "\n");
+        }
+#endif
         if (!a.fuse_step)
             hipLaunchKernelGGL(solver_step_kernel<T>, dim3(Bact), dim3(64), 0, s, a, (const T*)ws.f, (const T*)Zc, (T*)ws.Zt);
         // Convergence poll, one period late: the counter of THIS iteration is copied to a pinned slot behind an event and the

@@ -14,6 +14,8 @@ def main():
     os.makedirs(out, exist_ok=True)
     # only the translation units that see the kernels are rebuilt with the flags; the rest come from the main build
     kern = {"kernels_mfma_f64.hip", "kernels_mfma_f32.hip"} if "--all" not in sys.argv else set(_build.SOURCES)
+    if "--only" in sys.argv:
+        kern = set(sys.argv[sys.argv.index("--only") + 1].split(","))
     _build.build(verbose=False)
     def one(src):
         if src in kern:
