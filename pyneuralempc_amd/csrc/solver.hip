@@ -390,6 +390,33 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     // lane; the levels are known beforehand: decade steps).  `spec` lanes per problem now run the levels of a round at the
     // same time, each into its own region of the problem's block; the FIRST level that goes through is the one used, so
     // the result is what the sequential attempts gave.
+    constexpr bool PREF = FIX && NX * (NX + NU) + (NX + NU) * (NX + NU) <= 16;
+    struct StageIn {
+        T At[PREF ? NX * (NX + NU) : 1], W[PREF ? (NX + NU) * (NX + NU) : 1], gc[PREF ? NX : 1], gru[PREF ? NU : 1],
+            bhu[PREF ? NU : 1], grx[PREF ? NX : 1], bhx[PREF ? NX : 1];
+    };
+    auto fetch_stage = [&](const int t, StageIn& d) {
+        #pragma unroll
+        for (int e = 0; e < nx * nin; ++e) d.At[PREF ? e : 0] = tl[(size_t)t * nx * nin + e];
+        #pragma unroll
+        for (int e = 0; e < nin * nin; ++e) d.W[PREF ? e : 0] = Wb[(size_t)t * nin * nin + e];
+        #pragma unroll
+        for (int i = 0; i < nx; ++i) d.gc[PREF ? i : 0] = gc[t * nx + i];
+        #pragma unroll
+        for (int i = 0; i < nu; ++i) { d.gru[PREF ? i : 0] = gr[uo + t * nu + i]; d.bhu[PREF ? i : 0] = bh[uo + t * nu + i]; }
+        if (t > 0) {
+            #pragma unroll
+            for (int i = 0; i < nx; ++i) { d.grx[PREF ? i : 0] = gr[(t - 1) * nx + i]; d.bhx[PREF ? i : 0] = bh[(t - 1) * nx + i]; }
+        }
+    };
+#define AT(e) (PREF ? cur.At[PREF ? (e) : 0] : At[e])
+#define WT(e) (PREF ? cur.W[PREF ? (e) : 0] : Wt[e])
+#define GC(k) (PREF ? cur.gc[PREF ? (k) : 0] : gc[t * nx + (k)])
+#define GRU(i) (PREF ? cur.gru[PREF ? (i) : 0] : gr[uo + t * nu + (i)])
+#define BHU(i) (PREF ? cur.bhu[PREF ? (i) : 0] : bh[uo + t * nu + (i)])
+#define GRX(i) (PREF ? cur.grx[PREF ? (i) : 0] : gr[(t - 1) * nx + (i)])
+#define BHX(i) (PREF ? cur.bhx[PREF ? (i) : 0] : bh[(t - 1) * nx + (i)])
+    StageIn sin_a, sin_b;
     int restarts = 0;
     bool solved = false, any = false;
     const T reg_in = reg;
@@ -405,13 +432,15 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         ha = bh[(H - 1) * nx + i];
         #pragma unroll
         for (int j = 0; j < nx; ++j) TMP(oP + i * nx + j) = QTs[i * nx + j] + (i == j ? ha : T(0));   // terminal weight
-        TMP(op + i) = gr[(H - 1) * nx + i] + ga;
+        TMP(op + i) = gr[(H - 1) * nx + i];
     }
-#ifdef NEMPC_LQ_EXP_NOBACK
-    for (int t = H - 1; t >= H - 1 && pd; --t) {
-#else
-    for (int t = H - 1; t >= 0 && pd; --t) {
-#endif
+    if (PREF && pd) fetch_stage(H - 1, sin_a);
+    // One stage of the backward recursion.  Small stages (2/1): the stage's inputs (tile, Lagrangian block, defects,
+    // gradient and barrier entries) come from registers that were loaded a whole stage earlier (`cur`), and the next
+    // stage's are requested at the top (`nxt`) -- the sweep no longer stops four or five times per stage for an LDS
+    // round trip behind the stores of the recursion, which the compiler must assume to alias the loads.
+    auto stage = [&](const int t, const StageIn& cur, StageIn& nxt) -> bool {
+        if (PREF && t > 0) fetch_stage(t - 1, nxt);
         const T* At = tl + (size_t)t * nx * nin;   // [i][0:nx] = A, [i][nx:] = B
         const T* Wt = Wb + (size_t)t * nin * nin;  // Lagrangian block over (x_{t-1}, u_t)
         #pragma unroll
@@ -423,48 +452,48 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         // PA = P A, PB = P B, Pc = P c + p
         #pragma unroll
         for (int i = 0; i < nx; ++i) {
-            if (t > 0)
+            if (t > 0 || FIX)     // (fixed shapes: unconditional -- a guard turns into a select per entry and stage)
                 #pragma unroll
                 for (int j = 0; j < nx; ++j) {
                     T v = T(0);
                     #pragma unroll
-                    for (int k = 0; k < nx; ++k) v = fma(TMP(oP + i * nx + k), At[k * nin + j], v);
+                    for (int k = 0; k < nx; ++k) v = fma(TMP(oP + i * nx + k), AT(k * nin + j), v);
                     TMP(oPA + i * nx + j) = v;
                 }
             #pragma unroll
             for (int j = 0; j < nu; ++j) {
                 T v = T(0);
                 #pragma unroll
-                for (int k = 0; k < nx; ++k) v = fma(TMP(oP + i * nx + k), At[k * nin + nx + j], v);
+                for (int k = 0; k < nx; ++k) v = fma(TMP(oP + i * nx + k), AT(k * nin + nx + j), v);
                 TMP(oPB + i * nu + j) = v;
             }
             T v = TMP(op + i);
             #pragma unroll
-            for (int k = 0; k < nx; ++k) v = fma(TMP(oP + i * nx + k), gc[t * nx + k], v);
+            for (int k = 0; k < nx; ++k) v = fma(TMP(oP + i * nx + k), GC(k), v);
             TMP(oPc + i) = v;
         }
         // Quu = Rs + barrier + reg + B' PB ; qu = gu + barrier + B' Pc ; Qux = B' PA
         #pragma unroll
         for (int i = 0; i < nu; ++i) {
             T ga = T(0), ha = T(0);
-            ha = bh[uo + t * nu + i];
+            ha = BHU(i);
             #pragma unroll
             for (int j = 0; j < nu; ++j) {
-                T v = RS(i * nu + j) + Wt[(nx + i) * nin + nx + j] + (i == j ? ha + reg : T(0));
+                T v = RS(i * nu + j) + WT((nx + i) * nin + nx + j) + (i == j ? ha + reg : T(0));
                 #pragma unroll
-                for (int k = 0; k < nx; ++k) v = fma(At[k * nin + nx + i], TMP(oPB + k * nu + j), v);
+                for (int k = 0; k < nx; ++k) v = fma(AT(k * nin + nx + i), TMP(oPB + k * nu + j), v);
                 TMP(oQuu + i * nu + j) = v;
             }
-            T v = gr[uo + t * nu + i] + ga;
+            T v = GRU(i);
             #pragma unroll
-            for (int k = 0; k < nx; ++k) v = fma(At[k * nin + nx + i], TMP(oPc + k), v);
+            for (int k = 0; k < nx; ++k) v = fma(AT(k * nin + nx + i), TMP(oPc + k), v);
             TMP(oqu + i) = v;
-            if (t > 0)
+            if (t > 0 || FIX)     // (fixed shapes: unconditional -- a guard turns into a select per entry and stage)
                 #pragma unroll
                 for (int j = 0; j < nx; ++j) {
-                    T w = Wt[(nx + i) * nin + j];
+                    T w = WT((nx + i) * nin + j);
                     #pragma unroll
-                    for (int k = 0; k < nx; ++k) w = fma(At[k * nin + nx + i], TMP(oPA + k * nx + j), w);
+                    for (int k = 0; k < nx; ++k) w = fma(AT(k * nin + nx + i), TMP(oPA + k * nx + j), w);
                     TMP(oQux + i * nx + j) = w;
                 }
         }
@@ -487,9 +516,9 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                 TMP(oQuu + i * nu + j) = v * d;
             }
         }
-        if (!pd) break;
+        if (!pd) return false;
         // kv = -Quu^-1 qu ; K = -Quu^-1 Qux   (forward then backward substitution, column by column)
-        const int ncolK = t > 0 ? nx : 0;
+        const int ncolK = t > 0 || FIX ? nx : 0;
         for (int col = -1; col < ncolK; ++col) {
             #pragma unroll
             for (int i = 0; i < nu; ++i) {
@@ -517,19 +546,19 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             #pragma unroll
             for (int i = 0; i < nx; ++i) {
                 T ga = T(0), ha = T(0);
-                ha = bh[(t - 1) * nx + i];
+                ha = BHX(i);
                 #pragma unroll
                 for (int j = 0; j < nx; ++j) {
-                    T v = QS(i * nx + j) + Wt[i * nin + j] + (i == j ? ha : T(0));
+                    T v = QS(i * nx + j) + WT(i * nin + j) + (i == j ? ha : T(0));
                     #pragma unroll
-                    for (int k = 0; k < nx; ++k) v = fma(At[k * nin + i], TMP(oPA + k * nx + j), v);
+                    for (int k = 0; k < nx; ++k) v = fma(AT(k * nin + i), TMP(oPA + k * nx + j), v);
                     #pragma unroll
                     for (int k = 0; k < nu; ++k) v = fma(TMP(oQux + k * nx + i), TMP(oK + k * nx + j), v);
                     TMP(oPn + i * nx + j) = v;
                 }
-                T v = gr[(t - 1) * nx + i] + ga;
+                T v = GRX(i);
                 #pragma unroll
-                for (int k = 0; k < nx; ++k) v = fma(At[k * nin + i], TMP(oPc + k), v);
+                for (int k = 0; k < nx; ++k) v = fma(AT(k * nin + i), TMP(oPc + k), v);
                 #pragma unroll
                 for (int k = 0; k < nu; ++k) v = fma(TMP(oQux + k * nx + i), TMP(okv + k), v);
                 TMP(opn + i) = v;
@@ -537,10 +566,20 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             #pragma unroll
             for (int i = 0; i < nx; ++i) {
                 #pragma unroll
-                for (int j = 0; j < nx; ++j) TMP(oP + i * nx + j) = T(0.5) * (TMP(oPn + i * nx + j) + TMP(oPn + j * nx + i));
+                for (int j = 0; j < nx; ++j)
+                    TMP(oP + i * nx + j) = i == j ? TMP(oPn + i * nx + j) : T(0.5) * (TMP(oPn + i * nx + j) + TMP(oPn + j * nx + i));
                 TMP(op + i) = TMP(opn + i);
             }
         }
+            return true;
+    };
+#ifdef NEMPC_LQ_EXP_NOBACK
+    for (int t = H - 1; t >= H - 1 && pd; t -= 2) {
+#else
+    for (int t = H - 1; t >= 0 && pd; t -= 2) {
+#endif
+        pd = stage(t, sin_a, sin_b);
+        if (pd && t > 0) pd = stage(t - 1, sin_b, sin_a);
     }
     {
         const unsigned long long ok = __ballot(pd);
@@ -576,6 +615,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         info[INFO_RESTARTS] = (T)(-restarts);
         if (LDS) blk[Lbh] = (T)(-restarts);          // (the barrier diagonal is no longer needed: slot for the post-pass)
     } else {
+    LQ_STAMP(9);
     // forward sweep
     // The norms, the directional derivative and the fraction-to-the-boundary length of the step are NOT part of the
     // recursion: in LDS mode a wave per problem computes them from the staged arrays after the sweeps (below), with its
@@ -656,6 +696,13 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
 #undef TMP
 #undef QS
 #undef RS
+#undef AT
+#undef WT
+#undef GC
+#undef GRU
+#undef BHU
+#undef GRX
+#undef BHX
     }
     LQ_STAMP(2);
     if (LDS) {
@@ -1225,39 +1272,60 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T*
     const T* lb = (const T*)a.lb;
     const T* ub = (const T*)a.ub;
     const int H = a.H, nx = a.nx;
-    if (a.lsdone[b]) return;
+    // the problem's scalars, requested together (one global round trip instead of one per use)
+    const int done = a.lsdone[b];
+    const T mub = mu[b], nub = nu[b], ftb = ft[b], al = alpha[b], ph0 = phi0[b], drb = dir[b];
+    const T az = a.primal_dual ? ((const T*)a.alz)[b] : T(0);
+    const T lsr = info[INFO_LSR], lsk = info[INFO_LSK], regb = reg[b];
+    if (done) return;
     const T* zt = Zt + (size_t)b * a.n;
-    const double bar = barrier_value<T>(zt, lb, ub, a.n, mu[b], lane);
-    const double g1 = l1_norm<T>(gt + (size_t)b * a.m, H * nx, lane);
-    const T phit = (T)((double)ft[b] + bar + (double)nu[b] * g1);
-    const T al = alpha[b];
+    const T* gtb = gt + (size_t)b * a.m;
+    // log-barrier value and l1 norm of the defects at the trial point, one loop (the loads of both in flight together;
+    // per-lane order and tree as barrier_value / l1_norm)
+    double accb = 0.0, accg = 0.0;
+    for (int i = lane; i < a.n; i += 64) {
+        const T zi = zt[i], lo = lb[i], hi = ub[i];
+        const T gi = i < H * nx ? gtb[i] : T(0);
+        if (mub > T(0)) {
+            if (lo > -std::numeric_limits<T>::max()) accb -= (double)mub * log((double)(zi - lo));
+            if (hi < std::numeric_limits<T>::max()) accb -= (double)mub * log((double)(hi - zi));
+        }
+        if (i < H * nx) accg += fabs((double)gi);
+    }
+    const double bar = wave_bcast_lane0(wave_sum_lane0(accb));
+    const double g1 = wave_bcast_lane0(wave_sum_lane0(accg));
+    const T phit = (T)((double)ftb + bar + (double)nub * g1);
     // Armijo on the l1 merit; the directional derivative is negative for a descent direction
     // the slack absorbs the rounding of the merit value itself (f is a sum of ~n terms in T): without a dtype-sized one
     // an fp32 iterate close to its solution fails the test on noise, halves its step six times and gets damped
     const T slack = (T)a.armijo_slack;
-    const bool ok = (phit == phit) && phit <= phi0[b] + T(1e-4) * al * fmin(dir[b], T(0)) + slack * fabs(phi0[b]);
+    const bool ok = (phit == phit) && phit <= ph0 + T(1e-4) * al * fmin(drb, T(0)) + slack * fabs(ph0);
     if (ok) {
-        for (int i = lane; i < a.n; i += 64) Zcur[(size_t)b * a.n + i] = zt[i];
         T* lam = (T*)a.lam + (size_t)b * a.m;
         const T* lamn = (const T*)a.lamn + (size_t)b * a.m;
-        for (int i = lane; i < H * nx; i += 64) lam[i] = fma(al, lamn[i] - lam[i], lam[i]);
-        if (a.primal_dual && mu[b] > T(0)) {
-            // bound multipliers: their own step length, then kept within a factor kappa of mu / slack at the new point
-            // (the safeguard of primal-dual interior-point codes: a multiplier far from the central path is pulled back)
-            const T az = ((const T*)a.alz)[b], kap = T(1e10);
-            T* zl = (T*)a.zl + (size_t)b * a.n;
-            T* zu = (T*)a.zu + (size_t)b * a.n;
-            const T* dzl = (const T*)a.dzl + (size_t)b * a.n;
-            const T* dzu = (const T*)a.dzu + (size_t)b * a.n;
-            for (int i = lane; i < a.n; i += 64) {
-                if (lb[i] > -std::numeric_limits<T>::max()) {
-                    const T c = mu[b] / (zt[i] - lb[i]);
-                    zl[i] = fmin(fmax(fma(az, dzl[i], zl[i]), c / kap), c * kap);
-                }
-                if (ub[i] < std::numeric_limits<T>::max()) {
-                    const T c = mu[b] / (ub[i] - zt[i]);
-                    zu[i] = fmin(fmax(fma(az, dzu[i], zu[i]), c / kap), c * kap);
-                }
+        // bound multipliers: their own step length, then kept within a factor kappa of mu / slack at the new point
+        // (the safeguard of primal-dual interior-point codes: a multiplier far from the central path is pulled back)
+        const bool duals = a.primal_dual && mub > T(0);
+        const T kap = T(1e10);
+        T* zl = (T*)a.zl + (size_t)b * a.n;
+        T* zu = (T*)a.zu + (size_t)b * a.n;
+        const T* dzl = (const T*)a.dzl + (size_t)b * a.n;
+        const T* dzu = (const T*)a.dzu + (size_t)b * a.n;
+        for (int i = lane; i < a.n; i += 64) {
+            const T zi = zt[i], lo = lb[i], hi = ub[i];
+            const bool lof = duals && lo > -std::numeric_limits<T>::max(), hif = duals && hi < std::numeric_limits<T>::max();
+            const bool isl = i < H * nx;
+            const T l0 = isl ? lam[i] : T(0), l1 = isl ? lamn[i] : T(0);
+            const T zl0 = lof ? zl[i] : T(0), dl = lof ? dzl[i] : T(0), zu0 = hif ? zu[i] : T(0), du = hif ? dzu[i] : T(0);
+            Zcur[(size_t)b * a.n + i] = zi;
+            if (isl) lam[i] = fma(al, l1 - l0, l0);
+            if (lof) {
+                const T c = mub / (zi - lo);
+                zl[i] = fmin(fmax(fma(az, dl, zl0), c / kap), c * kap);
+            }
+            if (hif) {
+                const T c = mub / (hi - zi);
+                zu[i] = fmin(fmax(fma(az, du, zu0), c / kap), c * kap);
             }
         }
         // relax the damping only after a sweep that went through at the first attempt: a term that had to be raised
@@ -1266,7 +1334,7 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T*
             a.lsdone[b] = 1;
             // relax the damping only after a sweep that went through at the first attempt: a term that had to be raised
             // this iteration would fail again right away and cost a full extra sweep
-            if (!(info[INFO_LSR] > T(0))) reg[b] = fmax(reg[b] * T(0.1), T(1e-9));
+            if (!(lsr > T(0))) reg[b] = fmax(regb * T(0.1), T(1e-9));
             ((T*)a.info)[(size_t)b * INFO_N + INFO_LSK] = T(0);
         }
     } else if (lane == 0) {
@@ -1275,15 +1343,15 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T*
             // deferred backtracking (one trial per outer iteration): remember the halved length for the next iteration;
             // after max_ls rejections in a row the direction is given up and the next LQ solve is damped
             T* inf = (T*)a.info + (size_t)b * INFO_N;
-            const T k = inf[INFO_LSK] + T(1);
+            const T k = lsk + T(1);
             a.lsdone[b] = 1;
-            if (k >= (T)a.max_ls) { inf[INFO_LSK] = T(0); reg[b] = fmin(fmax(reg[b] * T(100), T(1e-6)), T(1e8)); }
+            if (k >= (T)a.max_ls) { inf[INFO_LSK] = T(0); reg[b] = fmin(fmax(regb * T(100), T(1e-6)), T(1e8)); }
             else { inf[INFO_LSK] = k; inf[INFO_LSA] = al * T(0.5); }
         } else {
             if (!last_ls) atomicAdd(a.n_pending, 1);  // still searching: the host polls this to stop the backtracking early
             if (last_ls) {   // no progress: damp the next LQ solve
                 a.lsdone[b] = 1;
-                reg[b] = fmin(fmax(reg[b] * T(100), T(1e-6)), T(1e8));
+                reg[b] = fmin(fmax(regb * T(100), T(1e-6)), T(1e8));
                 ((T*)a.info)[(size_t)b * INFO_N + INFO_LSK] = T(0);
             }
         }
@@ -1673,7 +1741,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             hipStreamSynchronize(s);
             hipMemcpyFromSymbol(st, HIP_SYMBOL(nempc_lq_stamps), sizeof(st));
             fprintf(stderr, "lq stamps (cycles since start):");
-            for (int i = 1; i <= 8; ++i) fprintf(stderr, " %lld", st[i] - st[0]);
+            for (int i = 1; i <= 9; ++i) fprintf(stderr, " %lld", st[i] - st[0]);
             fprintf(stderr, "\n");
         }
 #endif
