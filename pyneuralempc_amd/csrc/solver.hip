@@ -57,8 +57,10 @@ struct SolverArgs {
     const void* lb; const void* ub;                                      // (n) device, dtype T, +-inf allowed
     void* mu; void* pen; void* reg; void* alpha; void* phi0; void* dir;  // (B) per problem (pen = l1 penalty)
     int lq_attempts;      // Riccati sweeps a problem may try per iteration before it sits the iteration out
+    int carry;            // the trial evaluation is a full one and becomes the next iterate's on acceptance (tiles_t, grad_t)
+    const void *tiles_t, *grad_t;
     int fuse_step;        // thread-per-problem Riccati kernel in LDS mode: it also does solver_step_kernel's work
-    const void* f_it; void* Zt_it;   // ... with the iterate's objective values (B) and the trial-point buffer (B,n)
+    void* f_it; void* Zt_it;   // ... with the iterate's objective values (B) and the trial-point buffer (B,n)
     int* status; int* lsdone; int* n_active; int* n_pending;   // counters the host polls: unconverged problems / problems still backtracking
     int* iters_done; int cur_it;                                         // per problem: iteration at which it converged
     // bounds, primal-dual: zl / zu (B,n) multipliers of z >= lb / z <= ub, their steps, and the barrier diagonal the LQ
@@ -1319,6 +1321,10 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T*
             const T zl0 = lof ? zl[i] : T(0), dl = lof ? dzl[i] : T(0), zu0 = hif ? zu[i] : T(0), du = hif ? dzu[i] : T(0);
             Zcur[(size_t)b * a.n + i] = zi;
             if (isl) lam[i] = fma(al, l1 - l0, l0);
+            if (a.carry) {      // the accepted point's evaluation is the next iterate's: no launch for it
+                ((T*)a.grad)[(size_t)b * a.n + i] = ((const T*)a.grad_t)[(size_t)b * a.n + i];
+                if (i < a.m) ((T*)a.g)[(size_t)b * a.m + i] = gtb[i];
+            }
             if (lof) {
                 const T c = mub / (zi - lo);
                 zl[i] = fmin(fmax(fma(az, dl, zl0), c / kap), c * kap);
@@ -1327,6 +1333,14 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T*
                 const T c = mub / (hi - zi);
                 zu[i] = fmin(fmax(fma(az, du, zu0), c / kap), c * kap);
             }
+        }
+        if (a.carry) {
+            const int ntl = H * nx * (nx + a.nu);
+            const T* ts = (const T*)a.tiles_t + (size_t)b * ntl;
+            T* td = (T*)a.tiles + (size_t)b * ntl;
+            for (int i = lane; i < ntl; i += 64) td[i] = ts[i];
+            for (int i = a.n + lane; i < a.m; i += 64) ((T*)a.g)[(size_t)b * a.m + i] = gtb[i];      // (rows beyond n, if any)
+            if (lane == 0) ((T*)a.f_it)[b] = ftb;
         }
         // relax the damping only after a sweep that went through at the first attempt: a term that had to be raised
         // this iteration would fail again right away and cost a full extra sweep
@@ -1480,6 +1494,7 @@ __global__ __launch_bounds__(256) void solver_scatter_kernel(int B, int n, const
 
 struct SolverWs {
     void *Zt = nullptr, *f = nullptr, *ft = nullptr, *grad = nullptr, *g = nullptr, *gt = nullptr, *tiles = nullptr;
+    void *tiles_t = nullptr, *grad_t = nullptr;     // trial point's tiles and objective gradient (carried over on acceptance)
     void *lb = nullptr, *ub = nullptr, *mu = nullptr, *nu = nullptr, *reg = nullptr, *alpha = nullptr, *phi0 = nullptr,
          *dir = nullptr, *hblk = nullptr, *lam = nullptr, *lamn = nullptr, *sig = nullptr, *dz = nullptr, *Kst = nullptr, *kst = nullptr, *Pst = nullptr, *pst = nullptr,
          *tmp = nullptr;   // (info lives in infoc: it is read across iterations)
@@ -1505,7 +1520,8 @@ void solver_free(Handle& h) {
     SolverWs* w = static_cast<SolverWs*>(h.solver_ws);
     if (!w) return;
     void** ptrs[] = {&w->Zt, &w->f, &w->ft, &w->grad, &w->g, &w->gt, &w->tiles, &w->lb, &w->ub, &w->mu, &w->nu, &w->reg,
-                     &w->alpha, &w->phi0, &w->dir, &w->hblk, &w->lam, &w->lamn, &w->sig, &w->dz, &w->Kst, &w->kst, &w->Pst, &w->pst, &w->tmp};
+                     &w->alpha, &w->phi0, &w->dir, &w->hblk, &w->lam, &w->lamn, &w->sig, &w->dz, &w->Kst, &w->kst, &w->Pst, &w->pst, &w->tmp,
+                     &w->tiles_t, &w->grad_t};
     for (void** p : ptrs)
         if (*p) (void)hipFree(*p);
     if (w->lsdone) (void)hipFree(w->lsdone);
@@ -1559,7 +1575,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                 {&w2.sig, Bn * e}, {&w2.dz, Bn * n * e}, {&w2.Kst, Bn * H * nu * nx * e},
                 {&w2.kst, Bn * H * nu * e}, {&w2.Pst, Bn * H * nx * nx * e}, {&w2.pst, Bn * H * nx * e},
                 {&w2.tmp, Bn * lq_tmp_elems(nx, nu) * e}, {&w2.dzl, Bn * n * e}, {&w2.dzu, Bn * n * e}, {&w2.alz, Bn * e},
-                {&w2.bh, Bn * n * e}};
+                {&w2.bh, Bn * n * e}, {&w2.tiles_t, Bn * H * nx * nin * e}, {&w2.grad_t, Bn * n * e}};
             for (auto& x : al) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
             for (int k = 0; k < 2; ++k) {
                 struct { void** p; size_t bytes; } al2[] = {
@@ -1693,6 +1709,11 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lqk), lds_max));
     }
 
+    static const int no_carry = [] { const char* e = getenv("NEMPC_SOLVER_NO_CARRY"); return e ? atoi(e) : 0; }();   // A/B knob
+    const int lsm_carry = o.linesearch == 0 ? (wave_wanted ? 1 : 2) : o.linesearch;
+    bool carry = lsm_carry == 2 && !no_carry && a.use_lds && h.variant == NEMPC_KERNEL_MFMA && h.cfg.integrator != NEMPC_RK4;
+    bool have_eval = false;       // the evaluation buffers hold every active problem's current iterate
+    a.carry = 0; a.tiles_t = ws.tiles_t; a.grad_t = ws.grad_t;
     int poll_pending = -1;        // slot of the convergence-counter copy that is in flight, -1: none
     int poll_it[2] = {0, 0};      // iteration at which each slot's copy was issued
     const bool lagged_polls = !wave_wanted;     // small stages: iterations are chains of latency-bound launches
@@ -1715,7 +1736,13 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         // Gauss-Newton step).  The RK4 matrix-core pipeline produces defects, tiles and blocks from one row launch.
         const bool rk4_pipeline = h.variant != NEMPC_KERNEL_VALU && h.cfg.integrator == NEMPC_RK4;
         bool fused_eval = false;
-        if (rk4_pipeline) {
+        if (have_eval) {
+            // deferred backtracking on a compiled shape: the trial evaluation of the last iteration was a full one and the
+            // acceptance kernel kept, per problem, the evaluation of the point it stands on -- only the blocks are new
+            fused_eval = true;
+            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rowhess_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s)
+                                                : launch_rowhess_valu(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s);
+        } else if (rk4_pipeline) {
             rc = launch_rowhess_rk4_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s, ws.g, ws.tiles);
         } else {
             // compiled shapes: defects, tiles, f and grad from one launch
@@ -1798,8 +1825,18 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                                    (const T*)ws.alpha, (const int*)ws.lsdone, (T*)ws.Zt, a.n_pending);
             // the merit function needs the defects only: the matrix-core kernel skips its reverse sweeps (tiles = null)
             // (compiled shapes: defects and f of the trial point from one forward-only launch)
-            const bool fused_trial = h.variant == NEMPC_KERNEL_MFMA &&
-                (rc = launch_eval_fused(h, Bact, ws.Zt, X0c, ws.gt, nullptr, nullptr, ws.ft, nullptr, s)) != NEMPC_EUNSUPPORTED;
+            bool fused_trial = false;
+            a.carry = 0;
+            if (carry) {
+                // full evaluation of the trial point (tiles and gradient too): it is the next iterate's if accepted
+                fused_trial = (rc = launch_eval_fused(h, Bact, ws.Zt, X0c, ws.gt, ws.tiles_t, nullptr, ws.ft, ws.grad_t, s)) !=
+                              NEMPC_EUNSUPPORTED;
+                if (!fused_trial) carry = false;      // not a compiled shape
+                else a.carry = 1;
+            }
+            if (!fused_trial)
+                fused_trial = h.variant == NEMPC_KERNEL_MFMA &&
+                    (rc = launch_eval_fused(h, Bact, ws.Zt, X0c, ws.gt, nullptr, nullptr, ws.ft, nullptr, s)) != NEMPC_EUNSUPPORTED;
             if (!fused_trial)
                 rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, Bact, ws.Zt, X0c, ws.gt, nullptr, s)
                                                     : launch_rows_valu(h, Bact, ws.Zt, X0c, ws.gt, h.d_tiles_ws, s);
@@ -1808,6 +1845,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(Bact), dim3(64), 0, s, a, (const T*)ws.Zt,
                                (const T*)ws.gt, (const T*)ws.ft, (T*)Zc,
                                lsm == 2 ? 2 : (ls + 1 == o.max_linesearch ? 1 : 0));
+            have_eval = a.carry != 0;
             if (lsm == 2) break;          // one trial per outer iteration: nothing to poll
             // most iterations accept the first trial for every problem: one small poll saves the remaining
             // max_linesearch-1 callback evaluations
@@ -1890,6 +1928,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             // kernel, and no stream synchronisation is needed to learn the exact count
             cur = nxt;
             point_at(cur);
+            have_eval = false;            // (the evaluation buffers are not gathered: one launch after a compaction)
             if (lagged_polls) {
                 Bact = nact > 0 ? (nact < Bact ? nact : Bact) : 1;
             } else {
