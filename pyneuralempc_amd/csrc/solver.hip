@@ -1263,11 +1263,16 @@ __global__ __launch_bounds__(64) void solver_step_kernel(SolverArgs a, const T* 
 // Acceptance test of a trial point (Armijo on the l1 merit), one wave per problem
 template <typename T>
 __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T* __restrict__ Zt, const T* __restrict__ gt,
-                                                          const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+                                                          const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls,
+                                                          const int* __restrict__ list_in, int* __restrict__ list_out) {
+    // list_in: the trial buffers (Zt, gt, ft) hold only the problems that were still searching after the previous trial,
+    // densely, in the order of that list (inner-loop backtracking); null: one slot per problem.  list_out: the problems
+    // this trial rejects are appended for the next one.
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    const int b = list_in ? list_in[slot] : slot;
     // the convergence counter of the NEXT iteration, when its test runs inside the Riccati kernel (the host's copy of this
     // iteration's count was issued before this launch)
-    if (b == 0 && lane == 0 && a.fuse_step) *a.n_active = 0;
+    if (slot == 0 && lane == 0 && a.fuse_step) *a.n_active = 0;
     if (b >= a.B) return;
     T* mu = (T*)a.mu; T* nu = (T*)a.pen; T* reg = (T*)a.reg; T* alpha = (T*)a.alpha; T* phi0 = (T*)a.phi0; T* dir = (T*)a.dir;
     const T* info = (const T*)a.info + (size_t)b * INFO_N;
@@ -1276,12 +1281,12 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T*
     const int H = a.H, nx = a.nx;
     // the problem's scalars, requested together (one global round trip instead of one per use)
     const int done = a.lsdone[b];
-    const T mub = mu[b], nub = nu[b], ftb = ft[b], al = alpha[b], ph0 = phi0[b], drb = dir[b];
+    const T mub = mu[b], nub = nu[b], ftb = ft[slot], al = alpha[b], ph0 = phi0[b], drb = dir[b];
     const T az = a.primal_dual ? ((const T*)a.alz)[b] : T(0);
     const T lsr = info[INFO_LSR], lsk = info[INFO_LSK], regb = reg[b];
     if (done) return;
-    const T* zt = Zt + (size_t)b * a.n;
-    const T* gtb = gt + (size_t)b * a.m;
+    const T* zt = Zt + (size_t)slot * a.n;
+    const T* gtb = gt + (size_t)slot * a.m;
     // log-barrier value and l1 norm of the defects at the trial point, one loop (the loads of both in flight together;
     // per-lane order and tree as barrier_value / l1_norm)
     double accb = 0.0, accg = 0.0;
@@ -1362,7 +1367,10 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T*
             if (k >= (T)a.max_ls) { inf[INFO_LSK] = T(0); reg[b] = fmin(fmax(regb * T(100), T(1e-6)), T(1e8)); }
             else { inf[INFO_LSK] = k; inf[INFO_LSA] = al * T(0.5); }
         } else {
-            if (!last_ls) atomicAdd(a.n_pending, 1);  // still searching: the host polls this to stop the backtracking early
+            if (!last_ls) {     // still searching: the host polls the counter to stop the backtracking early
+                const int p = atomicAdd(a.n_pending, 1);
+                if (list_out) list_out[p] = b;
+            }
             if (last_ls) {   // no progress: damp the next LQ solve
                 a.lsdone[b] = 1;
                 reg[b] = fmin(fmax(regb * T(100), T(1e-6)), T(1e8));
@@ -1386,15 +1394,23 @@ __global__ __launch_bounds__(256) void solver_defer_kernel(SolverArgs a) {
     else { inf[INFO_LSK] = k; inf[INFO_LSA] = ((const T*)a.alpha)[b]; }
 }
 
+// Next trial point of the problems still searching (inner-loop backtracking), gathered densely in the order of `list`
+// together with their initial states and per-problem extras: the trial evaluation then runs over those problems only
+// (a trial over the whole active batch cost the same whether one problem or all of them were still searching)
 template <typename T>
-__global__ __launch_bounds__(256) void solver_trial_kernel(int B, int n, const T* __restrict__ Z, const T* __restrict__ dz,
-                                                           const T* __restrict__ alpha, const int* __restrict__ lsdone,
-                                                           T* __restrict__ Zt, int* __restrict__ n_pending) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *n_pending = 0;         // counter of the problems still searching after this trial
-    if (i >= (size_t)B * n) return;
-    const int b = (int)(i / n);
-    Zt[i] = lsdone[b] ? Z[i] : fma(alpha[b], dz[i], Z[i]);
+__global__ __launch_bounds__(64) void solver_trial_list_kernel(int n, int nx, int ex_per, const int* __restrict__ list,
+                                                               const T* __restrict__ Z, const T* __restrict__ dz,
+                                                               const T* __restrict__ alpha, const T* __restrict__ X0,
+                                                               const T* __restrict__ ex, T* __restrict__ Zt,
+                                                               T* __restrict__ X0p, T* __restrict__ exp_,
+                                                               int* __restrict__ n_pending) {
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (slot == 0 && lane == 0) *n_pending = 0;         // counter of the problems still searching after this trial
+    const int b = list[slot];
+    const T al = alpha[b];
+    for (int i = lane; i < n; i += 64) Zt[(size_t)slot * n + i] = fma(al, dz[(size_t)b * n + i], Z[(size_t)b * n + i]);
+    for (int i = lane; i < nx; i += 64) X0p[(size_t)slot * nx + i] = X0[(size_t)b * nx + i];
+    for (int i = lane; i < ex_per; i += 64) exp_[(size_t)slot * ex_per + i] = ex[(size_t)b * ex_per + i];
 }
 
 // strictly interior start + per-problem state
@@ -1495,6 +1511,8 @@ __global__ __launch_bounds__(256) void solver_scatter_kernel(int B, int n, const
 struct SolverWs {
     void *Zt = nullptr, *f = nullptr, *ft = nullptr, *grad = nullptr, *g = nullptr, *gt = nullptr, *tiles = nullptr;
     void *tiles_t = nullptr, *grad_t = nullptr;     // trial point's tiles and objective gradient (carried over on acceptance)
+    void *X0p = nullptr, *exp_ = nullptr;           // initial states / extras of the problems still backtracking, dense
+    int* pend[2] = {nullptr, nullptr};              // ... and their indices (two lists: one read, one appended to)
     void *lb = nullptr, *ub = nullptr, *mu = nullptr, *nu = nullptr, *reg = nullptr, *alpha = nullptr, *phi0 = nullptr,
          *dir = nullptr, *hblk = nullptr, *lam = nullptr, *lamn = nullptr, *sig = nullptr, *dz = nullptr, *Kst = nullptr, *kst = nullptr, *Pst = nullptr, *pst = nullptr,
          *tmp = nullptr;   // (info lives in infoc: it is read across iterations)
@@ -1521,10 +1539,12 @@ void solver_free(Handle& h) {
     if (!w) return;
     void** ptrs[] = {&w->Zt, &w->f, &w->ft, &w->grad, &w->g, &w->gt, &w->tiles, &w->lb, &w->ub, &w->mu, &w->nu, &w->reg,
                      &w->alpha, &w->phi0, &w->dir, &w->hblk, &w->lam, &w->lamn, &w->sig, &w->dz, &w->Kst, &w->kst, &w->Pst, &w->pst, &w->tmp,
-                     &w->tiles_t, &w->grad_t};
+                     &w->tiles_t, &w->grad_t, &w->X0p, &w->exp_};
     for (void** p : ptrs)
         if (*p) (void)hipFree(*p);
     if (w->lsdone) (void)hipFree(w->lsdone);
+    for (int k = 0; k < 2; ++k)
+        if (w->pend[k]) (void)hipFree(w->pend[k]);
     if (w->n_active) (void)hipFree(w->n_active);
     if (w->hpoll) (void)hipHostFree(w->hpoll);
     for (int k = 0; k < 2; ++k)
@@ -1575,7 +1595,8 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                 {&w2.sig, Bn * e}, {&w2.dz, Bn * n * e}, {&w2.Kst, Bn * H * nu * nx * e},
                 {&w2.kst, Bn * H * nu * e}, {&w2.Pst, Bn * H * nx * nx * e}, {&w2.pst, Bn * H * nx * e},
                 {&w2.tmp, Bn * lq_tmp_elems(nx, nu) * e}, {&w2.dzl, Bn * n * e}, {&w2.dzu, Bn * n * e}, {&w2.alz, Bn * e},
-                {&w2.bh, Bn * n * e}, {&w2.tiles_t, Bn * H * nx * nin * e}, {&w2.grad_t, Bn * n * e}};
+                {&w2.bh, Bn * n * e}, {&w2.tiles_t, Bn * H * nx * nin * e}, {&w2.grad_t, Bn * n * e},
+                {&w2.X0p, Bn * nx * e}, {&w2.exp_, Bn * ex_per * e}};
             for (auto& x : al) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
             for (int k = 0; k < 2; ++k) {
                 struct { void** p; size_t bytes; } al2[] = {
@@ -1587,8 +1608,9 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                 for (auto& x : al2) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
             }
             NEMPC_HIP(hipMalloc((void**)&w2.lsdone, Bn * sizeof(int)));
+            for (int k = 0; k < 2; ++k) NEMPC_HIP(hipMalloc((void**)&w2.pend[k], Bn * sizeof(int)));
             NEMPC_HIP(hipMalloc((void**)&w2.n_active, 2 * sizeof(int)));   // [unconverged, still backtracking]
-            NEMPC_HIP(hipHostMalloc((void**)&w2.hpoll, 2 * sizeof(int), hipHostMallocDefault));
+            NEMPC_HIP(hipHostMalloc((void**)&w2.hpoll, 4 * sizeof(int), hipHostMallocDefault));   // [0,1]: convergence polls, [2]: backtracking poll
             for (int k = 0; k < 2; ++k) NEMPC_HIP(hipEventCreateWithFlags(&w2.pev[k], hipEventDisableTiming));
             NEMPC_HIP(hipMalloc((void**)&w2.perm, Bn * sizeof(int)));
             NEMPC_HIP(hipMalloc((void**)&w2.count, sizeof(int)));
@@ -1818,40 +1840,52 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         // extra trial is a latency-bound launch chain plus a host poll.  It spends more ITERATIONS on a hard problem
         // (a retry is an iteration), so max_iter budgets are larger than with the inner loop.
         const int lsm = o.linesearch == 0 ? (wave_wanted ? 1 : 2) : o.linesearch;
+        int pending = 0;
+        const void* const extra_all = h.d_extra;
         for (int ls = 0; ls < o.max_linesearch; ++ls) {
-            // the first trial point comes from solver_step_kernel; later ones (inner-loop backtracking) from here
-            if (ls > 0)
-                hipLaunchKernelGGL(solver_trial_kernel<T>, dim3(gAn), dim3(256), 0, s, Bact, n, (const T*)Zc, (const T*)ws.dz,
-                                   (const T*)ws.alpha, (const int*)ws.lsdone, (T*)ws.Zt, a.n_pending);
+            // the first trial point comes from solver_step_kernel (or the Riccati kernel), for every active problem; later
+            // ones (inner-loop backtracking) are built here for the problems still searching ONLY, densely: their
+            // evaluation and acceptance test run over `pending` problems instead of the whole active batch
+            const int nb = ls > 0 ? pending : Bact;
+            const void* X0t = X0c;
+            if (ls > 0) {
+                hipLaunchKernelGGL(solver_trial_list_kernel<T>, dim3(nb), dim3(64), 0, s, n, nx, (int)ex_per,
+                                   (const int*)ws.pend[ls & 1], (const T*)Zc, (const T*)ws.dz, (const T*)ws.alpha, (const T*)X0c,
+                                   (const T*)extra_all, (T*)ws.Zt, (T*)ws.X0p, (T*)ws.exp_, a.n_pending);
+                X0t = ws.X0p;
+                if (ex_per) h.d_extra = ws.exp_;
+            }
             // the merit function needs the defects only: the matrix-core kernel skips its reverse sweeps (tiles = null)
             // (compiled shapes: defects and f of the trial point from one forward-only launch)
             bool fused_trial = false;
             a.carry = 0;
             if (carry) {
                 // full evaluation of the trial point (tiles and gradient too): it is the next iterate's if accepted
-                fused_trial = (rc = launch_eval_fused(h, Bact, ws.Zt, X0c, ws.gt, ws.tiles_t, nullptr, ws.ft, ws.grad_t, s)) !=
+                fused_trial = (rc = launch_eval_fused(h, nb, ws.Zt, X0t, ws.gt, ws.tiles_t, nullptr, ws.ft, ws.grad_t, s)) !=
                               NEMPC_EUNSUPPORTED;
                 if (!fused_trial) carry = false;      // not a compiled shape
                 else a.carry = 1;
             }
             if (!fused_trial)
                 fused_trial = h.variant == NEMPC_KERNEL_MFMA &&
-                    (rc = launch_eval_fused(h, Bact, ws.Zt, X0c, ws.gt, nullptr, nullptr, ws.ft, nullptr, s)) != NEMPC_EUNSUPPORTED;
+                    (rc = launch_eval_fused(h, nb, ws.Zt, X0t, ws.gt, nullptr, nullptr, ws.ft, nullptr, s)) != NEMPC_EUNSUPPORTED;
             if (!fused_trial)
-                rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, Bact, ws.Zt, X0c, ws.gt, nullptr, s)
-                                                    : launch_rows_valu(h, Bact, ws.Zt, X0c, ws.gt, h.d_tiles_ws, s);
+                rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, nb, ws.Zt, X0t, ws.gt, nullptr, s)
+                                                    : launch_rows_valu(h, nb, ws.Zt, X0t, ws.gt, h.d_tiles_ws, s);
+            if (!rc && !fused_trial) rc = launch_objective(h, nb, ws.Zt, ws.ft, nullptr, s);
+            h.d_extra = extra_all;
             if (rc) return rc;
-            if (!fused_trial && (rc = launch_objective(h, Bact, ws.Zt, ws.ft, nullptr, s))) return rc;
-            hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(Bact), dim3(64), 0, s, a, (const T*)ws.Zt,
+            hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(nb), dim3(64), 0, s, a, (const T*)ws.Zt,
                                (const T*)ws.gt, (const T*)ws.ft, (T*)Zc,
-                               lsm == 2 ? 2 : (ls + 1 == o.max_linesearch ? 1 : 0));
+                               lsm == 2 ? 2 : (ls + 1 == o.max_linesearch ? 1 : 0),
+                               ls > 0 ? (const int*)ws.pend[ls & 1] : (const int*)nullptr, ws.pend[(ls + 1) & 1]);
             have_eval = a.carry != 0;
             if (lsm == 2) break;          // one trial per outer iteration: nothing to poll
             // most iterations accept the first trial for every problem: one small poll saves the remaining
             // max_linesearch-1 callback evaluations
-            int pending = 0;
-            NEMPC_HIP(hipMemcpyAsync(&pending, a.n_pending, sizeof(int), hipMemcpyDeviceToHost, s));
+            NEMPC_HIP(hipMemcpyAsync(ws.hpoll + 2, a.n_pending, sizeof(int), hipMemcpyDeviceToHost, s));
             NEMPC_HIP(hipStreamSynchronize(s));
+            pending = ws.hpoll[2];
             if (pending == 0) break;
             if (lsm == 3 && ls == 0 && pending * 4 <= std::min(Bact, last_nact)) {
                 hipLaunchKernelGGL(solver_defer_kernel<T>, dim3((Bact + 255) / 256), dim3(256), 0, s, a);
