@@ -575,11 +575,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         }
             return true;
     };
-#ifdef NEMPC_LQ_EXP_NOBACK
-    for (int t = H - 1; t >= H - 1 && pd; t -= 2) {
-#else
     for (int t = H - 1; t >= 0 && pd; t -= 2) {
-#endif
         pd = stage(t, sin_a, sin_b);
         if (pd && t > 0) pd = stage(t - 1, sin_b, sin_a);
     }
@@ -628,11 +624,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     const T tau = T(0.995);
     #pragma unroll
     for (int i = 0; i < nx; ++i) TMP(odx + i) = T(0);
-#ifdef NEMPC_LQ_EXP_NOFWD
-    for (int t = 0; t < 1; ++t) {
-#else
     for (int t = 0; t < H; ++t) {
-#endif
         const T* At = tl + (size_t)t * nx * nin;
         #pragma unroll
         for (int i = 0; i < nu; ++i) {
@@ -767,11 +759,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                     info[INFO_AMAX] = amax; info[INFO_G1] = g1;
                     info[INFO_GINF] = ginf; info[INFO_D0] = D0; info[INFO_ZINF] = zinf;
                 }
-#ifdef NEMPC_LQ_EXP_NOPOST
-                if (false) {
-#else
                 if (a.fuse_step) {
-#endif
                     // what solver_step_kernel does, from the LDS copies and the norms still in registers: dual steps of the
                     // bounds, convergence test / barrier update / merit at the iterate, first trial point
                     si.ginf = (T)wave_bcast_lane0((double)ginf); si.zinf = (T)wave_bcast_lane0((double)zinf);
