@@ -507,8 +507,10 @@ class Rank:
                                   ("torch.distributed/" + self.backend if self.dist is not None else "single rank"),
                 "other_budgets_this_rank": budgets,
                 "note": "SQP + Riccati, exact Lagrangian blocks, bounds |x|<=3 |u|<=0.5 by a primal-dual interior point, "
-                        "deferred backtracking (one trial evaluation per iteration), unconverged problems compacted to the "
-                        "front as the batch converges; mpc_solved_per_s counts status == 0 only (this rank's iteration "
+                        + ("inner-loop backtracking with later trials evaluated for the problems still searching only"
+                           if cfg["nx"] * (cfg["nx"] + cfg["nu"]) >= 12 else
+                           "deferred backtracking (one evaluation per iteration: an accepted trial's is the next iterate's)")
+                        + ", unconverged problems compacted to the front as the batch converges; mpc_solved_per_s counts status == 0 only (this rank's iteration "
                         "statistics)"}
 
     def gather_latency_us(self, res, reps=200):
