@@ -26,6 +26,7 @@
 // compiled shapes).  Per iteration and small stage: fused evaluation, Hessian blocks, Riccati (+ barrier terms while
 // staging, + step norms by a wave per problem), step kernel (dual steps, convergence test / merit, first trial point),
 // trial evaluation, acceptance test -- six launches; the host reads the convergence counter one period late.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,8 @@ struct SolverArgs {
     const void* lb; const void* ub;                                      // (n) device, dtype T, +-inf allowed
     void* mu; void* pen; void* reg; void* alpha; void* phi0; void* dir;  // (B) per problem (pen = l1 penalty)
     int lq_attempts;      // Riccati sweeps a problem may try per iteration before it sits the iteration out
+    int* hpub;            // pinned host memory the acceptance kernel publishes the convergence counter to: [0] iteration
+                          // tag, [1] unconverged problems at that iteration, [2] first iteration at which none was left
     int carry;            // the trial evaluation is a full one and becomes the next iterate's on acceptance (tiles_t, grad_t)
     const void *tiles_t, *grad_t;
     int fuse_step;        // thread-per-problem Riccati kernel in LDS mode: it also does solver_step_kernel's work
@@ -1252,7 +1255,8 @@ __global__ __launch_bounds__(64) void solver_step_kernel(SolverArgs a, const T* 
 template <typename T>
 __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T* __restrict__ Zt, const T* __restrict__ gt,
                                                           const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls,
-                                                          const int* __restrict__ list_in, int* __restrict__ list_out) {
+                                                          const int* __restrict__ list_in, int* __restrict__ list_out,
+                                                          int publish) {
     // list_in: the trial buffers (Zt, gt, ft) hold only the problems that were still searching after the previous trial,
     // densely, in the order of that list (inner-loop backtracking); null: one slot per problem.  list_out: the problems
     // this trial rejects are appended for the next one.
@@ -1260,7 +1264,20 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T*
     const int b = list_in ? list_in[slot] : slot;
     // the convergence counter of the NEXT iteration, when its test runs inside the Riccati kernel (the host's copy of this
     // iteration's count was issued before this launch)
-    if (slot == 0 && lane == 0 && a.fuse_step) *a.n_active = 0;
+    if (slot == 0 && lane == 0 && publish) {
+        // first acceptance launch of the iteration: the iteration's convergence counter is complete (the Riccati / step
+        // kernel that counts ran earlier in the stream).  It goes to pinned host memory by a plain store -- the host reads
+        // it there whenever it likes: no copy launch, no event, no drained stream
+        if (a.hpub) {
+            const int v = *a.n_active;
+            a.hpub[1] = v;
+            if (v == 0 && a.hpub[2] == 0) a.hpub[2] = a.cur_it + 1;
+            __threadfence_system();
+            a.hpub[0] = a.cur_it + 1;
+            __threadfence_system();
+        }
+        if (a.fuse_step) *a.n_active = 0;
+    }
     if (b >= a.B) return;
     T* mu = (T*)a.mu; T* nu = (T*)a.pen; T* reg = (T*)a.reg; T* alpha = (T*)a.alpha; T* phi0 = (T*)a.phi0; T* dir = (T*)a.dir;
     const T* info = (const T*)a.info + (size_t)b * INFO_N;
@@ -1512,8 +1529,8 @@ struct SolverWs {
     void *dzl = nullptr, *dzu = nullptr, *alz = nullptr, *bh = nullptr;
     int *stc[2] = {nullptr, nullptr}, *orig[2] = {nullptr, nullptr}, *itc[2] = {nullptr, nullptr};
     int *perm = nullptr, *count = nullptr;
-    int* hpoll = nullptr;                      // pinned host: two slots the convergence counter is copied into
-    hipEvent_t pev[2] = {nullptr, nullptr};    // one event per slot
+    int* hpoll = nullptr;                      // pinned host: [0] convergence counter (blocking polls), [2] backtracking poll
+    int *hpub = nullptr, *hpub_dev = nullptr;  // pinned host memory the device publishes the convergence counter to
     int cap = 0;
     size_t ex_per = 0;
 };
@@ -1535,8 +1552,7 @@ void solver_free(Handle& h) {
         if (w->pend[k]) (void)hipFree(w->pend[k]);
     if (w->n_active) (void)hipFree(w->n_active);
     if (w->hpoll) (void)hipHostFree(w->hpoll);
-    for (int k = 0; k < 2; ++k)
-        if (w->pev[k]) (void)hipEventDestroy(w->pev[k]);
+    if (w->hpub) (void)hipHostFree(w->hpub);
     for (int k = 0; k < 2; ++k) {
         void* ps[] = {w->Zc[k], w->X0c[k], w->lamc[k], w->muc[k], w->nuc[k], w->regc[k], w->exc[k], w->infoc[k], w->stc[k],
                       w->orig[k], w->itc[k], w->zlc[k], w->zuc[k]};
@@ -1598,8 +1614,9 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             NEMPC_HIP(hipMalloc((void**)&w2.lsdone, Bn * sizeof(int)));
             for (int k = 0; k < 2; ++k) NEMPC_HIP(hipMalloc((void**)&w2.pend[k], Bn * sizeof(int)));
             NEMPC_HIP(hipMalloc((void**)&w2.n_active, 2 * sizeof(int)));   // [unconverged, still backtracking]
-            NEMPC_HIP(hipHostMalloc((void**)&w2.hpoll, 4 * sizeof(int), hipHostMallocDefault));   // [0,1]: convergence polls, [2]: backtracking poll
-            for (int k = 0; k < 2; ++k) NEMPC_HIP(hipEventCreateWithFlags(&w2.pev[k], hipEventDisableTiming));
+            NEMPC_HIP(hipHostMalloc((void**)&w2.hpoll, 4 * sizeof(int), hipHostMallocDefault));
+            NEMPC_HIP(hipHostMalloc((void**)&w2.hpub, 4 * sizeof(int), hipHostMallocMapped));
+            NEMPC_HIP(hipHostGetDevicePointer((void**)&w2.hpub_dev, w2.hpub, 0));
             NEMPC_HIP(hipMalloc((void**)&w2.perm, Bn * sizeof(int)));
             NEMPC_HIP(hipMalloc((void**)&w2.count, sizeof(int)));
             w2.cap = B;
@@ -1724,8 +1741,8 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     bool carry = lsm_carry == 2 && !no_carry && a.use_lds && h.variant == NEMPC_KERNEL_MFMA && h.cfg.integrator != NEMPC_RK4;
     bool have_eval = false;       // the evaluation buffers hold every active problem's current iterate
     a.carry = 0; a.tiles_t = ws.tiles_t; a.grad_t = ws.grad_t;
-    int poll_pending = -1;        // slot of the convergence-counter copy that is in flight, -1: none
-    int poll_it[2] = {0, 0};      // iteration at which each slot's copy was issued
+    a.hpub = ws.hpub_dev;
+    for (int k = 0; k < 4; ++k) ws.hpub[k] = 0;       // (the previous solve on this handle ended with a synchronised stream)
     const bool lagged_polls = !wave_wanted;     // small stages: iterations are chains of latency-bound launches
     int Bact = B;                 // slots [0, Bact) may still be unconverged; compaction keeps them in front
     int last_nact = B;            // unconverged problems at the last convergence poll
@@ -1784,38 +1801,19 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
 #endif
         if (!a.fuse_step)
             hipLaunchKernelGGL(solver_step_kernel<T>, dim3(Bact), dim3(64), 0, s, a, (const T*)ws.f, (const T*)Zc, (T*)ws.Zt);
-        // Convergence poll, one period late: the counter of THIS iteration is copied to a pinned slot behind an event and the
-        // host goes on issuing the next iterations; what it reads here is the copy issued a period ago, long complete.  A
-        // blocking poll drains the stream every time (10 polls of ~25 us in a 5.5 ms solve); the price of the lag is up to
-        // `check` iterations over an all-converged batch, which are launches that find nothing to do.
+        // Convergence poll.  Matrix-core-bound stages: a blocking copy every `check` iterations (an iteration is milliseconds,
+        // a drained stream costs nothing next to iterations at a stale batch size).  Small stages: see after the
+        // backtracking launches below.
         bool polled = false;
         int nact = Bact;
-        if ((it + 1) % check == 0 || it + 1 == o.max_iter) {
-            if (!lagged_polls) {
-                // matrix-core-bound stages: an iteration is milliseconds, a drained stream costs nothing next to four
-                // iterations at a stale batch size
-                NEMPC_HIP(hipMemcpyAsync(ws.hpoll, ws.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
-                NEMPC_HIP(hipStreamSynchronize(s));
-                nact = ws.hpoll[0];
-                polled = true;
-                last_nact = nact;
-                if (nact == 0) { ++it; break; }
-            } else {
-                if (poll_pending >= 0) {
-                    NEMPC_HIP(hipEventSynchronize(ws.pev[poll_pending]));
-                    nact = ws.hpoll[poll_pending];
-                    polled = true;
-                    last_nact = nact;
-                    // every problem had converged when that copy was issued: report THAT iteration count (the iterations
-                    // launched since found nothing to do)
-                    if (nact == 0) { it = poll_it[poll_pending] + 1; break; }
-                }
-                const int slot = poll_pending < 0 ? 0 : poll_pending ^ 1;
-                NEMPC_HIP(hipMemcpyAsync(ws.hpoll + slot, ws.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
-                NEMPC_HIP(hipEventRecord(ws.pev[slot], s));
-                poll_pending = slot;
-                poll_it[slot] = it;
-            }
+        if (!lagged_polls && ((it + 1) % check == 0 || it + 1 == o.max_iter)) {
+            NEMPC_HIP(hipMemcpyAsync(ws.hpoll, ws.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+            NEMPC_HIP(hipStreamSynchronize(s));
+            nact = ws.hpoll[0];
+            polled = true;
+            last_nact = nact;
+            // (report the iteration at which the last problem converged, as the published counter has it, not the poll's)
+            if (nact == 0) { it = ws.hpub[2] > 0 ? ws.hpub[2] : it + 1; break; }
         }
         // Backtracking in a lock-step batch.  An inner loop makes every problem pay for the one that needs six halvings
         // (measured: 5.7 trial evaluations per iteration at B=1024, C2 dims, 70 % of the solve time).  DEFERRED (2): one
@@ -1866,7 +1864,8 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(nb), dim3(64), 0, s, a, (const T*)ws.Zt,
                                (const T*)ws.gt, (const T*)ws.ft, (T*)Zc,
                                lsm == 2 ? 2 : (ls + 1 == o.max_linesearch ? 1 : 0),
-                               ls > 0 ? (const int*)ws.pend[ls & 1] : (const int*)nullptr, ws.pend[(ls + 1) & 1]);
+                               ls > 0 ? (const int*)ws.pend[ls & 1] : (const int*)nullptr, ws.pend[(ls + 1) & 1],
+                               ls == 0 ? 1 : 0);
             have_eval = a.carry != 0;
             if (lsm == 2) break;          // one trial per outer iteration: nothing to poll
             // most iterations accept the first trial for every problem: one small poll saves the remaining
@@ -1878,6 +1877,32 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             if (lsm == 3 && ls == 0 && pending * 4 <= std::min(Bact, last_nact)) {
                 hipLaunchKernelGGL(solver_defer_kernel<T>, dim3((Bact + 255) / 256), dim3(256), 0, s, a);
                 break;
+            }
+        }
+        if (lagged_polls) {
+            // Small stages: an iteration is a chain of latency-bound launches, and a blocking poll drains the stream (10
+            // polls of ~25 us in a 5.5 ms solve).  The acceptance kernel PUBLISHES the iteration's counter to pinned host
+            // memory; the host only makes sure it never runs more than two iterations ahead of the device (it would
+            // otherwise queue its whole budget before the first problem converges) and takes whatever the slot holds:
+            // a count a couple of iterations old is an upper bound of the unconverged problems (they only ever leave),
+            // which is all compaction needs, and "none left" is reported with the iteration at which it happened.
+            volatile int* hp = ws.hpub;
+            const int want = it + 1 - 2;
+            if (want > 0) {
+                const auto t0 = std::chrono::steady_clock::now();
+                long spins = 0;
+                while (hp[0] < want) {
+                    if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                        NEMPC_HIP(hipStreamSynchronize(s));      // a device fault surfaces here instead of a hang
+                        if (hp[0] < want) return NEMPC_EHIP;
+                    }
+                }
+            }
+            if (hp[0] > 0) {
+                if (hp[2] > 0) { it = hp[2]; break; }      // every problem had converged at that iteration
+                nact = hp[1];
+                polled = true;
+                last_nact = nact;
             }
         }
         static const bool stats = getenv("NEMPC_SOLVER_STATS") != nullptr;
