@@ -1686,7 +1686,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     a.lq_attempts = o.lq_attempts > 0 ? o.lq_attempts : (lq_attempts_env > 0 ? lq_attempts_env : 3);
     const bool wave_wanted = o.lq_kernel != 1 && (o.lq_kernel == 2 || nx * (nx + nu) >= 12);
     // thread-per-problem sweep: up to three damping levels side by side (lanes and LDS regions per problem)
-    static const int lq_spec_env = [] { const char* e = getenv("NEMPC_LQ_SPEC"); return e ? atoi(e) : 0; }();           // A/B knob
+    const int lq_spec_env = [] { const char* e = getenv("NEMPC_LQ_SPEC"); return e ? atoi(e) : 0; }();   // A/B knob (tests)
     a.spec = wave_wanted ? 1 : std::max(1, std::min(std::min(a.lq_attempts, lq_spec_env > 0 ? lq_spec_env : 3), 8));
     a.att_elems = H * nu * nx + H * nu + H * nx * nx + H * nx + lq_tmp_elems(nx, nu);
     int per_problem;
@@ -1723,7 +1723,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     // wave: 6/3 stages 6.5 k vs 5.0 k MPC solves/s at C3; 2/1 stages are 4 entries wide and stay on the
     // thread-per-problem kernel (22.0 vs 23.1 ms per 40 iterations at C2).  nempc_solver_opts.lq_kernel forces one.
     const bool lq_wave = a.use_lds && wave_wanted;
-    static const int no_fuse_step = [] { const char* e = getenv("NEMPC_SOLVER_NO_FUSE_STEP"); return e ? atoi(e) : 0; }();
+    const int no_fuse_step = [] { const char* e = getenv("NEMPC_SOLVER_NO_FUSE_STEP"); return e ? atoi(e) : 0; }();   // (tests)
     a.fuse_step = a.use_lds && !lq_wave && !no_fuse_step;
     a.f_it = ws.f; a.Zt_it = ws.Zt;
     if (a.fuse_step) NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, 2 * sizeof(int), s));
@@ -1736,7 +1736,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lqk), lds_max));
     }
 
-    static const int no_carry = [] { const char* e = getenv("NEMPC_SOLVER_NO_CARRY"); return e ? atoi(e) : 0; }();   // A/B knob
+    const int no_carry = [] { const char* e = getenv("NEMPC_SOLVER_NO_CARRY"); return e ? atoi(e) : 0; }();   // A/B knob (tests)
     const int lsm_carry = o.linesearch == 0 ? (wave_wanted ? 1 : 2) : o.linesearch;
     bool carry = lsm_carry == 2 && !no_carry && a.use_lds && h.variant == NEMPC_KERNEL_MFMA && h.cfg.integrator != NEMPC_RK4;
     bool have_eval = false;       // the evaluation buffers hold every active problem's current iterate

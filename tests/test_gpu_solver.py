@@ -325,6 +325,59 @@ def test_backtracking_modes_reach_the_same_solutions_and_barrier_kinds_agree():
     assert np.median(out["deferred"][3][both]) >= np.median(out["loop"][3][both])
 
 
+def test_iteration_shortcuts_do_not_change_the_iterates(monkeypatch):
+    """Three things the solver does to shorten an iteration are schedules, not approximations -- each can be switched off
+    by an environment knob and must give bit-identical iterates, statuses and iteration counts: the damping levels of a
+    Riccati sweep tried side by side on lanes of one wave (NEMPC_LQ_SPEC=1: one after the other), the step kernel's work
+    done inside the Riccati kernel (NEMPC_SOLVER_NO_FUSE_STEP), and the accepted trial's evaluation kept as the next
+    iterate's (NEMPC_SOLVER_NO_CARRY: the iterate is evaluated again)."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, H, B = 2, 1, 20, 300
+    net = orc.MLP.random(nx + nu, [64, 64], nx, seed=0)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B)
+    X0 = eng.to_device(np.random.default_rng(100).uniform(-0.5, 0.5, size=(B, nx)))
+    lb = np.concatenate([np.full(H * nx, -3.0), np.full(H * nu, -0.5)])
+    ref = eng.solve(X0, lb=lb, ub=-lb, max_iter=50, return_iterations=True)
+    assert int((ref[1] == 0).sum()) > B // 2
+    for knob in ("NEMPC_LQ_SPEC", "NEMPC_SOLVER_NO_FUSE_STEP", "NEMPC_SOLVER_NO_CARRY"):
+        monkeypatch.setenv(knob, "1")
+        got = eng.solve(X0, lb=lb, ub=-lb, max_iter=50, return_iterations=True)
+        monkeypatch.delenv(knob)
+        assert got[2] == ref[2] and torch.equal(got[1], ref[1]) and torch.equal(got[3], ref[3]), knob
+        assert torch.equal(got[0], ref[0]), knob
+    # inner-loop backtracking: later trials over the still-searching problems only -- same answer with and without compaction
+    a = eng.solve(X0, lb=lb, ub=-lb, max_iter=40, linesearch="loop", compact=False)
+    b = eng.solve(X0, lb=lb, ub=-lb, max_iter=40, linesearch="loop", compact=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_warm_started_closed_loop_converges_in_fewer_iterations():
+    """Closed loop on the network itself (tools/closed_loop_bench.py): each MPC step starts from the previous solution
+    shifted by one stage with a small initial barrier parameter; after the first steps every problem converges, in fewer
+    iterations than from the reference's cold start."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, H, B = 2, 1, 20, 64
+    net = orc.MLP.random(nx + nu, [64, 64], nx, seed=0)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B)
+    Xh = np.random.default_rng(100).uniform(-0.5, 0.5, size=(B, nx))
+    lb = np.concatenate([np.full(H * nx, -3.0), np.full(H * nu, -0.5)])
+    Zi, cold_it, its = None, None, []
+    for k in range(6):
+        X = eng.to_device(Xh)
+        Z, st, it = eng.solve(X, Zi, lb=lb, ub=-lb, max_iter=80, **({} if Zi is None else {"mu_init": 1e-4}))
+        if k == 0:
+            cold_it = it
+        its.append((it, int((st == 0).sum())))
+        z = Z.cpu().numpy()
+        xs, us = z[:, :H * nx].reshape(B, H, nx), z[:, H * nx:].reshape(B, H, nu)
+        Xh = np.stack([net.forward(np.concatenate([Xh[b], us[b, 0]])) for b in range(B)])   # Discret: x+ = net(x, u)
+        xs2 = np.clip(np.concatenate([xs[:, 1:], xs[:, -1:]], axis=1), -2.999, 2.999)
+        us2 = np.clip(np.concatenate([us[:, 1:], us[:, -1:]], axis=1), -0.499, 0.499)
+        Zi = eng.to_device(np.concatenate([xs2.reshape(B, -1), us2.reshape(B, -1)], axis=1))
+    assert all(ok == B for _, ok in its[3:]), its
+    assert max(i for i, _ in its[3:]) < cold_it, (its, cold_it)
+
+
 def test_solver_refuses_unknown_option_values():
     from pyneuralempc_amd import CallbackEngine
     net = orc.MLP.random(3, [16], 2, seed=1)
