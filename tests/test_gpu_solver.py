@@ -202,6 +202,16 @@ def test_next_batch_with_p_and_tvp_binds_per_problem_parameters():
     Sa, Ua, _ = ctl.next_batch(X0, p=P[1], tvp=TV[1], max_iter=80)
     Sb, Ub, _ = ctl.next_batch(X0, p=np.tile(P[1], (B, 1)), tvp=np.tile(TV[1][None], (B, 1, 1)), max_iter=80)
     assert np.array_equal(Sa, Sb) and np.array_equal(Ua, Ub)
+    # inner-loop backtracking gathers the still-searching problems (their parameters with them) for its later trials: the
+    # same solutions as the deferred schedule, and the defects vanish under each problem's own parameters
+    Sl, Ul, stl = ctl.next_batch(X0, p=P, tvp=TV, max_iter=80, linesearch="loop")
+    assert (stl == 0).all()
+    np.testing.assert_allclose(Sl, S, atol=1e-5)
+    np.testing.assert_allclose(Ul, U, atol=1e-5)
+    for b in range(B):
+        extra = np.concatenate([TV[b], np.tile(P[b].reshape(1, -1), (H, 1))], axis=1)
+        z = np.concatenate([Sl[b].ravel(), Ul[b].ravel()])
+        assert np.abs(orc.Problem(net, H, nx, nu, extra=extra).constraints(z, X0[b])).max() < 1e-7
 
 
 def test_objective_edits_between_solves_reach_the_device():
