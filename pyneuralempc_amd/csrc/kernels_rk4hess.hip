@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void rk4_nu_kernel(size_t R, int H, int nx, in
     }
 }
 
-// one wave per (problem, step) row; LDS per wave: Ht[4][nin*nin] | C[3][nx*nin] with C_s = c_s dk_{s-1}
+// one wave per (problem, step) row; LDS per wave: Ht[4][nin*nin] | C[3][nx*nin] with C_s = c_s dk_{s-1} | M[3][nin*nin] | out[nin*nin]
 template <typename T>
 __global__ __launch_bounds__(256) void rk4_congruence_kernel(size_t R, int nx, int nin, T DT,
                                                              const T* __restrict__ stage, int stride,
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void rk4_congruence_kernel(size_t R, int nx, i
     const size_t r = (size_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (r >= R) return;   // whole wave leaves together; no block-level barrier below
     const int nn = nin * nin, jn = nx * nin;
-    T* sH = reinterpret_cast<T*>(lds_raw) + (size_t)wave * (4 * nn + 3 * jn);
+    T* sH = reinterpret_cast<T*>(lds_raw) + (size_t)wave * (8 * nn + 3 * jn);
     T* sC = sH + 4 * nn;
     for (int e = lane; e < 4 * nn; e += 64) sH[e] = ht[r * 4 * nn + e];
     for (int e = lane; e < 3 * jn; e += 64) {
@@ -65,28 +65,43 @@ __global__ __launch_bounds__(256) void rk4_congruence_kernel(size_t R, int nx, i
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // entry (p,q) of R^T Ht R with R = I + [C ; 0]:
-    //   Ht[p][q] + sum_e Ht[p][e] C[e][q] + sum_e C[e][p] Ht[e][q] + sum_{e,e'} C[e][p] Ht[e][e'] C[e'][q]
-    auto entry = [&](int p, int q) -> T {
-        T v = sH[p * nin + q];
-        for (int s = 1; s < 4; ++s) {
-            const T* Hs = sH + s * nn;
-            const T* C = sC + (s - 1) * jn;
-            T acc = Hs[p * nin + q];
-            for (int e = 0; e < nx; ++e) {
-                acc = fma(Hs[p * nin + e], C[e * nin + q], acc);
-                T inner = Hs[e * nin + q];
-                for (int e2 = 0; e2 < nx; ++e2) inner = fma(Hs[e * nin + e2], C[e2 * nin + q], inner);
-                acc = fma(C[e * nin + p], inner, acc);
-            }
+    // R^T Ht R with R = I + [C ; 0], summed over the stages, in two products through LDS (entry by entry it is
+    // O(nx^2) multiply-adds and twice as many LDS reads per entry and stage, and both triangles are needed):
+    //   M_s = Ht_s R_s:        M_s[p][q] = Ht_s[p][q] + sum_e Ht_s[p][e] C_s[e][q]
+    //   out = Ht_0 + sum_s R_s^T M_s:  out[p][q] = Ht_0[p][q] + sum_s (M_s[p][q] + sum_e C_s[e][p] M_s[e][q])
+    T* sM = sC + 3 * jn;
+    T* sO = sM + 3 * nn;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int idx = lane; idx < 3 * nn; idx += 64) {
+        const int s = idx / nn, pq = idx - s * nn, p = pq / nin, q = pq - p * nin;
+        const T* Hs = sH + (s + 1) * nn;
+        const T* C = sC + s * jn;
+        T acc = Hs[pq];
+        for (int e = 0; e < nx; ++e) acc = fma(Hs[p * nin + e], C[e * nin + q], acc);
+        sM[idx] = acc;
+    }
+    wave_sync();
+    for (int pq = lane; pq < nn; pq += 64) {
+        const int p = pq / nin, q = pq - p * nin;
+        T v = sH[pq];
+        for (int s = 0; s < 3; ++s) {
+            const T* M = sM + s * nn;
+            const T* C = sC + s * jn;
+            T acc = M[pq];
+            for (int e = 0; e < nx; ++e) acc = fma(C[e * nin + p], M[e * nin + q], acc);
             v += acc;
         }
-        return v;
-    };
-    for (int idx = lane; idx < nn; idx += 64) {
-        const int p = idx / nin, q = idx - p * nin;
+        sO[pq] = v;
+    }
+    wave_sync();
+    for (int pq = lane; pq < nn; pq += 64) {
+        const int p = pq / nin, q = pq - p * nin;
         // the two triangles round differently: average them so the block is exactly symmetric
-        blocks[r * nn + idx] = (p == q) ? entry(p, q) : T(0.5) * (entry(p, q) + entry(q, p));
+        blocks[r * nn + pq] = (p == q) ? sO[pq] : T(0.5) * (sO[pq] + sO[q * nin + p]);
     }
 }
 
@@ -108,7 +123,8 @@ int run_small_kernels(Handle& h, size_t R, const void* lambda, void* blocks, int
         hipLaunchKernelGGL(rk4_nu_kernel<T>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, h.cfg.H, nx, nin, h.m,
                            (T)h.cfg.DT, (const T*)lambda, (const T*)h.d_rk4_stage, stride, (T*)h.d_rk4_nu);
     } else {
-        const size_t lds = 4 * (size_t)(4 * nin * nin + 3 * nx * nin) * sizeof(T);
+        const size_t lds = 4 * (size_t)(8 * nin * nin + 3 * nx * nin) * sizeof(T);
+        NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(rk4_congruence_kernel<T>), lds));
         hipLaunchKernelGGL(rk4_congruence_kernel<T>, dim3((unsigned)((R + 3) / 4)), dim3(256), lds, s, R, nx, nin,
                            (T)h.cfg.DT, (const T*)h.d_rk4_stage, stride, (const T*)h.d_rk4_ht, (T*)blocks);
     }
