@@ -11,8 +11,9 @@
 //   couple only (x_{t-1}, u_t), so every QP is still an LQ problem in the linearised dynamics
 //   dx_t = A_t dx_{t-1} + B_t du_t + g_t, solved exactly by one backward Riccati sweep and one forward sweep per
 //   problem (block-tridiagonal KKT, O(H (nx+nu)^3)).  Indefinite control Hessians Quu are handled the DDP way:
-//   the sweep restarts with a larger Levenberg term (decade steps from 1e-3, at most lq_attempts sweeps per
-//   iteration: a problem still indefinite then keeps its damping and sits the iteration out, so that the launch does
+//   the sweep is repeated with a larger Levenberg term (decade steps from 1e-3, at most lq_attempts levels per
+//   iteration, tried side by side on lanes of one wave in the per-thread kernel, the first level that goes through is
+//   used: a problem still indefinite then keeps its damping and sits the iteration out, so that the launch does
 //   not wait for it).  Multipliers = Riccati costates of the previous step;
 // * variable bounds (DomainConstraint, constraints.py:3-33): primal-dual interior point -- the multipliers of the
 //   bounds are iterates with their own step length; their diagonal terms keep the LQ structure (the primal log
@@ -22,10 +23,12 @@
 //   retries the same direction at half the length next iteration), an inner loop for matrix-core-bound ones.
 // Every problem carries its own mu, nu, step length, damping and status; the batch advances in lock step, the
 // unconverged problems are compacted to the front as it converges.  All arithmetic is in kernels here; the callbacks
-// are the handle's own row/objective kernels (one fused launch per iterate and one forward-only launch per trial on the
-// compiled shapes).  Per iteration and small stage: fused evaluation, Hessian blocks, Riccati (+ barrier terms while
-// staging, + step norms by a wave per problem), step kernel (dual steps, convergence test / merit, first trial point),
-// trial evaluation, acceptance test -- six launches; the host reads the convergence counter one period late.
+// are the handle's own row/objective kernels.  Per iteration on a compiled small shape: Hessian blocks, Riccati kernel
+// (barrier terms while staging; step norms, dual steps, convergence test, merit and first trial point by a wave per
+// problem after the sweeps), ONE fused evaluation of the trial point -- which the acceptance kernel keeps as the next
+// iterate's evaluation when it accepts -- and the acceptance test: four launches; the acceptance kernel publishes the
+// convergence counter to pinned host memory, the host stays at most two iterations ahead of the device.  Inner-loop
+// backtracking (matrix-core-bound stages) evaluates a second and later trial for the still-searching problems only.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
