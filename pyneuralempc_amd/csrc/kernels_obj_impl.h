@@ -73,10 +73,11 @@ __device__ __forceinline__ double wave_bcast_lane0(double s) {
 }
 
 // one wave per problem; lanes stride over the horizon.  z: the problem's variables (global memory, or a copy in LDS)
+// (returns the objective value, valid in lane 0; writes the gradient row of problem b when grad is given)
 template <typename T>
-__device__ __forceinline__ void objective_row(int b, int lane, int H, int nx, int nu, const ObjOffsets& o,
-                                              const T* __restrict__ P, const T* __restrict__ z,
-                                              T* __restrict__ f, T* __restrict__ grad) {
+__device__ __forceinline__ double objective_row_value(int b, int lane, int H, int nx, int nu, const ObjOffsets& o,
+                                                      const T* __restrict__ P, const T* __restrict__ z,
+                                                      T* __restrict__ grad) {
     const int n = H * (nx + nu);
     const T *Rm = P + o.R, *Rs = P + o.Rs;
     const T *xref = P + o.xref, *uref = P + o.uref, *cx = P + o.cx, *cu = P + o.cu;
@@ -110,7 +111,13 @@ __device__ __forceinline__ void objective_row(int b, int lane, int H, int nx, in
             if (grad) grad[(size_t)b * n + H * nx + t * nu + i] = rsd + cu[t * nu + i];
         }
     }
-    acc = wave_sum_lane0(acc);
+    return wave_sum_lane0(acc);
+}
+template <typename T>
+__device__ __forceinline__ void objective_row(int b, int lane, int H, int nx, int nu, const ObjOffsets& o,
+                                              const T* __restrict__ P, const T* __restrict__ z,
+                                              T* __restrict__ f, T* __restrict__ grad) {
+    const double acc = objective_row_value<T>(b, lane, H, nx, nu, o, P, z, grad);
     if (f && lane == 0) f[b] = (T)acc;
 }
 

@@ -1289,12 +1289,16 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T*
     const int H = a.H, nx = a.nx;
     // the problem's scalars, requested together (one global round trip instead of one per use)
     const int done = a.lsdone[b];
-    const T mub = mu[b], nub = nu[b], ftb = ft[slot], al = alpha[b], ph0 = phi0[b], drb = dir[b];
+    const T mub = mu[b], nub = nu[b], al = alpha[b], ph0 = phi0[b], drb = dir[b];
+    T ftb = ft ? ft[slot] : T(0);
     const T az = a.primal_dual ? ((const T*)a.alz)[b] : T(0);
     const T lsr = info[INFO_LSR], lsk = info[INFO_LSK], regb = reg[b];
     if (done) return;
     const T* zt = Zt + (size_t)slot * a.n;
     const T* gtb = gt + (size_t)slot * a.m;
+    // objective value of the trial point, when no launch has left it in `ft` (shapes without the fused evaluation): the
+    // wave has the point in hand, and a launch of its own for one number per problem costs more than the number
+    if (!ft) ftb = (T)wave_bcast_lane0(objective_row_value<T>(b, lane, H, nx, a.nu, a.oo, (const T*)a.obj, zt, (T*)nullptr));
     // log-barrier value and l1 norm of the defects at the trial point, one loop (the loads of both in flight together;
     // per-lane order and tree as barrier_value / l1_norm)
     double accb = 0.0, accg = 0.0;
@@ -1861,11 +1865,11 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             if (!fused_trial)
                 rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, nb, ws.Zt, X0t, ws.gt, nullptr, s)
                                                     : launch_rows_valu(h, nb, ws.Zt, X0t, ws.gt, h.d_tiles_ws, s);
-            if (!rc && !fused_trial) rc = launch_objective(h, nb, ws.Zt, ws.ft, nullptr, s);
             h.d_extra = extra_all;
             if (rc) return rc;
+            // (no fused evaluation: the acceptance kernel computes the trial point's objective value itself)
             hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(nb), dim3(64), 0, s, a, (const T*)ws.Zt,
-                               (const T*)ws.gt, (const T*)ws.ft, (T*)Zc,
+                               (const T*)ws.gt, fused_trial ? (const T*)ws.ft : (const T*)nullptr, (T*)Zc,
                                lsm == 2 ? 2 : (ls + 1 == o.max_linesearch ? 1 : 0),
                                ls > 0 ? (const int*)ws.pend[ls & 1] : (const int*)nullptr, ws.pend[(ls + 1) & 1],
                                ls == 0 ? 1 : 0);
