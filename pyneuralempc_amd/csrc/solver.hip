@@ -62,7 +62,9 @@ struct SolverArgs {
     void* mu; void* pen; void* reg; void* alpha; void* phi0; void* dir;  // (B) per problem (pen = l1 penalty)
     int lq_attempts;      // Riccati sweeps a problem may try per iteration before it sits the iteration out
     int* hpub;            // pinned host memory the acceptance kernel publishes the convergence counter to: [0] iteration
-                          // tag, [1] unconverged problems at that iteration, [2] first iteration at which none was left
+                          // tag, [1] unconverged problems at that iteration, [2] first iteration at which none was left;
+                          // inner-loop backtracking: [4] sequence number of the trial, [5] problems still searching after it
+    int* n_done;          // acceptance launches of the inner loop: blocks finished (the last one publishes)
     int carry;            // the trial evaluation is a full one and becomes the next iterate's on acceptance (tiles_t, grad_t)
     const void *tiles_t, *grad_t;
     int fuse_step;        // thread-per-problem Riccati kernel in LDS mode: it also does solver_step_kernel's work
@@ -1256,10 +1258,10 @@ __global__ __launch_bounds__(64) void solver_step_kernel(SolverArgs a, const T* 
 
 // Acceptance test of a trial point (Armijo on the l1 merit), one wave per problem
 template <typename T>
-__global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T* __restrict__ Zt, const T* __restrict__ gt,
-                                                          const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls,
-                                                          const int* __restrict__ list_in, int* __restrict__ list_out,
-                                                          int publish) {
+__device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* __restrict__ Zt, const T* __restrict__ gt,
+                                                  const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls,
+                                                  const int* __restrict__ list_in, int* __restrict__ list_out,
+                                                  int publish) {
     // list_in: the trial buffers (Zt, gt, ft) hold only the problems that were still searching after the previous trial,
     // densely, in the order of that list (inner-loop backtracking); null: one slot per problem.  list_out: the problems
     // this trial rejects are appended for the next one.
@@ -1404,6 +1406,29 @@ __global__ __launch_bounds__(256) void solver_defer_kernel(SolverArgs a) {
     a.lsdone[b] = 1;
     if (k >= (T)a.max_ls) { inf[INFO_LSK] = T(0); reg[b] = fmin(fmax(reg[b] * T(100), T(1e-6)), T(1e8)); }
     else { inf[INFO_LSK] = k; inf[INFO_LSA] = ((const T*)a.alpha)[b]; }
+}
+
+// seq > 0 (inner-loop backtracking): the block that finishes last publishes the number of problems still searching to
+// pinned host memory under that sequence number -- the host reads it there instead of copying it behind a drained stream
+template <typename T>
+__global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T* __restrict__ Zt, const T* __restrict__ gt,
+                                                          const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls,
+                                                          const int* __restrict__ list_in, int* __restrict__ list_out,
+                                                          int publish, int seq) {
+    solver_merit_body<T>(a, Zt, gt, ft, Zcur, last_ls, list_in, list_out, publish);
+    if (seq > 0 && threadIdx.x == 0) {
+        __threadfence();                                    // this block's list entry and count are out
+        const int t = atomicAdd(a.n_done, 1);
+        if (t == (int)gridDim.x - 1) {
+            __threadfence();
+            const int v = atomicAdd(a.n_pending, 0);
+            *a.n_done = 0;
+            a.hpub[5] = v;
+            __threadfence_system();
+            a.hpub[4] = seq;
+            __threadfence_system();
+        }
+    }
 }
 
 // Next trial point of the problems still searching (inner-loop backtracking), gathered densely in the order of `list`
@@ -1620,9 +1645,10 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             }
             NEMPC_HIP(hipMalloc((void**)&w2.lsdone, Bn * sizeof(int)));
             for (int k = 0; k < 2; ++k) NEMPC_HIP(hipMalloc((void**)&w2.pend[k], Bn * sizeof(int)));
-            NEMPC_HIP(hipMalloc((void**)&w2.n_active, 2 * sizeof(int)));   // [unconverged, still backtracking]
+            NEMPC_HIP(hipMalloc((void**)&w2.n_active, 4 * sizeof(int)));   // [unconverged, still backtracking, blocks done]
+            NEMPC_HIP(hipMemset(w2.n_active, 0, 4 * sizeof(int)));
             NEMPC_HIP(hipHostMalloc((void**)&w2.hpoll, 4 * sizeof(int), hipHostMallocDefault));
-            NEMPC_HIP(hipHostMalloc((void**)&w2.hpub, 4 * sizeof(int), hipHostMallocMapped));
+            NEMPC_HIP(hipHostMalloc((void**)&w2.hpub, 8 * sizeof(int), hipHostMallocMapped));
             NEMPC_HIP(hipHostGetDevicePointer((void**)&w2.hpub_dev, w2.hpub, 0));
             NEMPC_HIP(hipMalloc((void**)&w2.perm, Bn * sizeof(int)));
             NEMPC_HIP(hipMalloc((void**)&w2.count, sizeof(int)));
@@ -1678,7 +1704,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     a.hblk = ws.hblk; a.lamn = ws.lamn;
     a.obj = h.d_obj; a.oo = obj_offsets(H, nx, nu);
     a.lb = ws.lb; a.ub = ws.ub; a.alpha = ws.alpha; a.phi0 = ws.phi0;
-    a.dir = ws.dir; a.lsdone = ws.lsdone; a.n_active = ws.n_active; a.n_pending = ws.n_active + 1;
+    a.dir = ws.dir; a.lsdone = ws.lsdone; a.n_active = ws.n_active; a.n_pending = ws.n_active + 1; a.n_done = ws.n_active + 2;
     a.dz = ws.dz; a.Kst = ws.Kst;
     a.dzl = ws.dzl; a.dzu = ws.dzu; a.alz = ws.alz; a.bh = ws.bh;
     a.primal_dual = (has_bounds && o.barrier != 1) ? 1 : 0; a.kst = ws.kst; a.Pst = ws.Pst; a.pst = ws.pst;
@@ -1746,10 +1772,11 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     const int no_carry = [] { const char* e = getenv("NEMPC_SOLVER_NO_CARRY"); return e ? atoi(e) : 0; }();   // A/B knob (tests)
     const int lsm_carry = o.linesearch == 0 ? (wave_wanted ? 1 : 2) : o.linesearch;
     bool carry = lsm_carry == 2 && !no_carry && a.use_lds && h.variant == NEMPC_KERNEL_MFMA && h.cfg.integrator != NEMPC_RK4;
+    int pend_seq = 0;             // sequence number of the inner loop's acceptance launches (published with their count)
     bool have_eval = false;       // the evaluation buffers hold every active problem's current iterate
     a.carry = 0; a.tiles_t = ws.tiles_t; a.grad_t = ws.grad_t;
     a.hpub = ws.hpub_dev;
-    for (int k = 0; k < 4; ++k) ws.hpub[k] = 0;       // (the previous solve on this handle ended with a synchronised stream)
+    for (int k = 0; k < 8; ++k) ws.hpub[k] = 0;       // (the previous solve on this handle ended with a synchronised stream)
     const bool lagged_polls = !wave_wanted;     // small stages: iterations are chains of latency-bound launches
     int Bact = B;                 // slots [0, Bact) may still be unconverged; compaction keeps them in front
     int last_nact = B;            // unconverged problems at the last convergence poll
@@ -1872,14 +1899,23 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                                (const T*)ws.gt, fused_trial ? (const T*)ws.ft : (const T*)nullptr, (T*)Zc,
                                lsm == 2 ? 2 : (ls + 1 == o.max_linesearch ? 1 : 0),
                                ls > 0 ? (const int*)ws.pend[ls & 1] : (const int*)nullptr, ws.pend[(ls + 1) & 1],
-                               ls == 0 ? 1 : 0);
+                               ls == 0 ? 1 : 0, lsm == 2 ? 0 : ++pend_seq);
             have_eval = a.carry != 0;
             if (lsm == 2) break;          // one trial per outer iteration: nothing to poll
             // most iterations accept the first trial for every problem: one small poll saves the remaining
             // max_linesearch-1 callback evaluations
-            NEMPC_HIP(hipMemcpyAsync(ws.hpoll + 2, a.n_pending, sizeof(int), hipMemcpyDeviceToHost, s));
-            NEMPC_HIP(hipStreamSynchronize(s));
-            pending = ws.hpoll[2];
+            {
+                volatile int* hp = ws.hpub;
+                const auto t0 = std::chrono::steady_clock::now();
+                long spins = 0;
+                while (hp[4] != pend_seq) {
+                    if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                        NEMPC_HIP(hipStreamSynchronize(s));      // a device fault surfaces here instead of a hang
+                        if (hp[4] != pend_seq) return NEMPC_EHIP;
+                    }
+                }
+                pending = hp[5];
+            }
             if (pending == 0) break;
             if (lsm == 3 && ls == 0 && pending * 4 <= std::min(Bact, last_nact)) {
                 hipLaunchKernelGGL(solver_defer_kernel<T>, dim3((Bact + 255) / 256), dim3(256), 0, s, a);
