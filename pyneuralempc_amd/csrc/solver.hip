@@ -33,7 +33,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
+#include <vector>
 
 #include "nempc_internal.h"
 #include "kernels_obj_impl.h"
@@ -1455,8 +1457,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void solver_init_kernel(int B, int n, T* __restrict__ Z, const T* __restrict__ lb,
                                                           const T* __restrict__ ub, T* mu, T* nu, T* reg, int* status,
                                                           int* orig, int* iters_done, T* info, T* zl, T* zu, T mu0,
-                                                          T reg0, int has_bounds) {
+                                                          T reg0, int has_bounds, const T* __restrict__ Zin,
+                                                          const T* __restrict__ X0in, T* __restrict__ X0c, int nx,
+                                                          T* __restrict__ lam0, int m) {
+    // (the working copies of the caller's Z and X0 and the zero multipliers come from this launch too: three copy / fill
+    // launches less in a prologue that a single-problem closed loop pays every MPC step)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)B * nx) X0c[i] = X0in[i];
+    if (i < (size_t)B * m) lam0[i] = T(0);
     if (i < (size_t)B) {
         mu[i] = has_bounds ? mu0 : T(0); nu[i] = T(1); reg[i] = reg0; status[i] = -1;
         orig[i] = (int)i; iters_done[i] = 0;
@@ -1468,7 +1476,7 @@ __global__ __launch_bounds__(256) void solver_init_kernel(int B, int n, T* __res
     const int k = (int)(i % n);
     const T lo = lb[k], hi = ub[k];
     const bool flo = lo > -std::numeric_limits<T>::max(), fhi = hi < std::numeric_limits<T>::max();
-    T z = Z[i];
+    T z = Zin[i];
     T marg = T(1e-2);
     if (flo && fhi) marg = fmin(marg, T(0.25) * (hi - lo));
     if (flo) z = fmax(z, lo + marg);
@@ -1565,6 +1573,7 @@ struct SolverWs {
     int *hpub = nullptr, *hpub_dev = nullptr;  // pinned host memory the device publishes the convergence counter to
     int cap = 0;
     size_t ex_per = 0;
+    std::vector<unsigned char> bounds_host;   // the bounds as last uploaded (lb | ub in the handle's dtype)
 };
 
 int lq_tmp_elems(int nx, int nu) { return 3 * nx * nx + 3 * nx * nu + nu * nu + 5 * nx + 3 * nu + 1 + (nx + 1) * nu; }
@@ -1678,25 +1687,33 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         hu[i] = std::isfinite(hi) ? (T)hi : big;
         has_bounds = has_bounds || std::isfinite(lo) || std::isfinite(hi);
     }
-    NEMPC_HIP(hipMemcpyAsync(ws.lb, hl.data(), n * sizeof(T), hipMemcpyHostToDevice, s));
-    NEMPC_HIP(hipMemcpyAsync(ws.ub, hu.data(), n * sizeof(T), hipMemcpyHostToDevice, s));
-    NEMPC_HIP(hipStreamSynchronize(s));   // hl / hu are stack-owned
+    // (an MPC loop solves with the same bounds every step: they are uploaded when they change)
+    {
+        const size_t nb = (size_t)n * sizeof(T);
+        if (ws.bounds_host.size() != 2 * nb || memcmp(ws.bounds_host.data(), hl.data(), nb) != 0 ||
+            memcmp(ws.bounds_host.data() + nb, hu.data(), nb) != 0) {
+            NEMPC_HIP(hipMemcpyAsync(ws.lb, hl.data(), nb, hipMemcpyHostToDevice, s));
+            NEMPC_HIP(hipMemcpyAsync(ws.ub, hu.data(), nb, hipMemcpyHostToDevice, s));
+            NEMPC_HIP(hipStreamSynchronize(s));   // hl / hu are stack-owned
+            ws.bounds_host.resize(2 * nb);
+            memcpy(ws.bounds_host.data(), hl.data(), nb);
+            memcpy(ws.bounds_host.data() + nb, hu.data(), nb);
+        }
+    }
 
     // ---- working copies in buffer set `cur`; the caller's Z / status are written once, at the end, in the caller's order
     int cur = 0;
     ExtraBindingGuard extra_guard(h);
-    NEMPC_HIP(hipMemcpyAsync(ws.Zc[0], Z, (size_t)B * n * sizeof(T), hipMemcpyDeviceToDevice, s));
-    NEMPC_HIP(hipMemcpyAsync(ws.X0c[0], X0, (size_t)B * nx * sizeof(T), hipMemcpyDeviceToDevice, s));
     if (ex_per) {
         NEMPC_HIP(hipMemcpyAsync(ws.exc[0], h.d_extra, (size_t)B * ex_per * sizeof(T), hipMemcpyDeviceToDevice, s));
         h.d_extra = ws.exc[0];
         h.extra_B = B;
     }
-    const unsigned gBn = (unsigned)(((size_t)B * n + 255) / 256);
+    const unsigned gBn = (unsigned)(((size_t)B * std::max(n, std::max(m, nx)) + 255) / 256);
     hipLaunchKernelGGL(solver_init_kernel<T>, dim3(gBn), dim3(256), 0, s, B, n, (T*)ws.Zc[0], (const T*)ws.lb,
                        (const T*)ws.ub, (T*)ws.muc[0], (T*)ws.nuc[0], (T*)ws.regc[0], ws.stc[0], ws.orig[0], ws.itc[0],
-                       (T*)ws.infoc[0], (T*)ws.zlc[0], (T*)ws.zuc[0], (T)o.mu_init, (T)o.reg, has_bounds ? 1 : 0);
-    NEMPC_HIP(hipMemsetAsync(ws.lamc[0], 0, (size_t)B * m * sizeof(T), s));
+                       (T*)ws.infoc[0], (T*)ws.zlc[0], (T*)ws.zuc[0], (T)o.mu_init, (T)o.reg, has_bounds ? 1 : 0,
+                       (const T*)Z, (const T*)X0, (T*)ws.X0c[0], nx, (T*)ws.lamc[0], m);
 
     SolverArgs a{};
     a.H = H; a.nx = nx; a.nu = nu; a.nin = nin; a.n = n; a.m = m;
