@@ -1477,7 +1477,9 @@ __global__ __launch_bounds__(256) void solver_init_kernel(int B, int n, T* __res
     const T lo = lb[k], hi = ub[k];
     const bool flo = lo > -std::numeric_limits<T>::max(), fhi = hi < std::numeric_limits<T>::max();
     T z = Zin[i];
-    T marg = T(1e-2);
+    // distance kept from a bound: 1e-2 for the default barrier parameter; a warm start (small mu_init) stays closer to
+    // the active bounds it was handed
+    T marg = has_bounds ? fmin(T(1e-2), fmax(T(10) * mu0, T(1e-6))) : T(1e-2);
     if (flo && fhi) marg = fmin(marg, T(0.25) * (hi - lo));
     if (flo) z = fmax(z, lo + marg);
     if (fhi) z = fmin(z, hi - marg);

@@ -35,7 +35,7 @@ for k in range(steps):
     if Zi is None:
         Z, st, it, per = eng.solve(X, lb=lb, ub=-lb, max_iter=mi, return_iterations=True)
     else:
-        Z, st, it, per = eng.solve(X, Zi, lb=lb, ub=-lb, max_iter=mi, return_iterations=True, mu_init=1e-4)
+        Z, st, it, per = eng.solve(X, Zi, lb=lb, ub=-lb, max_iter=mi, return_iterations=True, mu_init=float(os.environ.get("MU0", "1e-4")))
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     ok = st == 0
     p = per[ok].float()
