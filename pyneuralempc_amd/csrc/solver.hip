@@ -634,6 +634,66 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     const T tau = T(0.995);
     #pragma unroll
     for (int i = 0; i < nx; ++i) TMP(odx + i) = T(0);
+    if (PREF && LDS) {
+        // small stages: as in the backward sweep, a stage's inputs (gains, tile, defects, value function) are in registers,
+        // requested one stage ahead -- the recursion carries dx only, and no longer stops twice per stage for LDS round
+        // trips behind its own stores
+        struct FwdIn {
+            T k[PREF ? NU : 1], K[PREF ? NU * NX : 1], A[PREF ? NX * (NX + NU) : 1], gc[PREF ? NX : 1], P[PREF ? NX * NX : 1],
+                p[PREF ? NX : 1];
+        };
+        auto fetch_f = [&](const int t, FwdIn& d) {
+            #pragma unroll
+            for (int e = 0; e < nu; ++e) d.k[PREF ? e : 0] = kst[(size_t)t * nu + e];
+            #pragma unroll
+            for (int e = 0; e < nu * nx; ++e) d.K[PREF ? e : 0] = Kst[(size_t)t * nu * nx + e];
+            #pragma unroll
+            for (int e = 0; e < nx * nin; ++e) d.A[PREF ? e : 0] = tl[(size_t)t * nx * nin + e];
+            #pragma unroll
+            for (int e = 0; e < nx; ++e) { d.gc[PREF ? e : 0] = gc[t * nx + e]; d.p[PREF ? e : 0] = pst[(size_t)t * nx + e]; }
+            #pragma unroll
+            for (int e = 0; e < nx * nx; ++e) d.P[PREF ? e : 0] = Pst[(size_t)t * nx * nx + e];
+        };
+        auto fstage = [&](const int t, const FwdIn& c, FwdIn& nxt) {
+            if (t + 1 < H) fetch_f(t + 1, nxt);
+            #pragma unroll
+            for (int i = 0; i < nu; ++i) {
+                T v = c.k[PREF ? i : 0];
+                if (t > 0)
+                    #pragma unroll
+                    for (int k = 0; k < nx; ++k) v = fma(c.K[PREF ? i * nx + k : 0], TMP(odx + k), v);
+                TMP(odu + i) = v;
+            }
+            #pragma unroll
+            for (int i = 0; i < nx; ++i) {
+                T v = c.gc[PREF ? i : 0];
+                if (t > 0)
+                    #pragma unroll
+                    for (int k = 0; k < nx; ++k) v = fma(c.A[PREF ? i * nin + k : 0], TMP(odx + k), v);
+                #pragma unroll
+                for (int k = 0; k < nu; ++k) v = fma(c.A[PREF ? i * nin + nx + k : 0], TMP(odu + k), v);
+                TMP(odxn + i) = v;
+            }
+            #pragma unroll
+            for (int i = 0; i < nx; ++i) {
+                T lam = c.p[PREF ? i : 0];
+                #pragma unroll
+                for (int k = 0; k < nx; ++k) lam = fma(c.P[PREF ? i * nx + k : 0], TMP(odxn + k), lam);
+                lamn[t * nx + i] = lam;
+                dz[t * nx + i] = TMP(odxn + i);
+            }
+            #pragma unroll
+            for (int i = 0; i < nx; ++i) TMP(odx + i) = TMP(odxn + i);
+            #pragma unroll
+            for (int i = 0; i < nu; ++i) dz[uo + t * nu + i] = TMP(odu + i);
+        };
+        FwdIn fa, fb;
+        fetch_f(0, fa);
+        for (int t = 0; t < H; t += 2) {
+            fstage(t, fa, fb);
+            if (t + 1 < H) fstage(t + 1, fb, fa);
+        }
+    } else
     for (int t = 0; t < H; ++t) {
         const T* At = tl + (size_t)t * nx * nin;
         #pragma unroll
