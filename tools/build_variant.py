@@ -10,6 +10,9 @@ from pyneuralempc_amd import _build
 def main():
     tag = sys.argv[1]
     defs = [a for a in sys.argv[2:] if a.startswith("-D")]
+    for a in sys.argv[2:]:          # --mllvm=<option>: passed to the backend as -mllvm <option> (scheduling experiments)
+        if a.startswith("--mllvm="):
+            defs += ["-mllvm", a[len("--mllvm="):]]
     out = os.path.join(_build.PKG, f"build_{tag}")
     os.makedirs(out, exist_ok=True)
     # only the translation units that see the kernels are rebuilt with the flags; the rest come from the main build
