@@ -194,7 +194,8 @@ int nempc_hess_gn(nempc_handle h, int32_t B, const void* Z, const void* X0, cons
 typedef struct nempc_solver_opts {
     int32_t max_iter;        /* outer iterations, e.g. 200 */
     int32_t max_linesearch;  /* halvings of a step before the direction is given up and the next LQ solve damped, e.g. 6 */
-    int32_t check_every;     /* host convergence poll period in iterations, e.g. 4 */
+    int32_t check_every;     /* period, in iterations, of the BLOCKING convergence poll used for matrix-core-bound stages
+                              * (e.g. 4); small stages do not poll: the device publishes the counter every iteration */
     int32_t lq_kernel;       /* Riccati sweep: 0 auto (by stage size), 1 one thread per problem, 2 one wave per problem */
     double tol_constraint;   /* max |defect| at convergence, e.g. 1e-8 */
     double tol_step;         /* max |dz| <= tol_step * (1 + max |z|), e.g. 1e-8 */
