@@ -201,8 +201,8 @@ typedef struct nempc_solver_opts {
     double tol_step;         /* max |dz| <= tol_step * (1 + max |z|), e.g. 1e-8 */
     double mu_init, mu_min, mu_factor; /* barrier schedule, e.g. 1e-1, 1e-9, 0.2 */
     double reg;              /* initial Levenberg term on the control Hessian, e.g. 1e-9 */
-    int32_t compact;         /* 1: whenever a quarter of the still-active problems has converged (checked every check_every
-                                iterations) gather the unconverged ones to the front and launch only over them -- the
+    int32_t compact;         /* 1: whenever a quarter of the still-active problems has converged (looked at whenever the
+                                convergence counter is read) gather the unconverged ones to the front and launch only over them -- the
                                 stragglers then stop costing batch-wide launches; 0: lock step over all B to the end.
                                 Results are identical either way (per-problem arithmetic does not depend on the slot). */
     int32_t barrier;         /* bounds: 0 primal-dual interior point (multipliers of the bounds carried along; default),
