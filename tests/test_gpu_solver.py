@@ -388,6 +388,29 @@ def test_warm_started_closed_loop_converges_in_fewer_iterations():
     assert max(i for i, _ in its[3:]) < cold_it, (its, cold_it)
 
 
+def test_bounds_are_uploaded_again_when_they_change():
+    """The solver keeps the bounds of the last solve on the device and uploads only when they differ: a second solve with
+    tighter bounds must respect them, and going back must give the first answer again."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, H, B = 2, 1, 12, 16
+    net = orc.MLP.random(nx + nu, [32, 32], nx, seed=2)
+    net.W[-1] *= 0.2
+    net.b[-1] *= 0.2
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B)
+    eng.set_objective(Q=np.eye(nx), R=0.05 * np.eye(nu), xref=np.full((H, nx), 1.0))
+    X0 = eng.to_device(np.random.default_rng(3).uniform(-0.6, 0.6, size=(B, nx)))
+    wide = np.concatenate([np.full(H * nx, -5.0), np.full(H * nu, -1.0)])
+    tight = np.concatenate([np.full(H * nx, -0.7), np.full(H * nu, -0.2)])
+    Za, sa, _ = eng.solve(X0, lb=wide, ub=-wide, max_iter=80)
+    Zb, sb, _ = eng.solve(X0, lb=tight, ub=-tight, max_iter=80)
+    Zc, sc, _ = eng.solve(X0, lb=wide, ub=-wide, max_iter=80)
+    Zd, sd, _ = eng.solve(X0, lb=wide, ub=-wide, max_iter=80)          # same bounds twice in a row: no upload
+    assert torch.equal(Za, Zc) and torch.equal(sa, sc) and torch.equal(Za, Zd)
+    zb = Zb.cpu().numpy()
+    assert (zb >= tight - 1e-12).all() and (zb <= -tight + 1e-12).all()
+    assert np.abs(Za.cpu().numpy()[:, H * nx:]).max() > 0.2 + 1e-3      # the wide solve does use controls beyond the tight limit
+
+
 def test_solver_refuses_unknown_option_values():
     from pyneuralempc_amd import CallbackEngine
     net = orc.MLP.random(3, [16], 2, seed=1)
