@@ -1856,7 +1856,8 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     a.carry = 0; a.tiles_t = ws.tiles_t; a.grad_t = ws.grad_t;
     a.hpub = ws.hpub_dev;
     for (int k = 0; k < 8; ++k) ws.hpub[k] = 0;       // (the previous solve on this handle ended with a synchronised stream)
-    const bool lagged_polls = !wave_wanted;     // small stages: iterations are chains of latency-bound launches
+    const bool published_polls = !wave_wanted;  // small stages (chains of latency-bound launches): no blocking polls, the host
+                                                // reads the counter the device publishes
     int Bact = B;                 // slots [0, Bact) may still be unconverged; compaction keeps them in front
     int last_nact = B;            // unconverged problems at the last convergence poll
     int it = 0, rc;
@@ -1919,7 +1920,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         // backtracking launches below.
         bool polled = false;
         int nact = Bact;
-        if (!lagged_polls && ((it + 1) % check == 0 || it + 1 == o.max_iter)) {
+        if (!published_polls && ((it + 1) % check == 0 || it + 1 == o.max_iter)) {
             NEMPC_HIP(hipMemcpyAsync(ws.hpoll, ws.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
             NEMPC_HIP(hipStreamSynchronize(s));
             nact = ws.hpoll[0];
@@ -2001,7 +2002,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                 break;
             }
         }
-        if (lagged_polls) {
+        if (published_polls) {
             // Small stages: an iteration is a chain of latency-bound launches, and a blocking poll drains the stream (10
             // polls of ~25 us in a 5.5 ms solve).  The acceptance kernel PUBLISHES the iteration's counter to pinned host
             // memory; the host only makes sure it never runs more than two iterations ahead of the device (it would
@@ -2098,7 +2099,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             cur = nxt;
             point_at(cur);
             have_eval = false;            // (the evaluation buffers are not gathered: one launch after a compaction)
-            if (lagged_polls) {
+            if (published_polls) {
                 Bact = nact > 0 ? (nact < Bact ? nact : Bact) : 1;
             } else {
                 NEMPC_HIP(hipMemcpyAsync(ws.hpoll, ws.count, sizeof(int), hipMemcpyDeviceToHost, s));
