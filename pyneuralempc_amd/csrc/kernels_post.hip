@@ -195,6 +195,35 @@ __global__ __launch_bounds__(256) void assemble_hess_kernel(int cnt, int w, int 
     }
 }
 
+// The Gauss-Newton form of the same assembly without the intermediate blocks: a block element is formed where it is
+// used, from the row kernel's tiles, with gn_blocks_kernel's arithmetic (product first, then the weighted sum over the
+// nx outputs of the row) -- one launch and one (B, H, nin, nin) round trip through memory less per callback
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_hess_gn_kernel(int cnt, int w, int rows, int nx, int nin,
+                                                               const int32_t* __restrict__ map, const T* __restrict__ objc,
+                                                               const T* __restrict__ tiles, const T* __restrict__ wgt,
+                                                               const T* __restrict__ sigma, T* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cnt) return;
+    const int nn = nin * nin;
+    T v = sigma[b] * objc[e];
+    for (int k = 0; k < w; ++k) {
+        const int32_t c = map[(size_t)e * w + k];
+        if (c < 0) continue;
+        const int r = c / nn, pq = c - r * nn, p = pq / nin, q = pq - p * nin;
+        const T* t = tiles + ((size_t)b * rows + r) * (size_t)(nx * nin);
+        const T* wr = wgt ? wgt + ((size_t)b * rows + r) * nx : nullptr;
+        T s = T(0);
+        for (int i = 0; i < nx; ++i) {
+            const T tt = t[i * nin + p] * t[i * nin + q];
+            s = fma(wr ? wr[i] : T(1), tt, s);
+        }
+        v += s;
+    }
+    out[(size_t)b * cnt + e] = v;
+}
+
 }  // namespace
 
 int launch_objective(Handle& h, int B, const void* Z, void* f, void* grad, hipStream_t s) {
@@ -364,6 +393,28 @@ int launch_assemble_hess(Handle& h, int B, const void* blocks, const void* sigma
                                (const float*)(objc + (size_t)nnz * esz), (const float*)blocks, (const float*)sigma,
                                (float*)hdense);
     }
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
+int launch_assemble_hess_gn(Handle& h, int B, const void* tiles, const void* w, const void* sigma, void* hvals, void* hdense,
+                            hipStream_t s) {
+    const int nnz = (int)h.hess_rows.size();
+    const int nn = h.n * h.n;
+    const dim3 block(256);
+    const size_t esz = h.esz;
+    const char* objc = (const char*)h.d_obj + (size_t)obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu).total * esz;
+    auto go = [&](int cnt, const int32_t* map, const char* oc, void* out) {
+        const dim3 grid((unsigned)((cnt + 255) / 256), (unsigned)B);
+        if (h.cfg.dtype == NEMPC_F64)
+            hipLaunchKernelGGL(assemble_hess_gn_kernel<double>, grid, block, 0, s, cnt, h.w, h.cfg.H, h.cfg.nx, h.nin, map,
+                               (const double*)oc, (const double*)tiles, (const double*)w, (const double*)sigma, (double*)out);
+        else
+            hipLaunchKernelGGL(assemble_hess_gn_kernel<float>, grid, block, 0, s, cnt, h.w, h.cfg.H, h.cfg.nx, h.nin, map,
+                               (const float*)oc, (const float*)tiles, (const float*)w, (const float*)sigma, (float*)out);
+    };
+    if (hvals) go(nnz, h.d_hess_map, objc, hvals);
+    if (hdense) go(nn, h.d_hess_map + (size_t)nnz * h.w, objc + (size_t)nnz * esz, hdense);
     NEMPC_HIP(hipGetLastError());
     return NEMPC_OK;
 }

@@ -616,10 +616,11 @@ int nempc_hess_gn(nempc_handle hh, int32_t B, const void* Z, const void* X0, con
     int rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, h.d_g_ws, h.d_tiles_ws, s)
                                             : launch_rows_valu(h, B, Z, X0, h.d_g_ws, h.d_tiles_ws, s);
     if (rc) return rc;
-    void* blocks = hblocks ? hblocks : h.d_hess_ws;
-    if ((rc = launch_gn_blocks(h, B, h.d_tiles_ws, w, blocks, s))) return rc;
+    // the caller does not ask for the per-row blocks: the assembly forms their elements where it uses them
+    if (!hblocks) return (hvals || hdense) ? launch_assemble_hess_gn(h, B, h.d_tiles_ws, w, sigma, hvals, hdense, s) : NEMPC_OK;
+    if ((rc = launch_gn_blocks(h, B, h.d_tiles_ws, w, hblocks, s))) return rc;
     if (!hvals && !hdense) return NEMPC_OK;
-    return launch_assemble_hess(h, B, blocks, sigma, hvals, hdense, s);
+    return launch_assemble_hess(h, B, hblocks, sigma, hvals, hdense, s);
 }
 
 int nempc_solve(nempc_handle hh, int32_t B, const void* X0, void* Z, const double* lb, const double* ub,

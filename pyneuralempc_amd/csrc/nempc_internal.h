@@ -191,6 +191,8 @@ void rk4hess_free(Handle& h);
 
 // ---- kernels_post.hip : objective, dense / sparse assembly, hessian assembly
 int launch_objective(Handle& h, int B, const void* Z, void* f, void* grad, hipStream_t s);
+int launch_assemble_hess_gn(Handle& h, int B, const void* tiles, const void* w, const void* sigma, void* hvals, void* hdense,
+                            hipStream_t s);
 int launch_assemble_dense(Handle& h, int B, const void* tiles, void* jac, hipStream_t s);
 int launch_assemble_sparse(Handle& h, int B, const void* tiles, void* vals, hipStream_t s);
 int launch_post(Handle& h, int B, const void* tiles, void* jac, const void* Z, void* f, void* grad, hipStream_t s);
