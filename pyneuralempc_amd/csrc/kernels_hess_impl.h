@@ -31,6 +31,15 @@ struct HessParams {
     int xi_stride;
     const void* lam_direct;  // (rows, nx) stage multipliers nu_s
     int vdiv;                // rows per (problem, step) row: the extra inputs of row r are those of r / vdiv
+    // fused assembly (cooperative kernel, plain models, tril values only): the kernel writes
+    // hvals[b][e] = sigma_b * objc[e] + block element straight from its block buffer in LDS -- smap[t*nin*nin + pq] is
+    // the tril entry a block element lands in (-1: none); the n_orph entries no block reaches (objective only) follow at
+    // smap[H*nin*nin ...] and are written by the problem's last row
+    void* hvals;
+    const void* sigma;
+    const int32_t* smap;
+    const void* objc;
+    int nnz, n_orph;
 };
 
 template <typename T, int WP, int NH, bool WLDS>

@@ -252,6 +252,32 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coop_kernel(HessPar
 
         // ---- output: exactly symmetric blocks (lower triangle mirrored), the tile's 16 rows contiguous in memory
         const int bsz = nin * nin;
+        if (hp.hvals) {
+            // fused assembly (nempc_hess asked for the tril values only): assemble_hess_kernel's arithmetic, here
+            T* hv = static_cast<T*>(hp.hvals);
+            const T* sg = static_cast<const T*>(hp.sigma);
+            const T* oc = static_cast<const T*>(hp.objc);
+            const int Hh = p.H;
+            for (int e = tid; e < 16 * bsz; e += NTHREADS) {
+                const int cc = e / bsz, rem = e - cc * bsz;
+                const size_t r = (size_t)row0 + cc;
+                if (r >= (size_t)R) continue;
+                const int a1 = rem / nin, a2 = rem - a1 * nin;
+                const int hi = a1 > a2 ? a1 : a2, lo = a1 > a2 ? a2 : a1;
+                const size_t b = r / Hh;
+                const int t = (int)(r - b * Hh);
+                const int ent = hp.smap[t * bsz + rem];
+                if (ent >= 0) {
+                    T v = sg[b] * oc[ent];
+                    v += s_H[(cc * nin + hi) * nin + lo];
+                    hv[b * hp.nnz + ent] = v;
+                }
+                if (t == Hh - 1 && rem < hp.n_orph) {
+                    const int oe = hp.smap[Hh * bsz + rem];
+                    hv[b * hp.nnz + oe] = sg[b] * oc[oe];
+                }
+            }
+        } else
         for (int e = tid; e < 16 * bsz; e += NTHREADS) {
             const int cc = e / bsz, rem = e - cc * bsz;
             const int a1 = rem / nin, a2 = rem - a1 * nin;

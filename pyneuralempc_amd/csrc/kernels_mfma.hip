@@ -224,6 +224,18 @@ int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const v
     return launch_rowhess_mfma_direct(h, B, Z, X0, lambda, blocks, nullptr, 0, nullptr, 1, s);
 }
 
+// blocks and assembly in one launch: the tril values of the Lagrangian Hessian written by the cooperative Hessian kernel
+// itself.  NEMPC_EUNSUPPORTED (nothing launched) when the shape runs on the wave-per-tile kernel or the model has a
+// rolling window (an entry then sums block elements of several rows).
+int launch_rowhess_mfma_hvals(Handle& h, int B, const void* Z, const void* X0, const void* lambda, const void* sigma,
+                              void* hvals, hipStream_t s) {
+    if (h.w != 1 || !h.d_hess_smap || h.hess_n_orph < 0) return NEMPC_EUNSUPPORTED;
+    h.fuse_hvals = hvals; h.fuse_sigma = sigma;
+    const int rc = launch_rowhess_mfma_direct(h, B, Z, X0, lambda, nullptr, nullptr, 0, nullptr, 1, s);
+    h.fuse_hvals = nullptr; h.fuse_sigma = nullptr;
+    return rc;
+}
+
 int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
                                const void* xi_direct, int xi_stride, const void* lam_direct, int vdiv, hipStream_t s) {
     if (!h.mfma.blob) {
@@ -245,6 +257,11 @@ int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, 
     p.scratch_per_wave = (16 * h.nin + 16 * h.cfg.nx + 16 * h.nin * h.nin + 16 * h.ne + 1) & ~1;
     p.dbg = nullptr;
     hp.lambda = lambda; hp.blocks = blocks;
+    if (h.fuse_hvals) {
+        hp.hvals = h.fuse_hvals; hp.sigma = h.fuse_sigma; hp.smap = h.d_hess_smap;
+        hp.objc = (const char*)h.d_obj + (size_t)obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu).total * h.esz;
+        hp.nnz = (int)h.hess_rows.size(); hp.n_orph = h.hess_n_orph;
+    }
     hp.p0tab = p.off.p0tab; hp.wLb = p.off.wLb; hp.ksx = (h.cfg.nx + 3) / 4;
     return h.cfg.dtype == NEMPC_F64 ? launch_rowhess_mfma_typed<double>(h, hp, s)
                                     : launch_rowhess_mfma_typed<float>(h, hp, s);

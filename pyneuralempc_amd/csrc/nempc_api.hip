@@ -232,6 +232,25 @@ int upload_objective(Handle& h, const ObjHost& o_in) {
     if ((rc = dev_alloc((void**)&h.d_hess_map, hmap.size() * sizeof(int32_t)))) return rc;
     if ((rc = upload(h, all, h.d_obj))) return rc;
     NEMPC_HIP(hipMemcpy(h.d_hess_map, hmap.data(), hmap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    // scatter form of the tril map for the Hessian kernel's fused assembly (plain models: one block element per entry)
+    p = h.d_hess_smap;
+    dev_free(p);
+    h.d_hess_smap = nullptr;
+    h.hess_n_orph = -1;
+    if (w == 1) {
+        const int nnz_t = (int)h.hess_rows.size(), be = H * nin * nin;
+        std::vector<int32_t> smap((size_t)be, -1), orph;
+        for (int e = 0; e < nnz_t; ++e) {
+            if (hmap[e] >= 0) smap[hmap[e]] = e;
+            else orph.push_back(e);
+        }
+        if ((int)orph.size() <= nin * nin) {
+            smap.insert(smap.end(), orph.begin(), orph.end());
+            if ((rc = dev_alloc((void**)&h.d_hess_smap, smap.size() * sizeof(int32_t)))) return rc;
+            NEMPC_HIP(hipMemcpy(h.d_hess_smap, smap.data(), smap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            h.hess_n_orph = (int)orph.size();
+        }
+    }
     h.have_objective = true;
     return NEMPC_OK;
 }
@@ -250,6 +269,7 @@ void destroy_impl(Handle* h) {
     void* p = h->d_dense_map; dev_free(p); h->d_dense_map = nullptr;
     p = h->d_sparse_map; dev_free(p); h->d_sparse_map = nullptr;
     p = h->d_hess_map; dev_free(p); h->d_hess_map = nullptr;
+    p = h->d_hess_smap; dev_free(p); h->d_hess_smap = nullptr;
     dev_free(h->d_tiles_ws);
     dev_free(h->d_g_ws);
     dev_free(h->d_valu_ws);
@@ -587,6 +607,11 @@ int nempc_hess(nempc_handle hh, int32_t B, const void* Z, const void* X0, const 
     if (!dg.ok) return fail(NEMPC_EHIP, "nempc_hess: hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
+    // tril values only, on a cooperative-kernel shape: the Hessian kernel assembles them itself (one launch)
+    if (hvals && !hdense && !hblocks && h.variant != NEMPC_KERNEL_VALU && h.cfg.integrator != NEMPC_RK4) {
+        rc = launch_rowhess_mfma_hvals(h, B, Z, X0, lambda, sigma, hvals, s);
+        if (rc != NEMPC_EUNSUPPORTED) return rc;
+    }
     void* blocks = hblocks ? hblocks : h.d_hess_ws;
     if (h.variant == NEMPC_KERNEL_VALU) rc = launch_rowhess_valu(h, B, Z, X0, lambda, blocks, s);
     else if (h.cfg.integrator == NEMPC_RK4) rc = launch_rowhess_rk4_mfma(h, B, Z, X0, lambda, blocks, s);

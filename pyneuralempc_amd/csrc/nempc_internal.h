@@ -122,6 +122,10 @@ struct Handle {
     int32_t* d_dense_map = nullptr;   // (m*n)
     int32_t* d_sparse_map = nullptr;  // (nnz_jac)
     int32_t* d_hess_map = nullptr;    // (nnz_hess + n*n, w) per-row block elements summed into each entry; -1 = none
+    int32_t* d_hess_smap = nullptr;   // plain models: (H*nin*nin) block element -> tril entry (-1 none), then the entries no
+    int hess_n_orph = -1;             //   block reaches (hess_n_orph of them; -1: no fused assembly for this handle)
+    void* fuse_hvals = nullptr;       // set around a launch that assembles the tril values itself
+    const void* fuse_sigma = nullptr;
 
     // workspaces sized for max_batch
     void* d_tiles_ws = nullptr;  // (Bmax,H,nx,nin) when the caller does not ask for tiles
@@ -178,6 +182,8 @@ int launch_eval_fused(Handle& h, int B, const void* Z, const void* X0, void* g, 
 void mfma_free(Handle& h);
 int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
                         hipStream_t s);
+int launch_rowhess_mfma_hvals(Handle& h, int B, const void* Z, const void* X0, const void* lambda, const void* sigma,
+                              void* hvals, hipStream_t s);
 int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* stage_out,
                             int stage_stride, hipStream_t s);
 int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
