@@ -577,6 +577,12 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
             rc = launch_eval_fused(h, B, Z, X0, gout, jac_tiles, jac_dense, f, grad, s);
             if (rc != NEMPC_EUNSUPPORTED) return rc;
         }
+        // sparse contract on a compiled shape: rows, tiles and the objective from the fused launch (without the dense
+        // matrix), then the band values gathered from the tiles
+        if (jac_sparse && !jac_dense && h.variant == NEMPC_KERNEL_MFMA) {
+            rc = launch_eval_fused(h, B, Z, X0, gout, tiles, nullptr, f, grad, s);
+            if (rc != NEMPC_EUNSUPPORTED) return rc ? rc : launch_assemble_sparse(h, B, tiles, jac_sparse, s);
+        }
         rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, gout, tiles, s)
                                             : launch_rows_valu(h, B, Z, X0, gout, tiles, s);
         if (rc) return rc;
