@@ -10,6 +10,7 @@ kernels (needs a GPU; SLSQP drives them because cyipopt is not installed).
 
     python examples/lotka_volterra/run.py --steps 20            # closed loop, one plant
     python examples/lotka_volterra/run.py --steps 5 --batch 256 # 256 plants solved in lock step on the device
+    python examples/lotka_volterra/run.py --steps 20 --device-solver   # one plant, the whole solve on the device
 """
 import argparse
 import os
@@ -61,7 +62,7 @@ def plant_step(x, u, dt):
     return x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
 
 
-def main(steps=20, batch=0, fit_iters=1500, device="cuda:0", verbose=True):
+def main(steps=20, batch=0, fit_iters=1500, device="cuda:0", verbose=True, device_solver=False):
     W, b, loss = fit_surrogate(fit_iters)
     if verbose:
         print(f"surrogate fitted, mse {loss:.2e}")
@@ -73,7 +74,8 @@ def main(steps=20, batch=0, fit_iters=1500, device="cuda:0", verbose=True):
     # run.py:84-93: cost = sum(u * 1.1) -- the linear member of the quadratic family
     objective_func = nEMPC.objective.QuadraticObjective(Q=np.zeros((2, 2)), R=np.zeros((1, 1)), cu=np.full((H, 1), 1.1),
                                                         device=device)
-    optimizer = nEMPC.optimizer.Slsqp(max_iteration=200, tolerance=1e-8, verbose=0, init_with_last_result=True)
+    optimizer = (nEMPC.optimizer.DeviceSqp(max_iteration=200, tolerance=1e-8, init_with_last_result=True) if device_solver
+                 else nEMPC.optimizer.Slsqp(max_iteration=200, tolerance=1e-8, verbose=0, init_with_last_result=True))
     MPC = nEMPC.controller.NMPC(integrator, objective_func, constraints_nmpc, H, DT, optimizer=optimizer)   # run.py:96
 
     if batch:
@@ -108,5 +110,6 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--fit-iters", type=int, default=1500)
+    ap.add_argument("--device-solver", action="store_true", help="NMPC.next with optimizer.DeviceSqp instead of SLSQP")
     a = ap.parse_args()
-    main(a.steps, a.batch, a.fit_iters)
+    main(a.steps, a.batch, a.fit_iters, device_solver=a.device_solver)

@@ -240,6 +240,13 @@ def test_lotka_volterra_example_runs():
     assert traj[:, 0].max() <= lv.X_MAX + 0.05          # state limit respected up to the surrogate's model error
     X = lv.main(steps=2, batch=16, fit_iters=300, verbose=False)
     assert X.shape == (16, 2) and np.all(np.isfinite(X))
+    # the same closed loop with the whole solve on the device (optimizer.DeviceSqp behind NMPC.next)
+    traj_dev = lv.main(steps=3, fit_iters=300, verbose=False, device_solver=True)
+    assert traj_dev.shape == (4, 2) and np.all(np.isfinite(traj_dev))
+    assert traj_dev[:, 0].max() <= lv.X_MAX + 0.05
+    # (an economic cost, linear in u: the two solvers need not pick the same minimiser step by step -- same plant path
+    # to a few 1e-3 over these steps)
+    np.testing.assert_allclose(traj_dev, traj, atol=3e-2)
 
 
 def test_torch_objective_through_the_unfused_glue():
