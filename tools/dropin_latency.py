@@ -49,5 +49,18 @@ with warnings.catch_warnings():
     for i in range(200):
         ip.hessian(z + 1e-9 * i, lam, 1.0)
     th = (time.perf_counter() - t3) / 200
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    mpc_d = nEMPC.controller.NMPC(integ, obj, [nEMPC.constraints.DomainConstraint([[-5.0, 5.0]] * nx, [[-1.0, 1.0]])], H, 1.0,
+                                  optimizer=nEMPC.optimizer.DeviceSqp(init_with_last_result=True))
+    xd = np.array([0.7, -0.4])
+    mpc_d.next(xd)
+    t4 = time.perf_counter()
+    for _ in range(steps):
+        sd, ud = mpc_d.next(xd)
+        xd = sd[0]
+    td = (time.perf_counter() - t4) / steps
+print(f"NMPC.next (DeviceSqp, warm-started, the whole solve on the device): {td * 1e3:.2f} ms per MPC step, "
+      f"{mpc_d.optimizer.last_iterations} iterations in the last one")
 print(f"sparse-Jacobian callback (band values from the device): {ts * 1e6:.0f} us; Lagrangian-Hessian callback: {th * 1e6:.0f} us")
 print(f"NMPC.next (warm-started SLSQP): {dt / steps * 1e3:.2f} ms per MPC step; fused callback evaluation incl. host copies: {te * 1e6:.0f} us")
