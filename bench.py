@@ -506,7 +506,9 @@ class Rank:
                 "allgather_path": "nempc_allgather_u0 (RCCL)" if eng.comm is not None else
                                   ("torch.distributed/" + self.backend if self.dist is not None else "single rank"),
                 "other_budgets_this_rank": budgets,
-                "note": "SQP + Riccati, exact Lagrangian blocks, bounds |x|<=3 |u|<=0.5 by a primal-dual interior point, "
+                "note": "SQP + Riccati, exact Lagrangian blocks, bounds |x|<=3 |u|<=0.5 "
+                        + (f"and the handle's box rows (states in [{cfg['box'][0]}, {cfg['box'][1]}], taken as state bounds) "
+                           if cfg["box"] is not None else "") + "by a primal-dual interior point, "
                         + ("inner-loop backtracking with later trials evaluated for the problems still searching only"
                            if cfg["nx"] * (cfg["nx"] + cfg["nu"]) >= 12 else
                            "deferred backtracking (one evaluation per iteration: an accepted trial's is the next iterate's)")
@@ -589,7 +591,7 @@ class Rank:
             if self.rank == 0:
                 out["pipelined_two_streams"] = self.two_stream_leg(res)
             # ---- batched solver + all-gather of the solved u0 (collective: every rank)
-            if cfg["box"] is None and (cfg["integrator"] != "rk4" or eng.kernel_variant != "valu"):
+            if cfg["integrator"] != "rk4" or eng.kernel_variant != "valu":
                 out["batched_solver"] = self.solver_leg(res)
             if args.hessian and (cfg["integrator"] != "rk4" or eng.kernel_variant != "valu"):
                 out["hessian_callback"] = self.hessian_leg(res)
