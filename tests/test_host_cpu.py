@@ -206,3 +206,19 @@ def test_reference_names_without_a_device_counterpart_explain_themselves():
         nEMPC.model.jax.DiffDiscretJaxModelRollingWindow(lambda x, u, p=None, tvp=None: x, 2, 1, rolling_window=2)
     with pytest.raises(NotImplementedError):
         nEMPC.model.base.ReOrderProxyModel(None, [])
+
+
+def test_device_optimizer_host_contract():
+    """optimizer.DeviceSqp on the host side: it is an Optimizer with Slsqp's start-vector plumbing and the same factory,
+    and a problem without the fused device path is refused (no CPU fallback behind it)."""
+    import pyneuralempc_amd as nEMPC
+    from pyneuralempc_amd.optimizer.slsqp import SlsqpProblemFactory
+    opt = nEMPC.optimizer.DeviceSqp(max_iteration=50, tolerance=1e-7, init_with_last_result=True, linesearch="deferred")
+    assert isinstance(opt, nEMPC.optimizer.Optimizer) and isinstance(opt.get_factory(), SlsqpProblemFactory)
+    assert opt.prev_result is None and opt.solver_opts == {"linesearch": "deferred"}
+
+    class NoFusedPath:
+        _fused = None
+
+    with pytest.raises(NotImplementedError, match="fused device path"):
+        opt.solve(NoFusedPath(), None)
