@@ -1638,6 +1638,13 @@ struct SolverWs {
     std::vector<unsigned char> bounds_host;   // the bounds as last uploaded (lb | ub in the handle's dtype)
 };
 
+// polite busy-wait on a word the device writes (the waits are microseconds: no yield, no sleep)
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
 int lq_tmp_elems(int nx, int nu) { return 3 * nx * nx + 3 * nx * nu + nu * nu + 5 * nx + 3 * nu + 1 + (nx + 1) * nu; }
 
 }  // namespace
@@ -1989,6 +1996,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                 const auto t0 = std::chrono::steady_clock::now();
                 long spins = 0;
                 while (hp[4] != pend_seq) {
+                    cpu_relax();
                     if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                         NEMPC_HIP(hipStreamSynchronize(s));      // a device fault surfaces here instead of a hang
                         if (hp[4] != pend_seq) return NEMPC_EHIP;
@@ -2015,6 +2023,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                 const auto t0 = std::chrono::steady_clock::now();
                 long spins = 0;
                 while (hp[0] < want) {
+                    cpu_relax();
                     if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                         NEMPC_HIP(hipStreamSynchronize(s));      // a device fault surfaces here instead of a hang
                         if (hp[0] < want) return NEMPC_EHIP;
