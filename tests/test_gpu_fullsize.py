@@ -199,3 +199,30 @@ def test_fused_launch_sweep_of_small_shapes(box):
                 if t >= 1:
                     np.testing.assert_allclose(T[:, t, :, :2], J[:, 2 * t:2 * t + 2, 2 * (t - 1):2 * t], **F64)
             del eng
+
+
+@pytest.mark.parametrize("dims", [(20, 9001, None), (50, 3301, (-2.0, 2.0))])
+def test_fused_evaluation_at_batches_of_many_passes_per_workgroup(dims):
+    """Batches beyond 8192 row tiles (every workgroup of the one-launch kernel runs many passes; ragged last tile): the
+    fixed-shape kernel keeps the launch, agrees with the wave-per-tile family to rounding and with the oracle on the
+    first / middle / last slices, structural zeros exact."""
+    H, B, box = dims
+    net = orc.MLP.random(3, [64, 64], 2, seed=0)
+    eng = _engine(net, H, 2, 1, B, box=box)
+    ref = _engine(net, H, 2, 1, B, kernel="mfma_tile", box=box)
+    Zh, X0h = orc.synthetic_inputs(B, H, 2, 1, seed=11)
+    Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+    a = eng.eval(Z, X0, DEFAULT)
+    assert eng.last_row_kernel == "rows_coopfx_kernel" and (B * H + 15) // 16 > 8192
+    b = ref.eval(Z, X0, DEFAULT)
+    for k in DEFAULT:
+        assert float((a[k] - b[k]).abs().max()) < 1e-12, k
+    prob = orc.Problem(net, H, 2, 1, box=box)
+    for sl in _slices(B):
+        f, grad, g, J = prob.eval_batch(Zh[sl], X0h[sl])
+        np.testing.assert_allclose(a["f"][sl].cpu().numpy(), f, **F64)
+        np.testing.assert_allclose(a["grad"][sl].cpu().numpy(), grad, **F64)
+        np.testing.assert_allclose(a["g"][sl].cpu().numpy(), g, **F64)
+        Jd = a["jac_dense"][sl].cpu().numpy()
+        np.testing.assert_allclose(Jd, J, **F64)
+        assert np.array_equal(Jd == 0.0, J == 0.0)

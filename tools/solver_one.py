@@ -9,7 +9,7 @@ from pyneuralempc_amd import CallbackEngine
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 mi = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 ls = sys.argv[3] if len(sys.argv) > 3 else "auto"
-B = 1024
+B = int(os.environ.get("NEMPC_TOOL_B", "1024"))
 if cfg == "c2":
     nx, nu, H, hidden, integ, DT, dt = 2, 1, 20, [64, 64], "discret", 1.0, torch.float64
 else:
