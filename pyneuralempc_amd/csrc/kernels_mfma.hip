@@ -230,14 +230,12 @@ int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const v
 int launch_rowhess_mfma_hvals(Handle& h, int B, const void* Z, const void* X0, const void* lambda, const void* sigma,
                               void* hvals, hipStream_t s) {
     if (h.w != 1 || !h.d_hess_smap || h.hess_n_orph < 0) return NEMPC_EUNSUPPORTED;
-    h.fuse_hvals = hvals; h.fuse_sigma = sigma;
-    const int rc = launch_rowhess_mfma_direct(h, B, Z, X0, lambda, nullptr, nullptr, 0, nullptr, 1, s);
-    h.fuse_hvals = nullptr; h.fuse_sigma = nullptr;
-    return rc;
+    return launch_rowhess_mfma_direct(h, B, Z, X0, lambda, nullptr, nullptr, 0, nullptr, 1, s, hvals, sigma);
 }
 
 int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
-                               const void* xi_direct, int xi_stride, const void* lam_direct, int vdiv, hipStream_t s) {
+                               const void* xi_direct, int xi_stride, const void* lam_direct, int vdiv, hipStream_t s,
+                               void* fuse_hvals, const void* fuse_sigma) {
     if (!h.mfma.blob) {
         set_error("launch_rowhess_mfma: weights not packed");
         return NEMPC_ESTATE;
@@ -257,8 +255,8 @@ int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, 
     p.scratch_per_wave = (16 * h.nin + 16 * h.cfg.nx + 16 * h.nin * h.nin + 16 * h.ne + 1) & ~1;
     p.dbg = nullptr;
     hp.lambda = lambda; hp.blocks = blocks;
-    if (h.fuse_hvals) {
-        hp.hvals = h.fuse_hvals; hp.sigma = h.fuse_sigma; hp.smap = h.d_hess_smap;
+    if (fuse_hvals) {       // the kernel assembles the tril values itself (launch_rowhess_mfma_hvals)
+        hp.hvals = fuse_hvals; hp.sigma = fuse_sigma; hp.smap = h.d_hess_smap;
         hp.objc = (const char*)h.d_obj + (size_t)obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu).total * h.esz;
         hp.nnz = (int)h.hess_rows.size(); hp.n_orph = h.hess_n_orph;
     }

@@ -124,8 +124,6 @@ struct Handle {
     int32_t* d_hess_map = nullptr;    // (nnz_hess + n*n, w) per-row block elements summed into each entry; -1 = none
     int32_t* d_hess_smap = nullptr;   // plain models: (H*nin*nin) block element -> tril entry (-1 none), then the entries no
     int hess_n_orph = -1;             //   block reaches (hess_n_orph of them; -1: no fused assembly for this handle)
-    void* fuse_hvals = nullptr;       // set around a launch that assembles the tril values itself
-    const void* fuse_sigma = nullptr;
 
     // workspaces sized for max_batch
     void* d_tiles_ws = nullptr;  // (Bmax,H,nx,nin) when the caller does not ask for tiles
@@ -187,7 +185,8 @@ int launch_rowhess_mfma_hvals(Handle& h, int B, const void* Z, const void* X0, c
 int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* stage_out,
                             int stage_stride, hipStream_t s);
 int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
-                               const void* xi_direct, int xi_stride, const void* lam_direct, int vdiv, hipStream_t s);
+                               const void* xi_direct, int xi_stride, const void* lam_direct, int vdiv, hipStream_t s,
+                               void* fuse_hvals = nullptr, const void* fuse_sigma = nullptr);
 
 // ---- kernels_rk4hess.hip : RK4 Lagrangian blocks on the matrix cores (stage records -> stage multipliers ->
 //      contracted network Hessians of the four stage inputs -> congruence sum)
