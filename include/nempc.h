@@ -245,6 +245,14 @@ int nempc_allgather_u0(nempc_handle h, int32_t B, int32_t rows_per_rank, const v
 int nempc_comm_size(nempc_handle h, int32_t* nranks, int32_t* rank);
 int nempc_comm_destroy(nempc_handle h);
 
+/* Launch planning of the cooperative kernels (host arithmetic only, no device needed): ntiles 16-row tiles over
+ * per_cu co-resident workgroups on each of num_cus compute units -> grid workgroups, workgroup i owning
+ * tiles_per_wg + (i < tiles_rem) consecutive tiles.  The library sizes every chip-filling launch this way from
+ * hipDeviceProp_t::multiProcessorCount of the handle's device (nempc_num_cus), never from a literal CU count. */
+int nempc_plan_grid(int32_t ntiles, int32_t num_cus, int32_t per_cu, int32_t* grid, int32_t* tiles_per_wg,
+                    int32_t* tiles_rem);
+int nempc_num_cus(nempc_handle h);
+
 /* which row kernel the handle resolved to (NEMPC_KERNEL_VALU | NEMPC_KERNEL_MFMA | NEMPC_KERNEL_MFMA_TILE) */
 int nempc_kernel_variant(nempc_handle h);
 

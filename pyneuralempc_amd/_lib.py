@@ -19,6 +19,7 @@ INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
 EXPORTS = ["nempc_create", "nempc_destroy", "nempc_reserve", "nempc_set_weights", "nempc_set_objective", "nempc_set_terminal_weight", "nempc_set_box_rows", "nempc_bind_extra", "nempc_bind_history",
            "nempc_dims", "nempc_constraint_bounds", "nempc_jac_structure", "nempc_hess_structure", "nempc_eval",
            "nempc_hess", "nempc_hess_gn", "nempc_solve", "nempc_sync", "nempc_kernel_variant", "nempc_last_row_kernel", "nempc_last_error", "nempc_abi_version",
+           "nempc_plan_grid", "nempc_num_cus",
            "nempc_comm_unique_id", "nempc_comm_init", "nempc_allgather_u0", "nempc_comm_size", "nempc_comm_destroy"]
 
 
@@ -79,6 +80,8 @@ def load():
     lib.nempc_sync.argtypes = [vp, vp]
     lib.nempc_kernel_variant.argtypes = [vp]
     lib.nempc_last_row_kernel.argtypes = [vp]
+    lib.nempc_plan_grid.argtypes = [i32, i32, i32, ip, ip, ip]
+    lib.nempc_num_cus.argtypes = [vp]
     lib.nempc_comm_unique_id.argtypes = [vp]
     lib.nempc_comm_init.argtypes = [vp, i32, i32, vp]
     lib.nempc_allgather_u0.argtypes = [vp, i32, i32, vp, vp, vp, vp]

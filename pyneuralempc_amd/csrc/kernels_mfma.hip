@@ -175,7 +175,7 @@ static MfmaParams base_params(Handle& h, int B, const void* Z, const void* X0, v
     p.ne = h.ne; p.extra = h.d_extra;
     p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin, (int)h.esz);
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
-    p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
+    p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0; p.num_cus = h.num_cus;
     p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
     p.gk = h.gather();
     p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
@@ -209,7 +209,7 @@ int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, voi
     p.ne = h.ne; p.extra = h.d_extra;
     p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin, (int)h.esz);
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
-    p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
+    p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0; p.num_cus = h.num_cus;
     p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
     p.gk = h.gather();
     p.stage_out = stage_out; p.stage_stride = stage_stride;
@@ -247,7 +247,7 @@ int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, 
     p.ne = h.ne; p.extra = h.d_extra;
     p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin, (int)h.esz);
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
-    p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0;
+    p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0; p.num_cus = h.num_cus;
     p.Z = Z; p.X0 = X0; p.g = nullptr; p.tiles = nullptr;
     p.gk = h.gather();
     p.ntiles = (int)(((size_t)B * h.cfg.H * (xi_direct ? vdiv : 1) + 15) / 16);

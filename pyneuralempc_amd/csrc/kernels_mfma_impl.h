@@ -52,6 +52,7 @@ struct MfmaParams {
     int kind;
     double DT;
     int B, H, m, box;
+    int num_cus;          // compute units of the handle's device: the launch geometry is sized from it
     const void* Z;
     const void* X0;
     void* g;

@@ -2,6 +2,7 @@
 // See include/nempc.h for the contract and the reference call sites each entry point stands for.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -146,6 +147,11 @@ int rebuild_structure(Handle& h) {
     return NEMPC_OK;
 }
 
+// Objective upload, in two parts.  The Hessian maps (tril structure, gather / scatter maps) depend on the problem's
+// SHAPE only and are built once per handle; the parameter block [Q | Qs | R | Rs | xref | uref | cx | cu | QT | QTs |
+// objective constants of every tril entry and of the dense (n,n) matrix] depends on the VALUES and is what a tracking
+// MPC changes every step (a moving xref / uref): that path overwrites d_obj in place -- no map rebuild, no hipFree
+// (a device synchronisation), no re-allocation.
 int upload_objective(Handle& h, const ObjHost& o_in) {
     h.obj_host = o_in;
     const ObjHost& o = h.obj_host;
@@ -160,18 +166,6 @@ int upload_objective(Handle& h, const ObjHost& o_in) {
     for (int i = 0; i < nu; ++i)
         for (int j = 0; j < nu; ++j) Rs[i * nu + j] = o.R[i * nu + j] + o.R[j * nu + i];
 
-    // Hessian structure (tril, row-major) + maps + objective constants.  Entry (r,c) sums the block elements of
-    // every step whose window holds both variables (<= w of them; exactly one for plain models,
-    // integrator/discret.py:61-81) on top of the constant objective term.
-    const int nin = h.nin, w = h.w;
-    std::vector<std::vector<int32_t>> codes((size_t)n * n);
-    std::vector<int> wv(nin);
-    for (int t = 0; t < H; ++t) {
-        for (int d = 0; d < nin; ++d) wv[d] = window_var(h, t, d);
-        for (int pp = 0; pp < nin; ++pp)
-            for (int qq = 0; qq < nin; ++qq)
-                if (wv[pp] >= 0 && wv[qq] >= 0) codes[(size_t)wv[pp] * n + wv[qq]].push_back(t * nin * nin + pp * nin + qq);
-    }
     auto obj_const = [&](int r, int c, bool* structural) -> double {
         *structural = false;
         const bool rx = r < H * nx, cx = c < H * nx;
@@ -185,32 +179,71 @@ int upload_objective(Handle& h, const ObjHost& o_in) {
         }
         return 0.0;
     };
-    h.hess_rows.clear();
-    h.hess_cols.clear();
-    std::vector<int32_t> hmap;
-    std::vector<double> objc;
-    auto emit = [&](int r, int c, double oc) {
-        const auto& cs = codes[(size_t)r * n + c];
-        for (int k = 0; k < w; ++k) hmap.push_back(k < (int)cs.size() ? cs[k] : -1);
-        objc.push_back(oc);
-    };
-    for (int r = 0; r < n; ++r)
-        for (int c = 0; c <= r; ++c) {
-            bool st;
-            const double oc = obj_const(r, c, &st);
-            if (st || !codes[(size_t)r * n + c].empty()) {
-                emit(r, c, oc);
-                h.hess_rows.push_back(r);
-                h.hess_cols.push_back(c);
+
+    int rc;
+    if (!h.hess_maps_built) {
+        // Hessian structure (tril, row-major) + maps.  Entry (r,c) sums the block elements of every step whose window
+        // holds both variables (<= w of them; exactly one for plain models, integrator/discret.py:61-81) on top of the
+        // constant objective term.
+        const int nin = h.nin, w = h.w;
+        std::vector<std::vector<int32_t>> codes((size_t)n * n);
+        std::vector<int> wv(nin);
+        for (int t = 0; t < H; ++t) {
+            for (int d = 0; d < nin; ++d) wv[d] = window_var(h, t, d);
+            for (int pp = 0; pp < nin; ++pp)
+                for (int qq = 0; qq < nin; ++qq)
+                    if (wv[pp] >= 0 && wv[qq] >= 0) codes[(size_t)wv[pp] * n + wv[qq]].push_back(t * nin * nin + pp * nin + qq);
+        }
+        h.hess_rows.clear();
+        h.hess_cols.clear();
+        std::vector<int32_t> hmap;
+        auto emit = [&](int r, int c) {
+            const auto& cs = codes[(size_t)r * n + c];
+            for (int k = 0; k < w; ++k) hmap.push_back(k < (int)cs.size() ? cs[k] : -1);
+        };
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c <= r; ++c) {
+                bool st;
+                (void)obj_const(r, c, &st);
+                if (st || !codes[(size_t)r * n + c].empty()) {
+                    emit(r, c);
+                    h.hess_rows.push_back(r);
+                    h.hess_cols.push_back(c);
+                }
+            }
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) emit(r, c);
+
+        void* p = h.d_hess_map;
+        dev_free(p);
+        h.d_hess_map = nullptr;
+        if ((rc = dev_alloc((void**)&h.d_hess_map, hmap.size() * sizeof(int32_t)))) return rc;
+        NEMPC_HIP(hipMemcpy(h.d_hess_map, hmap.data(), hmap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        // scatter form of the tril map for the Hessian kernel's fused assembly (plain models: one block element per entry)
+        p = h.d_hess_smap;
+        dev_free(p);
+        h.d_hess_smap = nullptr;
+        h.hess_n_orph = -1;
+        if (w == 1) {
+            const int nnz_t = (int)h.hess_rows.size(), be = H * nin * nin;
+            std::vector<int32_t> smap((size_t)be, -1), orph;
+            for (int e = 0; e < nnz_t; ++e) {
+                if (hmap[e] >= 0) smap[hmap[e]] = e;
+                else orph.push_back(e);
+            }
+            if ((int)orph.size() <= nin * nin) {
+                smap.insert(smap.end(), orph.begin(), orph.end());
+                if ((rc = dev_alloc((void**)&h.d_hess_smap, smap.size() * sizeof(int32_t)))) return rc;
+                NEMPC_HIP(hipMemcpy(h.d_hess_smap, smap.data(), smap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                h.hess_n_orph = (int)orph.size();
             }
         }
-    for (int r = 0; r < n; ++r)
-        for (int c = 0; c < n; ++c) {
-            bool st;
-            emit(r, c, obj_const(r, c, &st));
-        }
+        h.hess_maps_built = true;
+    }
 
-    std::vector<double> all((size_t)off.total);
+    // parameter block: the family's parameters, then the objective constant of every tril entry and of the dense matrix
+    const size_t nnz_t = h.hess_rows.size();
+    std::vector<double> all((size_t)off.total + nnz_t + (size_t)n * n);
     std::copy(o.Q.begin(), o.Q.end(), all.begin() + off.Q);
     std::copy(Qs.begin(), Qs.end(), all.begin() + off.Qs);
     std::copy(QT.begin(), QT.end(), all.begin() + off.QT);
@@ -221,36 +254,21 @@ int upload_objective(Handle& h, const ObjHost& o_in) {
     std::copy(o.uref.begin(), o.uref.end(), all.begin() + off.uref);
     std::copy(o.cx.begin(), o.cx.end(), all.begin() + off.cx);
     std::copy(o.cu.begin(), o.cu.end(), all.begin() + off.cu);
-    all.insert(all.end(), objc.begin(), objc.end());
-
-    void* p = h.d_obj;
-    dev_free(p);
-    p = h.d_hess_map;
-    dev_free(p);
-    int rc;
-    if ((rc = dev_alloc(&h.d_obj, all.size() * h.esz))) return rc;
-    if ((rc = dev_alloc((void**)&h.d_hess_map, hmap.size() * sizeof(int32_t)))) return rc;
-    if ((rc = upload(h, all, h.d_obj))) return rc;
-    NEMPC_HIP(hipMemcpy(h.d_hess_map, hmap.data(), hmap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    // scatter form of the tril map for the Hessian kernel's fused assembly (plain models: one block element per entry)
-    p = h.d_hess_smap;
-    dev_free(p);
-    h.d_hess_smap = nullptr;
-    h.hess_n_orph = -1;
-    if (w == 1) {
-        const int nnz_t = (int)h.hess_rows.size(), be = H * nin * nin;
-        std::vector<int32_t> smap((size_t)be, -1), orph;
-        for (int e = 0; e < nnz_t; ++e) {
-            if (hmap[e] >= 0) smap[hmap[e]] = e;
-            else orph.push_back(e);
-        }
-        if ((int)orph.size() <= nin * nin) {
-            smap.insert(smap.end(), orph.begin(), orph.end());
-            if ((rc = dev_alloc((void**)&h.d_hess_smap, smap.size() * sizeof(int32_t)))) return rc;
-            NEMPC_HIP(hipMemcpy(h.d_hess_smap, smap.data(), smap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            h.hess_n_orph = (int)orph.size();
-        }
+    {
+        bool st;
+        double* oc = all.data() + off.total;
+        for (size_t e = 0; e < nnz_t; ++e) oc[e] = obj_const(h.hess_rows[e], h.hess_cols[e], &st);
+        oc += nnz_t;
+        for (int r = 0; r < n; ++r)
+            for (int c = 0; c < n; ++c) oc[(size_t)r * n + c] = obj_const(r, c, &st);
     }
+    if (!h.d_obj || h.obj_elems != all.size()) {
+        dev_free(h.d_obj);
+        h.obj_elems = 0;
+        if ((rc = dev_alloc(&h.d_obj, all.size() * h.esz))) return rc;
+        h.obj_elems = all.size();
+    }
+    if ((rc = upload(h, all, h.d_obj))) return rc;
     h.have_objective = true;
     return NEMPC_OK;
 }
@@ -332,6 +350,17 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
         h->din[l] = l == 0 ? h->nin + h->ne : cfg->widths[l - 1];
         h->dout[l] = cfg->widths[l];
         if (l < h->nl - 1 && h->dout[l] > h->maxw) h->maxw = h->dout[l];
+    }
+    {
+        // compute units of the device: every "fill the chip" launch geometry is sized from this, never from a literal.
+        // NEMPC_NUM_CUS overrides it (tests of the launch planning on the one device a box has).
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+            h->num_cus = prop.multiProcessorCount;
+        if (const char* e = getenv("NEMPC_NUM_CUS")) {
+            const int v = atoi(e);
+            if (v > 0) h->num_cus = v;
+        }
     }
     h->variant = NEMPC_KERNEL_VALU;
     if (cfg->kernel == NEMPC_KERNEL_MFMA || cfg->kernel == NEMPC_KERNEL_MFMA_TILE) {
@@ -698,6 +727,20 @@ int nempc_debug_stamps(nempc_handle hh, long long* host_out) {
     return NEMPC_OK;
 }
 #endif
+
+int nempc_plan_grid(int32_t ntiles, int32_t num_cus, int32_t per_cu, int32_t* grid, int32_t* tiles_per_wg,
+                    int32_t* tiles_rem) {
+    if (ntiles < 1 || num_cus < 1 || per_cu < 1 || !grid || !tiles_per_wg || !tiles_rem)
+        return fail(NEMPC_EINVAL, "nempc_plan_grid: bad argument");
+    const GridPlan g = plan_grid(ntiles, num_cus, per_cu);
+    *grid = g.grid; *tiles_per_wg = g.tiles_per_wg; *tiles_rem = g.tiles_rem;
+    return NEMPC_OK;
+}
+
+int nempc_num_cus(nempc_handle hh) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_num_cus: null handle");
+    return reinterpret_cast<Handle*>(hh)->num_cus;
+}
 
 int nempc_last_row_kernel(nempc_handle hh) {
     if (!hh) return fail(NEMPC_EINVAL, "nempc_last_row_kernel: null handle");

@@ -76,8 +76,23 @@ struct ObjHost {   // host copy of the objective parameters (doubles), re-upload
     std::vector<double> Q, R, xref, uref, cx, cu;
 };
 
+// Launch geometry of the cooperative kernels: `per_cu` co-resident workgroups on each of the device's `num_cus`
+// compute units (fewer when there are fewer tiles), each owning a contiguous run of tiles_per_wg (+1 for the first
+// tiles_rem workgroups) 16-row tiles.  num_cus comes from hipDeviceProp_t::multiProcessorCount of the handle's device
+// (256 on an MI355X in SPX mode; a partitioned mode or another gfx950 part reports its own count).
+struct GridPlan {
+    int grid, tiles_per_wg, tiles_rem;
+};
+inline GridPlan plan_grid(int ntiles, int num_cus, int per_cu) {
+    long long g = (long long)(num_cus < 1 ? 1 : num_cus) * (per_cu < 1 ? 1 : per_cu);
+    if (g > ntiles) g = ntiles;
+    if (g < 1) g = 1;
+    return GridPlan{(int)g, ntiles / (int)g, ntiles % (int)g};
+}
+
 struct Handle {
     nempc_config cfg{};
+    int num_cus = 256;           // compute units of cfg.device (nempc_create)
     int n = 0, m = 0, nl = 0;
     int nin = 0;                 // tile width = decision inputs one row's network reads: w*(nx+nu)
     int ne = 0;                  // extra network inputs (tvp + p); the network's input width is nin + ne
@@ -112,6 +127,8 @@ struct Handle {
 
     // objective, dtype T: Q, Qs=Q+Q^T, R, Rs, xref, uref, cx, cu, QT, QTs (one allocation) + Hessian constants
     void* d_obj = nullptr;
+    size_t obj_elems = 0;        // elements of d_obj (a change of values overwrites it in place)
+    bool hess_maps_built = false;   // the Hessian structure / maps depend on the shape only: built once per handle
     ObjHost obj_host;            // last nempc_set_objective arguments (defaults filled in)
     std::vector<double> obj_QT;  // terminal state weight (host copy; empty = same as Q), nempc_set_terminal_weight
     // bounds (host)

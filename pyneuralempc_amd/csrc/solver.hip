@@ -1634,6 +1634,7 @@ struct SolverWs {
     int* hpoll = nullptr;                      // pinned host: [0] convergence counter (blocking polls), [2] backtracking poll
     int *hpub = nullptr, *hpub_dev = nullptr;  // pinned host memory the device publishes the convergence counter to
     int cap = 0;
+    int m = 0, n = 0;                         // row / variable counts the buffers were sized for (box rows change m)
     size_t ex_per = 0;
     std::vector<unsigned char> bounds_host;   // the bounds as last uploaded (lb | ub in the handle's dtype)
 };
@@ -1689,14 +1690,14 @@ struct ExtraBindingGuard {
 }  // namespace
 
 template <typename T>
-static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* lb, const double* ub,
-                       const nempc_solver_opts& o, int32_t* status_dev, int32_t* iters_host, hipStream_t s) {
+static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* lb, const double* ub,
+                      const nempc_solver_opts& o, int32_t* status_dev, int32_t* iters_host, hipStream_t s) {
     const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu, nin = h.nin, n = h.n, m = h.m;
     const size_t ex_per = (size_t)H * h.ne;
     if (!h.solver_ws) h.solver_ws = new SolverWs();
     {
         SolverWs& w = *static_cast<SolverWs*>(h.solver_ws);
-        if (w.cap < B || w.ex_per != ex_per) {
+        if (w.cap < B || w.ex_per != ex_per || w.m != m || w.n != n) {
             solver_free(h);
             h.solver_ws = new SolverWs();
             SolverWs& w2 = *static_cast<SolverWs*>(h.solver_ws);
@@ -1731,6 +1732,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
             NEMPC_HIP(hipMalloc((void**)&w2.perm, Bn * sizeof(int)));
             NEMPC_HIP(hipMalloc((void**)&w2.count, sizeof(int)));
             w2.cap = B;
+            w2.m = m; w2.n = n;
             w2.ex_per = ex_per;
         }
     }
@@ -1819,7 +1821,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
         if (ppw > 16) ppw = 16;
         if (ppw * a.spec > 64) ppw = 64 / a.spec;       // the sweeping lanes are one wave
         // the sweep is one latency chain per lane whatever the number of active lanes: spread the batch over the CUs
-        const int spread = (Bact + 255) / 256;
+        const int spread = (Bact + h.num_cus - 1) / h.num_cus;
         if (ppw > spread) ppw = spread < 1 ? 1 : spread;
         // the wave-per-problem kernel runs one problem per wave of a 256-thread workgroup
         if (wave_wanted && ppw > 4) ppw = 4;
@@ -1999,7 +2001,12 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                     cpu_relax();
                     if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                         NEMPC_HIP(hipStreamSynchronize(s));      // a device fault surfaces here instead of a hang
-                        if (hp[4] != pend_seq) return NEMPC_EHIP;
+                        if (hp[4] != pend_seq) {
+                            set_error("nempc_solve: iteration " + std::to_string(it) + ": the backtracking counter of trial " +
+                                      std::to_string(pend_seq) + " was never published (stream drained, word still " +
+                                      std::to_string(hp[4]) + ")");
+                            return NEMPC_EHIP;
+                        }
                     }
                 }
                 pending = hp[5];
@@ -2026,7 +2033,12 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
                     cpu_relax();
                     if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                         NEMPC_HIP(hipStreamSynchronize(s));      // a device fault surfaces here instead of a hang
-                        if (hp[0] < want) return NEMPC_EHIP;
+                        if (hp[0] < want) {
+                            set_error("nempc_solve: iteration " + std::to_string(it) + ": the convergence counter of iteration " +
+                                      std::to_string(want) + " was never published (stream drained, word still " +
+                                      std::to_string(hp[0]) + ")");
+                            return NEMPC_EHIP;
+                        }
                     }
                 }
             }
@@ -2125,6 +2137,24 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     NEMPC_HIP(hipStreamSynchronize(s));
     if (iters_host) *iters_host = it;
     return NEMPC_OK;
+}
+
+// Every exit of a failed solve leaves the handle as a finished one does: kernels that still write the published words
+// (hpub) and the device counters may be queued when an error return is taken from inside the iteration loop, and the
+// next solve zeroes those words on the assumption that nothing is in flight.  Drain the stream, reset the counters.
+template <typename T>
+static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* lb, const double* ub,
+                       const nempc_solver_opts& o, int32_t* status_dev, int32_t* iters_host, hipStream_t s) {
+    const int rc = solve_impl<T>(h, B, X0, Z, lb, ub, o, status_dev, iters_host, s);
+    if (rc != NEMPC_OK) {
+        (void)hipStreamSynchronize(s);
+        if (SolverWs* w = static_cast<SolverWs*>(h.solver_ws)) {
+            if (w->n_active) (void)hipMemset(w->n_active, 0, 4 * sizeof(int));
+            if (w->hpub) for (int k = 0; k < 8; ++k) w->hpub[k] = 0;
+        }
+        (void)hipGetLastError();
+    }
+    return rc;
 }
 
 int solver_run(Handle& h, int B, const void* X0, void* Z, const double* lb, const double* ub,

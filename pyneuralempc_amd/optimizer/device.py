@@ -15,9 +15,11 @@ from .slsqp import Slsqp, SlsqpProblemFactory
 
 
 class DeviceSqp(Slsqp):
-    def __init__(self, max_iteration=200, tolerance=1e-8, verbose=0, init_with_last_result=False, warm_mu=1e-4,
+    def __init__(self, max_iteration=200, tolerance=None, verbose=0, init_with_last_result=False, warm_mu=1e-4,
                  **solver_opts):
-        """tolerance: max |defect| and relative step at convergence (tol_constraint = tol_step); warm_mu: initial barrier
+        """tolerance: max |defect| and relative step at convergence (tol_constraint = tol_step); None = what an iterate
+        of the model's precision can reach (CallbackEngine.solve: 1e-8 for fp64, 1e-4 for fp32 -- an fp32 iterate stalls
+        near 1e-5 and would never report success against 1e-8); warm_mu: initial barrier
         parameter of a warm-started solve (a cold start uses the solver's default of 0.1); solver_opts: further keyword
         arguments of CallbackEngine.solve (linesearch, lq_kernel, mu_min, ...)."""
         super().__init__(max_iteration=max_iteration, tolerance=tolerance, verbose=verbose,
@@ -40,7 +42,9 @@ class DeviceSqp(Slsqp):
         z0 = np.asarray(self.initial_point(problem), dtype=np.float64).reshape(1, -1)
         lb = np.asarray(domain_constraint.get_lower_bounds(H), dtype=np.float64)
         ub = np.asarray(domain_constraint.get_upper_bounds(H), dtype=np.float64)
-        opts = dict(max_iter=self.max_iteration, tol_constraint=self.tolerance, tol_step=self.tolerance)
+        opts = dict(max_iter=self.max_iteration)
+        if self.tolerance is not None:
+            opts.update(tol_constraint=self.tolerance, tol_step=self.tolerance)
         if warm:
             opts["mu_init"] = self.warm_mu
         opts.update(self.solver_opts)

@@ -60,8 +60,9 @@ def _shard_counts(b, device, total, world, rank, group):
     return [int(s.item()) for s in all_sizes]
 
 
-def allgather_u0(u0_local, total=None, group=None, engine=None):
-    """Gather (b_r, nu) per rank into (sum_r b_r, nu), rank-major.
+def allgather_u0(u0_local, total=None, group=None, engine=None, out=None):
+    """Gather (b_r, nu) per rank into (sum_r b_r, nu), rank-major.  Always returns a tensor the caller owns: a fresh
+    one, or `out` (engine path with equal shards only: (world*b, nu), gathered into in place -- the hot-loop form).
 
     With `engine` holding a communicator (init_u0_comm) the exchange is libnempc.so's own nempc_allgather_u0 --
     ncclAllGather on RCCL, in place on a persistent buffer; pass `total` (the global problem count) so that no size
@@ -78,10 +79,14 @@ def allgather_u0(u0_local, total=None, group=None, engine=None):
     if engine is not None and engine.comm is not None:
         if engine.comm != (world, rank):
             raise ValueError("the engine's communicator does not span this process group")
-        out = engine.allgather_u0(u0=u0_local.contiguous(), rows_per_rank=bmax)
+        if out is not None and not equal:
+            raise ValueError("allgather_u0: `out` needs equal shards")
+        # without `out` the gather lands in the engine's persistent buffer, which the next call (or a reserve /
+        # set_box_rows) overwrites: hand back a copy, like the torch.distributed path below does
+        res = engine.allgather_u0(u0=u0_local.contiguous(), rows_per_rank=bmax, out=out)
         if equal:
-            return out
-        return torch.cat([out[r * bmax:r * bmax + c] for r, c in enumerate(counts)], dim=0)
+            return res if out is not None else res.clone()
+        return torch.cat([res[r * bmax:r * bmax + c] for r, c in enumerate(counts)], dim=0)
     fused = dist.get_backend(group) == "nccl"      # all_gather_into_tensor: a capability of the backend, not a try
     if equal:
         if fused:

@@ -95,3 +95,29 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".inc")):
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+@pytest.mark.parametrize("num_cus", [32, 64, 256, 304])
+def test_launch_planning_covers_every_tile_for_any_cu_count(num_cus):
+    """nempc_plan_grid (host arithmetic; the cooperative kernels' tiles-per-workgroup split): sized from the device's
+    CU count, never from a literal 256 -- every tile owned exactly once, contiguous runs, sizes differing by at most
+    one, at most per_cu workgroups per CU, and the larger runs in front (the first-dispatched workgroups)."""
+    from pyneuralempc_amd import _lib
+    lib = _lib.load()
+    g, q, r = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    for per_cu in (1, 2):
+        for ntiles in (1, 2, num_cus - 1, num_cus, num_cus + 1, 2 * num_cus, 2 * num_cus + 1, 1280, 3200, 8191, 130000):
+            if ntiles < 1:
+                continue
+            assert lib.nempc_plan_grid(ntiles, num_cus, per_cu, ctypes.byref(g), ctypes.byref(q), ctypes.byref(r)) == 0
+            grid, per, rem = g.value, q.value, r.value
+            assert 1 <= grid <= min(ntiles, num_cus * per_cu)
+            assert grid == min(ntiles, num_cus * per_cu)          # the chip is filled whenever there is enough work
+            begins = [i * per + min(i, rem) for i in range(grid)]
+            ends = [b + per + (1 if i < rem else 0) for i, b in enumerate(begins)]
+            assert begins[0] == 0 and ends[-1] == ntiles
+            assert all(e == b2 for e, b2 in zip(ends[:-1], begins[1:]))
+            sizes = [e - b for b, e in zip(begins, ends)]
+            assert min(sizes) >= 1 and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert lib.nempc_plan_grid(0, num_cus, 1, ctypes.byref(g), ctypes.byref(q), ctypes.byref(r)) == -1
+    assert lib.nempc_plan_grid(8, 0, 1, ctypes.byref(g), ctypes.byref(q), ctypes.byref(r)) == -1

@@ -226,3 +226,39 @@ def test_fused_evaluation_at_batches_of_many_passes_per_workgroup(dims):
         Jd = a["jac_dense"][sl].cpu().numpy()
         np.testing.assert_allclose(Jd, J, **F64)
         assert np.array_equal(Jd == 0.0, J == 0.0)
+
+
+@pytest.mark.parametrize("num_cus", [32, 64, 304])
+def test_launch_geometry_follows_the_device_cu_count(num_cus, monkeypatch):
+    """The chip-filling launches are sized from the device's CU count (hipDeviceProp_t::multiProcessorCount, or
+    NEMPC_NUM_CUS for this test), not from a literal 256: with a different count every kernel family still covers every
+    tile and -- per-problem arithmetic does not depend on which workgroup owns a tile -- gives the same bits."""
+    from pyneuralempc_amd import _lib
+    B, H, nx, nu = 520, 20, 2, 1
+    net = orc.MLP.random(3, [64, 64], 2, seed=0)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=4)
+    lamh = np.random.default_rng(5).normal(size=(B, H * nx))
+    ref = {}
+    for cus in (None, num_cus):
+        if cus is None:
+            monkeypatch.delenv("NEMPC_NUM_CUS", raising=False)
+        else:
+            monkeypatch.setenv("NEMPC_NUM_CUS", str(cus))
+        for kernel in ("auto", "mfma_tile"):
+            for integ, dt in (("discret", torch.float64), ("rk4", torch.float32)):
+                eng = _engine(net, H, nx, nu, B, kernel=kernel, integrator=integ, DT=0.1, dtype=dt)
+                want_cus = cus if cus is not None else torch.cuda.get_device_properties(0).multi_processor_count
+                assert _lib.load().nempc_num_cus(eng._handle) == want_cus
+                Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+                out = {k: v.clone() for k, v in eng.eval(Z, X0, ALL).items()}
+                fused = {k: v.clone() for k, v in eng.eval(Z, X0, DEFAULT).items()}
+                hv = eng.hess(Z, X0, eng.to_device(lamh), torch.ones(B, dtype=dt, device="cuda:0"))["hvals"].clone()
+                key = (kernel, integ)
+                if cus is None:
+                    ref[key] = (out, fused, hv)
+                else:
+                    for k in ALL:
+                        assert torch.equal(out[k], ref[key][0][k]), (key, k)
+                    for k in DEFAULT:
+                        assert torch.equal(fused[k], ref[key][1][k]), (key, k)
+                    assert torch.equal(hv, ref[key][2]), key
