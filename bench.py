@@ -377,15 +377,19 @@ class Rank:
                     gather()
                 self.barrier()
                 torch.cuda.synchronize(self.dev)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0 = time.perf_counter()
+                ev0.record()                       # HIP events on the launch stream, around the K timed launches
                 ng, last = 0, None
                 for i in range(steps):
                     step()
                     if gather and (i + 1) % gather_every == 0:
                         last = gather()
                         ng += 1
+                ev1.record()
                 torch.cuda.synchronize(self.dev)
                 w_ = time.perf_counter() - t0
+                self.region_event_s = ev0.elapsed_time(ev1) * 1e-3 / steps
                 self.barrier()
                 return self.max_over_ranks(w_), ng, last
 
@@ -395,6 +399,7 @@ class Rank:
             res["primed_ms"] = self.prime(step) if args.prime_ms > 0 else 0.0
             wall, n_gather, gathered = timed_region()
             res["wall"] = wall
+            res["t_region_events"] = self.region_event_s      # average launch-to-launch time of the timed launches
             res["n_gather"] = n_gather
             if gather and n_gather:
                 assert gathered.shape[0] == self.world * B
@@ -436,18 +441,43 @@ class Rank:
         return res
 
     def roofline_of(self, res):
-        """the binding roofline of a configuration: MFMA for the row kernel unless the dense-contract bytes of the whole
-        evaluation sit above the ridge (C5), then HBM over the whole evaluation"""
+        """Rooflines of a configuration.  The matrix-core one is computed for the kernel the TIMED loop launches: on the
+        compiled shapes that is ONE launch -- rows_coopfx_kernel<..., FUSE = true> (rows + dense Jacobian + objective) --
+        so its duration is the launch-to-launch time of the timed launches (HIP events on the launch stream around the
+        timed region when there is one, else around a loop of the same step); the row work alone (the unfused
+        <..., false> instantiation, which the timed loop never launches) is reported next to it.  Elsewhere the timed step
+        is the row kernel plus the assembly launch and the row kernel (timed on its own) is the dominant one.  Returns
+        (primary, secondary, extra): primary is the binding roofline -- HBM over the whole evaluation when the
+        dense-contract bytes sit below the ridge (C5), the matrix cores otherwise."""
         cfg, work = res["cfg"], res["work"]
         peak_tf = PEAK_F64_TFLOPS if cfg["dtype"] == "f64" else PEAK_F32_TFLOPS
         ai = work["flops"] / work["dense_bytes"]
         ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
         t_eval = res["t_all_rotating"] or res["t_all"]
-        mfma = {"bound": "mfma", "kernel": res["row_kernel"], "achieved": work["flops"] / res["t_rows"] / 1e12,
-                "peak": peak_tf, "unit": "TFLOP/s", "frac": work["flops"] / res["t_rows"] / 1e12 / peak_tf,
-                "traffic": None, "kernel_us": res["t_rows"] * 1e6, "flops_per_launch": work["flops"],
-                "arithmetic_intensity_dense": ai, "ridge": ridge}
         fused = res["row_kernel"] == "rows_coopfx_kernel"
+        extra = {}
+        if fused:
+            t_k = res.get("t_region_events") or res["t_all"]
+            mfma = {"bound": "mfma", "kernel": "rows_coopfx_kernel<..., FUSE = true>: the launch of the timed loop "
+                                               "(rows + dense Jacobian rows + objective in one launch)",
+                    "achieved": work["flops"] / t_k / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": work["flops"] / t_k / 1e12 / peak_tf, "traffic": None, "kernel_us": t_k * 1e6,
+                    "kernel_us_measured": ("HIP events on the launch stream around the timed region, / steps"
+                                           if res.get("t_region_events") else "HIP events around a loop of the timed step"),
+                    "kernel_us_event_loop": res["t_all"] * 1e6, "flops_per_launch": work["flops"],
+                    "arithmetic_intensity_dense": ai, "ridge": ridge}
+            extra["roofline_row_kernel_unfused"] = {
+                "bound": "mfma", "kernel": "rows_coopfx_kernel<..., FUSE = false> (g + compact tiles only; NOT the timed launch)",
+                "achieved": work["flops"] / res["t_rows"] / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                "frac": work["flops"] / res["t_rows"] / 1e12 / peak_tf, "traffic": None, "kernel_us": res["t_rows"] * 1e6}
+        else:
+            mfma = {"bound": "mfma", "kernel": str(res["row_kernel"]) + " (the dominant launch of the timed step; the "
+                                               "assembly launch follows it)",
+                    "achieved": work["flops"] / res["t_rows"] / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": work["flops"] / res["t_rows"] / 1e12 / peak_tf, "traffic": None,
+                    "kernel_us": res["t_rows"] * 1e6, "flops_per_launch": work["flops"],
+                    "frac_over_whole_eval": work["flops"] / res["t_all"] / 1e12 / peak_tf, "eval_us": res["t_all"] * 1e6,
+                    "arithmetic_intensity_dense": ai, "ridge": ridge}
         hbm = {"bound": "hbm", "kernel": ("whole evaluation: one launch, rows_coopfx_kernel<..., FUSE = true>" if fused else
                                            "whole evaluation (row kernel + post_flat_kernel)"),
                "achieved": work["dense_bytes"] / t_eval / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -456,7 +486,7 @@ class Rank:
                "eval_us_in_place": res["t_all"] * 1e6,
                "note": ("dense Jacobian written to a ring of buffers larger than the 256 MB Infinity Cache"
                         if res["t_all_rotating"] else "outputs rewritten in place (cache-resident when they fit 256 MB)")}
-        return (hbm, mfma) if ai < ridge else (mfma, hbm)
+        return ((hbm, mfma) if ai < ridge else (mfma, hbm)) + (extra,)
 
     # -------------------------------------------------------------------------------------------------------------
     def solver_leg(self, res):
@@ -538,7 +568,7 @@ class Rank:
         args = self.args
         res = self.run_config(args.config, args.steps, args.warmup, headline=True, kernel=args.kernel)
         cfg, B, eng, wall = res["cfg"], res["B"], res["eng"], res["wall"]
-        primary, secondary = self.roofline_of(res)
+        primary, secondary, rf_extra = self.roofline_of(res)
         out = {
             "metric": "nlp_callback_evals_per_sec (f + grad f + g + dense jac g)",
             "value": self.world * B * args.steps / wall,
@@ -549,12 +579,20 @@ class Rank:
             "dtype": cfg["dtype"], "data": "synthetic",
             "config": {"workload": cfg["label"], "batch_per_gpu": B, "H": cfg["H"], "nx": cfg["nx"], "nu": cfg["nu"],
                        "hidden": cfg["hidden"], "integrator": cfg["integrator"], "n": eng.n, "m": eng.m,
-                       "row_kernel": eng.kernel_variant, "parallelism": f"problem-sharded x{self.world}"},
+                       "row_kernel": eng.kernel_variant, "parallelism": f"problem-sharded x{self.world}",
+                       # `value` is a SUSTAINED-CLOCK rate: the timed region is run once as the process finds the GPU
+                       # (value_from_cold_gpu) and again after prime_ms of the same step, untimed (value)
+                       "clock": "sustained (timed region after prime_ms of the same step)" if args.prime_ms > 0 else "cold",
+                       "prime_ms": res.get("primed_ms", 0.0),
+                       "value_from_cold_gpu": (self.world * B * args.steps / res["wall_cold"]) if res.get("wall_cold") else None,
+                       "latency_bound_note": ("B=256 is 320 tiles on 256 CUs: launch latency, not throughput, sets the time"
+                                              if B * cfg["H"] <= 16 * 2 * 256 else None)},
             "batch_evals_per_s": args.steps / wall,
             "jacobian_max_abs_err_vs_cpu": res["errs"]["jac"], "max_abs_err_vs_cpu": res["errs"],
             "err_checked_on": f"outputs of the timed B={B} launch, problems {res['checked_slices']} (+16 each), rank {self.rank}",
             "roofline": primary,
             "roofline_" + secondary["bound"] + ("_whole_eval" if secondary["bound"] == "hbm" else "_row_kernel"): secondary,
+            **rf_extra,
             "eval_us": {"timed_loop": wall / args.steps * 1e6, "event_loop": res["t_all"] * 1e6,
                         "p10_median_p90": res["step_pcts"]},
             "value_from_cold_gpu": (self.world * B * args.steps / res["wall_cold"]) if res.get("wall_cold") else None,
@@ -562,6 +600,8 @@ class Rank:
                               "note": "untimed run of the same step before the W warm-up steps: an idle GPU starts below its "
                                       "sustained clock (--prime-ms 0 measures from cold)"},
         }
+        if self.dist is None and not args.only_eval:
+            out["allgather_u0"] = self.single_rank_gather_latency(res)
         if self.dist is not None:
             out["allgather_u0"] = {
                 "per_mpc_step_every_n_evals": max(1, args.evals_per_mpc_step), "issued_in_timed_loop": res["n_gather"],
@@ -571,20 +611,23 @@ class Rank:
             if getattr(self, "comm_error", None):
                 out["allgather_u0"]["cabi_error"] = self.comm_error
         # HBM bytes of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py):
-        # FETCH_SIZE * 2 (gfx950 correction) + WRITE_SIZE per launch, tools/summarize_profiles.py
+        # FETCH_SIZE * 2 (gfx950 correction) + WRITE_SIZE per launch, tools/summarize_profiles.py.  The headline roofline
+        # takes the entry of the FUSED instantiation (template argument FUSE = true), the kernel the timed loop launches.
         pmc_file = os.path.join(REPO, "profiles", args.pmc_file)
         if args.config == "c2" and B == 1024 and eng.kernel_variant == "mfma" and os.path.exists(pmc_file):
             pmc = json.load(open(pmc_file))
             for k, v in pmc.items():
                 if not k.startswith(str(res["row_kernel"])) or "hbm_traffic_bytes" not in v:
                     continue
-                fused = k.rstrip().endswith("true>")
-                for rf in (out["roofline"], secondary):
-                    if rf["bound"] == ("hbm" if fused else "mfma"):
-                        rf["traffic"] = v["hbm_traffic_bytes"]
-                        rf["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch of " + k + ", profiles/" + args.pmc_file +
-                                              (" (the fused evaluation: algorithmic 0.5 MB read, 20.5 MB written)" if fused else
-                                               " (algorithmic: 0.51 MB read, 1.3 MB written)"))
+                is_fused = ", true" in k
+                targets = ([out["roofline"], secondary] if is_fused else [rf_extra.get("roofline_row_kernel_unfused", {})])
+                for rf in targets:
+                    if not rf:
+                        continue
+                    rf["traffic"] = v["hbm_traffic_bytes"]
+                    rf["traffic_note"] = ("FETCH_SIZE*2 + WRITE_SIZE per launch of " + k + ", profiles/" + args.pmc_file +
+                                          (" (the fused evaluation: algorithmic 0.5 MB read, 20.5 MB written)" if is_fused else
+                                           " (algorithmic: 0.51 MB read, 1.3 MB written)"))
 
         if not args.only_eval:
             # ---- two independent batches in flight (reported apart; `value` is the single-stream figure)
@@ -593,7 +636,7 @@ class Rank:
             # ---- batched solver + all-gather of the solved u0 (collective: every rank)
             if cfg["integrator"] != "rk4" or eng.kernel_variant != "valu":
                 out["batched_solver"] = self.solver_leg(res)
-            if args.hessian and (cfg["integrator"] != "rk4" or eng.kernel_variant != "valu"):
+            if not args.no_hessian and (cfg["integrator"] != "rk4" or eng.kernel_variant != "valu"):
                 out["hessian_callback"] = self.hessian_leg(res)
             # ---- the other BASELINE configs under the same clock (HIP events; every rank runs them, rank 0 reports)
             if args.config == "c2" and not args.batch and not args.no_other_configs:
@@ -601,7 +644,7 @@ class Rank:
                 names = ["c2_b256", "c3", "c5"] + (["c4"] if self.world > 1 else [])
                 for nm in names:
                     r2 = self.run_config(nm, 50, 5, headline=False)
-                    p2, s2 = self.roofline_of(r2)
+                    p2, s2, x2 = self.roofline_of(r2)
                     c2 = r2["cfg"]
                     entry = {"workload": c2["label"], "batch_per_gpu": r2["B"], "dtype": c2["dtype"],
                              "ms_per_step": r2["t_all"] * 1e3,
@@ -612,6 +655,11 @@ class Rank:
                     if r2["t_all_rotating"]:
                         entry["ms_per_step_rotating_outputs"] = r2["t_all_rotating"] * 1e3
                         entry["rotation"] = r2["rotation"]
+                    entry.update(x2)
+                    if s2["bound"] == "mfma":
+                        entry["roofline_mfma"] = s2
+                    if not args.no_hessian and nm != "c4":
+                        entry["hessian_callback"] = self.hessian_leg(r2)
                     if nm == "c4":
                         entry["batched_solver"] = self.solver_leg(r2)
                     others[nm] = entry
@@ -657,20 +705,79 @@ class Rank:
                 "note": "two handles on two HIP streams, independent batches alternating (this rank only)"}
 
     def hessian_leg(self, res):
-        torch = self.torch
+        """The Hessian callbacks of the configuration (reference: IpoptProblem.hessian, optimizer/ipopt.py:66-86; the
+        Gauss-Newton variant is BASELINE.json's north_star / configs[4]): HIP-event time, roofline and the error of the
+        timed launch's own output against the oracle on three 16-problem slices.
+        Algorithmic work.  Exact blocks: base forward + base reverse sweep, then one tangent forward + one tangent reverse
+        sweep per network input: (2 + 2 nin) network passes per row and RK4 stage against the row kernel's (1 + nx), plus
+        -- RK4 -- the stage-record row launch itself.  Gauss-Newton: the row kernel's flops (tiles), then B * nnz values."""
+        np, torch = self.np, self.torch
         cfg, B, eng = res["cfg"], res["B"], res["eng"]
         from oracle import nempc_oracle as orc
         Zh, X0h = orc.synthetic_inputs(B, cfg["H"], cfg["nx"], cfg["nu"], seed=1 + self.rank)
         Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
-        lam = torch.randn(B, eng.m, dtype=eng.dtype, device=self.dev)
-        sig = torch.ones(B, dtype=eng.dtype, device=self.dev)
+        rng = np.random.default_rng(7 + self.rank)
+        lamh, sigh = rng.normal(size=(B, eng.m)), rng.uniform(0.5, 1.5, size=B)
+        wh = rng.uniform(0.2, 1.5, size=(B, cfg["H"] * cfg["nx"]))
+        lam, sig, wgt = eng.to_device(lamh), eng.to_device(sigh), eng.to_device(wh)
         reps = max(self.args.steps // 4, 10)
+        nx, nin, S = cfg["nx"], cfg["nx"] + cfg["nu"], (4 if cfg["integrator"] == "rk4" else 1)
+        peak_tf = PEAK_F64_TFLOPS if cfg["dtype"] == "f64" else PEAK_F32_TFLOPS
+        w = 8 if cfg["dtype"] == "f64" else 4
+        row_flops = res["work"]["flops"]
+        hess_flops = row_flops * (2 + 2 * nin) / (1 + nx) + (row_flops if S == 4 else 0)
         t_h = self.timed_events(lambda: eng.hess(Z, X0, lam, sig), reps)
-        info = {"hess_us": t_h * 1e6, "nnz_hess": eng.nnz_hess, "hess_batch_evals_per_s": 1.0 / t_h}
-        if hasattr(eng, "hess_gn"):
-            wgt = torch.rand(B, cfg["H"] * cfg["nx"], dtype=eng.dtype, device=self.dev)
-            t_g = self.timed_events(lambda: eng.hess_gn(Z, X0, wgt, sig), reps)
-            info.update(gauss_newton_hess_us=t_g * 1e6, gauss_newton_batch_evals_per_s=1.0 / t_g)
+        hv = eng.hess(Z, X0, lam, sig)["hvals"]
+        t_g = self.timed_events(lambda: eng.hess_gn(Z, X0, wgt, sig), reps)
+        gv = eng.hess_gn(Z, X0, wgt, sig)["hvals"]
+        torch.cuda.synchronize(self.dev)
+        _, prob = oracle_problem(cfg)
+        k = min(16, B)
+        starts = sorted({0, max(0, B // 2 - k // 2), B - k})
+        e_h = e_g = s_h = 0.0
+        for s0 in starts:
+            idx = range(s0, s0 + k) if cfg["nx"] <= 2 else range(s0, s0 + min(k, 4))     # (the 6/3 RK4 oracle is slow)
+            for i in idx:
+                ref = prob.hessian_values(Zh[i], X0h[i], lamh[i], sigh[i])
+                e_h = max(e_h, float(np.abs(hv[i].to("cpu", torch.float64).numpy() - ref).max()))
+                s_h = max(s_h, float(np.abs(ref).max()))
+                refg = prob.gauss_newton_values(Zh[i], X0h[i], wh[i], sigh[i])
+                e_g = max(e_g, float(np.abs(gv[i].to("cpu", torch.float64).numpy() - refg).max()))
+        out_bytes = B * eng.nnz_hess * w
+        return {"nnz_hess": eng.nnz_hess,
+                "exact": {"us": t_h * 1e6, "batch_evals_per_s": 1.0 / t_h, "max_abs_err_vs_cpu": e_h, "max_abs_ref": s_h,
+                          "roofline": {"bound": "mfma", "kernel": ("rowhess_coop_kernel (blocks and tril assembly in one launch)"
+                                                                    if S == 1 else "RK4 pipeline: stage-record rows, rk4_nu, "
+                                                                    "rowhess_coop_kernel (direct mode), rk4_congruence, assemble_hess"),
+                                       "achieved": hess_flops / t_h / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                                       "frac": hess_flops / t_h / 1e12 / peak_tf, "traffic": None,
+                                       "flops_per_callback": hess_flops,
+                                       "flops_note": "(2 + 2 nin) / (1 + nx) x the row kernel's flops"
+                                                     + (" + the stage-record row launch" if S == 4 else "")}},
+                "gauss_newton": {"us": t_g * 1e6, "batch_evals_per_s": 1.0 / t_g, "max_abs_err_vs_cpu": e_g,
+                                 "roofline": {"bound": "mfma", "kernel": "row kernel (tiles) + assemble_hess_gn_kernel: two launches",
+                                              "achieved": row_flops / t_g / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                                              "frac": row_flops / t_g / 1e12 / peak_tf, "traffic": None,
+                                              "flops_per_callback": row_flops, "bytes_written": out_bytes,
+                                              "hbm_frac_of_output": out_bytes / t_g / 1e9 / PEAK_HBM_GBS}},
+                "err_checked_on": f"hvals of the timed launches, problems {starts} (+{k if cfg['nx'] <= 2 else 4} each)"}
+
+    def single_rank_gather_latency(self, res, reps=200):
+        """N = 1: no gather is issued in the timed loop (there is nobody to exchange with), but the path exists -- a
+        one-rank RCCL communicator on the handle -- and its isolated latency is reported so that the N > 1 lines, which
+        issue it once per MPC step inside the loop, can be read against it."""
+        eng = res["eng"]
+        info = {"issued_in_timed_loop": 0, "n_gather": 0, "per_mpc_step_every_n_evals": max(1, self.args.evals_per_mpc_step),
+                "rows_gathered": res["B"], "path": "nempc_allgather_u0 (libnempc.so -> RCCL ncclAllGather), one-rank communicator",
+                "latency_us": None}
+        try:
+            from pyneuralempc_amd import CallbackEngine
+            if eng.comm is None:
+                eng.comm_init(1, 0, CallbackEngine.comm_unique_id())
+            Zd = self.torch.zeros(res["B"], eng.n, dtype=eng.dtype, device=self.dev)
+            info["latency_us"] = self.timed_events(lambda: eng.allgather_u0(Z=Zd), reps, prime_ms=0) * 1e6
+        except Exception as e:      # noqa: BLE001  (RCCL absent: the evaluation metric does not depend on it)
+            info["error"] = f"{type(e).__name__}: {e}"
         return info
 
 
@@ -688,13 +795,14 @@ def main():
                     help="profiling mode: the timed loop, the row-kernel timing and the accuracy check of the timed "
                          "launch only (no two-stream, solver, Hessian, other-config or CPU legs), so that a rocprofv3 "
                          "kernel trace of this command averages the headline launch alone")
-    ap.add_argument("--hessian", action="store_true", help="also time the Hessian callbacks (reported apart)")
+    ap.add_argument("--hessian", action="store_true", help="(kept for old command lines: the Hessian legs run by default)")
+    ap.add_argument("--no-hessian", action="store_true", help="skip the Hessian-callback legs (exact Lagrangian + Gauss-Newton)")
     ap.add_argument("--evals-per-mpc-step", type=int, default=17,
                     help="N > 1: one u0 all-gather per this many callback evaluations inside the timed loop")
     ap.add_argument("--prime-ms", type=float, default=40.0,
                     help="untimed run of the headline step before the warm-up steps, to reach the sustained clock (0: off)")
     ap.add_argument("--solver-iters", type=int, default=64)
-    ap.add_argument("--pmc-file", default="r02_c2_b1024_pmc.json")
+    ap.add_argument("--pmc-file", default="r03_c2_b1024_pmc.json")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -40,8 +40,10 @@ def vector_field(xn, un):
 def fit_surrogate(iters=1500, seed=0):
     """3 -> 30 tanh -> 30 tanh -> 2, the architecture of the reference's nn_model.h5"""
     g = torch.Generator().manual_seed(seed)
-    net = torch.nn.Sequential(torch.nn.Linear(3, 30), torch.nn.Tanh(), torch.nn.Linear(30, 30), torch.nn.Tanh(),
-                              torch.nn.Linear(30, 2)).double()
+    with torch.random.fork_rng(devices=[]):       # the layers draw their initial weights from the global generator
+        torch.manual_seed(seed)
+        net = torch.nn.Sequential(torch.nn.Linear(3, 30), torch.nn.Tanh(), torch.nn.Linear(30, 30), torch.nn.Tanh(),
+                                  torch.nn.Linear(30, 2)).double()
     xi = torch.rand(4096, 3, generator=g, dtype=torch.float64) * 2.0 - 1.0
     xi[:, 2] = xi[:, 2] * 0.5 * (U_MAX - U_MIN) + 0.5 * (U_MAX + U_MIN)
     target = torch.from_numpy(vector_field(xi[:, :2].numpy(), xi[:, 2:].numpy()))

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define NEMPC_ABI_VERSION 5
+#define NEMPC_ABI_VERSION 6
 #define NEMPC_MAX_LAYERS 8 /* dense layers incl. the linear output layer */
 
 /* status codes */
@@ -64,12 +64,25 @@ extern "C" {
 #define NEMPC_UNITY 1   /* Phi = f(x,u) */
 #define NEMPC_RK4 2     /* Phi = x + DT/6 (k1 + 2k2 + 2k3 + k4) */
 
+/* activation of a dense layer -- what the Keras Dense layers of the model KerasTFModel wraps are built with
+ * (model/tensorflow.py:8-29 takes ANY feed-forward Keras model; tensorflow.py:49-109 differentiates it by autodiff).
+ * Derivatives are evaluated from the layer's output a = s(z): s' = 1 (linear), 1 - a^2 (tanh), [a > 0] (relu: the
+ * gradient at 0 is 0, as TensorFlow's), a(1-a) (sigmoid), 1 - e^-a (softplus), 1 | a+1 (elu, alpha = 1). */
+#define NEMPC_ACT_LINEAR 0
+#define NEMPC_ACT_TANH 1
+#define NEMPC_ACT_RELU 2
+#define NEMPC_ACT_SIGMOID 3
+#define NEMPC_ACT_SOFTPLUS 4
+#define NEMPC_ACT_ELU 5
+#define NEMPC_ACT_COUNT 6
+
 /* row-kernel implementation */
 #define NEMPC_KERNEL_AUTO 0
 #define NEMPC_KERNEL_VALU 1 /* generic thread-per-row kernel, any dims */
 #define NEMPC_KERNEL_MFMA 2 /* matrix-core kernels, padded hidden width in {32,64,128}, <=3 hidden layers, nx <= 16,
-                               network inputs w*(nx+nu)+n_extra <= 32: CU-cooperative kernel when the weight slices
-                               fit the registers and the inputs <= 16, else wave-per-tile */
+                               network inputs w*(nx+nu)+n_extra <= 32, ONE non-linear activation on every hidden layer
+                               and a linear output layer: CU-cooperative kernel when the weight slices fit the
+                               registers and the inputs <= 16, else wave-per-tile */
 #define NEMPC_KERNEL_MFMA_TILE 3 /* force the wave-per-tile matrix-core kernel (A/B measurements) */
 
 typedef struct nempc_handle_s* nempc_handle;
@@ -80,7 +93,7 @@ typedef struct nempc_config {
     int32_t dtype;                    /* NEMPC_F64 | NEMPC_F32 */
     int32_t integrator;               /* NEMPC_DISCRET | NEMPC_UNITY | NEMPC_RK4 */
     int32_t H, nx, nu;                /* Integrator.H, Model.x_dim, Model.u_dim */
-    int32_t n_layers;                 /* dense layers, >= 1; all but the last use tanh */
+    int32_t n_layers;                 /* dense layers, >= 1; layer l applies activations[l] (below) */
     int32_t widths[NEMPC_MAX_LAYERS]; /* output width of each layer; widths[n_layers-1] == nx */
     int32_t max_batch;                /* capacity B_max of the workspaces */
     int32_t kernel;                   /* NEMPC_KERNEL_* */
@@ -91,6 +104,10 @@ typedef struct nempc_config {
                                          DISCRET or UNITY (the reference has no RK4 for rolling models) */
     int32_t rolling_reverse;          /* 0: window rows oldest -> newest (forward_rolling=True); 1: newest first */
     double DT;                        /* RK4 step (RK4Integrator.DT, rk4.py:49) */
+    int32_t activations[NEMPC_MAX_LAYERS]; /* NEMPC_ACT_* of each layer, the output layer included (the reference's
+                                         nn_model.h5: tanh, tanh, linear).  Any mix runs on the generic kernel; the
+                                         matrix-core kernels take one non-linear activation on all hidden layers and
+                                         a linear output layer (NEMPC_KERNEL_AUTO picks accordingly) */
 } nempc_config;
 
 /* lifetime ------------------------------------------------------------------------------- */

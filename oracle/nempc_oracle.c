@@ -2,7 +2,8 @@
  * CPU oracle in C (OpenMP) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
  * Batched fp64 restatement of the hessian-free callbacks (f, grad f, g, dense jac g) of
- * pyNeuralEMPC for a tanh MLP under Discret / Unity / RK4, used only
+ * pyNeuralEMPC for an MLP (per-layer activation from the family of nempc_oracle.py: linear, tanh, relu, sigmoid,
+ * softplus, elu) under Discret / Unity / RK4, used only
  *   - by tests/ (cross-checked against oracle/nempc_oracle.py, which is pinned to the
  *     reference-generated golden vectors), and
  *   - as the `cpu_baseline` leg of bench.py (kind "port", all host cores).
@@ -32,7 +33,30 @@ typedef struct {
     const double* b[MAXL];
     const double *Q, *R, *xref, *uref, *cx, *cu; /* (nx,nx) (nu,nu) (H,nx) (H,nu) (H,nx) (H,nu) */
     int box;
+    int act[MAXL]; /* per layer: 0 linear, 1 tanh, 2 relu, 3 sigmoid, 4 softplus, 5 elu (nempc_oracle.py ACT_IDS) */
 } oracle_problem;
+
+/* activation and its derivative written in terms of the layer's output a = s(z) (table in nempc_oracle.py) */
+static double act_f(int code, double z) {
+    switch (code) {
+        case 1: return tanh(z);
+        case 2: return z < 0.0 ? 0.0 : z;
+        case 3: return 1.0 / (1.0 + exp(-z));
+        case 4: return (z > 0.0 ? z : 0.0) + log1p(exp(-fabs(z)));
+        case 5: return z > 0.0 ? z : expm1(z);
+        default: return z;
+    }
+}
+static double act_d1(int code, double a) {
+    switch (code) {
+        case 1: return 1.0 - a * a;
+        case 2: return a > 0.0 ? 1.0 : 0.0;
+        case 3: return a * (1.0 - a);
+        case 4: return -expm1(-a);
+        case 5: return a > 0.0 ? 1.0 : a + 1.0;
+        default: return 1.0;
+    }
+}
 
 /* f (nx) and J (nx, nin) of the network at xi (nin); scratch holds activations + cotangents */
 static void net_eval(const oracle_problem* p, const double* xi, double* f, double* J, double* act, double* cot) {
@@ -50,21 +74,23 @@ static void net_eval(const oracle_problem* p, const double* xi, double* f, doubl
             const double* w = p->W[l] + (size_t)i * wo;
             for (int j = 0; j < wo; ++j) out[j] += a * w[j];
         }
-        if (l < nl - 1) for (int j = 0; j < wo; ++j) out[j] = tanh(out[j]);
+        if (p->act[l] != 0) for (int j = 0; j < wo; ++j) out[j] = act_f(p->act[l], out[j]);
         in = out;
     }
     /* reverse sweep per output */
     for (int k = 0; k < p->nx; ++k) {
         double* c = cot;
         double* cn = cot + maxw;
+        const double dout_k = p->act[nl - 1] != 0 ? act_d1(p->act[nl - 1], f[k]) : 1.0;   /* output-layer activation */
         if (nl == 1) {
-            for (int d = 0; d < nin; ++d) J[k * nin + d] = p->W[0][(size_t)d * p->dout[0] + k];
+            for (int d = 0; d < nin; ++d) J[k * nin + d] = p->W[0][(size_t)d * p->dout[0] + k] * dout_k;
             continue;
         }
         {
             const int w = p->din[nl - 1];
             const double* a = act + (size_t)(nl - 2) * maxw;
-            for (int j = 0; j < w; ++j) c[j] = p->W[nl - 1][(size_t)j * p->nx + k] * (1.0 - a[j] * a[j]);
+            for (int j = 0; j < w; ++j)
+                c[j] = p->W[nl - 1][(size_t)j * p->nx + k] * dout_k * act_d1(p->act[nl - 2], a[j]);
         }
         for (int l = nl - 2; l >= 0; --l) {
             const int wi = p->din[l], wo = p->dout[l];
@@ -73,10 +99,7 @@ static void net_eval(const oracle_problem* p, const double* xi, double* f, doubl
                 const double* w = p->W[l] + (size_t)i * wo;
                 double s = 0.0;
                 for (int j = 0; j < wo; ++j) s += w[j] * c[j];
-                if (l > 0) {
-                    const double a = act[(size_t)(l - 1) * maxw + i];
-                    s *= (1.0 - a * a);
-                }
+                if (l > 0) s *= act_d1(p->act[l - 1], act[(size_t)(l - 1) * maxw + i]);
                 dst[i] = s;
             }
             if (l > 0) { double* t = c; c = cn; cn = t; }

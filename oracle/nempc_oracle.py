@@ -5,8 +5,8 @@ may import this module.  The product path (``pyneuralempc_amd``) never does; it 
 the C-ABI HIP library and fails loudly when that library is missing.
 
 What it is: an fp64 NumPy restatement of the per-iterate evaluation the reference hands to its
-NLP solver -- ``f, grad f, g, jac g`` and the Lagrangian Hessian -- for a feed-forward tanh MLP
-dynamics model under the Discret / Unity / RK4 transcriptions.  File:line citations are into
+NLP solver -- ``f, grad f, g, jac g`` and the Lagrangian Hessian -- for a feed-forward MLP
+dynamics model (tanh by default; the activation family of `ACTIVATIONS`) under the Discret / Unity / RK4 transcriptions.  File:line citations are into
 ``/root/reference/pyNeuralEMPC``.
 
 Parity pinning (see DESIGN.md "Oracle"):
@@ -37,11 +37,76 @@ INTEGRATOR_NAMES = {DISCRET: "discret", UNITY: "unity", RK4: "rk4"}
 
 
 # --------------------------------------------------------------------------------------
-# Network: a_0 = xi ; a_l = tanh(a_{l-1} W_l + b_l) ; f = a_{L-1} W_L + b_L  (Keras kernel (in,out))
-# restates what model/tensorflow.py:49-51 evaluates with model.predict on [x | u] rows
+# Activations.  The reference wraps ANY feed-forward Keras model (model/tensorflow.py:8-29,49-51) or JAX callable
+# (model/jax.py:32-49) and lets TensorFlow / JAX differentiate it; the family below is what Keras Dense layers are
+# commonly built with.  Every derivative is written in terms of the layer's OUTPUT a = s(z), the value the forward pass
+# keeps (the device kernels keep nothing else):
+#     s'(z) = d1(a),      s''(z) = r2(a) * d1(a)
+#   linear    a = z                     d1 = 1                       r2 = 0
+#   tanh      a = tanh z                d1 = 1 - a^2                 r2 = -2a
+#   relu      a = max(z, 0)             d1 = [a > 0]                 r2 = 0           (TF's relu gradient at 0 is 0)
+#   sigmoid   a = 1/(1+e^-z)            d1 = a(1-a)                  r2 = 1 - 2a
+#   softplus  a = log(1+e^z)            d1 = 1 - e^-a (= sigmoid z)  r2 = e^-a (= 1 - sigmoid z)
+#   elu       a = z (z>0), e^z-1 (z<=0) d1 = 1 (a>0), a+1 (a<=0)     r2 = 0 (a>0), 1 (a<=0)   (alpha = 1, the Keras default)
+# --------------------------------------------------------------------------------------
+ACTIVATIONS = ("linear", "tanh", "relu", "sigmoid", "softplus", "elu")
+ACT_IDS = {name: i for i, name in enumerate(ACTIVATIONS)}     # the codes of include/nempc.h (NEMPC_ACT_*)
+
+
+def act_f(name, z):
+    if name == "linear":
+        return z
+    if name == "tanh":
+        return np.tanh(z)
+    if name == "relu":
+        return np.where(z < 0.0, 0.0, z)              # (a NaN stays a NaN)
+    if name == "sigmoid":
+        with np.errstate(over="ignore"):
+            return 1.0 / (1.0 + np.exp(-z))
+    if name == "softplus":
+        return np.maximum(z, 0.0) + np.log1p(np.exp(-np.abs(z)))
+    if name == "elu":
+        return np.where(z > 0.0, z, np.expm1(np.minimum(z, 0.0)))
+    raise ValueError(f"unknown activation {name!r}")
+
+
+def act_d1(name, a):
+    if name == "linear":
+        return np.ones_like(a)
+    if name == "tanh":
+        return 1.0 - a * a
+    if name == "relu":
+        return (a > 0.0).astype(np.float64)
+    if name == "sigmoid":
+        return a * (1.0 - a)
+    if name == "softplus":
+        return -np.expm1(-a)
+    if name == "elu":
+        return np.where(a > 0.0, 1.0, a + 1.0)
+    raise ValueError(f"unknown activation {name!r}")
+
+
+def act_r2(name, a):
+    if name in ("linear", "relu"):
+        return np.zeros_like(a)
+    if name == "tanh":
+        return -2.0 * a
+    if name == "sigmoid":
+        return 1.0 - 2.0 * a
+    if name == "softplus":
+        return np.exp(-a)
+    if name == "elu":
+        return np.where(a > 0.0, 0.0, 1.0)
+    raise ValueError(f"unknown activation {name!r}")
+
+
+# --------------------------------------------------------------------------------------
+# Network: a_0 = xi ; a_l = s_l(a_{l-1} W_l + b_l)  (Keras kernel (in,out)); default s = tanh on the hidden layers and a
+# linear output layer (the reference's own nn_model.h5).  Restates what model/tensorflow.py:49-51 evaluates with
+# model.predict on [x | u] rows
 # --------------------------------------------------------------------------------------
 class MLP:
-    def __init__(self, weights, biases):
+    def __init__(self, weights, biases, activations=None):
         self.W = [np.asarray(w, dtype=np.float64) for w in weights]
         self.b = [np.asarray(b, dtype=np.float64) for b in biases]
         assert len(self.W) == len(self.b) and len(self.W) >= 1
@@ -51,9 +116,15 @@ class MLP:
             assert w0.shape[1] == w1.shape[0]
         self.n_in = self.W[0].shape[0]
         self.n_out = self.W[-1].shape[1]
+        if activations is None:
+            activations = ["tanh"] * (len(self.W) - 1) + ["linear"]
+        elif isinstance(activations, str):             # one name: every hidden layer, linear output
+            activations = [activations] * (len(self.W) - 1) + ["linear"]
+        self.act = [str(a) for a in activations]
+        assert len(self.act) == len(self.W) and all(a in ACTIVATIONS for a in self.act)
 
     @staticmethod
-    def random(n_in, hidden, n_out, seed=0):
+    def random(n_in, hidden, n_out, seed=0, activations=None):
         """SURVEY.md 8(d) synthetic weights: W ~ N(0, 1/fan_in), b ~ N(0, 0.1^2)."""
         rng = np.random.default_rng(seed)
         dims = [n_in] + list(hidden) + [n_out]
@@ -61,33 +132,38 @@ class MLP:
         for i, o in zip(dims[:-1], dims[1:]):
             W.append(rng.normal(0.0, 1.0 / np.sqrt(i), size=(i, o)))
             b.append(rng.normal(0.0, 0.1, size=(o,)))
-        return MLP(W, b)
+        return MLP(W, b, activations)
 
     def _acts(self, xi):
+        """Outputs of every layer, acts[0] = the input, acts[l+1] = output of layer l (post-activation)."""
         acts = [np.asarray(xi, dtype=np.float64)]
-        for w, b in zip(self.W[:-1], self.b[:-1]):
-            acts.append(np.tanh(acts[-1] @ w + b))
+        for w, b, name in zip(self.W, self.b, self.act):
+            acts.append(act_f(name, acts[-1] @ w + b))
         return acts
 
     def forward(self, xi):
         """(R, n_in) -> (R, n_out)"""
-        acts = self._acts(xi)
-        return acts[-1] @ self.W[-1] + self.b[-1]
+        return self._acts(xi)[-1]
 
     def forward_jac(self, xi):
         """(R, n_in) -> f (R, n_out), J (R, n_out, n_in).
 
-        Reverse sweep: J = W_L^T diag(1-a_{L-1}^2) W_{L-1}^T ... diag(1-a_1^2) W_1^T, the same
-        value tf.GradientTape.jacobian returns per row (model/tensorflow.py:58-62) restricted
+        Reverse sweep: J = D_L W_L^T D_{L-1} W_{L-1}^T ... D_1 W_1^T with D_l = diag(s_l'(z_l)) (the identity for a
+        linear layer), the same value tf.GradientTape.jacobian returns per row (model/tensorflow.py:58-62) restricted
         to the t==t' blocks.
         """
         acts = self._acts(xi)
-        f = acts[-1] @ self.W[-1] + self.b[-1]
+        f = acts[-1]
         R = f.shape[0]
+        L = len(self.W)
         # cot[r, k, j] : d f_k / d z_l[j] walking back through the layers
-        cot = np.broadcast_to(self.W[-1].T[None, :, :], (R, self.n_out, self.W[-1].shape[0])).copy()
-        for l in range(len(self.W) - 2, -1, -1):
-            cot = cot * (1.0 - acts[l + 1] ** 2)[:, None, :]
+        if self.act[-1] == "linear":
+            cot = np.broadcast_to(self.W[-1].T[None, :, :], (R, self.n_out, self.W[-1].shape[0])).copy()
+        else:
+            cot = act_d1(self.act[-1], f)[:, :, None] * self.W[-1].T[None, :, :]
+        for l in range(L - 2, -1, -1):
+            if self.act[l] != "linear":
+                cot = cot * act_d1(self.act[l], acts[l + 1])[:, None, :]
             cot = cot @ self.W[l].T
         return f, cot
 
@@ -97,7 +173,7 @@ class MLP:
         Forward second-order propagation
             D_l = diag(s'(z_l)) W_l^T D_{l-1}
             S_l[i,p,q] = s''(z_l[i]) P[i,p] P[i,q] + s'(z_l[i]) (W_l^T S_{l-1})[i,p,q],  P = W_l^T D_{l-1}
-        with s = tanh: s' = 1-a^2, s'' = -2a(1-a^2); last layer linear.  Value-equivalent to the
+        with s' = d1(a), s'' = r2(a) d1(a) (table above; tanh: 1-a^2, -2a(1-a^2)).  Value-equivalent to the
         tf.hessians / jax.hessian call of model/tensorflow.py:80-85, model/jax.py:74 per row.
         """
         xi = np.asarray(xi, dtype=np.float64)
@@ -105,14 +181,14 @@ class MLP:
         a = xi
         D = np.broadcast_to(np.eye(nin)[None], (R, nin, nin)).copy()
         S = np.zeros((R, nin, nin, nin))
-        for l, (w, b) in enumerate(zip(self.W, self.b)):
+        for w, b, name in zip(self.W, self.b, self.act):
             P = np.einsum("ji,rjp->rip", w, D)
             WS = np.einsum("ji,rjpq->ripq", w, S)
             z = a @ w + b
-            if l < len(self.W) - 1:
-                a = np.tanh(z)
-                s1 = 1.0 - a * a
-                s2 = -2.0 * a * s1
+            if name != "linear":
+                a = act_f(name, z)
+                s1 = act_d1(name, a)
+                s2 = act_r2(name, a) * s1
                 D = s1[:, :, None] * P
                 S = s2[:, :, None, None] * P[:, :, :, None] * P[:, :, None, :] + s1[:, :, None, None] * WS
             else:

@@ -10,15 +10,19 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libnempc.so")
-SOURCES = ["nempc_api.hip", "kernels_valu.hip", "kernels_post.hip", "kernels_mfma.hip",
-           "kernels_mfma_f64.hip", "kernels_mfma_f32.hip", "kernels_rk4hess.hip", "solver.hip", "comm.hip"]
+# the matrix-core kernels: one translation unit per (dtype, hidden activation); tanh (the headline) first, it is the longest
+_MFMA_ACTS = ["relu", "sigmoid", "softplus", "elu"]
+SOURCES = (["kernels_mfma_f64.hip", "kernels_mfma_f32.hip", "solver.hip"] +
+           [f"kernels_mfma_{t}_{a}.hip" for t in ("f64", "f32") for a in _MFMA_ACTS] +
+           ["nempc_api.hip", "kernels_valu.hip", "kernels_post.hip", "kernels_mfma.hip", "kernels_rk4hess.hip", "comm.hip"])
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]
 
 
 # per-source extra flags.  Kernel-argument preload: the leading 16 dwords of a kernel's plain arguments are placed in
 # scalar registers by the dispatcher (the fixed-shape row kernel lists what its first loads need there)
-EXTRA_FLAGS = {"kernels_mfma_f64.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
+EXTRA_FLAGS = {f: ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
+               for f in ["kernels_mfma_f64.hip"] + [f"kernels_mfma_f64_{a}.hip" for a in _MFMA_ACTS]}
 
 
 def _hipcc():
@@ -57,7 +61,7 @@ def build(force=False, verbose=True):
         return s
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for s in ex.map(compile_one, jobs):
                 if verbose:
                     print(f"[nempc build] compiled {os.path.basename(s)}", file=sys.stderr)

@@ -7,7 +7,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # NEMPC_LIB: an alternative build of the same library (A/B kernel experiments, tools/build_variant.py)
 LIB_PATH = os.environ.get("NEMPC_LIB") or os.path.join(PKG, "libnempc.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 COMM_ID_BYTES = 128
 MAX_LAYERS = 8
 F64, F32 = 0, 1
@@ -15,6 +15,8 @@ DISCRET, UNITY, RK4 = 0, 1, 2
 KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_TILE = 0, 1, 2, 3
 KERNEL_NAMES = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA, "mfma_tile": KERNEL_MFMA_TILE}
 INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
+# NEMPC_ACT_*: the activation of a dense layer (names as Keras spells them)
+ACTIVATION_IDS = {"linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3, "softplus": 4, "elu": 5}
 
 EXPORTS = ["nempc_create", "nempc_destroy", "nempc_reserve", "nempc_set_weights", "nempc_set_objective", "nempc_set_terminal_weight", "nempc_set_box_rows", "nempc_bind_extra", "nempc_bind_history",
            "nempc_dims", "nempc_constraint_bounds", "nempc_jac_structure", "nempc_hess_structure", "nempc_eval",
@@ -34,7 +36,8 @@ class NempcConfig(ctypes.Structure):
                 ("integrator", ctypes.c_int32), ("H", ctypes.c_int32), ("nx", ctypes.c_int32),
                 ("nu", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("widths", ctypes.c_int32 * MAX_LAYERS),
                 ("max_batch", ctypes.c_int32), ("kernel", ctypes.c_int32), ("n_extra", ctypes.c_int32),
-                ("rolling_window", ctypes.c_int32), ("rolling_reverse", ctypes.c_int32), ("DT", ctypes.c_double)]
+                ("rolling_window", ctypes.c_int32), ("rolling_reverse", ctypes.c_int32), ("DT", ctypes.c_double),
+                ("activations", ctypes.c_int32 * MAX_LAYERS)]
 
 
 class NempcSolverOpts(ctypes.Structure):

@@ -86,7 +86,7 @@ class NMPC:
         from .integrator.base import DeviceIntegrator
         from .constraints import BoxStateConstraint
         boxes = [c for c in self.constraint_list if isinstance(c, BoxStateConstraint)]
-        if not (isinstance(self.integrator, DeviceIntegrator) and isinstance(self.objective_func, QuadraticObjective)
+        if not (isinstance(self.integrator, DeviceIntegrator) and self.integrator.on_device and isinstance(self.objective_func, QuadraticObjective)
                 and len(boxes) == len(self.constraint_list)):
             raise NotImplementedError("next_batch needs a device integrator, a QuadraticObjective and no extra "
                                       "constraint rows other than BoxStateConstraint")

@@ -1,0 +1,162 @@
+// Activation family of the row / Hessian kernels (nempc_config.activations, NEMPC_ACT_*).
+//
+// The reference wraps any feed-forward Keras model (model/tensorflow.py:8-29,49-51) and lets TensorFlow differentiate
+// it (tensorflow.py:53-109).  Here every derivative is written in terms of the layer's OUTPUT a = s(z) -- the one value
+// the kernels keep from the forward pass (the tanh kernels have always used 1 - a^2):
+//     s'(z) = d1(a),        s''(z) = r2(a) * d1(a)
+//   linear    a = z                      d1 = 1                       r2 = 0
+//   tanh      a = tanh z                 d1 = 1 - a^2                 r2 = -2a
+//   relu      a = max(z, 0)              d1 = [a > 0]                 r2 = 0        (TensorFlow's relu gradient at 0 is 0)
+//   sigmoid   a = 1 / (1 + e^-z)         d1 = a (1 - a)               r2 = 1 - 2a
+//   softplus  a = log(1 + e^z)           d1 = 1 - e^-a (= sigmoid z)  r2 = e^-a
+//   elu       a = z (z > 0), e^z - 1     d1 = 1 (a > 0), a + 1        r2 = 0 (a > 0), 1          (alpha = 1, Keras' default)
+// r2 is what the forward-over-reverse Hessian sweeps need: d(delta * s') = s' d(delta) + delta * r2 * da, da the tangent
+// of the activation itself.
+//
+// Two forms: Act<T, ACT> for the matrix-core kernels (the activation is a template parameter: one instantiation per
+// activation, the tanh one unchanged), act_* (code, x) for the generic thread-per-row kernel (per-layer codes at run
+// time, any mix, also on the output layer).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "nempc.h"
+
+namespace nempc {
+
+// tanh for the row kernels: t = 1 - 2 / (exp(2|x|) + 1), sign restored.  ocml's tanh(double) costs ~670 cycles per
+// wave-instruction on gfx950.  On this chip every vector instruction -- double, single or integer -- takes the same 4
+// issue cycles (v_rcp_f64: 16) and a v_mfma_f64 holds the vector pipe for all of its 64 (tools/ubench_dpops.hip: MFMA
+// waves and vector waves on one SIMD serialise whatever the vector instruction is), so what a tanh costs the matrix
+// kernels is its instruction COUNT.  24 issue slots here against 33 for the straightforward form (degree-13 Taylor,
+// v_rndne + v_cvt_i32, two Newton steps, NaN select), same 2.2e-16 max abs error against tanhl on [-30, 30]
+// (tools/ubench_tanh.hip; absolute accuracy is what the 1 - a^2 derivative factors need):
+//  * |x| is clamped at 20 (tanh(20) rounds to 1) on its HIGH dword only: one compare, one select.  A NaN fails the
+//    compare and flows through every later operation, so a diverged iterate stays visible without a select at the end
+//  * n = rint(|x| * 2/ln2) by the 1.5*2^52 shift: one fma and one subtract, and the integer n is the low dword of
+//    the shifted value (no v_rndne_f64, no v_cvt_i32_f64)
+//  * s = |x| - n ln2/2 with ln2/2 as ONE double: its rounding error (1.9e-17) times n is an error of 2.2 n 1.9e-17 in
+//    exp(2s), which reaches tanh scaled by 2e/(e+1)^2 ~ 2^(1-n): at most 2.4e-17 absolute (n = 2), so the second
+//    Cody-Waite step buys nothing here
+//  * exp(2s) on |s| <= ln2/4 by a degree-11 Chebyshev fit (relative error 1.7e-17 with the rounded coefficients)
+//  * 1/d from v_rcp_f64 and ONE cubic step (three fmas)
+__device__ __forceinline__ double nempc_tanh(double x) {
+    const double a = __hiloint2double(fabs(x) > 20.0 ? 0x40340000 : __double2hiint(x), __double2loint(x));
+    const double SHIFT = 6755399441055744.0;
+    const double t = fma(fabs(a), 2.8853900817779268, SHIFT);
+    const double nf = t - SHIFT;
+    const double s = fma(-nf, 0.34657359027997264, fabs(a));      // ln2/2 in one piece, see above
+    double p = 5.1425357017013815e-05;
+    p = fma(p, s, 0.00028295822990378013);
+    p = fma(p, s, 0.0014109307350312432);
+    p = fma(p, s, 0.0063491802834760944);
+    p = fma(p, s, 0.025396825459260305);
+    p = fma(p, s, 0.08888888929481456);
+    p = fma(p, s, 0.26666666666622724);
+    p = fma(p, s, 0.6666666666638096);
+    p = fma(p, s, 1.3333333333333344);
+    p = fma(p, s, 2.0000000000000075);
+    p = fma(p, s, 2.0);
+    p = fma(p, s, 1.0);
+    const double d = ldexp(p, __double2loint(t)) + 1.0;
+    double q = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, q, 1.0);
+    q = fma(fma(e, e, e), q, q);
+    return copysign(fma(-2.0, q, 1.0), x);
+}
+
+// fp32: hardware exp2 / rcp; abs error ~1e-7, inside the fp32 configs' 1e-4 tolerance
+__device__ __forceinline__ float nempc_tanh(float x) {
+    const float ax = fminf(fabsf(x), 10.0f);
+    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);  // exp(2|x|)
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    return x != x ? x : copysignf(t, x);
+}
+
+// exp / log1p / expm1 of the other activations.  fp64: the library routines (their cost is not on the headline path; what
+// they must be is accurate -- the fp64 parity bar is 1e-12 against NumPy's).  fp32: the hardware exp2 / log2 (branch-free;
+// absolute error ~1e-7, inside the fp32 configs' 1e-4 tolerance -- what nempc_tanh(float) does too); the arguments these
+// are called with keep them away from the cancellation a true expm1 / log1p guards against only to that same 1e-7.
+// A NaN flows through all of them.
+__device__ __forceinline__ double nempc_exp(double x) { return exp(x); }
+__device__ __forceinline__ float nempc_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ double nempc_expm1(double x) { return expm1(x); }
+__device__ __forceinline__ float nempc_expm1(float x) { return nempc_exp(x) - 1.0f; }
+__device__ __forceinline__ double nempc_log1p(double x) { return log1p(x); }
+__device__ __forceinline__ float nempc_log1p(float x) { return __builtin_amdgcn_logf(1.0f + x) * 0.6931471805599453f; }
+
+template <typename T, int ACT>
+struct Act;
+
+template <typename T>
+struct Act<T, NEMPC_ACT_LINEAR> {
+    static __device__ __forceinline__ T f(T x) { return x; }
+    static __device__ __forceinline__ T d1(T) { return T(1); }
+    static __device__ __forceinline__ T r2(T) { return T(0); }
+};
+template <typename T>
+struct Act<T, NEMPC_ACT_TANH> {
+    static __device__ __forceinline__ T f(T x) { return nempc_tanh(x); }
+    static __device__ __forceinline__ T d1(T a) { return T(1) - a * a; }
+    static __device__ __forceinline__ T r2(T a) { return T(-2) * a; }
+};
+template <typename T>
+struct Act<T, NEMPC_ACT_RELU> {
+    static __device__ __forceinline__ T f(T x) { return x < T(0) ? T(0) : x; }       // (a NaN fails the compare and stays)
+    static __device__ __forceinline__ T d1(T a) { return a > T(0) ? T(1) : T(0); }
+    static __device__ __forceinline__ T r2(T) { return T(0); }
+};
+template <typename T>
+struct Act<T, NEMPC_ACT_SIGMOID> {
+    static __device__ __forceinline__ T f(T x) { return T(1) / (T(1) + nempc_exp(-x)); }   // e^-x = inf gives 0
+    static __device__ __forceinline__ T d1(T a) { return a * (T(1) - a); }
+    static __device__ __forceinline__ T r2(T a) { return T(1) - T(2) * a; }
+};
+template <typename T>
+struct Act<T, NEMPC_ACT_SOFTPLUS> {
+    static __device__ __forceinline__ T f(T x) { return (x > T(0) ? x : (x != x ? x : T(0))) + nempc_log1p(nempc_exp(-fabs(x))); }
+    static __device__ __forceinline__ T d1(T a) { return -nempc_expm1(-a); }
+    static __device__ __forceinline__ T r2(T a) { return nempc_exp(-a); }
+};
+template <typename T>
+struct Act<T, NEMPC_ACT_ELU> {
+    static __device__ __forceinline__ T f(T x) { return x > T(0) ? x : nempc_expm1(x); }   // expm1(NaN) = NaN
+    static __device__ __forceinline__ T d1(T a) { return a > T(0) ? T(1) : a + T(1); }
+    static __device__ __forceinline__ T r2(T a) { return a > T(0) ? T(0) : (a != a ? a : T(1)); }
+};
+
+// run-time forms (generic kernel: the code is wave-uniform, the switch a scalar branch)
+template <typename T>
+__device__ __forceinline__ T act_f(int code, T x) {
+    switch (code) {
+        case NEMPC_ACT_TANH: return sizeof(T) == 8 ? (T)tanh((double)x) : (T)tanhf((float)x);
+        case NEMPC_ACT_RELU: return Act<T, NEMPC_ACT_RELU>::f(x);
+        case NEMPC_ACT_SIGMOID: return Act<T, NEMPC_ACT_SIGMOID>::f(x);
+        case NEMPC_ACT_SOFTPLUS: return Act<T, NEMPC_ACT_SOFTPLUS>::f(x);
+        case NEMPC_ACT_ELU: return Act<T, NEMPC_ACT_ELU>::f(x);
+        default: return x;
+    }
+}
+template <typename T>
+__device__ __forceinline__ T act_d1(int code, T a) {
+    switch (code) {
+        case NEMPC_ACT_TANH: return Act<T, NEMPC_ACT_TANH>::d1(a);
+        case NEMPC_ACT_RELU: return Act<T, NEMPC_ACT_RELU>::d1(a);
+        case NEMPC_ACT_SIGMOID: return Act<T, NEMPC_ACT_SIGMOID>::d1(a);
+        case NEMPC_ACT_SOFTPLUS: return Act<T, NEMPC_ACT_SOFTPLUS>::d1(a);
+        case NEMPC_ACT_ELU: return Act<T, NEMPC_ACT_ELU>::d1(a);
+        default: return T(1);
+    }
+}
+template <typename T>
+__device__ __forceinline__ T act_r2(int code, T a) {
+    switch (code) {
+        case NEMPC_ACT_TANH: return Act<T, NEMPC_ACT_TANH>::r2(a);
+        case NEMPC_ACT_SIGMOID: return Act<T, NEMPC_ACT_SIGMOID>::r2(a);
+        case NEMPC_ACT_SOFTPLUS: return Act<T, NEMPC_ACT_SOFTPLUS>::r2(a);
+        case NEMPC_ACT_ELU: return Act<T, NEMPC_ACT_ELU>::r2(a);
+        default: return T(0);
+    }
+}
+
+}  // namespace nempc

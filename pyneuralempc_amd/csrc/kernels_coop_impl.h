@@ -262,11 +262,12 @@ __device__ __forceinline__ void stage_direct(const CoopCtx<T>& cx, int t0, int n
 // buffer (SCRnext / RInext) just before this pass's first global store.  Placed there for the vmcnt counter: stores
 // count in it too and retire in order, so a wait for those loads issued after the epilogue's (runtime-many) stores
 // degenerates to vmcnt(0) and sat out the stores' acknowledgement, 1.4 us per pass boundary.
-template <typename T, int WP, int NH, int NT, bool SR, int TPW>
+template <typename T, int WP, int NH, int NT, bool SR, int TPW, int ACT>
 __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeights<T, WP, NH>& W, int t0, int tid,
                                           const StageRegs<T, WP / 16, TPW>& nxt, bool has_nxt, T* SCRnext, int* RInext,
                                           int nrows_next) {
     using Ops = MfmaOps<T>;
+    using A = Act<T, ACT>;
     using V4 = typename Ops::V4;
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
@@ -319,7 +320,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[0][j][r] = Ops::tanh_(a[0][j][r]);
+                for (int r = 0; r < 4; ++r) a[0][j][r] = A::f(a[0][j][r]);
         }
         COOP_STAMP(4);
         // ---- hidden-to-hidden layers.  The exchange buffer has two halves used alternately: a wave may
@@ -350,7 +351,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[l][j][r] = Ops::tanh_(a[l][j][r]);
+                for (int r = 0; r < 4; ++r) a[l][j][r] = A::f(a[l][j][r]);
         }
         COOP_STAMP(5);
         // ---- network output: K-split partial over this wave's block
@@ -366,7 +367,9 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
 #pragma unroll
         for (int l = 0; l < NH; ++l)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) a[l][j] = T(1) - a[l][j] * a[l][j];
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[l][j][r] = A::d1(a[l][j][r]);
 
         COOP_STAMP(6);
         // ---- reverse sweep: KG cotangents (network outputs) at a time; an odd leftover is swept twice, its second copy
@@ -585,7 +588,7 @@ struct CoopArgs {
 // SR: also write the per-(row, stage) records of the RK4 Hessian pipeline (its own instantiation: the extra stores and
 // their address arithmetic cost the plain kernel 0.3 - 0.9 us when they are only branched around)
 // OCC: waves per SIMD the register allocation must allow (workgroups per CU = OCC * 4 / MT)
-template <typename T, int WP, int NH, int TPW, bool SR = false, int OCC = 2>
+template <typename T, int WP, int NH, int TPW, bool SR, int OCC, int ACT>
 __global__ __launch_bounds__((WP / 16) * 64, OCC) void rows_coop_kernel(CoopArgs a) {
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
@@ -741,10 +744,10 @@ __global__ __launch_bounds__((WP / 16) * 64, OCC) void rows_coop_kernel(CoopArgs
 #endif
         T* const scr_n = scr_base + (parity ^ 1) * scr_sz;
         int* const ri_n = ri_base + (parity ^ 1) * ri_sz;
-        if (n_cur == 1) coop_pass<T, WP, NH, 1, SR, TPW>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16);
-        if constexpr (TPW >= 2) { if (n_cur == 2) coop_pass<T, WP, NH, 2, SR, TPW>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
-        if constexpr (TPW >= 3) { if (n_cur == 3) coop_pass<T, WP, NH, 3, SR, TPW>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
-        if constexpr (TPW >= 4) { if (n_cur == 4) coop_pass<T, WP, NH, 4, SR, TPW>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
+        if (n_cur == 1) coop_pass<T, WP, NH, 1, SR, TPW, ACT>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16);
+        if constexpr (TPW >= 2) { if (n_cur == 2) coop_pass<T, WP, NH, 2, SR, TPW, ACT>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
+        if constexpr (TPW >= 3) { if (n_cur == 3) coop_pass<T, WP, NH, 3, SR, TPW, ACT>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
+        if constexpr (TPW >= 4) { if (n_cur == 4) coop_pass<T, WP, NH, 4, SR, TPW, ACT>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
         if (!NEMPC_COOP_MIDSTAGE && early && t0 < t_end) stage_store<T, MT, TPW>(cx, scr_n, ri_n, nact * 16, tid, sr);
         parity ^= 1;
         cx.SCR = scr_n;

@@ -241,11 +241,12 @@ __device__ __forceinline__ void fx_rowsums_store(const T (&s)[NV], T* dst, int l
 // `nxt` / `in_next` (when has_next): the NEXT pass's inputs, already in registers; they go to the other input buffer
 // BEFORE this pass's global stores are issued -- vmcnt counts stores too and retires in order, so a wait for those loads
 // placed after the stores would sit out the stores' acknowledgement (with the dense rows fused in: the whole HBM time).
-template <typename T, int WP, int NH, int TPW, int NX, int NU, int NT, bool FUSE>
+template <typename T, int WP, int NH, int TPW, int NX, int NU, int NT, bool FUSE, int ACT>
 __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx, const CoopWeights<T, WP, NH>& W,
                                         const T* in, int t0, int tid, int& xsel,
                                         const FxStage<T, TPW, (WP / 16) * 64, NX + NU + NX>& nxt, bool has_next, T* in_next) {
     using Ops = MfmaOps<T>;
+    using A = Act<T, ACT>;
     using V4 = typename Ops::V4;
     using L = FxLayout<T, WP, NH, TPW, NX, NU>;
     constexpr int MT = WP / 16, NTHREADS = MT * 64, NIN = NX + NU, KS = L::KS, JROW = L::JROW;
@@ -276,7 +277,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a[0][j][r] = Ops::tanh_(a[0][j][r]);
+            for (int r = 0; r < 4; ++r) a[0][j][r] = A::f(a[0][j][r]);
     }
     FX_STAMP_PRO(cx.dbg, 10);
     // ---- hidden-to-hidden layers through the double-buffered exchange area (see kernels_coop_impl.h)
@@ -305,7 +306,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a[l][j][r] = Ops::tanh_(a[l][j][r]);
+            for (int r = 0; r < 4; ++r) a[l][j][r] = A::f(a[l][j][r]);
     }
     FX_STAMP_PRO(cx.dbg, 11);
     // ---- network output: K-split partial over this wave's 16 hidden units.  The two skinny layers (NX outputs here,
@@ -339,7 +340,9 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
     for (int l = 0; l < NH; ++l)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) a[l][j] = T(1) - a[l][j] * a[l][j];
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[l][j][r] = A::d1(a[l][j][r]);
 
     // ---- reverse sweep, one cotangent (network output) at a time
 #pragma unroll
@@ -607,7 +610,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 }
 
 // FUSE: the whole hessian-free evaluation in this launch -- g, [tiles,] dense jac, f, grad
-template <typename T, int WP, int NH, int TPW, int NX, int NU, bool FUSE = false>
+template <typename T, int WP, int NH, int TPW, int NX, int NU, bool FUSE, int ACT>
 __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     // what the prologue's loads depend on, as plain arguments: with -amdgpu-kernarg-preload-count the leading 14 dwords are
     // in scalar registers when the wave starts instead of behind a scalar-load round trip (the struct carries the rest;
@@ -809,9 +812,9 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         FX_STAMP_PRO(pa.dbg, 9);
         const T* in = in_base + parity * L::IN_SZ;
         T* const in_next = in_base + (parity ^ 1) * L::IN_SZ;
-        if (n_cur == 1) fx_pass<T, WP, NH, TPW, NX, NU, 1, FUSE>(cx, W, in, t_cur, tid, xsel, sr, more, in_next);
-        if constexpr (TPW >= 2) { if (n_cur == 2) fx_pass<T, WP, NH, TPW, NX, NU, 2, FUSE>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
-        if constexpr (TPW >= 3) { if (n_cur == 3) fx_pass<T, WP, NH, TPW, NX, NU, 3, FUSE>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
+        if (n_cur == 1) fx_pass<T, WP, NH, TPW, NX, NU, 1, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next);
+        if constexpr (TPW >= 2) { if (n_cur == 2) fx_pass<T, WP, NH, TPW, NX, NU, 2, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
+        if constexpr (TPW >= 3) { if (n_cur == 3) fx_pass<T, WP, NH, TPW, NX, NU, 3, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
         parity ^= 1;
     }
     if constexpr (FUSE) {

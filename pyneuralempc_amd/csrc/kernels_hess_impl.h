@@ -6,8 +6,8 @@
 // Method: forward-over-reverse.  One wave owns a tile of 16 rows (same operand layout as
 // kernels_mfma_impl.h: features on the MFMA M dimension, rows on N, activations never leave registers).
 //   base sweep    a_l (forward), delta_l = d(lambda.f)/d a_l (reverse); kept as
-//                 S1_l = 1 - a_l^2  and  E_l = -2 delta_l a_l      (so that d(delta_l * S1_l) =
-//                 S1_l * d delta_l + E_l * d a_l)
+//                 S1_l = s'(z_l) = d1(a_l)  and  E_l = delta_l r2(a_l)   (activations.h; tanh: 1 - a^2 and -2 delta a;
+//                 so that d(delta_l * S1_l) = S1_l * d delta_l + E_l * d a_l)
 //   per input p   tangent forward  da_0 = S1_0 * W_0[p,:],  da_l = S1_l * (W_l^T da_{l-1})
 //                 tangent reverse  dcz_{L} = E_L * da_L,  dcz_{l-1} = S1_{l-1} * (W_l dcz_l) + E_{l-1} * da_{l-1}
 //                 column           H[:, p] = W_0 dcz_0        (skinny MFMA, like the Jacobian's last step)
@@ -42,9 +42,10 @@ struct HessParams {
     int nnz, n_orph;
 };
 
-template <typename T, int WP, int NH, bool WLDS>
+template <typename T, int WP, int NH, bool WLDS, int ACT>
 __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
     using Ops = MfmaOps<T>;
+    using A = Act<T, ACT>;
     using V4 = typename Ops::V4;
     constexpr int MT = WP / 16;
     const MfmaParams& p = hp.base;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S1[0][mo][r] = Ops::tanh_(S1[0][mo][r]);
+                for (int r = 0; r < 4; ++r) S1[0][mo][r] = A::f(S1[0][mo][r]);
         }
 #pragma unroll
         for (int l = 1; l < NH; ++l) {
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S1[l][mo][r] = Ops::tanh_(S1[l][mo][r]);
+                for (int r = 0; r < 4; ++r) S1[l][mo][r] = A::f(S1[l][mo][r]);
         }
 
         // ---- base reverse sweep: delta_l, then S1_l = 1 - a_l^2 and E_l = -2 delta_l a_l
@@ -171,8 +172,13 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const V4 a = S1[l][mt];
-                    const V4 s1 = T(1) - a * a;
-                    E[l][mt] = T(-2) * dl[mt] * a;
+                    V4 s1, e;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        s1[r] = A::d1(a[r]);
+                        e[r] = dl[mt][r] * A::r2(a[r]);
+                    }
+                    E[l][mt] = e;
                     S1[l][mt] = s1;
                     cz[mt] = dl[mt] * s1;
                 }
@@ -248,6 +254,8 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
     }
 }
 
+template <typename T, int ACT>
+int launch_rowhess_mfma_act(const Handle& h, HessParams hp, hipStream_t s);
 template <typename T>
 int launch_rowhess_mfma_typed(const Handle& h, HessParams hp, hipStream_t s);
 

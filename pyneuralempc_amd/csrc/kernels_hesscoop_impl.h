@@ -24,9 +24,10 @@ struct HessCoopLayout {  // element offsets inside dynamic LDS
     int total;
 };
 
-template <typename T, int WP, int NH, int TG>
+template <typename T, int WP, int NH, int TG, int ACT>
 __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coop_kernel(HessParams hp, HessCoopLayout lay) {
     using Ops = MfmaOps<T>;
+    using A = Act<T, ACT>;
     using V4 = typename Ops::V4;
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coop_kernel(HessPar
         }
         lds_barrier();
 
-        // ---- forward values of this wave's feature block: S1[l] holds a_l, later 1 - a_l^2
+        // ---- forward values of this wave's feature block: S1[l] holds a_l, later s'(z_l) (tanh: 1 - a_l^2)
         V4 S1[NH], E[NH];
         {
             const T* bias = s_bias + w * 16;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coop_kernel(HessPar
                 S1[0] = Ops::mma(s_w0f[(ks * MT + w) * 64 + lane], v, S1[0]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S1[0][r] = Ops::tanh_(S1[0][r]);
+            for (int r = 0; r < 4; ++r) S1[0][r] = A::f(S1[0][r]);
         }
 #pragma unroll
         for (int l = 1; l < NH; ++l) {
@@ -135,10 +136,10 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coop_kernel(HessPar
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S1[l] = Ops::mma(W.wf[l - 1][mt * 4 + r], X[(mt * 4 + r) * 64 + lane], S1[l]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S1[l][r] = Ops::tanh_(S1[l][r]);
+            for (int r = 0; r < 4; ++r) S1[l][r] = A::f(S1[l][r]);
         }
 
-        // ---- base reverse sweep: delta_l = d(lambda.f)/d a_l; keep S1_l = 1 - a_l^2 and E_l = -2 delta_l a_l
+        // ---- base reverse sweep: delta_l = d(lambda.f)/d a_l; keep S1_l = s'(z_l) and E_l = delta_l r2(a_l) (tanh: 1 - a_l^2, -2 delta_l a_l)
         {
             V4 dl = V4{T(0), T(0), T(0), T(0)};
             for (int ks = 0; ks < hp.ksx; ++ks) {
@@ -149,8 +150,13 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coop_kernel(HessPar
 #pragma unroll
             for (int l = NH - 1; l >= 0; --l) {
                 const V4 a = S1[l];
-                const V4 s1 = T(1) - a * a;
-                E[l] = T(-2) * dl * a;
+                V4 s1, e;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s1[r] = A::d1(a[r]);
+                    e[r] = dl[r] * A::r2(a[r]);
+                }
+                E[l] = e;
                 S1[l] = s1;
                 if (l > 0) {
                     const V4 cz = dl * s1;

@@ -59,7 +59,7 @@ int scratch_elems(const Handle& h) {
 
 bool mfma_supported(const Handle& h) {
     const int nh = h.nl - 1;
-    if (nh < 1 || nh > 3) return false;
+    if (nh < 1 || nh > 3 || h.mfma_act < 0) return false;
     // network outputs on one 16-row block; inputs (window + extras) on up to kMaxKs k-steps, the window itself on up
     // to two 16-row blocks of the last reverse step (wave-per-tile kernels; the cooperative ones take <= 16)
     if (h.cfg.nx > 16 || h.nin + h.ne > 4 * kMaxKs || h.nin > 32) return false;
@@ -162,6 +162,44 @@ int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b)
     h.mfma.kin = 4 * ks;
     h.mfma.blob_elems = blob.size();
     return NEMPC_OK;
+}
+
+// one translation unit per (dtype, hidden activation) defines these (kernels_mfma_typed.inc)
+#define NEMPC_DECL_ACT(T, A)                                                                       \
+    template <> int launch_rows_mfma_act<T, A>(const Handle& h, MfmaParams p, hipStream_t s);     \
+    template <> int launch_rowhess_mfma_act<T, A>(const Handle& h, HessParams hp, hipStream_t s);
+#define NEMPC_DECL_ACTS(T)                                                                         \
+    NEMPC_DECL_ACT(T, NEMPC_ACT_TANH) NEMPC_DECL_ACT(T, NEMPC_ACT_RELU) NEMPC_DECL_ACT(T, NEMPC_ACT_SIGMOID) \
+    NEMPC_DECL_ACT(T, NEMPC_ACT_SOFTPLUS) NEMPC_DECL_ACT(T, NEMPC_ACT_ELU)
+NEMPC_DECL_ACTS(double)
+NEMPC_DECL_ACTS(float)
+#undef NEMPC_DECL_ACTS
+#undef NEMPC_DECL_ACT
+
+template <typename T>
+int launch_rows_mfma_typed(const Handle& h, MfmaParams p, hipStream_t s) {
+    switch (h.mfma_act) {
+        case NEMPC_ACT_TANH: return launch_rows_mfma_act<T, NEMPC_ACT_TANH>(h, p, s);
+        case NEMPC_ACT_RELU: return launch_rows_mfma_act<T, NEMPC_ACT_RELU>(h, p, s);
+        case NEMPC_ACT_SIGMOID: return launch_rows_mfma_act<T, NEMPC_ACT_SIGMOID>(h, p, s);
+        case NEMPC_ACT_SOFTPLUS: return launch_rows_mfma_act<T, NEMPC_ACT_SOFTPLUS>(h, p, s);
+        case NEMPC_ACT_ELU: return launch_rows_mfma_act<T, NEMPC_ACT_ELU>(h, p, s);
+    }
+    set_error("launch_rows_mfma: the matrix-core kernels do not take this network's activations");
+    return NEMPC_EUNSUPPORTED;
+}
+
+template <typename T>
+int launch_rowhess_mfma_typed(const Handle& h, HessParams hp, hipStream_t s) {
+    switch (h.mfma_act) {
+        case NEMPC_ACT_TANH: return launch_rowhess_mfma_act<T, NEMPC_ACT_TANH>(h, hp, s);
+        case NEMPC_ACT_RELU: return launch_rowhess_mfma_act<T, NEMPC_ACT_RELU>(h, hp, s);
+        case NEMPC_ACT_SIGMOID: return launch_rowhess_mfma_act<T, NEMPC_ACT_SIGMOID>(h, hp, s);
+        case NEMPC_ACT_SOFTPLUS: return launch_rowhess_mfma_act<T, NEMPC_ACT_SOFTPLUS>(h, hp, s);
+        case NEMPC_ACT_ELU: return launch_rowhess_mfma_act<T, NEMPC_ACT_ELU>(h, hp, s);
+    }
+    set_error("launch_rowhess_mfma: the matrix-core kernels do not take this network's activations");
+    return NEMPC_EUNSUPPORTED;
 }
 
 int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s) {

@@ -9,8 +9,8 @@
 // transposed; only the (host pre-packed) weight fragments are permuted to match.  The reverse sweep
 // (one cotangent per network output) uses the same trick with W instead of W^T.
 //
-//   forward   a_l = tanh(W_l^T a_{l-1} + b_l),  f = W_L^T a_{L-1} + b_L
-//   reverse   c = W_L[:,k] (1-a^2);  c <- (W_l c) (1-a_{l-1}^2) ... ;  J[k,:] = W_1 c
+//   forward   a_l = s(W_l^T a_{l-1} + b_l),  f = W_L^T a_{L-1} + b_L       (s = Act<T, ACT>, activations.h: tanh by default)
+//   reverse   c = W_L[:,k] s'(z);  c <- (W_l c) s'(z_{l-1}) ... ;  J[k,:] = W_1 c   (s' from a: tanh 1-a^2)
 //   (value-equivalent to what tf.GradientTape.jacobian yields per row, model/tensorflow.py:53-75)
 //
 // The per-row integrator algebra (rk4.py:147-159 chain rule, discret.py:52 identity) runs on a
@@ -20,6 +20,7 @@
 // fragment read is one conflict-free ds_read / one fully coalesced global load).
 #pragma once
 
+#include "activations.h"
 #include "nempc_internal.h"
 
 namespace nempc {
@@ -90,55 +91,6 @@ struct MfmaParams {
     } while (0)
 #endif
 
-// tanh for the row kernels: t = 1 - 2 / (exp(2|x|) + 1), sign restored.  ocml's tanh(double) costs ~670 cycles per
-// wave-instruction on gfx950.  On this chip every vector instruction -- double, single or integer -- takes the same 4
-// issue cycles (v_rcp_f64: 16) and a v_mfma_f64 holds the vector pipe for all of its 64 (tools/ubench_dpops.hip: MFMA
-// waves and vector waves on one SIMD serialise whatever the vector instruction is), so what a tanh costs the matrix
-// kernels is its instruction COUNT.  24 issue slots here against 33 for the straightforward form (degree-13 Taylor,
-// v_rndne + v_cvt_i32, two Newton steps, NaN select), same 2.2e-16 max abs error against tanhl on [-30, 30]
-// (tools/ubench_tanh.hip; absolute accuracy is what the 1 - a^2 derivative factors need):
-//  * |x| is clamped at 20 (tanh(20) rounds to 1) on its HIGH dword only: one compare, one select.  A NaN fails the
-//    compare and flows through every later operation, so a diverged iterate stays visible without a select at the end
-//  * n = rint(|x| * 2/ln2) by the 1.5*2^52 shift: one fma and one subtract, and the integer n is the low dword of
-//    the shifted value (no v_rndne_f64, no v_cvt_i32_f64)
-//  * s = |x| - n ln2/2 with ln2/2 as ONE double: its rounding error (1.9e-17) times n is an error of 2.2 n 1.9e-17 in
-//    exp(2s), which reaches tanh scaled by 2e/(e+1)^2 ~ 2^(1-n): at most 2.4e-17 absolute (n = 2), so the second
-//    Cody-Waite step buys nothing here
-//  * exp(2s) on |s| <= ln2/4 by a degree-11 Chebyshev fit (relative error 1.7e-17 with the rounded coefficients)
-//  * 1/d from v_rcp_f64 and ONE cubic step (three fmas)
-__device__ __forceinline__ double nempc_tanh(double x) {
-    const double a = __hiloint2double(fabs(x) > 20.0 ? 0x40340000 : __double2hiint(x), __double2loint(x));
-    const double SHIFT = 6755399441055744.0;
-    const double t = fma(fabs(a), 2.8853900817779268, SHIFT);
-    const double nf = t - SHIFT;
-    const double s = fma(-nf, 0.34657359027997264, fabs(a));      // ln2/2 in one piece, see above
-    double p = 5.1425357017013815e-05;
-    p = fma(p, s, 0.00028295822990378013);
-    p = fma(p, s, 0.0014109307350312432);
-    p = fma(p, s, 0.0063491802834760944);
-    p = fma(p, s, 0.025396825459260305);
-    p = fma(p, s, 0.08888888929481456);
-    p = fma(p, s, 0.26666666666622724);
-    p = fma(p, s, 0.6666666666638096);
-    p = fma(p, s, 1.3333333333333344);
-    p = fma(p, s, 2.0000000000000075);
-    p = fma(p, s, 2.0);
-    p = fma(p, s, 1.0);
-    const double d = ldexp(p, __double2loint(t)) + 1.0;
-    double q = __builtin_amdgcn_rcp(d);
-    const double e = fma(-d, q, 1.0);
-    q = fma(fma(e, e, e), q, q);
-    return copysign(fma(-2.0, q, 1.0), x);
-}
-
-// fp32: hardware exp2 / rcp; abs error ~1e-7, inside the fp32 configs' 1e-4 tolerance
-__device__ __forceinline__ float nempc_tanh(float x) {
-    const float ax = fminf(fabsf(x), 10.0f);
-    const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);  // exp(2|x|)
-    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
-    return x != x ? x : copysignf(t, x);
-}
-
 template <typename T>
 struct MfmaOps;
 
@@ -149,7 +101,6 @@ struct MfmaOps<double> {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
     }
     static __host__ __device__ __forceinline__ int row(int q, int r) { return q + 4 * r; }
-    static __device__ __forceinline__ double tanh_(double x) { return nempc_tanh(x); }
 };
 
 template <>
@@ -159,7 +110,6 @@ struct MfmaOps<float> {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
     static __host__ __device__ __forceinline__ int row(int q, int r) { return 4 * q + r; }
-    static __device__ __forceinline__ float tanh_(float x) { return nempc_tanh(x); }
 };
 
 // same-wave LDS hand-off between lanes: DS ops of one wave execute in order; keep the compiler from
@@ -235,9 +185,10 @@ __device__ __forceinline__ void layer_mma(const T* __restrict__ w, int lane,
     }
 }
 
-template <typename T, int WP, int NH, bool WLDS, int MAXWAVES>
+template <typename T, int WP, int NH, bool WLDS, int MAXWAVES, int ACT>
 __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) {
     using Ops = MfmaOps<T>;
+    using A = Act<T, ACT>;
     using V4 = typename Ops::V4;
     constexpr int MT = WP / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -345,7 +296,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a[0][mo][r] = Ops::tanh_(a[0][mo][r]);
+                    for (int r = 0; r < 4; ++r) a[0][mo][r] = A::f(a[0][mo][r]);
             }
 #pragma unroll
             for (int l = 1; l < NH; ++l) {
@@ -358,7 +309,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a[l][mo][r] = Ops::tanh_(a[l][mo][r]);
+                    for (int r = 0; r < 4; ++r) a[l][mo][r] = A::f(a[l][mo][r]);
             }
             {
                 V4 fo;
@@ -374,14 +325,14 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
                     if (o < nx) s_k[c * nx + o] = fo[r];
                 }
             }
-            // 1 - a^2 once, reused by every cotangent
+            // s'(z) from a (tanh: 1 - a^2) once, reused by every cotangent
             if (want_jac) {
 #pragma unroll
                 for (int l = 0; l < NH; ++l)
 #pragma unroll
                     for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) a[l][mo][r] = T(1) - a[l][mo][r] * a[l][mo][r];
+                        for (int r = 0; r < 4; ++r) a[l][mo][r] = A::d1(a[l][mo][r]);
             }
 
             // ---- reverse sweep, one cotangent per network output (skipped by defect-only launches: tiles == null)
@@ -498,16 +449,19 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
     }
 }
 
-template <typename T, int WP, int NH, bool WLDS, int MAXWAVES>
+template <typename T, int WP, int NH, bool WLDS, int MAXWAVES, int ACT>
 int launch_one(const MfmaParams& p, int waves, int grid, size_t lds_bytes, hipStream_t s) {
-    auto kern = rows_mfma_kernel<T, WP, NH, WLDS, MAXWAVES>;
+    auto kern = rows_mfma_kernel<T, WP, NH, WLDS, MAXWAVES, ACT>;
     NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds_bytes));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(waves * 64), lds_bytes, s, p);
     NEMPC_HIP(hipGetLastError());
     return NEMPC_OK;
 }
 
-// picks the instantiation for (WP, NH, weights-in-LDS)
+// picks the instantiation for (WP, NH, weights-in-LDS): one translation unit per (dtype, hidden activation)
+// (kernels_mfma_typed.inc); launch_rows_mfma_typed dispatches on the handle's activation (kernels_mfma.hip)
+template <typename T, int ACT>
+int launch_rows_mfma_act(const Handle& h, MfmaParams p, hipStream_t s);
 template <typename T>
 int launch_rows_mfma_typed(const Handle& h, MfmaParams p, hipStream_t s);
 

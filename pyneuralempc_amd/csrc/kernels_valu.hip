@@ -7,9 +7,11 @@
 //
 // Math per row (reference call sites integrator/discret.py:22-30,48-56,
 // unity.py:24-32, rk4.py:66-80,137-159):
-//   xi = [x_{t-1} ; u_t] (or the rolling window of both),  f(xi) = tanh-MLP,  J = df/dxi by one reverse sweep per output,
+//   xi = [x_{t-1} ; u_t] (or the rolling window of both),  f(xi) = MLP (any per-layer activation of activations.h, the
+//   output layer included),  J = df/dxi by one reverse sweep per output,
 //   DISCRET Phi = x + f, dPhi = J + [I 0];  UNITY Phi = f;  RK4 per rk4.py with
 //   dk_{i+1} = J_{i+1} + c_i DT J_{i+1}[:, :nx] dk_i   (== J_{i+1} (I + c_i DT [dk_i; 0])).
+#include "activations.h"
 #include "nempc_internal.h"
 
 namespace nempc {
@@ -21,13 +23,14 @@ struct NetDev {
     const void* extra;               // (B,H,ne) or null
     RowGather gk;                    // where the nin window inputs of a row come from
     int din[NEMPC_MAX_LAYERS], dout[NEMPC_MAX_LAYERS];
+    int act[NEMPC_MAX_LAYERS];       // NEMPC_ACT_* per layer
     const void* W[NEMPC_MAX_LAYERS];
     const void* Wt[NEMPC_MAX_LAYERS];
     const void* b[NEMPC_MAX_LAYERS];
 };
 
 struct WsOff {  // slot offsets (multiply by Rcap)
-    int xi, act, cot, fout, jst, kcur, dk, acck, accdk, dkn, P, rk_xin, rk_J, rk_dk, rk_nu, htmp, htmp2, total;
+    int xi, act, cot, fout, jst, kcur, dk, acck, accdk, dkn, P, cL, rk_xin, rk_J, rk_dk, rk_nu, htmp, htmp2, total;
 };
 
 WsOff ws_offsets(const Handle& h) {
@@ -43,7 +46,8 @@ WsOff ws_offsets(const Handle& h) {
     o.acck = p; p += h.cfg.nx;
     o.accdk = p; p += h.cfg.nx * h.nin;
     o.dkn = p; p += h.cfg.nx * h.nin;
-    o.P = p; p += nhid * h.maxw * h.nin;
+    o.P = p; p += (nhid * h.maxw + h.cfg.nx) * h.nin;   // pre-activation tangents: hidden layers, then the output layer
+    o.cL = p; p += h.cfg.nx;                            // cotangent w.r.t. the output layer's pre-activation
     // RK4 Lagrangian Hessian: per stage input, Jacobian, previous chain Jacobian, stage multiplier; two nin^2 temporaries
     o.rk_xin = p; p += 4 * h.nin;
     o.rk_J = p; p += 4 * h.cfg.nx * h.nin;
@@ -54,13 +58,6 @@ WsOff ws_offsets(const Handle& h) {
     o.total = p;
     return o;
 }
-
-template <typename T>
-__device__ __forceinline__ T dev_tanh(T x);
-template <>
-__device__ __forceinline__ double dev_tanh<double>(double x) { return tanh(x); }
-template <>
-__device__ __forceinline__ float dev_tanh<float>(float x) { return tanhf(x); }
 
 // forward through the network for this lane's row; hidden activations -> ws act, output -> ws fout
 template <typename T>
@@ -94,7 +91,7 @@ __device__ void net_forward(const NetDev& net, T* ws, const WsOff& o, size_t R, 
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (jb + q < wout) out[(size_t)(jb + q) * R + r] = last ? acc[q] : dev_tanh<T>(acc[q]);
+                if (jb + q < wout) out[(size_t)(jb + q) * R + r] = act_f<T>(net.act[l], acc[q]);
         }
     }
 }
@@ -104,24 +101,29 @@ template <typename T>
 __device__ void net_jacobian_row(const NetDev& net, T* ws, const WsOff& o, size_t R, size_t r, int k) {
     const int nl = net.nl;
     T* jrow = ws + (size_t)(o.jst + k * net.nin) * R;
+    // the output layer's own activation (1 for the usual linear output)
+    const T dLk = act_d1<T>(net.act[nl - 1], ws[(size_t)(o.fout + k) * R + r]);
     if (nl == 1) {
         const T* W0 = (const T*)net.W[0];
-        for (int d = 0; d < net.nin; ++d) jrow[(size_t)d * R + r] = W0[(size_t)d * net.dout[0] + k];
+        for (int d = 0; d < net.nin; ++d) jrow[(size_t)d * R + r] = W0[(size_t)d * net.dout[0] + k] * dLk;
         return;
     }
-    // seed at the last hidden layer: cot[j] = W_L[j][k] (1 - a^2)
+    // seed at the last hidden layer: cot[j] = W_L[j][k] s_L'(z_L[k]) s'(z_{L-1}[j])
     int cur = 0;
     {
         const T* WL = (const T*)net.W[nl - 1];
         const int w = net.din[nl - 1];
         const T* a = ws + (size_t)(o.act + (nl - 2) * net.maxw) * R;
         T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;
+        const bool lin_out = net.act[nl - 1] == NEMPC_ACT_LINEAR;
         for (int j = 0; j < w; ++j) {
             const T av = a[(size_t)j * R + r];
-            c[(size_t)j * R + r] = WL[(size_t)j * net.dout[nl - 1] + k] * (T(1) - av * av);
+            T wv = WL[(size_t)j * net.dout[nl - 1] + k];
+            if (!lin_out) wv *= dLk;
+            c[(size_t)j * R + r] = wv * act_d1<T>(net.act[nl - 2], av);
         }
     }
-    // hidden layers nl-2 .. 1 : cot_in[i] = (sum_j W_l[i][j] cot[j]) (1 - a_{l-1}[i]^2)
+    // hidden layers nl-2 .. 1 : cot_in[i] = (sum_j W_l[i][j] cot[j]) s'(z_{l-1}[i])
     for (int l = nl - 2; l >= 0; --l) {
         const T* Wt = (const T*)net.Wt[l];  // (out, in) row-major: Wt[j][i] = W[i][j]
         const int win = net.din[l], wout = net.dout[l];
@@ -144,10 +146,7 @@ __device__ void net_jacobian_row(const NetDev& net, T* ws, const WsOff& o, size_
             for (int q = 0; q < 8; ++q) {
                 if (ib + q < win && (!first || ib + q < net.nin)) {   // extra inputs (tvp, p) get no Jacobian column
                     T v = acc[q];
-                    if (!first) {
-                        const T av = aprev[(size_t)(ib + q) * R + r];
-                        v *= (T(1) - av * av);
-                    }
+                    if (!first) v *= act_d1<T>(net.act[l - 1], aprev[(size_t)(ib + q) * R + r]);
                     cn[(size_t)(ib + q) * R + r] = v;
                 }
             }
@@ -254,7 +253,8 @@ __global__ __launch_bounds__(256) void rows_valu_kernel(NetDev net, WsOff o, int
 // Contracted network Hessian at the input currently held in ws.xi:
 //     hout[p][q] = sum_k mult_k d2 f_k / dxi_p dxi_q  =  sum_l P_l^T diag(delta_l * s''(z_l)) P_l
 // with P_l = W_l^T D_{l-1} the pre-activation tangents (forward mode, nin directions),
-// delta_l = d(mult . f)/d a_l (one reverse sweep) and s'' = -2 a (1 - a^2).
+// delta_l = d(mult . f)/d a_l (one reverse sweep) and s'' = r2(a) d1(a) (activations.h; tanh: -2 a (1 - a^2)); the sum
+// runs over the hidden layers and, when it has an activation of its own, the output layer.
 // Value-equivalent to model/tensorflow.py:77-109 contracted as in optimizer/ipopt.py:79-80.
 // mult[k * mstride], hout[(p*nin+q) * hstride] (full symmetric block, lower triangle mirrored).
 template <typename T>
@@ -262,14 +262,15 @@ __device__ void net_hessian_contracted(const NetDev& net, T* ws, const WsOff& o,
                                        size_t mstride, T* hout, size_t hstride) {
     const int nx = net.nx, nin = net.nin, nl = net.nl;
     for (int p = 0; p < nin * nin; ++p) hout[(size_t)p * hstride] = T(0);
-    if (nl == 1) return;  // linear network: no curvature
+    const bool lin_out = net.act[nl - 1] == NEMPC_ACT_LINEAR;
+    if (nl == 1 && lin_out) return;  // linear network: no curvature
     net_forward<T>(net, ws, o, R, r);
 
-    // forward tangents: P_l[i][p] (pre-activation), stored per hidden layer; D_l = (1-a^2) P_l
-    for (int l = 0; l < nl - 1; ++l) {
+    // forward tangents: P_l[i][p] (pre-activation), stored per layer that has an activation; D_l = s'(z_l) P_l
+    for (int l = 0; l < (lin_out ? nl - 1 : nl); ++l) {
         const T* W = (const T*)net.W[l];
         const int win = net.din[l], wout = net.dout[l];
-        T* P = ws + (size_t)(o.P + l * net.maxw * nin) * R;
+        T* P = ws + (size_t)(o.P + l * net.maxw * nin) * R;      // (the output layer's block follows the hidden ones)
         const T* Pprev = (l == 0) ? nullptr : ws + (size_t)(o.P + (l - 1) * net.maxw * nin) * R;
         const T* aprev = (l == 0) ? nullptr : ws + (size_t)(o.act + (l - 1) * net.maxw) * R;
         for (int p = 0; p < nin; ++p) {
@@ -280,7 +281,7 @@ __device__ void net_hessian_contracted(const NetDev& net, T* ws, const WsOff& o,
                 } else {
                     for (int i = 0; i < win; ++i) {
                         const T av = aprev[(size_t)i * R + r];
-                        acc = fma(W[(size_t)i * wout + j], (T(1) - av * av) * Pprev[(size_t)(i * nin + p) * R + r],
+                        acc = fma(W[(size_t)i * wout + j], act_d1<T>(net.act[l - 1], av) * Pprev[(size_t)(i * nin + p) * R + r],
                                   acc);
                     }
                 }
@@ -290,13 +291,32 @@ __device__ void net_hessian_contracted(const NetDev& net, T* ws, const WsOff& o,
     }
     // reverse sweep for delta_l = d(mult . f)/d a_l, accumulate the block on the way down
     int cur = 0;
-    {
+    T* cL = ws + (size_t)o.cL * R;          // d(mult . f)/d z_L: mult itself for a linear output layer
+    if (lin_out) {
+        for (int k = 0; k < nx; ++k) cL[(size_t)k * R + r] = mult[(size_t)k * mstride];
+    } else {
+        const T* fo = ws + (size_t)o.fout * R;
+        const T* P = ws + (size_t)(o.P + (nl - 1) * net.maxw * nin) * R;
+        for (int k = 0; k < nx; ++k) {
+            const T av = fo[(size_t)k * R + r];
+            const T s1 = act_d1<T>(net.act[nl - 1], av);
+            const T wgt = mult[(size_t)k * mstride] * (act_r2<T>(net.act[nl - 1], av) * s1);
+            for (int p = 0; p < nin; ++p) {
+                const T pp = wgt * P[(size_t)(k * nin + p) * R + r];
+                for (int q = 0; q <= p; ++q)
+                    hout[(size_t)(p * nin + q) * hstride] =
+                        fma(pp, P[(size_t)(k * nin + q) * R + r], hout[(size_t)(p * nin + q) * hstride]);
+            }
+            cL[(size_t)k * R + r] = mult[(size_t)k * mstride] * s1;
+        }
+    }
+    if (nl > 1) {
         const T* WL = (const T*)net.W[nl - 1];
         const int w = net.din[nl - 1];
         T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;
         for (int j = 0; j < w; ++j) {
             T acc = T(0);
-            for (int k = 0; k < nx; ++k) acc = fma(WL[(size_t)j * nx + k], mult[(size_t)k * mstride], acc);
+            for (int k = 0; k < nx; ++k) acc = fma(WL[(size_t)j * nx + k], cL[(size_t)k * R + r], acc);
             c[(size_t)j * R + r] = acc;
         }
     }
@@ -307,8 +327,8 @@ __device__ void net_hessian_contracted(const NetDev& net, T* ws, const WsOff& o,
         T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;  // delta_l (wrt a_l)
         for (int j = 0; j < wout; ++j) {
             const T av = a[(size_t)j * R + r];
-            const T s1 = T(1) - av * av;
-            const T wgt = c[(size_t)j * R + r] * (T(-2) * av * s1);
+            const T s1 = act_d1<T>(net.act[l], av);
+            const T wgt = c[(size_t)j * R + r] * (act_r2<T>(net.act[l], av) * s1);
             for (int p = 0; p < nin; ++p) {
                 const T pp = wgt * P[(size_t)(j * nin + p) * R + r];
                 for (int q = 0; q <= p; ++q)
@@ -455,7 +475,7 @@ NetDev make_netdev(const Handle& h) {
     nd.ne = h.ne; nd.extra = h.d_extra;
     nd.gk = h.gather();
     for (int l = 0; l < h.nl; ++l) {
-        nd.din[l] = h.din[l]; nd.dout[l] = h.dout[l];
+        nd.din[l] = h.din[l]; nd.dout[l] = h.dout[l]; nd.act[l] = h.act[l];
         nd.W[l] = h.d_W[l]; nd.Wt[l] = h.d_Wt[l]; nd.b[l] = h.d_b[l];
     }
     return nd;

@@ -318,8 +318,11 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
         return fail(NEMPC_EINVAL, "nempc_create: n_layers out of range");
     if (cfg->widths[cfg->n_layers - 1] != cfg->nx)
         return fail(NEMPC_EINVAL, "nempc_create: last layer width must equal nx (model output = state dim)");
-    for (int l = 0; l < cfg->n_layers; ++l)
+    for (int l = 0; l < cfg->n_layers; ++l) {
         if (cfg->widths[l] < 1) return fail(NEMPC_EINVAL, "nempc_create: layer width must be >= 1");
+        if (cfg->activations[l] < 0 || cfg->activations[l] >= NEMPC_ACT_COUNT)
+            return fail(NEMPC_EINVAL, "nempc_create: unknown activation code (NEMPC_ACT_*)");
+    }
     if (cfg->max_batch < 1) return fail(NEMPC_EINVAL, "nempc_create: max_batch must be >= 1");
     if (cfg->n_extra < 0) return fail(NEMPC_EINVAL, "nempc_create: n_extra must be >= 0");
     if (cfg->kernel < NEMPC_KERNEL_AUTO || cfg->kernel > NEMPC_KERNEL_MFMA_TILE)
@@ -350,6 +353,14 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
         h->din[l] = l == 0 ? h->nin + h->ne : cfg->widths[l - 1];
         h->dout[l] = cfg->widths[l];
         if (l < h->nl - 1 && h->dout[l] > h->maxw) h->maxw = h->dout[l];
+        h->act[l] = cfg->activations[l];
+    }
+    // matrix-core kernels: one non-linear activation on every hidden layer, linear output
+    h->mfma_act = -1;
+    if (h->nl >= 2 && h->act[h->nl - 1] == NEMPC_ACT_LINEAR && h->act[0] != NEMPC_ACT_LINEAR) {
+        h->mfma_act = h->act[0];
+        for (int l = 1; l < h->nl - 1; ++l)
+            if (h->act[l] != h->act[0]) h->mfma_act = -1;
     }
     {
         // compute units of the device: every "fill the chip" launch geometry is sized from this, never from a literal.
@@ -366,7 +377,7 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
     if (cfg->kernel == NEMPC_KERNEL_MFMA || cfg->kernel == NEMPC_KERNEL_MFMA_TILE) {
         if (!mfma_supported(*h)) {
             delete h;
-            return fail(NEMPC_EUNSUPPORTED, "nempc_create: MFMA row kernel does not cover these layer dims");
+            return fail(NEMPC_EUNSUPPORTED, "nempc_create: MFMA row kernel does not cover these layer dims / activations");
         }
         h->variant = cfg->kernel;
     } else if (cfg->kernel == NEMPC_KERNEL_AUTO && mfma_supported(*h)) {

@@ -112,6 +112,9 @@ struct Handle {
         return gk;
     }
     int din[NEMPC_MAX_LAYERS]{}, dout[NEMPC_MAX_LAYERS]{};
+    int act[NEMPC_MAX_LAYERS]{};   // NEMPC_ACT_* per layer (cfg.activations)
+    int mfma_act = -1;             // the one hidden activation when the matrix-core kernels can take the network
+                                   // (same non-linear activation on every hidden layer, linear output layer), else -1
     int maxw = 0;
     bool box = false;
     bool have_weights = false;

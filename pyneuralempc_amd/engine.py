@@ -15,6 +15,25 @@ from . import _lib
 _TORCH_DTYPES = {torch.float64: _lib.F64, torch.float32: _lib.F32}
 
 
+def resolve_activations(activations, n_layers):
+    """Per-layer activation names of an n_layers-deep dense stack.  None: tanh hidden layers and a linear output layer
+    (the reference's nn_model.h5); one name: that activation on every hidden layer, linear output; a sequence: one name
+    per layer, the output layer included.  Names as Keras spells them (_lib.ACTIVATION_IDS)."""
+    if activations is None:
+        names = ["tanh"] * (n_layers - 1) + ["linear"]
+    elif isinstance(activations, str):
+        names = [activations] * (n_layers - 1) + ["linear"]
+    else:
+        names = [str(a) for a in activations]
+        if len(names) != n_layers:
+            raise ValueError(f"activations: expected one name per dense layer ({n_layers}), got {len(names)}")
+    for a in names:
+        if a not in _lib.ACTIVATION_IDS:
+            raise NotImplementedError(f"activation '{a}' is not supported on the device path "
+                                      f"(supported: {', '.join(_lib.ACTIVATION_IDS)})")
+    return names
+
+
 def _as_c_double(a):
     a = np.ascontiguousarray(a, dtype=np.float64)
     return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
@@ -22,7 +41,8 @@ def _as_c_double(a):
 
 class CallbackEngine:
     def __init__(self, weights, biases, H, nx, nu, integrator="discret", DT=1.0, dtype=torch.float64,
-                 device="cuda", max_batch=1, kernel="auto", n_extra=0, rolling_window=1, forward_rolling=True):
+                 device="cuda", max_batch=1, kernel="auto", n_extra=0, rolling_window=1, forward_rolling=True,
+                 activations=None):
         if not torch.cuda.is_available():
             raise RuntimeError("pyneuralempc_amd needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -63,6 +83,7 @@ class CallbackEngine:
         if prev != self.nx:
             raise ValueError("Your model do not provide a suitable output dim ! It must get the same dim as the "
                              "state dim.")
+        self.activations = resolve_activations(activations, len(self._weights))
         self._objective = None
         self._box = None
         self._handle = None
@@ -82,6 +103,7 @@ class CallbackEngine:
         cfg.n_layers = len(self._weights)
         for i, w in enumerate(self._weights):
             cfg.widths[i] = w.shape[1]
+            cfg.activations[i] = _lib.ACTIVATION_IDS[self.activations[i]]
         cfg.max_batch = max_batch
         cfg.kernel = _lib.KERNEL_NAMES[self.kernel] if isinstance(self.kernel, str) else int(self.kernel)
         cfg.n_extra = self.n_extra

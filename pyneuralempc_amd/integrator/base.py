@@ -62,19 +62,32 @@ class Integrator:
 
 
 class DeviceIntegrator(Integrator):
-    """Shared implementation of Discret / Unity / RK4 on the HIP engine."""
+    """Shared implementation of Discret / Unity / RK4: on the HIP engine for dense-network models (MLPModel /
+    KerasTFModel and their rolling-window forms), through the generic host algebra (integrator/host.py) for every other
+    Model plug-in (model.TorchModel, a user's own subclass) -- those have no kernel, exactly as in the reference every
+    model goes through Model.forward / jacobian / hessian."""
 
     def __init__(self, model, H, DT=1.0):
-        if not isinstance(model, MLPModel):
-            if isinstance(model, Model):
-                raise NotImplementedError("the device integrators need an MLPModel / KerasTFModel (feed-forward "
-                                          "tanh network); other Model plug-ins have no HIP path")
+        if not isinstance(model, Model):
             raise ValueError("The model provided isn't a Model object !")
         super().__init__(model, H, model.x_dim * H)
         self.DT = DT
+        self.on_device = isinstance(model, MLPModel)
+        self._host = None
+        if not self.on_device:
+            from .host import HostAlgebra
+            if int(getattr(model, "rolling_window", 1)) > 1:
+                raise NotImplementedError("rolling-window models run on the device path only (MLPModelRollingInput)")
+            self._host = HostAlgebra(model, H, self.KIND, DT)
+
+    def _need_device(self, what):
+        if not self.on_device:
+            raise NotImplementedError(f"{what} needs a dense-network model (MLPModel / KerasTFModel): "
+                                      f"{type(self.model).__name__} is evaluated on the host, one problem per call")
 
     # -- engine ---------------------------------------------------------------------------
     def engine(self, max_batch=1):
+        self._need_device("the batched device engine")
         if self._engine is None:
             self._engine = self.model.make_engine(self.H, self.KIND, DT=self.DT, max_batch=max_batch)
         self._engine.reserve(max_batch)
@@ -90,11 +103,15 @@ class DeviceIntegrator(Integrator):
 
     # -- reference signatures (one problem, NumPy in / out) ---------------------------------
     def forward(self, x, u, x0, p=None, tvp=None):
+        if self._host is not None:
+            return self._host.forward(x, u, x0, p=p, tvp=tvp)
         eng, Z, X0 = self._pack(x, u, x0, p, tvp)
         g = eng.eval(Z, X0, want=("g",))["g"]
         return g[0, :self.nb_contraints].to("cpu", torch.float64).numpy()
 
     def jacobian(self, x, u, x0, p=None, tvp=None):
+        if self._host is not None:
+            return self._host.jacobian(x, u, x0, p=p, tvp=tvp)
         eng, Z, X0 = self._pack(x, u, x0, p, tvp)
         J = eng.eval(Z, X0, want=("jac_dense",))["jac_dense"]
         return J[0, :self.nb_contraints].to("cpu", torch.float64).numpy()
@@ -102,6 +119,8 @@ class DeviceIntegrator(Integrator):
     def hessian(self, x, u, x0, p=None, tvp=None):
         """(H*nx, n, n) like integrator/discret.py:61-81: one device call per constraint row block
         (one-hot multipliers); meant for inspection, the solver path uses the contracted form."""
+        if self._host is not None:
+            return self._host.hessian(x, u, x0, p=p, tvp=tvp)
         eng, Z, X0 = self._pack(x, u, x0, p, tvp)
         n, m = eng.n, eng.m
         out = np.zeros((self.nb_contraints, n, n))

@@ -4,7 +4,9 @@ from . import mlp
 from . import rolling
 from . import jax
 from . import tensorflow
+from . import torch_model
 from .base import Model
 from .mlp import MLPModel
 from .rolling import MLPModelRollingInput
 from .tensorflow import KerasTFModel, KerasTFModelRollingInput
+from .torch_model import TorchModel

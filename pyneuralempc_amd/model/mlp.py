@@ -1,4 +1,4 @@
-"""Feed-forward tanh network evaluated on the device (reference: model/tensorflow.py:8-109,
+"""Feed-forward dense network evaluated on the device (reference: model/tensorflow.py:8-109,
 model/jax.py:32-88 -- there the derivatives come from TF / JAX autodiff of the whole (H, .) batch,
 here from the analytic per-row sweeps in csrc/)."""
 import numpy as np
@@ -9,13 +9,16 @@ from ..engine import CallbackEngine
 
 
 class MLPModel(Model):
-    """x_{next-ish} = f([x | u]) with f = Dense-tanh ... Dense-linear.
+    """x_{next-ish} = f([x | u]) with f a stack of Dense layers (Dense-tanh ... Dense-linear by default).
 
     weights[l] is the Keras ``kernel`` (in, out), biases[l] is (out,).  The output width must be
-    x_dim and the input width x_dim + u_dim (same checks as KerasTFModel.__init__)."""
+    x_dim and the input width x_dim + u_dim (same checks as KerasTFModel.__init__).
+    activations: None (tanh hidden layers, linear output), one Keras activation name for every hidden layer, or one name
+    per layer including the output layer -- linear, tanh, relu, sigmoid, softplus, elu.  One non-linear activation on
+    all hidden layers with a linear output runs on the matrix-core kernels; any other mix on the generic kernel."""
 
     def __init__(self, weights, biases, x_dim, u_dim, p_dim=0, tvp_dim=0, dtype=torch.float64, device="cuda",
-                 kernel="auto", _input_width=None):
+                 kernel="auto", _input_width=None, activations=None):
         p_dim, tvp_dim = int(p_dim or 0), int(tvp_dim or 0)
         weights = [np.asarray(w, dtype=np.float64) for w in weights]
         biases = [np.asarray(b, dtype=np.float64).reshape(-1) for b in biases]
@@ -29,6 +32,8 @@ class MLPModel(Model):
                              "sum of all input vars (x, u, p, tvp).")
         super().__init__(x_dim, u_dim, p_dim, tvp_dim)
         self.weights, self.biases = weights, biases
+        from ..engine import resolve_activations
+        self.activations = resolve_activations(activations, len(weights))
         self.dtype, self.device, self.kernel = dtype, device, kernel
         self._row_engine = None
 
@@ -42,7 +47,7 @@ class MLPModel(Model):
     def make_engine(self, H, integrator, DT=1.0, max_batch=1):
         return CallbackEngine(self.weights, self.biases, H, self.x_dim, self.u_dim, integrator=integrator, DT=DT,
                               dtype=self.dtype, device=self.device, max_batch=max_batch, kernel=self.kernel,
-                              n_extra=self.p_dim + self.tvp_dim)
+                              n_extra=self.p_dim + self.tvp_dim, activations=self.activations)
 
     def gather_extra(self, rows, p=None, tvp=None):
         """(rows, tvp_dim + p_dim) array [tvp_t | p] in the reference's concatenation order

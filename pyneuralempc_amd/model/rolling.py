@@ -16,7 +16,7 @@ from ..engine import CallbackEngine
 
 class MLPModelRollingInput(MLPModel):
     def __init__(self, weights, biases, x_dim, u_dim, p_dim=0, tvp_dim=0, rolling_window=2, forward_rolling=True,
-                 dtype=torch.float64, device="cuda", kernel="auto"):
+                 dtype=torch.float64, device="cuda", kernel="auto", activations=None):
         if not isinstance(rolling_window, int) or rolling_window < 1:
             raise ValueError("Your rolling windows need to be an integer gretter than 1.")
         p_dim, tvp_dim = int(p_dim or 0), int(tvp_dim or 0)
@@ -29,7 +29,7 @@ class MLPModelRollingInput(MLPModel):
         self.prev_x, self.prev_u, self.prev_tvp = None, None, None
         # MLPModel checks in = x + u + p + tvp: present the windowed widths to it
         MLPModel.__init__(self, weights, biases, x_dim, u_dim, p_dim, tvp_dim, dtype=dtype, device=device,
-                          kernel=kernel, _input_width=w0.shape[0])
+                          kernel=kernel, _input_width=w0.shape[0], activations=activations)
 
     def __getstate__(self):   # tensorflow.py:168-175: the history does not travel
         d = MLPModel.__getstate__(self)
@@ -59,7 +59,7 @@ class MLPModelRollingInput(MLPModel):
         return CallbackEngine(self.weights, self.biases, H, self.x_dim, self.u_dim, integrator=integrator, DT=DT,
                               dtype=self.dtype, device=self.device, max_batch=max_batch, kernel=self.kernel,
                               n_extra=self.n_extra, rolling_window=self.rolling_window,
-                              forward_rolling=self.forward_rolling)
+                              forward_rolling=self.forward_rolling, activations=self.activations)
 
     def _roll(self, prev, cur):
         ext = np.concatenate([prev, cur], axis=0)

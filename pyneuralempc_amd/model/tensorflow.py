@@ -1,40 +1,49 @@
 """KerasTFModel drop-in (reference: model/tensorflow.py:8-109) without importing TensorFlow.
 
-The reference wraps a live Keras model and differentiates it with tf.GradientTape on the CPU.
-Here the Keras object is only *read*: its Dense kernels/biases are copied once and the network is
-evaluated by the HIP kernels.  Anything that is not a stack of Dense layers with tanh hidden
-activations and a linear output is rejected loudly."""
+The reference wraps a live Keras model -- any feed-forward one (model/tensorflow.py:8-29) -- and differentiates it with
+tf.GradientTape on the CPU.  Here the Keras object is only *read*: its Dense kernels / biases / activation names are
+copied once and the network is evaluated by the HIP kernels.  Dense stacks with any of the activations linear, tanh,
+relu, sigmoid, softplus, elu (per layer, the output layer included) are taken; anything else -- other layer types,
+other activations -- is rejected loudly."""
 import numpy as np
 
 from .mlp import MLPModel
 from .rolling import MLPModelRollingInput
 
 
+from .. import _lib
+
+
 def _activation_name(layer):
     act = getattr(layer, "activation", None)
     if act is None:
         return "linear"
-    return getattr(act, "__name__", str(act))
+    if isinstance(act, str):
+        return act
+    return getattr(act, "__name__", None) or getattr(act, "name", None) or str(act)
 
 
 def extract_dense_stack(keras_model):
-    """-> (weights, biases) from a duck-typed Keras Sequential/Functional model of Dense layers."""
+    """-> (weights, biases, activations) from a duck-typed Keras Sequential/Functional model of Dense layers;
+    activations holds one Keras activation name per dense layer (what Dense(..., activation=...) was given)."""
     layers = [l for l in getattr(keras_model, "layers", []) if len(l.get_weights()) > 0]
     if not layers:
         raise ValueError("The provided model has no parameterised layers")
-    weights, biases = [], []
+    weights, biases, activations = [], [], []
     for i, layer in enumerate(layers):
         params = layer.get_weights()
         if len(params) != 2 or np.ndim(params[0]) != 2 or np.ndim(params[1]) != 1:
             raise NotImplementedError("Only Dense layers (kernel, bias) are supported on the device path")
         name = _activation_name(layer)
-        expected = "linear" if i == len(layers) - 1 else "tanh"
-        if name != expected:
-            raise NotImplementedError(f"layer {i}: activation '{name}' unsupported (need tanh hidden layers and a "
-                                      "linear output layer)")
+        if name not in _lib.ACTIVATION_IDS:
+            raise NotImplementedError(f"layer {i}: activation '{name}' unsupported on the device path (supported: "
+                                      f"{', '.join(_lib.ACTIVATION_IDS)})")
+        if name == "elu" and float(getattr(layer.activation, "alpha", 1.0)) != 1.0:
+            raise NotImplementedError(f"layer {i}: elu with alpha != 1 is unsupported on the device path")
         weights.append(np.asarray(params[0], dtype=np.float64))
         biases.append(np.asarray(params[1], dtype=np.float64))
-    return weights, biases
+        activations.append(name)
+    return weights, biases, activations
 
 
 class KerasTFModel(MLPModel):
@@ -49,8 +58,8 @@ class KerasTFModel(MLPModel):
         if model.input_shape[-1] != sum((x_dim, u_dim, p_dim, tvp_dim)):
             raise ValueError("Your Keras model do not provide a suitable input dim ! \n It must get the same dim as "
                              "the sum of all input vars (x, u, p, tvp).")
-        weights, biases = extract_dense_stack(model)
-        super().__init__(weights, biases, x_dim, u_dim, p_dim, tvp_dim, **device_kwargs)
+        weights, biases, activations = extract_dense_stack(model)
+        super().__init__(weights, biases, x_dim, u_dim, p_dim, tvp_dim, activations=activations, **device_kwargs)
 
 
 class KerasTFModelRollingInput(MLPModelRollingInput):
@@ -66,6 +75,6 @@ class KerasTFModelRollingInput(MLPModelRollingInput):
                              "as the state dim.")
         if not isinstance(rolling_window, int) or rolling_window < 1:
             raise ValueError("Your rolling windows need to be an integer gretter than 1.")
-        weights, biases = extract_dense_stack(model)
+        weights, biases, activations = extract_dense_stack(model)
         super().__init__(weights, biases, x_dim, u_dim, p_dim, tvp_dim, rolling_window=rolling_window,
-                         forward_rolling=forward_rolling, **device_kwargs)
+                         forward_rolling=forward_rolling, activations=activations, **device_kwargs)

@@ -297,7 +297,7 @@ class _CallbackGlue:
         self.tvp = tvp
         self._fused = None
         boxes = [c for c in constraints if isinstance(c, BoxStateConstraint)]
-        if (isinstance(integrator, DeviceIntegrator) and isinstance(objective_func, QuadraticObjective)
+        if (isinstance(integrator, DeviceIntegrator) and integrator.on_device and isinstance(objective_func, QuadraticObjective)
                 and len(boxes) == len(constraints) and len(boxes) <= 1):
             self._fused = fused_evaluator(integrator, objective_func, boxes[0] if boxes else None)
             self._fused.set_parameters(p, tvp)

@@ -267,6 +267,23 @@ CASES = {
     # time-varying + constant parameters as extra network inputs: (.., with_hessian, p_dim, tvp_dim)
     "tvp_p_discret": (2, 1, [32, 32], 6, orc.DISCRET, 1.0, None, 2, True, 1, 2),
     "tvp_p_rk4": (2, 1, [32, 32], 6, orc.RK4, 0.2, None, 2, True, 1, 2),
+    # activation family (ABI v6): (.., with_hessian, p_dim, tvp_dim, activations) -- one configs[1]-shaped case (2/1, 2x64,
+    # H=20, Discret, with the Lagrangian Hessian) and one configs[2]-shaped case (6/3, 3x128, RK4; a short horizon keeps the
+    # fixture small) per activation, through the reference's own integrators / IpoptProblem like every case above
+    "act_relu_c2": (2, 1, [64, 64], 20, orc.DISCRET, 1.0, None, 2, True, 0, 0, "relu"),
+    "act_sigmoid_c2": (2, 1, [64, 64], 20, orc.DISCRET, 1.0, None, 2, True, 0, 0, "sigmoid"),
+    "act_softplus_c2": (2, 1, [64, 64], 20, orc.DISCRET, 1.0, None, 2, True, 0, 0, "softplus"),
+    "act_elu_c2": (2, 1, [64, 64], 20, orc.DISCRET, 1.0, None, 2, True, 0, 0, "elu"),
+    "act_relu_c3": (6, 3, [128, 128, 128], 6, orc.RK4, 0.1, None, 1, False, 0, 0, "relu"),
+    "act_sigmoid_c3": (6, 3, [128, 128, 128], 6, orc.RK4, 0.1, None, 1, False, 0, 0, "sigmoid"),
+    "act_softplus_c3": (6, 3, [128, 128, 128], 6, orc.RK4, 0.1, None, 1, False, 0, 0, "softplus"),
+    "act_elu_c3": (6, 3, [128, 128, 128], 6, orc.RK4, 0.1, None, 1, False, 0, 0, "elu"),
+    # a different activation on every layer, the output layer included (generic kernel): box rows + Hessian under Discret,
+    # and RK4 with nx+nu = 3 so that the reference's own rk4.hessian applies
+    "act_mixed_box": (2, 1, [32, 24, 16], 9, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True, 0, 0,
+                      ["relu", "softplus", "elu", "sigmoid"]),
+    "act_mixed_rk4": (2, 1, [24, 24], 7, orc.RK4, 0.2, None, 2, True, 0, 0, ["elu", "sigmoid", "tanh"]),
+    "act_linear_hidden": (2, 1, [16, 16], 5, orc.UNITY, 1.0, None, 2, True, 0, 0, ["linear", "tanh", "linear"]),
 }
 
 
@@ -279,11 +296,14 @@ def check_network_derivatives_by_ad(net, n_in, seed=11, rows=3, with_hess=True):
     Wt = [torch.tensor(w, dtype=torch.float64) for w in net.W]
     bt = [torch.tensor(b, dtype=torch.float64) for b in net.b]
 
+    tact = {"linear": lambda z: z, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid,
+            "softplus": torch.nn.functional.softplus, "elu": torch.nn.functional.elu}
+
     def f(xi):
         a = xi
-        for w, b in zip(Wt[:-1], bt[:-1]):
-            a = torch.tanh(a @ w + b)
-        return a @ Wt[-1] + bt[-1]
+        for w, b, name in zip(Wt, bt, net.act):
+            a = tact[name](a @ w + b)
+        return a
 
     xi = np.random.default_rng(seed).normal(size=(rows, n_in))
     fo, Jo, So = net.forward_jac_hess(xi)
@@ -302,7 +322,8 @@ def build_case(ref, plugins, name, spec):
     NumpyMLPModel, QuadObjective, BoxStateRows = plugins[:3]
     nx, nu, hidden, H, kind, DT, box, B, with_h = spec[:9]
     p_dim, tvp_dim = (spec[9], spec[10]) if len(spec) > 9 else (0, 0)
-    net = orc.MLP.random(nx + nu + p_dim + tvp_dim, hidden, nx, seed=0)
+    activations = spec[11] if len(spec) > 11 else None
+    net = orc.MLP.random(nx + nu + p_dim + tvp_dim, hidden, nx, seed=0, activations=activations)
     check_network_derivatives_by_ad(net, nx + nu + p_dim + tvp_dim, with_hess=max(hidden) <= 64)
     rng = np.random.default_rng(7)
     xref = rng.normal(size=(H, nx)) * 0.3
@@ -340,6 +361,8 @@ def build_case(ref, plugins, name, spec):
         out["box_lo"], out["box_hi"] = np.full(nx, box[0]), np.full(nx, box[1])
     for i, (w, b) in enumerate(zip(net.W, net.b)):
         out[f"W{i}"], out[f"b{i}"] = w, b
+    if activations is not None:
+        out["activations"] = np.array([orc.ACT_IDS[a] for a in net.act])     # NEMPC_ACT_* per layer
 
     f, grad, g, jac, hvals, hdense = [], [], [], [], [], []
     g_int, j_int = [], []

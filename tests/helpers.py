@@ -9,6 +9,10 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 CASE_NAMES = ["c1_discret", "c2_discret", "c2_unity", "c2_rk4", "c3_rk4", "c3_discret", "c5_box",
               "odd_dims", "h1", "tvp_p_discret", "tvp_p_rk4"]
+# activation family: uniform hidden activation + linear output (every kernel family), and per-layer mixes incl. the
+# output layer (generic kernel only)
+ACT_UNIFORM_NAMES = [f"act_{a}_{c}" for a in ("relu", "sigmoid", "softplus", "elu") for c in ("c2", "c3")]
+ACT_MIXED_NAMES = ["act_mixed_box", "act_mixed_rk4", "act_linear_hidden"]
 ROLLING_NAMES = ["roll2_discret", "roll3_unity_rev", "roll3_discret_rev", "roll4_wide", "roll2_tvp_p", "roll4_short"]
 
 
@@ -38,9 +42,16 @@ def load_case(name):
     return d, W, b
 
 
+def case_activations(d):
+    """Per-layer activation names of a golden case (None = the default tanh ... linear stack)."""
+    if "activations" not in d:
+        return None
+    return [orc.ACTIVATIONS[int(c)] for c in d["activations"]]
+
+
 def oracle_problem(d, W, b, i=0):
     """Oracle Problem of a golden case; for rolling cases with the history of problem i of the batch."""
-    net = orc.MLP(W, b)
+    net = orc.MLP(W, b, case_activations(d))
     box = (d["box_lo"], d["box_hi"]) if int(d["has_box"]) else None
     w = int(d.get("window", 1))
     roll = {} if w == 1 else dict(window=w, forward_rolling=bool(int(d["forward_rolling"])),

@@ -27,10 +27,15 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_matches_header_layout():
     from pyneuralempc_amd import _lib
-    # 8 int32 + 8 widths + 5 int32 = 21 int32 (84 B) -> padded to 88, + double = 96
-    assert ctypes.sizeof(_lib.NempcConfig) == 96
+    # 8 int32 + 8 widths + 5 int32 = 21 int32 (84 B) -> padded to 88, + double = 96, + 8 activation codes = 128
+    assert ctypes.sizeof(_lib.NempcConfig) == 128
     assert _lib.NempcConfig.rolling_window.offset == 76
     assert _lib.NempcConfig.DT.offset == 88
+    assert _lib.NempcConfig.activations.offset == 96
+    # the codes of include/nempc.h
+    text = open(os.path.join(REPO, "include", "nempc.h")).read()
+    for name, code in _lib.ACTIVATION_IDS.items():
+        assert re.search(rf"#define NEMPC_ACT_{name.upper()} {code}\b", text), name
 
 
 def test_create_validates_before_touching_the_device_and_fails_loudly_without_gpu():
@@ -49,6 +54,9 @@ def test_create_validates_before_touching_the_device_and_fails_loudly_without_gp
     cfg.widths[0] = 3          # last width != nx
     assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     cfg.widths[0] = 2
+    cfg.activations[0] = 6            # no such activation
+    assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"activation" in lib.nempc_last_error()
+    cfg.activations[0] = 0
     cfg.max_batch = 1
     cfg.integrator, cfg.DT = 2, 0.0   # RK4 without DT
     assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1

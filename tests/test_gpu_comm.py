@@ -106,3 +106,35 @@ def test_bound_extras_smaller_than_the_batch_are_refused():
     assert rc == -1 and b"bound extras" in eng.lib.nempc_last_error()
     eng.bind_extra(torch.zeros(8, 6, 2, dtype=torch.float64, device="cuda:0"))
     eng.eval(Z, X0)
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2` end to end on the one GPU a box has: the launcher starts two ranks, both share cuda:0 and
+    the collectives go through gloo (NEMPC_BENCH_BACKEND=gloo; RCCL refuses two ranks on one device) -- every line of
+    the N > 1 code path except the RCCL calls themselves: sharded inputs per rank, the u0 all-gather inside the timed
+    loop once per MPC step with the returned shard checked, barrier-bracketed timing with the MAX over ranks, the
+    batched solve + gather of the solved u0, rank 0's single JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NEMPC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "34", "--warmup", "3",
+                        "--batch", "64", "--no-cpu", "--no-other-configs", "--no-hessian", "--prime-ms", "0",
+                        "--solver-iters", "10"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 34 and out["scaling"] == "weak"
+    assert out["config"]["batch_per_gpu"] == 64 and out["config"]["parallelism"] == "problem-sharded x2"
+    # whole-job aggregate: both ranks' problems over the slowest rank's time
+    assert abs(out["value"] - 2 * 64 * 34 / (out["ms_per_step"] * 34 * 1e-3)) / out["value"] < 1e-9
+    ag = out["allgather_u0"]
+    assert ag["issued_in_timed_loop"] == 2 and ag["rows_gathered"] == 128 and ag["latency_us"] > 0     # 34 steps / 17
+    assert out["batched_solver"]["gathered_rows"] == 128
+    assert out["jacobian_max_abs_err_vs_cpu"] < 1e-12
+    assert out["roofline"]["frac"] > 0 and "FUSE = true" in out["roofline"]["kernel"]

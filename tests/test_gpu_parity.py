@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import nempc_oracle as orc
-from helpers import CASE_NAMES, case_extra, load_case, oracle_problem
+from helpers import ACT_MIXED_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, case_activations, case_extra, load_case, oracle_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,7 @@ def _engine(d, W, b, dtype, kernel, max_batch=8):
     ex = case_extra(d)
     eng = CallbackEngine(W, b, int(d["H"]), int(d["nx"]), int(d["nu"]), integrator=KIND_NAME[int(d["kind"])],
                          DT=float(d["DT"]), dtype=dtype, device="cuda:0", max_batch=max_batch, kernel=kernel,
-                         n_extra=0 if ex is None else ex.shape[1])
+                         n_extra=0 if ex is None else ex.shape[1], activations=case_activations(d))
     if ex is not None:   # the same parameters for every problem of the golden batch
         eng.bind_extra(eng.to_device(np.broadcast_to(ex[None], (max_batch,) + ex.shape).copy()))
     eng.set_objective(Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"])
@@ -38,8 +38,12 @@ def _f32_close(a, b, what):
 ALL = ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma", "mfma_tile"])
-@pytest.mark.parametrize("name", CASE_NAMES)
+# every golden case x every kernel family; per-layer activation mixes run on the generic kernel only
+_FP64_CASES = ([(n, k) for n in CASE_NAMES + ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile")] +
+               [(n, "valu") for n in ACT_MIXED_NAMES])
+
+
+@pytest.mark.parametrize("name,kernel", _FP64_CASES)
 def test_golden_fp64(name, kernel):
     d, W, b = load_case(name)
     eng = _engine(d, W, b, torch.float64, kernel)
@@ -63,8 +67,9 @@ def test_golden_fp64(name, kernel):
     np.testing.assert_array_equal(cu, d["cu_bound"])
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma", "mfma_tile"])
-@pytest.mark.parametrize("name", ["c2_discret", "c3_rk4", "c3_discret", "c5_box", "odd_dims"])
+@pytest.mark.parametrize("name,kernel", [(n, k) for n in ["c2_discret", "c3_rk4", "c3_discret", "c5_box", "odd_dims"] +
+                                         ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile")] +
+                         [(n, "valu") for n in ACT_MIXED_NAMES])
 def test_golden_fp32(name, kernel):
     d, W, b = load_case(name)
     eng = _engine(d, W, b, torch.float32, kernel)
@@ -74,8 +79,10 @@ def test_golden_fp32(name, kernel):
     assert np.array_equal(res["jac_dense"] != 0, d["jac"] != 0)
 
 
-@pytest.mark.parametrize("kernel", ["valu", "mfma", "mfma_tile"])
-@pytest.mark.parametrize("name", [n for n in CASE_NAMES if n not in ("c3_rk4", "odd_dims", "c3_discret")])
+@pytest.mark.parametrize("name,kernel",
+                         [(n, k) for n in [c for c in CASE_NAMES if c not in ("c3_rk4", "odd_dims", "c3_discret")] +
+                          [c for c in ACT_UNIFORM_NAMES if c.endswith("_c2")] for k in ("valu", "mfma", "mfma_tile")] +
+                         [(n, "valu") for n in ACT_MIXED_NAMES])
 def test_golden_hessian_fp64(name, kernel):
     d, W, b = load_case(name)
     eng = _engine(d, W, b, torch.float64, kernel)
@@ -428,8 +435,9 @@ def test_two_handles_on_two_streams():
     assert not torch.equal(outs[0]["g"], outs[1]["g"])
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma_tile", "valu"])
-@pytest.mark.parametrize("name", ["c2_discret", "c5_box", "tvp_p_discret"])
+@pytest.mark.parametrize("name,kernel", [(n, k) for n in ["c2_discret", "c5_box", "tvp_p_discret"] +
+                                         [c for c in ACT_UNIFORM_NAMES if c.endswith("_c2")]
+                                         for k in ("mfma", "mfma_tile", "valu")] + [("act_mixed_box", "valu")])
 def test_golden_hessian_fp32(name, kernel):
     """fp32 Lagrangian Hessian (cooperative, wave-per-tile and generic kernels) within 1e-4 of the fp64 golden."""
     d, W, b = load_case(name)
@@ -505,3 +513,82 @@ def test_eval_pipeline_keeps_independent_batches_in_flight():
     pipe.synchronize()
     with pytest.raises(ValueError):
         EvalPipeline(make, depth=0)
+
+
+
+@pytest.mark.parametrize("act", ["relu", "sigmoid", "softplus", "elu"])
+def test_activation_family_seeded_against_oracle(act):
+    """One activation on every hidden layer: all three kernel families against the oracle at shapes the goldens do not
+    hold -- the fixed-shape one-launch path (2/1, 2x64, B*H not a multiple of 16, with box rows), RK4 at 6/3 3x128, the
+    RK4 Lagrangian Hessian pipeline, the Gauss-Newton callback -- and against each other."""
+    from pyneuralempc_amd import CallbackEngine
+    rng = np.random.default_rng(12)
+    for nx, nu, hidden, H, kind, DT, box, B in ((2, 1, [64, 64], 20, orc.DISCRET, 1.0, (-2.0, 2.0), 37),
+                                                (6, 3, [128, 128, 128], 5, orc.RK4, 0.1, None, 7),
+                                                (3, 2, [48, 32], 4, orc.RK4, 0.2, None, 5)):
+        net = orc.MLP.random(nx + nu, hidden, nx, seed=3, activations=act)
+        prob = orc.Problem(net, H, nx, nu, kind, DT, box=box)
+        Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=6)
+        lamh, sigh = rng.normal(size=(B, prob.m)), rng.uniform(0.5, 1.5, size=B)
+        wh = rng.uniform(0.2, 1.5, size=(B, H * nx))
+        f, grad, g, jac = prob.eval_batch(Zh, X0h)
+        hv = np.stack([prob.hessian_values(Zh[i], X0h[i], lamh[i], sigh[i]) for i in range(B)])
+        gn = np.stack([prob.gauss_newton_values(Zh[i], X0h[i], wh[i], sigh[i]) for i in range(B)])
+        outs = {}
+        for kernel in ("valu", "mfma", "mfma_tile"):
+            eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=KIND_NAME[kind], DT=DT, dtype=torch.float64,
+                                 device="cuda:0", max_batch=B, kernel=kernel, activations=act)
+            assert eng.kernel_variant == kernel
+            if box is not None:
+                eng.set_box_rows(*box)
+            Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+            res = {k: v.cpu().numpy() for k, v in eng.eval(Z, X0, ("f", "grad", "g", "jac_dense")).items()}
+            if kernel == "mfma" and nx == 2:
+                assert eng.last_row_kernel == "rows_coopfx_kernel"
+            np.testing.assert_allclose(res["f"], f, **F64)
+            np.testing.assert_allclose(res["grad"], grad, **F64)
+            np.testing.assert_allclose(res["g"], g, **F64)
+            np.testing.assert_allclose(res["jac_dense"], jac, **F64)
+            assert np.array_equal(res["jac_dense"] != 0, jac != 0) or act == "relu"    # (a dead relu row is an exact 0)
+            h = eng.hess(Z, X0, eng.to_device(lamh), eng.to_device(sigh))["hvals"].cpu().numpy()
+            np.testing.assert_allclose(h, hv, rtol=1e-10, atol=1e-11)
+            hg = eng.hess_gn(Z, X0, eng.to_device(wh), eng.to_device(sigh))["hvals"].cpu().numpy()
+            np.testing.assert_allclose(hg, gn, rtol=1e-11, atol=1e-12)
+            outs[kernel] = res
+        np.testing.assert_allclose(outs["mfma"]["jac_dense"], outs["valu"]["jac_dense"], **F64)
+
+
+def test_mixed_activations_run_on_the_generic_kernel_and_are_refused_by_the_matrix_core_ones():
+    from pyneuralempc_amd import CallbackEngine, _lib
+    net = orc.MLP.random(3, [32, 32], 2, seed=1, activations=["relu", "tanh", "linear"])
+    eng = CallbackEngine(net.W, net.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=4, activations=net.act)
+    assert eng.kernel_variant == "valu"                     # auto: a per-layer mix has no matrix-core instantiation
+    Zh, X0h = orc.synthetic_inputs(4, 6, 2, 1, seed=2)
+    res = eng.eval_numpy(Zh, X0h)
+    f, grad, g, jac = orc.Problem(net, 6, 2, 1).eval_batch(Zh, X0h)
+    np.testing.assert_allclose(res["jac_dense"], jac, **F64)
+    np.testing.assert_allclose(res["g"], g, **F64)
+    with pytest.raises(_lib.NempcError, match="activations"):
+        CallbackEngine(net.W, net.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", kernel="mfma", activations=net.act)
+    with pytest.raises(NotImplementedError, match="swish"):
+        CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["swish", "tanh", "linear"])
+    with pytest.raises(ValueError, match="one name per dense layer"):
+        CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["tanh", "linear"])
+    # a non-linear OUTPUT layer with one hidden activation is a mix too
+    n2 = orc.MLP.random(3, [32], 2, seed=1, activations=["tanh", "sigmoid"])
+    e2 = CallbackEngine(n2.W, n2.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=4, activations=n2.act)
+    assert e2.kernel_variant == "valu"
+    np.testing.assert_allclose(e2.eval_numpy(Zh, X0h)["jac_dense"], orc.Problem(n2, 6, 2, 1).eval_batch(Zh, X0h)[3], **F64)
+
+
+@pytest.mark.parametrize("act", ["relu", "elu", "sigmoid", "softplus"])
+def test_nan_inputs_stay_visible_for_every_activation(act):
+    from pyneuralempc_amd import CallbackEngine
+    net = orc.MLP.random(3, [64, 64], 2, seed=0, activations=act)
+    for kernel in ("valu", "mfma", "mfma_tile"):
+        eng = CallbackEngine(net.W, net.b, 20, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=4, kernel=kernel,
+                             activations=act)
+        Zh, X0h = orc.synthetic_inputs(4, 20, 2, 1, seed=1)
+        Zh[1, 5] = np.nan
+        res = eng.eval_numpy(Zh, X0h, want=("g", "jac_tiles"))
+        assert np.isnan(res["g"][1]).any() and not np.isnan(res["g"][[0, 2, 3]]).any(), (act, kernel)

@@ -307,3 +307,50 @@ def test_b1_fast_path_and_sparse_view_match_the_engine():
         np.testing.assert_allclose(sv.objective(z), d["f"][i], **F64)
         hr, hc = pb.hessianstructure()
         np.testing.assert_allclose(pb.hessian(z, d["lam"][i], float(d["sigma"][i])), d["hdense"][i][hr, hc], rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind,DT", [("discret", 1.0), ("unity", 1.0), ("rk4", 0.2)])
+def test_torch_model_matches_the_kernel_path(kind, DT):
+    """The same network expressed both ways -- MLPModel (HIP kernels) and model.TorchModel (a torch callable on the
+    device, differentiated by torch.func, through the integrators' host algebra) -- gives the same defects, Jacobian,
+    Hessian rows and, through SLSQP, the same NMPC step."""
+    import pyneuralempc_amd as nEMPC
+    m = dict(np.load(os.path.join(GOLDEN, "misc.npz")))
+    W = [m[f"W{i}"] for i in range(3)]
+    b = [m[f"b{i}"] for i in range(3)]
+    H = 6
+    Wt = [torch.tensor(w, device="cuda:0") for w in W]
+    bt = [torch.tensor(x, device="cuda:0") for x in b]
+
+    def f(x, u, p=None, tvp=None):
+        a = torch.cat([x, u], dim=-1)
+        for w, bb in zip(Wt[:-1], bt[:-1]):
+            a = torch.tanh(a @ w + bb)
+        return a @ Wt[-1] + bt[-1]
+    dev_model = nEMPC.model.MLPModel(W, b, 2, 1, device="cuda:0")
+    mk = {"discret": lambda mod: nEMPC.integrator.DiscretIntegrator(mod, H), "unity": lambda mod: nEMPC.integrator.UnityIntegrator(mod, H),
+          "rk4": lambda mod: nEMPC.integrator.RK4Integrator(mod, H, DT)}[kind]
+    rng = np.random.default_rng(4)
+    x, u, x0 = rng.normal(size=(H, 2)), rng.uniform(-1, 1, size=(H, 1)), rng.uniform(-1, 1, size=2)
+    ref = mk(dev_model)
+    for vector_mode in (True, False):
+        tm = nEMPC.model.TorchModel(f, 2, 1, vector_mode=vector_mode, device="cuda:0")
+        integ = mk(tm)
+        np.testing.assert_allclose(integ.forward(x, u, x0), ref.forward(x, u, x0), rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(integ.jacobian(x, u, x0), ref.jacobian(x, u, x0), rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(integ.hessian(x, u, x0), ref.hessian(x, u, x0), rtol=1e-9, atol=1e-10)
+    if kind == "discret":
+        obj = nEMPC.objective.QuadraticObjective(Q=np.eye(2), R=0.1 * np.eye(1), device="cuda:0")
+        out = {}
+        for name, model in (("kernel", dev_model), ("torch", nEMPC.model.TorchModel(f, 2, 1, vector_mode=False, device="cuda:0"))):
+            dom = nEMPC.constraints.DomainConstraint(states_constraint=[[-5.0, 5.0]] * 2, control_constraint=[[-1.0, 1.0]])
+            mpc = nEMPC.controller.NMPC(nEMPC.integrator.DiscretIntegrator(model, H), obj, [dom], H, 1.0,
+                                        optimizer=nEMPC.optimizer.Slsqp(verbose=0, tolerance=1e-10))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out[name] = mpc.next(m["nmpc_x0"])
+            assert out[name][0] is not None
+        np.testing.assert_allclose(out["torch"][0], out["kernel"][0], atol=1e-6)
+        np.testing.assert_allclose(out["torch"][1], out["kernel"][1], atol=1e-6)
+        with pytest.raises(NotImplementedError, match="next_batch"):
+            mpc.next_batch(np.stack([m["nmpc_x0"]]))

@@ -108,10 +108,10 @@ def test_keras_adapter_validation_without_device():
             self.layers, self.input_shape, self.output_shape = layers, (None, nin), (None, nout)
 
     good = Fake([Layer(np.ones((3, 8)), np.zeros(8), tanh), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2)
-    W, b = extract_dense_stack(good)
-    assert [w.shape for w in W] == [(3, 8), (8, 2)]
+    W, b, acts = extract_dense_stack(good)
+    assert [w.shape for w in W] == [(3, 8), (8, 2)] and acts == ["tanh", "linear"]
     m = KerasTFModel(good, x_dim=2, u_dim=1)
-    assert (m.x_dim, m.u_dim, m.p_dim, m.tvp_dim) == (2, 1, 0, 0)
+    assert (m.x_dim, m.u_dim, m.p_dim, m.tvp_dim) == (2, 1, 0, 0) and m.activations == ["tanh", "linear"]
     m2 = pickle.loads(pickle.dumps(m))
     assert m2._row_engine is None and np.array_equal(m2.weights[0], m.weights[0])
     with pytest.raises(ValueError, match="output dim"):
@@ -120,9 +120,29 @@ def test_keras_adapter_validation_without_device():
         KerasTFModel(good, x_dim=2, u_dim=2)
     with pytest.raises(NotImplementedError):
         KerasTFModel(good, x_dim=2, u_dim=1, standardScaler=object())
-    bad = Fake([Layer(np.ones((3, 8)), np.zeros(8), relu), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2)
-    with pytest.raises(NotImplementedError, match="activation"):
+    # any Keras activation of the device family is taken, per layer, the output layer included (the reference wraps
+    # ANY feed-forward Keras model, model/tensorflow.py:8-29); names also arrive as strings or objects with .name
+    def softplus(x): return x
+
+    class Named:
+        name = "elu"
+    mixed = Fake([Layer(np.ones((3, 8)), np.zeros(8), relu), Layer(np.ones((8, 8)), np.zeros(8), "sigmoid"),
+                  Layer(np.ones((8, 8)), np.zeros(8), Named()), Layer(np.ones((8, 2)), np.zeros(2), softplus)], 3, 2)
+    mm = KerasTFModel(mixed, x_dim=2, u_dim=1)
+    assert mm.activations == ["relu", "sigmoid", "elu", "softplus"]
+    assert pickle.loads(pickle.dumps(mm)).activations == mm.activations
+    none_act = Fake([Layer(np.ones((3, 2)), np.zeros(2), None)], 3, 2)
+    assert KerasTFModel(none_act, x_dim=2, u_dim=1).activations == ["linear"]
+
+    def swish(x): return x
+    bad = Fake([Layer(np.ones((3, 8)), np.zeros(8), swish), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2)
+    with pytest.raises(NotImplementedError, match="activation 'swish'"):
         KerasTFModel(bad, x_dim=2, u_dim=1)
+
+    class Elu2:
+        name, alpha = "elu", 0.5
+    with pytest.raises(NotImplementedError, match="alpha"):
+        KerasTFModel(Fake([Layer(np.ones((3, 2)), np.zeros(2), Elu2())], 3, 2), x_dim=2, u_dim=1)
     rnn = Fake(good.layers, 3, 2)
     rnn.input_shape = (None, 5, 3)
     with pytest.raises(NotImplementedError, match="Recurrent"):
@@ -134,8 +154,12 @@ def test_integrator_rejects_foreign_models():
     from pyneuralempc_amd.model.base import Model
     with pytest.raises(ValueError):
         DiscretIntegrator(object(), 5)
+    # any Model plug-in is taken (host algebra over its forward / jacobian / hessian, as in the reference); the abstract
+    # base itself has no forward, and says so when the integrator calls it
+    integ = DiscretIntegrator(Model(2, 1), 5)
+    assert not integ.on_device
     with pytest.raises(NotImplementedError):
-        DiscretIntegrator(Model(2, 1), 5)
+        integ.forward(np.zeros((5, 2)), np.zeros((5, 1)), np.zeros(2))
 
 
 def test_quadratic_objective_host_side():
@@ -222,3 +246,92 @@ def test_device_optimizer_host_contract():
 
     with pytest.raises(NotImplementedError, match="fused device path"):
         opt.solve(NoFusedPath(), None)
+
+
+@pytest.mark.parametrize("kind,DT", [("discret", 1.0), ("unity", 1.0), ("rk4", 0.2)])
+@pytest.mark.parametrize("vector_mode", [True, False])
+def test_torch_model_through_the_host_integrators_matches_the_oracle(kind, DT, vector_mode):
+    """model.TorchModel (the DiffDiscretJaxModel counterpart: dynamics as a differentiable callable, model/jax.py:32-88)
+    under the three integrators' host algebra and the unfused Ipopt glue -- against the oracle, with the callable being
+    the same tanh network the oracle evaluates analytically.  Runs on the CPU torch device: no kernel is involved."""
+    import torch
+    from oracle import nempc_oracle as orc
+    from pyneuralempc_amd.model import TorchModel
+    from pyneuralempc_amd.integrator import DiscretIntegrator, RK4Integrator, UnityIntegrator
+    from pyneuralempc_amd.objective.autodiff import TorchObjectifFunc
+    from pyneuralempc_amd.optimizer.ipopt import IpoptProblem
+    H, nx, nu = 5, 2, 1
+    net = orc.MLP.random(nx + nu, [12, 9], nx, seed=3)
+    Wt = [torch.tensor(w) for w in net.W]
+    bt = [torch.tensor(b) for b in net.b]
+
+    def f(x, u, p=None, tvp=None):           # whole trajectory (H, .) or one row (.), the same expression
+        a = torch.cat([x, u], dim=-1)
+        for w, b in zip(Wt[:-1], bt[:-1]):
+            a = torch.tanh(a @ w + b)
+        return a @ Wt[-1] + bt[-1]
+    model = TorchModel(f, nx, nu, vector_mode=vector_mode, device="cpu")
+    integ = {"discret": lambda: DiscretIntegrator(model, H), "unity": lambda: UnityIntegrator(model, H),
+             "rk4": lambda: RK4Integrator(model, H, DT)}[kind]()
+    assert not integ.on_device
+    okind = {"discret": orc.DISCRET, "unity": orc.UNITY, "rk4": orc.RK4}[kind]
+    Q, R = np.diag([1.0, 2.0]), np.array([[0.3]])
+    prob = orc.Problem(net, H, nx, nu, okind, DT, Q=Q, R=R)
+    Z, X0 = orc.synthetic_inputs(2, H, nx, nu, seed=5)
+    lam = np.random.default_rng(6).normal(size=H * nx)
+    Qt, Rt = torch.tensor(Q), torch.tensor(R)
+    obj = TorchObjectifFunc(lambda s, c, p, tvp: torch.einsum("ti,ij,tj->", s, Qt, s) + torch.einsum("ti,ij,tj->", c, Rt, c),
+                            device="cpu")
+    for z, x0 in zip(Z, X0):
+        x, u = prob.split(z)
+        np.testing.assert_allclose(integ.forward(x, u, x0), prob.constraints(z, x0), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(integ.jacobian(x, u, x0), prob.jacobian(z, x0), rtol=1e-11, atol=1e-12)
+        Hc = np.tensordot(lam, integ.hessian(x, u, x0), axes=1)
+        np.testing.assert_allclose(Hc, prob.lagrangian_hessian(z, x0, lam, 0.0), rtol=1e-9, atol=1e-11)
+        pb = IpoptProblem(x0, obj, [], integ)
+        assert pb._fused is None                                   # the unfused glue: one plug-in call per callback
+        np.testing.assert_allclose(pb.objective(z), prob.objective(z), rtol=1e-12)
+        np.testing.assert_allclose(pb.gradient(z), prob.gradient(z), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(pb.constraints(z), prob.constraints(z, x0), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(pb.jacobian(z), prob.jacobian(z, x0), rtol=1e-11, atol=1e-12)
+        rows, cols = pb.hessianstructure()
+        np.testing.assert_allclose(pb.hessian(z, lam, 0.7), prob.lagrangian_hessian(z, x0, lam, 0.7)[rows, cols],
+                                   rtol=1e-9, atol=1e-11)
+    # block layouts of the model itself (model/jax.py:52-88)
+    x, u = prob.split(Z[0])
+    fo, Jo, So = net.forward_jac_hess(np.concatenate([x, u], axis=1))
+    np.testing.assert_allclose(model.forward(x, u), fo, rtol=1e-13, atol=1e-14)
+    mj, mh = model.jacobian(x, u), model.hessian(x, u)
+    assert mj.shape == (H * nx, H * (nx + nu)) and mh.shape == (H, nx, H * (nx + nu), H * (nx + nu))
+    for t in range(H):
+        np.testing.assert_allclose(mj[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx], Jo[t][:, :nx], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(mj[t * nx:(t + 1) * nx, H * nx + t * nu:H * nx + (t + 1) * nu], Jo[t][:, nx:], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(mh[t][:, t * nx:(t + 1) * nx, H * nx + t * nu:H * nx + (t + 1) * nu], So[t][:, :nx, nx:],
+                                   rtol=1e-10, atol=1e-12)
+    off = mj.copy()
+    for t in range(H):
+        off[t * nx:(t + 1) * nx, t * nx:(t + 1) * nx] = 0
+        off[t * nx:(t + 1) * nx, H * nx + t * nu:H * nx + (t + 1) * nu] = 0
+    assert np.all(off == 0)
+
+
+def test_torch_model_validation_and_the_jax_names():
+    import torch
+    from pyneuralempc_amd.model import TorchModel
+    from pyneuralempc_amd.model.jax import DiffDiscretJaxModel, DiffDiscretJaxModelRollingWindow
+    from pyneuralempc_amd.integrator import DiscretIntegrator
+    with pytest.raises(ValueError, match="not differentiable"):
+        TorchModel(lambda x, u, p=None, tvp=None: torch.tensor(x.detach().numpy()), 2, 1, device="cpu")
+    with pytest.raises(NotImplementedError, match="TorchModel"):
+        DiffDiscretJaxModel(lambda x, u, p, tvp: x, 2, 1)
+    with pytest.raises(NotImplementedError, match="MLPModelRollingInput"):
+        DiffDiscretJaxModelRollingWindow(lambda x, u, p, tvp: x, 2, 1, rolling_window=2)
+    # parameters reach the callable: p constant, tvp per step
+    m = TorchModel(lambda x, u, p=None, tvp=None: x * p[0] + u * tvp, 1, 1, p_dim=1, tvp_dim=1, device="cpu")
+    x, u = np.array([[1.0], [2.0]]), np.array([[0.5], [0.25]])
+    np.testing.assert_allclose(m.forward(x, u, p=np.array([3.0]), tvp=np.array([[2.0], [4.0]])), [[4.0], [7.0]])
+    np.testing.assert_allclose(m.jacobian(x, u, p=np.array([3.0]), tvp=np.array([[2.0], [4.0]])),
+                               [[3.0, 0.0, 2.0, 0.0], [0.0, 3.0, 0.0, 4.0]])
+    integ = DiscretIntegrator(m, 2)
+    with pytest.raises(NotImplementedError, match="dense-network model"):
+        integ.engine(4)

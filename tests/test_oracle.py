@@ -5,12 +5,12 @@ import pytest
 import torch
 
 from oracle import nempc_oracle as orc
-from helpers import CASE_NAMES, ROLLING_NAMES, load_case, oracle_problem
+from helpers import ACT_MIXED_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, ROLLING_NAMES, load_case, oracle_problem
 
 TOL = dict(rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("name", CASE_NAMES)
+@pytest.mark.parametrize("name", CASE_NAMES + ACT_UNIFORM_NAMES + ACT_MIXED_NAMES)
 def test_oracle_matches_reference_golden(name):
     d, W, b = load_case(name)
     prob = oracle_problem(d, W, b)
@@ -32,7 +32,8 @@ def test_oracle_matches_reference_golden(name):
     assert np.array_equal(prob.jacobian(d["Z"][0], d["X0"][0]) != 0, d["jac"][0] != 0)
 
 
-@pytest.mark.parametrize("name", [n for n in CASE_NAMES if n not in ("c3_rk4", "c3_discret", "odd_dims")])
+@pytest.mark.parametrize("name", [n for n in CASE_NAMES if n not in ("c3_rk4", "c3_discret", "odd_dims")] +
+                         [n for n in ACT_UNIFORM_NAMES if n.endswith("_c2")] + ACT_MIXED_NAMES)
 def test_oracle_hessian_matches_reference_golden(name):
     d, W, b = load_case(name)
     prob = oracle_problem(d, W, b)
@@ -111,16 +112,57 @@ def test_bounds_and_warm_start_against_reference():
 
 
 # ---- the network derivative: independent AD (torch.func, fp64) ----
-def _torch_net(W, b):
+_TORCH_ACT = {"linear": lambda z: z, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid,
+              "softplus": torch.nn.functional.softplus, "elu": torch.nn.functional.elu}
+
+
+def _torch_net(W, b, act=None):
     Wt = [torch.tensor(w, dtype=torch.float64) for w in W]
     bt = [torch.tensor(x, dtype=torch.float64) for x in b]
+    act = ["tanh"] * (len(W) - 1) + ["linear"] if act is None else act
 
     def f(xi):
         a = xi
-        for w, bb in zip(Wt[:-1], bt[:-1]):
-            a = torch.tanh(a @ w + bb)
-        return a @ Wt[-1] + bt[-1]
+        for w, bb, name in zip(Wt, bt, act):
+            a = _TORCH_ACT[name](a @ w + bb)
+        return a
     return f
+
+
+@pytest.mark.parametrize("acts", ["relu", "sigmoid", "softplus", "elu", ["relu", "softplus", "sigmoid"],
+                                  ["elu", "sigmoid", "tanh"], ["linear", "tanh", "softplus"], ["sigmoid", "elu", "elu"]])
+def test_activation_family_derivatives_vs_torch_ad(acts):
+    """Every activation of the device family, uniform on the hidden layers and mixed per layer with a non-linear output
+    layer: the oracle's first and second derivatives -- written from the layer OUTPUT a = s(z), as the kernels do -- against
+    torch's own activations under torch.func autodiff (fp64).  This is the guard the fixtures of these activations rest
+    on (make_golden.check_network_derivatives_by_ad runs the same comparison while they are made)."""
+    nin, hidden, nout = 5, [24, 17], 3
+    net = orc.MLP.random(nin, hidden, nout, seed=4, activations=acts)
+    xi = np.random.default_rng(5).normal(size=(6, nin)) * 1.5
+    f, J, S = net.forward_jac_hess(xi)
+    f2, J2 = net.forward_jac(xi)
+    np.testing.assert_allclose(f, f2, rtol=1e-13, atol=1e-14)
+    np.testing.assert_allclose(J, J2, rtol=1e-12, atol=1e-13)
+    tf = _torch_net(net.W, net.b, net.act)
+    for r in range(xi.shape[0]):
+        x = torch.tensor(xi[r], dtype=torch.float64)
+        np.testing.assert_allclose(tf(x).numpy(), f[r], rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(torch.func.jacrev(tf)(x).numpy(), J[r], rtol=1e-11, atol=1e-13)
+        np.testing.assert_allclose(torch.func.hessian(tf)(x).numpy(), S[r], rtol=1e-10, atol=1e-12)
+
+
+def test_activation_functions_at_their_edges():
+    """Values the formulas must survive: large |z| (no overflow / NaN), the kinks, NaN propagation."""
+    z = np.array([-800.0, -40.0, -1e-300, 0.0, 1e-300, 40.0, 800.0])
+    for name in orc.ACTIVATIONS:
+        a = orc.act_f(name, z)
+        assert np.all(np.isfinite(a)), name
+        assert np.all(np.isfinite(orc.act_d1(name, a))) and np.all(np.isfinite(orc.act_r2(name, a))), name
+        assert np.isnan(orc.act_f(name, np.array([np.nan]))[0]), name
+    assert orc.act_d1("relu", orc.act_f("relu", np.array([0.0])))[0] == 0.0          # TensorFlow's convention at the kink
+    assert orc.act_d1("elu", orc.act_f("elu", np.array([0.0])))[0] == 1.0
+    np.testing.assert_allclose(orc.act_d1("softplus", orc.act_f("softplus", z)), 1.0 / (1.0 + np.exp(-np.clip(z, -700, 700))),
+                               rtol=1e-12, atol=1e-300)
 
 
 @pytest.mark.parametrize("dims", [(3, [64, 64], 2), (9, [128, 128, 128], 6), (5, [48, 32], 3), (3, [16], 2)])
@@ -183,7 +225,9 @@ def test_jacobian_and_gradient_vs_finite_differences():
     assert np.abs(gr - gfd).max() < 1e-7
 
 
-@pytest.mark.parametrize("name", ["c2_discret", "c2_unity", "c3_rk4", "c5_box", "odd_dims", "h1"])
+@pytest.mark.parametrize("name", ["c2_discret", "c2_unity", "c3_rk4", "c5_box", "odd_dims", "h1", "act_relu_c2",
+                                  "act_sigmoid_c3", "act_softplus_c2", "act_elu_c3", "act_mixed_box", "act_mixed_rk4",
+                                  "act_linear_hidden"])
 def test_c_oracle_matches_numpy_oracle(name):
     from oracle.c_oracle import COracle
     d, W, b = load_case(name)
