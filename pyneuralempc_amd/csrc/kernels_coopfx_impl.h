@@ -16,6 +16,14 @@
 #include "kernels_coop_impl.h"
 #include "kernels_obj_impl.h"
 
+// A/B switches of the fused dense output (tools/build_variant.py -D...)
+#ifndef NEMPC_FX_ZERO_EARLY
+#define NEMPC_FX_ZERO_EARLY 0      // 1: background zeros before the pass's first barrier instead of behind layer 0
+#endif
+#ifndef NEMPC_FX_NZ_PLAIN
+#define NEMPC_FX_NZ_PLAIN 0        // 1: the non-zero entries as plain stores (dirty in L2 until the end-of-kernel write-back)
+#endif
+
 // diagnostic builds only (tools/diag_stamps.py): the per-workgroup timeline has 13 event slots; -DNEMPC_STAMPS_PRO spends
 // them on the prologue instead of the pass
 #ifdef NEMPC_STAMPS_PRO
@@ -46,8 +54,6 @@ struct FxLayout {   // element offsets inside dynamic LDS, all compile-time
     // exchange buffer: two halves of TPW activation sets (one cotangent per sweep)
     static constexpr int XH = TPW * MT * 256;
     static constexpr int X = (SMALL_END + 15) & ~15;
-    // fused evaluation, epilogue: the exchange area is reused as the buffer the dense rows are assembled in
-    static constexpr int RB_CAP = 2 * XH;
     // K-split partials, one value per (wave, tile, quantity, row): network outputs PF[w][j][k][16], Jacobian rows
     // PJ[k][w][j][d][16] (value-major inside a wave's block: fx_rowsums_store writes four values per store)
     static constexpr int PART = X + 2 * XH;
@@ -84,8 +90,6 @@ struct FxArgs {   // host-prepared; the fields the first loads need come first
     const void* P;          // objective table (Handle::d_obj), copied to LDS behind the layout
     int p_elems;
     int zp_max;             // problems whose variables fit the LDS copy (FX_ZCOPY / n; 0 when the table itself is too long)
-    int rb_rows;            // dense rows per chunk of the LDS row buffer (FxLayout::RB_CAP / n, at least 1)
-    unsigned inv_nvec;      // ceil(2^32 / (n / VEC)): flat vector index -> row by multiply-high
     long long* dbg;         // diagnostic builds only
     ObjOffsets oo;
 };
@@ -95,7 +99,7 @@ struct FxArgs {   // host-prepared; the fields the first loads need come first
 // into vector lanes: a cold round trip (0.3-0.5 us) in front of the very first vector load.  What the prologue needs
 // travels in the preloaded leading arguments; the rest -- output pointers, m, box, ... -- is only used by a pass's
 // epilogue and is read THERE through the kernarg segment pointer (the empty asm pins the earliest point).
-constexpr int FX_ARGS_KERNARG_OFFSET = 56;      // five pointers and four dwords precede the FxArgs argument
+constexpr int FX_ARGS_KERNARG_OFFSET = 64;      // five pointers, four dwords and the dense-matrix pointer precede the FxArgs argument
 typedef const FxArgs __attribute__((address_space(4)))* FxArgsK;
 __device__ __forceinline__ FxArgsK fx_late_args() {
     const char __attribute__((address_space(4)))* kp =
@@ -113,6 +117,8 @@ struct FxCtx {
     unsigned R, invH;
     int H, n;
     bool rev;               // reverse sweeps wanted (tiles or dense rows asked for); false: defects [+ objective] only
+    T* jac;                 // fused evaluation: the dense Jacobian (null: not asked for)
+    bool box;               // box rows follow each problem's defect rows
     long long* dbg;         // diagnostic builds only (-DNEMPC_STAMPS, tools/diag_stamps.py): per-workgroup timeline
 };
 
@@ -238,6 +244,76 @@ __device__ __forceinline__ void fx_rowsums_store(const T (&s)[NV], T* dst, int l
     }
 }
 
+// Write-through stores (sc0 sc1): the data leaves for memory as it is issued instead of sitting dirty in L2 until the
+// end-of-kernel write-back (C2, B=1024: whole evaluation 21.9 -> 20.3 us when the dense rows were first fused in).
+#if NEMPC_FX_NZ_PLAIN
+#define NEMPC_FX_WT ""
+#else
+#define NEMPC_FX_WT " sc0 sc1"
+#endif
+__device__ __forceinline__ void fx_store_wt(double* p, double v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" NEMPC_FX_WT ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void fx_store_wt(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off" NEMPC_FX_WT ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void fx_store_wt2(double* p, double v0, double v1) {      // p 16-byte aligned
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 v = {v0, v1};
+    asm volatile("global_store_dwordx4 %0, %1, off" NEMPC_FX_WT ::"v"(p), "v"(v) : "memory");
+}
+
+// Fused evaluation, dense Jacobian (integrator/discret.py:38-56, unity.py:38-56; ipopt.py:88-96), part one: the
+// BACKGROUND.  Of a dense row's n entries all but 1 + NX + NU are structural zeros -- 98 % of the matrix at C2, 97 % at
+// C5 -- and WHICH entries are zero does not depend on the iterate.  So the zeros of a pass's rows are streamed at the
+// START of the pass, from registers, as one flat run of 16-byte write-through stores per contiguous block: they cost a
+// store instruction each (no LDS, no address arithmetic beyond an add), need nothing the pass computes, and reach HBM
+// while the matrix pipe works -- the memory system is idle then.  Part two (the pass's epilogue) overwrites the few
+// non-zeros once every zero store of the workgroup has been acknowledged (vmcnt(0) on every wave, then the barrier):
+// same-address writes from one workgroup go through one L2 channel in the order they were issued, and the earlier one
+// has arrived.  Before, the rows were assembled in LDS after the sweeps and copied out from there: the whole 20 MB
+// (246 MB at C5) left in the launch's tail, the last workgroup's copy-out exposed (2.3 us of a 17 us launch), with a
+// zero-fill, a row buffer, two barriers per chunk and ~400 vector instructions per wave on the pipe the matrix
+// instructions need.
+//   no box rows: m = H*NX, dense row (r, i) is row r*NX + i of ONE (R*NX, n) matrix -- the pass's rows are one block.
+//   box rows:    per problem a defect block and a box block (+1 selectors, written in part two as well); the run is
+//                cut where the problem changes (scalar arithmetic, at most a few pieces).
+template <typename T, int NX, int NTHREADS>
+__device__ __forceinline__ void fx_zero_rows(T* o_jac, unsigned r0, int nrows, int n, int H, unsigned invH, bool box, int tid) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    const vecT zero = {};
+    const int nvec = n / VEC;
+#if defined(NEMPC_EXP_NODENSE) || defined(NEMPC_EXP_NOZERO)      // timing experiments only
+    const int drv = 0;
+#else
+    const int drv = nrows * NX;                     // dense rows of the pass that exist
+#endif
+    if (!box) {
+        const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) + (size_t)r0 * NX * (size_t)n * sizeof(T));
+        const int nv = drv * nvec;
+        for (int fv = tid; fv < nv; fv += NTHREADS)
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(zero), "s"(base) : "memory");
+    } else {
+        const int HNX = H * NX;
+        for (int s0 = 0; s0 < drv;) {
+            const unsigned r = r0 + (unsigned)(s0 / NX);
+            const unsigned b = invH ? __umulhi(r, invH) : r;
+            const int k = (int)(r - b * (unsigned)H) * NX;              // first dense row of the piece within its block
+            const int len = drv - s0 < HNX - k ? drv - s0 : HNX - k;    // rows up to the end of the problem / pass
+            const int nv = len * nvec;
+#pragma unroll
+            for (int kind = 0; kind < 2; ++kind) {
+                const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) +
+                                                  ((size_t)b * (2 * HNX) + (size_t)(kind * HNX + k)) * (size_t)n * sizeof(T));
+                for (int fv = tid; fv < nv; fv += NTHREADS)
+                    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(zero), "s"(base) : "memory");
+            }
+            s0 += len;
+        }
+    }
+}
+
 // `nxt` / `in_next` (when has_next): the NEXT pass's inputs, already in registers; they go to the other input buffer
 // BEFORE this pass's global stores are issued -- vmcnt counts stores too and retires in order, so a wait for those loads
 // placed after the stores would sit out the stores' acknowledgement (with the dense rows fused in: the whole HBM time).
@@ -280,6 +356,17 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             for (int r = 0; r < 4; ++r) a[0][j][r] = A::f(a[0][j][r]);
     }
     FX_STAMP_PRO(cx.dbg, 10);
+#if !NEMPC_FX_ZERO_EARLY
+    if constexpr (FUSE) {
+        // background zeros of this pass's dense rows (fx_zero_rows): issued here, behind layer 0 -- the first thing a
+        // pass computes needs no store slot, and in the first pass the prologue's loads are ahead of them in the queue
+        if (cx.jac) {
+            const unsigned r0 = (unsigned)t0 * 16u;
+            const int nrows = r0 + (unsigned)NT * 16u <= cx.R ? NT * 16 : (int)(cx.R - r0);
+            fx_zero_rows<T, NX, NTHREADS>(cx.jac, r0, nrows, cx.n, cx.H, cx.invH, cx.box, tid);
+        }
+    }
+#endif
     // ---- hidden-to-hidden layers through the double-buffered exchange area (see kernels_coop_impl.h)
 #pragma unroll
     for (int l = 1; l < NH; ++l) {
@@ -400,6 +487,11 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
     T* const o_tiles = static_cast<T*>(ka->tiles);
     T* const o_g = static_cast<T*>(ka->g);
     const int a_ident = ka->ident, a_box = ka->box, a_m = ka->m;
+    if constexpr (FUSE) {
+        // (the background zeros of this pass's dense rows: every wave waits for its own stores' acknowledgements, the
+        // barrier then covers the workgroup; they were issued a whole pass ago)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     lds_barrier();
     if (has_next) fx_stage_store<T, WP, NH, TPW, NX, NU, TPW>(in_next, tid, nxt);
     FX_STAMP_PASS(cx.dbg, 7);
@@ -449,157 +541,56 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
     }
     FX_STAMP_PASS(cx.dbg, 8);
     if constexpr (FUSE) {
-        // ---- dense Jacobian rows of the pass (integrator/discret.py:38-56, unity.py:38-56; ipopt.py:88-96): row (t, i)
-        //      of problem b holds -1 at x_t[i], the tile's state block at x_{t-1} (t >= 1), its control block at u_t,
-        //      zeros elsewhere; box rows (+1 selectors) follow the defect rows of each problem.
-        //      Every vector instruction costs the matrix pipe four cycles (tools/ubench_dpops.hip), so the rows are NOT
-        //      computed per output vector (classify the column, compare with the row's step, select: ~66 vector
-        //      instructions per store, 1.3 M per launch = 2.3 us at B=1024).  They are assembled in LDS -- the idle
-        //      exchange area, zero-filled, then the 4 non-zeros per row dropped in by one lane per row, which sums them
-        //      from the K-split partials on the spot -- and streamed out as a flat copy: one ds_read_b128 and one
-        //      1 KB-per-wave store per vector, addressing on the scalar unit.
-        constexpr int VEC = 16 / (int)sizeof(T);
-        typedef T vecT __attribute__((ext_vector_type(VEC)));
-        constexpr int DR = NT * 16 * NX;                                 // dense rows of a full pass
+        // ---- dense Jacobian rows of the pass, part two: the non-zeros over the background streamed at the start of the
+        //      pass (fx_zero_rows; every zero store of the workgroup was acknowledged before the barrier above).  Row
+        //      (t, i) of problem b holds -1 at x_t[i], the tile's state block at x_{t-1} (t >= 1), its control block at
+        //      u_t; box rows (+1 selectors) follow the defect rows of each problem.  One lane per dense row sums the row's
+        //      tile entries from the K-split partials in wave order (the unfused kernel's loop above) and stores them.
         T* const o_jac = static_cast<T*>(ka->jac);
-        const int a_rb_rows = ka->rb_rows;
-        T* const RB = lds + L::X;
-        vecT* const RBv = reinterpret_cast<vecT*>(RB);
-        const int n = cx.n, nvec = n / VEC;
-        const unsigned r0 = (unsigned)t0 * 16u;
-        const int drv = r0 + NT * 16u <= cx.R ? DR : (int)(cx.R - r0) * NX;     // rows of the pass that exist
-        const int rpc = drv < a_rb_rows ? drv : a_rb_rows;            // rows per chunk of the LDS row buffer
-        const vecT zero = {};
-#ifdef NEMPC_EXP_NODENSE      // timing experiment only
-        const int nkind = 0;
+        constexpr int DR = NT * 16 * NX;                                 // dense rows of a full pass
+#if defined(NEMPC_EXP_NODENSE) || defined(NEMPC_EXP_NONZ)      // timing experiments only
+        const bool dense = false;
 #else
-        const int nkind = o_jac ? (a_box ? 2 : 1) : 0;       // fused objective without the dense matrix: nothing to assemble
+        const bool dense = o_jac != nullptr;
 #endif
-        // each wave owns a fixed run of the buffer's row slots: it zeroes them once per pass, and from the second chunk on
-        // only takes back the few entries the previous chunk's row left in a slot before one lane per row drops the new
-        // row's non-zeros in (the LDS executes one wave's operations in order, so no barrier in between; zero-filling the
-        // buffer per chunk was a fifth of the dense phase's instructions at 150 columns with box rows)
-        const int rpw = (rpc + MT - 1) / MT;
-        const int lo = w * rpw;
-        int pc0 = -1, pnr = 0, pkind = 0;
-        for (int kind = 0; kind < nkind; ++kind) {
-            for (int c0 = 0; c0 < drv; c0 += rpc) {
-                const int nr = drv - c0 < rpc ? drv - c0 : rpc;
-                if (kind + c0 > 0) lds_barrier();      // the previous chunk has left the buffer
-                const int hi = lo + rpw < nr ? lo + rpw : nr;
-                if (pc0 < 0) {
-                    const int zhi = lo + rpw < rpc ? lo + rpw : rpc;
-                    for (int v = lo * nvec + lane; v < zhi * nvec; v += 64) RBv[v] = zero;
-                } else if (lo + lane < (lo + rpw < pnr ? lo + rpw : pnr)) {
-                    const int lr = pc0 + lo + lane;
-                    const int lrow = lr / NX, i = lr - lrow * NX;
-                    const unsigned r = r0 + (unsigned)lrow;
+        if (dense) {
+            const int n = cx.n;
+            const unsigned r0 = (unsigned)t0 * 16u;
+#pragma unroll
+            for (int it = 0; it < (DR + NTHREADS - 1) / NTHREADS; ++it) {
+                const int lr = tid + it * NTHREADS;
+                const int lrow = lr / NX, i = lr - lrow * NX;           // compile-time divisor
+                const unsigned r = r0 + (unsigned)lrow;
+                if (lr < DR && r < cx.R) {
                     const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
                     const int t = (int)(r - b * (unsigned)cx.H);
-                    T* row = RB + (lo + lane) * n;
-                    row[t * NX + i] = T(0);
-                    if (pkind == 0) {
-                        if (t >= 1) {
+                    const int j = lrow >> 4, cc = lrow & 15;
+                    T ts[NIN];
 #pragma unroll
-                            for (int jj = 0; jj < NX; ++jj) row[(t - 1) * NX + jj] = T(0);
-                        }
+                    for (int d = 0; d < NIN; ++d) {
+                        T v = T(0);
 #pragma unroll
-                        for (int jj = 0; jj < NU; ++jj) row[cx.H * NX + t * NU + jj] = T(0);
+                        for (int ww = 0; ww < MT; ++ww) v += PJ[((i * MT + ww) * (TPW * NIN) + j * NIN + d) * 16 + cc];
+                        if (a_ident && d == i) v += T(1);
+                        ts[d] = v;
                     }
-                }
-                pc0 = c0; pnr = nr; pkind = kind;
-                asm volatile("" ::: "memory");
-                if (lo + lane < hi) {
-                    const int lr = c0 + lo + lane;
-                    const int lrow = lr / NX, i = lr - lrow * NX;
-                    const unsigned r = r0 + (unsigned)lrow;
-                    const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
-                    const int t = (int)(r - b * (unsigned)cx.H);
-                    T* row = RB + (lo + lane) * n;
-                    if (kind == 0) {
-                        // the row's tile entries: K-split partials summed in wave order (the unfused kernel's loop above)
-                        const int j = lrow >> 4, cc = lrow & 15;
-                        T ts[NIN];
+                    if (o_tiles) {
 #pragma unroll
-                        for (int d = 0; d < NIN; ++d) {
-                            T v = T(0);
-#pragma unroll
-                            for (int ww = 0; ww < MT; ++ww) v += PJ[((i * MT + ww) * (TPW * NIN) + j * NIN + d) * 16 + cc];
-                            if (a_ident && d == i) v += T(1);
-                            ts[d] = v;
-                        }
-                        if (o_tiles) {
-#pragma unroll
-                            for (int d = 0; d < NIN; ++d) o_tiles[(size_t)r * JROW + i * NIN + d] = ts[d];
-                        }
-                        if (t >= 1) {
-#pragma unroll
-                            for (int jj = 0; jj < NX; ++jj) row[(t - 1) * NX + jj] = ts[jj];
-                        }
-                        row[t * NX + i] = T(-1);
-#pragma unroll
-                        for (int jj = 0; jj < NU; ++jj) row[cx.H * NX + t * NU + jj] = ts[NX + jj];
-                    } else {
-                        row[t * NX + i] = T(1);
+                        for (int d = 0; d < NIN; ++d) o_tiles[(size_t)r * JROW + i * NIN + d] = ts[d];
                     }
-                }
-                FX_STAMP_PASS(cx.dbg, 9);
-                lds_barrier();
-                FX_STAMP_PASS(cx.dbg, 10);
-                const int nvc = nr * nvec;
-                // write-through stores (sc0 sc1): the rows go out to memory as they are issued instead of sitting dirty
-                // in L2 until the end-of-kernel write-back (C2, B=1024: whole evaluation 21.9 -> 20.3 us)
-                if (!a_box) {
-                    // without box rows m = H*NX: dense row (r, i) is row r*NX + i of one (R*NX, n) matrix, the chunk is
-                    // one contiguous block of memory
-                    const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) +
-                                                      ((size_t)r0 * NX + (size_t)c0) * (size_t)n * sizeof(T));
-                    // reads of a batch are all in flight before the first store waits for its data
-                    constexpr int UB = 4;
-                    for (int f0 = tid; f0 < nvc; f0 += UB * NTHREADS) {
-                        vecT v[UB];
+                    T* const row = o_jac + ((size_t)b * a_m + (size_t)(t * NX + i)) * (size_t)n;
+                    if (t >= 1) {
+                        if constexpr (NX == 2 && sizeof(T) == 8) {
+                            fx_store_wt2(row + (t - 1) * NX, ts[0], ts[1]);      // n even: the block is 16-byte aligned
+                        } else {
 #pragma unroll
-                        for (int u = 0; u < UB; ++u) {
-                            const int fv = f0 + u * NTHREADS;
-                            if (fv < nvc) v[u] = RBv[fv];
-                        }
-#pragma unroll
-                        for (int u = 0; u < UB; ++u) {
-                            const int fv = f0 + u * NTHREADS;
-                            if (fv < nvc) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(v[u]), "s"(base));
+                            for (int jj = 0; jj < NX; ++jj) fx_store_wt(row + (t - 1) * NX + jj, ts[jj]);
                         }
                     }
-                } else {
-                    // with box rows a problem's defect rows and its box rows are two separate contiguous blocks: the chunk is
-                    // cut where the problem changes (scalar arithmetic, at most a few pieces) and every piece is a flat copy
-                    // like the one above -- no per-vector address arithmetic
-                    const int HNXr = cx.H * NX;
-                    for (int s0 = 0; s0 < nr;) {
-                        const int lr = c0 + s0;                                  // first dense row of the piece
-                        const unsigned r = r0 + (unsigned)(lr / NX);
-                        const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
-                        const int k = (int)(r - b * (unsigned)cx.H) * NX + (lr - (lr / NX) * NX);   // its row within the block
-                        const int len = nr - s0 < HNXr - k ? nr - s0 : HNXr - k;  // rows up to the end of the problem / chunk
-                        const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) +
-                                                          ((size_t)b * a_m + (kind ? HNXr : 0) + k) * (size_t)n * sizeof(T));
-                        const vecT* src = RBv + s0 * nvec;
-                        const int nv = len * nvec;
-                        constexpr int UB = 4;
-                        for (int f0 = tid; f0 < nv; f0 += UB * NTHREADS) {
-                            vecT v[UB];
+                    fx_store_wt(row + t * NX + i, T(-1));
 #pragma unroll
-                            for (int u = 0; u < UB; ++u) {
-                                const int fv = f0 + u * NTHREADS;
-                                if (fv < nv) v[u] = src[fv];
-                            }
-#pragma unroll
-                            for (int u = 0; u < UB; ++u) {
-                                const int fv = f0 + u * NTHREADS;
-                                if (fv < nv) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(v[u]), "s"(base));
-                            }
-                        }
-                        s0 += len;
-                    }
+                    for (int jj = 0; jj < NU; ++jj) fx_store_wt(row + cx.H * NX + t * NU + jj, ts[NX + jj]);
+                    if (a_box) fx_store_wt(row + (size_t)cx.H * NX * (size_t)n + t * NX + i, T(1));
                 }
             }
         }
@@ -616,7 +607,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     // in scalar registers when the wave starts instead of behind a scalar-load round trip (the struct carries the rest;
     // n and the objective table's offsets follow from H and the compiled shape)
     const void* pZ, const void* pX0, const void* psmall, const void* pwslice, const void* pP, unsigned ppack, unsigned pR,
-    unsigned pinvH, int pH, FxArgs a) {
+    unsigned pinvH, int pH, void* pjac, FxArgs a) {
     // `a` itself is never read here (see fx_late_args); a local block holds what the preloaded arguments say
     struct {
         const void *Z, *X0, *small, *wslice, *P;
@@ -634,6 +625,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     const bool want_obj = ((ppack >> 28) & 3u) != 0;     // f or grad asked for
 #endif
     const bool want_rev = (ppack >> 30) & 1u;            // tiles or dense rows asked for
+    const bool has_box = (ppack >> 31) & 1u;             // box rows follow the defect rows (m = 2 H NX)
     pa.R = pR; pa.invH = pinvH; pa.H = pH; pa.n = pH * (NX + NU);
     pa.oo = obj_offsets(pH, NX, NU);
     pa.p_elems = FUSE ? pa.oo.total : 0;
@@ -665,6 +657,8 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     cx.Z = static_cast<const T*>(pa.Z);
     cx.X0 = static_cast<const T*>(pa.X0);
     cx.R = pa.R; cx.invH = pa.invH; cx.H = pa.H; cx.n = pa.n; cx.rev = want_rev;
+    cx.jac = FUSE ? static_cast<T*>(pjac) : nullptr;
+    cx.box = has_box;
 
     const int t_begin = blockIdx.x * pa.tiles_per_wg + ((int)blockIdx.x < pa.tiles_rem ? (int)blockIdx.x : pa.tiles_rem);
     const int t_end = t_begin + pa.tiles_per_wg + ((int)blockIdx.x < pa.tiles_rem ? 1 : 0);
@@ -687,30 +681,49 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         }
     }
     FX_STAMP_PRO(pa.dbg, 2);
-    // fused evaluation: the objective of this workgroup's problems (those whose first row lies in its tile range).  Their
-    // variables -- one contiguous piece of Z -- are fetched in the prologue and parked in LDS next to the
-    // objective's table; the first pass evaluates them from there, one problem per wave.  Evaluated from global memory it
-    // cost a round trip of its own wherever it stood (at the end of the kernel 1.3 us; in the prologue, 19 loads per lane
-    // ahead of the weight slices in the in-order return queue, about the same).  Everything these loads need is
-    // among the preloaded arguments, so they go out without waiting for the argument block.
-    unsigned ob_lo = 0, ob_hi = 0;
-    int ob_n = 0;                       // problems whose variables fit the LDS copy
+    // fused evaluation: the objective.  A problem belongs to the workgroup whose tile range holds its first row.  WHO
+    // evaluates it: the two workgroups of a CU do not interleave -- the one dispatched first (the first half of the grid)
+    // runs its passes at nearly full speed and is done ~1.5 us before the other, which fills gaps and finishes last
+    // (tools/diag_stamps.py).  The objective is a serial chain on a single wave per problem (0.3 us); in the workgroup
+    // that finishes last it is on the launch's critical path wherever it stands (at its start it delayed the whole
+    // pass: 1.3 us of a 16.4 us launch, measured by leaving it out).  So the first-half workgroups, which have the slack,
+    // evaluate at their END the problems of BOTH members of a pair (i, i + ceil(grid / 2)); the second half evaluates
+    // none.  Both ranges' variables -- two contiguous pieces of Z -- are fetched in the prologue and parked in LDS next
+    // to the objective's table (evaluated from global memory it cost a round trip of its own wherever it stood).
+    // Everything these loads need is among the preloaded arguments, so they go out without waiting for the argument block.
+    // (the ranges are recomputed where they are used, at the end of the kernel: kept live across the passes they cost
+    // scalar registers the pass code then spills)
+    auto obj_range = [&](int side, unsigned& lo, unsigned& hi, int& nlds) {
+        const unsigned half_lo = gridDim.x / 2u, half_hi = gridDim.x - half_lo;
+        const unsigned Hh = (unsigned)pa.H;
+        const unsigned wg = side == 0 ? blockIdx.x : blockIdx.x + half_hi;       // the partner's index
+        const bool have = blockIdx.x < half_hi && (side == 0 || blockIdx.x < half_lo);
+        const unsigned tb = wg * (unsigned)pa.tiles_per_wg + (wg < (unsigned)pa.tiles_rem ? wg : (unsigned)pa.tiles_rem);
+        const unsigned te = tb + (unsigned)pa.tiles_per_wg + (wg < (unsigned)pa.tiles_rem ? 1u : 0u);
+        unsigned r_lo = tb * 16u, r_hi = te * 16u;
+        if (r_lo > pa.R) r_lo = pa.R;
+        if (r_hi > pa.R) r_hi = pa.R;
+        lo = pa.invH ? __umulhi(r_lo + Hh - 1, pa.invH) : r_lo;
+        hi = have ? (pa.invH ? __umulhi(r_hi + Hh - 1, pa.invH) : r_hi) : lo;       // problems lo .. hi - 1
+        nlds = (int)(hi - lo) < pa.zp_max ? (int)(hi - lo) : pa.zp_max;             // ... whose variables fit the LDS copy
+    };
     constexpr int ZV_PER_THREAD = 2;
-    T zv[ZV_PER_THREAD];
+    T zv[2][ZV_PER_THREAD];
+    int zcount[2] = {0, 0};             // elements of Z parked per side
     if constexpr (FUSE) {
         if (want_obj) {
-            const unsigned r_lo = (unsigned)t_begin * 16u;
-            unsigned r_hi = (unsigned)t_end * 16u;
-            if (r_hi > pa.R) r_hi = pa.R;
-            const unsigned Hh = (unsigned)pa.H;
-            ob_lo = pa.invH ? __umulhi(r_lo + Hh - 1, pa.invH) : r_lo;
-            ob_hi = pa.invH ? __umulhi(r_hi + Hh - 1, pa.invH) : r_hi;      // problems ob_lo .. ob_hi - 1
-            ob_n = (int)(ob_hi - ob_lo) < pa.zp_max ? (int)(ob_hi - ob_lo) : pa.zp_max;
-            const T* __restrict__ zsrc = cx.Z + (size_t)ob_lo * pa.n;
 #pragma unroll
-            for (int u = 0; u < ZV_PER_THREAD; ++u) {
-                const int idx = tid + u * NTHREADS;
-                zv[u] = idx < ob_n * pa.n ? zsrc[idx] : T(0);
+            for (int side = 0; side < 2; ++side) {
+                unsigned lo, hi;
+                int nl;
+                obj_range(side, lo, hi, nl);
+                zcount[side] = nl * pa.n;
+                const T* __restrict__ zsrc = cx.Z + (size_t)lo * pa.n;
+#pragma unroll
+                for (int u = 0; u < ZV_PER_THREAD; ++u) {
+                    const int idx = tid + u * NTHREADS;
+                    zv[side][u] = idx < zcount[side] ? zsrc[idx] : T(0);
+                }
             }
         }
     }
@@ -757,10 +770,12 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     const int p_pad = (pa.p_elems + 15) & ~15;
     if constexpr (FUSE) {
 #pragma unroll
-        for (int u = 0; u < ZV_PER_THREAD; ++u) {
-            const int idx = tid + u * NTHREADS;
-            if (idx < ob_n * pa.n) lds[L::TOTAL + p_pad + idx] = zv[u];
-        }
+        for (int side = 0; side < 2; ++side)
+#pragma unroll
+            for (int u = 0; u < ZV_PER_THREAD; ++u) {
+                const int idx = tid + u * NTHREADS;
+                if (idx < zcount[side]) lds[L::TOTAL + p_pad + side * FX_ZCOPY + idx] = zv[side][u];
+            }
     }
     FX_STAMP_PASS(pa.dbg, 2);
     FX_STAMP_PRO(pa.dbg, 6);
@@ -781,11 +796,6 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     }
 
     FX_STAMP_PASS(pa.dbg, 3);
-    // When the objective is evaluated.  The two workgroups of a CU do not interleave: the one dispatched first (the first
-    // half of the grid) runs its passes at nearly full speed and is done ~1.5 us before the other, which fills gaps and
-    // finishes last (tools/diag_stamps.py).  So the first has slack at its END and the second at its START: the objective
-    // (0.6 us of one wave's time, LDS-resident by then either way) goes where the slack is.
-    const bool obj_last = 2 * blockIdx.x < gridDim.x;
     int parity = 0, xsel = 0;
     T* const in_base = lds + L::IN;
     fx_stage_store<T, WP, NH, TPW, NX, NU, TPW>(in_base, tid, sr);
@@ -796,19 +806,18 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         t0 += n_cur;
         const bool more = t0 < t_end;
         if (more) fx_stage_load<T, WP, NH, TPW, NX, NU, TPW>(cx, t0, tid, sr);   // next pass's inputs, under this pass
+#if NEMPC_FX_ZERO_EARLY
+        if constexpr (FUSE) {
+            if (cx.jac) {
+                const unsigned r0 = (unsigned)t_cur * 16u;
+                const int nrows = r0 + (unsigned)n_cur * 16u <= pa.R ? n_cur * 16 : (int)(pa.R - r0);
+                fx_zero_rows<T, NX, NTHREADS>(cx.jac, r0, nrows, pa.n, pa.H, pa.invH, has_box, tid);
+            }
+        }
+#endif
         lds_barrier();
         FX_STAMP_PASS(pa.dbg, 4);
         FX_STAMP_PRO(pa.dbg, 8);
-        if constexpr (FUSE) {
-            if (t_cur == t_begin && ob_n > 0 && !obj_last) {
-                const FxArgsK ka = fx_late_args();
-                T* const o_f = static_cast<T*>(ka->f);
-                T* const o_grad = static_cast<T*>(ka->grad);
-                for (int k = w; k < ob_n; k += MT)
-                    objective_row<T>((int)ob_lo + k, lane, pa.H, NX, NU, pa.oo, lds + L::TOTAL, lds + L::TOTAL + p_pad + k * pa.n,
-                                     o_f, o_grad);
-            }
-        }
         FX_STAMP_PRO(pa.dbg, 9);
         const T* in = in_base + parity * L::IN_SZ;
         T* const in_next = in_base + (parity ^ 1) * L::IN_SZ;
@@ -818,26 +827,35 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         parity ^= 1;
     }
     if constexpr (FUSE) {
-        if (ob_n > 0 && obj_last) {
+        if (want_obj && blockIdx.x < gridDim.x - gridDim.x / 2u) {
             const FxArgsK ka = fx_late_args();
             T* const o_f = static_cast<T*>(ka->f);
             T* const o_grad = static_cast<T*>(ka->grad);
-            for (int k = w; k < ob_n; k += MT)
-                objective_row<T>((int)ob_lo + k, lane, pa.H, NX, NU, pa.oo, lds + L::TOTAL, lds + L::TOTAL + p_pad + k * pa.n,
-                                 o_f, o_grad);
-        }
-        // ---- problems beyond the LDS copy (long horizons, many problems per workgroup): from global memory, one
-        //      problem per wave at a time (same routine, hence the same bits)
-        if (want_obj && ob_lo + (unsigned)ob_n < ob_hi) {
-            const FxArgsK ka = fx_late_args();
-            if (pa.p_elems > PV_PER_THREAD * NTHREADS) {
-                const T* __restrict__ gp = static_cast<const T*>(pa.P);
-                for (int i = tid + PV_PER_THREAD * NTHREADS; i < pa.p_elems; i += NTHREADS) lds[L::TOTAL + i] = gp[i];
-                __syncthreads();
+            unsigned ob_lo[2], ob_hi[2];
+            int ob_n[2];
+            obj_range(0, ob_lo[0], ob_hi[0], ob_n[0]);
+            obj_range(1, ob_lo[1], ob_hi[1], ob_n[1]);
+            // the LDS-resident problems of both ranges, one problem per wave (flat over the two ranges so that the
+            // waves share them evenly)
+            const int ntot = ob_n[0] + ob_n[1];
+            for (int k = w; k < ntot; k += MT) {
+                const int side = k < ob_n[0] ? 0 : 1, kk = k - (side ? ob_n[0] : 0);
+                objective_row<T>((int)ob_lo[side] + kk, lane, pa.H, NX, NU, pa.oo, lds + L::TOTAL,
+                                 lds + L::TOTAL + p_pad + side * FX_ZCOPY + kk * pa.n, o_f, o_grad);
             }
-            for (unsigned b = ob_lo + (unsigned)ob_n + (unsigned)w; b < ob_hi; b += MT)
-                objective_body<T>((int)b, lane, pa.H, NX, NU, pa.oo, lds + L::TOTAL, cx.Z, static_cast<T*>(ka->f),
-                                  static_cast<T*>(ka->grad));
+            // ---- problems beyond the LDS copy (long horizons, many problems per workgroup): from global memory, one
+            //      problem per wave at a time (same routine, hence the same bits)
+            if (ob_lo[0] + (unsigned)ob_n[0] < ob_hi[0] || ob_lo[1] + (unsigned)ob_n[1] < ob_hi[1]) {
+                if (pa.p_elems > PV_PER_THREAD * NTHREADS) {
+                    const T* __restrict__ gp = static_cast<const T*>(pa.P);
+                    for (int i = tid + PV_PER_THREAD * NTHREADS; i < pa.p_elems; i += NTHREADS) lds[L::TOTAL + i] = gp[i];
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int side = 0; side < 2; ++side)
+                    for (unsigned b = ob_lo[side] + (unsigned)ob_n[side] + (unsigned)w; b < ob_hi[side]; b += MT)
+                        objective_body<T>((int)b, lane, pa.H, NX, NU, pa.oo, lds + L::TOTAL, cx.Z, o_f, o_grad);
+            }
         }
     }
     COOP_WGSTAMP(pa.dbg, 14);
