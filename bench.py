@@ -746,7 +746,8 @@ class Rank:
         out_bytes = B * eng.nnz_hess * w
         return {"nnz_hess": eng.nnz_hess,
                 "exact": {"us": t_h * 1e6, "batch_evals_per_s": 1.0 / t_h, "max_abs_err_vs_cpu": e_h, "max_abs_ref": s_h,
-                          "roofline": {"bound": "mfma", "kernel": ("rowhess_coop_kernel (blocks and tril assembly in one launch)"
+                          "roofline": {"bound": "mfma", "kernel": (("rowhess_coopfx_kernel" if (cfg["nx"], cfg["nu"], cfg["hidden"], cfg["dtype"]) == (2, 1, [64, 64], "f64")
+                                                                     else "rowhess_coop_kernel") + " (blocks and tril assembly in one launch)"
                                                                     if S == 1 else "RK4 pipeline: stage-record rows, rk4_nu, "
                                                                     "rowhess_coop_kernel (direct mode), rk4_congruence, assemble_hess"),
                                        "achieved": hess_flops / t_h / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
