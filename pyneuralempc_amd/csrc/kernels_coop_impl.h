@@ -96,6 +96,73 @@ namespace nempc {
 #define NEMPC_COOP_MIDSTAGE 1
 #endif
 
+// A pointer the whole wave agrees on, pinned to scalar registers (the "s" operand of the stores below must not be left to
+// the compiler's uniformity analysis)
+__device__ __forceinline__ const char* fx_uniform_ptr(const char* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+}
+
+// A/B switch of the fused dense output (tools/build_variant.py -D...)
+#ifndef NEMPC_FX_NZ_PLAIN
+#define NEMPC_FX_NZ_PLAIN 0        // 1: the non-zero entries as plain stores (dirty in L2 until the end-of-kernel write-back)
+#endif
+#if NEMPC_FX_NZ_PLAIN
+#define NEMPC_FX_WT ""
+#else
+#define NEMPC_FX_WT " sc0 sc1"
+#endif
+// Write-through stores (sc0 sc1): the data leaves for memory as it is issued instead of sitting dirty in L2 until the
+// end-of-kernel write-back (C2, B=1024: whole evaluation 21.9 -> 20.3 us when the dense rows were first fused in).
+__device__ __forceinline__ void fx_store_wt(double* p, double v) {
+    asm volatile("global_store_dwordx2 %0, %1, off" NEMPC_FX_WT ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void fx_store_wt(float* p, float v) {
+    asm volatile("global_store_dword %0, %1, off" NEMPC_FX_WT ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void fx_store_wt2(double* p, double v0, double v1) {      // p 16-byte aligned
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 v = {v0, v1};
+    asm volatile("global_store_dwordx4 %0, %1, off" NEMPC_FX_WT ::"v"(p), "v"(v) : "memory");
+}
+
+// Fused dense Jacobian, part one: the BACKGROUND (see fx_zero_rows in kernels_coopfx_impl.h, the compiled-shape twin of
+// this routine, for why and for the ordering argument).  The structural zeros of a pass's dense rows are streamed from
+// registers at the start of the pass as flat runs of 16-byte write-through stores; the pass's outputs overwrite the few
+// non-zeros.  The host launches this form only when a problem's block of rows is a whole number of 16-byte vectors
+// (nx * n * sizeof(T) divisible by 16) and 16-byte aligned.
+template <typename T, int NTHREADS>
+__device__ __forceinline__ void coop_zero_rows(T* o_jac, unsigned r0, int nrows, int nx, int n, int H, unsigned invH, bool box, int tid) {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    typedef T vecT __attribute__((ext_vector_type(VEC)));
+    const vecT zero = {};
+    const size_t row_bytes = (size_t)n * sizeof(T);
+    const int drv = nrows * nx;                     // dense rows of the pass that exist
+    if (!box) {
+        const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) + (size_t)r0 * nx * row_bytes);
+        const int nv = (int)((size_t)drv * row_bytes / 16);
+        for (int fv = tid; fv < nv; fv += NTHREADS)
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(zero), "s"(base) : "memory");
+    } else {
+        const int HNX = H * nx;
+        for (int s0 = 0; s0 < drv;) {
+            const unsigned r = r0 + (unsigned)(s0 / nx);
+            const unsigned b = invH ? __umulhi(r, invH) : r;
+            const int k = (int)(r - b * (unsigned)H) * nx;              // first dense row of the piece within its block
+            const int len = drv - s0 < HNX - k ? drv - s0 : HNX - k;    // rows up to the end of the problem / pass
+            const int nv = (int)((size_t)len * row_bytes / 16);
+            for (int kind = 0; kind < 2; ++kind) {
+                const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) +
+                                                  ((size_t)b * (2 * HNX) + (size_t)(kind * HNX + k)) * row_bytes);
+                for (int fv = tid; fv < nv; fv += NTHREADS)
+                    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(zero), "s"(base) : "memory");
+            }
+            s0 += len;
+        }
+    }
+}
+
 struct CoopLayout {  // element offsets inside dynamic LDS
     int w0f;         // layer-0 fragments          ks * MT * 64
     int tail;        // seed | bias_l | biasL      (off.total - off.seed)
@@ -159,6 +226,7 @@ struct CoopCtx {
     const T* X0;
     T* gout;
     T* tiles;
+    T* jac;                         // fused dense Jacobian (B, m, n) or null (plain models only)
     int nx, nu, nin, H, n, m, NR, jsz, spt, nstages, ks, kind, box, xt_off, ex_off, ne, inv_nin;
     const T* extra;
     unsigned inv32_jrow, inv32_nx;
@@ -262,7 +330,10 @@ __device__ __forceinline__ void stage_direct(const CoopCtx<T>& cx, int t0, int n
 // buffer (SCRnext / RInext) just before this pass's first global store.  Placed there for the vmcnt counter: stores
 // count in it too and retire in order, so a wait for those loads issued after the epilogue's (runtime-many) stores
 // degenerates to vmcnt(0) and sat out the stores' acknowledgement, 1.4 us per pass boundary.
-template <typename T, int WP, int NH, int NT, bool SR, int TPW, int ACT>
+// NXc / NUc > 0: the problem's dims as compile-time constants (plain models, window 1): every index division of the
+// reduction, chain-rule and output phases folds, their inner loops unroll -- the same source, a second instantiation
+// for a shape that is worth it (BASELINE configs[2]: 6 states, 3 controls).
+template <typename T, int WP, int NH, int NT, bool SR, int TPW, int ACT, int NXc = 0, int NUc = 0>
 __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeights<T, WP, NH>& W, int t0, int tid,
                                           const StageRegs<T, WP / 16, TPW>& nxt, bool has_nxt, T* SCRnext, int* RInext,
                                           int nrows_next) {
@@ -279,7 +350,12 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
     T* SCR = cx.SCR;
     const T* __restrict__ Z = cx.Z;
     const T* __restrict__ X0 = cx.X0;
-    const int nx = cx.nx, nu = cx.nu, nin = cx.nin, H = cx.H, n = cx.n, NR = cx.NR, jsz = cx.jsz, spt = cx.spt;
+    constexpr bool FX = NXc > 0;
+    const int nx = FX ? NXc : cx.nx, nu = FX ? NUc : cx.nu, nin = FX ? NXc + NUc : cx.nin;
+    const int H = cx.H, n = cx.n, spt = cx.spt;
+    const int NR = FX ? (sizeof(T) == 8 ? (NXc + NUc + 3) / 4 : 4) : cx.NR;
+    const int jsz = FX ? 16 * NXc * (NXc + NUc) : cx.jsz;
+    auto div_nin = [&](int kd) { return FX ? kd / nin : (kd * cx.inv_nin) >> 16; };      // kd < 256
     const size_t R = cx.R;
     const bool rk4 = cx.rk4;
     const T DT = cx.DT;
@@ -445,7 +521,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                 const int j = idx >> 4, cc = idx & 15;
                 const bool isf = col < nx;
                 const int kd = isf ? 0 : col - nx;
-                const int k = (kd * cx.inv_nin) >> 16;
+                const int k = div_nin(kd);
                 const int dsel = isf ? col : kd - k * nin;               // output index (f) / input index (J)
                 const int slot = isf ? 0 : 1 + k;
                 const int qq = sizeof(T) == 8 ? (dsel & 3) : (dsel >> 2), rr = sizeof(T) == 8 ? (dsel >> 2) : (dsel & 3);
@@ -495,7 +571,8 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                     const int i = rem2 / nin, d = rem2 - i * nin;
                     const T* sj = SCR + j * spt + 16 * nin + 2 * 16 * nx;
                     T v = T(0);
-                    for (int e3 = 0; e3 < nx; ++e3)
+#pragma unroll
+                    for (int e3 = 0; e3 < (FX ? NXc : nx); ++e3)
                         v = fma(sj[(cc * nx + i) * nin + e3], sj[jsz + (cc * nx + e3) * nin + d], v);
                     SCR[j * spt + 16 * nin + 2 * 16 * nx + 3 * jsz + e2] = fma(cdt, v, sj[e2]);
                 }
@@ -518,23 +595,38 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
     }
 
     COOP_STAMP(9);
+    // fused dense Jacobian (plain models): the background zeros of the pass's rows were streamed at its start
+    // (coop_zero_rows); every wave waits for its own stores' acknowledgements, the barrier covers the workgroup, then the
+    // non-zeros go over them with the compact outputs below (see fx_zero_rows in kernels_coopfx_impl.h for the ordering)
+    T* const jac = cx.jac;
+    if (jac) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+    }
     if (has_nxt) stage_store<T, WP / 16, TPW>(cx, SCRnext, RInext, nrows_next, tid, nxt);
     // ---- outputs: compact tiles (16 rows contiguous in memory) and defects
     const T s6 = DT / T(6);
     // tiles: the pass's NT*16 rows are contiguous in memory -> lanes run over the flat element index (coalesced)
     const int jrow = nx * nin;
     for (int item = tid; item < NT * jsz; item += NTHREADS) {
-        const int idx = jrow == 1 ? item : (int)__umulhi((unsigned)item, cx.inv32_jrow), kd = item - idx * jrow;
+        const int idx = FX ? item / jrow : (jrow == 1 ? item : (int)__umulhi((unsigned)item, cx.inv32_jrow)), kd = item - idx * jrow;
         if (RI[2 * idx] >= 0) {
-            const int i = (kd * cx.inv_nin) >> 16, d = kd - i * nin;
+            const int i = div_nin(kd), d = kd - i * nin;
             const T* sj = SCR + (idx >> 4) * spt + 16 * nin + 2 * 16 * nx + (idx & 15) * jrow;
             const T ident = (d == cx.gk.xcur + i && (rk4 || cx.kind == NEMPC_DISCRET)) ? T(1) : T(0);
-            cx.tiles[(size_t)t0 * 16 * jrow + item] = (rk4 ? s6 * sj[2 * jsz + kd] : sj[kd]) + ident;
+            const T v = (rk4 ? s6 * sj[2 * jsz + kd] : sj[kd]) + ident;
+            if (cx.tiles) cx.tiles[(size_t)t0 * 16 * jrow + item] = v;
+            if (jac) {
+                // dense row (t, i) of problem b: the state block at x_{t-1} (t >= 1; x0 has no column), the control block at u_t
+                const int b = RI[2 * idx], t = RI[2 * idx + 1];
+                const int col = d < nx ? (t - 1) * nx + d : H * nx + t * nu + (d - nx);
+                if (d >= nx || t >= 1) fx_store_wt(jac + ((size_t)b * cx.m + (size_t)(t * nx + i)) * (size_t)n + col, v);
+            }
         }
     }
     // defects: lanes run over (row, state) with the state fastest -> contiguous inside a problem
     for (int item = tid; item < NT * 16 * nx; item += NTHREADS) {
-        const int idx = nx == 1 ? item : (int)__umulhi((unsigned)item, cx.inv32_nx), i = item - idx * nx;
+        const int idx = FX ? item / nx : (nx == 1 ? item : (int)__umulhi((unsigned)item, cx.inv32_nx)), i = item - idx * nx;
         const int b = RI[2 * idx], t = RI[2 * idx + 1];
         if (b >= 0) {
             const int cc = idx & 15;
@@ -547,6 +639,11 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
             const T xt = s_xi0[cx.xt_off + cc * nx + i];
             cx.gout[(size_t)b * cx.m + t * nx + i] = phi - xt;
             if (cx.box) cx.gout[(size_t)b * cx.m + (size_t)H * nx + t * nx + i] = xt;
+            if (jac) {
+                T* const row = jac + ((size_t)b * cx.m + (size_t)(t * nx + i)) * (size_t)n;
+                fx_store_wt(row + t * nx + i, T(-1));
+                if (cx.box) fx_store_wt(row + (size_t)H * nx * (size_t)n + t * nx + i, T(1));
+            }
         }
     }
     lds_barrier();
@@ -577,6 +674,7 @@ struct CoopArgs {
     // ---- the rest of CoopCtx
     void* g;
     void* tiles;
+    void* jac;              // dense Jacobian written by this launch (plain models; null: the assembly kernel does it)
     void* stage_out;
     long long* dbg;
     int m, NR, jsz, spt, nstages, ks, kind, box, xt_off, ex_off, inv_nin, rk4, stage_stride;
@@ -588,7 +686,7 @@ struct CoopArgs {
 // SR: also write the per-(row, stage) records of the RK4 Hessian pipeline (its own instantiation: the extra stores and
 // their address arithmetic cost the plain kernel 0.3 - 0.9 us when they are only branched around)
 // OCC: waves per SIMD the register allocation must allow (workgroups per CU = OCC * 4 / MT)
-template <typename T, int WP, int NH, int TPW, bool SR, int OCC, int ACT>
+template <typename T, int WP, int NH, int TPW, bool SR, int OCC, int ACT, int NXc = 0, int NUc = 0>
 __global__ __launch_bounds__((WP / 16) * 64, OCC) void rows_coop_kernel(CoopArgs a) {
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
@@ -686,6 +784,7 @@ __global__ __launch_bounds__((WP / 16) * 64, OCC) void rows_coop_kernel(CoopArgs
     cx.RI = ri_base;
     cx.gout = static_cast<T*>(a.g);
     cx.tiles = static_cast<T*>(a.tiles);
+    cx.jac = static_cast<T*>(a.jac);
     cx.m = a.m;
     cx.gk = a.gk;
     cx.stage_out = static_cast<T*>(a.stage_out); cx.stage_stride = a.stage_stride;
@@ -738,16 +837,22 @@ __global__ __launch_bounds__((WP / 16) * 64, OCC) void rows_coop_kernel(CoopArgs
             nact = t_end - t0 < TPW ? t_end - t0 : TPW;
             if (early) stage_load<T, MT, TPW>(cx, t0, nact * 16, tid, sr);
         }
+        if (cx.jac) {
+            // background zeros of this pass's dense rows: out now, overwritten by the pass's outputs
+            const unsigned r0 = (unsigned)t_cur * 16u;
+            const int nrows = (size_t)r0 + (size_t)n_cur * 16 <= cx.R ? n_cur * 16 : (int)(cx.R - r0);
+            coop_zero_rows<T, NTHREADS>(cx.jac, r0, nrows, cx.nx, cx.n, cx.H, cx.invH, cx.box != 0, tid);
+        }
         lds_barrier();
 #ifdef NEMPC_STAMPS
         if (npass < 4) COOP_WGSTAMP(a.dbg, 4 + 2 * npass);
 #endif
         T* const scr_n = scr_base + (parity ^ 1) * scr_sz;
         int* const ri_n = ri_base + (parity ^ 1) * ri_sz;
-        if (n_cur == 1) coop_pass<T, WP, NH, 1, SR, TPW, ACT>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16);
-        if constexpr (TPW >= 2) { if (n_cur == 2) coop_pass<T, WP, NH, 2, SR, TPW, ACT>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
-        if constexpr (TPW >= 3) { if (n_cur == 3) coop_pass<T, WP, NH, 3, SR, TPW, ACT>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
-        if constexpr (TPW >= 4) { if (n_cur == 4) coop_pass<T, WP, NH, 4, SR, TPW, ACT>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
+        if (n_cur == 1) coop_pass<T, WP, NH, 1, SR, TPW, ACT, NXc, NUc>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16);
+        if constexpr (TPW >= 2) { if (n_cur == 2) coop_pass<T, WP, NH, 2, SR, TPW, ACT, NXc, NUc>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
+        if constexpr (TPW >= 3) { if (n_cur == 3) coop_pass<T, WP, NH, 3, SR, TPW, ACT, NXc, NUc>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
+        if constexpr (TPW >= 4) { if (n_cur == 4) coop_pass<T, WP, NH, 4, SR, TPW, ACT, NXc, NUc>(cx, W, t_cur, tid, sr, pf, scr_n, ri_n, nact * 16); }
         if (!NEMPC_COOP_MIDSTAGE && early && t0 < t_end) stage_store<T, MT, TPW>(cx, scr_n, ri_n, nact * 16, tid, sr);
         parity ^= 1;
         cx.SCR = scr_n;

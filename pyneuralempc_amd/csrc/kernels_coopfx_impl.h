@@ -20,9 +20,6 @@
 #ifndef NEMPC_FX_ZERO_EARLY
 #define NEMPC_FX_ZERO_EARLY 0      // 1: background zeros before the pass's first barrier instead of behind layer 0
 #endif
-#ifndef NEMPC_FX_NZ_PLAIN
-#define NEMPC_FX_NZ_PLAIN 0        // 1: the non-zero entries as plain stores (dirty in L2 until the end-of-kernel write-back)
-#endif
 
 // diagnostic builds only (tools/diag_stamps.py): the per-workgroup timeline has 13 event slots; -DNEMPC_STAMPS_PRO spends
 // them on the prologue instead of the pass
@@ -191,14 +188,6 @@ __device__ __forceinline__ float fx_qsum(float s) {
     return __uint_as_float(a32[0]) + __uint_as_float(a32[1]);
 }
 
-// A pointer the whole wave agrees on, pinned to scalar registers (the "s" operand of the stores below must not be left to
-// the compiler's uniformity analysis)
-__device__ __forceinline__ const char* fx_uniform_ptr(const char* p) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
-}
-
 // Several row sums at once.  v_permlane16_swap exchanges the odd rows of its first operand with the even rows of the
 // second; fed two DIFFERENT values a, b it leaves [a0 b0 a2 b2] and [a1 b1 a3 b3], whose sum holds a0+a1 and a2+a3 in rows
 // 0 / 2 and b0+b1, b2+b3 in rows 1 / 3: one swap pair and one add take two values through a stage (fx_qsum spends that
@@ -242,25 +231,6 @@ __device__ __forceinline__ void fx_rowsums_store(const T (&s)[NV], T* dst, int l
         const T v = fx_swap32_add(fx_swap16_add(s[4 * G], s[4 * G + 1]), fx_swap16_add(s[4 * G + 2], s[4 * G + 2]));
         if (q < 3) dst[G * 64 + lane] = v;
     }
-}
-
-// Write-through stores (sc0 sc1): the data leaves for memory as it is issued instead of sitting dirty in L2 until the
-// end-of-kernel write-back (C2, B=1024: whole evaluation 21.9 -> 20.3 us when the dense rows were first fused in).
-#if NEMPC_FX_NZ_PLAIN
-#define NEMPC_FX_WT ""
-#else
-#define NEMPC_FX_WT " sc0 sc1"
-#endif
-__device__ __forceinline__ void fx_store_wt(double* p, double v) {
-    asm volatile("global_store_dwordx2 %0, %1, off" NEMPC_FX_WT ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void fx_store_wt(float* p, float v) {
-    asm volatile("global_store_dword %0, %1, off" NEMPC_FX_WT ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void fx_store_wt2(double* p, double v0, double v1) {      // p 16-byte aligned
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    const d2 v = {v0, v1};
-    asm volatile("global_store_dwordx4 %0, %1, off" NEMPC_FX_WT ::"v"(p), "v"(v) : "memory");
 }
 
 // Fused evaluation, dense Jacobian (integrator/discret.py:38-56, unity.py:38-56; ipopt.py:88-96), part one: the

@@ -235,6 +235,17 @@ int launch_eval_fused(Handle& h, int B, const void* Z, const void* X0, void* g, 
     return h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
 }
 
+// Rows, compact tiles (optional) and the DENSE Jacobian from one launch of the cooperative kernel (any shape it takes,
+// plain models): background zeros streamed at the start of each pass, non-zeros written with the pass's outputs.
+// NEMPC_EUNSUPPORTED (nothing launched, no error message) sends nempc_eval to the row + assembly launches.
+int launch_rows_mfma_dense(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, hipStream_t s) {
+    static const int on = [] { const char* e = getenv("NEMPC_COOP_DENSE"); return e ? atoi(e) : 1; }();
+    if (!on || !h.mfma.blob || !jac) return NEMPC_EUNSUPPORTED;
+    MfmaParams p = base_params(h, B, Z, X0, g, tiles);
+    p.fuse_jac = jac;
+    return h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+}
+
 int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* stage_out,
                             int stage_stride, hipStream_t s) {
     if (!h.mfma.blob) {

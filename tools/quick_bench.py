@@ -44,7 +44,20 @@ def run(H, B, box, hess=True):
     return {k: round(v, 2) for k, v in out.items()}
 
 
+def run_c3(B=1024):
+    net = orc.MLP.random(9, [128, 128, 128], 6, seed=0)
+    eng = CallbackEngine(net.W, net.b, 30, 6, 3, integrator="rk4", DT=0.1, dtype=torch.float32, device="cuda:0", max_batch=B)
+    Zh, X0h = orc.synthetic_inputs(B, 30, 6, 3, seed=1)
+    Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+    out = {}
+    step, _ = eng.bind(Z, X0, ("f", "grad", "g", "jac_dense")); out["eval_us"] = timed(step, 60, 100)
+    step, _ = eng.bind(Z, X0, ("g", "jac_tiles")); out["rows_us"] = timed(step, 60, 100)
+    lam = torch.randn(B, eng.m, dtype=torch.float32, device="cuda:0"); sig = torch.ones(B, dtype=torch.float32, device="cuda:0")
+    out["hess_us"] = timed(lambda: eng.hess(Z, X0, lam, sig), 20, 100)
+    return {k: round(v, 1) for k, v in out.items()}
+
+
 if __name__ == "__main__":
     res = {"c2_b1024": run(20, 1024, False), "c2_b256": run(20, 256, False), "c5": run(50, 1024, True),
-           "c2_b4096": run(20, 4096, False, hess=False)}
+           "c2_b4096": run(20, 4096, False, hess=False), "c3": run_c3()}
     print(json.dumps(res))
