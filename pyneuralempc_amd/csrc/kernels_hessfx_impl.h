@@ -27,8 +27,8 @@
 
 namespace nempc {
 
-template <typename T, int WP, int NH, int NT, int NX, int NU>
-struct HfxLayout {   // element offsets inside dynamic LDS, all compile-time
+template <typename T, int WP, int NH, int NT, int NX, int NU, int TG = NX + NU>
+struct HfxLayout {   // element offsets inside dynamic LDS, all compile-time (TG: tangent directions per exchange)
     static constexpr int MT = WP / 16;
     static constexpr int NIN = NX + NU;
     static constexpr int KS = (NIN + 3) / 4;
@@ -42,7 +42,7 @@ struct HfxLayout {   // element offsets inside dynamic LDS, all compile-time
     static constexpr int P0 = BIASL + 16;                            // first-layer rows per lane: [d][MT*16]
     static constexpr int SMALL_END = P0 + NIN * MT * 16;
     static constexpr int PP = up16(SMALL_END);                       // pair products P0[p] * P0[q] per feature: [pq][MT*16]
-    static constexpr int XH = NT * NIN * MT * 256;                   // exchange buffer: two halves of NT * NIN sets
+    static constexpr int XH = NT * TG * MT * 256;                    // exchange buffer: two halves of NT * TG sets
     static constexpr int X = up16(PP + NPAIR * MT * 16);
     static constexpr int PART = X + 2 * XH;                          // K-split partials [w][j][pq][16 rows]
     static constexpr int PART_SZ = up16(MT * NT * NPAIR * 16);
@@ -63,7 +63,12 @@ struct HfxArgs {   // host-prepared
     unsigned invH;          // ceil(2^32 / H), 0 for H == 1
     int H, n, m;
     int nload;              // 16-byte loads per lane of a wave's packed slice (the kernel takes the hidden-layer part)
-    void* blocks;           // (B, H, nin, nin) or null
+    // direct mode (RK4 pipeline, kernels_rk4hess.hip): the rows are (row, stage) pairs whose network input and
+    // multipliers are given explicitly -- record r at xi_direct + r * xi_stride (first nin values), lam_direct (rows, nx)
+    const void* xi_direct;
+    const void* lam_direct;
+    int xi_stride;
+    void* blocks;           // (B, H, nin, nin) [direct mode: (rows, nin, nin)] or null
     // fused tril assembly (see HessParams)
     void* hvals;
     const void* sigma;
@@ -92,21 +97,26 @@ __device__ __forceinline__ void hfx_stage_load(const HfxArgs& a, int t0, int tid
         T v = T(0);
         const unsigned r = (unsigned)t0 * 16u + (unsigned)idx;
         if (col < NCOL && r < a.R) {
-            const unsigned b = a.invH ? __umulhi(r, a.invH) : r;
-            const int t = (int)(r - b * (unsigned)a.H);
-            const T* z = Z + (size_t)b * a.n;
-            if (col < NX) v = (t == 0) ? X0[(size_t)b * NX + col] : z[(t - 1) * NX + col];
-            else if (col < NIN) v = z[a.H * NX + t * NU + (col - NX)];
-            else v = lam[(size_t)b * a.m + t * NX + (col - NIN)];
+            if (a.xi_direct) {
+                v = col < NIN ? static_cast<const T*>(a.xi_direct)[(size_t)r * a.xi_stride + col]
+                              : static_cast<const T*>(a.lam_direct)[(size_t)r * NX + (col - NIN)];
+            } else {
+                const unsigned b = a.invH ? __umulhi(r, a.invH) : r;
+                const int t = (int)(r - b * (unsigned)a.H);
+                const T* z = Z + (size_t)b * a.n;
+                if (col < NX) v = (t == 0) ? X0[(size_t)b * NX + col] : z[(t - 1) * NX + col];
+                else if (col < NIN) v = z[a.H * NX + t * NU + (col - NX)];
+                else v = lam[(size_t)b * a.m + t * NX + (col - NIN)];
+            }
         }
         sr.v[it] = v;
     }
 }
 
-template <typename T, int WP, int NH, int NTL, int NT, int NX, int NU>
+template <typename T, int WP, int NH, int NTL, int NT, int NX, int NU, int TG>
 __device__ __forceinline__ void hfx_stage_store(T* in, int tid, const HfxStage<T, NT, (WP / 16) * 64, NX + NU + NX>& sr) {
     constexpr int NIN = NX + NU, NCOL = NIN + NX, ROWS = NT * 16, NTHREADS = (WP / 16) * 64;
-    using L = HfxLayout<T, WP, NH, NTL, NX, NU>;
+    using L = HfxLayout<T, WP, NH, NTL, NX, NU, TG>;
 #pragma unroll
     for (int it = 0; it < HfxStage<T, NT, NTHREADS, NCOL>::ITEMS; ++it) {
         const int item = tid + it * NTHREADS;
@@ -120,19 +130,43 @@ __device__ __forceinline__ void hfx_stage_store(T* in, int tid, const HfxStage<T
 }
 
 // One pass over NTc (<= NT) tiles starting at tile t0, inputs in `in`.
-template <typename T, int WP, int NH, int NT, int NX, int NU, int NTc, int ACT>
+// RWB: the backward slices (W_l as an A operand) are fetched at the start of every pass instead of living in registers
+// for the whole kernel -- they are read by the base reverse sweep only, and at widths where a pass is tens of thousands
+// of cycles (3x128) their registers are what the tangent / contraction phase needs.
+template <typename T, int WP, int NH, int NT, int NX, int NU, int NTc, int ACT, int TG, bool RWB>
 __device__ __forceinline__ void hfx_pass(const HfxArgs& a, T* lds, const T (&wf)[NH > 1 ? NH - 1 : 1][(WP / 16) * 4],
-                                         const T (&wb)[NH > 1 ? NH - 1 : 1][(WP / 16) * 4], const T* in, int t0, int tid,
+                                         const T (&wb_res)[NH > 1 ? NH - 1 : 1][(WP / 16) * 4], const T* in, int t0, int tid,
                                          int& xsel, const HfxStage<T, NT, (WP / 16) * 64, NX + NU + NX>& nxt, bool has_next,
                                          T* in_next) {
     using Ops = MfmaOps<T>;
     using A = Act<T, ACT>;
     using V4 = typename Ops::V4;
-    using L = HfxLayout<T, WP, NH, NT, NX, NU>;
+    using L = HfxLayout<T, WP, NH, NT, NX, NU, TG>;
     constexpr int MT = WP / 16, NTHREADS = MT * 64, NIN = NX + NU, KS = L::KS, NPAIR = L::NPAIR;
     const int lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
 
+    T wb[NH > 1 ? NH - 1 : 1][MT * 4];
+    if constexpr (RWB) {
+        constexpr int VEC = 16 / (int)sizeof(T);
+        typedef T vecT __attribute__((ext_vector_type(VEC)));
+        const vecT* __restrict__ ws = static_cast<const vecT*>(a.wslice) + (size_t)w * a.nload * 64 + lane;
+#pragma unroll
+        for (int l = 1; l < NH; ++l) {
+            constexpr int PER = MT * 4 / VEC;                         // 16-byte vectors per fragment set
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const vecT v = ws[((l - 1) * 2 * PER + PER + k) * 64];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) wb[l - 1][k * VEC + e] = v[e];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int l = 1; l < NH; ++l)
+#pragma unroll
+            for (int i = 0; i < MT * 4; ++i) wb[l - 1][i] = wb_res[l - 1][i];
+    }
     V4 s[NH][NTc];          // a_l first, then s'(z_l)
     // ---- layer 0, this wave's feature block
     {
@@ -265,29 +299,38 @@ __device__ __forceinline__ void hfx_pass(const HfxArgs& a, T* lds, const T (&wf)
         }
 #pragma unroll
         for (int l = 1; l < NH; ++l) {
-            T* X = lds + L::X + (xsel & 1) * L::XH;
-            ++xsel;
-#pragma unroll
-            for (int p = 0; p < NIN; ++p)
-#pragma unroll
-                for (int j = 0; j < NTc; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) X[(((p * NTc + j) * MT + w) * 4 + r) * 64 + lane] = tg[p][j][r];
-            lds_barrier();
             V4 P[NIN][NTc];
+            // TG directions per exchange (all of them when they fit the exchange area)
 #pragma unroll
-            for (int p = 0; p < NIN; ++p)
+            for (int g0 = 0; g0 < NIN; g0 += TG) {
+                T* X = lds + L::X + (xsel & 1) * L::XH;
+                ++xsel;
 #pragma unroll
-                for (int j = 0; j < NTc; ++j) P[p][j] = V4{T(0), T(0), T(0), T(0)};
+                for (int g = 0; g < TG; ++g)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                    for (int j = 0; j < NTc; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                        for (int r = 0; r < 4; ++r)
+                            if (g0 + g < NIN) X[(((g * NTc + j) * MT + w) * 4 + r) * 64 + lane] = tg[g0 + g < NIN ? g0 + g : 0][j][r];
+                lds_barrier();
 #pragma unroll
-                    for (int p = 0; p < NIN; ++p)
+                for (int g = 0; g < TG; ++g)
 #pragma unroll
-                        for (int j = 0; j < NTc; ++j)
-                            P[p][j] = Ops::mma(wf[l - 1][mt * 4 + r], X[(((p * NTc + j) * MT + mt) * 4 + r) * 64 + lane], P[p][j]);
+                    for (int j = 0; j < NTc; ++j)
+                        if (g0 + g < NIN) P[g0 + g < NIN ? g0 + g : 0][j] = V4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int g = 0; g < TG; ++g)
+#pragma unroll
+                            for (int j = 0; j < NTc; ++j)
+                                if (g0 + g < NIN)
+                                    P[g0 + g < NIN ? g0 + g : 0][j] = Ops::mma(wf[l - 1][mt * 4 + r],
+                                                                               X[(((g * NTc + j) * MT + mt) * 4 + r) * 64 + lane],
+                                                                               P[g0 + g < NIN ? g0 + g : 0][j]);
+            }
             // acc[pq] += sum_r (delta s'')_r P[p]_r P[q]_r   over this lane's four features
 #pragma unroll
             for (int j = 0; j < NTc; ++j) {
@@ -319,7 +362,7 @@ __device__ __forceinline__ void hfx_pass(const HfxArgs& a, T* lds, const T (&wf)
         fx_rowsums_store<T, NTc * NPAIR>(sv, lds + L::PART + w * (NT * NPAIR) * 16, lane);
     }
     lds_barrier();
-    if (has_next) hfx_stage_store<T, WP, NH, NT, NT, NX, NU>(in_next, tid, nxt);
+    if (has_next) hfx_stage_store<T, WP, NH, NT, NT, NX, NU, TG>(in_next, tid, nxt);
 
     // ---- outputs: the sum over the MT waves is taken here, in wave order
     constexpr int BSZ = NIN * NIN;
@@ -359,9 +402,9 @@ __device__ __forceinline__ void hfx_pass(const HfxArgs& a, T* lds, const T (&wf)
     lds_barrier();
 }
 
-template <typename T, int WP, int NH, int NT, int NX, int NU, int ACT>
+template <typename T, int WP, int NH, int NT, int NX, int NU, int ACT, int TG = NX + NU, bool RWB = false>
 __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coopfx_kernel(HfxArgs a) {
-    using L = HfxLayout<T, WP, NH, NT, NX, NU>;
+    using L = HfxLayout<T, WP, NH, NT, NX, NU, TG>;
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -415,11 +458,11 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coopfx_kernel(HfxAr
 #pragma unroll
             for (int i = 0; i < MT * 4; ++i, ++f) wf[l - 1][i] = wv[f / VEC][f % VEC];
 #pragma unroll
-            for (int i = 0; i < MT * 4; ++i, ++f) wb[l - 1][i] = wv[f / VEC][f % VEC];
+            for (int i = 0; i < MT * 4; ++i, ++f) wb[l - 1][i] = RWB ? T(0) : wv[f / VEC][f % VEC];
         }
     }
     T* const in_base = lds + L::IN;
-    hfx_stage_store<T, WP, NH, NT, NT, NX, NU>(in_base, tid, sr);
+    hfx_stage_store<T, WP, NH, NT, NT, NX, NU, TG>(in_base, tid, sr);
     lds_barrier();
     // pair products of the first layer's rows, per feature: PP[pq][i] = P0[p][i] * P0[q][i]
     for (int e = tid; e < L::NPAIR * MT * 16; e += NTHREADS) {
@@ -440,8 +483,8 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coopfx_kernel(HfxAr
         lds_barrier();
         const T* in = in_base + parity * L::IN_SZ;
         T* const in_next = in_base + (parity ^ 1) * L::IN_SZ;
-        if (n_cur == 1) hfx_pass<T, WP, NH, NT, NX, NU, 1, ACT>(a, lds, wf, wb, in, t_cur, tid, xsel, sr, more, in_next);
-        if constexpr (NT >= 2) { if (n_cur == 2) hfx_pass<T, WP, NH, NT, NX, NU, 2, ACT>(a, lds, wf, wb, in, t_cur, tid, xsel, sr, more, in_next); }
+        if (n_cur == 1) hfx_pass<T, WP, NH, NT, NX, NU, 1, ACT, TG, RWB>(a, lds, wf, wb, in, t_cur, tid, xsel, sr, more, in_next);
+        if constexpr (NT >= 2) { if (n_cur == 2) hfx_pass<T, WP, NH, NT, NX, NU, 2, ACT, TG, RWB>(a, lds, wf, wb, in, t_cur, tid, xsel, sr, more, in_next); }
         parity ^= 1;
     }
 }
