@@ -566,6 +566,18 @@ class Rank:
     def main(self):
         np, torch = self.np, self.torch
         args = self.args
+        if args.only_hessian:
+            # profiling mode: the Hessian-callback legs of one configuration alone, so that a rocprofv3 kernel trace of
+            # this command averages those launches only
+            res = self.run_config(args.config, 5, 2, headline=False, kernel=args.kernel)
+            out = {"config": {"workload": res["cfg"]["label"], "batch_per_gpu": res["B"]},
+                   "hessian_callback": self.hessian_leg(res)}
+            if self.rank == 0:
+                sys.stdout.flush()
+                os.dup2(self.saved_stdout, 1)
+                print(json.dumps(out), flush=True)
+                os.dup2(2, 1)
+            return
         res = self.run_config(args.config, args.steps, args.warmup, headline=True, kernel=args.kernel)
         cfg, B, eng, wall = res["cfg"], res["B"], res["eng"], res["wall"]
         primary, secondary, rf_extra = self.roofline_of(res)
@@ -754,7 +766,13 @@ class Rank:
                                        "frac": hess_flops / t_h / 1e12 / peak_tf, "traffic": None,
                                        "flops_per_callback": hess_flops,
                                        "flops_note": "(2 + 2 nin) / (1 + nx) x the row kernel's flops"
-                                                     + (" + the stage-record row launch" if S == 4 else "")}},
+                                                     + (" + the stage-record row launch" if S == 4 else "")
+                                                     + ": the pass count of forward-over-reverse (one tangent-forward and one "
+                                                       "tangent-reverse sweep per input).  The compiled-shape kernels sum the "
+                                                       "second-order chain rule layer by layer instead and run (2 + nin) passes on "
+                                                       "the matrix cores (flops_matrix_executed); the contraction is vector work",
+                                       "flops_matrix_executed": row_flops * (2 + nin) / (1 + nx) + (row_flops if S == 4 else 0),
+                                       "frac_of_executed": (row_flops * (2 + nin) / (1 + nx) + (row_flops if S == 4 else 0)) / t_h / 1e12 / peak_tf}},
                 "gauss_newton": {"us": t_g * 1e6, "batch_evals_per_s": 1.0 / t_g, "max_abs_err_vs_cpu": e_g,
                                  "roofline": {"bound": "mfma", "kernel": "row kernel (tiles) + assemble_hess_gn_kernel: two launches",
                                               "achieved": row_flops / t_g / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
@@ -796,6 +814,8 @@ def main():
                     help="profiling mode: the timed loop, the row-kernel timing and the accuracy check of the timed "
                          "launch only (no two-stream, solver, Hessian, other-config or CPU legs), so that a rocprofv3 "
                          "kernel trace of this command averages the headline launch alone")
+    ap.add_argument("--only-hessian", action="store_true",
+                    help="profiling mode: the Hessian-callback legs (exact + Gauss-Newton) of --config only")
     ap.add_argument("--hessian", action="store_true", help="(kept for old command lines: the Hessian legs run by default)")
     ap.add_argument("--no-hessian", action="store_true", help="skip the Hessian-callback legs (exact Lagrangian + Gauss-Newton)")
     ap.add_argument("--evals-per-mpc-step", type=int, default=17,
