@@ -428,6 +428,7 @@ class Rank:
         row_kernel = eng.last_row_kernel
         step, outs = eng.bind(Z, X0, want)
         t_all = self.timed_events(step, reps)
+        res["dense_from_row_launch"] = eng.last_row_kernel == "rows_coop_kernel+dense"
         res.update(t_rows=t_rows, t_all=t_all, row_kernel=row_kernel, work=work)
         res["step_pcts"] = self.per_step_us(step, reps) if headline else None
 
@@ -481,6 +482,18 @@ class Rank:
                 "bound": "mfma", "kernel": "rows_coopfx_kernel<..., FUSE = false> (g + compact tiles only; NOT the timed launch)",
                 "achieved": work["flops"] / res["t_rows"] / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
                 "frac": work["flops"] / res["t_rows"] / 1e12 / peak_tf, "traffic": None, "kernel_us": res["t_rows"] * 1e6}
+        elif res.get("dense_from_row_launch"):
+            # the timed step = the cooperative row kernel writing the dense rows itself + the small objective launch: the
+            # roofline is taken over the whole step (an upper bound of the row launch's duration); the same kernel without
+            # the dense rows (the compact contract) next to it
+            mfma = {"bound": "mfma", "kernel": "rows_coop_kernel writing the dense Jacobian rows (the dominant launch of the "
+                                               "timed step; objective_kernel follows it, inside kernel_us)",
+                    "achieved": work["flops"] / res["t_all"] / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": work["flops"] / res["t_all"] / 1e12 / peak_tf, "traffic": None,
+                    "kernel_us": res["t_all"] * 1e6, "flops_per_launch": work["flops"],
+                    "frac_compact_contract": work["flops"] / res["t_rows"] / 1e12 / peak_tf,
+                    "kernel_us_compact_contract": res["t_rows"] * 1e6,
+                    "arithmetic_intensity_dense": ai, "ridge": ridge}
         else:
             mfma = {"bound": "mfma", "kernel": str(res["row_kernel"]) + " (the dominant launch of the timed step; the "
                                                "assembly launch follows it)",

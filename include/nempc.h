@@ -275,7 +275,8 @@ int nempc_kernel_variant(nempc_handle h);
 
 /* row kernel the handle's most recent evaluation actually launched: 1 generic (rows_valu_kernel),
  * 2 cooperative matrix-core (rows_coop_kernel), 3 wave-per-tile matrix-core (rows_mfma_kernel), 4 cooperative
- * matrix-core compiled for the problem's shape (rows_coopfx_kernel); 0 = none yet */
+ * matrix-core compiled for the problem's shape (rows_coopfx_kernel), 5 rows_coop_kernel writing the dense Jacobian
+ * rows itself (no assembly launch); 0 = none yet */
 int nempc_last_row_kernel(nempc_handle h);
 
 const char* nempc_last_error(void);

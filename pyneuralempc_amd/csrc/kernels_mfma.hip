@@ -243,7 +243,9 @@ int launch_rows_mfma_dense(Handle& h, int B, const void* Z, const void* X0, void
     if (!on || !h.mfma.blob || !jac) return NEMPC_EUNSUPPORTED;
     MfmaParams p = base_params(h, B, Z, X0, g, tiles);
     p.fuse_jac = jac;
-    return h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+    const int rc = h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+    if (rc == NEMPC_OK) h.last_row_kernel = 5;        // the cooperative kernel, dense rows included
+    return rc;
 }
 
 int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* stage_out,

@@ -167,7 +167,8 @@ class CallbackEngine:
     @property
     def last_row_kernel(self):
         """Name of the row kernel the most recent evaluation launched."""
-        return {0: None, 1: "rows_valu_kernel", 2: "rows_coop_kernel", 3: "rows_mfma_kernel", 4: "rows_coopfx_kernel"}[
+        return {0: None, 1: "rows_valu_kernel", 2: "rows_coop_kernel", 3: "rows_mfma_kernel", 4: "rows_coopfx_kernel",
+                5: "rows_coop_kernel+dense"}[
             self.lib.nempc_last_row_kernel(self._handle)]
 
     # ------------------------------------------------------------------ parameters
