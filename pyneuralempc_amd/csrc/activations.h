@@ -97,7 +97,7 @@ struct Act<T, NEMPC_ACT_LINEAR> {
 template <typename T>
 struct Act<T, NEMPC_ACT_TANH> {
     static __device__ __forceinline__ T f(T x) { return nempc_tanh(x); }
-    static __device__ __forceinline__ T d1(T a) { return T(1) - a * a; }
+    static __device__ __forceinline__ T d1(T a) { return fma(-a, a, T(1)); }      // one instruction (1 - a*a is two)
     static __device__ __forceinline__ T r2(T a) { return T(-2) * a; }
 };
 template <typename T>

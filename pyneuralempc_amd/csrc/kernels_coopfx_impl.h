@@ -287,11 +287,10 @@ __device__ __forceinline__ void fx_zero_rows(T* o_jac, unsigned r0, int nrows, i
 // `nxt` / `in_next` (when has_next): the NEXT pass's inputs, already in registers; they go to the other input buffer
 // BEFORE this pass's global stores are issued -- vmcnt counts stores too and retires in order, so a wait for those loads
 // placed after the stores would sit out the stores' acknowledgement (with the dense rows fused in: the whole HBM time).
-template <typename T, int WP, int NH, int TPW, int NX, int NU, int NT, bool FUSE, int ACT, class Post0>
+template <typename T, int WP, int NH, int TPW, int NX, int NU, int NT, bool FUSE, int ACT>
 __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx, const CoopWeights<T, WP, NH>& W,
                                         const T* in, int t0, int tid, int& xsel,
-                                        const FxStage<T, TPW, (WP / 16) * 64, NX + NU + NX>& nxt, bool has_next, T* in_next,
-                                        Post0&& post0) {
+                                        const FxStage<T, TPW, (WP / 16) * 64, NX + NU + NX>& nxt, bool has_next, T* in_next) {
     using Ops = MfmaOps<T>;
     using A = Act<T, ACT>;
     using V4 = typename Ops::V4;
@@ -327,7 +326,6 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             for (int r = 0; r < 4; ++r) a[0][j][r] = A::f(a[0][j][r]);
     }
     FX_STAMP_PRO(cx.dbg, 10);
-    post0();            // (first pass of the fused evaluation: the objective's data goes to LDS here)
 #if !NEMPC_FX_ZERO_EARLY
     if constexpr (FUSE) {
         // background zeros of this pass's dense rows (fx_zero_rows): issued here, behind layer 0 -- the first thing a
@@ -653,16 +651,6 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         }
     }
     FX_STAMP_PRO(pa.dbg, 2);
-    FX_STAMP_PRO(pa.dbg, 3);
-    constexpr int NFRAG = (NH - 1) * 2 * MT * 4 + 8;
-    constexpr int NLOAD = (NFRAG + VEC - 1) / VEC;
-    vecT wv[NLOAD];
-    {
-        const vecT* __restrict__ ws = static_cast<const vecT*>(pa.wslice) + (size_t)w * NLOAD * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < NLOAD; ++k) wv[k] = ws[k * 64];
-    }
-    FX_STAMP_PRO(pa.dbg, 4);
     // fused evaluation: the objective.  A problem belongs to the workgroup whose tile range holds its first row.  WHO
     // evaluates it: the two workgroups of a CU do not interleave -- the one dispatched first (the first half of the grid)
     // runs its passes at nearly full speed and is done ~1.5 us before the other, which fills gaps and finishes last
@@ -672,9 +660,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     // evaluate at their END the problems of BOTH members of a pair (i, i + ceil(grid / 2)); the second half evaluates
     // none.  Both ranges' variables -- two contiguous pieces of Z -- are fetched in the prologue and parked in LDS next
     // to the objective's table (evaluated from global memory it cost a round trip of its own wherever it stood).
-    // Everything these loads need is among the preloaded arguments.  They are issued LAST of the prologue's loads and parked
-    // in LDS behind layer 0 of the first pass: nothing before the very end of the kernel reads them, and ahead of the
-    // weight slices they held the first barrier back by the time it takes to issue them (0.4 - 0.7 us, stamps).
+    // Everything these loads need is among the preloaded arguments, so they go out without waiting for the argument block.
     // (the ranges are recomputed where they are used, at the end of the kernel: kept live across the passes they cost
     // scalar registers the pass code then spills)
     auto obj_range = [&](int side, unsigned& lo, unsigned& hi, int& nlds) {
@@ -723,7 +709,17 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
             pv[u] = idx < pa.p_elems ? gp[idx] : T(0);
         }
     }
+    FX_STAMP_PRO(pa.dbg, 3);
+    constexpr int NFRAG = (NH - 1) * 2 * MT * 4 + 8;
+    constexpr int NLOAD = (NFRAG + VEC - 1) / VEC;
+    vecT wv[NLOAD];
+    {
+        const vecT* __restrict__ ws = static_cast<const vecT*>(pa.wslice) + (size_t)w * NLOAD * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < NLOAD; ++k) wv[k] = ws[k * 64];
+    }
     FX_STAMP_PASS(pa.dbg, 1);
+    FX_STAMP_PRO(pa.dbg, 4);
     cx.dbg = pa.dbg;
     {
         vecT* ls = reinterpret_cast<vecT*>(lds + L::W0F);
@@ -734,26 +730,23 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         }
     }
     FX_STAMP_PRO(pa.dbg, 5);
-    const int p_pad = (pa.p_elems + 15) & ~15;
-    bool parked = false;
-    auto park_objective = [&]() {           // (called behind layer 0 of the first pass)
-        if constexpr (FUSE) {
-            if (parked) return;
-            parked = true;
+    if constexpr (FUSE) {
 #pragma unroll
-            for (int u = 0; u < PV_PER_THREAD; ++u) {
-                const int idx = tid + u * NTHREADS;
-                if (idx < pa.p_elems) lds[L::TOTAL + idx] = pv[u];
-            }
-#pragma unroll
-            for (int side = 0; side < 2; ++side)
-#pragma unroll
-                for (int u = 0; u < ZV_PER_THREAD; ++u) {
-                    const int idx = tid + u * NTHREADS;
-                    if (idx < zcount[side]) lds[L::TOTAL + p_pad + side * FX_ZCOPY + idx] = zv[side][u];
-                }
+        for (int u = 0; u < PV_PER_THREAD; ++u) {
+            const int idx = tid + u * NTHREADS;
+            if (idx < pa.p_elems) lds[L::TOTAL + idx] = pv[u];
         }
-    };
+    }
+    const int p_pad = (pa.p_elems + 15) & ~15;
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int side = 0; side < 2; ++side)
+#pragma unroll
+            for (int u = 0; u < ZV_PER_THREAD; ++u) {
+                const int idx = tid + u * NTHREADS;
+                if (idx < zcount[side]) lds[L::TOTAL + p_pad + side * FX_ZCOPY + idx] = zv[side][u];
+            }
+    }
     FX_STAMP_PASS(pa.dbg, 2);
     FX_STAMP_PRO(pa.dbg, 6);
     CoopWeights<T, WP, NH> W;
@@ -798,9 +791,9 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         FX_STAMP_PRO(pa.dbg, 9);
         const T* in = in_base + parity * L::IN_SZ;
         T* const in_next = in_base + (parity ^ 1) * L::IN_SZ;
-        if (n_cur == 1) fx_pass<T, WP, NH, TPW, NX, NU, 1, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next, park_objective);
-        if constexpr (TPW >= 2) { if (n_cur == 2) fx_pass<T, WP, NH, TPW, NX, NU, 2, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next, park_objective); }
-        if constexpr (TPW >= 3) { if (n_cur == 3) fx_pass<T, WP, NH, TPW, NX, NU, 3, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next, park_objective); }
+        if (n_cur == 1) fx_pass<T, WP, NH, TPW, NX, NU, 1, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next);
+        if constexpr (TPW >= 2) { if (n_cur == 2) fx_pass<T, WP, NH, TPW, NX, NU, 2, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
+        if constexpr (TPW >= 3) { if (n_cur == 3) fx_pass<T, WP, NH, TPW, NX, NU, 3, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
         parity ^= 1;
     }
     if constexpr (FUSE) {
