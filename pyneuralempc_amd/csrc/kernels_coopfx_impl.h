@@ -486,7 +486,19 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             o_tiles[(size_t)t0 * (16 * JROW) + item] = v;
         }
     }
-    // defects: lanes run over (row, state) with the state fastest -> contiguous inside a problem
+    // ---- defects, and -- fused evaluation -- the non-zeros of the dense Jacobian rows, in ONE loop: lanes run over
+    //      (row, state) with the state fastest, which is both the defect entry g[(t, i)] and the dense row (t, i).
+    //      Dense rows, part two: over the background streamed at the start of the pass (fx_zero_rows; every zero store of
+    //      the workgroup was acknowledged before the barrier above) row (t, i) of problem b gets -1 at x_t[i], the tile's
+    //      state block at x_{t-1} (t >= 1), its control block at u_t; box rows (+1 selectors) follow the defect rows of
+    //      each problem.  The lane sums the row's tile entries from the K-split partials in wave order (the unfused
+    //      kernel's loop above) and stores them.
+    T* o_jac = nullptr;
+    if constexpr (FUSE) {
+#if !(defined(NEMPC_EXP_NODENSE) || defined(NEMPC_EXP_NONZ))      // (timing experiments only)
+        o_jac = static_cast<T*>(ka->jac);
+#endif
+    }
 #pragma unroll
     for (int it = 0; it < (NT * 16 * NX + NTHREADS - 1) / NTHREADS; ++it) {
         const int item = tid + it * NTHREADS;
@@ -507,34 +519,9 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             T* gp = o_g + (size_t)b * a_m + t * NX + i;
             gp[0] = phi - xt;
             if (a_box) gp[(size_t)cx.H * NX] = xt;
-        }
-    }
-    FX_STAMP_PASS(cx.dbg, 8);
-    if constexpr (FUSE) {
-        // ---- dense Jacobian rows of the pass, part two: the non-zeros over the background streamed at the start of the
-        //      pass (fx_zero_rows; every zero store of the workgroup was acknowledged before the barrier above).  Row
-        //      (t, i) of problem b holds -1 at x_t[i], the tile's state block at x_{t-1} (t >= 1), its control block at
-        //      u_t; box rows (+1 selectors) follow the defect rows of each problem.  One lane per dense row sums the row's
-        //      tile entries from the K-split partials in wave order (the unfused kernel's loop above) and stores them.
-        T* const o_jac = static_cast<T*>(ka->jac);
-        constexpr int DR = NT * 16 * NX;                                 // dense rows of a full pass
-#if defined(NEMPC_EXP_NODENSE) || defined(NEMPC_EXP_NONZ)      // timing experiments only
-        const bool dense = false;
-#else
-        const bool dense = o_jac != nullptr;
-#endif
-        if (dense) {
-            const int n = cx.n;
-            const unsigned r0 = (unsigned)t0 * 16u;
-#pragma unroll
-            for (int it = 0; it < (DR + NTHREADS - 1) / NTHREADS; ++it) {
-                const int lr = tid + it * NTHREADS;
-                const int lrow = lr / NX, i = lr - lrow * NX;           // compile-time divisor
-                const unsigned r = r0 + (unsigned)lrow;
-                if (lr < DR && r < cx.R) {
-                    const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
-                    const int t = (int)(r - b * (unsigned)cx.H);
-                    const int j = lrow >> 4, cc = lrow & 15;
+            if constexpr (FUSE) {
+                if (o_jac) {
+                    const int n = cx.n;
                     T ts[NIN];
 #pragma unroll
                     for (int d = 0; d < NIN; ++d) {
@@ -564,8 +551,9 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
                 }
             }
         }
-        FX_STAMP_PASS(cx.dbg, 11);
     }
+    FX_STAMP_PASS(cx.dbg, 8);
+    FX_STAMP_PASS(cx.dbg, 11);
     lds_barrier();
     FX_STAMP_PASS(cx.dbg, 12);
 }
