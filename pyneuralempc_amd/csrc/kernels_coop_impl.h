@@ -139,11 +139,20 @@ __device__ __forceinline__ void coop_zero_rows(T* o_jac, unsigned r0, int nrows,
     const vecT zero = {};
     const size_t row_bytes = (size_t)n * sizeof(T);
     const int drv = nrows * nx;                     // dense rows of the pass that exist
+    // a flat run of nv 16-byte vectors from `base`: whole rounds of NTHREADS stores with the lane's offset fixed and the
+    // (scalar) base stepping -- no vector instruction in the loop but the store -- then the partial round
+    auto run = [&](const char* base, int nv) {
+        const int full = nv / NTHREADS;
+        const int voff = tid * 16;
+        for (int k = 0; k < full; ++k) {
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
+            base += NTHREADS * 16;
+        }
+        if (tid < nv - full * NTHREADS)
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
+    };
     if (!box) {
-        const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) + (size_t)r0 * nx * row_bytes);
-        const int nv = (int)((size_t)drv * row_bytes / 16);
-        for (int fv = tid; fv < nv; fv += NTHREADS)
-            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(zero), "s"(base) : "memory");
+        run(fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) + (size_t)r0 * nx * row_bytes), (int)((size_t)drv * row_bytes / 16));
     } else {
         const int HNX = H * nx;
         for (int s0 = 0; s0 < drv;) {
@@ -151,13 +160,9 @@ __device__ __forceinline__ void coop_zero_rows(T* o_jac, unsigned r0, int nrows,
             const unsigned b = invH ? __umulhi(r, invH) : r;
             const int k = (int)(r - b * (unsigned)H) * nx;              // first dense row of the piece within its block
             const int len = drv - s0 < HNX - k ? drv - s0 : HNX - k;    // rows up to the end of the problem / pass
-            const int nv = (int)((size_t)len * row_bytes / 16);
-            for (int kind = 0; kind < 2; ++kind) {
-                const char* base = fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) +
-                                                  ((size_t)b * (2 * HNX) + (size_t)(kind * HNX + k)) * row_bytes);
-                for (int fv = tid; fv < nv; fv += NTHREADS)
-                    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(fv * 16), "v"(zero), "s"(base) : "memory");
-            }
+            for (int kind = 0; kind < 2; ++kind)
+                run(fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) + ((size_t)b * (2 * HNX) + (size_t)(kind * HNX + k)) * row_bytes),
+                    (int)((size_t)len * row_bytes / 16));
             s0 += len;
         }
     }
