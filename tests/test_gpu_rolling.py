@@ -309,3 +309,38 @@ def test_nmpc_next_with_rolling_model_slsqp():
     J, gr = prob.jacobian(z, x0), prob.gradient(z)
     lam = np.linalg.lstsq(J.T, -gr, rcond=None)[0]
     assert np.abs(gr + J.T @ lam).max() < 1e-5
+
+
+@pytest.mark.parametrize("act", ["relu", "sigmoid", "softplus", "elu"])
+def test_rolling_window_and_parameters_with_the_activation_family(act):
+    """The activation is orthogonal to the input gather: a rolling window of 3 with time-varying / constant parameters
+    (extra network inputs) and box rows, every activation, the three kernel families against the oracle incl. the
+    Lagrangian Hessian and the Gauss-Newton callback."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, H, w, ne, B = 2, 1, 6, 3, 2, 5
+    rng = np.random.default_rng(21)
+    net = orc.MLP.random(w * (nx + nu) + ne, [32, 32], nx, seed=5, activations=act)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=8)
+    hx, hu = rng.normal(size=(B, w - 1, nx)), rng.uniform(-1, 1, size=(B, w - 1, nu))
+    ex = rng.normal(size=(H, ne))
+    lamh, sigh, wh = rng.normal(size=(B, 2 * H * nx)), rng.uniform(0.5, 1.5, size=B), rng.uniform(0.2, 1.5, size=(B, H * nx))
+    probs = [orc.Problem(net, H, nx, nu, orc.DISCRET, box=(-2.0, 2.0), extra=ex, window=w, hist_x=hx[i], hist_u=hu[i])
+             for i in range(B)]
+    g = np.stack([p.constraints(Zh[i], X0h[i]) for i, p in enumerate(probs)])
+    jac = np.stack([p.jacobian(Zh[i], X0h[i]) for i, p in enumerate(probs)])
+    hv = np.stack([p.hessian_values(Zh[i], X0h[i], lamh[i], sigh[i]) for i, p in enumerate(probs)])
+    gn = np.stack([p.gauss_newton_values(Zh[i], X0h[i], wh[i], sigh[i]) for i, p in enumerate(probs)])
+    for kernel in ("valu", "mfma", "mfma_tile"):
+        eng = CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B, kernel=kernel,
+                             n_extra=ne, rolling_window=w, activations=act)
+        eng.set_box_rows(-2.0, 2.0)
+        eng.bind_extra(eng.to_device(np.broadcast_to(ex[None], (B, H, ne)).copy()))
+        eng.bind_history(eng.to_device(hx), eng.to_device(hu))
+        Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+        res = eng.eval(Z, X0, ("g", "jac_dense"))
+        np.testing.assert_allclose(res["g"].cpu().numpy(), g, **F64)
+        np.testing.assert_allclose(res["jac_dense"].cpu().numpy(), jac, **F64)
+        h = eng.hess(Z, X0, eng.to_device(lamh), eng.to_device(sigh))["hvals"].cpu().numpy()
+        np.testing.assert_allclose(h, hv, rtol=1e-10, atol=1e-11)
+        hg = eng.hess_gn(Z, X0, eng.to_device(wh), eng.to_device(sigh))["hvals"].cpu().numpy()
+        np.testing.assert_allclose(hg, gn, rtol=1e-11, atol=1e-12)
