@@ -89,6 +89,14 @@ struct FxArgs {   // host-prepared; the fields the first loads need come first
     int zp_max;             // problems whose variables fit the LDS copy (FX_ZCOPY / n; 0 when the table itself is too long)
     long long* dbg;         // diagnostic builds only
     ObjOffsets oo;
+    // ---- Gauss-Newton Hessian callback from this launch (GN instantiation; nempc_hess_gn asked for the tril values only):
+    //      hvals[b][e] = sigma_b * objc[e] + sum_i w_i T_ip T_iq through the scatter form of the Hessian map (see HessParams)
+    void* gn_hvals;
+    const void* gn_sigma;
+    const void* gn_w;       // (B, H*nx) weights per defect row, null = ones
+    const int32_t* gn_smap;
+    const void* gn_objc;
+    int gn_nnz, gn_n_orph;
 };
 
 // The argument block proper, read where it is needed.  Kernel arguments are fetched by scalar loads that the compiler
@@ -292,7 +300,7 @@ __device__ __forceinline__ void fx_zero_rows(T* o_jac, unsigned r0, int nrows, i
 // `nxt` / `in_next` (when has_next): the NEXT pass's inputs, already in registers; they go to the other input buffer
 // BEFORE this pass's global stores are issued -- vmcnt counts stores too and retires in order, so a wait for those loads
 // placed after the stores would sit out the stores' acknowledgement (with the dense rows fused in: the whole HBM time).
-template <typename T, int WP, int NH, int TPW, int NX, int NU, int NT, bool FUSE, int ACT>
+template <typename T, int WP, int NH, int TPW, int NX, int NU, int NT, bool FUSE, int ACT, bool GN = false>
 __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx, const CoopWeights<T, WP, NH>& W,
                                         const T* in, int t0, int tid, int& xsel,
                                         const FxStage<T, TPW, (WP / 16) * 64, NX + NU + NX>& nxt, bool has_next, T* in_next) {
@@ -471,6 +479,78 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
     if (has_next) fx_stage_store<T, WP, NH, TPW, NX, NU, TPW>(in_next, tid, nxt);
     FX_STAMP_PASS(cx.dbg, 7);
 
+    if constexpr (GN) {
+        // ---- Gauss-Newton callback: the blocks sum_i w_i T_i^T T_i and their tril assembly, here -- no tile round trip
+        //      through memory, no assembly launch.  Lanes run over (row, state) with the state fastest: a lane sums ITS
+        //      row of the tile (state i) from the K-split partials, forms w_i T_ip T_iq for the pairs, and the NX lanes
+        //      of a tile row add up by a quad permute (NX = 2); the lane of state 0 writes the block's entries through
+        //      the scatter map (assemble_hess_gn_kernel's arithmetic: sigma * objective constant + block element).
+        static_assert(NX == 2, "the fused Gauss-Newton assembly sums the states of a row by one quad permute");
+        constexpr int NPAIR = NIN * (NIN + 1) / 2, BSZ = NIN * NIN;
+        T* const hv = static_cast<T*>(ka->gn_hvals);
+        const T* const sg = static_cast<const T*>(ka->gn_sigma);
+        const T* const gw = static_cast<const T*>(ka->gn_w);
+        const T* const oc = static_cast<const T*>(ka->gn_objc);
+        const int32_t* const smap = ka->gn_smap;
+        const int nnz = ka->gn_nnz, n_orph = ka->gn_n_orph;
+#pragma unroll
+        for (int it = 0; it < (NT * 16 * NX + NTHREADS - 1) / NTHREADS; ++it) {
+            const int item = tid + it * NTHREADS;
+            const int idx = item / NX, i = item - idx * NX;
+            const unsigned r = (unsigned)t0 * 16u + (unsigned)idx;
+            const bool valid = item < NT * 16 * NX && r < cx.R;
+            const int j = (idx >> 4) < NT ? (idx >> 4) : 0, cc = idx & 15;
+            const unsigned b = cx.invH ? __umulhi(r, cx.invH) : r;
+            const int t = (int)(r - b * (unsigned)cx.H);
+            T c[NPAIR];
+            {
+                T ts[NIN];
+#pragma unroll
+                for (int d = 0; d < NIN; ++d) {
+                    T v = T(0);
+#pragma unroll
+                    for (int ww = 0; ww < MT; ++ww) v += PJ[((i * MT + ww) * (TPW * NIN) + j * NIN + d) * 16 + cc];
+                    if (a_ident && d == i) v += T(1);
+                    ts[d] = valid ? v : T(0);
+                }
+                const T wi = (valid && gw) ? gw[(size_t)b * (cx.H * NX) + t * NX + i] : T(1);
+                int pq = 0;
+#pragma unroll
+                for (int p = 0; p < NIN; ++p) {
+                    const T wp = wi * ts[p];
+#pragma unroll
+                    for (int qq = 0; qq <= p; ++qq, ++pq) c[pq] = wp * ts[qq];
+                }
+            }
+            // + the other state's lane (lanes 2k, 2k+1 hold states 0, 1 of one tile row): state 0 first, then state 1
+#pragma unroll
+            for (int pq = 0; pq < NPAIR; ++pq) {
+                const int lo = __double2loint((double)c[pq]), hi = __double2hiint((double)c[pq]);
+                const int l2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xf, 0xf, false);     // quad_perm [1, 0, 3, 2]
+                const int h2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xf, 0xf, false);
+                const T other = (T)__hiloint2double(h2, l2);
+                c[pq] = i == 0 ? c[pq] + other : other + c[pq];
+            }
+            if (valid && i == 0) {
+                const T sb = sg[b];
+#pragma unroll
+                for (int e = 0; e < BSZ; ++e) {
+                    const int a1 = e / NIN, a2 = e - a1 * NIN;
+                    const int hi2 = a1 > a2 ? a1 : a2, lo2 = a1 > a2 ? a2 : a1;
+                    const int ent = smap[t * BSZ + e];
+                    if (ent >= 0) hv[(size_t)b * nnz + ent] = sb * oc[ent] + c[hi2 * (hi2 + 1) / 2 + lo2];
+                }
+                if (t == cx.H - 1)
+                    for (int e = 0; e < n_orph; ++e) {
+                        const int oe = smap[cx.H * BSZ + e];
+                        hv[(size_t)b * nnz + oe] = sb * oc[oe];
+                    }
+            }
+        }
+        lds_barrier();
+        return;
+    }
+
     // ---- outputs straight from the partials (no reduction phase): the sum over the MT waves is taken here, in wave
     //      order like the generic kernel's reduction
     // tiles: the pass's NT*16 rows are contiguous in memory -> lanes run over the flat element index (coalesced).
@@ -564,7 +644,8 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 }
 
 // FUSE: the whole hessian-free evaluation in this launch -- g, [tiles,] dense jac, f, grad
-template <typename T, int WP, int NH, int TPW, int NX, int NU, bool FUSE, int ACT>
+// GN: the Gauss-Newton Hessian callback from this launch (tril values only; no g / tiles / dense outputs)
+template <typename T, int WP, int NH, int TPW, int NX, int NU, bool FUSE, int ACT, bool GN = false>
 __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     // what the prologue's loads depend on, as plain arguments: with -amdgpu-kernarg-preload-count the leading 14 dwords are
     // in scalar registers when the wave starts instead of behind a scalar-load round trip (the struct carries the rest;
@@ -784,9 +865,9 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
         FX_STAMP_PRO(pa.dbg, 9);
         const T* in = in_base + parity * L::IN_SZ;
         T* const in_next = in_base + (parity ^ 1) * L::IN_SZ;
-        if (n_cur == 1) fx_pass<T, WP, NH, TPW, NX, NU, 1, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next);
-        if constexpr (TPW >= 2) { if (n_cur == 2) fx_pass<T, WP, NH, TPW, NX, NU, 2, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
-        if constexpr (TPW >= 3) { if (n_cur == 3) fx_pass<T, WP, NH, TPW, NX, NU, 3, FUSE, ACT>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
+        if (n_cur == 1) fx_pass<T, WP, NH, TPW, NX, NU, 1, FUSE, ACT, GN>(cx, W, in, t_cur, tid, xsel, sr, more, in_next);
+        if constexpr (TPW >= 2) { if (n_cur == 2) fx_pass<T, WP, NH, TPW, NX, NU, 2, FUSE, ACT, GN>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
+        if constexpr (TPW >= 3) { if (n_cur == 3) fx_pass<T, WP, NH, TPW, NX, NU, 3, FUSE, ACT, GN>(cx, W, in, t_cur, tid, xsel, sr, more, in_next); }
         parity ^= 1;
     }
     if constexpr (FUSE) {

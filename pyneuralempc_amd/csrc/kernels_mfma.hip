@@ -1,6 +1,7 @@
 // Host side of the matrix-core row kernel: shape gate, weight packing, launch geometry.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "kernels_hess_impl.h"
 
@@ -233,6 +234,21 @@ int launch_eval_fused(Handle& h, int B, const void* Z, const void* X0, void* g, 
     p.obj = h.d_obj;
     p.oo = obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu);
     return h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+}
+
+// Gauss-Newton Hessian callback (tril values) in ONE launch of the fixed-shape kernel: the blocks sum_i w_i T_i^T T_i are
+// formed and assembled in the row kernel's epilogue.  NEMPC_EUNSUPPORTED (nothing launched) for every other shape, for
+// rolling windows, and when the Hessian map has no scatter form.
+int launch_hess_gn_fused(Handle& h, int B, const void* Z, const void* X0, const void* w, const void* sigma, void* hvals,
+                         hipStream_t s) {
+    static const int on = [] { const char* e = getenv("NEMPC_GN_FUSED"); return e ? atoi(e) : 1; }();
+    if (!on || !h.mfma.blob || !hvals || h.w != 1 || !h.d_hess_smap || h.hess_n_orph < 0 || h.cfg.dtype != NEMPC_F64)
+        return NEMPC_EUNSUPPORTED;
+    MfmaParams p = base_params(h, B, Z, X0, h.d_g_ws, nullptr);
+    p.gn_hvals = hvals; p.gn_sigma = sigma; p.gn_w = w; p.gn_smap = h.d_hess_smap;
+    p.gn_objc = (const char*)h.d_obj + (size_t)obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu).total * h.esz;
+    p.gn_nnz = (int)h.hess_rows.size(); p.gn_n_orph = h.hess_n_orph;
+    return launch_rows_mfma_typed<double>(h, p, s);
 }
 
 // Rows, compact tiles (optional) and the DENSE Jacobian from one launch of the cooperative kernel (any shape it takes,

@@ -72,6 +72,13 @@ struct MfmaParams {
     void* fuse_grad;
     const void* obj;
     ObjOffsets oo;
+    // Gauss-Newton Hessian callback from the row launch (fixed-shape kernel only, launch_hess_gn_fused)
+    void* gn_hvals;
+    const void* gn_sigma;
+    const void* gn_w;
+    const int32_t* gn_smap;
+    const void* gn_objc;
+    int gn_nnz, gn_n_orph;
 };
 
 // In-kernel stamps exist only in the diagnostic library built by tools/diag_stamps.py; the shipped

@@ -692,6 +692,11 @@ int nempc_hess_gn(nempc_handle hh, int32_t B, const void* Z, const void* X0, con
     DeviceGuard dg(h.cfg.device);
     if (!dg.ok) return fail(NEMPC_EHIP, "nempc_hess_gn: hipSetDevice failed");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // compiled shape, tril values only: blocks and assembly in the row launch's epilogue (one launch)
+    if (hvals && !hdense && !hblocks && h.variant == NEMPC_KERNEL_MFMA) {
+        const int rc1 = launch_hess_gn_fused(h, B, Z, X0, w, sigma, hvals, s);
+        if (rc1 != NEMPC_EUNSUPPORTED) return rc1;
+    }
     // first-order model only: the row kernel's tiles (no second-order sweep), then the same assembly as nempc_hess
     int rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, h.d_g_ws, h.d_tiles_ws, s)
                                             : launch_rows_valu(h, B, Z, X0, h.d_g_ws, h.d_tiles_ws, s);

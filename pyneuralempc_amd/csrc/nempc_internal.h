@@ -198,6 +198,8 @@ int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, v
 int launch_eval_fused(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, void* f,
                       void* grad, hipStream_t s);
 int launch_rows_mfma_dense(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, hipStream_t s);
+int launch_hess_gn_fused(Handle& h, int B, const void* Z, const void* X0, const void* w, const void* sigma, void* hvals,
+                         hipStream_t s);
 void mfma_free(Handle& h);
 int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
                         hipStream_t s);
