@@ -762,10 +762,13 @@ class Rank:
         w = 8 if cfg["dtype"] == "f64" else 4
         row_flops = res["work"]["flops"]
         hess_flops = row_flops * (2 + 2 * nin) / (1 + nx) + (row_flops if S == 4 else 0)
-        t_h = self.timed_events(lambda: eng.hess(Z, X0, lam, sig), reps)
-        hv = eng.hess(Z, X0, lam, sig)["hvals"]
-        t_g = self.timed_events(lambda: eng.hess_gn(Z, X0, wgt, sig), reps)
-        gv = eng.hess_gn(Z, X0, wgt, sig)["hvals"]
+        # (bound calls: at B = 256 a callback is 10 us of device time, less than the checked Python wrapper costs per call)
+        call_h, out_h = eng.bind_hess(Z, X0, lam, sig)
+        t_h = self.timed_events(call_h, reps)
+        hv = out_h["hvals"].clone()
+        call_g, out_g = eng.bind_hess(Z, X0, wgt, sig, gauss_newton=True)
+        t_g = self.timed_events(call_g, reps)
+        gv = out_g["hvals"].clone()
         torch.cuda.synchronize(self.dev)
         _, prob = oracle_problem(cfg)
         k = min(16, B)
@@ -798,7 +801,10 @@ class Rank:
                                        "flops_matrix_executed": row_flops * (2 + nin) / (1 + nx) + (row_flops if S == 4 else 0),
                                        "frac_of_executed": (row_flops * (2 + nin) / (1 + nx) + (row_flops if S == 4 else 0)) / t_h / 1e12 / peak_tf}},
                 "gauss_newton": {"us": t_g * 1e6, "batch_evals_per_s": 1.0 / t_g, "max_abs_err_vs_cpu": e_g,
-                                 "roofline": {"bound": "mfma", "kernel": "row kernel (tiles) + assemble_hess_gn_kernel: two launches",
+                                 "roofline": {"bound": "mfma", "kernel": ("rows_coopfx_kernel<..., GN = true>: tiles, blocks and tril assembly in one launch"
+                                                                          if (cfg["nx"], cfg["nu"], cfg["hidden"], cfg["dtype"]) == (2, 1, [64, 64], "f64")
+                                                                          and os.environ.get("NEMPC_GN_FUSED", "1") != "0"
+                                                                          else "row kernel (tiles) + assemble_hess_gn_kernel: two launches"),
                                               "achieved": row_flops / t_g / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
                                               "frac": row_flops / t_g / 1e12 / peak_tf, "traffic": None,
                                               "flops_per_callback": row_flops, "bytes_written": out_bytes,

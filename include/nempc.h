@@ -207,7 +207,9 @@ int nempc_hess_gn(nempc_handle h, int32_t B, const void* Z, const void* X0, cons
  *   Box ROWS (nempc_set_box_rows) are state limits: they are intersected with lb / ub on the state variables (what the
  *   reference's glue would hand Ipopt as constraint rows, optimizer/ipopt.py:44-52, is a bound here).
  *   lb[i] == ub[i] (a fixed variable) is NEMPC_EINVAL: the log barrier needs an interior.
- *   rolling_window > 1 is NEMPC_EUNSUPPORTED (the stage structure the Riccati sweep relies on is gone). */
+ *   rolling_window > 1: needs nempc_bind_history.  The window is made the state (s_t = the last w states and w-1
+ *   controls, w*nx + (w-1)*nu entries) and the same solver runs on that stage-wise problem, the callbacks staying the
+ *   window kernels on the caller's variables; one trial step per iteration and no compaction whatever the options say. */
 typedef struct nempc_solver_opts {
     int32_t max_iter;        /* outer iterations, e.g. 200 */
     int32_t max_linesearch;  /* halvings of a step before the direction is given up and the next LQ solve damped, e.g. 6 */

@@ -73,12 +73,14 @@ class NMPC:
         return z[:nxh].reshape(self.integrator.H, -1), z[nxh:].reshape(self.integrator.H, -1)
 
 
-    def next_batch(self, X0, init_z=None, p=None, tvp=None, **solver_opts):
+    def next_batch(self, X0, init_z=None, p=None, tvp=None, prev_x=None, prev_u=None, prev_tvp=None, **solver_opts):
         """Solve B MPC problems at once on the device (no reference counterpart).  X0 (B,nx) NumPy
         array or device tensor.  Needs the fused device path (device integrator + QuadraticObjective; the only
         extra rows accepted are BoxStateConstraint, which become bounds on the state variables).  Models with
         parameters take p (p_dim,) or (B,p_dim) and tvp (H,tvp_dim) or (B,H,tvp_dim) -- one set for all problems or one
-        per problem (the batched form of NMPC.next's p / tvp, controller.py:65).  Returns (states (B,H,nx), u (B,H,nu),
+        per problem (the batched form of NMPC.next's p / tvp, controller.py:65).  Rolling-window models take the histories
+        prev_x (w-1, nx) or (B, w-1, nx), prev_u, prev_tvp -- the batched form of set_prev_data (model/tensorflow.py:178-189);
+        left out, what set_prev_data stored serves every problem.  Returns (states (B,H,nx), u (B,H,nu),
         status (B,) with Optimizer.SUCCESS / FAIL per problem) as NumPy arrays."""
         import torch
         from .optimizer.base import fused_evaluator
@@ -95,6 +97,22 @@ class NMPC:
         X0t = X0 if isinstance(X0, torch.Tensor) else eng.to_device(np.atleast_2d(np.asarray(X0, dtype=np.float64)))
         B = int(X0t.shape[0])
         model = self.integrator.model
+        w = int(getattr(model, "rolling_window", 1))
+
+        def history(given, stored, d, name):
+            v = stored if given is None else given
+            if v is None:
+                raise ValueError(f"rolling-window model: pass {name} or call set_prev_data first")
+            v = np.asarray(v, dtype=np.float64)
+            if v.shape[-2:] != (w - 1, d) or v.ndim not in (2, 3) or (v.ndim == 3 and v.shape[0] != B):
+                raise ValueError(f"{name} must have shape {(w - 1, d)} or {(B, w - 1, d)} (received : {v.shape})")
+            return np.ascontiguousarray(np.broadcast_to(v if v.ndim == 3 else v[None], (B, w - 1, d)))
+
+        if w > 1:
+            eng.bind_history(eng.to_device(history(prev_x, model.prev_x, model.x_dim, "prev_x")),
+                             eng.to_device(history(prev_u, model.prev_u, model.u_dim, "prev_u")))
+        elif prev_x is not None or prev_u is not None or prev_tvp is not None:
+            raise ValueError("this model has no rolling window: it takes no prev_x / prev_u / prev_tvp")
         if model.p_dim + model.tvp_dim:
             # extra network inputs of every problem: (B, H, tvp_dim + p_dim) = [tvp_t | p], the reference's
             # concatenation order (model/tensorflow.py:39-47); a (1, ...) binding left by NMPC.next never serves B > 1
@@ -104,6 +122,9 @@ class NMPC:
                     raise ValueError("this model has tvp_dim > 0: pass tvp (H, tvp_dim) or (B, H, tvp_dim)")
                 tv = np.asarray(tvp, dtype=np.float64)
                 tv = np.broadcast_to(tv if tv.ndim == 3 else tv[None], (B, H, model.tvp_dim))
+                if w > 1:      # rolled like the states: (B, H, w * tvp_dim)  (_gather_input_V2, model/tensorflow.py:218-233)
+                    ptv = history(prev_tvp, model.prev_tvp, model.tvp_dim, "prev_tvp")
+                    tv = np.stack([model._roll(ptv[b], tv[b]) for b in range(B)], axis=0)
                 parts.append(tv)
             if model.p_dim:
                 if p is None:

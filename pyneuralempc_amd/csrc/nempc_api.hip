@@ -718,7 +718,9 @@ int nempc_solve(nempc_handle hh, int32_t B, const void* X0, void* Z, const doubl
     if (!h.have_weights) return fail(NEMPC_ESTATE, "nempc_solve: call nempc_set_weights first");
     if (h.ne > 0 && !h.d_extra) return fail(NEMPC_ESTATE, "nempc_solve: n_extra > 0 but nempc_bind_extra was not called");
     if (h.ne > 0 && B > h.extra_B) return fail(NEMPC_EINVAL, "nempc_solve: B exceeds the batch the bound extras cover");
-    if (h.w > 1) return fail(NEMPC_EUNSUPPORTED, "nempc_solve: rolling-window models are not handled by the batched solver");
+    if (h.w > 1 && !h.d_hist_x)
+        return fail(NEMPC_ESTATE, "nempc_solve: rolling_window > 1 but nempc_bind_history was not called");
+    if (h.w > 1 && B > h.hist_B) return fail(NEMPC_EINVAL, "nempc_solve: B exceeds the batch the bound history covers");
     if (opts->max_iter < 1 || opts->max_linesearch < 1 || !(opts->mu_factor > 0.0 && opts->mu_factor < 1.0) ||
         !(opts->mu_init > 0.0) || !(opts->mu_min > 0.0) || opts->lq_kernel < 0 || opts->lq_kernel > 2)
         return fail(NEMPC_EINVAL, "nempc_solve: bad options");

@@ -1513,6 +1513,18 @@ __global__ __launch_bounds__(64) void solver_trial_list_kernel(int n, int nx, in
 }
 
 // strictly interior start + per-problem state
+// the caller's initial guess, moved into the interior of its bounds.  Distance kept from a bound: 1e-2 for the default
+// barrier parameter; a warm start (small mu_init) stays closer to the active bounds it was handed
+template <typename T>
+__device__ __forceinline__ T start_inside(T z, T lo, T hi, T mu0, int has_bounds) {
+    const bool flo = lo > -std::numeric_limits<T>::max(), fhi = hi < std::numeric_limits<T>::max();
+    T marg = has_bounds ? fmin(T(1e-2), fmax(T(10) * mu0, T(1e-6))) : T(1e-2);
+    if (flo && fhi) marg = fmin(marg, T(0.25) * (hi - lo));
+    if (flo) z = fmax(z, lo + marg);
+    if (fhi) z = fmin(z, hi - marg);
+    return z;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void solver_init_kernel(int B, int n, T* __restrict__ Z, const T* __restrict__ lb,
                                                           const T* __restrict__ ub, T* mu, T* nu, T* reg, int* status,
@@ -1536,13 +1548,7 @@ __global__ __launch_bounds__(256) void solver_init_kernel(int B, int n, T* __res
     const int k = (int)(i % n);
     const T lo = lb[k], hi = ub[k];
     const bool flo = lo > -std::numeric_limits<T>::max(), fhi = hi < std::numeric_limits<T>::max();
-    T z = Zin[i];
-    // distance kept from a bound: 1e-2 for the default barrier parameter; a warm start (small mu_init) stays closer to
-    // the active bounds it was handed
-    T marg = has_bounds ? fmin(T(1e-2), fmax(T(10) * mu0, T(1e-6))) : T(1e-2);
-    if (flo && fhi) marg = fmin(marg, T(0.25) * (hi - lo));
-    if (flo) z = fmax(z, lo + marg);
-    if (fhi) z = fmin(z, hi - marg);
+    const T z = start_inside(Zin[i], lo, hi, mu0, has_bounds);
     Z[i] = z;
     if (zl) {   // bound multipliers on the central path of the first barrier parameter
         zl[i] = flo ? mu0 / (z - lo) : T(0);
@@ -1615,7 +1621,127 @@ __global__ __launch_bounds__(256) void solver_scatter_kernel(int B, int n, const
     }
 }
 
+// ---- rolling-window models (model/tensorflow.py:132-340: the network of step t reads the last w states and controls).
+// The Riccati sweeps need a STAGE-wise problem: the window is made the state,
+//     s_tau = [x_tau, x_{tau-1}, .., x_{tau-w+1} | u_{tau-1}, .., u_{tau-w+1}]            (ns = w nx + (w-1) nu entries)
+//     s_{t+1} = [Phi(window of step t) ; shifted copies of s_t and u_t]
+// (x_tau indexes [x0 ; states], slots before the horizon are x0 and the bound history and make up s_0), and the solver
+// runs UNCHANGED on that plain problem with stage dimensions (ns, nu).  The callbacks stay the handle's own window kernels
+// on the caller's variables: before an evaluation the primary copies [x_tau | u_t] are gathered out of the augmented
+// iterate; after it the defects, tiles, Lagrangian blocks and the objective gradient are spread into augmented form --
+// a tile / block column of the window IS a column of (s_t, u_t), and the shift rows are constant 0/1 rows.  The shift
+// rows are linear and hold at the start (the copies are built from the primaries), so every Newton step keeps them and
+// the network is always evaluated at the point the augmented iterate stands on.
+struct RollTables {        // device, int32; built once per workspace (they depend on the handle's shape only)
+    int* src = nullptr;    // (n_s)  augmented variable -> caller's variable v >= 0, or -(1 + k): entry k of the problem's data
+                           //        [x0 (nx) | hist_x (w-1, nx) | hist_u (w-1, nu)]
+    int* src0 = nullptr;   // (ns)   the same for s_0 (data only)
+    int* prim = nullptr;   // (n_r)  caller's variable -> its primary copy in the augmented vector
+    int* isprim = nullptr; // (n_s)  1 where the augmented variable is a primary copy
+    int* dcol = nullptr;   // (ns + nu) column of (s_t, u_t) -> window column of the handle's tiles / blocks
+    int* shift = nullptr;  // (ns)   row i >= nx of a stage: column of (s_t, u_t) it copies
+};
+
+template <typename T>
+__device__ __forceinline__ T roll_data(int k, int b, int nx, int nu, int back, const T* __restrict__ X0,
+                                       const T* __restrict__ hx, const T* __restrict__ hu) {
+    if (k < nx) return X0[(size_t)b * nx + k];
+    k -= nx;
+    if (k < back * nx) return hx[(size_t)b * back * nx + k];
+    return hu[(size_t)b * back * nu + (k - back * nx)];
+}
+
+// augmented start: primaries = the caller's guess moved inside its bounds (what solver_init_kernel would do to them:
+// it then leaves them alone), copies = those same values, s_0 from the data
+template <typename T>
+__global__ __launch_bounds__(256) void roll_build_kernel(int B, int n_s, int ns, int n_r, int nx, int nu, int back,
+                                                         RollTables rt, const T* __restrict__ Zin, const T* __restrict__ X0,
+                                                         const T* __restrict__ hx, const T* __restrict__ hu,
+                                                         const T* __restrict__ lb, const T* __restrict__ ub, T mu0,
+                                                         int has_bounds, T* __restrict__ Zaug, T* __restrict__ S0) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)B * ns) {
+        const int b = (int)(i / ns), k = (int)(i % ns);
+        S0[i] = roll_data(-1 - rt.src0[k], b, nx, nu, back, X0, hx, hu);
+    }
+    if (i >= (size_t)B * n_s) return;
+    const int b = (int)(i / n_s), k = (int)(i % n_s);
+    const int v = rt.src[k];
+    if (v < 0) { Zaug[i] = roll_data(-1 - v, b, nx, nu, back, X0, hx, hu); return; }
+    const int pk = rt.prim[v];
+    Zaug[i] = start_inside(Zin[(size_t)b * n_r + v], lb[pk], ub[pk], mu0, has_bounds);
+}
+
+// caller's variables (and multipliers of the network rows) out of the augmented ones
+template <typename T>
+__global__ __launch_bounds__(256) void roll_in_kernel(int B, int n_s, int n_r, int H, int nx, int ns, int m_r, RollTables rt,
+                                                      const T* __restrict__ Zaug, T* __restrict__ Zr,
+                                                      const T* __restrict__ lam_aug, T* __restrict__ lam_r) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)B * n_r) {
+        const int b = (int)(i / n_r), v = (int)(i % n_r);
+        Zr[i] = Zaug[(size_t)b * n_s + rt.prim[v]];
+    }
+    if (lam_r && i < (size_t)B * H * nx) {
+        const int b = (int)(i / (H * nx)), r = (int)(i % (H * nx));
+        lam_r[(size_t)b * m_r + r] = lam_aug[(size_t)b * H * ns + (r / nx) * ns + (r % nx)];
+    }
+}
+
+// the window evaluation spread into augmented form; one workgroup per (problem, step).  Any of tiles / hblk / grad may be
+// null (a trial point needs the defects only)
+template <typename T>
+__global__ __launch_bounds__(256) void roll_out_kernel(int H, int nx, int nu, int ns, int nin_w, int n_r, int m_r, RollTables rt,
+                                                       const T* __restrict__ Zaug, const T* __restrict__ S0,
+                                                       const T* __restrict__ g_r, const T* __restrict__ tiles_r,
+                                                       const T* __restrict__ hblk_r, const T* __restrict__ grad_r,
+                                                       T* __restrict__ g_aug, T* __restrict__ tiles_aug,
+                                                       T* __restrict__ hblk_aug, T* __restrict__ grad_aug) {
+    const int b = blockIdx.x / H, t = blockIdx.x % H, nin_s = ns + nu, n_s = H * nin_s;
+    const T* za = Zaug + (size_t)b * n_s;
+    // value of column c of (s_t, u_t)
+    auto col_value = [&](int c) -> T {
+        if (c >= ns) return za[H * ns + t * nu + (c - ns)];
+        return t == 0 ? S0[(size_t)b * ns + c] : za[(t - 1) * ns + c];
+    };
+    for (int i = threadIdx.x; i < ns; i += 256)
+        g_aug[(size_t)b * H * ns + t * ns + i] =
+            i < nx ? g_r[(size_t)b * m_r + t * nx + i] : col_value(rt.shift[i]) - za[t * ns + i];
+    if (tiles_aug) {
+        T* ta = tiles_aug + ((size_t)b * H + t) * ns * nin_s;
+        const T* tr = tiles_r + ((size_t)b * H + t) * nx * nin_w;
+        for (int e = threadIdx.x; e < ns * nin_s; e += 256) {
+            const int i = e / nin_s, c = e % nin_s;
+            T v;
+            if (i < nx) { const int d = rt.dcol[c]; v = d >= 0 ? tr[i * nin_w + d] : T(0); }
+            else v = rt.shift[i] == c ? T(1) : T(0);
+            ta[e] = v;
+        }
+    }
+    if (hblk_aug) {
+        T* ha = hblk_aug + ((size_t)b * H + t) * nin_s * nin_s;
+        const T* hr = hblk_r + ((size_t)b * H + t) * nin_w * nin_w;
+        for (int e = threadIdx.x; e < nin_s * nin_s; e += 256) {
+            const int dp = rt.dcol[e / nin_s], dq = rt.dcol[e % nin_s];
+            ha[e] = (dp >= 0 && dq >= 0) ? hr[dp * nin_w + dq] : T(0);
+        }
+    }
+    if (grad_aug) {
+        // this step's share of the gradient: the state block s_{t+1} and the control block u_t
+        for (int i = threadIdx.x; i < nin_s; i += 256) {
+            const int k = i < ns ? t * ns + i : H * ns + t * nu + (i - ns);
+            grad_aug[(size_t)b * n_s + k] = rt.isprim[k] ? grad_r[(size_t)b * n_r + rt.src[k]] : T(0);
+        }
+    }
+}
+
 struct SolverWs {
+    // rolling-window models: tables, the caller-side evaluation buffers and the augmented objective table
+    RollTables rt;
+    void *rZ = nullptr, *rg = nullptr, *rtiles = nullptr, *rhblk = nullptr, *rgrad = nullptr, *rlam = nullptr,
+         *rZin = nullptr, *rS0 = nullptr, *rZout = nullptr, *robj = nullptr;
+    std::vector<int> prim_host;               // (n_r) primary copy of every caller variable
+    std::vector<unsigned char> robj_host;     // the augmented objective table as last uploaded
     void *Zt = nullptr, *f = nullptr, *ft = nullptr, *grad = nullptr, *g = nullptr, *gt = nullptr, *tiles = nullptr;
     void *tiles_t = nullptr, *grad_t = nullptr;     // trial point's tiles and objective gradient (carried over on acceptance)
     void *X0p = nullptr, *exp_ = nullptr;           // initial states / extras of the problems still backtracking, dense
@@ -1674,6 +1800,10 @@ void solver_free(Handle& h) {
         if (p) (void)hipFree(p);
     if (w->perm) (void)hipFree(w->perm);
     if (w->count) (void)hipFree(w->count);
+    for (void* p : {w->rZ, w->rg, w->rtiles, w->rhblk, w->rgrad, w->rlam, w->rZin, w->rS0, w->rZout, w->robj,
+                    (void*)w->rt.src, (void*)w->rt.src0, (void*)w->rt.prim, (void*)w->rt.isprim, (void*)w->rt.dcol,
+                    (void*)w->rt.shift})
+        if (p) (void)hipFree(p);
     delete w;
     h.solver_ws = nullptr;
 }
@@ -1692,7 +1822,12 @@ struct ExtraBindingGuard {
 template <typename T>
 static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* lb, const double* ub,
                       const nempc_solver_opts& o, int32_t* status_dev, int32_t* iters_host, hipStream_t s) {
-    const int H = h.cfg.H, nx = h.cfg.nx, nu = h.cfg.nu, nin = h.nin, n = h.n, m = h.m;
+    // rolling-window models run as a plain problem in the augmented (window) state, see RollTables: nx, nin, n, m below are
+    // the SOLVER's stage dimensions; *_r the handle's (the caller's variables, the callbacks' shapes)
+    const bool rolling = h.w > 1;
+    const int H = h.cfg.H, nx_r = h.cfg.nx, nu = h.cfg.nu, nin_r = h.nin, n_r = h.n, m_r = h.m, back = h.w - 1;
+    const int nx = rolling ? h.w * nx_r + back * nu : nx_r, nin = rolling ? nx + nu : nin_r, n = rolling ? H * (nx + nu) : n_r,
+              m = rolling ? H * nx : m_r;
     const size_t ex_per = (size_t)H * h.ne;
     if (!h.solver_ws) h.solver_ws = new SolverWs();
     {
@@ -1731,6 +1866,63 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
             NEMPC_HIP(hipHostGetDevicePointer((void**)&w2.hpub_dev, w2.hpub, 0));
             NEMPC_HIP(hipMalloc((void**)&w2.perm, Bn * sizeof(int)));
             NEMPC_HIP(hipMalloc((void**)&w2.count, sizeof(int)));
+            if (rolling) {
+                struct { void** p; size_t bytes; } alr[] = {
+                    {&w2.rZ, Bn * n_r * e}, {&w2.rg, Bn * m_r * e}, {&w2.rtiles, Bn * H * nx_r * nin_r * e},
+                    {&w2.rhblk, Bn * H * nin_r * nin_r * e}, {&w2.rgrad, Bn * n_r * e}, {&w2.rlam, Bn * m_r * e},
+                    {&w2.rZin, Bn * n * e}, {&w2.rS0, Bn * nx * e}, {&w2.rZout, Bn * n * e},
+                    {&w2.robj, (size_t)obj_offsets(H, nx, nu).total * e}};
+                for (auto& x : alr) NEMPC_HIP(hipMalloc(x.p, x.bytes));
+                NEMPC_HIP(hipMemsetAsync(w2.rlam, 0, Bn * m_r * e, s));     // (box rows of the handle keep zero multipliers)
+                // index tables.  x-slot k of s_tau is x_{tau-k} (index into [x0 ; states]), u-slot k is u_{tau-1-k}
+                const int wx = h.w * nx_r;
+                auto data_x = [&](int tau, int c) { return tau == 0 ? c : nx_r + (back + tau) * nx_r + c; };           // tau <= 0
+                auto data_u = [&](int tau, int c) { return nx_r + back * nx_r + (back + tau) * nu + c; };               // tau < 0
+                std::vector<int> src(n), src0(nx), prim(n_r, -1), isprim(n, 0), dcol(nin, -1), shift(nx, -1);
+                auto slot_source = [&](int tau_s, int i) {     // entry i of s_{tau_s}: caller variable or -(1 + data index)
+                    if (i < wx) {
+                        const int tau = tau_s - i / nx_r, c = i % nx_r;
+                        return tau >= 1 ? (tau - 1) * nx_r + c : -(1 + data_x(tau, c));
+                    }
+                    const int k = (i - wx) / nu, c = (i - wx) % nu, tau = tau_s - 1 - k;
+                    return tau >= 0 ? H * nx_r + tau * nu + c : -(1 + data_u(tau, c));
+                };
+                for (int i = 0; i < nx; ++i) src0[i] = slot_source(0, i);
+                for (int t = 0; t < H; ++t) {
+                    for (int i = 0; i < nx; ++i) {
+                        src[t * nx + i] = slot_source(t + 1, i);
+                        if (i < nx_r) { isprim[t * nx + i] = 1; prim[t * nx_r + i] = t * nx + i; }
+                    }
+                    for (int c = 0; c < nu; ++c) {
+                        const int k = H * nx + t * nu + c;
+                        src[k] = H * nx_r + t * nu + c; isprim[k] = 1; prim[H * nx_r + t * nu + c] = k;
+                    }
+                }
+                // window column d of step t (network input order, window_var in nempc_api.hip) -> column of (s_t, u_t)
+                for (int d = 0; d < nin_r; ++d) {
+                    int col;
+                    if (d < wx) {
+                        const int j = d / nx_r, c = d % nx_r;
+                        col = (h.rev ? j : back - j) * nx_r + c;                 // x_{t - k}: x-slot k of s_t
+                    } else {
+                        const int j = (d - wx) / nu, c = (d - wx) % nu, k = h.rev ? j : back - j;   // u_{t - k}
+                        col = k == 0 ? nx + c : wx + (k - 1) * nu + c;
+                    }
+                    dcol[col] = d;
+                }
+                // shift rows of s_{t+1}: x-slot k >= 1 copies x-slot k-1 of s_t; u-slot 0 copies u_t, u-slot k copies u-slot k-1
+                for (int i = nx_r; i < nx; ++i) {
+                    if (i < wx) shift[i] = i - nx_r;
+                    else { const int k = (i - wx) / nu, c = (i - wx) % nu; shift[i] = k == 0 ? nx + c : wx + (k - 1) * nu + c; }
+                }
+                struct { int** p; const std::vector<int>* v; } tb[] = {{&w2.rt.src, &src}, {&w2.rt.src0, &src0}, {&w2.rt.prim, &prim},
+                                                                       {&w2.rt.isprim, &isprim}, {&w2.rt.dcol, &dcol}, {&w2.rt.shift, &shift}};
+                for (auto& x : tb) {
+                    NEMPC_HIP(hipMalloc((void**)x.p, x.v->size() * sizeof(int)));
+                    NEMPC_HIP(hipMemcpy(*x.p, x.v->data(), x.v->size() * sizeof(int), hipMemcpyHostToDevice));
+                }
+                w2.prim_host = prim;
+            }
             w2.cap = B;
             w2.m = m; w2.n = n;
             w2.ex_per = ex_per;
@@ -1740,22 +1932,23 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
     // bounds -> device (dtype T); +-inf become +-max so that comparisons stay exact.  Box ROWS on the states
     // (nempc_set_box_rows; a Constraint's rows in the reference's glue, optimizer/ipopt.py:44-52) are bounds on the
     // state variables for this solver: intersected here, what controller.py:101-105 of this package does on the host.
-    std::vector<T> hl(n), hu(n);
-    bool has_bounds = false;
     const T big = std::numeric_limits<T>::max();
-    for (int i = 0; i < n; ++i) {
+    std::vector<T> hl(n, -big), hu(n, big);      // (rolling: the copies inside the window state carry no bounds of their own)
+    bool has_bounds = false;
+    for (int i = 0; i < n_r; ++i) {
         double lo = lb ? lb[i] : -INFINITY, hi = ub ? ub[i] : INFINITY;
-        if (h.box && i < H * nx) {
-            lo = std::max(lo, h.box_lo[i % nx]);
-            hi = std::min(hi, h.box_hi[i % nx]);
+        if (h.box && i < H * nx_r) {
+            lo = std::max(lo, h.box_lo[i % nx_r]);
+            hi = std::min(hi, h.box_hi[i % nx_r]);
         }
         if (lo > hi) { set_error("nempc_solve: lb > ub"); return NEMPC_EINVAL; }
         if (lo == hi) {
             set_error("nempc_solve: lb == ub (a fixed variable has no interior for the barrier); eliminate it from the problem");
             return NEMPC_EINVAL;
         }
-        hl[i] = std::isfinite(lo) ? (T)lo : -big;
-        hu[i] = std::isfinite(hi) ? (T)hi : big;
+        const int k = rolling ? ws.prim_host[i] : i;
+        hl[k] = std::isfinite(lo) ? (T)lo : -big;
+        hu[k] = std::isfinite(hi) ? (T)hi : big;
         has_bounds = has_bounds || std::isfinite(lo) || std::isfinite(hi);
     }
     // (an MPC loop solves with the same bounds every step: they are uploaded when they change)
@@ -1781,16 +1974,60 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         h.extra_B = B;
     }
     const unsigned gBn = (unsigned)(((size_t)B * std::max(n, std::max(m, nx)) + 255) / 256);
+    const void* Zstart = Z;
+    const void* X0start = X0;
+    const void* obj_dev = h.d_obj;
+    if (rolling) {
+        // the window state's start (augmented guess, s_0) and the objective table over the augmented stage: the caller's
+        // weights on the primary block of s, zeros on the copies
+        hipLaunchKernelGGL(roll_build_kernel<T>, dim3(gBn), dim3(256), 0, s, B, n, nx, n_r, nx_r, nu, back, ws.rt, (const T*)Z,
+                           (const T*)X0, (const T*)h.d_hist_x, (const T*)h.d_hist_u, (const T*)ws.lb, (const T*)ws.ub,
+                           (T)o.mu_init, has_bounds ? 1 : 0, (T*)ws.rZin, (T*)ws.rS0);
+        Zstart = ws.rZin; X0start = ws.rS0;
+        const ObjOffsets ao = obj_offsets(H, nx, nu);
+        const ObjHost& oh = h.obj_host;
+        const std::vector<double>& QT = h.obj_QT.empty() ? oh.Q : h.obj_QT;
+        std::vector<T> tab((size_t)ao.total, T(0));
+        for (int i = 0; i < nx_r; ++i)
+            for (int j = 0; j < nx_r; ++j) {
+                tab[ao.Q + i * nx + j] = (T)oh.Q[i * nx_r + j];
+                tab[ao.Qs + i * nx + j] = (T)(oh.Q[i * nx_r + j] + oh.Q[j * nx_r + i]);
+                tab[ao.QT + i * nx + j] = (T)QT[i * nx_r + j];
+                tab[ao.QTs + i * nx + j] = (T)(QT[i * nx_r + j] + QT[j * nx_r + i]);
+            }
+        for (int i = 0; i < nu; ++i)
+            for (int j = 0; j < nu; ++j) {
+                tab[ao.R + i * nu + j] = (T)oh.R[i * nu + j];
+                tab[ao.Rs + i * nu + j] = (T)(oh.R[i * nu + j] + oh.R[j * nu + i]);
+            }
+        for (int t = 0; t < H; ++t) {
+            for (int i = 0; i < nx_r; ++i) {
+                tab[ao.xref + t * nx + i] = (T)oh.xref[t * nx_r + i];
+                tab[ao.cx + t * nx + i] = (T)oh.cx[t * nx_r + i];
+            }
+            for (int i = 0; i < nu; ++i) {
+                tab[ao.uref + t * nu + i] = (T)oh.uref[t * nu + i];
+                tab[ao.cu + t * nu + i] = (T)oh.cu[t * nu + i];
+            }
+        }
+        const size_t tb = tab.size() * sizeof(T);
+        if (ws.robj_host.size() != tb || memcmp(ws.robj_host.data(), tab.data(), tb) != 0) {
+            NEMPC_HIP(hipMemcpyAsync(ws.robj, tab.data(), tb, hipMemcpyHostToDevice, s));
+            NEMPC_HIP(hipStreamSynchronize(s));   // tab is stack-owned
+            ws.robj_host.assign((const unsigned char*)tab.data(), (const unsigned char*)tab.data() + tb);
+        }
+        obj_dev = ws.robj;
+    }
     hipLaunchKernelGGL(solver_init_kernel<T>, dim3(gBn), dim3(256), 0, s, B, n, (T*)ws.Zc[0], (const T*)ws.lb,
                        (const T*)ws.ub, (T*)ws.muc[0], (T*)ws.nuc[0], (T*)ws.regc[0], ws.stc[0], ws.orig[0], ws.itc[0],
                        (T*)ws.infoc[0], (T*)ws.zlc[0], (T*)ws.zuc[0], (T)o.mu_init, (T)o.reg, has_bounds ? 1 : 0,
-                       (const T*)Z, (const T*)X0, (T*)ws.X0c[0], nx, (T*)ws.lamc[0], m);
+                       (const T*)Zstart, (const T*)X0start, (T*)ws.X0c[0], nx, (T*)ws.lamc[0], m);
 
     SolverArgs a{};
     a.H = H; a.nx = nx; a.nu = nu; a.nin = nin; a.n = n; a.m = m;
     a.grad = ws.grad; a.g = ws.g; a.tiles = ws.tiles;
     a.hblk = ws.hblk; a.lamn = ws.lamn;
-    a.obj = h.d_obj; a.oo = obj_offsets(H, nx, nu);
+    a.obj = obj_dev; a.oo = obj_offsets(H, nx, nu);
     a.lb = ws.lb; a.ub = ws.ub; a.alpha = ws.alpha; a.phi0 = ws.phi0;
     a.dir = ws.dir; a.lsdone = ws.lsdone; a.n_active = ws.n_active; a.n_pending = ws.n_active + 1; a.n_done = ws.n_active + 2;
     a.dz = ws.dz; a.Kst = ws.Kst;
@@ -1859,7 +2096,8 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
 
     const int no_carry = [] { const char* e = getenv("NEMPC_SOLVER_NO_CARRY"); return e ? atoi(e) : 0; }();   // A/B knob (tests)
     const int lsm_carry = o.linesearch == 0 ? (wave_wanted ? 1 : 2) : o.linesearch;
-    bool carry = lsm_carry == 2 && !no_carry && a.use_lds && h.variant == NEMPC_KERNEL_MFMA && h.cfg.integrator != NEMPC_RK4;
+    bool carry = lsm_carry == 2 && !no_carry && a.use_lds && h.variant == NEMPC_KERNEL_MFMA && h.cfg.integrator != NEMPC_RK4 &&
+                 !rolling;
     int pend_seq = 0;             // sequence number of the inner loop's acceptance launches (published with their count)
     bool have_eval = false;       // the evaluation buffers hold every active problem's current iterate
     a.carry = 0; a.tiles_t = ws.tiles_t; a.grad_t = ws.grad_t;
@@ -1873,7 +2111,44 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
     const int check = o.check_every > 0 ? o.check_every : 4;
     static const int trace_slot = [] { const char* e = getenv("NEMPC_SOLVER_TRACE"); return e ? atoi(e) : -1; }();
     const bool trace = trace_slot >= 0 && trace_slot < B;
-    const bool compact = o.compact != 0 && !trace;
+    // rolling: the callbacks read the caller's x0 / history by problem index, so the batch keeps its order (a finished
+    // problem is skipped by every solver kernel; its callback rows are evaluated and ignored)
+    const bool compact = o.compact != 0 && !trace && !rolling;
+    // ---- callbacks.  Plain models: the handle's launches on the solver's buffers.  Rolling: gather the caller's
+    //      variables, launch on them, spread the results into the window-state form (RollTables)
+    auto launch_rows = [&](int nb, const void* Zs, const void* X0s, void* g, void* tiles, void* tiles_scratch) -> int {
+        return h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, nb, Zs, X0s, g, tiles, s)
+                                              : launch_rows_valu(h, nb, Zs, X0s, g, tiles ? tiles : tiles_scratch, s);
+    };
+    auto launch_blocks = [&](int nb, const void* Zs, const void* X0s, const void* lam, void* blocks) -> int {
+        return h.variant != NEMPC_KERNEL_VALU ? launch_rowhess_mfma(h, nb, Zs, X0s, lam, blocks, s)
+                                              : launch_rowhess_valu(h, nb, Zs, X0s, lam, blocks, s);
+    };
+    const unsigned gRn = (unsigned)(((size_t)B * n_r + 255) / 256);
+    // everything at an iterate: defects, tiles, f, gradient, Lagrangian blocks
+    auto roll_eval_iterate = [&](const void* Zaug, const void* lam_aug) -> int {
+        hipLaunchKernelGGL(roll_in_kernel<T>, dim3(gRn), dim3(256), 0, s, B, n, n_r, H, nx_r, nx, m_r, ws.rt, (const T*)Zaug,
+                           (T*)ws.rZ, (const T*)lam_aug, (T*)ws.rlam);
+        int r = launch_rows(B, ws.rZ, X0, ws.rg, ws.rtiles, nullptr);
+        if (r) return r;
+        if ((r = launch_blocks(B, ws.rZ, X0, ws.rlam, ws.rhblk))) return r;
+        if ((r = launch_objective(h, B, ws.rZ, ws.f, ws.rgrad, s))) return r;
+        hipLaunchKernelGGL(roll_out_kernel<T>, dim3(B * H), dim3(256), 0, s, H, nx_r, nu, nx, nin_r, n_r, m_r, ws.rt,
+                           (const T*)Zaug, (const T*)ws.rS0, (const T*)ws.rg, (const T*)ws.rtiles, (const T*)ws.rhblk,
+                           (const T*)ws.rgrad, (T*)ws.g, (T*)ws.tiles, (T*)ws.hblk, (T*)ws.grad);
+        return NEMPC_OK;
+    };
+    // a trial point: defects only (the acceptance kernel evaluates the objective from the augmented table itself)
+    auto roll_eval_trial = [&](const void* Zaug) -> int {
+        hipLaunchKernelGGL(roll_in_kernel<T>, dim3(gRn), dim3(256), 0, s, B, n, n_r, H, nx_r, nx, m_r, ws.rt, (const T*)Zaug,
+                           (T*)ws.rZ, (const T*)nullptr, (T*)nullptr);
+        const int r = launch_rows(B, ws.rZ, X0, ws.rg, nullptr, h.d_tiles_ws);
+        if (r) return r;
+        hipLaunchKernelGGL(roll_out_kernel<T>, dim3(B * H), dim3(256), 0, s, H, nx_r, nu, nx, nin_r, n_r, m_r, ws.rt,
+                           (const T*)Zaug, (const T*)ws.rS0, (const T*)ws.rg, (const T*)nullptr, (const T*)nullptr,
+                           (const T*)nullptr, (T*)ws.gt, (T*)nullptr, (T*)nullptr, (T*)nullptr);
+        return NEMPC_OK;
+    };
     for (; it < o.max_iter; ++it) {
         a.B = Bact;
         a.cur_it = it;
@@ -1886,7 +2161,10 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         // Gauss-Newton step).  The RK4 matrix-core pipeline produces defects, tiles and blocks from one row launch.
         const bool rk4_pipeline = h.variant != NEMPC_KERNEL_VALU && h.cfg.integrator == NEMPC_RK4;
         bool fused_eval = false;
-        if (have_eval) {
+        if (rolling) {
+            fused_eval = true;                  // (f and grad come with it)
+            rc = roll_eval_iterate(Zc, ws.lamc[cur]);
+        } else if (have_eval) {
             // deferred backtracking on a compiled shape: the trial evaluation of the last iteration was a full one and the
             // acceptance kernel kept, per problem, the evaluation of the point it stands on -- only the blocks are new
             fused_eval = true;
@@ -1948,7 +2226,9 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         // 24.9 ms), in the wide phase because a trial evaluation costs real time and among the stragglers because each
         // extra trial is a latency-bound launch chain plus a host poll.  It spends more ITERATIONS on a hard problem
         // (a retry is an iteration), so max_iter budgets are larger than with the inner loop.
-        const int lsm = o.linesearch == 0 ? (wave_wanted ? 1 : 2) : o.linesearch;
+        // (rolling: one trial per iteration whatever was asked for -- the dense trial lists of the inner loop would need the
+        //  callbacks' x0 / history gathered per list)
+        const int lsm = rolling ? 2 : (o.linesearch == 0 ? (wave_wanted ? 1 : 2) : o.linesearch);
         int pending = 0;
         const void* const extra_all = h.d_extra;
         for (int ls = 0; ls < o.max_linesearch; ++ls) {
@@ -1975,12 +2255,14 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
                 if (!fused_trial) carry = false;      // not a compiled shape
                 else a.carry = 1;
             }
-            if (!fused_trial)
-                fused_trial = h.variant == NEMPC_KERNEL_MFMA &&
-                    (rc = launch_eval_fused(h, nb, ws.Zt, X0t, ws.gt, nullptr, nullptr, ws.ft, nullptr, s)) != NEMPC_EUNSUPPORTED;
-            if (!fused_trial)
-                rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, nb, ws.Zt, X0t, ws.gt, nullptr, s)
-                                                    : launch_rows_valu(h, nb, ws.Zt, X0t, ws.gt, h.d_tiles_ws, s);
+            if (rolling) {
+                rc = roll_eval_trial(ws.Zt);
+            } else {
+                if (!fused_trial)
+                    fused_trial = h.variant == NEMPC_KERNEL_MFMA &&
+                        (rc = launch_eval_fused(h, nb, ws.Zt, X0t, ws.gt, nullptr, nullptr, ws.ft, nullptr, s)) != NEMPC_EUNSUPPORTED;
+                if (!fused_trial) rc = launch_rows(nb, ws.Zt, X0t, ws.gt, nullptr, h.d_tiles_ws);
+            }
             h.d_extra = extra_all;
             if (rc) return rc;
             // (no fused evaluation: the acceptance kernel computes the trial point's objective value itself)
@@ -2131,8 +2413,11 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         }
     }
     hipLaunchKernelGGL(solver_scatter_kernel<T>, dim3(B), dim3(256), 0, s, B, n, (const T*)ws.Zc[cur],
-                       (const int*)ws.stc[cur], (const int*)ws.orig[cur], (const int*)ws.itc[cur], (T*)Z, status_dev,
-                       (int*)o.iters_out);
+                       (const int*)ws.stc[cur], (const int*)ws.orig[cur], (const int*)ws.itc[cur],
+                       rolling ? (T*)ws.rZout : (T*)Z, status_dev, (int*)o.iters_out);
+    if (rolling)      // the caller's variables are the primary copies
+        hipLaunchKernelGGL(roll_in_kernel<T>, dim3(gRn), dim3(256), 0, s, B, n, n_r, H, nx_r, nx, m_r, ws.rt, (const T*)ws.rZout,
+                           (T*)Z, (const T*)nullptr, (T*)nullptr);
     NEMPC_HIP(hipGetLastError());
     NEMPC_HIP(hipStreamSynchronize(s));
     if (iters_host) *iters_host = it;

@@ -385,6 +385,26 @@ class CallbackEngine:
                                               ptr["hblocks"], self._stream()))
         return res
 
+    def bind_hess(self, Z, X0, lam, sigma, want=("hvals",), gauss_newton=False):
+        """Pre-validated Hessian callback for hot loops (the counterpart of bind): returns (launch, outputs); launch()
+        re-evaluates the callback at the CURRENT contents of Z / X0 / lam / sigma into the fixed outputs with one ctypes
+        call.  gauss_newton=True binds nempc_hess_gn, `lam` then being the (B, H*nx) row weights or None."""
+        B = int(Z.shape[0])
+        res = self.hess_gn(Z, X0, lam, sigma, want) if gauss_newton else self.hess(Z, X0, lam, sigma, want)
+        if gauss_newton and sigma is None:
+            raise ValueError("bind_hess: pass sigma explicitly (the bound call reads the tensor every time)")
+        ptr = {k: (ctypes.c_void_p(res[k].data_ptr()) if k in res else None) for k in ("hvals", "hdense", "hblocks")}
+        fn = self.lib.nempc_hess_gn if gauss_newton else self.lib.nempc_hess
+        args = (self._handle, B, ctypes.c_void_p(Z.data_ptr()), ctypes.c_void_p(X0.data_ptr()),
+                None if lam is None else ctypes.c_void_p(lam.data_ptr()), ctypes.c_void_p(sigma.data_ptr()),
+                ptr["hvals"], ptr["hdense"], ptr["hblocks"], self._stream())
+
+        def launch():
+            rc = fn(*args)
+            if rc:
+                _lib.check(rc)
+        return launch, res
+
     def solve(self, X0, Z_init=None, lb=None, ub=None, max_iter=200, max_linesearch=6, check_every=4,
               tol_constraint=None, tol_step=None, mu_init=1e-1, mu_min=None, mu_factor=0.2, reg=None, lq_kernel="auto",
               compact=True, return_iterations=False, barrier="primal-dual", linesearch="auto", lq_attempts=0):
@@ -507,7 +527,8 @@ class CallbackEngine:
 
     # ------------------------------------------------------------------ host convenience (B=1 drop-in path)
     def to_device(self, a):
-        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device, self.dtype)
+        # (a read-only view -- np.broadcast_to -- is copied: torch refuses to alias memory it may not write)
+        return torch.as_tensor(np.require(a, dtype=np.float64, requirements=["C", "W"])).to(self.device, self.dtype)
 
     def eval_numpy(self, Z, X0, want=("f", "grad", "g", "jac_dense")):
         Z = np.atleast_2d(np.asarray(Z, dtype=np.float64))

@@ -77,3 +77,31 @@ def test_gauss_newton_hessian_rolling_window_and_fp32():
     p32 = orc.Problem(net, 30, 6, 3, orc.RK4, 0.1)
     ref = np.stack([p32.gauss_newton_values(Zh[i], X0h[i], None, 1.0) for i in range(4)])
     assert np.abs(hv - ref).max() / np.abs(ref).max() < 1e-4
+
+
+def test_bound_hessian_callbacks_reevaluate_in_place():
+    """CallbackEngine.bind_hess: one ctypes call per evaluation, outputs fixed, inputs read at their current contents."""
+    nx, nu, H, B = 2, 1, 20, 33
+    net = orc.MLP.random(nx + nu, [64, 64], nx, seed=2)
+    eng = _engine(net, H, nx, nu, B)
+    eng.set_objective(Q=np.eye(nx), R=0.2 * np.eye(nu))
+    prob = orc.Problem(net, H, nx, nu, orc.DISCRET, 1.0, Q=np.eye(nx), R=0.2 * np.eye(nu))
+    rng = np.random.default_rng(3)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=6)
+    Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+    lam, sig = eng.to_device(rng.normal(size=(B, eng.m))), eng.to_device(rng.uniform(0.5, 1.5, size=B))
+    wgt = eng.to_device(rng.uniform(0.1, 2.0, size=(B, H * nx)))
+    call_h, out_h = eng.bind_hess(Z, X0, lam, sig)
+    call_g, out_g = eng.bind_hess(Z, X0, wgt, sig, gauss_newton=True)
+    Z2h, _ = orc.synthetic_inputs(B, H, nx, nu, seed=7)
+    Z.copy_(eng.to_device(Z2h))                          # new iterate in the SAME tensor
+    call_h()
+    call_g()
+    torch.cuda.synchronize()
+    hv, gv = out_h["hvals"].cpu().numpy(), out_g["hvals"].cpu().numpy()
+    lh, sh, wh = lam.cpu().numpy(), sig.cpu().numpy(), wgt.cpu().numpy()
+    for b in (0, 16, B - 1):
+        np.testing.assert_allclose(hv[b], prob.hessian_values(Z2h[b], X0h[b], lh[b], sh[b]), rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(gv[b], prob.gauss_newton_values(Z2h[b], X0h[b], wh[b], sh[b]), rtol=1e-11, atol=1e-11)
+    with pytest.raises(ValueError, match="sigma"):
+        eng.bind_hess(Z, X0, wgt, None, gauss_newton=True)

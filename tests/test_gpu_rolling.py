@@ -160,8 +160,71 @@ def test_rolling_errors():
     eng.bind_history(torch.zeros(2, 1, nx, dtype=torch.float64, device="cuda:0"),
                      torch.zeros(2, 1, nu, dtype=torch.float64, device="cuda:0"))
     eng.eval(Z, X0)
-    with pytest.raises(NempcError, match="rolling-window"):
+    eng.bind_history(torch.zeros(1, 1, nx, dtype=torch.float64, device="cuda:0"),
+                     torch.zeros(1, 1, nu, dtype=torch.float64, device="cuda:0"))
+    with pytest.raises(ValueError, match="set_prev_data"):       # the history must cover the batch that is solved
         eng.solve(X0)
+
+
+@pytest.mark.parametrize("cfg", [(2, 1, [32, 32], 12, 2, True, "valu", "none", 24), (2, 1, [32, 32], 12, 3, False, "mfma", "controls", 40),
+                                 (3, 2, [24], 6, 2, True, "mfma", "box", 9), (1, 1, [16, 16], 8, 4, True, "valu", "controls", 7)])
+def test_batched_solve_of_rolling_window_models(cfg):
+    """nempc_solve on rolling-window models: the window is made the state and the same Riccati SQP runs on it.  Checked on
+    the CALLER's problem with the oracle: feasibility, first-order optimality, and SciPy SLSQP on the oracle's callbacks."""
+    from scipy.optimize import Bounds, minimize
+    import warnings
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, hidden, H, w, fwd, kernel, bounds, B = cfg
+    net = orc.MLP.random(w * (nx + nu), hidden, nx, seed=4)
+    net.W[-1] *= 0.2
+    net.b[-1] *= 0.2
+    rng = np.random.default_rng(21)
+    hx, hu = rng.uniform(-1, 1, size=(B, w - 1, nx)), rng.uniform(-0.3, 0.3, size=(B, w - 1, nu))
+    X0 = rng.uniform(-1.0, 1.0, size=(B, nx))
+    Q, R = np.eye(nx), 0.1 * np.eye(nu)
+    n = H * (nx + nu)
+    lb, ub = np.full(n, -np.inf), np.full(n, np.inf)
+    if bounds != "none":
+        lb[H * nx:], ub[H * nx:] = -0.05, 0.05
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B, kernel=kernel,
+                         rolling_window=w, forward_rolling=fwd)
+    eng.set_objective(Q=Q, R=R)
+    if bounds == "box":
+        eng.set_box_rows(-3.0, 3.0)
+        lb[:H * nx], ub[:H * nx] = -3.0, 3.0
+    eng.bind_history(eng.to_device(hx), eng.to_device(hu))
+    Z, status, iters, its = eng.solve(eng.to_device(X0), lb=lb if bounds != "none" else None, ub=ub if bounds != "none" else None,
+                                      max_iter=400, return_iterations=True)
+    Z, status = Z.cpu().numpy(), status.cpu().numpy()
+    assert (status == 0).all(), f"{int((status != 0).sum())} of {B} problems did not converge in {iters} iterations"
+    assert int(its.max()) <= iters
+    same = 0
+    for i in range(B):
+        prob = orc.Problem(net, H, nx, nu, orc.DISCRET, Q=Q, R=R, window=w, forward_rolling=fwd, hist_x=hx[i], hist_u=hu[i])
+        assert np.abs(prob.constraints(Z[i], X0[i])[:H * nx]).max() < 1e-7
+        assert (Z[i] >= lb - 1e-12).all() and (Z[i] <= ub + 1e-12).all()
+        if i % max(1, B // 5):
+            continue
+        J, gr = prob.jacobian(Z[i], X0[i])[:H * nx], prob.gradient(Z[i])
+        free = (Z[i] > lb + 1e-3) & (Z[i] < ub - 1e-3)
+        lam = np.linalg.lstsq(J[:, free].T, -gr[free], rcond=None)[0]
+        assert np.abs(gr[free] + J[:, free].T @ lam).max() < 1e-5 * max(1.0, np.abs(gr).max())
+        rest = gr + J.T @ lam
+        assert (rest[Z[i] <= lb + 1e-3] > -1e-3).all() and (rest[Z[i] >= ub - 1e-3] < 1e-3).all()
+        zi = np.clip(orc.cold_start(X0[i], H, nu), np.where(np.isfinite(lb), lb + 1e-3, -np.inf),
+                     np.where(np.isfinite(ub), ub - 1e-3, np.inf))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = minimize(prob.objective, zi, method="SLSQP", jac=prob.gradient, bounds=Bounds(lb, ub),
+                           constraints=[{"type": "eq", "fun": lambda z: prob.constraints(z, X0[i])[:H * nx],
+                                         "jac": lambda z: prob.jacobian(z, X0[i])[:H * nx]}],
+                           options={"maxiter": 500, "ftol": 1e-12})
+        f_gpu = prob.objective(Z[i])
+        assert f_gpu <= ref.fun * (1 + 1e-6) + 1e-8, (f_gpu, ref.fun)
+        if abs(f_gpu - ref.fun) <= 1e-5 * max(1.0, abs(ref.fun)):
+            np.testing.assert_allclose(Z[i], ref.x, rtol=0, atol=2e-4)
+            same += 1
+    assert same >= 3, "most sampled problems should land in SLSQP's minimum"
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -344,3 +407,72 @@ def test_rolling_window_and_parameters_with_the_activation_family(act):
         np.testing.assert_allclose(h, hv, rtol=1e-10, atol=1e-11)
         hg = eng.hess_gn(Z, X0, eng.to_device(wh), eng.to_device(sigh))["hvals"].cpu().numpy()
         np.testing.assert_allclose(hg, gn, rtol=1e-11, atol=1e-12)
+
+
+def test_nmpc_next_with_rolling_model_on_the_device_solver():
+    """The same scenario with the batched device solver behind the Optimizer interface (DeviceSqp): the window is made
+    the state inside nempc_solve; the answer is the SLSQP one."""
+    import pyneuralempc_amd as nEMPC
+    nx, nu, w, H = 2, 1, 2, 10
+    net = orc.MLP.random(w * (nx + nu), [24, 24], nx, seed=4)
+    net.W[-1] *= 0.2
+    net.b[-1] *= 0.2
+    model = nEMPC.model.MLPModelRollingInput(net.W, net.b, nx, nu, rolling_window=w, forward_rolling=True,
+                                             device="cuda:0")
+    x_past, u_past = np.array([[0.2, 0.1]]), np.array([[0.0]])
+    model.set_prev_data(x_past, u_past)
+    integ = nEMPC.integrator.discret.DiscretIntegrator(model, H)
+    obj = nEMPC.objective.QuadraticObjective(Q=np.zeros((nx, nx)), R=np.eye(nu), uref=2.0, device="cuda:0")
+    dom = nEMPC.constraints.DomainConstraint(states_constraint=[[-np.inf, np.inf]] * nx,
+                                             control_constraint=[[-np.inf, np.inf]])
+    opt = nEMPC.optimizer.DeviceSqp(max_iteration=200)
+    mpc = nEMPC.controller.NMPC(integ, obj, [dom], H, 1, optimizer=opt)
+    x0 = x_past.reshape(-1)
+    pred, u = mpc.next(x0)
+    assert pred is not None and pred.shape == (H, nx) and u.shape == (H, nu)
+    prob = orc.Problem(net, H, nx, nu, orc.DISCRET, Q=np.zeros((nx, nx)), R=np.eye(nu), uref=2.0, window=w,
+                       hist_x=x_past, hist_u=u_past)
+    z = np.concatenate([pred.ravel(), u.ravel()])
+    assert np.abs(prob.constraints(z, x0)).max() < 1e-8
+    np.testing.assert_allclose(u, 2.0, atol=1e-6)
+
+
+def test_next_batch_with_rolling_model_histories_and_rolled_parameters():
+    """NMPC.next_batch on a rolling-window model with parameters: one history (states, controls, time-varying parameters)
+    per problem, tvp rolled like the states.  Every problem against the oracle's problem with ITS history and extras."""
+    import pyneuralempc_amd as nEMPC
+    nx, nu, w, H, B, pd, td = 2, 1, 3, 8, 11, 1, 1
+    net = orc.MLP.random(w * (nx + nu + td) + pd, [32, 32], nx, seed=9)
+    net.W[-1] *= 0.2
+    net.b[-1] *= 0.2
+    model = nEMPC.model.MLPModelRollingInput(net.W, net.b, nx, nu, p_dim=pd, tvp_dim=td, rolling_window=w, device="cuda:0")
+    integ = nEMPC.integrator.discret.DiscretIntegrator(model, H)
+    Q, R = np.eye(nx), 0.1 * np.eye(nu)
+    obj = nEMPC.objective.QuadraticObjective(Q=Q, R=R, device="cuda:0")
+    dom = nEMPC.constraints.DomainConstraint(states_constraint=[[-np.inf, np.inf]] * nx, control_constraint=[[-0.2, 0.2]])
+    mpc = nEMPC.controller.NMPC(integ, obj, [dom], H, 1, optimizer=nEMPC.optimizer.DeviceSqp())
+    rng = np.random.default_rng(2)
+    X0 = rng.uniform(-1, 1, size=(B, nx))
+    px, pu = rng.uniform(-1, 1, size=(B, w - 1, nx)), rng.uniform(-0.2, 0.2, size=(B, w - 1, nu))
+    ptv, tvp, p = rng.normal(size=(B, w - 1, td)), rng.normal(size=(B, H, td)), rng.normal(size=(B, pd))
+    with pytest.raises(ValueError, match="prev_x"):
+        mpc.next_batch(X0, p=p, tvp=tvp)                              # no history given, none stored
+    xs, us, status = mpc.next_batch(X0, p=p, tvp=tvp, prev_x=px, prev_u=pu, prev_tvp=ptv, max_iter=300)
+    assert (status == nEMPC.optimizer.Optimizer.SUCCESS).all()
+    lb = np.concatenate([np.full(H * nx, -np.inf), np.full(H * nu, -0.2)])
+    ub = -lb
+    for i in range(B):
+        model.set_prev_data(px[i], pu[i], ptv[i])
+        ex = model.gather_extra(H, p=p[i], tvp=tvp[i])
+        prob = orc.Problem(net, H, nx, nu, orc.DISCRET, Q=Q, R=R, extra=ex, window=w, hist_x=px[i], hist_u=pu[i])
+        z = np.concatenate([xs[i].ravel(), us[i].ravel()])
+        assert np.abs(prob.constraints(z, X0[i])).max() < 1e-7
+        assert (z >= lb - 1e-12).all() and (z <= ub + 1e-12).all()
+        J, gr = prob.jacobian(z, X0[i]), prob.gradient(z)
+        free = (z > lb + 1e-3) & (z < ub - 1e-3)
+        lam = np.linalg.lstsq(J[:, free].T, -gr[free], rcond=None)[0]
+        assert np.abs(gr[free] + J[:, free].T @ lam).max() < 1e-5 * max(1.0, np.abs(gr).max())
+    # one stored history serves the whole batch when none is passed
+    model.set_prev_data(px[0], pu[0], ptv[0])
+    xs1, us1, st1 = mpc.next_batch(X0[:1], p=p[:1], tvp=tvp[:1], max_iter=300)
+    np.testing.assert_allclose(us1[0], us[0], atol=1e-9)
