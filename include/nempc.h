@@ -215,7 +215,9 @@ typedef struct nempc_solver_opts {
     int32_t max_linesearch;  /* halvings of a step before the direction is given up and the next LQ solve damped, e.g. 6 */
     int32_t check_every;     /* period, in iterations, of the BLOCKING convergence poll used for matrix-core-bound stages
                               * (e.g. 4); small stages do not poll: the device publishes the counter every iteration */
-    int32_t lq_kernel;       /* Riccati sweep: 0 auto (by stage size), 1 one thread per problem, 2 one wave per problem */
+    int32_t lq_kernel;       /* LQ solve: 0 auto (by stage size), 1 sweep, one thread per problem, 2 sweep, one wave per problem,
+                              * 3 parallel-in-time scan, one lane per stage (2-state / 1-control stages, fp64, H <= 63:
+                              * what auto picks there; NEMPC_EUNSUPPORTED elsewhere) */
     double tol_constraint;   /* max |defect| at convergence, e.g. 1e-8 */
     double tol_step;         /* max |dz| <= tol_step * (1 + max |z|), e.g. 1e-8 */
     double mu_init, mu_min, mu_factor; /* barrier schedule, e.g. 1e-1, 1e-9, 0.2 */

@@ -722,7 +722,7 @@ int nempc_solve(nempc_handle hh, int32_t B, const void* X0, void* Z, const doubl
         return fail(NEMPC_ESTATE, "nempc_solve: rolling_window > 1 but nempc_bind_history was not called");
     if (h.w > 1 && B > h.hist_B) return fail(NEMPC_EINVAL, "nempc_solve: B exceeds the batch the bound history covers");
     if (opts->max_iter < 1 || opts->max_linesearch < 1 || !(opts->mu_factor > 0.0 && opts->mu_factor < 1.0) ||
-        !(opts->mu_init > 0.0) || !(opts->mu_min > 0.0) || opts->lq_kernel < 0 || opts->lq_kernel > 2)
+        !(opts->mu_init > 0.0) || !(opts->mu_min > 0.0) || opts->lq_kernel < 0 || opts->lq_kernel > 3)
         return fail(NEMPC_EINVAL, "nempc_solve: bad options");
     DeviceGuard dg(h.cfg.device);
     if (!dg.ok) return fail(NEMPC_EHIP, "nempc_solve: hipSetDevice failed");

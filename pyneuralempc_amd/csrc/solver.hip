@@ -223,6 +223,243 @@ __device__ __forceinline__ float inv_sqrt_pos(float d) {
     return fmaf(0.5f * y, r, y);
 }
 
+// ---- Parallel-in-time LQ solve for 2-state / 1-control stages (one wave per problem, one LANE per stage).
+// The backward Riccati recursion is a chain of H dependent stages; a lone lane issues its ~140 instructions per stage one
+// per 5 cycles (11 us of the iteration at H = 20).  The recursion is also a product of associative elements (Sarkka &
+// Garcia-Fernandez, "Temporal parallelization of dynamic programming and linear quadratic control", IEEE TAC 2023): the
+// conditional value function of a run of stages k..i-1,
+//     V(x_k, x_i) = max_l  1/2 x_k' J x_k - eta' x_k - 1/2 l' C l - l' (x_i - A x_k - b),
+// is closed under composition, (A, b, C, eta, J)_{k,j} (x) (A, b, C, eta, J)_{j,i} below, so a suffix scan over the stages
+// (log2(H+1) combination steps, every lane working) gives every stage its value function, and the closed-loop rollout
+// dx_{t+1} = (A + B K) dx_t + (c + B k) is a prefix scan of affine maps.
+// What makes it usable here, where the exact Lagrangian blocks make stage Hessians indefinite:
+//  * a stage element needs its OWN control Hessian U = Rs + W_uu + barrier + damping inverted, while the sweep only needs
+//    Quu = U + B' P B > 0.  The cost 1/2 s_t |dx_{t+1}|^2 is added to stage t (through its dynamics) and taken back from the
+//    state entering stage t+1 -- an exact rewriting -- with s_t = 1, raised to 2 |U| / |B|^2 where U + |B|^2 / 2 < 0: on
+//    random indefinite problems the scan then goes through exactly when the sweep does (tools/lq_scan_proto.py: 0
+//    disagreements in 5,400 solves, results equal to 1e-11);
+//  * the sweep's own test decides: with every P_t known, Quu_t > 1e-12 is checked for all stages at once; a level that
+//    fails is repeated with ten times the damping, the levels of a round side by side in lane segments of H + 1.
+template <typename T>
+struct LqEl { T a00, a01, a10, a11, b0, b1, c00, c01, c11, e0, e1, j00, j01, j11; };
+
+__device__ __forceinline__ double lq_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(e, r, r);
+    e = fma(-x, r, 1.0);
+    return fma(e, r, r);
+}
+
+template <typename T>
+__device__ __forceinline__ LqEl<T> lq_shfl_down(const LqEl<T>& v, int d) {
+    LqEl<T> r;
+    r.a00 = __shfl_down(v.a00, d, 64); r.a01 = __shfl_down(v.a01, d, 64); r.a10 = __shfl_down(v.a10, d, 64);
+    r.a11 = __shfl_down(v.a11, d, 64); r.b0 = __shfl_down(v.b0, d, 64); r.b1 = __shfl_down(v.b1, d, 64);
+    r.c00 = __shfl_down(v.c00, d, 64); r.c01 = __shfl_down(v.c01, d, 64); r.c11 = __shfl_down(v.c11, d, 64);
+    r.e0 = __shfl_down(v.e0, d, 64); r.e1 = __shfl_down(v.e1, d, 64);
+    r.j00 = __shfl_down(v.j00, d, 64); r.j01 = __shfl_down(v.j01, d, 64); r.j11 = __shfl_down(v.j11, d, 64);
+    return r;
+}
+
+// (first: stages k..j-1) (x) (second: stages j..i-1)
+template <typename T>
+__device__ __forceinline__ LqEl<T> lq_combine(const LqEl<T>& i, const LqEl<T>& j) {
+    // M = (I + C_i J_j)^-1
+    const T n00 = fma(i.c00, j.j00, fma(i.c01, j.j01, T(1))), n01 = fma(i.c00, j.j01, i.c01 * j.j11);
+    const T n10 = fma(i.c01, j.j00, i.c11 * j.j01), n11 = fma(i.c01, j.j01, fma(i.c11, j.j11, T(1)));
+    const T id = lq_rcp(fma(n00, n11, -n01 * n10));
+    const T m00 = n11 * id, m01 = -n01 * id, m10 = -n10 * id, m11 = n00 * id;
+    // AM = A_j M
+    const T am00 = fma(j.a00, m00, j.a01 * m10), am01 = fma(j.a00, m01, j.a01 * m11);
+    const T am10 = fma(j.a10, m00, j.a11 * m10), am11 = fma(j.a10, m01, j.a11 * m11);
+    LqEl<T> r;
+    r.a00 = fma(am00, i.a00, am01 * i.a10); r.a01 = fma(am00, i.a01, am01 * i.a11);
+    r.a10 = fma(am10, i.a00, am11 * i.a10); r.a11 = fma(am10, i.a01, am11 * i.a11);
+    // b = AM (b_i + C_i eta_j) + b_j
+    const T v0 = fma(i.c00, j.e0, fma(i.c01, j.e1, i.b0)), v1 = fma(i.c01, j.e0, fma(i.c11, j.e1, i.b1));
+    r.b0 = fma(am00, v0, fma(am01, v1, j.b0)); r.b1 = fma(am10, v0, fma(am11, v1, j.b1));
+    // C = AM C_i A_j' + C_j
+    const T t00 = fma(am00, i.c00, am01 * i.c01), t01 = fma(am00, i.c01, am01 * i.c11);
+    const T t10 = fma(am10, i.c00, am11 * i.c01), t11 = fma(am10, i.c01, am11 * i.c11);
+    r.c00 = fma(t00, j.a00, fma(t01, j.a01, j.c00));
+    r.c01 = fma(T(0.5), fma(t00, j.a10, t01 * j.a11) + fma(t10, j.a00, t11 * j.a01), j.c01);
+    r.c11 = fma(t10, j.a10, fma(t11, j.a11, j.c11));
+    // eta = A_i' M' (eta_j - J_j b_i) + eta_i
+    const T w0 = j.e0 - fma(j.j00, i.b0, j.j01 * i.b1), w1 = j.e1 - fma(j.j01, i.b0, j.j11 * i.b1);
+    const T x0 = fma(m00, w0, m10 * w1), x1 = fma(m01, w0, m11 * w1);
+    r.e0 = fma(i.a00, x0, fma(i.a10, x1, i.e0)); r.e1 = fma(i.a01, x0, fma(i.a11, x1, i.e1));
+    // J = A_i' (M' J_j) A_i + J_i
+    const T y00 = fma(m00, j.j00, m10 * j.j01), y01 = fma(m00, j.j01, m10 * j.j11);
+    const T y10 = fma(m01, j.j00, m11 * j.j01), y11 = fma(m01, j.j01, m11 * j.j11);
+    const T z00 = fma(y00, i.a00, y01 * i.a10), z01 = fma(y00, i.a01, y01 * i.a11);
+    const T z10 = fma(y10, i.a00, y11 * i.a10), z11 = fma(y10, i.a01, y11 * i.a11);
+    r.j00 = fma(i.a00, z00, fma(i.a10, z10, i.j00));
+    r.j01 = fma(T(0.5), fma(i.a00, z01, i.a10 * z11) + fma(i.a01, z00, i.a11 * z10), i.j01);
+    r.j11 = fma(i.a01, z01, fma(i.a11, z11, i.j11));
+    return r;
+}
+
+// One problem on one wave: its working set is staged in the LDS block `blk` (offsets as in solver_lq_kernel); the step and
+// the costates are left in blk[Ldz..], blk[Llam..], the restart count (negative: sat out) in blk[Lbh].
+template <typename T>
+__device__ __forceinline__ void lq_scan_problem(const SolverArgs& a, int b, int ln, T* __restrict__ blk, int Lgr, int Lgc,
+                                                int Ltl, int LW, int Llam, int Ldz, int Lbh) {
+    constexpr int nx = 2, nin = 3;
+    const int H = a.H, n = a.n, uo = H * nx, seg = H + 1;
+    const int specs = a.spec;
+    T* info = (T*)a.info + (size_t)b * INFO_N;
+    if (a.status[b] >= 0) {          // finished problem: zero step, multipliers unchanged
+        const T* lcur = (const T*)a.lam + (size_t)b * a.m;
+        for (int i = ln; i < n; i += 64) blk[Ldz + i] = T(0);
+        for (int i = ln; i < H * nx; i += 64) blk[Llam + i] = lcur[i];
+        return;
+    }
+    int lv = 0;
+    for (int k = 1; k < specs; ++k) lv += ln >= k * seg ? 1 : 0;
+    const int e = ln - lv * seg;                    // stage of this lane (e == H: the terminal element)
+    const bool active = ln < specs * seg, is_stage = active && e < H;
+    const int t = is_stage ? e : H - 1;             // (the terminal lane reads the last state's entries)
+    // inputs of this lane's stage: all read before anything of the block is written
+    const T* At = blk + Ltl + t * nx * nin;
+    const T* Wt = blk + LW + t * nin * nin;
+    const T A00 = At[0], A01 = At[1], B0 = At[2], A10 = At[3], A11 = At[4], B1 = At[5];
+    const T Wxx00 = Wt[0], Wxx01 = Wt[1], Wxx11 = Wt[4], Wux0 = Wt[6], Wux1 = Wt[7], Wuu = Wt[8];
+    const T c0 = blk[Lgc + t * nx], c1 = blk[Lgc + t * nx + 1];
+    const T gru = blk[Lgr + uo + t], bhu = blk[Lbh + uo + t];
+    const int sx = is_stage ? (e > 0 ? e - 1 : 0) : H - 1;       // state entering the stage (none for stage 0)
+    const T grx0 = blk[Lgr + sx * nx], grx1 = blk[Lgr + sx * nx + 1], bhx0 = blk[Lbh + sx * nx], bhx1 = blk[Lbh + sx * nx + 1];
+    const T* Qs = (const T*)a.obj + a.oo.Qs;
+    const T* QTs = (const T*)a.obj + a.oo.QTs;
+    const T Rs = ((const T*)a.obj)[a.oo.Rs];
+    const T q00 = Qs[0], q01 = T(0.5) * (Qs[1] + Qs[2]), q11 = Qs[3];
+    const T qt00 = QTs[0], qt01 = T(0.5) * (QTs[1] + QTs[2]), qt11 = QTs[3];
+    const T reg_in = ((const T*)a.reg)[b];
+    const T bb = fma(B0, B0, B1 * B1);
+    int restarts = a.lq_attempts;
+    bool any = false;
+    T reg = reg_in;
+    for (int base = 0; base < a.lq_attempts && !any; base += specs) {
+        const int aj = base + lv;
+        reg = reg_in;
+        for (int k = 0; k < aj; ++k) reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));
+        bool ok = false;
+        // shift of the state this stage produces (see above); the state entering it carries the previous stage's
+        const T U = Rs + Wuu + bhu + reg;
+        T sg = T(1);
+        if (U < T(-0.5) * bb) sg = T(2) * (-U) * lq_rcp(fmax(bb, T(1e-300)));
+        T P00, P01, P11, p0, p1, Quu, quf, Qux0, Qux1;
+        // Second pass where the first one was ill-conditioned: a combination inverts I + C J, whose eigenvalue along B is
+        // Quu / U' at the last level -- with U' = U + s |B|^2 far from Quu = U + B'PB (an objective without curvature:
+        // P ~ 1e-6 against s = 1) the first pass loses log10(U' / Quu) digits.  Its P is good enough to choose s = B'PB / |B|^2,
+        // i.e. U' = Quu, and the second pass is then as accurate as the sweep.  Well-scaled problems never take it.
+        for (int pass = 0; pass < 2; ++pass) {
+        ok = active && aj < a.lq_attempts;
+        T sg_in = __shfl_up(sg, 1, 64);
+        if (e == 0) sg_in = T(0);
+        T Up = T(1);
+        LqEl<T> E;
+        if (is_stage) {
+            Up = fma(sg, bb, U);
+            ok = ok && Up > T(1e-12);
+            const T iu = lq_rcp(Up);
+            const T wu0 = fma(sg, fma(B0, A00, B1 * A10), Wux0), wu1 = fma(sg, fma(B0, A01, B1 * A11), Wux1);
+            const T qu = fma(sg, fma(B0, c0, B1 * c1), gru);
+            // state cost of the entering state: objective weight + Lagrangian block + barrier + s A'A - s_in I
+            const T x00 = q00 + Wxx00 + bhx0 + sg * fma(A00, A00, A10 * A10) - sg_in;
+            const T x01 = q01 + Wxx01 + sg * fma(A00, A01, A10 * A11);
+            const T x11 = q11 + Wxx11 + bhx1 + sg * fma(A01, A01, A11 * A11) - sg_in;
+            const T qx0 = fma(sg, fma(A00, c0, A10 * c1), grx0), qx1 = fma(sg, fma(A01, c0, A11 * c1), grx1);
+            const T bi0 = B0 * iu, bi1 = B1 * iu;
+            E.a00 = fma(-bi0, wu0, A00); E.a01 = fma(-bi0, wu1, A01); E.a10 = fma(-bi1, wu0, A10); E.a11 = fma(-bi1, wu1, A11);
+            E.b0 = fma(-bi0, qu, c0); E.b1 = fma(-bi1, qu, c1);
+            E.c00 = bi0 * B0; E.c01 = bi0 * B1; E.c11 = bi1 * B1;
+            const T wi0 = wu0 * iu, wi1 = wu1 * iu;
+            E.j00 = fma(-wi0, wu0, x00); E.j01 = fma(-wi0, wu1, x01); E.j11 = fma(-wi1, wu1, x11);
+            E.e0 = fma(wi0, qu, -qx0); E.e1 = fma(wi1, qu, -qx1);
+        } else {
+            E.a00 = E.a01 = E.a10 = E.a11 = E.b0 = E.b1 = E.c00 = E.c01 = E.c11 = T(0);
+            E.j00 = qt00 + bhx0 - sg_in; E.j01 = qt01; E.j11 = qt11 + bhx1 - sg_in;
+            E.e0 = -grx0; E.e1 = -grx1;
+        }
+        // suffix scan: after the step of distance d lane e holds stages e .. e + 2d - 1 (cut at the terminal)
+        for (int d = 1; d < seg; d <<= 1) {
+            const LqEl<T> nb = lq_shfl_down(E, d);
+            if (active && e + d <= H) E = lq_combine(E, nb);
+        }
+        // value function of the state this stage produces: the suffix from the next lane, shift undone
+        P00 = __shfl_down(E.j00, 1, 64) + sg; P01 = __shfl_down(E.j01, 1, 64); P11 = __shfl_down(E.j11, 1, 64) + sg;
+        p0 = -__shfl_down(E.e0, 1, 64); p1 = -__shfl_down(E.e1, 1, 64);
+        // the sweep's stage: Quu = U + B'PB, qu = gu + B'(Pc + p), Qux = W_ux + B'PA
+        const T PB0 = fma(P00, B0, P01 * B1), PB1 = fma(P01, B0, P11 * B1);
+        const T Pc0 = fma(P00, c0, fma(P01, c1, p0)), Pc1 = fma(P01, c0, fma(P11, c1, p1));
+        Quu = fma(B0, PB0, fma(B1, PB1, U));
+        quf = fma(B0, Pc0, fma(B1, Pc1, gru));
+        Qux0 = fma(PB0, A00, fma(PB1, A10, Wux0)); Qux1 = fma(PB0, A01, fma(PB1, A11, Wux1));
+        ok = ok && (!is_stage || Quu > T(1e-12));
+        if (pass == 0) {
+            const bool far = is_stage && ok && (Quu < T(1.0 / 64) * Up || Quu > T(64) * Up);
+            if (!__any(far)) break;
+            if (is_stage && ok && bb > T(1e-300)) sg = (Quu - U) * lq_rcp(bb);
+        }
+        }
+        const T iq = lq_rcp(Quu);
+        const T kv = -quf * iq, K0 = e == 0 ? T(0) : -Qux0 * iq, K1 = e == 0 ? T(0) : -Qux1 * iq;
+        // which level is used: the first whose stages all went through
+        const unsigned long long okm = __ballot(ok || (active && !is_stage));
+        int win = -1;
+        for (int jj = specs - 1; jj >= 0; --jj) {
+            const unsigned long long m = (seg >= 64 ? ~0ull : ((1ull << seg) - 1ull)) << (jj * seg);
+            if (base + jj < a.lq_attempts && (okm & m) == m) win = jj;
+        }
+        if (win < 0) continue;
+        any = true;
+        restarts = base + win;
+        // closed-loop rollout dx_{t+1} = F dx_t + f, dx_0 = 0: prefix scan of the affine maps
+        T F00 = e == 0 ? T(0) : fma(B0, K0, A00), F01 = e == 0 ? T(0) : fma(B0, K1, A01);
+        T F10 = e == 0 ? T(0) : fma(B1, K0, A10), F11 = e == 0 ? T(0) : fma(B1, K1, A11);
+        T f0 = fma(B0, kv, c0), f1 = fma(B1, kv, c1);
+        for (int d = 1; d < H; d <<= 1) {
+            const T g00 = __shfl_up(F00, d, 64), g01 = __shfl_up(F01, d, 64), g10 = __shfl_up(F10, d, 64), g11 = __shfl_up(F11, d, 64);
+            const T h0 = __shfl_up(f0, d, 64), h1 = __shfl_up(f1, d, 64);
+            if (is_stage && e - d >= 0) {
+                const T nf0 = fma(F00, h0, fma(F01, h1, f0)), nf1 = fma(F10, h0, fma(F11, h1, f1));
+                const T n00 = fma(F00, g00, F01 * g10), n01 = fma(F00, g01, F01 * g11);
+                const T n10 = fma(F10, g00, F11 * g10), n11 = fma(F10, g01, F11 * g11);
+                F00 = n00; F01 = n01; F10 = n10; F11 = n11; f0 = nf0; f1 = nf1;
+            }
+        }
+        T dx0 = __shfl_up(f0, 1, 64), dx1 = __shfl_up(f1, 1, 64);
+        if (e == 0) { dx0 = T(0); dx1 = T(0); }
+        const T du = fma(K0, dx0, fma(K1, dx1, kv));
+        // (the new state from the stage's own linearisation, as the sweep writes it)
+        const T xn0 = fma(A00, dx0, fma(A01, dx1, fma(B0, du, c0))), xn1 = fma(A10, dx0, fma(A11, dx1, fma(B1, du, c1)));
+        if (is_stage && lv == win) {
+            blk[Ldz + e * nx] = xn0; blk[Ldz + e * nx + 1] = xn1; blk[Ldz + uo + e] = du;
+            blk[Llam + e * nx] = fma(P00, xn0, fma(P01, xn1, p0)); blk[Llam + e * nx + 1] = fma(P01, xn0, fma(P11, xn1, p1));
+            if (e == 0) {
+                ((T*)a.reg)[b] = reg;
+                info[INFO_RESTARTS] = (T)restarts;
+                blk[Lbh] = (T)restarts;
+            }
+        }
+    }
+    if (!any) {
+        // out of attempts: no step this iteration, the damping keeps what it has climbed to (as in the sweep kernel)
+        const T* lcur = (const T*)a.lam + (size_t)b * a.m;
+        for (int i = ln; i < n; i += 64) blk[Ldz + i] = T(0);
+        for (int i = ln; i < H * nx; i += 64) blk[Llam + i] = lcur[i];
+        if (ln == 0) {
+            reg = reg_in;
+            for (int k = 0; k < a.lq_attempts; ++k) reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));
+            ((T*)a.reg)[b] = reg;
+            info[INFO_STEP] = std::numeric_limits<T>::max();
+            info[INFO_RESTARTS] = (T)(-a.lq_attempts);
+            blk[Lbh] = (T)(-a.lq_attempts);
+        }
+    }
+}
+
 // One thread per problem.  The sweep is a long chain of tiny dependent matrix products: straight from global
 // memory every operand costs a ~600-cycle round trip (measured 720 us per call at B=1024, 2/1, H=20).  So a
 // workgroup first copies the whole working set of its `ppw` problems (iterate, gradient, defects, tiles,
@@ -231,7 +468,9 @@ __device__ __forceinline__ float inv_sqrt_pos(float d) {
 // Problems whose working set does not fit in LDS fall back to global temporaries (ppw = 64, use_lds = 0).
 // NX, NU > 0: dimensions fixed at compile time -- every small loop unrolls and the temporaries live in registers
 // (2/1 and 6/3, the BASELINE shapes); NX = NU = 0: runtime dimensions, temporaries in LDS / global memory.
-template <typename T, int NX, int NU, bool LDS>
+// SCAN (2/1 stages, LDS mode): the sweeps are replaced by lq_scan_problem, a wave per problem; staging and the post-pass
+// are the same code.
+template <typename T, int NX, int NU, bool LDS, bool SCAN = false>
 __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T* lds = reinterpret_cast<T*>(lds_raw);
@@ -330,6 +569,11 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         }
     }
     LQ_STAMP(1);
+    if constexpr (SCAN) {
+        static_assert(LDS && NX == 2 && NU == 1, "the scan is written for 2-state / 1-control stages staged in LDS");
+        for (int pp = wvu; pp < np; pp += 4)
+            lq_scan_problem<T>(a, b0 + pp, lane & 63, lds + (size_t)pp * a.lds_stride, Lgr, Lgc, Ltl, LW, Llam, Ldz, Lbh);
+    } else {
     T* dzg = mine ? (T*)a.dz + (size_t)b * n : nullptr;
     if (mine && a.status[b] >= 0) {
         // finished problem: zero step (written through the copy-out below in LDS mode)
@@ -768,6 +1012,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
 #undef GRX
 #undef BHX
     }
+    }   // !SCAN
     LQ_STAMP(2);
     if (LDS) {
         __syncthreads();
@@ -2047,6 +2292,18 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
     const int lq_spec_env = [] { const char* e = getenv("NEMPC_LQ_SPEC"); return e ? atoi(e) : 0; }();   // A/B knob (tests)
     a.spec = wave_wanted ? 1 : std::max(1, std::min(std::min(a.lq_attempts, lq_spec_env > 0 ? lq_spec_env : 3), 8));
     a.att_elems = H * nu * nx + H * nu + H * nx * nx + H * nx + lq_tmp_elems(nx, nu);
+    // parallel-in-time solve (lq_scan_problem): 2/1 stages in double, a stage per lane
+    static const int lq_scan_env = [] { const char* e = getenv("NEMPC_LQ_SCAN"); return e ? atoi(e) : 1; }();   // A/B knob
+    const bool scan_fits = sizeof(T) == 8 && nx == 2 && nu == 1 && H + 1 <= 64;
+    if (o.lq_kernel == 3 && !scan_fits) {
+        set_error("nempc_solve: lq_kernel = 3 (scan) is built for 2-state / 1-control stages in fp64 with H <= 63");
+        return NEMPC_EUNSUPPORTED;
+    }
+    const bool lq_scan = scan_fits && (o.lq_kernel == 3 || (o.lq_kernel == 0 && lq_scan_env != 0));
+    if (lq_scan) {
+        a.spec = std::max(1, std::min(a.lq_attempts, 64 / (H + 1)));     // levels side by side: lane segments of H + 1
+        a.att_elems = 0;                                                    // (no per-attempt region: the scan lives in registers)
+    }
     int per_problem;
     for (;; --a.spec) {
         per_problem = 2 * n + 2 * H * nx + H * nx * nin + H * nin * nin + n + n + a.spec * a.att_elems;
@@ -2088,6 +2345,8 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
     if (lq_wave)
         lqk = (nx == 2 && nu == 1) ? solver_lqw_kernel<T, 2, 1>
                                    : ((nx == 6 && nu == 3) ? solver_lqw_kernel<T, 6, 3> : solver_lqw_kernel<T, 0, 0>);
+    if constexpr (sizeof(T) == 8)
+        if (lq_scan && a.use_lds && !lq_wave) lqk = solver_lq_kernel<T, 2, 1, true, true>;
     {
         const int ppw_max = (int)((size_t)150 * 1024 / ((size_t)per_problem * sizeof(T)));
         const size_t lds_max = a.use_lds ? (size_t)std::min(std::max(ppw_max, 1), 16) * per_problem * sizeof(T) : 0;

@@ -410,8 +410,8 @@ class CallbackEngine:
               compact=True, return_iterations=False, barrier="primal-dual", linesearch="auto", lq_attempts=0):
         """Batched on-device solve (Gauss-Newton SQP, see csrc/solver.hip).  X0 (B,nx) device tensor; Z_init (B,n)
         or None for the reference's cold start [x0 tiled H ; zeros] (optimizer/ipopt.py:149); lb/ub (n) host
-        vectors as DomainConstraint produces them; tolerances default by dtype (fp64 1e-8, fp32 1e-4); lq_kernel picks the Riccati sweep ("auto" | "thread" per problem | "wave"
-        per problem); compact=True gathers the unconverged problems to the front as the batch converges (same results,
+        vectors as DomainConstraint produces them; tolerances default by dtype (fp64 1e-8, fp32 1e-4); lq_kernel picks the LQ solve ("auto" | "thread" per problem | "wave"
+        per problem | "scan": parallel in time, 2/1 stages in fp64); compact=True gathers the unconverged problems to the front as the batch converges (same results,
         shorter launches); linesearch "loop" backtracks inside an iteration (every problem waits for the slowest search),
         "deferred" tries one step length per iteration and lets a rejected problem retry at half the length in the next one
         (about half the time per iteration at the 2/1 shape, more iterations for hard problems), "auto" defers for small
@@ -444,7 +444,7 @@ class CallbackEngine:
                 ptrs.append(p)
         its_dev = torch.zeros(B, dtype=torch.int32, device=self.device) if return_iterations else None
         opts = _lib.NempcSolverOpts(max_iter=max_iter, max_linesearch=max_linesearch, check_every=check_every,
-                                    lq_kernel={"auto": 0, "thread": 1, "wave": 2}[lq_kernel],
+                                    lq_kernel={"auto": 0, "thread": 1, "wave": 2, "scan": 3}[lq_kernel],
                                     tol_constraint=tol_constraint, tol_step=tol_step, mu_init=mu_init, mu_min=mu_min,
                                     mu_factor=mu_factor, reg=reg, compact=1 if compact else 0,
                                     barrier={"primal-dual": 0, "primal": 1}[barrier],
