@@ -40,6 +40,10 @@ struct HessParams {
     const int32_t* smap;
     const void* objc;
     int nnz, n_orph;
+    // blocks AND the rows' first-order evaluation from one launch (fixed-shape kernel only; the batched solver's trial
+    // point): defects (B, m) and compact tiles (B, H, nx, nin)
+    void* ev_g;
+    void* ev_tiles;
 };
 
 template <typename T, int WP, int NH, bool WLDS, int ACT>

@@ -27,12 +27,13 @@
 
 namespace nempc {
 
-template <typename T, int WP, int NH, int NT, int NX, int NU, int TG = NX + NU>
+template <typename T, int WP, int NH, int NT, int NX, int NU, int TG = NX + NU, bool EV = false>
 struct HfxLayout {   // element offsets inside dynamic LDS, all compile-time (TG: tangent directions per exchange)
     static constexpr int MT = WP / 16;
     static constexpr int NIN = NX + NU;
     static constexpr int KS = (NIN + 3) / 4;
     static constexpr int NPAIR = NIN * (NIN + 1) / 2;
+    static constexpr int NVT = NPAIR + (EV ? NX * NIN + NX : 0);      // K-split quantities per row: pairs [+ tile + outputs]
     static constexpr int up16(int v) { return (v + 15) & ~15; }
     // small tables, copied flat from off.fx_small: [w0f | seed | bias_0..NH-1 | biasL | p0tab]
     static constexpr int W0F = 0;
@@ -45,7 +46,7 @@ struct HfxLayout {   // element offsets inside dynamic LDS, all compile-time (TG
     static constexpr int XH = NT * TG * MT * 256;                    // exchange buffer: two halves of NT * TG sets
     static constexpr int X = up16(PP + NPAIR * MT * 16);
     static constexpr int PART = X + 2 * XH;                          // K-split partials [w][j][pq][16 rows]
-    static constexpr int PART_SZ = up16(MT * NT * NPAIR * 16);
+    static constexpr int PART_SZ = up16(MT * NT * NVT * 16);
     static constexpr int IN_TILE = 16 * (NIN + NX);                  // per tile xi[16][NIN] then lambda[16][NX]
     static constexpr int IN = PART + PART_SZ;
     static constexpr int IN_SZ = up16(NT * IN_TILE);
@@ -75,6 +76,11 @@ struct HfxArgs {   // host-prepared
     const int32_t* smap;
     const void* objc;
     int nnz, n_orph;
+    // EV instantiation (the batched solver): the first-order evaluation of the same rows leaves with the blocks -- defects
+    // g (B, m) [the first H*NX rows of a problem] and compact tiles (B, H, NX, NIN), as the row kernels write them
+    void* g_out;
+    void* tiles_out;
+    int ident;              // 1: Discret (Phi = x + f), 0: Unity
 };
 
 template <typename T, int NT, int NTHREADS, int NCOL>
@@ -133,7 +139,10 @@ __device__ __forceinline__ void hfx_stage_store(T* in, int tid, const HfxStage<T
 // RWB: the backward slices (W_l as an A operand) are fetched at the start of every pass instead of living in registers
 // for the whole kernel -- they are read by the base reverse sweep only, and at widths where a pass is tens of thousands
 // of cycles (3x128) their registers are what the tangent / contraction phase needs.
-template <typename T, int WP, int NH, int NT, int NX, int NU, int NTc, int ACT, int TG, bool RWB>
+// EV: the pass also leaves the rows' first-order evaluation (HfxArgs::g_out / tiles_out): the outputs W_L a + b_L from the
+// activations the forward sweep holds, the tile W_L (s' * P_{NH-1}) from the last layer's tangents -- NX * (NIN + 1) more
+// K-split quantities per row next to the NPAIR pair sums, no further matrix product.
+template <typename T, int WP, int NH, int NT, int NX, int NU, int NTc, int ACT, int TG, bool RWB, bool EV = false>
 __device__ __forceinline__ void hfx_pass(const HfxArgs& a, T* lds, const T (&wf)[NH > 1 ? NH - 1 : 1][(WP / 16) * 4],
                                          const T (&wb_res)[NH > 1 ? NH - 1 : 1][(WP / 16) * 4], const T* in, int t0, int tid,
                                          int& xsel, const HfxStage<T, NT, (WP / 16) * 64, NX + NU + NX>& nxt, bool has_next,
@@ -141,10 +150,12 @@ __device__ __forceinline__ void hfx_pass(const HfxArgs& a, T* lds, const T (&wf)
     using Ops = MfmaOps<T>;
     using A = Act<T, ACT>;
     using V4 = typename Ops::V4;
-    using L = HfxLayout<T, WP, NH, NT, NX, NU, TG>;
-    constexpr int MT = WP / 16, NTHREADS = MT * 64, NIN = NX + NU, KS = L::KS, NPAIR = L::NPAIR;
+    using L = HfxLayout<T, WP, NH, NT, NX, NU, TG, EV>;
+    constexpr int MT = WP / 16, NTHREADS = MT * 64, NIN = NX + NU, KS = L::KS, NPAIR = L::NPAIR, NVT = L::NVT;
+    static_assert(!EV || NH > 1, "the evaluation outputs read the last hidden layer's tangents");
     const int lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
+    T ev[NTc][EV ? NX * NIN + NX : 1];      // EV: tile partials [k][p], then output partials [k]
 
     T wb[NH > 1 ? NH - 1 : 1][MT * 4];
     if constexpr (RWB) {
@@ -236,6 +247,12 @@ __device__ __forceinline__ void hfx_pass(const HfxArgs& a, T* lds, const T (&wf)
                 const T lm = in[j * L::IN_TILE + 16 * NIN + c * NX + k];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dl[j][r] = fma(wl[r], lm, dl[j][r]);
+                if constexpr (EV) {      // output k over this lane's features (s still holds the activations)
+                    T v = wl[0] * s[NH - 1][j][0];
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) v = fma(wl[r], s[NH - 1][j][r], v);
+                    ev[j][NX * NIN + k] = v;
+                }
             }
         }
 #pragma unroll
@@ -350,16 +367,42 @@ __device__ __forceinline__ void hfx_pass(const HfxArgs& a, T* lds, const T (&wf)
 #pragma unroll
                     for (int j = 0; j < NTc; ++j) tg[p][j] = s[l][j] * P[p][j];
             }
+            if constexpr (EV) {
+                if (l == NH - 1) {       // tile[k][p] = sum_features W_L[k] * s'(z) * P[p]
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) {
+                        const T* seed = lds + L::SEED + k * MT * 16 + w * 16;
+                        V4 wl;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) wl[r] = seed[r * 4 + q];
+#pragma unroll
+                        for (int j = 0; j < NTc; ++j) {
+                            const V4 ws1 = wl * s[l][j];
+#pragma unroll
+                            for (int p = 0; p < NIN; ++p) {
+                                T v = ws1[0] * P[p][j][0];
+#pragma unroll
+                                for (int r = 1; r < 4; ++r) v = fma(ws1[r], P[p][j][r], v);
+                                ev[j][k * NIN + p] = v;
+                            }
+                        }
+                    }
+                }
+            }
         }
     }
     // ---- quad sums -> this wave's partials [j][pq][16 rows]
     {
-        T sv[NTc * NPAIR];
+        T sv[NTc * NVT];
 #pragma unroll
-        for (int j = 0; j < NTc; ++j)
+        for (int j = 0; j < NTc; ++j) {
 #pragma unroll
-            for (int pq = 0; pq < NPAIR; ++pq) sv[j * NPAIR + pq] = acc[j][pq];
-        fx_rowsums_store<T, NTc * NPAIR>(sv, lds + L::PART + w * (NT * NPAIR) * 16, lane);
+            for (int pq = 0; pq < NPAIR; ++pq) sv[j * NVT + pq] = acc[j][pq];
+            if constexpr (EV)
+#pragma unroll
+                for (int e = 0; e < NVT - NPAIR; ++e) sv[j * NVT + NPAIR + e] = ev[j][e];
+        }
+        fx_rowsums_store<T, NTc * NVT>(sv, lds + L::PART + w * (NT * NVT) * 16, lane);
     }
     lds_barrier();
     if (has_next) hfx_stage_store<T, WP, NH, NT, NT, NX, NU, TG>(in_next, tid, nxt);
@@ -381,7 +424,7 @@ __device__ __forceinline__ void hfx_pass(const HfxArgs& a, T* lds, const T (&wf)
             const int pq = hi * (hi + 1) / 2 + lo;
             T v = T(0);
 #pragma unroll
-            for (int ww = 0; ww < MT; ++ww) v += PART[(ww * (NT * NPAIR) + j * NPAIR + pq) * 16 + cc];
+            for (int ww = 0; ww < MT; ++ww) v += PART[(ww * (NT * NVT) + j * NVT + pq) * 16 + cc];
             if (hv) {
                 // fused assembly (nempc_hess asked for the tril values only): assemble_hess_kernel's arithmetic, here
                 const T* sg = static_cast<const T*>(a.sigma);
@@ -399,12 +442,43 @@ __device__ __forceinline__ void hfx_pass(const HfxArgs& a, T* lds, const T (&wf)
             }
         }
     }
+    if constexpr (EV) {
+        // the rows' evaluation: tile entries (+ the identity of Discret), then the defects Phi - x_t
+        constexpr int ESZ = NX * NIN + NX;
+        T* const tl = static_cast<T*>(a.tiles_out);
+        T* const go = static_cast<T*>(a.g_out);
+        const T* __restrict__ Zg = static_cast<const T*>(a.Z);
+#pragma unroll
+        for (int it = 0; it < (NTc * 16 * ESZ + NTHREADS - 1) / NTHREADS; ++it) {
+            const int item = tid + it * NTHREADS;
+            const int idx = item / ESZ, e = item - idx * ESZ;
+            const unsigned r = (unsigned)t0 * 16u + (unsigned)idx;
+            if (item < NTc * 16 * ESZ && r < a.R) {
+                const int j = idx >> 4, cc = idx & 15;
+                T v = T(0);
+#pragma unroll
+                for (int ww = 0; ww < MT; ++ww) v += PART[(ww * (NT * NVT) + j * NVT + NPAIR + e) * 16 + cc];
+                if (e < NX * NIN) {
+                    const int k = e / NIN, pcol = e - k * NIN;
+                    if (a.ident && pcol == k) v += T(1);
+                    tl[(size_t)r * (NX * NIN) + e] = v;
+                } else {
+                    const int k = e - NX * NIN;
+                    const unsigned b = a.invH ? __umulhi(r, a.invH) : r;
+                    const int t = (int)(r - b * (unsigned)a.H);
+                    v += lds[L::BIASL + (sizeof(T) == 8 ? k : (k & 3) * 4 + (k >> 2))];     // (packed in the output tile's lane order)
+                    if (a.ident) v += in[j * L::IN_TILE + cc * NIN + k];
+                    go[(size_t)b * a.m + t * NX + k] = v - Zg[(size_t)b * a.n + t * NX + k];
+                }
+            }
+        }
+    }
     lds_barrier();
 }
 
-template <typename T, int WP, int NH, int NT, int NX, int NU, int ACT, int TG = NX + NU, bool RWB = false>
+template <typename T, int WP, int NH, int NT, int NX, int NU, int ACT, int TG = NX + NU, bool RWB = false, bool EV = false>
 __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coopfx_kernel(HfxArgs a) {
-    using L = HfxLayout<T, WP, NH, NT, NX, NU, TG>;
+    using L = HfxLayout<T, WP, NH, NT, NX, NU, TG, EV>;
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
     constexpr int VEC = 16 / (int)sizeof(T);
@@ -483,8 +557,8 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coopfx_kernel(HfxAr
         lds_barrier();
         const T* in = in_base + parity * L::IN_SZ;
         T* const in_next = in_base + (parity ^ 1) * L::IN_SZ;
-        if (n_cur == 1) hfx_pass<T, WP, NH, NT, NX, NU, 1, ACT, TG, RWB>(a, lds, wf, wb, in, t_cur, tid, xsel, sr, more, in_next);
-        if constexpr (NT >= 2) { if (n_cur == 2) hfx_pass<T, WP, NH, NT, NX, NU, 2, ACT, TG, RWB>(a, lds, wf, wb, in, t_cur, tid, xsel, sr, more, in_next); }
+        if (n_cur == 1) hfx_pass<T, WP, NH, NT, NX, NU, 1, ACT, TG, RWB, EV>(a, lds, wf, wb, in, t_cur, tid, xsel, sr, more, in_next);
+        if constexpr (NT >= 2) { if (n_cur == 2) hfx_pass<T, WP, NH, NT, NX, NU, 2, ACT, TG, RWB, EV>(a, lds, wf, wb, in, t_cur, tid, xsel, sr, more, in_next); }
         parity ^= 1;
     }
 }

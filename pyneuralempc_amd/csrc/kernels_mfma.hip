@@ -300,9 +300,18 @@ int launch_rowhess_mfma_hvals(Handle& h, int B, const void* Z, const void* X0, c
     return launch_rowhess_mfma_direct(h, B, Z, X0, lambda, nullptr, nullptr, 0, nullptr, 1, s, hvals, sigma);
 }
 
+// Lagrangian blocks and the first-order evaluation (defects, compact tiles) of the same rows in ONE launch of the
+// fixed-shape Hessian kernel -- the batched solver's trial point.  NEMPC_EUNSUPPORTED (nothing launched) for other shapes.
+int launch_rowhess_eval_mfma(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks, void* g,
+                             void* tiles, hipStream_t s) {
+    static const int on = [] { const char* e = getenv("NEMPC_HFX_EVAL"); return e ? atoi(e) : 1; }();
+    if (!on || !h.mfma.blob || h.w != 1 || h.ne != 0 || !blocks || !g || !tiles) return NEMPC_EUNSUPPORTED;
+    return launch_rowhess_mfma_direct(h, B, Z, X0, lambda, blocks, nullptr, 0, nullptr, 1, s, nullptr, nullptr, g, tiles);
+}
+
 int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
                                const void* xi_direct, int xi_stride, const void* lam_direct, int vdiv, hipStream_t s,
-                               void* fuse_hvals, const void* fuse_sigma) {
+                               void* fuse_hvals, const void* fuse_sigma, void* ev_g, void* ev_tiles) {
     if (!h.mfma.blob) {
         set_error("launch_rowhess_mfma: weights not packed");
         return NEMPC_ESTATE;
@@ -322,6 +331,7 @@ int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, 
     p.scratch_per_wave = (16 * h.nin + 16 * h.cfg.nx + 16 * h.nin * h.nin + 16 * h.ne + 1) & ~1;
     p.dbg = nullptr;
     hp.lambda = lambda; hp.blocks = blocks;
+    hp.ev_g = ev_g; hp.ev_tiles = ev_tiles;
     if (fuse_hvals) {       // the kernel assembles the tril values itself (launch_rowhess_mfma_hvals)
         hp.hvals = fuse_hvals; hp.sigma = fuse_sigma; hp.smap = h.d_hess_smap;
         hp.objc = (const char*)h.d_obj + (size_t)obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu).total * h.esz;

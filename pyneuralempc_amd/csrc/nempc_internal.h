@@ -209,7 +209,10 @@ int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, voi
                             int stage_stride, hipStream_t s);
 int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
                                const void* xi_direct, int xi_stride, const void* lam_direct, int vdiv, hipStream_t s,
-                               void* fuse_hvals = nullptr, const void* fuse_sigma = nullptr);
+                               void* fuse_hvals = nullptr, const void* fuse_sigma = nullptr, void* ev_g = nullptr,
+                               void* ev_tiles = nullptr);
+int launch_rowhess_eval_mfma(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks, void* g,
+                             void* tiles, hipStream_t s);
 
 // ---- kernels_rk4hess.hip : RK4 Lagrangian blocks on the matrix cores (stage records -> stage multipliers ->
 //      contracted network Hessians of the four stage inputs -> congruence sum)

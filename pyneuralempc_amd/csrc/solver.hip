@@ -69,6 +69,10 @@ struct SolverArgs {
     int* n_done;          // acceptance launches of the inner loop: blocks finished (the last one publishes)
     int carry;            // the trial evaluation is a full one and becomes the next iterate's on acceptance (tiles_t, grad_t)
     const void *tiles_t, *grad_t;
+    // ... with the Lagrangian blocks of the trial point too (one launch: blocks + evaluation, launch_rowhess_eval_mfma): the
+    // step kernel writes the multipliers the trial point would have, lam + alpha (lamn - lam); hblk_t is carried over on
+    // acceptance like the tiles
+    void* lam_t; const void* hblk_t;
     int fuse_step;        // thread-per-problem Riccati kernel in LDS mode: it also does solver_step_kernel's work
     void* f_it; void* Zt_it;   // ... with the iterate's objective values (B) and the trial-point buffer (B,n)
     int* status; int* lsdone; int* n_active; int* n_pending;   // counters the host polls: unconverged problems / problems still backtracking
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     const int pl = lane < ppw * spec ? lane - aj0 * ppw : lane;   // its problem's slot in the workgroup
     // element offsets of the per-problem LDS block: the arrays every attempt reads, the results, then one region per attempt
     const int Lz = 0, Lgr = Lz + n, Lgc = Lgr + n, Ltl = Lgc + H * nx, LW = Ltl + H * nx * nin, Llam = LW + H * nin * nin,
-              Ldz = Llam + H * nx, Lbh = Ldz + n, Latt = Lbh + n + aj0 * a.att_elems, LK = Latt, Lk = LK + H * nu * nx,
+              Ldz = Llam + H * nx, Lbh = Ldz + n, Llc = Lbh + n, Latt = Llc + H * nx + aj0 * a.att_elems, LK = Latt, Lk = LK + H * nu * nx,
               LP = Lk + H * nu, Lp = LP + H * nx * nx, Ltmp = Lp + H * nx;
     const int b = blockIdx.x * ppw + pl;
     const bool mine = lane < ppw * spec && b < a.B;
@@ -528,6 +532,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                 const T vzl = in_n && pdl ? ((const T*)a.zl)[(size_t)bq * n + e] : T(0);
                 const T vzu = in_n && pdl ? ((const T*)a.zu)[(size_t)bq * n + e] : T(0);
                 const T vgc = e < H * nx ? ((const T*)a.g)[(size_t)bq * a.m + e] : T(0);
+                const T vlc = e < H * nx && a.lam_t ? ((const T*)a.lam)[(size_t)bq * a.m + e] : T(0);
                 const T* tq = (const T*)a.tiles + (size_t)bq * Ntl;
                 const T* wq = (const T*)a.hblk + (size_t)bq * NW;
                 const T vt0 = e < Ntl ? tq[e] : T(0), vt1 = e1 < Ntl ? tq[e1] : T(0);
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                 if (e < NW) blkp[LW + e] = vw0;
                 if (e1 < NW) blkp[LW + e1] = vw1;
                 if (e2 < NW) blkp[LW + e2] = vw2;
-                if (e < H * nx) blkp[Lgc + e] = vgc;
+                if (e < H * nx) { blkp[Lgc + e] = vgc; blkp[Llc + e] = vlc; }
                 if (in_n) {
                     T ga, ha;
                     barrier_terms_of<T>(pdl, mu_q, st_q, vz, vlo, vhi, vzl, vzu, ga, ha);
@@ -563,6 +568,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             }
         }
         stage_in((const T*)a.g, H * nx, a.m, Lgc);
+        if (a.lam_t) stage_in((const T*)a.lam, H * nx, a.m, Llc);
         stage_in((const T*)a.tiles, H * nx * nin, H * nx * nin, Ltl);
         stage_in((const T*)a.hblk, H * nin * nin, H * nin * nin, LW);
         __syncthreads();
@@ -1090,6 +1096,13 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                     LQ_STAMP(6);
                     T* zt = (T*)a.Zt_it + (size_t)bp * n;
                     for (int i = ln; i < n; i += 64) zt[i] = lsd ? blk[Lz + i] : fma(al, blk[Ldz + i], blk[Lz + i]);
+                    if (a.lam_t) {       // multipliers of the trial point (what the acceptance kernel sets on acceptance)
+                        T* lt = (T*)a.lam_t + (size_t)bp * a.m;
+                        for (int i = ln; i < H * nx; i += 64) {
+                            const T l0 = blk[Llc + i];          // (the current multipliers were staged with the working set)
+                            lt[i] = lsd ? l0 : fma(al, blk[Llam + i] - l0, l0);
+                        }
+                    }
                 }
             }
         }
@@ -1596,18 +1609,23 @@ __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* 
     const T* lb = (const T*)a.lb;
     const T* ub = (const T*)a.ub;
     const int H = a.H, nx = a.nx;
+    // objective value of the trial point, when no launch has left it in `ft` (shapes without the fused evaluation, and the
+    // compiled shape whose trial launch computes the Lagrangian blocks instead): the wave has the point in hand, and a
+    // launch of its own for one number per problem costs more than the number.  First in the kernel, before the problem's
+    // scalars are waited for: its loads share their round trip.  (carry: the trial point's objective gradient is written too,
+    // it is the next iterate's)
+    T ftb = T(0);
+    if (!ft) ftb = (T)wave_bcast_lane0(objective_row_value<T>(b, lane, H, nx, a.nu, a.oo, (const T*)a.obj, Zt + (size_t)slot * a.n,
+                                                                 a.carry ? (T*)a.grad_t : (T*)nullptr));
     // the problem's scalars, requested together (one global round trip instead of one per use)
     const int done = a.lsdone[b];
     const T mub = mu[b], nub = nu[b], al = alpha[b], ph0 = phi0[b], drb = dir[b];
-    T ftb = ft ? ft[slot] : T(0);
+    if (ft) ftb = ft[slot];
     const T az = a.primal_dual ? ((const T*)a.alz)[b] : T(0);
     const T lsr = info[INFO_LSR], lsk = info[INFO_LSK], regb = reg[b];
     if (done) return;
     const T* zt = Zt + (size_t)slot * a.n;
     const T* gtb = gt + (size_t)slot * a.m;
-    // objective value of the trial point, when no launch has left it in `ft` (shapes without the fused evaluation): the
-    // wave has the point in hand, and a launch of its own for one number per problem costs more than the number
-    if (!ft) ftb = (T)wave_bcast_lane0(objective_row_value<T>(b, lane, H, nx, a.nu, a.oo, (const T*)a.obj, zt, (T*)nullptr));
     // log-barrier value and l1 norm of the defects at the trial point, one loop (the loads of both in flight together;
     // per-lane order and tree as barrier_value / l1_norm)
     double accb = 0.0, accg = 0.0;
@@ -1665,6 +1683,12 @@ __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* 
             const T* ts = (const T*)a.tiles_t + (size_t)b * ntl;
             T* td = (T*)a.tiles + (size_t)b * ntl;
             for (int i = lane; i < ntl; i += 64) td[i] = ts[i];
+            if (a.hblk_t) {
+                const int nhb = H * (nx + a.nu) * (nx + a.nu);
+                const T* hs = (const T*)a.hblk_t + (size_t)b * nhb;
+                T* hd = (T*)a.hblk + (size_t)b * nhb;
+                for (int i = lane; i < nhb; i += 64) hd[i] = hs[i];
+            }
             for (int i = a.n + lane; i < a.m; i += 64) ((T*)a.g)[(size_t)b * a.m + i] = gtb[i];      // (rows beyond n, if any)
             if (lane == 0) ((T*)a.f_it)[b] = ftb;
         }
@@ -1989,6 +2013,7 @@ struct SolverWs {
     std::vector<unsigned char> robj_host;     // the augmented objective table as last uploaded
     void *Zt = nullptr, *f = nullptr, *ft = nullptr, *grad = nullptr, *g = nullptr, *gt = nullptr, *tiles = nullptr;
     void *tiles_t = nullptr, *grad_t = nullptr;     // trial point's tiles and objective gradient (carried over on acceptance)
+    void *lam_t = nullptr, *hblk_t = nullptr;       // ... its multipliers and Lagrangian blocks (blocks + evaluation in one launch)
     void *X0p = nullptr, *exp_ = nullptr;           // initial states / extras of the problems still backtracking, dense
     int* pend[2] = {nullptr, nullptr};              // ... and their indices (two lists: one read, one appended to)
     void *lb = nullptr, *ub = nullptr, *mu = nullptr, *nu = nullptr, *reg = nullptr, *alpha = nullptr, *phi0 = nullptr,
@@ -2026,7 +2051,7 @@ void solver_free(Handle& h) {
     if (!w) return;
     void** ptrs[] = {&w->Zt, &w->f, &w->ft, &w->grad, &w->g, &w->gt, &w->tiles, &w->lb, &w->ub, &w->mu, &w->nu, &w->reg,
                      &w->alpha, &w->phi0, &w->dir, &w->hblk, &w->lam, &w->lamn, &w->sig, &w->dz, &w->Kst, &w->kst, &w->Pst, &w->pst, &w->tmp,
-                     &w->tiles_t, &w->grad_t, &w->X0p, &w->exp_};
+                     &w->tiles_t, &w->grad_t, &w->X0p, &w->exp_, &w->lam_t, &w->hblk_t};
     for (void** p : ptrs)
         if (*p) (void)hipFree(*p);
     if (w->lsdone) (void)hipFree(w->lsdone);
@@ -2091,7 +2116,7 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
                 {&w2.kst, Bn * H * nu * e}, {&w2.Pst, Bn * H * nx * nx * e}, {&w2.pst, Bn * H * nx * e},
                 {&w2.tmp, Bn * lq_tmp_elems(nx, nu) * e}, {&w2.dzl, Bn * n * e}, {&w2.dzu, Bn * n * e}, {&w2.alz, Bn * e},
                 {&w2.bh, Bn * n * e}, {&w2.tiles_t, Bn * H * nx * nin * e}, {&w2.grad_t, Bn * n * e},
-                {&w2.X0p, Bn * nx * e}, {&w2.exp_, Bn * ex_per * e}};
+                {&w2.X0p, Bn * nx * e}, {&w2.exp_, Bn * ex_per * e}, {&w2.lam_t, Bn * m * e}, {&w2.hblk_t, Bn * H * nin * nin * e}};
             for (auto& x : al) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
             for (int k = 0; k < 2; ++k) {
                 struct { void** p; size_t bytes; } al2[] = {
@@ -2306,7 +2331,7 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
     }
     int per_problem;
     for (;; --a.spec) {
-        per_problem = 2 * n + 2 * H * nx + H * nx * nin + H * nin * nin + n + n + a.spec * a.att_elems;
+        per_problem = 2 * n + 2 * H * nx + H * nx * nin + H * nin * nin + n + n + H * nx + a.spec * a.att_elems;
         per_problem |= 1;   // odd stride: the ppw lanes of a sweep hit different LDS banks
         if (a.spec == 1 || (size_t)per_problem * sizeof(T) <= (size_t)150 * 1024) break;   // (levels one after the other if not)
     }
@@ -2359,7 +2384,12 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
                  !rolling;
     int pend_seq = 0;             // sequence number of the inner loop's acceptance launches (published with their count)
     bool have_eval = false;       // the evaluation buffers hold every active problem's current iterate
-    a.carry = 0; a.tiles_t = ws.tiles_t; a.grad_t = ws.grad_t;
+    bool have_blocks = false;     // ... and so does the block buffer
+    // the trial point's Lagrangian blocks from the launch that evaluates it (compiled shape): an iteration is then the LQ
+    // solve, ONE callback launch and the acceptance test
+    const int hess_trial_env = [] { const char* e = getenv("NEMPC_SOLVER_HESS_TRIAL"); return e ? atoi(e) : 1; }();   // A/B knob (tests)
+    bool hess_trial = carry && a.fuse_step && hess_trial_env != 0;
+    a.carry = 0; a.tiles_t = ws.tiles_t; a.grad_t = ws.grad_t; a.lam_t = nullptr; a.hblk_t = nullptr;
     a.hpub = ws.hpub_dev;
     for (int k = 0; k < 8; ++k) ws.hpub[k] = 0;       // (the previous solve on this handle ended with a synchronised stream)
     const bool published_polls = !wave_wanted;  // small stages (chains of latency-bound launches): no blocking polls, the host
@@ -2425,12 +2455,18 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
             rc = roll_eval_iterate(Zc, ws.lamc[cur]);
         } else if (have_eval) {
             // deferred backtracking on a compiled shape: the trial evaluation of the last iteration was a full one and the
-            // acceptance kernel kept, per problem, the evaluation of the point it stands on -- only the blocks are new
+            // acceptance kernel kept, per problem, the evaluation of the point it stands on -- only the blocks are new, and
+            // not even those when the trial launch computed them
             fused_eval = true;
-            rc = h.variant != NEMPC_KERNEL_VALU ? launch_rowhess_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s)
-                                                : launch_rowhess_valu(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s);
+            rc = have_blocks ? NEMPC_OK
+                             : (h.variant != NEMPC_KERNEL_VALU ? launch_rowhess_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s)
+                                                               : launch_rowhess_valu(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s));
         } else if (rk4_pipeline) {
             rc = launch_rowhess_rk4_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s, ws.g, ws.tiles);
+        } else if (carry && hess_trial &&
+                   (rc = launch_rowhess_eval_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, ws.g, ws.tiles, s)) != NEMPC_EUNSUPPORTED) {
+            // first iterate (and the one after a compaction) through the kernel the trial points go through -- the same
+            // arithmetic whichever way an iterate's evaluation was obtained: blocks, defects, tiles; f and grad below
         } else {
             // compiled shapes: defects, tiles, f and grad from one launch
             fused_eval = h.variant == NEMPC_KERNEL_MFMA &&
@@ -2446,6 +2482,7 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         if (!fused_eval && (rc = launch_objective(h, Bact, Zc, ws.f, ws.grad, s))) return rc;
         // bounds: barrier diagonal for the LQ model, barrier gradient folded into grad
         if (!a.use_lds) hipLaunchKernelGGL(solver_barrier_kernel<T>, dim3(gAn), dim3(256), 0, s, a);
+        a.lam_t = carry && hess_trial ? ws.lam_t : nullptr;
         // LDS mode: four waves stage the working set, the first ppw lanes run the sweeps
         hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (Bact + a.ppw - 1) / a.ppw : (Bact + 63) / 64), dim3(a.use_lds ? 256 : 64),
                            lds_need, s, a);
@@ -2505,16 +2542,23 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
             }
             // the merit function needs the defects only: the matrix-core kernel skips its reverse sweeps (tiles = null)
             // (compiled shapes: defects and f of the trial point from one forward-only launch)
-            bool fused_trial = false;
-            a.carry = 0;
-            if (carry) {
+            bool fused_trial = false, trial_done = false;
+            a.carry = 0; a.hblk_t = nullptr;
+            if (carry && hess_trial) {
+                // blocks, defects and tiles of the trial point from one launch (the acceptance kernel evaluates the objective)
+                rc = launch_rowhess_eval_mfma(h, nb, ws.Zt, X0t, ws.lam_t, ws.hblk_t, ws.gt, ws.tiles_t, s);
+                if (rc == NEMPC_EUNSUPPORTED) hess_trial = false;
+                else { trial_done = true; a.carry = 1; a.hblk_t = ws.hblk_t; }
+            }
+            if (carry && !trial_done) {
                 // full evaluation of the trial point (tiles and gradient too): it is the next iterate's if accepted
                 fused_trial = (rc = launch_eval_fused(h, nb, ws.Zt, X0t, ws.gt, ws.tiles_t, nullptr, ws.ft, ws.grad_t, s)) !=
                               NEMPC_EUNSUPPORTED;
                 if (!fused_trial) carry = false;      // not a compiled shape
                 else a.carry = 1;
             }
-            if (rolling) {
+            if (trial_done) {
+            } else if (rolling) {
                 rc = roll_eval_trial(ws.Zt);
             } else {
                 if (!fused_trial)
@@ -2531,6 +2575,7 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
                                ls > 0 ? (const int*)ws.pend[ls & 1] : (const int*)nullptr, ws.pend[(ls + 1) & 1],
                                ls == 0 ? 1 : 0, lsm == 2 ? 0 : ++pend_seq);
             have_eval = a.carry != 0;
+            have_blocks = have_eval && a.hblk_t != nullptr;
             if (lsm == 2) break;          // one trial per outer iteration: nothing to poll
             // most iterations accept the first trial for every problem: one small poll saves the remaining
             // max_linesearch-1 callback evaluations
@@ -2661,6 +2706,7 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
             cur = nxt;
             point_at(cur);
             have_eval = false;            // (the evaluation buffers are not gathered: one launch after a compaction)
+            have_blocks = false;
             if (published_polls) {
                 Bact = nact > 0 ? (nact < Bact ? nact : Bact) : 1;
             } else {
