@@ -1614,24 +1614,42 @@ __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* 
     // launch of its own for one number per problem costs more than the number.  First in the kernel, before the problem's
     // scalars are waited for: its loads share their round trip.  (carry: the trial point's objective gradient is written too,
     // it is the next iterate's)
-    T ftb = T(0);
-    if (!ft) ftb = (T)wave_bcast_lane0(objective_row_value<T>(b, lane, H, nx, a.nu, a.oo, (const T*)a.obj, Zt + (size_t)slot * a.n,
-                                                                 a.carry ? (T*)a.grad_t : (T*)nullptr));
-    // the problem's scalars, requested together (one global round trip instead of one per use)
+    // The kernel is a chain of global round trips of a lone wave (~1.5 us each): everything that does not depend on the
+    // decision is requested HERE, before anything is waited for -- the problem's scalars, this lane's first element of every
+    // array the merit value and the acceptance read (the loops below take it from registers in their first trip), the
+    // first trips of the carried-over tiles / blocks -- and the objective's own loads follow in the same flight.
     const int done = a.lsdone[b];
     const T mub = mu[b], nub = nu[b], al = alpha[b], ph0 = phi0[b], drb = dir[b];
-    if (ft) ftb = ft[slot];
+    T ftb = ft ? ft[slot] : T(0);
     const T az = a.primal_dual ? ((const T*)a.alz)[b] : T(0);
     const T lsr = info[INFO_LSR], lsk = info[INFO_LSK], regb = reg[b];
-    if (done) return;
     const T* zt = Zt + (size_t)slot * a.n;
     const T* gtb = gt + (size_t)slot * a.m;
+    const bool in0 = lane < a.n, isl0 = lane < H * nx, pdl = a.primal_dual != 0;
+    const T zi_0 = in0 ? zt[lane] : T(0), lo_0 = in0 ? lb[lane] : T(0), hi_0 = in0 ? ub[lane] : T(0);
+    const T gi_0 = isl0 ? gtb[lane] : T(0);
+    const T l0_0 = isl0 ? ((const T*)a.lam)[(size_t)b * a.m + lane] : T(0), l1_0 = isl0 ? ((const T*)a.lamn)[(size_t)b * a.m + lane] : T(0);
+    const T zl_0 = in0 && pdl ? ((const T*)a.zl)[(size_t)b * a.n + lane] : T(0), dl_0 = in0 && pdl ? ((const T*)a.dzl)[(size_t)b * a.n + lane] : T(0);
+    const T zu_0 = in0 && pdl ? ((const T*)a.zu)[(size_t)b * a.n + lane] : T(0), du_0 = in0 && pdl ? ((const T*)a.dzu)[(size_t)b * a.n + lane] : T(0);
+    constexpr int PRE_T = 2, PRE_H = 3;       // trips of the tile / block copies held in registers (2/1: 120 / 180 elements)
+    const int ntl_c = H * nx * (nx + a.nu), nhb_c = H * (nx + a.nu) * (nx + a.nu);
+    T tpre[PRE_T], hpre[PRE_H];
+    if (a.carry) {
+        #pragma unroll
+        for (int k = 0; k < PRE_T; ++k) tpre[k] = lane + 64 * k < ntl_c ? ((const T*)a.tiles_t)[(size_t)b * ntl_c + lane + 64 * k] : T(0);
+        #pragma unroll
+        for (int k = 0; k < PRE_H; ++k) hpre[k] = a.hblk_t && lane + 64 * k < nhb_c ? ((const T*)a.hblk_t)[(size_t)b * nhb_c + lane + 64 * k] : T(0);
+    }
+    if (!ft) ftb = (T)wave_bcast_lane0(objective_row_value<T>(b, lane, H, nx, a.nu, a.oo, (const T*)a.obj, zt,
+                                                                 a.carry ? (T*)a.grad_t : (T*)nullptr));
+    if (done) return;
     // log-barrier value and l1 norm of the defects at the trial point, one loop (the loads of both in flight together;
     // per-lane order and tree as barrier_value / l1_norm)
     double accb = 0.0, accg = 0.0;
     for (int i = lane; i < a.n; i += 64) {
-        const T zi = zt[i], lo = lb[i], hi = ub[i];
-        const T gi = i < H * nx ? gtb[i] : T(0);
+        const bool first = i == lane;
+        const T zi = first ? zi_0 : zt[i], lo = first ? lo_0 : lb[i], hi = first ? hi_0 : ub[i];
+        const T gi = i < H * nx ? (first ? gi_0 : gtb[i]) : T(0);
         if (mub > T(0)) {
             if (lo > -std::numeric_limits<T>::max()) accb -= (double)mub * log((double)(zi - lo));
             if (hi < std::numeric_limits<T>::max()) accb -= (double)mub * log((double)(hi - zi));
@@ -1658,11 +1676,13 @@ __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* 
         const T* dzl = (const T*)a.dzl + (size_t)b * a.n;
         const T* dzu = (const T*)a.dzu + (size_t)b * a.n;
         for (int i = lane; i < a.n; i += 64) {
-            const T zi = zt[i], lo = lb[i], hi = ub[i];
+            const bool first = i == lane;
+            const T zi = first ? zi_0 : zt[i], lo = first ? lo_0 : lb[i], hi = first ? hi_0 : ub[i];
             const bool lof = duals && lo > -std::numeric_limits<T>::max(), hif = duals && hi < std::numeric_limits<T>::max();
             const bool isl = i < H * nx;
-            const T l0 = isl ? lam[i] : T(0), l1 = isl ? lamn[i] : T(0);
-            const T zl0 = lof ? zl[i] : T(0), dl = lof ? dzl[i] : T(0), zu0 = hif ? zu[i] : T(0), du = hif ? dzu[i] : T(0);
+            const T l0 = isl ? (first ? l0_0 : lam[i]) : T(0), l1 = isl ? (first ? l1_0 : lamn[i]) : T(0);
+            const T zl0 = lof ? (first ? zl_0 : zl[i]) : T(0), dl = lof ? (first ? dl_0 : dzl[i]) : T(0);
+            const T zu0 = hif ? (first ? zu_0 : zu[i]) : T(0), du = hif ? (first ? du_0 : dzu[i]) : T(0);
             Zcur[(size_t)b * a.n + i] = zi;
             if (isl) lam[i] = fma(al, l1 - l0, l0);
             if (a.carry) {      // the accepted point's evaluation is the next iterate's: no launch for it
@@ -1682,12 +1702,18 @@ __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* 
             const int ntl = H * nx * (nx + a.nu);
             const T* ts = (const T*)a.tiles_t + (size_t)b * ntl;
             T* td = (T*)a.tiles + (size_t)b * ntl;
-            for (int i = lane; i < ntl; i += 64) td[i] = ts[i];
+            #pragma unroll
+            for (int k = 0; k < PRE_T; ++k)
+                if (lane + 64 * k < ntl) td[lane + 64 * k] = tpre[k];
+            for (int i = lane + 64 * PRE_T; i < ntl; i += 64) td[i] = ts[i];
             if (a.hblk_t) {
-                const int nhb = H * (nx + a.nu) * (nx + a.nu);
+                const int nhb = nhb_c;
                 const T* hs = (const T*)a.hblk_t + (size_t)b * nhb;
                 T* hd = (T*)a.hblk + (size_t)b * nhb;
-                for (int i = lane; i < nhb; i += 64) hd[i] = hs[i];
+                #pragma unroll
+                for (int k = 0; k < PRE_H; ++k)
+                    if (lane + 64 * k < nhb) hd[lane + 64 * k] = hpre[k];
+                for (int i = lane + 64 * PRE_H; i < nhb; i += 64) hd[i] = hs[i];
             }
             for (int i = a.n + lane; i < a.m; i += 64) ((T*)a.g)[(size_t)b * a.m + i] = gtb[i];      // (rows beyond n, if any)
             if (lane == 0) ((T*)a.f_it)[b] = ftb;
