@@ -130,23 +130,29 @@ __global__ __launch_bounds__(256) void solver_barrier_kernel(SolverArgs a) {
 // after the LQ solve: dual steps and their fraction-to-the-boundary length (one wave per problem)
 template <typename T>
 __device__ __forceinline__ void solver_dual_body(const SolverArgs& a, int b, int lane, const T* __restrict__ zp,
-                                                 const T* __restrict__ dzp, T mu, int status) {
-    // zp / dzp: the problem's iterate and step (global memory, or the Riccati kernel's LDS copies)
+                                                 const T* __restrict__ dzp, T mu, int status, const T* lbp = nullptr,
+                                                 const T* ubp = nullptr, const T* zlp = nullptr, const T* zup = nullptr) {
+    // zp / dzp: the problem's iterate and step (global memory, or the Riccati kernel's LDS copies); lbp / ubp / zlp / zup:
+    // staged copies of the bounds and of this problem's bound multipliers, when the caller has them
     if (!a.primal_dual) return;
     const T tau = T(0.995);
     T amax = T(1);
+    const T* lbv = lbp ? lbp : (const T*)a.lb;
+    const T* ubv = ubp ? ubp : (const T*)a.ub;
+    const T* zlv = zlp ? zlp : (const T*)a.zl + (size_t)b * a.n;
+    const T* zuv = zup ? zup : (const T*)a.zu + (size_t)b * a.n;
     if (mu > T(0) && status < 0)
         for (int i = lane; i < a.n; i += 64) {
             const size_t idx = (size_t)b * a.n + i;
-            const T z = zp[i], d = dzp[i], lo = ((const T*)a.lb)[i], hi = ((const T*)a.ub)[i];
+            const T z = zp[i], d = dzp[i], lo = lbv[i], hi = ubv[i];
             T sl = T(0), su = T(0);
             if (lo > -std::numeric_limits<T>::max()) {
-                const T dl = z - lo, zl = ((const T*)a.zl)[idx];
+                const T dl = z - lo, zl = zlv[i];
                 sl = mu / dl - zl - (zl / dl) * d;
                 if (sl < T(0)) amax = fmin(amax, -tau * zl / sl);
             }
             if (hi < std::numeric_limits<T>::max()) {
-                const T du = hi - z, zu = ((const T*)a.zu)[idx];
+                const T du = hi - z, zu = zuv[i];
                 su = mu / du - zu + (zu / du) * d;
                 if (su < T(0)) amax = fmin(amax, -tau * zu / su);
             }
@@ -200,7 +206,7 @@ struct StepInfo {   // what the Riccati kernel leaves in the info row (read from
 template <typename T>
 __device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, int lane, const T* __restrict__ f,
                                                    const T* __restrict__ zp, const T* __restrict__ gp, const StepInfo<T>& si,
-                                                   int& lsd, T& al);
+                                                   int& lsd, T& al, const T* lbp = nullptr, const T* ubp = nullptr);
 
 #ifdef NEMPC_LQ_STAMPS
 __device__ long long nempc_lq_stamps[16];
@@ -308,12 +314,13 @@ __device__ __forceinline__ LqEl<T> lq_combine(const LqEl<T>& i, const LqEl<T>& j
 // the costates are left in blk[Ldz..], blk[Llam..], the restart count (negative: sat out) in blk[Lbh].
 template <typename T>
 __device__ __forceinline__ void lq_scan_problem(const SolverArgs& a, int b, int ln, T* __restrict__ blk, int Lgr, int Lgc,
-                                                int Ltl, int LW, int Llam, int Ldz, int Lbh) {
+                                                int Ltl, int LW, int Llam, int Ldz, int Lbh, int status_b, T reg_b) {
+    // (status_b, reg_b: the problem's status and damping, requested by the caller ahead of the staging)
     constexpr int nx = 2, nin = 3;
     const int H = a.H, n = a.n, uo = H * nx, seg = H + 1;
     const int specs = a.spec;
     T* info = (T*)a.info + (size_t)b * INFO_N;
-    if (a.status[b] >= 0) {          // finished problem: zero step, multipliers unchanged
+    if (status_b >= 0) {          // finished problem: zero step, multipliers unchanged
         const T* lcur = (const T*)a.lam + (size_t)b * a.m;
         for (int i = ln; i < n; i += 64) blk[Ldz + i] = T(0);
         for (int i = ln; i < H * nx; i += 64) blk[Llam + i] = lcur[i];
@@ -338,7 +345,7 @@ __device__ __forceinline__ void lq_scan_problem(const SolverArgs& a, int b, int 
     const T Rs = ((const T*)a.obj)[a.oo.Rs];
     const T q00 = Qs[0], q01 = T(0.5) * (Qs[1] + Qs[2]), q11 = Qs[3];
     const T qt00 = QTs[0], qt01 = T(0.5) * (QTs[1] + QTs[2]), qt11 = QTs[3];
-    const T reg_in = ((const T*)a.reg)[b];
+    const T reg_in = reg_b;
     const T bb = fma(B0, B0, B1 * B1);
     int restarts = a.lq_attempts;
     bool any = false;
@@ -487,7 +494,8 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     const int pl = lane < ppw * spec ? lane - aj0 * ppw : lane;   // its problem's slot in the workgroup
     // element offsets of the per-problem LDS block: the arrays every attempt reads, the results, then one region per attempt
     const int Lz = 0, Lgr = Lz + n, Lgc = Lgr + n, Ltl = Lgc + H * nx, LW = Ltl + H * nx * nin, Llam = LW + H * nin * nin,
-              Ldz = Llam + H * nx, Lbh = Ldz + n, Llc = Lbh + n, Latt = Llc + H * nx + aj0 * a.att_elems, LK = Latt, Lk = LK + H * nu * nx,
+              Ldz = Llam + H * nx, Lbh = Ldz + n, Llc = Lbh + n, Lzl = Llc + H * nx, Lzu = Lzl + n,
+              Latt = Lzu + n + aj0 * a.att_elems, LK = Latt, Lk = LK + H * nu * nx,
               LP = Lk + H * nu, Lp = LP + H * nx * nx, Ltmp = Lp + H * nx;
     const int b = blockIdx.x * ppw + pl;
     const bool mine = lane < ppw * spec && b < a.B;
@@ -501,6 +509,9 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     const int wvu = __builtin_amdgcn_readfirstlane(lane >> 6);
     const int lgw = np >= 3 ? 0 : (np == 2 ? 1 : 2);                 // log2(waves per problem), 4 waves
     const int st_p0 = wvu >> lgw, st_pstep = 4 >> lgw, st_e0 = ((wvu & ((1 << lgw) - 1)) << 6) + (lane & 63), st_estep = 64 << lgw;
+    // bounds (the same for every problem): one copy per workgroup behind the problem blocks; the post-pass reads them there
+    T* const lds_lb = lds + (size_t)ppw * a.lds_stride;
+    T* const lds_ub = lds_lb + n;
     auto stage_in = [&](const T* __restrict__ src, int per, int src_stride, int loff) {
         for (int pp = st_p0; pp < np; pp += st_pstep) {
             const T* sp = src + (size_t)(b0 + pp) * src_stride;
@@ -509,6 +520,22 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         }
     };
     LQ_STAMP(0);
+    // The scalars of the problem this wave solves (scan) and post-processes first -- status, damping, barrier parameter,
+    // penalty, objective value, backtracking memory: requested with the staging loads, each was a ~2,000-cycle round trip of
+    // its own where it is used (status before the solve, the others at the top of the post-pass)
+    const int pf_b = b0 + wvu;
+    const bool pf_ok = LDS && wvu < np;
+    int pf_status = -1;
+    T pf_reg = T(0), pf_mu = T(0), pf_pen = T(0), pf_f = T(0), pf_lsk = T(0), pf_lsa = T(0), pf_lsr = T(0);
+    if (pf_ok) {
+        pf_status = a.status[pf_b];
+        pf_reg = ((const T*)a.reg)[pf_b];
+        if (a.fuse_step) {
+            const T* infp = (const T*)a.info + (size_t)pf_b * INFO_N;
+            pf_mu = ((const T*)a.mu)[pf_b]; pf_pen = ((const T*)a.pen)[pf_b]; pf_f = ((const T*)a.f_it)[pf_b];
+            pf_lsk = infp[INFO_LSK]; pf_lsa = infp[INFO_LSA]; pf_lsr = infp[INFO_LSR];
+        }
+    }
     if (LDS) {
         // counters of the convergence test (zeroed here unless the test runs inside this kernel: then the previous
         // iteration's acceptance kernel did it) and of the trial's acceptance test
@@ -550,6 +577,8 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                     blkp[Lz + e] = vz;
                     blkp[Lgr + e] = vgr + ga;
                     blkp[Lbh + e] = ha;
+                    blkp[Lzl + e] = vzl; blkp[Lzu + e] = vzu;
+                    lds_lb[e] = vlo; lds_ub[e] = vhi;          // (every problem's stagers write the same values)
                 }
             }
             __syncthreads();
@@ -568,6 +597,8 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
             }
         }
         stage_in((const T*)a.g, H * nx, a.m, Lgc);
+        if (a.primal_dual) { stage_in((const T*)a.zl, n, n, Lzl); stage_in((const T*)a.zu, n, n, Lzu); }
+        for (int e = lane; e < n; e += nthr) { lds_lb[e] = ((const T*)a.lb)[e]; lds_ub[e] = ((const T*)a.ub)[e]; }
         if (a.lam_t) stage_in((const T*)a.lam, H * nx, a.m, Llc);
         stage_in((const T*)a.tiles, H * nx * nin, H * nx * nin, Ltl);
         stage_in((const T*)a.hblk, H * nin * nin, H * nin * nin, LW);
@@ -578,7 +609,8 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     if constexpr (SCAN) {
         static_assert(LDS && NX == 2 && NU == 1, "the scan is written for 2-state / 1-control stages staged in LDS");
         for (int pp = wvu; pp < np; pp += 4)
-            lq_scan_problem<T>(a, b0 + pp, lane & 63, lds + (size_t)pp * a.lds_stride, Lgr, Lgc, Ltl, LW, Llam, Ldz, Lbh);
+            lq_scan_problem<T>(a, b0 + pp, lane & 63, lds + (size_t)pp * a.lds_stride, Lgr, Lgc, Ltl, LW, Llam, Ldz, Lbh,
+                               pp == wvu ? pf_status : a.status[b0 + pp], pp == wvu ? pf_reg : ((const T*)a.reg)[b0 + pp]);
     } else {
     T* dzg = mine ? (T*)a.dz + (size_t)b * n : nullptr;
     if (mine && a.status[b] >= 0) {
@@ -1026,8 +1058,8 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         {
             // norms of the steps just computed: wave w takes problems w, w + #waves, ...
             const int wv = lane >> 6, ln = lane & 63, nwv = nthr >> 6;
-            const T* lb = (const T*)a.lb;
-            const T* ub = (const T*)a.ub;
+            const T* lb = lds_lb;
+            const T* ub = lds_ub;
             const T tau = T(0.995);
             for (int pp = wv; pp < np; pp += nwv) {
                 const int bp = b0 + pp;
@@ -1035,10 +1067,15 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                 // the problem's scalars for the step part below: all requested now, used after the norms
                 const T* infg = (const T*)a.info + (size_t)bp * INFO_N;
                 StepInfo<T> si;
-                si.status = a.status[bp];
-                if (a.fuse_step) {
-                    si.mu = ((const T*)a.mu)[bp]; si.nu = ((const T*)a.pen)[bp]; si.f = ((const T*)a.f_it)[bp];
-                    si.lsk = infg[INFO_LSK]; si.lsa = infg[INFO_LSA]; si.lsr = infg[INFO_LSR];
+                if (pp == wvu && pf_ok) {       // (nothing in this kernel has written them since the prefetch)
+                    si.status = pf_status;
+                    si.mu = pf_mu; si.nu = pf_pen; si.f = pf_f; si.lsk = pf_lsk; si.lsa = pf_lsa; si.lsr = pf_lsr;
+                } else {
+                    si.status = a.status[bp];
+                    if (a.fuse_step) {
+                        si.mu = ((const T*)a.mu)[bp]; si.nu = ((const T*)a.pen)[bp]; si.f = ((const T*)a.f_it)[bp];
+                        si.lsk = infg[INFO_LSK]; si.lsa = infg[INFO_LSA]; si.lsr = infg[INFO_LSR];
+                    }
                 }
                 if (si.status >= 0) {
                     if (a.fuse_step) {      // finished problem: no step, its trial point is the iterate
@@ -1088,11 +1125,11 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
                     si.d0 = (T)wave_bcast_lane0((double)D0); si.amax = (T)wave_bcast_lane0((double)amax);
                     si.step = sat_out ? std::numeric_limits<T>::max() : (T)wave_bcast_lane0((double)step_inf);
                     si.restarts = rst;
-                    solver_dual_body<T>(a, bp, ln, blk + Lz, blk + Ldz, si.mu, si.status);
+                    solver_dual_body<T>(a, bp, ln, blk + Lz, blk + Ldz, si.mu, si.status, lb, ub, blk + Lzl, blk + Lzu);
                     LQ_STAMP(5);
                     int lsd;
                     T al;
-                    solver_merit0_body<T>(a, bp, ln, (const T*)a.f_it, blk + Lz, blk + Lgc, si, lsd, al);
+                    solver_merit0_body<T>(a, bp, ln, (const T*)a.f_it, blk + Lz, blk + Lgc, si, lsd, al, lb, ub);
                     LQ_STAMP(6);
                     T* zt = (T*)a.Zt_it + (size_t)bp * n;
                     for (int i = ln; i < n; i += 64) zt[i] = lsd ? blk[Lz + i] : fma(al, blk[Ldz + i], blk[Lz + i]);
@@ -1504,10 +1541,10 @@ __device__ __forceinline__ StepInfo<T> step_info_from(const SolverArgs& a, int b
 template <typename T>
 __device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, int lane, const T* __restrict__ f,
                                                    const T* __restrict__ zp, const T* __restrict__ gp, const StepInfo<T>& si,
-                                                   int& lsd, T& al) {
+                                                   int& lsd, T& al, const T* lbp, const T* ubp) {
     T* mu = (T*)a.mu; T* nu = (T*)a.pen; T* alpha = (T*)a.alpha; T* phi0 = (T*)a.phi0; T* dir = (T*)a.dir;
-    const T* lb = (const T*)a.lb;
-    const T* ub = (const T*)a.ub;
+    const T* lb = lbp ? lbp : (const T*)a.lb;
+    const T* ub = ubp ? ubp : (const T*)a.ub;
     const int H = a.H, nx = a.nx;
     lsd = 1;
     al = T(0);
@@ -2356,13 +2393,16 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         a.att_elems = 0;                                                    // (no per-attempt region: the scan lives in registers)
     }
     int per_problem;
+    // LDS of a workgroup: the problems' blocks + one copy of the bounds (2 n) behind them
+    const size_t wg_extra = (size_t)2 * n * sizeof(T);
+    const size_t lds_budget = (size_t)150 * 1024 > wg_extra ? (size_t)150 * 1024 - wg_extra : 0;
     for (;; --a.spec) {
-        per_problem = 2 * n + 2 * H * nx + H * nx * nin + H * nin * nin + n + n + H * nx + a.spec * a.att_elems;
+        per_problem = 2 * n + 2 * H * nx + H * nx * nin + H * nin * nin + n + n + H * nx + 2 * n + a.spec * a.att_elems;
         per_problem |= 1;   // odd stride: the ppw lanes of a sweep hit different LDS banks
-        if (a.spec == 1 || (size_t)per_problem * sizeof(T) <= (size_t)150 * 1024) break;   // (levels one after the other if not)
+        if (a.spec == 1 || (size_t)per_problem * sizeof(T) <= lds_budget) break;   // (levels one after the other if not)
     }
     auto pick_ppw = [&](int Bact) {
-        int ppw = (int)((size_t)150 * 1024 / ((size_t)per_problem * sizeof(T)));
+        int ppw = (int)(lds_budget / ((size_t)per_problem * sizeof(T)));
         if (ppw > 16) ppw = 16;
         if (ppw * a.spec > 64) ppw = 64 / a.spec;       // the sweeping lanes are one wave
         // the sweep is one latency chain per lane whatever the number of active lanes: spread the batch over the CUs
@@ -2399,8 +2439,8 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
     if constexpr (sizeof(T) == 8)
         if (lq_scan && a.use_lds && !lq_wave) lqk = solver_lq_kernel<T, 2, 1, true, true>;
     {
-        const int ppw_max = (int)((size_t)150 * 1024 / ((size_t)per_problem * sizeof(T)));
-        const size_t lds_max = a.use_lds ? (size_t)std::min(std::max(ppw_max, 1), 16) * per_problem * sizeof(T) : 0;
+        const int ppw_max = (int)(lds_budget / ((size_t)per_problem * sizeof(T)));
+        const size_t lds_max = a.use_lds ? (size_t)std::min(std::max(ppw_max, 1), 16) * per_problem * sizeof(T) + wg_extra : 0;
         NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(lqk), lds_max));
     }
 
@@ -2467,7 +2507,7 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
     for (; it < o.max_iter; ++it) {
         a.B = Bact;
         a.cur_it = it;
-        const size_t lds_need = a.use_lds ? (size_t)a.ppw * per_problem * sizeof(T) : 0;
+        const size_t lds_need = a.use_lds ? (size_t)a.ppw * per_problem * sizeof(T) + wg_extra : 0;
         const unsigned gAn = (unsigned)(((size_t)Bact * n + 255) / 256);
         void* Zc = ws.Zc[cur];
         const void* X0c = ws.X0c[cur];
