@@ -73,6 +73,11 @@ struct SolverArgs {
     // step kernel writes the multipliers the trial point would have, lam + alpha (lamn - lam); hblk_t is carried over on
     // acceptance like the tiles
     void* lam_t; const void* hblk_t;
+    // ... and the acceptance test of that trial point at the START of the next iteration's LQ kernel instead of in a launch
+    // of its own (two launches per iteration): the LQ kernel's waves run solver_merit_body for their problems before they
+    // stage.  The convergence counter alternates between two words by iteration parity -- the accept phase publishes and
+    // clears the PREVIOUS iteration's word while this kernel's post-pass counts into its own
+    int accept_first; int* n_active_prev; const void* gt_acc;
     int fuse_step;        // thread-per-problem Riccati kernel in LDS mode: it also does solver_step_kernel's work
     void* f_it; void* Zt_it;   // ... with the iterate's objective values (B) and the trial-point buffer (B,n)
     int* status; int* lsdone; int* n_active; int* n_pending;   // counters the host polls: unconverged problems / problems still backtracking
@@ -207,6 +212,11 @@ template <typename T>
 __device__ __forceinline__ void solver_merit0_body(const SolverArgs& a, int b, int lane, const T* __restrict__ f,
                                                    const T* __restrict__ zp, const T* __restrict__ gp, const StepInfo<T>& si,
                                                    int& lsd, T& al, const T* lbp = nullptr, const T* ubp = nullptr);
+template <typename T>
+__device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* __restrict__ Zt, const T* __restrict__ gt,
+                                                  const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls,
+                                                  const int* __restrict__ list_in, int* __restrict__ list_out,
+                                                  int publish, int slot, int lane, int* n_active_word, int tag);
 
 #ifdef NEMPC_LQ_STAMPS
 __device__ long long nempc_lq_stamps[16];
@@ -520,6 +530,16 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
         }
     };
     LQ_STAMP(0);
+    if constexpr (LDS) {
+        if (a.accept_first) {
+            // acceptance test of the previous iteration's trial point for this workgroup's problems (a wave per problem), then
+            // everything below reads the iterate it left: the staging waits behind the barrier
+            for (int pp = wvu; pp < np; pp += 4)
+                solver_merit_body<T>(a, (const T*)a.Zt_it, (const T*)a.gt_acc, (const T*)nullptr, (T*)a.Z, 2, (const int*)nullptr,
+                                     (int*)nullptr, 1, b0 + pp, lane & 63, a.n_active_prev, a.cur_it);
+            __syncthreads();
+        }
+    }
     // The scalars of the problem this wave solves (scan) and post-processes first -- status, damping, barrier parameter,
     // penalty, objective value, backtracking memory: requested with the staging loads, each was a ~2,000-cycle round trip of
     // its own where it is used (status before the solve, the others at the top of the post-pass)
@@ -1618,11 +1638,11 @@ template <typename T>
 __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* __restrict__ Zt, const T* __restrict__ gt,
                                                   const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls,
                                                   const int* __restrict__ list_in, int* __restrict__ list_out,
-                                                  int publish) {
+                                                  int publish, int slot, int lane, int* n_active_word, int tag) {
     // list_in: the trial buffers (Zt, gt, ft) hold only the problems that were still searching after the previous trial,
     // densely, in the order of that list (inner-loop backtracking); null: one slot per problem.  list_out: the problems
-    // this trial rejects are appended for the next one.
-    const int slot = blockIdx.x, lane = threadIdx.x;
+    // this trial rejects are appended for the next one.  slot / lane: the problem slot this wave works on; n_active_word /
+    // tag: the convergence counter that is published (and cleared) and the iteration number it is published under.
     const int b = list_in ? list_in[slot] : slot;
     // the convergence counter of the NEXT iteration, when its test runs inside the Riccati kernel (the host's copy of this
     // iteration's count was issued before this launch)
@@ -1631,14 +1651,14 @@ __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* 
         // kernel that counts ran earlier in the stream).  It goes to pinned host memory by a plain store -- the host reads
         // it there whenever it likes: no copy launch, no event, no drained stream
         if (a.hpub) {
-            const int v = *a.n_active;
+            const int v = *n_active_word;
             a.hpub[1] = v;
-            if (v == 0 && a.hpub[2] == 0) a.hpub[2] = a.cur_it + 1;
+            if (v == 0 && a.hpub[2] == 0) a.hpub[2] = tag;
             __threadfence_system();
-            a.hpub[0] = a.cur_it + 1;
+            a.hpub[0] = tag;
             __threadfence_system();
         }
-        if (a.fuse_step) *a.n_active = 0;
+        if (a.fuse_step) *n_active_word = 0;
     }
     if (b >= a.B) return;
     T* mu = (T*)a.mu; T* nu = (T*)a.pen; T* reg = (T*)a.reg; T* alpha = (T*)a.alpha; T* phi0 = (T*)a.phi0; T* dir = (T*)a.dir;
@@ -1809,7 +1829,8 @@ __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T*
                                                           const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls,
                                                           const int* __restrict__ list_in, int* __restrict__ list_out,
                                                           int publish, int seq) {
-    solver_merit_body<T>(a, Zt, gt, ft, Zcur, last_ls, list_in, list_out, publish);
+    solver_merit_body<T>(a, Zt, gt, ft, Zcur, last_ls, list_in, list_out, publish, (int)blockIdx.x, (int)threadIdx.x, a.n_active,
+                         a.cur_it + 1);
     if (seq > 0 && threadIdx.x == 0) {
         __threadfence();                                    // this block's list entry and count are out
         const int t = atomicAdd(a.n_done, 1);
@@ -2192,8 +2213,8 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
             }
             NEMPC_HIP(hipMalloc((void**)&w2.lsdone, Bn * sizeof(int)));
             for (int k = 0; k < 2; ++k) NEMPC_HIP(hipMalloc((void**)&w2.pend[k], Bn * sizeof(int)));
-            NEMPC_HIP(hipMalloc((void**)&w2.n_active, 4 * sizeof(int)));   // [unconverged, still backtracking, blocks done]
-            NEMPC_HIP(hipMemset(w2.n_active, 0, 4 * sizeof(int)));
+            NEMPC_HIP(hipMalloc((void**)&w2.n_active, 8 * sizeof(int)));   // [unconverged, still backtracking, blocks done, -, unconverged (odd iterations)]
+            NEMPC_HIP(hipMemset(w2.n_active, 0, 8 * sizeof(int)));
             NEMPC_HIP(hipHostMalloc((void**)&w2.hpoll, 4 * sizeof(int), hipHostMallocDefault));
             NEMPC_HIP(hipHostMalloc((void**)&w2.hpub, 8 * sizeof(int), hipHostMallocMapped));
             NEMPC_HIP(hipHostGetDevicePointer((void**)&w2.hpub_dev, w2.hpub, 0));
@@ -2432,7 +2453,7 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
     const int no_fuse_step = [] { const char* e = getenv("NEMPC_SOLVER_NO_FUSE_STEP"); return e ? atoi(e) : 0; }();   // (tests)
     a.fuse_step = a.use_lds && !lq_wave && !no_fuse_step;
     a.f_it = ws.f; a.Zt_it = ws.Zt;
-    if (a.fuse_step) NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, 2 * sizeof(int), s));
+    if (a.fuse_step) NEMPC_HIP(hipMemsetAsync(ws.n_active, 0, 8 * sizeof(int), s));
     if (lq_wave)
         lqk = (nx == 2 && nu == 1) ? solver_lqw_kernel<T, 2, 1>
                                    : ((nx == 6 && nu == 3) ? solver_lqw_kernel<T, 6, 3> : solver_lqw_kernel<T, 0, 0>);
@@ -2456,6 +2477,12 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
     const int hess_trial_env = [] { const char* e = getenv("NEMPC_SOLVER_HESS_TRIAL"); return e ? atoi(e) : 1; }();   // A/B knob (tests)
     bool hess_trial = carry && a.fuse_step && hess_trial_env != 0;
     a.carry = 0; a.tiles_t = ws.tiles_t; a.grad_t = ws.grad_t; a.lam_t = nullptr; a.hblk_t = nullptr;
+    // the acceptance test inside the next iteration's LQ kernel (see SolverArgs::accept_first): two launches per iteration
+    const int fuse_accept_env = [] { const char* e = getenv("NEMPC_SOLVER_FUSE_ACCEPT"); return e ? atoi(e) : 1; }();   // A/B knob (tests)
+    const bool fuse_accept = fuse_accept_env != 0;
+    static const bool stats_on = getenv("NEMPC_SOLVER_STATS") != nullptr;
+    bool accept_pending = false;       // the last trial point has been evaluated, its acceptance test has not been launched
+    a.accept_first = 0; a.n_active_prev = ws.n_active; a.gt_acc = ws.gt;
     a.hpub = ws.hpub_dev;
     for (int k = 0; k < 8; ++k) ws.hpub[k] = 0;       // (the previous solve on this handle ended with a synchronised stream)
     const bool published_polls = !wave_wanted;  // small stages (chains of latency-bound launches): no blocking polls, the host
@@ -2549,6 +2576,11 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         // bounds: barrier diagonal for the LQ model, barrier gradient folded into grad
         if (!a.use_lds) hipLaunchKernelGGL(solver_barrier_kernel<T>, dim3(gAn), dim3(256), 0, s, a);
         a.lam_t = carry && hess_trial ? ws.lam_t : nullptr;
+        // this iteration's convergence counter; the pending acceptance (if any) publishes and clears the other word
+        a.n_active = fuse_accept && a.fuse_step ? ws.n_active + (it & 1) * 4 : ws.n_active;
+        a.n_active_prev = ws.n_active + ((it & 1) ^ 1) * 4;
+        a.accept_first = accept_pending ? 1 : 0;
+        accept_pending = false;
         // LDS mode: four waves stage the working set, the first ppw lanes run the sweeps
         hipLaunchKernelGGL(lqk, dim3(a.use_lds ? (Bact + a.ppw - 1) / a.ppw : (Bact + 63) / 64), dim3(a.use_lds ? 256 : 64),
                            lds_need, s, a);
@@ -2635,11 +2667,17 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
             h.d_extra = extra_all;
             if (rc) return rc;
             // (no fused evaluation: the acceptance kernel computes the trial point's objective value itself)
-            hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(nb), dim3(64), 0, s, a, (const T*)ws.Zt,
-                               (const T*)ws.gt, fused_trial ? (const T*)ws.ft : (const T*)nullptr, (T*)Zc,
-                               lsm == 2 ? 2 : (ls + 1 == o.max_linesearch ? 1 : 0),
-                               ls > 0 ? (const int*)ws.pend[ls & 1] : (const int*)nullptr, ws.pend[(ls + 1) & 1],
-                               ls == 0 ? 1 : 0, lsm == 2 ? 0 : ++pend_seq);
+            // Deferred backtracking with the trial point's blocks in hand: the test runs at the start of the next LQ kernel,
+            // unless this is the last iteration of the budget or somebody reads the iterate before that kernel (diagnostics;
+            // a compaction launches it below)
+            accept_pending = fuse_accept && a.fuse_step && trial_done && lsm == 2 && published_polls && it + 1 < o.max_iter && !trace &&
+                             !stats_on;
+            if (!accept_pending)
+                hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(nb), dim3(64), 0, s, a, (const T*)ws.Zt,
+                                   (const T*)ws.gt, fused_trial ? (const T*)ws.ft : (const T*)nullptr, (T*)Zc,
+                                   lsm == 2 ? 2 : (ls + 1 == o.max_linesearch ? 1 : 0),
+                                   ls > 0 ? (const int*)ws.pend[ls & 1] : (const int*)nullptr, ws.pend[(ls + 1) & 1],
+                                   ls == 0 ? 1 : 0, lsm == 2 ? 0 : ++pend_seq);
             have_eval = a.carry != 0;
             have_blocks = have_eval && a.hblk_t != nullptr;
             if (lsm == 2) break;          // one trial per outer iteration: nothing to poll
@@ -2701,8 +2739,7 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
                 last_nact = nact;
             }
         }
-        static const bool stats = getenv("NEMPC_SOLVER_STATS") != nullptr;
-        if (stats) {   // NEMPC_SOLVER_STATS=1: Riccati restarts per iteration over the active slots (diagnostic, synchronises)
+        if (stats_on) {   // NEMPC_SOLVER_STATS=1: Riccati restarts per iteration over the active slots (diagnostic, synchronises)
             std::vector<T> inf((size_t)Bact * INFO_N);
             std::vector<T> rg((size_t)Bact);
             NEMPC_HIP(hipStreamSynchronize(s));
@@ -2733,6 +2770,11 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         // ---- compaction: once a quarter of the active slots has finished, gather the unconverged problems to the
         //      front of the other buffer set and shrink every launch to them
         if (compact && polled && nact < Bact - Bact / 4 && Bact > 64) {
+            if (accept_pending) {       // the gather below reads the iterate: the trial's acceptance test now, in a launch of its own
+                hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(Bact), dim3(64), 0, s, a, (const T*)ws.Zt, (const T*)ws.gt,
+                                   (const T*)nullptr, (T*)Zc, 2, (const int*)nullptr, ws.pend[1], 1, 0);
+                accept_pending = false;
+            }
             const int nxt = cur ^ 1;
             hipLaunchKernelGGL(solver_partition_kernel, dim3(1), dim3(1024), 0, s, Bact, (const int*)ws.stc[cur], ws.perm,
                                ws.count);
@@ -2783,6 +2825,11 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
             a.ppw = pick_ppw(Bact);
         }
     }
+    if (accept_pending) {           // (the loop was left with a trial point evaluated and not yet tested)
+        hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(a.B), dim3(64), 0, s, a, (const T*)ws.Zt, (const T*)ws.gt,
+                           (const T*)nullptr, (T*)ws.Zc[cur], 2, (const int*)nullptr, ws.pend[1], 1, 0);
+        accept_pending = false;
+    }
     hipLaunchKernelGGL(solver_scatter_kernel<T>, dim3(B), dim3(256), 0, s, B, n, (const T*)ws.Zc[cur],
                        (const int*)ws.stc[cur], (const int*)ws.orig[cur], (const int*)ws.itc[cur],
                        rolling ? (T*)ws.rZout : (T*)Z, status_dev, (int*)o.iters_out);
@@ -2805,7 +2852,7 @@ static int solve_typed(Handle& h, int B, const void* X0, void* Z, const double* 
     if (rc != NEMPC_OK) {
         (void)hipStreamSynchronize(s);
         if (SolverWs* w = static_cast<SolverWs*>(h.solver_ws)) {
-            if (w->n_active) (void)hipMemset(w->n_active, 0, 4 * sizeof(int));
+            if (w->n_active) (void)hipMemset(w->n_active, 0, 8 * sizeof(int));
             if (w->hpub) for (int k = 0; k < 8; ++k) w->hpub[k] = 0;
         }
         (void)hipGetLastError();
