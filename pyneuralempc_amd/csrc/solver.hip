@@ -23,12 +23,15 @@
 //   retries the same direction at half the length next iteration), an inner loop for matrix-core-bound ones.
 // Every problem carries its own mu, nu, step length, damping and status; the batch advances in lock step, the
 // unconverged problems are compacted to the front as it converges.  All arithmetic is in kernels here; the callbacks
-// are the handle's own row/objective kernels.  Per iteration on a compiled small shape: Hessian blocks, Riccati kernel
-// (barrier terms while staging; step norms, dual steps, convergence test, merit and first trial point by a wave per
-// problem after the sweeps), ONE fused evaluation of the trial point -- which the acceptance kernel keeps as the next
-// iterate's evaluation when it accepts -- and the acceptance test: four launches; the acceptance kernel publishes the
-// convergence counter to pinned host memory, the host stays at most two iterations ahead of the device.  Inner-loop
-// backtracking (matrix-core-bound stages) evaluates a second and later trial for the still-searching problems only.
+// are the handle's own row/objective kernels.  Per iteration on the compiled small shape (2 states, 1 control, fp64), TWO
+// launches: (1) the LQ kernel -- acceptance test of the previous iteration's trial point (a wave per problem, before the
+// staging; the accepted point's evaluation and Lagrangian blocks are carried over as the iterate's), barrier terms while
+// staging, the LQ solve parallel in time (lq_scan_problem: a lane per stage), then step norms, dual steps, convergence test,
+// merit and the trial point with its multipliers by a wave per problem; (2) ONE callback launch at the trial point:
+// Lagrangian blocks, defects and tiles (rowhess_coopfx_kernel with evaluation outputs).  The accept phase publishes the
+// convergence counter to pinned host memory, the host stays at most two iterations ahead of the device.  Other shapes: the
+// Riccati sweep (thread or wave per problem), separate evaluation / block / acceptance launches; inner-loop backtracking
+// (matrix-core-bound stages) evaluates a second and later trial for the still-searching problems only.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
