@@ -158,6 +158,53 @@ def fused_evaluator(integrator, objective, box):
     return ent[2]
 
 
+class _StreamWaiter:
+    """Wait for a stream's work from the host without a stream synchronisation: the stream writes a sequence number into a
+    pinned word after the queued kernel (hipStreamWriteValue32, a packet of the command processor), the host spins on that
+    word.  2.9 us less per B = 1 callback than stream.synchronize() (26.8 -> 24.0 us, tools/host_sync_probe.py).  A spin that
+    does not end within ~a second falls back to the synchronisation, which surfaces a device fault as an error; a HIP
+    runtime without the entry point uses the synchronisation from the start."""
+
+    _fn = None
+    _probed = False
+
+    def __init__(self, stream):
+        import ctypes
+        self.stream = stream
+        self.seq = 0
+        self.flag = None
+        if not _StreamWaiter._probed:
+            _StreamWaiter._probed = True
+            try:
+                hip = ctypes.CDLL("libamdhip64.so")
+                fn = hip.hipStreamWriteValue32
+                fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint]
+                fn.restype = ctypes.c_int
+                _StreamWaiter._fn = fn
+            except (OSError, AttributeError):
+                _StreamWaiter._fn = None
+        if _StreamWaiter._fn is not None:
+            self.flag = torch.zeros(16, dtype=torch.int32, pin_memory=True)
+            self.word = self.flag.numpy()
+            self.fptr = ctypes.c_void_p(self.flag.data_ptr())
+            self.sptr = ctypes.c_void_p(stream.cuda_stream)
+
+    def wait(self):
+        if self.flag is None:
+            self.stream.synchronize()
+            return
+        self.seq = (self.seq % 0x7fffffff) + 1
+        if _StreamWaiter._fn(self.sptr, self.fptr, self.seq, 0) != 0:
+            self.flag = None                    # not supported on this stream / memory: synchronise from now on
+            self.stream.synchronize()
+            return
+        word, seq = self.word, self.seq
+        for _ in range(4000000):
+            if word[0] == seq:
+                return
+        self.stream.synchronize()               # (a device fault ends here as an exception instead of an endless spin)
+
+
 class _FusedEvaluator:
     """integrator + QuadraticObjective [+ BoxStateConstraint] on ONE engine: a single device call
     yields f, grad f, g, dense jac g for an iterate; results are cached per (z, x0) because the
@@ -219,6 +266,7 @@ class _FusedEvaluator:
         stream = torch.cuda.Stream(eng.device)
         outp = hout.data_ptr()
         st = dict(key=key, hin=hin, hout=hout, zin=hin.numpy()[:n], xin=hin.numpy()[n:], out=hout.numpy(), stream=stream,
+                  waiter=_StreamWaiter(stream),
                   n=n, m=m, nj=nj, sparse=bool(sparse),
                   args=(eng._handle, 1, vp(hin.data_ptr()), vp(hin.data_ptr() + n * esz), vp(outp), vp(outp + esz),
                         vp(outp + (1 + n) * esz), None if sparse else vp(outp + (1 + n + m) * esz), None,
@@ -241,7 +289,7 @@ class _FusedEvaluator:
         rc = self.engine.lib.nempc_eval(*st["args"])      # (the library selects the handle's device itself)
         if rc:
             _lib.check(rc)
-        st["stream"].synchronize()
+        st["waiter"].wait()
         o, n, m, nj = st["out"], st["n"], st["m"], st["nj"]
         jac = o[1 + n + m:1 + n + m + nj].astype(np.float64)
         self._val = {"f": float(o[0]), "grad": o[1:1 + n].astype(np.float64), "g": o[1 + n:1 + n + m].astype(np.float64),
@@ -263,7 +311,7 @@ class _FusedEvaluator:
             vp = ctypes.c_void_p
             stream = torch.cuda.Stream(eng.device)
             base = hin.data_ptr()
-            hs = dict(key=key, hin=hin, hout=hout, inp=hin.numpy(), out=hout.numpy(), stream=stream,
+            hs = dict(key=key, hin=hin, hout=hout, inp=hin.numpy(), out=hout.numpy(), stream=stream, waiter=_StreamWaiter(stream),
                       args=(eng._handle, 1, vp(base), vp(base + n * esz), vp(base + (n + nx) * esz),
                             vp(base + (n + nx + m) * esz), vp(hout.data_ptr()), None, None, vp(stream.cuda_stream)))
             self._hess_state = hs
@@ -277,7 +325,7 @@ class _FusedEvaluator:
         rc = eng.lib.nempc_hess(*hs["args"])
         if rc:
             _lib.check(rc)
-        hs["stream"].synchronize()
+        hs["waiter"].wait()
         return hs["out"].astype(np.float64)
 
 
