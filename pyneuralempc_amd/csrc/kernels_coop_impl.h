@@ -31,6 +31,7 @@
 #pragma once
 
 #include "kernels_mfma_impl.h"
+#include "kernels_obj_impl.h"
 
 namespace nempc {
 
@@ -686,6 +687,13 @@ struct CoopArgs {
     unsigned inv32_jrow, inv32_nx;
     double DT;
     RowGather gk;
+    // the objective of the batch from this launch too (dense evaluations of plain models, launch_rows_mfma_dense): f (B) and
+    // grad (B, n), either may be null; P = the handle's objective table; every workgroup takes a slice of the problems
+    void* obj_f;
+    void* obj_grad;
+    const void* obj_P;
+    ObjOffsets oo;
+    int B;
 };
 
 // SR: also write the per-(row, stage) records of the RK4 Hessian pipeline (its own instantiation: the extra stores and
@@ -867,6 +875,15 @@ __global__ __launch_bounds__((WP / 16) * 64, OCC) void rows_coop_kernel(CoopArgs
         if (npass < 4) COOP_WGSTAMP(a.dbg, 5 + 2 * npass);
         ++npass;
 #endif
+    }
+    // The objective of a slice of the batch, a problem per wave (objective_body: the routine of the objective kernel, hence
+    // its bits) -- after the passes, where a workgroup that has finished its tiles would otherwise idle until the launch
+    // ends; a launch of its own cost 23 us behind a 550 us row launch at configs[2] and a third of the evaluation at small
+    // shapes
+    if (a.obj_f || a.obj_grad) {
+        const T* __restrict__ Pg = static_cast<const T*>(a.obj_P);
+        for (int b = (int)blockIdx.x * MT + w; b < a.B; b += (int)gridDim.x * MT)
+            objective_body<T>(b, lane, a.H, a.nx, a.nu, a.oo, Pg, cx.Z, static_cast<T*>(a.obj_f), static_cast<T*>(a.obj_grad));
     }
     NEMPC_STAMP_A(12);
     COOP_WGSTAMP(a.dbg, 14);

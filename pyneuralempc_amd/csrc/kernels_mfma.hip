@@ -254,11 +254,16 @@ int launch_hess_gn_fused(Handle& h, int B, const void* Z, const void* X0, const 
 // Rows, compact tiles (optional) and the DENSE Jacobian from one launch of the cooperative kernel (any shape it takes,
 // plain models): background zeros streamed at the start of each pass, non-zeros written with the pass's outputs.
 // NEMPC_EUNSUPPORTED (nothing launched, no error message) sends nempc_eval to the row + assembly launches.
-int launch_rows_mfma_dense(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, hipStream_t s) {
+int launch_rows_mfma_dense(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, void* f,
+                           void* grad, hipStream_t s) {
     static const int on = [] { const char* e = getenv("NEMPC_COOP_DENSE"); return e ? atoi(e) : 1; }();
-    if (!on || !h.mfma.blob || !jac) return NEMPC_EUNSUPPORTED;
+    if (!on || !h.mfma.blob || !jac || ((f || grad) && !h.d_obj)) return NEMPC_EUNSUPPORTED;
     MfmaParams p = base_params(h, B, Z, X0, g, tiles);
     p.fuse_jac = jac;
+    if (f || grad) {        // the objective from the same launch (its workgroups take slices of the batch after their passes)
+        p.fuse_f = f; p.fuse_grad = grad; p.obj = h.d_obj;
+        p.oo = obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu);
+    }
     const int rc = h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
     if (rc == NEMPC_OK) h.last_row_kernel = 5;        // the cooperative kernel, dense rows included
     return rc;

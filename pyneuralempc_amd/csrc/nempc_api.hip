@@ -623,14 +623,11 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
             rc = launch_eval_fused(h, B, Z, X0, gout, tiles, nullptr, f, grad, s);
             if (rc != NEMPC_EUNSUPPORTED) return rc ? rc : launch_assemble_sparse(h, B, tiles, jac_sparse, s);
         }
-        // dense contract on any shape the cooperative kernel takes (plain models): the dense rows leave from the row
-        // launch itself -- no assembly launch, no tile round trip through memory; the objective follows on its own
+        // dense contract on any shape the cooperative kernel takes (plain models): the dense rows AND the objective leave
+        // from the row launch itself -- no assembly launch, no tile round trip through memory, no objective launch
         if (jac_dense && !jac_sparse && h.variant == NEMPC_KERNEL_MFMA) {
-            rc = launch_rows_mfma_dense(h, B, Z, X0, gout, jac_tiles, jac_dense, s);
-            if (rc != NEMPC_EUNSUPPORTED) {
-                if (rc) return rc;
-                return (f || grad) ? launch_objective(h, B, Z, f, grad, s) : NEMPC_OK;
-            }
+            rc = launch_rows_mfma_dense(h, B, Z, X0, gout, jac_tiles, jac_dense, f, grad, s);
+            if (rc != NEMPC_EUNSUPPORTED) return rc;
         }
         rc = h.variant != NEMPC_KERNEL_VALU ? launch_rows_mfma(h, B, Z, X0, gout, tiles, s)
                                             : launch_rows_valu(h, B, Z, X0, gout, tiles, s);

@@ -197,7 +197,8 @@ int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b)
 int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s);
 int launch_eval_fused(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, void* f,
                       void* grad, hipStream_t s);
-int launch_rows_mfma_dense(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, hipStream_t s);
+int launch_rows_mfma_dense(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, void* f,
+                           void* grad, hipStream_t s);
 int launch_hess_gn_fused(Handle& h, int B, const void* Z, const void* X0, const void* w, const void* sigma, void* hvals,
                          hipStream_t s);
 void mfma_free(Handle& h);
