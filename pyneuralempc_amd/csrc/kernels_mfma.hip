@@ -288,7 +288,12 @@ int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, voi
     p.ntiles = (int)(((size_t)B * h.cfg.H + 15) / 16);
     p.scratch_per_wave = (scratch_elems(h) + 1) & ~1;
     p.dbg = h.d_dbg;
-    return h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+    const int rc = h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+    if (rc != NEMPC_INTERNAL_USE_VALU) return rc;
+    // an instantiation of the wave-per-tile kernel that is not used (launch_shape): the generic kernel computes the rows.
+    // It has no stage records: the RK4 Hessian pipeline's callers take their generic path on NEMPC_EUNSUPPORTED
+    if (stage_out) return NEMPC_EUNSUPPORTED;
+    return launch_rows_valu(h, B, Z, X0, g, tiles ? tiles : h.d_tiles_ws, s);
 }
 
 int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,

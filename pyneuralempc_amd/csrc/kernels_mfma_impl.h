@@ -122,9 +122,13 @@ struct MfmaOps<float> {
 // same-wave LDS hand-off between lanes: DS ops of one wave execute in order; keep the compiler from
 // moving accesses across the point
 __device__ __forceinline__ void wave_sync() {
+#ifdef NEMPC_TILE_STRONG_SYNC
+    __syncthreads();
+#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 // Workgroup-cooperative copy of the packed blob into LDS: 16-byte loads, eight in flight per lane.
@@ -160,7 +164,12 @@ __device__ __forceinline__ void layer_mma(const T* __restrict__ w, int lane,
                                           const typename MfmaOps<T>::V4 (&bop)[MT_IN],
                                           typename MfmaOps<T>::V4 (&acc)[MO]) {
     using Ops = MfmaOps<T>;
-    if constexpr (WLDS) {
+#ifdef NEMPC_TILE_NO_PREFETCH
+    constexpr bool SIMPLE = true;
+#else
+    constexpr bool SIMPLE = WLDS;
+#endif
+    if constexpr (SIMPLE) {
 #pragma unroll
         for (int mt = 0; mt < MT_IN; ++mt)
 #pragma unroll
@@ -171,9 +180,11 @@ __device__ __forceinline__ void layer_mma(const T* __restrict__ w, int lane,
     } else {
         // the fragments do not depend on the enclosing cotangent / stage loops: without an opaque
         // offset LICM hoists every one of them out of those loops and the kernel spills
+#ifndef NEMPC_TILE_NO_OPAQUE
         int opaque = 0;
         asm volatile("" : "+s"(opaque));
         w += opaque;
+#endif
         T wcur[MO], wnxt[MO];
 #pragma unroll
         for (int mo = 0; mo < MO; ++mo) wcur[mo] = w[mo * 64 + lane];
@@ -185,7 +196,9 @@ __device__ __forceinline__ void layer_mma(const T* __restrict__ w, int lane,
             }
 #pragma unroll
             for (int mo = 0; mo < MO; ++mo) acc[mo] = Ops::mma(wcur[mo], bop[it >> 2][it & 3], acc[mo]);
+#ifndef NEMPC_TILE_NO_SCHEDBARRIER
             __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int mo = 0; mo < MO; ++mo) wcur[mo] = wnxt[mo];
         }

@@ -666,8 +666,11 @@ int nempc_hess(nempc_handle hh, int32_t B, const void* Z, const void* X0, const 
     }
     void* blocks = hblocks ? hblocks : h.d_hess_ws;
     if (h.variant == NEMPC_KERNEL_VALU) rc = launch_rowhess_valu(h, B, Z, X0, lambda, blocks, s);
-    else if (h.cfg.integrator == NEMPC_RK4) rc = launch_rowhess_rk4_mfma(h, B, Z, X0, lambda, blocks, s);
-    else rc = launch_rowhess_mfma(h, B, Z, X0, lambda, blocks, s);
+    else if (h.cfg.integrator == NEMPC_RK4) {
+        rc = launch_rowhess_rk4_mfma(h, B, Z, X0, lambda, blocks, s);
+        // (a shape whose stage records would come from a wave-per-tile instantiation that is not used: generic kernel)
+        if (rc == NEMPC_EUNSUPPORTED) rc = launch_rowhess_valu(h, B, Z, X0, lambda, blocks, s);
+    } else rc = launch_rowhess_mfma(h, B, Z, X0, lambda, blocks, s);
     if (rc) return rc;
     if (!hvals && !hdense) return NEMPC_OK;
     return launch_assemble_hess(h, B, blocks, sigma, hvals, hdense, s);

@@ -72,6 +72,10 @@ struct MfmaNet {
     size_t blob_elems = 0;
 };
 
+// internal return code of the matrix-core row launchers: "this launch belongs on the generic kernel" (translated by
+// launch_rows_mfma_stages; never leaves the library)
+constexpr int NEMPC_INTERNAL_USE_VALU = -9001;
+
 struct ObjHost {   // host copy of the objective parameters (doubles), re-uploaded whenever one of them changes
     std::vector<double> Q, R, xref, uref, cx, cu;
 };

@@ -2559,6 +2559,12 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
                                                                : launch_rowhess_valu(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s));
         } else if (rk4_pipeline) {
             rc = launch_rowhess_rk4_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s, ws.g, ws.tiles);
+            if (rc == NEMPC_EUNSUPPORTED) {
+                // (a shape whose stage records would come from a wave-per-tile instantiation that is not used: rows through
+                //  the matrix-core entry point -- it falls back by itself -- and the blocks from the generic kernel)
+                if ((rc = launch_rows_mfma(h, Bact, Zc, X0c, ws.g, ws.tiles, s))) return rc;
+                rc = launch_rowhess_valu(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s);
+            }
         } else if (carry && hess_trial &&
                    (rc = launch_rowhess_eval_mfma(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, ws.g, ws.tiles, s)) != NEMPC_EUNSUPPORTED) {
             // first iterate (and the one after a compaction) through the kernel the trial points go through -- the same

@@ -592,3 +592,35 @@ def test_nan_inputs_stay_visible_for_every_activation(act):
         Zh[1, 5] = np.nan
         res = eng.eval_numpy(Zh, X0h, want=("g", "jac_tiles"))
         assert np.isnan(res["g"][1]).any() and not np.isnan(res["g"][[0, 2, 3]]).any(), (act, kernel)
+
+
+def test_every_matrix_core_row_instantiation_against_the_oracle():
+    """Every (dtype, padded width 32 / 64 / 128, hidden layers 1..3) instantiation of the wave-per-tile row kernel x activation
+    x transcription once, defects and dense Jacobian against the oracle.  Three streamed instantiations at the register cap
+    produced wrong rows for some of these combinations (csrc/kernels_mfma_typed.inc, launch_shape): they are not used -- the
+    generic kernel serves those shapes -- and this sweep is what found them."""
+    import itertools
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu, H, B = 2, 1, 7, 37
+    fell_back = set()
+    for dt, width, depth, integ, act in itertools.product((torch.float64, torch.float32), (24, 48, 96), (1, 2, 3),
+                                                         ("discret", "rk4"), ("tanh", "relu", "sigmoid", "softplus", "elu")):
+        DT = 0.1 if integ == "rk4" else 1.0
+        net = orc.MLP.random(nx + nu, [width] * depth, nx, seed=5, activations=act)
+        Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=5)
+        prob = orc.Problem(net, H, nx, nu, orc.RK4 if integ == "rk4" else orc.DISCRET, DT)
+        f, grad, g, J = prob.eval_batch(Zh, X0h)
+        eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=dt, device="cuda:0", max_batch=B,
+                             kernel="mfma_tile", activations=act)
+        res = eng.eval_numpy(Zh, X0h, want=("g", "jac_dense"))
+        tol = 2e-4 if dt == torch.float32 else 1e-10
+        tag = (str(dt), width, depth, integ, act)
+        assert np.abs(res["g"] - g).max() / max(1.0, np.abs(g).max()) < tol, tag
+        assert np.abs(res["jac_dense"] - J).max() / max(1.0, np.abs(J).max()) < tol, tag
+        # defect-only launches (line-search trials) take the wave-per-tile kernel on every variant
+        g_only = eng.eval_numpy(Zh, X0h, want=("g",))["g"]
+        assert np.abs(g_only - g).max() / max(1.0, np.abs(g).max()) < tol, tag
+        if eng.last_row_kernel == "rows_valu_kernel":
+            fell_back.add((str(dt), width, depth))
+        del eng
+    assert fell_back == {("torch.float64", 48, 3), ("torch.float64", 96, 2), ("torch.float32", 96, 2)}

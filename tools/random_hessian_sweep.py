@@ -1,11 +1,11 @@
 """Random sweep of shapes for the Lagrangian-Hessian and Gauss-Newton-Hessian callbacks against the CPU oracle (one-off
 confidence run on the GPU box).   python tools/random_hessian_sweep.py [trials]"""
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 from oracle import nempc_oracle as orc
 from pyneuralempc_amd import CallbackEngine
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.default_rng(77)
+rng = np.random.default_rng(int(os.environ.get("NEMPC_SWEEP_SEED", "77")))
 bad = 0
 kinds = {"discret": orc.DISCRET, "unity": orc.UNITY, "rk4": orc.RK4}
 for trial in range(trials):

@@ -1,10 +1,10 @@
 """Random sweep of horizons / batch sizes / transcriptions / box rows for the 2-state 1-control shape against the CPU oracle
 (one-off confidence run on the GPU box; the committed tests cover fixed grids).   python tools/random_parity_sweep.py"""
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 from oracle import nempc_oracle as orc
 from pyneuralempc_amd import CallbackEngine
-rng = np.random.default_rng(123)
+rng = np.random.default_rng(int(os.environ.get("NEMPC_SWEEP_SEED", "123")))
 net = orc.MLP.random(3, [64, 64], 2, seed=7)
 bad = 0
 for trial in range(120):

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import nempc_oracle as orc
 from pyneuralempc_amd import CallbackEngine
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(2024)
+rng = np.random.default_rng(int(os.environ.get("NEMPC_SWEEP_SEED", "2024")))
 net = orc.MLP.random(3, [64, 64], 2, seed=0)
 bad = 0
 for trial in range(trials):
