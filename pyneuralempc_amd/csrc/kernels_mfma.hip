@@ -293,6 +293,13 @@ int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, voi
     // an instantiation of the wave-per-tile kernel that is not used (launch_shape): the generic kernel computes the rows.
     // It has no stage records: the RK4 Hessian pipeline's callers take their generic path on NEMPC_EUNSUPPORTED
     if (stage_out) return NEMPC_EUNSUPPORTED;
+    if (!tiles && h.variant == NEMPC_KERNEL_MFMA) {
+        // a defect-only launch (they take the wave-per-tile kernel): the cooperative kernel with its tiles into the workspace
+        // is still far ahead of the generic kernel where it serves the shape
+        p.tiles = h.d_tiles_ws;
+        const int rc2 = h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+        if (rc2 != NEMPC_INTERNAL_USE_VALU) return rc2;
+    }
     return launch_rows_valu(h, B, Z, X0, g, tiles ? tiles : h.d_tiles_ws, s);
 }
 
