@@ -9,7 +9,7 @@ from pyneuralempc_amd import _build
 
 def main():
     tag = sys.argv[1]
-    defs = [a for a in sys.argv[2:] if a.startswith("-D")]
+    defs = [a for a in sys.argv[2:] if a.startswith("-D") or a in ("-O1", "-O2", "-O0")]
     for a in sys.argv[2:]:          # --mllvm=<option>: passed to the backend as -mllvm <option> (scheduling experiments)
         if a.startswith("--mllvm="):
             defs += ["-mllvm", a[len("--mllvm="):]]
