@@ -99,6 +99,7 @@ struct SolverArgs {
                            // one attempt's region (gains, value function, temporaries) in the problem's LDS block
     double tol_g, tol_step, mu_min, mu_factor;
     double armijo_slack;                                                 // relative slack of the Armijo test (see merit kernel)
+    double reg_relax;                                                    // factor by which the Levenberg term is relaxed after a clean sweep
     int max_ls;                                                          // halvings before the next LQ solve is damped
 };
 
@@ -1784,7 +1785,7 @@ __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* 
             a.lsdone[b] = 1;
             // relax the damping only after a sweep that went through at the first attempt: a term that had to be raised
             // this iteration would fail again right away and cost a full extra sweep
-            if (!(lsr > T(0))) reg[b] = fmax(regb * T(0.1), T(1e-9));
+            if (!(lsr > T(0))) reg[b] = fmax(regb * (T)a.reg_relax, T(1e-9));
             ((T*)a.info)[(size_t)b * INFO_N + INFO_LSK] = T(0);
         }
     } else if (lane == 0) {
@@ -2445,6 +2446,10 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         a.armijo_slack = std::max(1e-12, slack_eps * (double)std::numeric_limits<T>::epsilon());
     }
     a.max_ls = o.max_linesearch;
+    {
+        static const double relax_env = [] { const char* e = getenv("NEMPC_SOLVER_REG_RELAX"); return e ? atof(e) : 0.1; }();   // A/B knob
+        a.reg_relax = relax_env > 0.0 && relax_env < 1.0 ? relax_env : 0.1;
+    }
     auto lqk = a.use_lds ? ((nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1, true>
                                                   : ((nx == 6 && nu == 3) ? solver_lq_kernel<T, 6, 3, true> : solver_lq_kernel<T, 0, 0, true>))
                          : ((nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1, false>
