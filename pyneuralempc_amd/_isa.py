@@ -1,0 +1,95 @@
+"""Build stage between hipcc's code generation and the assembler: find, and repair, vector instructions that the compiler
+placed in front of an exec restore (gfx950 assembly text in, gfx950 assembly text out).
+
+The defect (AMD clang 22 / ROCm 7.2, found in round 4 from the wrong rows of three wave-per-tile kernels in round 3):
+when the register allocator needs a vector-register spill store (`v_accvgpr_write_b32 aN, vM`, `scratch_store_*`), a reload
+or a live-range-split copy at the top of the block that JOINS a divergent region, it can put it in front of the
+`s_or_b64 exec, exec, s[..]` that re-opens the lanes the region had closed:
+
+    s_and_saveexec_b64 s[0:1], s[12:13]      ; lanes with e < 16 * ne  (none at all when ne == 0)
+    s_cbranch_execz .LBB47_49
+      ...                                    ; the region's body
+  .LBB47_49:
+    v_accvgpr_write_b32 a163, v18            ; <-- spill store of a value EVERY lane needs later, executed by the region's
+    s_or_b64 exec, exec, s[0:1]              ;     lanes only: with exec == 0 nothing is stored at all
+      ...
+    v_accvgpr_read_b32 v18, a163             ; reload, all lanes: whatever the register file held (machine dependent)
+
+`v_readlane / v_writelane / v_readfirstlane` and scalar instructions do not depend on exec and are what the compiler means to
+have there (scalar-register spill reloads).  Moving the stray vector instructions directly behind the restore is the
+placement the allocator should have chosen: `s_or_b64` reads and writes scalar registers only, so no operand of the moved
+instruction changes, and nothing stands between the two positions.
+
+`scan` is also the check of the finished code: `_build.py` runs it on the repaired text and fails the build on any finding;
+`tests/test_cabi_cpu.py` runs both on text fixtures and on the reports the build leaves next to the objects.
+"""
+import re
+
+LABEL = re.compile(r"^([.\w$]+):")
+KERNEL = re.compile(r"^(_Z\w+):")
+SKIP = re.compile(r"^\s*s_cbranch_execz\s+([.\w$]+)")
+EXEC_RESTORE = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,\s*s\[")
+# what may stand between a join label and the restore: scalar instructions and the lane-addressed moves (exec-independent)
+SAFE = re.compile(r"^\s*(s_\w+|v_readlane_b32|v_writelane_b32|v_readfirstlane_b32)\b")
+BRANCH = re.compile(r"^\s*s_(cbranch\w*|branch|endpgm|setpc_b64)\b")
+# anything else that writes exec opens a region of its own (an `if` without a skip branch: saveexec, body, restore in one
+# block): what stands between it and its restore is the region's body, not a misplaced instruction
+EXEC_WRITE = re.compile(r"^\s*(s_\w+saveexec_b64\b|s_\w+\s+exec\s*,|v_cmpx_)")
+
+
+def _is_code(text):
+    s = text.strip()
+    return bool(s) and not s.startswith(";") and not s.startswith(".")
+
+
+def _walk(lines):
+    """Yields (kernel, restore_index, [indices of vector instructions between the join label and the restore])."""
+    # join labels: where the lanes that skipped a region (or left a divergent loop) arrive -- the targets of
+    # `s_cbranch_execz`.  A body laid out of line (entered by `s_cbranch_execnz`) legitimately ends with its own restore.
+    joins = set(m.group(1) for m in (SKIP.match(t) for t in lines) if m)
+    kernel = None
+    block = None            # indices since the last join label; None = not directly behind one
+    for i, text in enumerate(lines):
+        m = KERNEL.match(text)
+        if m:
+            kernel, block = m.group(1), None
+            continue
+        m = LABEL.match(text)
+        if m:
+            block = [] if m.group(1) in joins else None
+            continue
+        if not _is_code(text):
+            continue
+        if EXEC_RESTORE.match(text):
+            bad = [j for j in (block or []) if not SAFE.match(lines[j])]
+            if bad:
+                yield kernel, i, bad
+            block = None
+            continue
+        if BRANCH.match(text) or EXEC_WRITE.match(text):
+            block = None
+            continue
+        if block is not None:
+            block.append(i)
+
+
+def scan(text):
+    """-> [{"kernel", "line" (1-based, of the restore), "instructions": [(line, text), ...]}, ...]"""
+    lines = text.split("\n")
+    return [{"kernel": k, "line": r + 1, "instructions": [(j + 1, lines[j].strip()) for j in bad]}
+            for k, r, bad in _walk(lines)]
+
+
+def repair(text):
+    """Moves every stray vector instruction directly behind its restore.  -> (new text, findings of the input)."""
+    lines = text.split("\n")
+    found = list(_walk(lines))
+    findings = [{"kernel": k, "line": r + 1, "instructions": [(j + 1, lines[j].strip()) for j in bad]} for k, r, bad in found]
+    # back to front, so that earlier indices stay valid
+    for _, r, bad in reversed(found):
+        moved = [lines[j] for j in bad]
+        for j in reversed(bad):
+            del lines[j]
+        r -= len(bad)
+        lines[r + 1:r + 1] = moved
+    return "\n".join(lines), findings

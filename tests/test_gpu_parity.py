@@ -596,13 +596,13 @@ def test_nan_inputs_stay_visible_for_every_activation(act):
 
 def test_every_matrix_core_row_instantiation_against_the_oracle():
     """Every (dtype, padded width 32 / 64 / 128, hidden layers 1..3) instantiation of the wave-per-tile row kernel x activation
-    x transcription once, defects and dense Jacobian against the oracle.  Three streamed instantiations at the register cap
-    produced wrong rows for some of these combinations (csrc/kernels_mfma_typed.inc, launch_shape): they are not used -- the
-    generic kernel serves those shapes -- and this sweep is what found them."""
+    x transcription once, defects and dense Jacobian against the oracle.  Round 3 found three streamed instantiations at the
+    register cap returning wrong rows for some of these combinations and kept them away from the launcher; round 4 found the
+    cause (a spill store in front of an exec restore, pyneuralempc_amd/_isa.py), the build repairs it, and every
+    instantiation is launched again: nothing may fall back to the generic kernel here."""
     import itertools
     from pyneuralempc_amd import CallbackEngine
     nx, nu, H, B = 2, 1, 7, 37
-    fell_back = set()
     for dt, width, depth, integ, act in itertools.product((torch.float64, torch.float32), (24, 48, 96), (1, 2, 3),
                                                          ("discret", "rk4"), ("tanh", "relu", "sigmoid", "softplus", "elu")):
         DT = 0.1 if integ == "rk4" else 1.0
@@ -615,12 +615,43 @@ def test_every_matrix_core_row_instantiation_against_the_oracle():
         res = eng.eval_numpy(Zh, X0h, want=("g", "jac_dense"))
         tol = 2e-4 if dt == torch.float32 else 1e-10
         tag = (str(dt), width, depth, integ, act)
+        assert eng.last_row_kernel == "rows_mfma_kernel", tag
         assert np.abs(res["g"] - g).max() / max(1.0, np.abs(g).max()) < tol, tag
         assert np.abs(res["jac_dense"] - J).max() / max(1.0, np.abs(J).max()) < tol, tag
         # defect-only launches (line-search trials) take the wave-per-tile kernel on every variant
         g_only = eng.eval_numpy(Zh, X0h, want=("g",))["g"]
         assert np.abs(g_only - g).max() / max(1.0, np.abs(g).max()) < tol, tag
-        if eng.last_row_kernel == "rows_valu_kernel":
-            fell_back.add((str(dt), width, depth))
         del eng
-    assert fell_back == {("torch.float64", 48, 3), ("torch.float64", 96, 2), ("torch.float32", 96, 2)}
+
+
+def test_every_matrix_core_instantiation_with_its_hessian_against_the_oracle():
+    """The same sweep over the kernels the DEFAULT dispatch launches (`kernel="mfma"`: cooperative rows, cooperative /
+    fixed-shape / wave-per-tile Hessian kernels, the RK4 Hessian pipeline) and the wave-per-tile family, rows AND Lagrangian
+    Hessian values, 2/1 and 6/3 dims: every launched instantiation that sits at the 256-register cap or has scratch
+    (`rows_coop_kernel<.., 64, 3, ..>`, `<.., 128, 2, ..>`, `rowhess_coop_kernel<.., 64, 3, 3>`, `rowhess_mfma_kernel<.., 128,
+    {2, 3}, false>`) is in it, each activation."""
+    import itertools
+    from pyneuralempc_amd import CallbackEngine
+    H, B = 7, 11
+    for dt, width, depth, integ, act, kern, (nx, nu) in itertools.product(
+            (torch.float64, torch.float32), (48, 96), (2, 3), ("discret", "rk4"), ("tanh", "relu", "sigmoid", "softplus", "elu"),
+            ("mfma", "mfma_tile"), ((2, 1), (6, 3))):
+        DT = 0.1 if integ == "rk4" else 1.0
+        net = orc.MLP.random(nx + nu, [width] * depth, nx, seed=5, activations=act)
+        Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=5)
+        prob = orc.Problem(net, H, nx, nu, orc.RK4 if integ == "rk4" else orc.DISCRET, DT)
+        f, grad, g, J = prob.eval_batch(Zh, X0h)
+        eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=dt, device="cuda:0", max_batch=B,
+                             kernel=kern, activations=act)
+        tag = (str(dt), width, depth, integ, act, kern, nx)
+        res = eng.eval_numpy(Zh, X0h, want=("g", "jac_dense"))
+        assert eng.last_row_kernel != "rows_valu_kernel", tag
+        tol = 2e-4 if dt == torch.float32 else 1e-10
+        assert np.abs(res["g"] - g).max() / max(1.0, np.abs(g).max()) < tol, tag
+        assert np.abs(res["jac_dense"] - J).max() / max(1.0, np.abs(J).max()) < tol, tag
+        rng = np.random.default_rng(1)
+        lam, sig = rng.normal(size=(B, eng.m)), rng.uniform(0.5, 1.5, size=B)
+        hv = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lam), eng.to_device(sig))["hvals"].cpu().double().numpy()
+        ref = np.stack([prob.hessian_values(Zh[i], X0h[i], lam[i], sig[i]) for i in range(B)])
+        assert np.abs(hv - ref).max() / max(1.0, np.abs(ref).max()) < (2e-3 if dt == torch.float32 else 1e-9), tag
+        del eng

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Build a variant of libnempc.so with extra -D flags into pyneuralempc_amd/build_<tag>/libnempc_<tag>.so (A/B kernel
-experiments; run with NEMPC_LIB=<that path>).   python tools/build_variant.py <tag> [-DNAME=VALUE ...] [--only a.hip,b.hip]"""
+experiments; run with NEMPC_LIB=<that path>).   python tools/build_variant.py <tag> [-DNAME=VALUE ...] [--only a.hip,b.hip]
+--no-repair: assemble the compiler's text as it is (the control for the exec-restore repair of _isa.py)"""
 import os, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,7 +24,8 @@ def main():
     def one(src):
         if src in kern:
             o = os.path.join(out, src.replace(".hip", ".o"))
-            subprocess.run([_build._hipcc()] + _build.FLAGS + (_build.EXTRA_FLAGS.get(src, []) if "--no-extra" not in sys.argv else []) + defs + ["-c", os.path.join(_build.CSRC, src), "-o", o], check=True)
+            extra = (_build.EXTRA_FLAGS.get(src, []) if "--no-extra" not in sys.argv else []) + defs
+            _build.compile_unit(os.path.join(_build.CSRC, src), o, extra, repair="--no-repair" not in sys.argv)
             return o
         return os.path.join(_build.PKG, "build", src.replace(".hip", ".o"))
     with ThreadPoolExecutor(max_workers=4) as ex:
