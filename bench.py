@@ -693,6 +693,7 @@ class Rank:
                 out["batched_solver"] = self.solver_leg(res)
             if not args.no_hessian and (cfg["integrator"] != "rk4" or eng.kernel_variant != "valu"):
                 out["hessian_callback"] = self.hessian_leg(res)
+            out["sparse_contract"] = self.sparse_leg(res)
             # ---- the other BASELINE configs under the same clock (HIP events; every rank runs them, rank 0 reports)
             if args.config == "c2" and not args.batch and not args.no_other_configs:
                 others = {}
@@ -715,6 +716,8 @@ class Rank:
                         entry["roofline_mfma"] = s2
                     if not args.no_hessian and nm != "c4":
                         entry["hessian_callback"] = self.hessian_leg(r2)
+                    if nm != "c4":
+                        entry["sparse_contract"] = self.sparse_leg(r2)
                     if nm == "c4":
                         entry["batched_solver"] = self.solver_leg(r2)
                     others[nm] = entry
@@ -802,33 +805,81 @@ class Rank:
                 refg = prob.gauss_newton_values(Zh[i], X0h[i], wh[i], sigh[i])
                 e_g = max(e_g, float(np.abs(gv[i].to("cpu", torch.float64).numpy() - refg).max()))
         out_bytes = B * eng.nnz_hess * w
+        # flops the launched kernel EXECUTES on the matrix cores: the compiled-shape kernel (rowhess_coopfx_kernel) sums the
+        # second-order chain rule layer by layer -- base forward + base reverse + nin tangent-forward sweeps = (2 + nin)
+        # network passes; the forward-over-reverse kernels (rowhess_coop / rowhess_mfma) run a tangent-forward AND a
+        # tangent-reverse sweep per input = (2 + 2 nin) passes.  `frac` is taken over the executed count.
+        hk = eng.last_hess_kernel or ""
+        passes_fwd_over_rev = 2 + 2 * nin
+        passes = (2 + nin) if hk.endswith("rowhess_coopfx_kernel") else passes_fwd_over_rev
+        stage_rows = row_flops if S == 4 else 0
+        flops_exec = row_flops * passes / (1 + nx) + stage_rows
+        flops_f_o_r = row_flops * passes_fwd_over_rev / (1 + nx) + stage_rows
+        kname = (hk + " (blocks and tril assembly in one launch)" if S == 1 else
+                 "RK4 pipeline: stage-record rows, rk4_nu, " + hk.replace("rk4:", "") + " (direct mode), rk4_congruence, assemble_hess")
+        gn_fused = eng.last_row_kernel == "rows_coopfx_kernel"
         return {"nnz_hess": eng.nnz_hess,
                 "exact": {"us": t_h * 1e6, "batch_evals_per_s": 1.0 / t_h, "max_abs_err_vs_cpu": e_h, "max_abs_ref": s_h,
-                          "roofline": {"bound": "mfma", "kernel": (("rowhess_coopfx_kernel" if (cfg["nx"], cfg["nu"], cfg["hidden"], cfg["dtype"]) == (2, 1, [64, 64], "f64")
-                                                                     else "rowhess_coop_kernel") + " (blocks and tril assembly in one launch)"
-                                                                    if S == 1 else "RK4 pipeline: stage-record rows, rk4_nu, "
-                                                                    "rowhess_coop_kernel (direct mode), rk4_congruence, assemble_hess"),
-                                       "achieved": hess_flops / t_h / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
-                                       "frac": hess_flops / t_h / 1e12 / peak_tf, "traffic": None,
-                                       "flops_per_callback": hess_flops,
-                                       "flops_note": "(2 + 2 nin) / (1 + nx) x the row kernel's flops"
+                          "roofline": {"bound": "mfma", "kernel": kname,
+                                       "achieved": flops_exec / t_h / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                                       "frac": flops_exec / t_h / 1e12 / peak_tf, "traffic": None,
+                                       "flops_per_callback": flops_exec,
+                                       "flops_note": f"matrix-core flops the launched kernel executes: ({passes} network passes per row"
+                                                     + (" and RK4 stage" if S == 4 else "") + ") / (1 + nx) x the row kernel's flops"
                                                      + (" + the stage-record row launch" if S == 4 else "")
-                                                     + ": the pass count of forward-over-reverse (one tangent-forward and one "
-                                                       "tangent-reverse sweep per input).  The compiled-shape kernels sum the "
-                                                       "second-order chain rule layer by layer instead and run (2 + nin) passes on "
-                                                       "the matrix cores (flops_matrix_executed); the contraction is vector work",
-                                       "flops_matrix_executed": row_flops * (2 + nin) / (1 + nx) + (row_flops if S == 4 else 0),
-                                       "frac_of_executed": (row_flops * (2 + nin) / (1 + nx) + (row_flops if S == 4 else 0)) / t_h / 1e12 / peak_tf}},
+                                                     + "; the contraction over the hidden units is vector work and not counted",
+                                       "frac_vs_fwd_over_rev_equivalent": flops_f_o_r / t_h / 1e12 / peak_tf,
+                                       "fwd_over_rev_note": "the same time priced at forward-over-reverse's (2 + 2 nin) passes: what "
+                                                            "the callback would cost in flops without the layer-wise factorisation"}},
                 "gauss_newton": {"us": t_g * 1e6, "batch_evals_per_s": 1.0 / t_g, "max_abs_err_vs_cpu": e_g,
                                  "roofline": {"bound": "mfma", "kernel": ("rows_coopfx_kernel<..., GN = true>: tiles, blocks and tril assembly in one launch"
-                                                                          if (cfg["nx"], cfg["nu"], cfg["hidden"], cfg["dtype"]) == (2, 1, [64, 64], "f64")
-                                                                          and os.environ.get("NEMPC_GN_FUSED", "1") != "0"
-                                                                          else "row kernel (tiles) + assemble_hess_gn_kernel: two launches"),
+                                                                          if gn_fused else
+                                                                          str(eng.last_row_kernel) + " (tiles) + assemble_hess_gn_kernel: two launches"),
                                               "achieved": row_flops / t_g / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
                                               "frac": row_flops / t_g / 1e12 / peak_tf, "traffic": None,
                                               "flops_per_callback": row_flops, "bytes_written": out_bytes,
                                               "hbm_frac_of_output": out_bytes / t_g / 1e9 / PEAK_HBM_GBS}},
                 "err_checked_on": f"hvals of the timed launches, problems {starts} (+{k if cfg['nx'] <= 2 else 4} each)"}
+
+    def sparse_leg(self, res):
+        """The sparse contract (what a real Ipopt run wants; the reference hands cyipopt the dense (m, n),
+        optimizer/ipopt.py:88-96): f, grad, g and the band-pattern Jacobian values in nempc_jac_structure order from ONE
+        launch -- no dense matrix, no tile round trip, no assembly launch.  HIP-event time, both rooflines over the
+        compact bytes of SURVEY 8d (inputs, f, grad, g, band values), error of the timed launch's output vs the oracle."""
+        np, torch = self.np, self.torch
+        cfg, B, eng = res["cfg"], res["B"], res["eng"]
+        from oracle import nempc_oracle as orc
+        Zh, X0h = orc.synthetic_inputs(B, cfg["H"], cfg["nx"], cfg["nu"], seed=1 + self.rank)
+        Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+        step, outs = eng.bind(Z, X0, ("f", "grad", "g", "jac_sparse"))
+        t = self.timed_events(step, max(self.args.steps, 50))
+        kern = eng.last_row_kernel
+        rows, cols = eng.jac_structure()
+        _, prob = oracle_problem(cfg)
+        k = min(16, B)
+        starts = sorted({0, max(0, B // 2 - k // 2), B - k})
+        err = {"f": 0.0, "grad": 0.0, "g": 0.0, "jac_sparse": 0.0}
+        for s0 in starts:
+            sl = slice(s0, s0 + (k if cfg["nx"] <= 2 else min(k, 4)))
+            f, grad, g, jac = prob.eval_batch(Zh[sl], X0h[sl])
+            for key, ref in (("f", f), ("grad", grad), ("g", g), ("jac_sparse", jac[:, rows, cols])):
+                err[key] = max(err[key], float(np.abs(outs[key][sl].to("cpu", torch.float64).numpy() - ref).max()))
+        w = 8 if cfg["dtype"] == "f64" else 4
+        peak_tf = PEAK_F64_TFLOPS if cfg["dtype"] == "f64" else PEAK_F32_TFLOPS
+        nnz = int(len(rows))
+        nbytes = B * w * ((eng.n + cfg["nx"]) + 1 + eng.n + eng.m + nnz)
+        flops = res["work"]["flops"]
+        ai, ridge = flops / nbytes, peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+        mfma = {"bound": "mfma", "kernel": str(kern), "achieved": flops / t / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
+                "frac": flops / t / 1e12 / peak_tf, "traffic": None, "kernel_us": t * 1e6, "flops_per_launch": flops,
+                "arithmetic_intensity": ai, "ridge": ridge}
+        hbm = {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "frac": nbytes / t / 1e9 / PEAK_HBM_GBS, "traffic": None, "bytes_per_launch": nbytes}
+        return {"us": t * 1e6, "batch_evals_per_s": 1.0 / t, "problem_evals_per_s": B / t, "nnz_jac": nnz,
+                "one_launch": kern in ("rows_coopfx_kernel+sparse", "rows_coop_kernel+sparse"),
+                "dense_contract_us": res["t_all"] * 1e6,
+                "roofline": mfma if ai >= ridge else hbm, ("roofline_hbm" if ai >= ridge else "roofline_mfma"): hbm if ai >= ridge else mfma,
+                "max_abs_err_vs_cpu": err, "err_checked_on": f"outputs of the timed launch, problems {starts}"}
 
     def single_rank_gather_latency(self, res, reps=200):
         """N = 1: no gather is issued in the timed loop (there is nobody to exchange with), but the path exists -- a

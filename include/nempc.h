@@ -280,8 +280,16 @@ int nempc_kernel_variant(nempc_handle h);
 /* row kernel the handle's most recent evaluation actually launched: 1 generic (rows_valu_kernel),
  * 2 cooperative matrix-core (rows_coop_kernel), 3 wave-per-tile matrix-core (rows_mfma_kernel), 4 cooperative
  * matrix-core compiled for the problem's shape (rows_coopfx_kernel), 5 rows_coop_kernel writing the dense Jacobian
- * rows itself (no assembly launch); 0 = none yet */
+ * rows itself (no assembly launch), 6 / 7 rows_coopfx_kernel / rows_coop_kernel writing the band-pattern values of the
+ * sparse contract itself (no tile round trip, no assembly launch); 0 = none yet */
 int nempc_last_row_kernel(nempc_handle h);
+
+/* network kernel the handle's most recent nempc_hess (or solver iteration) launched for the Lagrangian blocks: 1 generic
+ * (rowhess_valu_kernel), 2 cooperative matrix-core, forward-over-reverse (rowhess_coop_kernel), 3 wave-per-tile
+ * matrix-core (rowhess_mfma_kernel), 4 compiled for the problem's shape, layer-wise contraction (rowhess_coopfx_kernel);
+ * + 10 when it ran inside the RK4 pipeline (stage records, stage multipliers, that kernel in direct mode, congruence
+ * sum: integrator/rk4.py:181-285); 0 = none yet */
+int nempc_last_hess_kernel(nempc_handle h);
 
 const char* nempc_last_error(void);
 int nempc_abi_version(void);

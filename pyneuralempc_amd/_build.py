@@ -82,11 +82,15 @@ def compile_unit(src, obj, extra=(), keep_asm=False, repair=True):
         text = fh.read()
     text, found = _isa.repair(text) if repair else (text, [])
     left = _isa.scan(text)
-    report = {"unit": os.path.basename(src), "repaired": found, "left": left}
+    hazards = _isa.scan_store_hazard(text)
+    report = {"unit": os.path.basename(src), "repaired": found, "left": left, "store_hazards": hazards}
     with open(stem + ".isa.json", "w") as fh:
         json.dump(report, fh, indent=1)
     if left and repair:
         raise RuntimeError(f"{src}: vector instructions in front of an exec restore survived the repair: {left}")
+    if hazards and repair:
+        raise RuntimeError(f"{src}: an inline-asm store of > 64 bits has its data registers overwritten inside the hazard "
+                           f"window (put `s_nop 1` behind the store in the asm statement): {hazards}")
     if found:
         with open(asm, "w") as fh:
             fh.write(text)

@@ -20,6 +20,12 @@ have there (scalar-register spill reloads).  Moving the stray vector instruction
 placement the allocator should have chosen: `s_or_b64` reads and writes scalar registers only, so no operand of the moved
 instruction changes, and nothing stands between the two positions.
 
+A second check, same stage (`scan_store_hazard`): a store of more than 64 bits written as inline asm whose data registers a
+vector instruction overwrites within two wait states.  The compiler pads its own wide stores (gfx9 "store data hazard") but
+cannot see into an asm statement; round 4's first sparse-contract epilogue had `v_lshl_add_u64 v[2:3], ...` directly behind
+`global_store_dwordx4 v[12:13], v[2:5]` and lanes 12..15 of every 16 stored garbage.  Such stores carry their own `s_nop 1`
+in the source; the check keeps it that way.
+
 `scan` is also the check of the finished code: `_build.py` runs it on the repaired text and fails the build on any finding;
 `tests/test_cabi_cpu.py` runs both on text fixtures and on the reports the build leaves next to the objects.
 """
@@ -93,3 +99,54 @@ def repair(text):
         r -= len(bad)
         lines[r + 1:r + 1] = moved
     return "\n".join(lines), findings
+
+
+# ---- inline-asm wide stores: the store-data hazard the compiler cannot pad for (module docstring)
+_ASM_START, _ASM_END = re.compile(r"^\s*;;#ASMSTART"), re.compile(r"^\s*;;#ASMEND")
+_WIDE_STORE = re.compile(r"^\s*(?:global|flat|scratch)_store_dwordx[34]\s+[^,]+,\s*v\[(\d+):(\d+)\]")
+_VALU_DEF = re.compile(r"^\s*v_\w+\s+(?:v(\d+)\b|v\[(\d+):(\d+)\])")
+_S_NOP = re.compile(r"^\s*s_nop\s+(\d+)")
+STORE_DATA_WAIT_STATES = 2       # gfx940+ (LLVM GCNHazardRecognizer: VALU write of >64-bit VMEM store data)
+
+
+def scan_store_hazard(text):
+    """-> [{"kernel", "line", "store", "clobber"}]: asm-block stores of > 64 bits with a VALU write of their data registers
+    inside the hazard window."""
+    lines = text.split("\n")
+    out, kernel, in_asm = [], None, False
+    for i, t in enumerate(lines):
+        m = KERNEL.match(t)
+        if m:
+            kernel = m.group(1)
+        if _ASM_START.match(t):
+            in_asm = True
+            continue
+        if _ASM_END.match(t):
+            in_asm = False
+            continue
+        m = _WIDE_STORE.match(t) if in_asm else None
+        if not m:
+            continue
+        lo, hi = int(m.group(1)), int(m.group(2))
+        waited = 0
+        for j in range(i + 1, min(i + 40, len(lines))):
+            u = lines[j]
+            if not _is_code(u) or _ASM_START.match(u) or _ASM_END.match(u):
+                continue
+            if LABEL.match(u) or BRANCH.match(u):
+                break
+            n = _S_NOP.match(u)
+            if n:
+                waited += int(n.group(1)) + 1
+            else:
+                d = _VALU_DEF.match(u)
+                if d and not u.strip().startswith(("v_cmp", "v_readlane", "v_readfirstlane")):
+                    a = int(d.group(1)) if d.group(1) is not None else int(d.group(2))
+                    b = int(d.group(1)) if d.group(1) is not None else int(d.group(3))
+                    if a <= hi and b >= lo:
+                        out.append({"kernel": kernel, "line": i + 1, "store": t.strip(), "clobber": u.strip()})
+                        break
+                waited += 1
+            if waited >= STORE_DATA_WAIT_STATES:
+                break
+    return out

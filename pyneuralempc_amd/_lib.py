@@ -20,7 +20,7 @@ ACTIVATION_IDS = {"linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3, "softplus": 4
 
 EXPORTS = ["nempc_create", "nempc_destroy", "nempc_reserve", "nempc_set_weights", "nempc_set_objective", "nempc_set_terminal_weight", "nempc_set_box_rows", "nempc_bind_extra", "nempc_bind_history",
            "nempc_dims", "nempc_constraint_bounds", "nempc_jac_structure", "nempc_hess_structure", "nempc_eval",
-           "nempc_hess", "nempc_hess_gn", "nempc_solve", "nempc_sync", "nempc_kernel_variant", "nempc_last_row_kernel", "nempc_last_error", "nempc_abi_version",
+           "nempc_hess", "nempc_hess_gn", "nempc_solve", "nempc_sync", "nempc_kernel_variant", "nempc_last_row_kernel", "nempc_last_hess_kernel", "nempc_last_error", "nempc_abi_version",
            "nempc_plan_grid", "nempc_num_cus",
            "nempc_comm_unique_id", "nempc_comm_init", "nempc_allgather_u0", "nempc_comm_size", "nempc_comm_destroy"]
 
@@ -83,6 +83,7 @@ def load():
     lib.nempc_sync.argtypes = [vp, vp]
     lib.nempc_kernel_variant.argtypes = [vp]
     lib.nempc_last_row_kernel.argtypes = [vp]
+    lib.nempc_last_hess_kernel.argtypes = [vp]
     lib.nempc_plan_grid.argtypes = [i32, i32, i32, ip, ip, ip]
     lib.nempc_num_cus.argtypes = [vp]
     lib.nempc_comm_unique_id.argtypes = [vp]

@@ -122,10 +122,15 @@ __device__ __forceinline__ void fx_store_wt(double* p, double v) {
 __device__ __forceinline__ void fx_store_wt(float* p, float v) {
     asm volatile("global_store_dword %0, %1, off" NEMPC_FX_WT ::"v"(p), "v"(v) : "memory");
 }
+// (gfx9 store-data hazard: a vector instruction that overwrites the data registers of a store of more than 64 bits needs two
+// wait states behind it.  The compiler inserts them for its own stores, but it cannot see into an asm statement -- the
+// sparse contract's second store had its pointer computed into the first one's data registers in the very next
+// instruction, and lanes 12..15 of every 16 stored the pointer.  Every 16-byte store written as asm carries its own
+// `s_nop 1`; _isa.py checks the assembled text for the pattern.)
 __device__ __forceinline__ void fx_store_wt2(double* p, double v0, double v1) {      // p 16-byte aligned
     typedef double d2 __attribute__((ext_vector_type(2)));
     const d2 v = {v0, v1};
-    asm volatile("global_store_dwordx4 %0, %1, off" NEMPC_FX_WT ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off" NEMPC_FX_WT "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // Fused dense Jacobian, part one: the BACKGROUND (see fx_zero_rows in kernels_coopfx_impl.h, the compiled-shape twin of
@@ -151,6 +156,7 @@ __device__ __forceinline__ void coop_zero_rows(T* o_jac, unsigned r0, int nrows,
         }
         if (tid < nv - full * NTHREADS)
             asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
+        asm volatile("s_nop 1" ::: "memory");      // store-data hazard: `zero`'s registers may be re-used right behind the run
     };
     if (!box) {
         run(fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) + (size_t)r0 * nx * row_bytes), (int)((size_t)drv * row_bytes / 16));
@@ -233,6 +239,8 @@ struct CoopCtx {
     T* gout;
     T* tiles;
     T* jac;                         // fused dense Jacobian (B, m, n) or null (plain models only)
+    T* sp;                          // band-pattern values (B, sp_nnz) in nempc_jac_structure order or null (plain models only)
+    int sp_nnz;
     int nx, nu, nin, H, n, m, NR, jsz, spt, nstages, ks, kind, box, xt_off, ex_off, ne, inv_nin;
     const T* extra;
     unsigned inv32_jrow, inv32_nx;
@@ -628,6 +636,15 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                 const int col = d < nx ? (t - 1) * nx + d : H * nx + t * nu + (d - nx);
                 if (d >= nx || t >= 1) fx_store_wt(jac + ((size_t)b * cx.m + (size_t)(t * nx + i)) * (size_t)n + col, v);
             }
+            if (cx.sp) {
+                // sparse contract: entry (t, i, d) of the band pattern -- per dense row [state block (t >= 1) | -1 | control
+                // block], rows in order, row 0's blocks without the state part (nempc_jac_structure)
+                const int b = RI[2 * idx], t = RI[2 * idx + 1];
+                const int row0 = 1 + nu, rowt = nx + 1 + nu;
+                const int base = t >= 1 ? nx * row0 + ((t - 1) * nx + i) * rowt : i * row0;
+                if (d >= nx) cx.sp[(size_t)b * cx.sp_nnz + base + (t >= 1 ? nx : 0) + 1 + (d - nx)] = v;
+                else if (t >= 1) cx.sp[(size_t)b * cx.sp_nnz + base + d] = v;
+            }
         }
     }
     // defects: lanes run over (row, state) with the state fastest -> contiguous inside a problem
@@ -649,6 +666,12 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                 T* const row = jac + ((size_t)b * cx.m + (size_t)(t * nx + i)) * (size_t)n;
                 fx_store_wt(row + t * nx + i, T(-1));
                 if (cx.box) fx_store_wt(row + (size_t)H * nx * (size_t)n + t * nx + i, T(1));
+            }
+            if (cx.sp) {
+                const int row0 = 1 + nu, rowt = nx + 1 + nu;
+                T* const spb = cx.sp + (size_t)b * cx.sp_nnz;
+                spb[t >= 1 ? nx * row0 + ((t - 1) * nx + i) * rowt + nx : i * row0] = T(-1);
+                if (cx.box) spb[nx * row0 + (H - 1) * nx * rowt + t * nx + i] = T(1);
             }
         }
     }
@@ -681,6 +704,8 @@ struct CoopArgs {
     void* g;
     void* tiles;
     void* jac;              // dense Jacobian written by this launch (plain models; null: the assembly kernel does it)
+    void* sp;               // sparse contract: the band values written by this launch (plain models), row-major pattern order
+    int sp_nnz;
     void* stage_out;
     long long* dbg;
     int m, NR, jsz, spt, nstages, ks, kind, box, xt_off, ex_off, inv_nin, rk4, stage_stride;
@@ -798,6 +823,7 @@ __global__ __launch_bounds__((WP / 16) * 64, OCC) void rows_coop_kernel(CoopArgs
     cx.gout = static_cast<T*>(a.g);
     cx.tiles = static_cast<T*>(a.tiles);
     cx.jac = static_cast<T*>(a.jac);
+    cx.sp = static_cast<T*>(a.sp); cx.sp_nnz = a.sp_nnz;
     cx.m = a.m;
     cx.gk = a.gk;
     cx.stage_out = static_cast<T*>(a.stage_out); cx.stage_stride = a.stage_stride;

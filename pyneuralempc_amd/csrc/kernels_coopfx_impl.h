@@ -97,6 +97,11 @@ struct FxArgs {   // host-prepared; the fields the first loads need come first
     const int32_t* gn_smap;
     const void* gn_objc;
     int gn_nnz, gn_n_orph;
+    // ---- sparse contract from this launch: the band-pattern values (B, nnz) in nempc_jac_structure order (row-major over the
+    //      dense matrix: per defect row (t, i) the state block at x_{t-1} (t >= 1), -1 at x_t[i], the control block at u_t;
+    //      then the box rows' +1 selectors), written by the lane that holds the row -- no tile round trip, no assembly launch
+    void* jac_sp;
+    int sp_nnz;
 };
 
 // The argument block proper, read where it is needed.  Kernel arguments are fetched by scalar loads that the compiler
@@ -278,6 +283,7 @@ __device__ __forceinline__ void fx_zero_rows(T* o_jac, unsigned r0, int nrows, i
         }
         if (tid < nv - full * NTHREADS)
             asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
+        asm volatile("s_nop 1" ::: "memory");      // store-data hazard: `zero`'s registers may be re-used right behind the run
     };
     if (!box) {
         run(fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) + (size_t)r0 * NX * (size_t)n * sizeof(T)), drv * nvec);
@@ -579,10 +585,14 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
     //      each problem.  The lane sums the row's tile entries from the K-split partials in wave order (the unfused
     //      kernel's loop above) and stores them.
     T* o_jac = nullptr;
+    T* o_sp = nullptr;
+    int sp_nnz = 0;
     if constexpr (FUSE) {
 #if !(defined(NEMPC_EXP_NODENSE) || defined(NEMPC_EXP_NONZ))      // (timing experiments only)
         o_jac = static_cast<T*>(ka->jac);
 #endif
+        o_sp = static_cast<T*>(ka->jac_sp);
+        sp_nnz = ka->sp_nnz;
     }
 #pragma unroll
     for (int it = 0; it < (NT * 16 * NX + NTHREADS - 1) / NTHREADS; ++it) {
@@ -605,7 +615,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             gp[0] = phi - xt;
             if (a_box) gp[(size_t)cx.H * NX] = xt;
             if constexpr (FUSE) {
-                if (o_jac) {
+                if (o_jac || o_sp) {
                     const int n = cx.n;
                     T ts[NIN];
 #pragma unroll
@@ -616,6 +626,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
                         if (a_ident && d == i) v += T(1);
                         ts[d] = v;
                     }
+                    if (o_jac) {
                     if (o_tiles) {
 #pragma unroll
                         for (int d = 0; d < NIN; ++d) o_tiles[(size_t)r * JROW + i * NIN + d] = ts[d];
@@ -633,6 +644,37 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
                     for (int jj = 0; jj < NU; ++jj) fx_store_wt(row + cx.H * NX + t * NU + jj, ts[NX + jj]);
                     if (a_box) fx_store_wt(row + (size_t)cx.H * NX * (size_t)n + t * NX + i, T(1));
+                    }
+                    if (o_sp) {
+                        // the band values of dense row (t, i), in the row's column order: [state block | -1 | control block]
+                        // (t = 0 has no state block: x0 is data); consecutive lanes write consecutive pieces of the problem's
+                        // value vector.  2/1 in double: a piece is 32 bytes (16 at t = 0) at a 16-byte aligned offset.
+                        constexpr int ROW0 = 1 + NU, ROWT = NX + 1 + NU;
+                        T* const sp = o_sp + (size_t)b * sp_nnz;
+                        if (t >= 1) {
+                            T* const pc = sp + NX * ROW0 + ((t - 1) * NX + i) * ROWT;
+                            if constexpr (NX == 2 && NU == 1 && sizeof(T) == 8) {
+                                fx_store_wt2(pc, ts[0], ts[1]);
+                                fx_store_wt2(pc + 2, T(-1), ts[2]);
+                            } else {
+#pragma unroll
+                                for (int jj = 0; jj < NX; ++jj) pc[jj] = ts[jj];
+                                pc[NX] = T(-1);
+#pragma unroll
+                                for (int jj = 0; jj < NU; ++jj) pc[NX + 1 + jj] = ts[NX + jj];
+                            }
+                        } else {
+                            T* const pc = sp + i * ROW0;
+                            if constexpr (NX == 2 && NU == 1 && sizeof(T) == 8) {
+                                fx_store_wt2(pc, T(-1), ts[2]);
+                            } else {
+                                pc[0] = T(-1);
+#pragma unroll
+                                for (int jj = 0; jj < NU; ++jj) pc[1 + jj] = ts[NX + jj];
+                            }
+                        }
+                        if (a_box) sp[NX * ROW0 + (cx.H - 1) * NX * ROWT + t * NX + i] = T(1);
+                    }
                 }
             }
         }

@@ -226,14 +226,36 @@ static MfmaParams base_params(Handle& h, int B, const void* Z, const void* X0, v
 // Whole hessian-free evaluation (g, dense jac, f, grad [, tiles]) in ONE launch where a fixed-shape kernel covers the
 // problem; NEMPC_EUNSUPPORTED (no error message, nothing launched) tells nempc_eval to take the two-launch path.
 int launch_eval_fused(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, void* f,
-                      void* grad, hipStream_t s) {
-    if (!h.mfma.blob || !h.d_obj || (!jac && !f && !grad)) return NEMPC_EUNSUPPORTED;
+                      void* grad, hipStream_t s, void* sparse) {
+    if (!h.mfma.blob || !h.d_obj || (!jac && !f && !grad && !sparse)) return NEMPC_EUNSUPPORTED;
+    if (sparse && (h.w != 1 || jac)) return NEMPC_EUNSUPPORTED;
     MfmaParams p = base_params(h, B, Z, X0, g, tiles);
     p.fuse_obj = true;
     p.fuse_jac = jac; p.fuse_f = f; p.fuse_grad = grad;
+    p.fuse_sparse = sparse; p.sp_nnz = (int)h.jac_rows.size();
     p.obj = h.d_obj;
     p.oo = obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu);
-    return h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+    const int rc = h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+    if (rc == NEMPC_OK && sparse) h.last_row_kernel = 6;     // the fixed-shape kernel, band values included
+    return rc;
+}
+
+// Rows, compact tiles (optional), the band-pattern Jacobian values and the objective from one launch of the cooperative
+// kernel (any shape it takes, plain models): the sparse contract without the tile round trip and the assembly launch.
+// NEMPC_EUNSUPPORTED (nothing launched, no error message) sends nempc_eval to the row + assembly launches.
+int launch_rows_mfma_sparse(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* sparse, void* f,
+                            void* grad, hipStream_t s) {
+    static const int on = [] { const char* e = getenv("NEMPC_COOP_SPARSE"); return e ? atoi(e) : 1; }();
+    if (!on || !h.mfma.blob || !sparse || h.w != 1 || ((f || grad) && !h.d_obj)) return NEMPC_EUNSUPPORTED;
+    MfmaParams p = base_params(h, B, Z, X0, g, tiles);
+    p.fuse_sparse = sparse; p.sp_nnz = (int)h.jac_rows.size();
+    if (f || grad) {
+        p.fuse_f = f; p.fuse_grad = grad; p.obj = h.d_obj;
+        p.oo = obj_offsets(h.cfg.H, h.cfg.nx, h.cfg.nu);
+    }
+    const int rc = h.cfg.dtype == NEMPC_F64 ? launch_rows_mfma_typed<double>(h, p, s) : launch_rows_mfma_typed<float>(h, p, s);
+    if (rc == NEMPC_OK) h.last_row_kernel = 7;        // the cooperative kernel, band values included
+    return rc;
 }
 
 // Gauss-Newton Hessian callback (tril values) in ONE launch of the fixed-shape kernel: the blocks sum_i w_i T_i^T T_i are

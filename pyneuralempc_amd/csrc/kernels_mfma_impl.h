@@ -68,6 +68,8 @@ struct MfmaParams {
     // fused evaluation (fixed-shape kernel only): dense Jacobian and objective from the same launch
     bool fuse_obj;         // one-launch evaluation asked for (launch_eval_fused); fuse_jac may be null (no dense matrix)
     void* fuse_jac;
+    void* fuse_sparse;     // band-pattern Jacobian values (B, nnz) in nempc_jac_structure order from the row launch (plain models)
+    int sp_nnz;
     void* fuse_f;
     void* fuse_grad;
     const void* obj;

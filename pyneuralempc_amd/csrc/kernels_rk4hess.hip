@@ -163,6 +163,7 @@ int launch_rowhess_rk4_mfma(Handle& h, int B, const void* Z, const void* X0, con
     // 3. contracted network Hessians at the four stage inputs
     if ((rc = launch_rowhess_mfma_direct(h, B, Z, X0, lambda, h.d_rk4_ht, h.d_rk4_stage, stride, h.d_rk4_nu, 4, s)))
         return rc;
+    h.last_hess_kernel += 10;      // (the network kernel of step 3, inside the pipeline)
     // 4. congruence sum
     return f64 ? run_small_kernels<double>(h, R, lambda, blocks, stride, true, s)
                : run_small_kernels<float>(h, R, lambda, blocks, stride, true, s);

@@ -513,6 +513,7 @@ int launch_rowhess_valu(Handle& h, int B, const void* Z, const void* X0, const v
     const dim3 block(256), grid((unsigned)((rows + 255) / 256));
     NetDev nd = make_netdev(h);
     WsOff o = ws_offsets(h);
+    h.last_hess_kernel = 1;
     if (h.cfg.dtype == NEMPC_F64)
         hipLaunchKernelGGL(rowhess_valu_kernel<double>, grid, block, 0, s, nd, o, h.cfg.integrator, h.cfg.DT, B, h.cfg.H,
                            Rcap, (const double*)Z, (const double*)X0, (const double*)lambda, h.m, (double*)blocks,

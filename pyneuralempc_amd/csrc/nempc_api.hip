@@ -617,11 +617,15 @@ int nempc_eval(nempc_handle hh, int32_t B, const void* Z, const void* X0, void* 
             rc = launch_eval_fused(h, B, Z, X0, gout, jac_tiles, jac_dense, f, grad, s);
             if (rc != NEMPC_EUNSUPPORTED) return rc;
         }
-        // sparse contract on a compiled shape: rows, tiles and the objective from the fused launch (without the dense
-        // matrix), then the band values gathered from the tiles
+        // sparse contract (what a real Ipopt run wants: SURVEY 8f-2; the reference hands cyipopt the dense (m, n),
+        // optimizer/ipopt.py:88-96): rows, band values in nempc_jac_structure order and the objective from ONE launch -- of
+        // the fixed-shape kernel on a compiled shape, of the cooperative kernel on every other plain-model shape it takes.
+        // No tile round trip through memory, no assembly launch.
         if (jac_sparse && !jac_dense && h.variant == NEMPC_KERNEL_MFMA) {
-            rc = launch_eval_fused(h, B, Z, X0, gout, tiles, nullptr, f, grad, s);
-            if (rc != NEMPC_EUNSUPPORTED) return rc ? rc : launch_assemble_sparse(h, B, tiles, jac_sparse, s);
+            rc = launch_eval_fused(h, B, Z, X0, gout, jac_tiles, nullptr, f, grad, s, jac_sparse);
+            if (rc != NEMPC_EUNSUPPORTED) return rc;
+            rc = launch_rows_mfma_sparse(h, B, Z, X0, gout, jac_tiles, jac_sparse, f, grad, s);
+            if (rc != NEMPC_EUNSUPPORTED) return rc;
         }
         // dense contract on any shape the cooperative kernel takes (plain models): the dense rows AND the objective leave
         // from the row launch itself -- no assembly launch, no tile round trip through memory, no objective launch
@@ -767,6 +771,11 @@ int nempc_plan_grid(int32_t ntiles, int32_t num_cus, int32_t per_cu, int32_t* gr
 int nempc_num_cus(nempc_handle hh) {
     if (!hh) return fail(NEMPC_EINVAL, "nempc_num_cus: null handle");
     return reinterpret_cast<Handle*>(hh)->num_cus;
+}
+
+int nempc_last_hess_kernel(nempc_handle hh) {
+    if (!hh) return fail(NEMPC_EINVAL, "nempc_last_hess_kernel: null handle");
+    return reinterpret_cast<Handle*>(hh)->last_hess_kernel;
 }
 
 int nempc_last_row_kernel(nempc_handle hh) {

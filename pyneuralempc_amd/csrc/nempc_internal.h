@@ -162,6 +162,7 @@ struct Handle {
     void* solver_ws = nullptr;   // solver.hip
     void* comm = nullptr;        // comm.hip: RCCL communicator of the u0 all-gather
     mutable int last_row_kernel = 0;  // 1 valu, 2 coop, 3 wave-tile
+    mutable int last_hess_kernel = 0; // 1 valu, 2 coop, 3 wave-tile, 4 fixed shape; + 10: inside the RK4 pipeline (nempc_last_hess_kernel)
 };
 
 struct ObjOffsets {  // element offsets into Handle::d_obj
@@ -200,7 +201,9 @@ bool mfma_supported(const Handle& h);
 int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b);
 int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s);
 int launch_eval_fused(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, void* f,
-                      void* grad, hipStream_t s);
+                      void* grad, hipStream_t s, void* sparse = nullptr);
+int launch_rows_mfma_sparse(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* sparse, void* f,
+                            void* grad, hipStream_t s);
 int launch_rows_mfma_dense(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, void* f,
                            void* grad, hipStream_t s);
 int launch_hess_gn_fused(Handle& h, int B, const void* Z, const void* X0, const void* w, const void* sigma, void* hvals,

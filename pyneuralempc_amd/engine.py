@@ -168,8 +168,16 @@ class CallbackEngine:
     def last_row_kernel(self):
         """Name of the row kernel the most recent evaluation launched."""
         return {0: None, 1: "rows_valu_kernel", 2: "rows_coop_kernel", 3: "rows_mfma_kernel", 4: "rows_coopfx_kernel",
-                5: "rows_coop_kernel+dense"}[
+                5: "rows_coop_kernel+dense", 6: "rows_coopfx_kernel+sparse", 7: "rows_coop_kernel+sparse"}[
             self.lib.nempc_last_row_kernel(self._handle)]
+
+    @property
+    def last_hess_kernel(self):
+        """Name of the network kernel the most recent Lagrangian-Hessian evaluation launched ("rk4:" prefix: inside the RK4
+        pipeline)."""
+        v = self.lib.nempc_last_hess_kernel(self._handle)
+        name = {0: None, 1: "rowhess_valu_kernel", 2: "rowhess_coop_kernel", 3: "rowhess_mfma_kernel", 4: "rowhess_coopfx_kernel"}[v % 10]
+        return ("rk4:" + name) if v >= 10 and name else name
 
     # ------------------------------------------------------------------ parameters
     def set_objective(self, Q=None, R=None, xref=None, uref=None, cx=None, cu=None, QT=None):

@@ -77,6 +77,39 @@ def test_repair_moves_them_behind_the_restore_and_nothing_else():
     assert same == FINE and none == []
 
 
+HAZARD = """\
+_ZN5nempc3badEv:
+\t;;#ASMSTART
+\tglobal_store_dwordx4 v[12:13], v[2:5], off sc0 sc1
+\t;;#ASMEND
+\tv_lshl_add_u64 v[2:3], v[8:9], 0, 48
+\ts_endpgm
+_ZN5nempc4goodEv:
+\t;;#ASMSTART
+\tglobal_store_dwordx4 v[12:13], v[2:5], off sc0 sc1
+\ts_nop 1
+\t;;#ASMEND
+\tv_lshl_add_u64 v[2:3], v[8:9], 0, 48
+\t;;#ASMSTART
+\tglobal_store_dwordx4 v[12:13], v[2:5], off sc0 sc1
+\t;;#ASMEND
+\tv_add_u32_e32 v9, 1, v9
+\tv_mov_b32_e32 v6, 0
+\tv_mov_b32_e32 v2, 0
+\tglobal_store_dwordx4 v[12:13], v[2:5], off
+\tv_mov_b32_e32 v2, 0
+\ts_endpgm
+"""
+
+
+def test_store_data_hazard_of_inline_asm_stores_is_found():
+    """A vector write of the data registers of a > 64-bit store inside two wait states: the compiler pads its own stores, an
+    asm statement has to carry its `s_nop 1` (round 4: lanes 12..15 of every 16 stored a pointer in the sparse contract)."""
+    from pyneuralempc_amd import _isa
+    h = _isa.scan_store_hazard(HAZARD)
+    assert len(h) == 1 and h[0]["kernel"] == "_ZN5nempc3badEv" and h[0]["clobber"].startswith("v_lshl_add_u64 v[2:3]")
+
+
 def test_every_translation_unit_of_the_shipped_library_scans_clean():
     """The build fails when a repaired text still has a finding; its reports say what was repaired.  (Round 4: ten join
     blocks in seven units, all in streamed `rows_mfma_kernel` instantiations -- DESIGN.md.)"""
@@ -87,5 +120,6 @@ def test_every_translation_unit_of_the_shipped_library_scans_clean():
     assert sorted(reports) == sorted(_build.SOURCES), "build/<unit>.isa.json missing: rebuild with python -m pyneuralempc_amd._build"
     for unit, rep in reports.items():
         assert rep["left"] == [], unit
+        assert rep["store_hazards"] == [], unit
         for f in rep["repaired"]:
             assert f["instructions"], unit

@@ -324,21 +324,41 @@ def test_defect_only_evaluation_matches_full_evaluation(name):
             assert np.array_equal(only_g, full)
 
 
-@pytest.mark.parametrize("name", ["c2_discret", "c5_box", "odd_dims", "c3_rk4", "h1"])
+@pytest.mark.parametrize("name", ["c1_discret", "c2_discret", "c2_unity", "c2_rk4", "c5_box", "odd_dims", "c3_rk4", "c3_discret", "h1",
+                                  "act_relu_c2", "act_elu_c3"])
 def test_sparse_contract_fused_launch(name):
-    """f, grad, g and the band-pattern Jacobian values without the dense matrix (one fused post launch)."""
+    """f, grad, g and the band-pattern Jacobian values without the dense matrix: ONE launch -- the row kernel writes the
+    values in nempc_jac_structure order itself (fixed-shape kernel on the compiled shape, cooperative kernel elsewhere); no
+    tile round trip, no assembly launch (reference: dense (m, n) to cyipopt, optimizer/ipopt.py:88-96)."""
     d, W, b = load_case(name)
     for dtype in (torch.float64, torch.float32):
         eng = _engine(d, W, b, dtype, "auto")
+        eng.eval_numpy(d["Z"], d["X0"], want=("f", "grad", "g", "jac_dense"))
+        k_dense = eng.last_row_kernel
         res = eng.eval_numpy(d["Z"], d["X0"], want=("f", "grad", "g", "jac_sparse"))
+        # wherever the dense contract is one launch (fixed-shape or cooperative kernel), the sparse one is too; shapes only
+        # the wave-per-tile kernel serves (fp64 3 x 128: the slices do not fit registers) keep the row + assembly launches
+        expect = {"rows_coopfx_kernel": "rows_coopfx_kernel+sparse", "rows_coop_kernel+dense": "rows_coop_kernel+sparse"}
+        if k_dense in expect:
+            assert eng.last_row_kernel == expect[k_dense], (name, dtype)
+        if name in ("c2_discret", "c5_box", "c1_discret", "c3_rk4") and not (name == "c3_rk4" and dtype == torch.float64):
+            assert k_dense in expect, (name, dtype, k_dense)
         rows, cols = eng.jac_structure()
+        # every output subset of the same launch, bit for bit: values alone, with the compact tiles, with the dense matrix
+        # (the dense request takes the assembly path: the band values are then gathered from the tiles)
+        alone = eng.eval_numpy(d["Z"], d["X0"], want=("jac_sparse",))
+        assert np.array_equal(alone["jac_sparse"], res["jac_sparse"])
+        wt = eng.eval_numpy(d["Z"], d["X0"], want=("g", "jac_sparse", "jac_tiles"))
+        assert np.array_equal(wt["jac_sparse"], res["jac_sparse"]) and np.array_equal(wt["g"], res["g"])
+        full = eng.eval_numpy(d["Z"], d["X0"], want=ALL)
+        assert np.array_equal(res["jac_sparse"], full["jac_sparse"]) and np.array_equal(res["f"], full["f"])
+        assert np.array_equal(wt["jac_tiles"], full["jac_tiles"])
+        assert np.array_equal(res["jac_sparse"], full["jac_dense"][:, rows, cols])
         if dtype == torch.float64:
             np.testing.assert_allclose(res["f"], d["f"], **F64)
             np.testing.assert_allclose(res["grad"], d["grad"], **F64)
             np.testing.assert_allclose(res["g"], d["g"], **F64)
             np.testing.assert_allclose(res["jac_sparse"], d["jac"][:, rows, cols], **F64)
-            full = eng.eval_numpy(d["Z"], d["X0"], want=ALL)
-            assert np.array_equal(res["jac_sparse"], full["jac_sparse"]) and np.array_equal(res["f"], full["f"])
         else:
             _f32_close(res["jac_sparse"], d["jac"][:, rows, cols], f"{name}/jac_sparse")
             _f32_close(res["f"], d["f"], f"{name}/f")
