@@ -125,7 +125,12 @@ int nempc_set_weights(nempc_handle h, const double* const* W, const double* cons
 /* objective family standing in for JAXObjectifFunc (objective/jax.py:16-57):
  *   f = sum_t (x_t-xref_t)^T Q (x_t-xref_t) + (u_t-uref_t)^T R (u_t-uref_t) + cx_t.x_t + cu_t.u_t
  * Q (nx,nx), R (nu,nu), xref/cx (H,nx), uref/cu (H,nu); any pointer may be NULL (= zeros;
- * Q NULL = identity, R NULL = 0.1*identity, the SURVEY 8(d) defaults). Host doubles. */
+ * Q NULL = identity, R NULL = 0.1*identity, the SURVEY 8(d) defaults). Host doubles.
+ * Ordering: the values overwrite the handle's parameter block in place with a copy on the NULL stream (no re-allocation, no
+ * device synchronisation -- a tracking MPC moves xref / uref every step).  The NULL stream orders the copy against work on
+ * blocking streams only: a caller that queues nempc_eval / nempc_hess / nempc_solve on a NON-BLOCKING stream must
+ * nempc_sync that stream before changing the objective (same for nempc_set_terminal_weight), or the queued kernels may
+ * read a half-updated block. */
 int nempc_set_objective(nempc_handle h, const double* Q, const double* R, const double* xref,
                         const double* uref, const double* cx, const double* cu);
 

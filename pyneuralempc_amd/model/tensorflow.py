@@ -23,15 +23,60 @@ def _activation_name(layer):
     return getattr(act, "__name__", None) or getattr(act, "name", None) or str(act)
 
 
+# layers that are the identity at inference time (what the reference's model.predict evaluates, model/tensorflow.py:49-51)
+_IDENTITY_LAYERS = {"InputLayer", "Dropout", "AlphaDropout", "GaussianDropout", "GaussianNoise", "ActivityRegularization",
+                    "Flatten"}
+
+
+def _standalone_activation(layer, i):
+    """Keras activation name of a parameter-less activation layer (`Activation('tanh')`, `ReLU()`, `ELU()`, `Softplus`-like
+    wrappers), or a loud refusal: such a layer must never be dropped silently -- the network would be evaluated as a
+    different function."""
+    kind = type(layer).__name__
+    if kind == "Activation":
+        return _activation_name(layer)
+    if kind == "ReLU":
+        if (getattr(layer, "max_value", None) is not None or float(getattr(layer, "negative_slope", 0.0) or 0.0) != 0.0
+                or float(getattr(layer, "threshold", 0.0) or 0.0) != 0.0):
+            raise NotImplementedError(f"layer {i}: ReLU with max_value / negative_slope / threshold is unsupported on the device path")
+        return "relu"
+    if kind == "ELU":
+        if float(getattr(layer, "alpha", 1.0)) != 1.0:
+            raise NotImplementedError(f"layer {i}: elu with alpha != 1 is unsupported on the device path")
+        return "elu"
+    raise NotImplementedError(f"layer {i}: parameter-less layer '{kind}' is unsupported on the device path (it would be "
+                              "dropped from the network); supported: Dense, Activation, ReLU, ELU(alpha=1) and the "
+                              "inference-identity layers " + ", ".join(sorted(_IDENTITY_LAYERS)))
+
+
 def extract_dense_stack(keras_model):
     """-> (weights, biases, activations) from a duck-typed Keras Sequential/Functional model of Dense layers;
-    activations holds one Keras activation name per dense layer (what Dense(..., activation=...) was given)."""
-    layers = [l for l in getattr(keras_model, "layers", []) if len(l.get_weights()) > 0]
-    if not layers:
-        raise ValueError("The provided model has no parameterised layers")
+    activations holds one Keras activation name per dense layer.  EVERY layer is walked in order: a stand-alone activation
+    layer (`Dense(64)` + `Activation('tanh')`, `ReLU()`, `ELU()`) is folded into the linear Dense in front of it, layers that
+    are the identity at inference (InputLayer, Dropout, ...) are skipped, anything else is refused -- the reference evaluates
+    the Keras model as built (model/tensorflow.py:49-51), so no layer may be ignored."""
+    all_layers = list(getattr(keras_model, "layers", []))
     weights, biases, activations = [], [], []
-    for i, layer in enumerate(layers):
+    for i, layer in enumerate(all_layers):
         params = layer.get_weights()
+        if len(params) == 0:
+            if type(layer).__name__ in _IDENTITY_LAYERS:
+                continue
+            name = _standalone_activation(layer, i)
+            if name == "linear":
+                continue
+            if not activations:
+                raise NotImplementedError(f"layer {i}: an activation layer in front of the first Dense layer is unsupported")
+            if activations[-1] != "linear":
+                raise NotImplementedError(f"layer {i}: activation '{name}' on top of a Dense layer that already applies "
+                                          f"'{activations[-1]}' is unsupported on the device path")
+            if name not in _lib.ACTIVATION_IDS:
+                raise NotImplementedError(f"layer {i}: activation '{name}' unsupported on the device path (supported: "
+                                          f"{', '.join(_lib.ACTIVATION_IDS)})")
+            activations[-1] = name
+            continue
+        if len(params) == 1 and np.ndim(params[0]) == 2:          # Dense(use_bias=False)
+            params = [params[0], np.zeros(np.shape(params[0])[1])]
         if len(params) != 2 or np.ndim(params[0]) != 2 or np.ndim(params[1]) != 1:
             raise NotImplementedError("Only Dense layers (kernel, bias) are supported on the device path")
         name = _activation_name(layer)
@@ -43,6 +88,8 @@ def extract_dense_stack(keras_model):
         weights.append(np.asarray(params[0], dtype=np.float64))
         biases.append(np.asarray(params[1], dtype=np.float64))
         activations.append(name)
+    if not weights:
+        raise ValueError("The provided model has no parameterised layers")
     return weights, biases, activations
 
 

@@ -158,15 +158,70 @@ def fused_evaluator(integrator, objective, box):
     return ent[2]
 
 
+class _CoherentHostBuffer:
+    """Host memory the device addresses directly AND that is coherent with the host while a kernel runs: hipHostMalloc with
+    hipHostMallocCoherent | hipHostMallocMapped, asked for explicitly (what a default hipHostMalloc -- torch's
+    pin_memory=True -- gives depends on HIP_HOST_COHERENT).  Fine-grained pages are mapped uncached on the device: a kernel's
+    stores are not held in the GPU's L2 for an end-of-kernel write-back, they leave for host memory as PCIe posted writes when
+    they are issued.  `array(dtype)` is a NumPy view of the whole buffer; `ptr` is valid on host and device."""
+
+    _hip = None
+    COHERENT, MAPPED = 0x40000000, 0x2          # hipHostMallocCoherent, hipHostMallocMapped (hip_runtime_api.h)
+
+    def __init__(self, nbytes):
+        import ctypes
+        if _CoherentHostBuffer._hip is None:
+            hip = ctypes.CDLL("libamdhip64.so")
+            hip.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+            hip.hipHostMalloc.restype = ctypes.c_int
+            hip.hipHostFree.argtypes = [ctypes.c_void_p]
+            hip.hipHostFree.restype = ctypes.c_int
+            _CoherentHostBuffer._hip = hip
+        self.nbytes = max(int(nbytes), 64)
+        p = ctypes.c_void_p()
+        rc = _CoherentHostBuffer._hip.hipHostMalloc(ctypes.byref(p), self.nbytes, self.COHERENT | self.MAPPED)
+        if rc != 0 or not p.value:
+            raise RuntimeError(f"hipHostMalloc(coherent, {self.nbytes} bytes) failed with HIP error {rc}")
+        self.ptr = p.value
+        self._raw = (ctypes.c_ubyte * self.nbytes).from_address(self.ptr)
+        self.array(np.uint8)[:] = 0
+
+    def array(self, dtype):
+        return np.frombuffer(self._raw, dtype=dtype)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                self._raw = None
+                _CoherentHostBuffer._hip.hipHostFree(self.ptr)
+                self.ptr = None
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 class _StreamWaiter:
     """Wait for a stream's work from the host without a stream synchronisation: the stream writes a sequence number into a
-    pinned word after the queued kernel (hipStreamWriteValue32, a packet of the command processor), the host spins on that
-    word.  2.9 us less per B = 1 callback than stream.synchronize() (26.8 -> 24.0 us, tools/host_sync_probe.py).  A spin that
-    does not end within ~a second falls back to the synchronisation, which surfaces a device fault as an error; a HIP
-    runtime without the entry point uses the synchronisation from the start."""
+    word of coherent host memory after the queued kernel (hipStreamWriteValue32), the host spins on that word.  2.9 us less
+    per B = 1 callback than stream.synchronize() (26.8 -> 24.0 us, tools/host_sync_probe.py).
+
+    Why the kernel's results are visible when the word is -- the contract this relies on, piece by piece:
+    (1) the result buffer and the word are `_CoherentHostBuffer`s: fine-grained host memory, uncached on the device, so the
+        kernel's stores do not wait in L2 for the end-of-kernel release; they travel to host memory as posted writes in the
+        order the memory system issues them and are complete before the kernel's completion is signalled (the dispatch
+        packet's release fence is system scope for fine-grained memory);
+    (2) hipStreamWriteValue32 is stream-ordered: "the write is performed after all earlier commands on the stream have
+        completed" (HIP API); it is a packet of its own behind the kernel's, with the barrier bit, so its write is issued
+        after (1)'s writes have been acknowledged;
+    (3) the host reads the word, THEN the results (x86 loads are not reordered with older loads; NumPy copies out after the
+        spin returns).
+    `tests/test_gpu_plugins.py::test_waiter_path_matches_the_synchronised_path_bit_for_bit` is the backstop: a poisoned result
+    buffer before every call, alternating inputs, a few hundred callbacks against stream.synchronize().
+    A spin that does not end within a second falls back to the synchronisation, which surfaces a device fault as an error; a
+    HIP runtime without the entry point uses the synchronisation from the start."""
 
     _fn = None
     _probed = False
+    SPIN_SECONDS = 1.0
 
     def __init__(self, stream):
         import ctypes
@@ -184,9 +239,9 @@ class _StreamWaiter:
             except (OSError, AttributeError):
                 _StreamWaiter._fn = None
         if _StreamWaiter._fn is not None:
-            self.flag = torch.zeros(16, dtype=torch.int32, pin_memory=True)
-            self.word = self.flag.numpy()
-            self.fptr = ctypes.c_void_p(self.flag.data_ptr())
+            self.flag = _CoherentHostBuffer(64)
+            self.word = self.flag.array(np.int32)
+            self.fptr = ctypes.c_void_p(self.flag.ptr)
             self.sptr = ctypes.c_void_p(stream.cuda_stream)
 
     def wait(self):
@@ -199,9 +254,17 @@ class _StreamWaiter:
             self.stream.synchronize()
             return
         word, seq = self.word, self.seq
-        for _ in range(4000000):
-            if word[0] == seq:
-                return
+        import time
+        deadline = None
+        while True:
+            for _ in range(2048):
+                if word[0] == seq:
+                    return
+            now = time.perf_counter()
+            if deadline is None:
+                deadline = now + self.SPIN_SECONDS
+            elif now > deadline:
+                break
         self.stream.synchronize()               # (a device fault ends here as an exception instead of an endless spin)
 
 
@@ -259,16 +322,18 @@ class _FusedEvaluator:
             return st
         n, m, nx = eng.n, eng.m, eng.nx
         nj = eng.nnz_jac if sparse else m * n
-        hin = torch.empty(n + nx, dtype=eng.dtype, pin_memory=True)
-        hout = torch.zeros(1 + n + m + nj, dtype=eng.dtype, pin_memory=True)
-        esz = hin.element_size()
+        npdt = np.float64 if eng.dtype == torch.float64 else np.float32
+        esz = np.dtype(npdt).itemsize
+        hin = _CoherentHostBuffer((n + nx) * esz)
+        hout = _CoherentHostBuffer((1 + n + m + nj) * esz)
         vp = ctypes.c_void_p
         stream = torch.cuda.Stream(eng.device)
-        outp = hout.data_ptr()
-        st = dict(key=key, hin=hin, hout=hout, zin=hin.numpy()[:n], xin=hin.numpy()[n:], out=hout.numpy(), stream=stream,
+        outp = hout.ptr
+        st = dict(key=key, hin=hin, hout=hout, zin=hin.array(npdt)[:n], xin=hin.array(npdt)[n:n + nx],
+                  out=hout.array(npdt)[:1 + n + m + nj], stream=stream,
                   waiter=_StreamWaiter(stream),
                   n=n, m=m, nj=nj, sparse=bool(sparse),
-                  args=(eng._handle, 1, vp(hin.data_ptr()), vp(hin.data_ptr() + n * esz), vp(outp), vp(outp + esz),
+                  args=(eng._handle, 1, vp(hin.ptr), vp(hin.ptr + n * esz), vp(outp), vp(outp + esz),
                         vp(outp + (1 + n) * esz), None if sparse else vp(outp + (1 + n + m) * esz), None,
                         vp(outp + (1 + n + m) * esz) if sparse else None, vp(stream.cuda_stream)))
         self._fast_state[bool(sparse)] = st
@@ -305,15 +370,17 @@ class _FusedEvaluator:
         key = (eng.n, eng.m, eng.nnz_hess, eng._handle.value)
         if hs is None or hs["key"] != key:
             n, m, nx, nh = eng.n, eng.m, eng.nx, eng.nnz_hess
-            hin = torch.empty(n + nx + m + 1, dtype=eng.dtype, pin_memory=True)
-            hout = torch.zeros(nh, dtype=eng.dtype, pin_memory=True)
-            esz = hin.element_size()
+            npdt = np.float64 if eng.dtype == torch.float64 else np.float32
+            esz = np.dtype(npdt).itemsize
+            hin = _CoherentHostBuffer((n + nx + m + 1) * esz)
+            hout = _CoherentHostBuffer(nh * esz)
             vp = ctypes.c_void_p
             stream = torch.cuda.Stream(eng.device)
-            base = hin.data_ptr()
-            hs = dict(key=key, hin=hin, hout=hout, inp=hin.numpy(), out=hout.numpy(), stream=stream, waiter=_StreamWaiter(stream),
+            base = hin.ptr
+            hs = dict(key=key, hin=hin, hout=hout, inp=hin.array(npdt)[:n + nx + m + 1], out=hout.array(npdt)[:nh], stream=stream,
+                      waiter=_StreamWaiter(stream),
                       args=(eng._handle, 1, vp(base), vp(base + n * esz), vp(base + (n + nx) * esz),
-                            vp(base + (n + nx + m) * esz), vp(hout.data_ptr()), None, None, vp(stream.cuda_stream)))
+                            vp(base + (n + nx + m) * esz), vp(hout.ptr), None, None, vp(stream.cuda_stream)))
             self._hess_state = hs
         from .. import _lib
         n, m, nx = eng.n, eng.m, eng.nx

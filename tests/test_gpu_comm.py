@@ -138,3 +138,70 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     assert out["batched_solver"]["gathered_rows"] == 128
     assert out["jacobian_max_abs_err_vs_cpu"] < 1e-12
     assert out["roofline"]["frac"] > 0 and "FUSE = true" in out["roofline"]["kernel"]
+
+
+_TWO_RANK_WORKER = r'''
+import os, sys, json
+rank, world, port, repo = int(sys.argv[1]), 2, sys.argv[2], sys.argv[3]
+sys.path.insert(0, repo)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank))
+import numpy as np, torch
+import torch.distributed as dist
+from oracle import nempc_oracle as orc
+from pyneuralempc_amd import CallbackEngine
+from pyneuralempc_amd.parallel import init_u0_comm
+torch.cuda.set_device(rank)
+dist.init_process_group("gloo", rank=rank, world_size=world)          # bootstrap + the reference answer; the gather under test is RCCL
+net = orc.MLP.random(3, [32, 32], 2, seed=3)
+rows = [37, 22]                                                        # ragged shards: slots pad to the largest
+eng = CallbackEngine(net.W, net.b, 6, 2, 1, dtype=torch.float64, device=f"cuda:{rank}", max_batch=64)
+init_u0_comm(eng)                                                      # nempc_comm_unique_id on rank 0, broadcast, nempc_comm_init
+assert eng.comm == (2, rank)
+ok = True
+for rep in range(3):
+    u0 = torch.full((rows[rank], 1), float(10 * rank + rep), dtype=torch.float64, device=f"cuda:{rank}") + \
+        torch.arange(rows[rank], dtype=torch.float64, device=f"cuda:{rank}")[:, None] / 100
+    got = eng.allgather_u0(u0=u0, rows_per_rank=max(rows))             # in-place ncclAllGather of the padded slots
+    torch.cuda.synchronize()
+    parts = [torch.zeros(max(rows), 1, dtype=torch.float64) for _ in range(world)]
+    mine = torch.zeros(max(rows), 1, dtype=torch.float64)
+    mine[:rows[rank]] = u0.cpu()
+    dist.all_gather(parts, mine)                                       # gloo: the answer
+    ok = ok and torch.equal(got.cpu(), torch.cat(parts))
+Z = torch.randn(rows[0], eng.n, dtype=torch.float64, device=f"cuda:{rank}")
+g2 = eng.allgather_u0(Z=Z)
+torch.cuda.synchronize()
+ok = ok and g2.shape == (2 * rows[0], 1) and torch.equal(g2[rank * rows[0]:(rank + 1) * rows[0]], Z[:, 12:13])
+print(json.dumps({"rank": rank, "ok": bool(ok)}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_rccl_allgather_on_two_gpus(tmp_path):
+    """nempc_comm_init + nempc_allgather_u0 over RCCL with TWO ranks, ragged shards, against gloo's answer -- on a box that
+    has two GPUs (one process per GPU, started before this test touches a second device; skipped on the one-GPU boxes the
+    round's own runs get).  The path `bench.py --gpus N` takes for configs[3]."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    script = tmp_path / "two_rank_worker.py"
+    script.write_text(_TWO_RANK_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), port, repo], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}: {se[-2000:]}"
+        line = [ln for ln in so.splitlines() if ln.startswith("{")][-1]
+        assert json.loads(line) == {"rank": r, "ok": True}

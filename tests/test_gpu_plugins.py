@@ -309,6 +309,65 @@ def test_b1_fast_path_and_sparse_view_match_the_engine():
         np.testing.assert_allclose(pb.hessian(z, d["lam"][i], float(d["sigma"][i])), d["hdense"][i][hr, hc], rtol=1e-11, atol=1e-12)
 
 
+def test_waiter_path_matches_the_synchronised_path_bit_for_bit():
+    """The B=1 callback path reads its results from coherent host memory as soon as the stream's write-value word flips
+    (optimizer/base.py:_StreamWaiter; the visibility contract is stated there).  Backstop of that argument: a few hundred
+    callbacks of alternating iterates, dense and sparse view and the Hessian, the result buffer poisoned before every call,
+    against the same call followed by stream.synchronize()."""
+    import pyneuralempc_amd as nEMPC
+    from pyneuralempc_amd.optimizer.base import _StreamWaiter
+    from pyneuralempc_amd.optimizer.ipopt import IpoptProblem
+    d, W, b = load_case("c5_box")
+    H, nx, nu = int(d["H"]), int(d["nx"]), int(d["nu"])
+    model = nEMPC.model.MLPModel(W, b, nx, nu, device="cuda:0")
+    integ = nEMPC.integrator.discret.DiscretIntegrator(model, H)
+    obj = nEMPC.objective.QuadraticObjective(Q=d["Q"], R=d["R"], xref=d["xref"], uref=d["uref"], cu=d["cu"], device="cuda:0")
+    box = nEMPC.constraints.BoxStateConstraint(d["box_lo"], d["box_hi"])
+    pb = IpoptProblem(d["X0"][0], obj, [box], integ)
+    fe = pb._fused
+    rng = np.random.default_rng(0)
+    iterates = [d["Z"][i % d["Z"].shape[0]] + 0.01 * rng.normal(size=d["Z"].shape[1]) for i in range(6)]
+    x0s = [d["X0"][i % d["X0"].shape[0]] for i in range(6)]
+    lam = rng.normal(size=fe.engine.m)
+
+    class Sync:                                     # the reference behaviour: drain the stream
+        def __init__(self, stream): self.stream = stream
+        def wait(self): self.stream.synchronize()
+
+    def run(sparse, use_sync, reps):
+        out = []
+        st = fe._fast(sparse)
+        keep = st["waiter"]
+        assert isinstance(keep, _StreamWaiter) and keep.flag is not None     # the write-value path is the one under test
+        if use_sync:
+            st["waiter"] = Sync(st["stream"])
+        try:
+            for k in range(reps):
+                st["out"][:] = np.nan                # poison: a result read before it has landed cannot pass
+                fe._key = None
+                v = fe.evaluate(iterates[k % 6], x0s[k % 6], sparse=sparse)
+                out.append(np.concatenate([[v["f"]], v["grad"], v["g"], np.ravel(v["jac_sparse" if sparse else "jac_dense"])]))
+        finally:
+            st["waiter"] = keep
+        return out
+    for sparse in (False, True):
+        ref = run(sparse, True, 12)
+        got = run(sparse, False, 300)
+        for k, v in enumerate(got):
+            assert not np.isnan(v).any()
+            assert np.array_equal(v, ref[k % 6]), (sparse, k)
+    hs_ref = None
+    for k in range(200):
+        if fe._hess_state is not None:
+            fe._hess_state["out"][:] = np.nan
+        hv = fe.hessian_values(iterates[k % 6], x0s[k % 6], lam, 1.0 + (k % 6))
+        assert not np.isnan(hv).any()
+        if k < 6:
+            hs_ref = (hs_ref or []) + [hv]
+        else:
+            assert np.array_equal(hv, hs_ref[k % 6]), k
+
+
 @pytest.mark.parametrize("kind,DT", [("discret", 1.0), ("unity", 1.0), ("rk4", 0.2)])
 def test_torch_model_matches_the_kernel_path(kind, DT):
     """The same network expressed both ways -- MLPModel (HIP kernels) and model.TorchModel (a torch callable on the

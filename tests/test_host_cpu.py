@@ -134,6 +134,53 @@ def test_keras_adapter_validation_without_device():
     none_act = Fake([Layer(np.ones((3, 2)), np.zeros(2), None)], 3, 2)
     assert KerasTFModel(none_act, x_dim=2, u_dim=1).activations == ["linear"]
 
+    # parameter-less layers are never dropped silently: Dense(8) + Activation('tanh') / ReLU() / ELU() fold into the linear
+    # Dense in front of them, inference-identity layers are skipped, anything else is refused
+    class Activation:
+        def __init__(self, act): self.activation = act
+        def get_weights(self): return []
+
+    class ReLU:
+        max_value, negative_slope, threshold = None, 0.0, 0.0
+        def get_weights(self): return []
+
+    class ELU:
+        alpha = 1.0
+        def get_weights(self): return []
+
+    class Dropout:
+        def get_weights(self): return []
+
+    class InputLayer(Dropout):
+        pass
+
+    class LeakyReLU(Dropout):
+        pass
+
+    split = Fake([InputLayer(), Layer(np.ones((3, 8)), np.zeros(8), linear), Activation(tanh), Dropout(),
+                  Layer(np.ones((8, 8)), np.zeros(8), None), ReLU(), Layer(np.ones((8, 8)), np.zeros(8), "linear"), ELU(),
+                  Layer(np.ones((8, 2)), np.zeros(2), linear), Activation("linear")], 3, 2)
+    W, b, acts = extract_dense_stack(split)
+    assert len(W) == 4 and acts == ["tanh", "relu", "elu", "linear"]
+    assert KerasTFModel(split, x_dim=2, u_dim=1).activations == acts
+    with pytest.raises(NotImplementedError, match="LeakyReLU"):
+        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), linear), LeakyReLU(),
+                                  Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
+    with pytest.raises(NotImplementedError, match="already applies"):
+        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), tanh), Activation(relu),
+                                  Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
+    leaky = ReLU()
+    leaky.negative_slope = 0.1
+    with pytest.raises(NotImplementedError, match="negative_slope"):
+        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), linear), leaky,
+                                  Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
+
+    class NoBias:
+        activation = "tanh"
+        def get_weights(self): return [np.ones((3, 8))]
+    W, b, acts = extract_dense_stack(Fake([NoBias(), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
+    assert np.array_equal(b[0], np.zeros(8)) and acts == ["tanh", "linear"]
+
     def swish(x): return x
     bad = Fake([Layer(np.ones((3, 8)), np.zeros(8), swish), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2)
     with pytest.raises(NotImplementedError, match="activation 'swish'"):
