@@ -262,3 +262,74 @@ def test_launch_geometry_follows_the_device_cu_count(num_cus, monkeypatch):
                     for k in DEFAULT:
                         assert torch.equal(fused[k], ref[key][1][k]), (key, k)
                     assert torch.equal(hv, ref[key][2]), key
+
+
+@pytest.mark.parametrize("dtype,hidden", [(torch.float64, [30, 30]), (torch.float32, [30, 30]), (torch.float32, [64, 64])])
+def test_compiled_shape_table_beyond_the_baseline_shape(dtype, hidden):
+    """The table of compiled fixed shapes (csrc/kernels_mfma_typed.inc, FxTable): the reference's own example network
+    3 -> 30 -> 30 -> 2 (examples/lotka_volterra/run.py:64-98, nn_model.h5) in both precisions and 2/1 2 x 64 in fp32 take
+    rows_coopfx_kernel / rowhess_coopfx_kernel -- every output subset of the one-launch evaluation (dense, sparse, tiles,
+    forward only), box rows, ragged batches, the Hessian callbacks and the batched solver -- against the oracle."""
+    from pyneuralempc_amd import CallbackEngine
+    nx, nu = 2, 1
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=11)
+    f64 = dtype == torch.float64
+    tol = dict(rtol=1e-12, atol=1e-12) if f64 else dict(rtol=2e-4, atol=2e-4)
+    # (fp32: the dense rows leave as 16-byte vectors of four, so the one-launch dense evaluation needs n = 3 H divisible by 4)
+    for H, B, box in ((10 if f64 else 8, 1, None), (10 if f64 else 12, 37, None), (20, 300, (-1.5, 1.5)), (12, 1024, None)):
+        prob = orc.Problem(net, H, nx, nu, orc.DISCRET, Q=np.array([[1.0, 0.1], [0.1, 0.5]]), R=np.array([[0.2]]),
+                           cx=np.full((H, nx), 0.03), cu=np.full((H, nu), -0.1), box=box)
+        eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator="discret", dtype=dtype, device="cuda:0", max_batch=B)
+        eng.set_objective(Q=[[1.0, 0.1], [0.1, 0.5]], R=[[0.2]], cx=0.03, cu=-0.1)
+        if box:
+            eng.set_box_rows(*box)
+        Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=H + B)
+        Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+        sl = slice(0, min(B, 24))
+        f, grad, g, J = prob.eval_batch(Zh[sl], X0h[sl])
+        res = {k: v.to("cpu", torch.float64).numpy() for k, v in eng.eval(Z, X0, DEFAULT).items()}
+        assert eng.last_row_kernel == "rows_coopfx_kernel", (H, B)
+        for k, ref in (("f", f), ("grad", grad), ("g", g), ("jac_dense", J)):
+            np.testing.assert_allclose(res[k][sl], ref, **tol, err_msg=f"{k} H={H} B={B}")
+        rows, cols = eng.jac_structure()
+        mask = np.zeros((eng.m, eng.n), dtype=bool)
+        mask[rows, cols] = True
+        assert np.all(res["jac_dense"][:, ~mask] == 0.0)
+        sp = {k: v.to("cpu", torch.float64).numpy() for k, v in eng.eval(Z, X0, ("f", "grad", "g", "jac_sparse")).items()}
+        assert eng.last_row_kernel == "rows_coopfx_kernel+sparse"
+        assert np.array_equal(sp["jac_sparse"], res["jac_dense"][:, rows, cols]) and np.array_equal(sp["g"], res["g"])
+        ct = {k: v.to("cpu", torch.float64).numpy() for k, v in eng.eval(Z, X0, ("f", "g", "jac_tiles")).items()}
+        assert eng.last_row_kernel == "rows_coopfx_kernel" and np.array_equal(ct["f"], res["f"])
+        for i in range(min(B, 3)):
+            _, A, Bt = prob.tiles_AB(Zh[i], X0h[i])
+            np.testing.assert_allclose(ct["jac_tiles"][i][:, :, :nx], A, **tol)
+            np.testing.assert_allclose(ct["jac_tiles"][i][:, :, nx:], Bt, **tol)
+        fo = eng.eval(Z, X0, ("f", "g"))
+        assert np.array_equal(fo["g"].to("cpu", torch.float64).numpy(), res["g"])
+        # Hessian callbacks
+        rng = np.random.default_rng(1)
+        lam, sig = rng.normal(size=(B, eng.m)), rng.uniform(0.5, 1.5, size=B)
+        hv = eng.hess(Z, X0, eng.to_device(lam), eng.to_device(sig))["hvals"].to("cpu", torch.float64).numpy()
+        assert eng.last_hess_kernel == "rowhess_coopfx_kernel"
+        wgt = rng.uniform(0.2, 1.5, size=(B, H * nx))
+        gv = eng.hess_gn(Z, X0, eng.to_device(wgt), eng.to_device(sig))["hvals"].to("cpu", torch.float64).numpy()
+        for i in range(min(B, 6)):
+            ref = prob.hessian_values(Zh[i], X0h[i], lam[i], sig[i])
+            np.testing.assert_allclose(hv[i], ref, rtol=0, atol=(1e-10 if f64 else 2e-3) * max(1.0, np.abs(ref).max()))
+            refg = prob.gauss_newton_values(Zh[i], X0h[i], wgt[i], sig[i])
+            np.testing.assert_allclose(gv[i], refg, rtol=0, atol=(1e-10 if f64 else 2e-3) * max(1.0, np.abs(refg).max()))
+    # the batched solver on this shape (its trial-point launch is the fixed-shape Hessian kernel's EV variant)
+    H, B = 10, 64
+    net2 = orc.MLP.random(nx + nu, hidden, nx, seed=11)
+    net2.W[-1] *= 0.2
+    net2.b[-1] *= 0.2
+    prob = orc.Problem(net2, H, nx, nu, orc.DISCRET, Q=np.eye(nx), R=0.1 * np.eye(nu))
+    eng = CallbackEngine(net2.W, net2.b, H, nx, nu, integrator="discret", dtype=dtype, device="cuda:0", max_batch=B)
+    eng.set_objective(Q=np.eye(nx), R=0.1 * np.eye(nu))
+    X0 = np.random.default_rng(2).uniform(-0.5, 0.5, size=(B, nx))
+    lb = np.concatenate([np.full(H * nx, -3.0), np.full(H * nu, -0.5)])
+    Zs, status, iters = eng.solve(eng.to_device(X0), lb=lb, ub=-lb, max_iter=200)
+    Zs, status = Zs.to("cpu", torch.float64).numpy(), status.cpu().numpy()
+    assert (status == 0).mean() >= 0.9
+    for i in np.nonzero(status == 0)[0][:16]:
+        assert np.abs(prob.constraints(Zs[i], X0[i])).max() < (1e-6 if f64 else 2e-3)
