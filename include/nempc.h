@@ -84,6 +84,11 @@ extern "C" {
                                and a linear output layer: CU-cooperative kernel when the weight slices fit the
                                registers and the inputs <= 16, else wave-per-tile */
 #define NEMPC_KERNEL_MFMA_TILE 3 /* force the wave-per-tile matrix-core kernel (A/B measurements) */
+#define NEMPC_KERNEL_LAYERED 4 /* layer-at-a-time matrix-core path: one GEMM launch per dense layer over all B*H rows, any
+                                  activation per layer (output layer included), hidden widths <= 1024, up to 8 layers,
+                                  w*(nx+nu) <= 32, nx <= 16 -- what any feed-forward Keras model the reference wraps
+                                  (model/tensorflow.py:8-29) that NEMPC_KERNEL_MFMA does not take runs on under AUTO.
+                                  Rows only: the Lagrangian Hessian of such a model stays on the generic kernel */
 
 typedef struct nempc_handle_s* nempc_handle;
 
@@ -279,14 +284,16 @@ int nempc_plan_grid(int32_t ntiles, int32_t num_cus, int32_t per_cu, int32_t* gr
                     int32_t* tiles_rem);
 int nempc_num_cus(nempc_handle h);
 
-/* which row kernel the handle resolved to (NEMPC_KERNEL_VALU | NEMPC_KERNEL_MFMA | NEMPC_KERNEL_MFMA_TILE) */
+/* which row kernel the handle resolved to (NEMPC_KERNEL_VALU | NEMPC_KERNEL_MFMA | NEMPC_KERNEL_MFMA_TILE |
+ * NEMPC_KERNEL_LAYERED) */
 int nempc_kernel_variant(nempc_handle h);
 
 /* row kernel the handle's most recent evaluation actually launched: 1 generic (rows_valu_kernel),
  * 2 cooperative matrix-core (rows_coop_kernel), 3 wave-per-tile matrix-core (rows_mfma_kernel), 4 cooperative
  * matrix-core compiled for the problem's shape (rows_coopfx_kernel), 5 rows_coop_kernel writing the dense Jacobian
  * rows itself (no assembly launch), 6 / 7 rows_coopfx_kernel / rows_coop_kernel writing the band-pattern values of the
- * sparse contract itself (no tile round trip, no assembly launch); 0 = none yet */
+ * sparse contract itself (no tile round trip, no assembly launch), 8 the layer-at-a-time GEMM pipeline
+ * (NEMPC_KERNEL_LAYERED); 0 = none yet */
 int nempc_last_row_kernel(nempc_handle h);
 
 /* network kernel the handle's most recent nempc_hess (or solver iteration) launched for the Lagrangian blocks: 1 generic

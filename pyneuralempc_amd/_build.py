@@ -29,7 +29,8 @@ LIB = os.path.join(PKG, "libnempc.so")
 _MFMA_ACTS = ["relu", "sigmoid", "softplus", "elu"]
 SOURCES = (["kernels_mfma_f64.hip", "kernels_mfma_f32.hip", "solver.hip"] +
            [f"kernels_mfma_{t}_{a}.hip" for t in ("f64", "f32") for a in _MFMA_ACTS] +
-           ["nempc_api.hip", "kernels_valu.hip", "kernels_post.hip", "kernels_mfma.hip", "kernels_rk4hess.hip", "comm.hip"])
+           ["nempc_api.hip", "kernels_valu.hip", "kernels_layered.hip", "kernels_post.hip", "kernels_mfma.hip", "kernels_rk4hess.hip",
+            "comm.hip"])
 ARCH = "gfx950"
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off",
          "-I", os.path.join(REPO, "include"), "-I", CSRC]

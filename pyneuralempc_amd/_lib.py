@@ -12,8 +12,9 @@ COMM_ID_BYTES = 128
 MAX_LAYERS = 8
 F64, F32 = 0, 1
 DISCRET, UNITY, RK4 = 0, 1, 2
-KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_TILE = 0, 1, 2, 3
-KERNEL_NAMES = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA, "mfma_tile": KERNEL_MFMA_TILE}
+KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_MFMA_TILE, KERNEL_LAYERED = 0, 1, 2, 3, 4
+KERNEL_NAMES = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA, "mfma_tile": KERNEL_MFMA_TILE,
+                "layered": KERNEL_LAYERED}
 INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
 # NEMPC_ACT_*: the activation of a dense layer (names as Keras spells them)
 ACTIVATION_IDS = {"linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3, "softplus": 4, "elu": 5}

@@ -1,0 +1,446 @@
+// Layer-at-a-time matrix-core path (gfx950) for networks the register-resident kernels do not take: hidden widths up to
+// 1024, up to NEMPC_MAX_LAYERS dense layers, any activation per layer (the output layer included).
+//
+// The reference wraps ANY feed-forward Keras model (model/tensorflow.py:8-29,49-51) and differentiates it per row
+// (tensorflow.py:53-75).  The fused row kernels of this library keep a network's weight slices in registers, which ends at
+// three hidden layers of width 128 with one activation; everything else used to run on the thread-per-row kernel
+// (rows_valu_kernel: ~50x slower).  For those networks a dense layer over all B*H rows is a GEMM large enough to stand on
+// its own -- (B*H) x width x width -- so the network is walked one layer per launch:
+//
+//   forward   X_l = s_l(X_{l-1} W_l + b_l),  D_l = s_l'(z_l)                 one GEMM per layer, activation in the epilogue
+//   reverse   G_{L-2} = (W_{L-1} e_k s_{L-1}') . D_{L-2}                    seed: all nx cotangents side by side
+//             G_{l-1} = (G_l W_l^T) . D_{l-1}                               one GEMM per layer over nx * (B*H) columns
+//             J       = G_0 W_0^T                                           skinny: onto the nin inputs
+//   integrator algebra (discret.py:27,52-56 / unity.py:29 / rk4.py:69-80,147-159) per row, then the same g / compact-tile
+//   outputs as the row kernels; the dense / sparse / objective launches of nempc_eval follow unchanged.
+//
+// Layout: every activation matrix is stored FEATURE-MAJOR, X^T[feature][row] with a row stride Rp (multiple of 64): the
+// 16x16x4 matrix instructions compute Z^T (features x rows) = W^T (features x k) . X^T (k x rows), so a result register is
+// 16 consecutive rows of one feature -- a coalesced store -- and the next layer's operand tile is a plain 2-D sub-block of
+// X^T: no transposition anywhere, and the weights are used as nempc_set_weights left them (W row-major (in, out) forward,
+// W^T row-major (out, in) reverse: d_W / d_Wt of the generic kernel).
+//
+// GEMM kernel: 256 threads = 4 waves own a 64 (features) x 64 (rows) block, each wave 32 x 32 = 2 x 2 accumulator tiles;
+// K in chunks of 16 through double-buffered LDS (global loads of chunk c+1 in flight under the matrix instructions of
+// chunk c).  Per chunk and wave: 16 matrix instructions (1024 cycles in fp64), 16 ds_read, 8 global loads.  A v_mfma_f64
+// holds the vector pipe for its 64 cycles, so the bound is the matrix pipe; arbitrary M, N, K (edge tiles are
+// zero-filled on load and masked on store).
+#include <cstdlib>
+
+#include "activations.h"
+#include "kernels_mfma_impl.h"
+#include "nempc_internal.h"
+
+namespace nempc {
+
+namespace {
+
+constexpr int LG_BM = 64, LG_BN = 64, LG_BK = 16, LG_LD = 80;     // LD: padded tile row (spreads the four k-rows of a fragment over banks)
+
+enum { LG_FORWARD = 0, LG_REVERSE = 1 };
+
+template <typename T>
+__device__ __forceinline__ T lg_act_f(int code, T x) {
+    if (code == NEMPC_ACT_TANH) return Act<T, NEMPC_ACT_TANH>::f(x);     // the 24-slot tanh of the row kernels
+    return act_f<T>(code, x);
+}
+
+struct GemmArgs {
+    const void* A;      // A^T: (K, M) element (k, m) at A[k * lda + m]
+    const void* Bw;     // (K, N) row-major, element (k, n) at Bw[k * ldb + n]
+    void* C;            // C^T: (N, M), element (n, m) at C[n * ldc + m]
+    void* D;            // forward: s'(z) out, (N, M) like C;  reverse: s'(z) in, (N, Rmod) -- column m reads m % Rmod
+    const void* bias;   // forward only, (N)
+    long long lda, ldc, ldd;
+    int ldb, M, N, K, mode, act;
+    long long Rmod;     // reverse: rows per cotangent block (a multiple of LG_BM, so a block never straddles two)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
+    using Ops = MfmaOps<T>;
+    using V4 = typename Ops::V4;
+    __shared__ T Ws[2][LG_BK][LG_LD];
+    __shared__ T As[2][LG_BK][LG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int wn = w & 1, wm = w >> 1;
+    const long long m0 = (long long)blockIdx.x * LG_BM;
+    const int n0 = blockIdx.y * LG_BN;
+    const T* __restrict__ A = static_cast<const T*>(a.A);
+    const T* __restrict__ Bw = static_cast<const T*>(a.Bw);
+    const int K = a.K, N = a.N;
+    const long long M = a.M;
+
+    // loader: element e = tid + 256 u of a 16 x 64 tile -> (kk = e / 64, x = e % 64): 64 consecutive threads read one
+    // contiguous row piece of either operand
+    const int lx = tid & 63, lk = tid >> 6;      // kk = lk + 4 u
+    T rw[4], ra[4];
+    auto load_chunk = [&](int ch) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = ch * LG_BK + lk + 4 * u;
+            const bool kin = k < K;
+            rw[u] = (kin && n0 + lx < N) ? Bw[(size_t)k * a.ldb + n0 + lx] : T(0);
+            ra[u] = (kin && m0 + lx < M) ? A[(size_t)k * a.lda + m0 + lx] : T(0);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Ws[buf][lk + 4 * u][lx] = rw[u];
+            As[buf][lk + 4 * u][lx] = ra[u];
+        }
+    };
+
+    V4 acc[2][2];
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+        for (int rm = 0; rm < 2; ++rm) acc[fn][rm] = V4{T(0), T(0), T(0), T(0)};
+
+    const int nchunks = (K + LG_BK - 1) / LG_BK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < nchunks;
+        if (more) load_chunk(ch + 1);
+#pragma unroll
+        for (int ks = 0; ks < LG_BK / 4; ++ks) {
+            T af[2], bf[2];
+#pragma unroll
+            for (int fn = 0; fn < 2; ++fn) af[fn] = Ws[buf][4 * ks + q][32 * wn + 16 * fn + c];
+#pragma unroll
+            for (int rm = 0; rm < 2; ++rm) bf[rm] = As[buf][4 * ks + q][32 * wm + 16 * rm + c];
+#pragma unroll
+            for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+                for (int rm = 0; rm < 2; ++rm) acc[fn][rm] = Ops::mma(af[fn], bf[rm], acc[fn][rm]);
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: register r of lane (c, q) is feature row(q, r) of the 16 x 16 tile, row c
+    T* __restrict__ C = static_cast<T*>(a.C);
+    T* __restrict__ D = static_cast<T*>(a.D);
+    const T* __restrict__ bias = static_cast<const T*>(a.bias);
+    // reverse: the derivative's column of m.  A block of 64 columns never straddles two cotangent blocks (Rmod is a multiple
+    // of 64), so one division per workgroup places it
+    const long long mD0 = a.mode == LG_REVERSE ? m0 % a.Rmod - m0 : 0;
+#pragma unroll
+    for (int fn = 0; fn < 2; ++fn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 32 * wn + 16 * fn + Ops::row(q, r);
+            if (n >= N) continue;
+#pragma unroll
+            for (int rm = 0; rm < 2; ++rm) {
+                const long long m = m0 + 32 * wm + 16 * rm + c;
+                if (m >= M) continue;
+                const T v = acc[fn][rm][r];
+                if (a.mode == LG_FORWARD) {
+                    const T x = lg_act_f<T>(a.act, v + bias[n]);
+                    C[(size_t)n * a.ldc + m] = x;
+                    D[(size_t)n * a.ldd + m] = act_d1<T>(a.act, x);
+                } else {
+                    C[(size_t)n * a.ldc + m] = v * D[(size_t)n * a.ldd + (m + mD0)];
+                }
+            }
+        }
+}
+
+// ---- the small launches around the GEMMs (thread per row / per element; all feature-major, coalesced across rows) ----
+
+// xi^T[d][r] = input d of row r0 + r (window inputs, then the extra inputs); RK4 stages add c DT k_{s-1} to the state part
+template <typename T>
+__global__ void layered_gather_kernel(RowGather gk, int nin, int ne, const T* __restrict__ extra, const T* __restrict__ Z,
+                                      const T* __restrict__ X0, long long r0, int R, long long Rp, T* __restrict__ xi,
+                                      const T* __restrict__ kprev, T cdt) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const long long gr = r0 + r;
+    const int b = (int)(gr / gk.H), t = (int)(gr - (long long)b * gk.H);
+    const T* z = Z + (size_t)b * gk.n;
+    for (int d = 0; d < nin; ++d) {
+        T v = gather_input<T>(gk, z, X0, b, t, d);
+        if (kprev && d >= gk.xcur && d < gk.xcur + gk.nx) v = fma(cdt, kprev[(size_t)(d - gk.xcur) * Rp + r], v);
+        xi[(size_t)d * Rp + r] = v;
+    }
+    for (int j = 0; j < ne; ++j) xi[(size_t)(nin + j) * Rp + r] = extra[(size_t)gr * ne + j];
+}
+
+// N <= 32 outputs per column on the vector unit: out^T[n][m] = epi(sum_k A^T[k][m] Bw[k][n]).  mode 0: the network's
+// output layer (bias, activation; f and s'(z_L) stored), mode 2: plain (the last reverse step onto the inputs)
+template <typename T>
+__global__ void layered_skinny_kernel(const T* __restrict__ A, long long lda, const T* __restrict__ Bw, int ldb, int K, int N,
+                                      long long M, T* __restrict__ out, long long ldo, const T* __restrict__ bias, int mode,
+                                      int act, T* __restrict__ dout) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    T acc[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) acc[n] = T(0);
+    for (int k = 0; k < K; ++k) {
+        const T x = A[(size_t)k * lda + m];
+        const T* wrow = Bw + (size_t)k * ldb;
+#pragma unroll
+        for (int n = 0; n < 32; ++n)
+            if (n < N) acc[n] = fma(x, wrow[n], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < 32; ++n)
+        if (n < N) {
+            if (mode == 0) {
+                const T x = lg_act_f<T>(act, acc[n] + bias[n]);
+                out[(size_t)n * ldo + m] = x;
+                dout[(size_t)n * ldo + m] = act_d1<T>(act, x);
+            } else {
+                out[(size_t)n * ldo + m] = acc[n];
+            }
+        }
+}
+
+// seed of the reverse sweep: G^T[j][k Rp + r] = W_last[j][k] s_L'(z_L)[k][r] D_{L-2}^T[j][r]  (all nx cotangents side by side)
+template <typename T>
+__global__ void layered_seed_kernel(const T* __restrict__ Wlast, int wdt, int nx, const T* __restrict__ dL, const T* __restrict__ Dh,
+                                    int R, long long Rp, T* __restrict__ G) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (r >= R || j >= wdt) return;
+    const T d = Dh[(size_t)j * Rp + r];
+    for (int k = 0; k < nx; ++k) G[(size_t)j * (nx * Rp) + (size_t)k * Rp + r] = Wlast[(size_t)j * nx + k] * dL[(size_t)k * Rp + r] * d;
+}
+
+// RK4 stage bookkeeping per row (rk4.py:69-80,147-159): k_s = f, dk_s = J_s + c DT J_s[:, :nx] dk_{s-1}; weighted sums
+template <typename T>
+__global__ void layered_rk4_kernel(int stage, int nx, int nin, T cdt, T wgt, const T* __restrict__ f, const T* __restrict__ J,
+                                   int R, long long Rp, T* __restrict__ kprev, T* __restrict__ acck, T* __restrict__ dk,
+                                   T* __restrict__ dkn, T* __restrict__ accdk) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    // J^T[d][k Rp + r] = dPhi_k / dxi_d of row r
+    for (int i = 0; i < nx; ++i)
+        for (int d = 0; d < nin; ++d) {
+            T v = J[(size_t)d * (nx * Rp) + (size_t)i * Rp + r];
+            if (stage > 0) {
+                T s = T(0);
+                for (int e = 0; e < nx; ++e)
+                    s = fma(J[(size_t)e * (nx * Rp) + (size_t)i * Rp + r], dk[(size_t)(e * nin + d) * Rp + r], s);
+                v = v + cdt * s;
+            }
+            dkn[(size_t)(i * nin + d) * Rp + r] = v;
+        }
+    for (int i = 0; i < nx; ++i) {
+        const T kv = f[(size_t)i * Rp + r];
+        kprev[(size_t)i * Rp + r] = kv;
+        acck[(size_t)i * Rp + r] = stage == 0 ? kv : fma(wgt, kv, acck[(size_t)i * Rp + r]);
+        for (int d = 0; d < nin; ++d) {
+            const T v = dkn[(size_t)(i * nin + d) * Rp + r];
+            dk[(size_t)(i * nin + d) * Rp + r] = v;
+            accdk[(size_t)(i * nin + d) * Rp + r] = stage == 0 ? v : fma(wgt, v, accdk[(size_t)(i * nin + d) * Rp + r]);
+        }
+    }
+}
+
+// defects, box rows and compact tiles of the chunk's rows (same formulas as rows_valu_kernel)
+template <typename T>
+__global__ void layered_finish_kernel(RowGather gk, int kind, T DT, int nin, const T* __restrict__ Z, const T* __restrict__ X0,
+                                      long long r0, int R, long long Rp, const T* __restrict__ f, const T* __restrict__ J,
+                                      const T* __restrict__ acck, const T* __restrict__ accdk, T* __restrict__ g, int m, int box,
+                                      T* __restrict__ tiles) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const long long gr = r0 + r;
+    const int nx = gk.nx, H = gk.H;
+    const int b = (int)(gr / H), t = (int)(gr - (long long)b * H);
+    const T* z = Z + (size_t)b * gk.n;
+    T* gout = g + (size_t)b * m + (size_t)t * nx;
+    T* tile = tiles + (size_t)gr * nx * nin;
+    const T s6 = DT / T(6);
+    for (int i = 0; i < nx; ++i) {
+        const T xp = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
+        const T xt = z[t * nx + i];
+        T phi;
+        if (kind == NEMPC_RK4) phi = xp + s6 * acck[(size_t)i * Rp + r];
+        else phi = (kind == NEMPC_DISCRET ? xp : T(0)) + f[(size_t)i * Rp + r];
+        gout[i] = phi - xt;
+        if (box) gout[(size_t)H * nx + i] = xt;
+        for (int d = 0; d < nin; ++d) {
+            T v;
+            if (kind == NEMPC_RK4) v = s6 * accdk[(size_t)(i * nin + d) * Rp + r] + (d == i ? T(1) : T(0));
+            else v = J[(size_t)d * (nx * Rp) + (size_t)i * Rp + r] + ((kind == NEMPC_DISCRET && d == gk.xcur + i) ? T(1) : T(0));
+            tile[i * nin + d] = v;
+        }
+    }
+}
+
+struct LayeredWs {      // element offsets into the chunk workspace (times nothing: already multiplied by Rp)
+    size_t xi, x0, x1, d[NEMPC_MAX_LAYERS], f, dl, g0, g1, j, kprev, acck, dk, dkn, accdk, total;
+};
+
+LayeredWs layered_offsets(const Handle& h, size_t Rp) {
+    LayeredWs o{};
+    const int nx = h.cfg.nx, nin = h.nin;
+    size_t p = 0;
+    o.xi = p; p += (size_t)(nin + h.ne) * Rp;
+    o.x0 = p; p += (size_t)h.maxw * Rp;
+    o.x1 = p; p += (size_t)h.maxw * Rp;
+    for (int l = 0; l < h.nl - 1; ++l) { o.d[l] = p; p += (size_t)h.dout[l] * Rp; }
+    o.f = p; p += (size_t)nx * Rp;
+    o.dl = p; p += (size_t)nx * Rp;
+    o.g0 = p; p += (size_t)h.maxw * nx * Rp;
+    o.g1 = p; p += (size_t)h.maxw * nx * Rp;
+    o.j = p; p += (size_t)nin * nx * Rp;
+    if (h.cfg.integrator == NEMPC_RK4) {
+        o.kprev = p; p += (size_t)nx * Rp;
+        o.acck = p; p += (size_t)nx * Rp;
+        o.dk = p; p += (size_t)nx * nin * Rp;
+        o.dkn = p; p += (size_t)nx * nin * Rp;
+        o.accdk = p; p += (size_t)nx * nin * Rp;
+    }
+    o.total = p;
+    return o;
+}
+
+template <typename T>
+int gemm(hipStream_t s, int mode, int act, const T* A, long long lda, const T* Bw, int ldb, T* C, long long ldc, T* D,
+         long long ldd, const T* bias, long long M, int N, int K, long long Rmod) {
+    GemmArgs a{};
+    a.A = A; a.Bw = Bw; a.C = C; a.D = D; a.bias = bias;
+    a.lda = lda; a.ldc = ldc; a.ldd = ldd; a.ldb = ldb;
+    a.M = (int)M; a.N = N; a.K = K; a.mode = mode; a.act = act; a.Rmod = Rmod;
+    const dim3 grid((unsigned)((M + LG_BM - 1) / LG_BM), (unsigned)((N + LG_BN - 1) / LG_BN));
+    hipLaunchKernelGGL(layered_gemm_kernel<T>, grid, dim3(256), 0, s, a);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
+template <typename T>
+int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, void* tilesv, hipStream_t s) {
+    const T* Z = static_cast<const T*>(Zv);
+    const T* X0 = static_cast<const T*>(X0v);
+    T* g = static_cast<T*>(gv);
+    T* tiles = static_cast<T*>(tilesv);
+    const int nx = h.cfg.nx, nin = h.nin, ne = h.ne, nl = h.nl, H = h.cfg.H;
+    const long long rows = (long long)B * H;
+    const long long Rc = h.layered_chunk_rows;           // multiple of 64
+    T* ws = static_cast<T*>(h.d_layered_ws);
+    const RowGather gk = h.gather();
+    const bool rk4 = h.cfg.integrator == NEMPC_RK4;
+    const int nstages = rk4 ? 4 : 1;
+    const T DT = (T)h.cfg.DT;
+    int rc;
+    for (long long r0 = 0; r0 < rows; r0 += Rc) {
+        const int R = (int)(rows - r0 < Rc ? rows - r0 : Rc);
+        // row stride of every matrix of this chunk: its row count rounded to whole GEMM blocks (a short batch on a handle
+        // sized for a large one does not pay for the columns it does not have)
+        const long long Rm = ((long long)R + LG_BM - 1) / LG_BM * LG_BM;
+        const long long Rp = Rm;
+        const LayeredWs o = layered_offsets(h, (size_t)Rp);
+        const dim3 rb(256), rg((unsigned)((R + 255) / 256));
+        for (int st = 0; st < nstages; ++st) {
+            const T cdt = st == 0 ? T(0) : (st == 3 ? DT : T(0.5) * DT);
+            hipLaunchKernelGGL(layered_gather_kernel<T>, rg, rb, 0, s, gk, nin, ne, static_cast<const T*>(h.d_extra), Z, X0, r0, R, Rp,
+                               ws + o.xi, st > 0 ? ws + o.kprev : nullptr, cdt);
+            NEMPC_HIP(hipGetLastError());
+            // ---- forward: hidden layers 0 .. nl-2 (GEMM), output layer nl-1 (skinny)
+            const T* in = ws + o.xi;
+            for (int l = 0; l < nl - 1; ++l) {
+                T* out = ws + ((l & 1) ? o.x1 : o.x0);
+                if ((rc = gemm<T>(s, LG_FORWARD, h.act[l], in, Rp, static_cast<const T*>(h.d_W[l]), h.dout[l], out, Rp, ws + o.d[l], Rp,
+                                  static_cast<const T*>(h.d_b[l]), R, h.dout[l], h.din[l], 0)))
+                    return rc;
+                in = out;
+            }
+            hipLaunchKernelGGL(layered_skinny_kernel<T>, rg, rb, 0, s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx,
+                               (long long)R, ws + o.f, Rp, static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl);
+            NEMPC_HIP(hipGetLastError());
+            // ---- reverse, all nx cotangents side by side: column k Rp + r is (cotangent k, row r)
+            const long long ldg = (long long)nx * Rp;
+            T* G = ws + o.g0;
+            hipLaunchKernelGGL(layered_seed_kernel<T>, dim3(rg.x, (unsigned)h.dout[nl - 2]), rb, 0, s, static_cast<const T*>(h.d_W[nl - 1]),
+                               h.dout[nl - 2], nx, ws + o.dl, ws + o.d[nl - 2], R, Rp, G);
+            NEMPC_HIP(hipGetLastError());
+            for (int l = nl - 3; l >= 0; --l) {
+                // G_l = (W_{l+1} G_{l+1}) . D_l : K = dout[l+1], N = dout[l], operand W_{l+1}^T row-major (out, in) = d_Wt[l+1]
+                T* Gn = (G == ws + o.g0) ? ws + o.g1 : ws + o.g0;
+                // the nx blocks of Rp columns are covered as one run of columns; block k's columns beyond Rm are never read
+                if ((rc = gemm<T>(s, LG_REVERSE, 0, G, ldg, static_cast<const T*>(h.d_Wt[l + 1]), h.dout[l], Gn, ldg, ws + o.d[l], Rp,
+                                  nullptr, (long long)(nx - 1) * Rp + Rm, h.dout[l], h.dout[l + 1], Rp)))
+                    return rc;
+                G = Gn;
+            }
+            // J^T[d][k Rp + r] = sum_o W_0[d][o] G_0[o][.]: operand W_0^T (out, in) = d_Wt[0], only the nin decision inputs
+            {
+                const long long Mj = (long long)(nx - 1) * Rp + R;
+                hipLaunchKernelGGL(layered_skinny_kernel<T>, dim3((unsigned)((Mj + 255) / 256)), rb, 0, s, G, ldg,
+                                   static_cast<const T*>(h.d_Wt[0]), h.din[0], h.dout[0], nin, Mj, ws + o.j, ldg,
+                                   static_cast<const T*>(nullptr), 2, 0, static_cast<T*>(nullptr));
+                NEMPC_HIP(hipGetLastError());
+            }
+            if (rk4) {
+                hipLaunchKernelGGL(layered_rk4_kernel<T>, rg, rb, 0, s, st, nx, nin, cdt, (st == 0 || st == 3) ? T(1) : T(2), ws + o.f,
+                                   ws + o.j, R, Rp, ws + o.kprev, ws + o.acck, ws + o.dk, ws + o.dkn, ws + o.accdk);
+                NEMPC_HIP(hipGetLastError());
+            }
+        }
+        hipLaunchKernelGGL(layered_finish_kernel<T>, rg, rb, 0, s, gk, h.cfg.integrator, DT, nin, Z, X0, r0, R, Rp, ws + o.f, ws + o.j,
+                           rk4 ? ws + o.acck : nullptr, rk4 ? ws + o.accdk : nullptr, g, h.m, h.box ? 1 : 0, tiles);
+        NEMPC_HIP(hipGetLastError());
+    }
+    return NEMPC_OK;
+}
+
+}  // namespace
+
+// Which networks take this path: at least one hidden layer, decision + extra inputs within the skinny kernel's 32
+// accumulators, nx within 16, plain or rolling-window models (the gather handles both); everything the register-resident
+// matrix-core kernels (mfma_supported) do not take.
+bool layered_supported(const Handle& h) {
+    if (h.nl < 2 || h.nl > NEMPC_MAX_LAYERS) return false;
+    if (h.nin > 32 || h.cfg.nx > 16 || h.maxw > 1024) return false;
+    return true;
+}
+
+// chunk workspace: rows per chunk so that the whole workspace stays near 1.5 GB, between 4096 and 65536 rows
+int layered_prepare(Handle& h) {
+    const size_t cap = (size_t)h.cfg.max_batch * h.cfg.H;
+    const LayeredWs per = layered_offsets(h, 1);
+    size_t rc_rows = ((size_t)1536 << 20) / (per.total * h.esz);
+    if (rc_rows > 65536) rc_rows = 65536;
+    if (rc_rows < 4096) rc_rows = 4096;
+    if (const char* e = getenv("NEMPC_LAYERED_CHUNK_ROWS")) {     // (tests of the chunk loop)
+        const long long v = atoll(e);
+        if (v > 0) rc_rows = (size_t)v;
+    }
+    if (rc_rows > cap) rc_rows = cap;
+    rc_rows = (rc_rows + LG_BM - 1) / LG_BM * LG_BM;
+    if (h.d_layered_ws && h.layered_chunk_rows == (long long)rc_rows) return NEMPC_OK;
+    if (h.d_layered_ws) (void)hipFree(h.d_layered_ws);
+    h.d_layered_ws = nullptr;
+    h.layered_chunk_rows = (long long)rc_rows;
+    const size_t bytes = layered_offsets(h, rc_rows).total * h.esz;
+    hipError_t e = hipMalloc(&h.d_layered_ws, bytes);
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc (layered workspace): ") + hipGetErrorString(e));
+        return NEMPC_ENOMEM;
+    }
+    return NEMPC_OK;
+}
+
+void layered_free(Handle& h) {
+    if (h.d_layered_ws) (void)hipFree(h.d_layered_ws);
+    h.d_layered_ws = nullptr;
+}
+
+int launch_rows_layered(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s) {
+    int rc = layered_prepare(h);
+    if (rc) return rc;
+    h.last_row_kernel = 8;
+    return h.cfg.dtype == NEMPC_F64 ? run_layered<double>(h, B, Z, X0, g, tiles, s) : run_layered<float>(h, B, Z, X0, g, tiles, s);
+}
+
+}  // namespace nempc

@@ -488,6 +488,8 @@ size_t valu_workspace_elems(const Handle& h) {
 }
 
 int launch_rows_valu(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s) {
+    // networks outside the register-resident kernels' shapes: the rows come from the layer-at-a-time GEMM pipeline
+    if (h.layered) return launch_rows_layered(h, B, Z, X0, g, tiles, s);
     h.last_row_kernel = 1;
     const size_t rows = (size_t)B * h.cfg.H;
     const size_t Rcap = (size_t)h.cfg.max_batch * h.cfg.H;

@@ -280,6 +280,7 @@ void destroy_impl(Handle* h) {
         dev_free(h->d_b[l]);
     }
     mfma_free(*h);
+    layered_free(*h);
     rk4hess_free(*h);
     solver_free(*h);
     comm_free(*h);
@@ -325,7 +326,7 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
     }
     if (cfg->max_batch < 1) return fail(NEMPC_EINVAL, "nempc_create: max_batch must be >= 1");
     if (cfg->n_extra < 0) return fail(NEMPC_EINVAL, "nempc_create: n_extra must be >= 0");
-    if (cfg->kernel < NEMPC_KERNEL_AUTO || cfg->kernel > NEMPC_KERNEL_MFMA_TILE)
+    if (cfg->kernel < NEMPC_KERNEL_AUTO || cfg->kernel > NEMPC_KERNEL_LAYERED)
         return fail(NEMPC_EINVAL, "nempc_create: bad kernel selector");
     if (cfg->integrator == NEMPC_RK4 && !(cfg->DT > 0.0)) return fail(NEMPC_EINVAL, "nempc_create: RK4 needs DT > 0");
     if (cfg->rolling_window < 1) return fail(NEMPC_EINVAL, "nempc_create: rolling_window must be >= 1");
@@ -382,6 +383,17 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
         h->variant = cfg->kernel;
     } else if (cfg->kernel == NEMPC_KERNEL_AUTO && mfma_supported(*h)) {
         h->variant = NEMPC_KERNEL_MFMA;
+    } else if (cfg->kernel == NEMPC_KERNEL_LAYERED || cfg->kernel == NEMPC_KERNEL_AUTO) {
+        // wide / deep / mixed-activation networks: rows through the layer-at-a-time GEMM pipeline (kernels_layered.hip).
+        // Internally the handle stays on the generic variant -- Hessian blocks and everything else the pipeline does not
+        // produce come from the generic kernels -- with launch_rows_valu handing the rows over
+        if (layered_supported(*h)) {
+            h->layered = true;
+        } else if (cfg->kernel == NEMPC_KERNEL_LAYERED) {
+            delete h;
+            return fail(NEMPC_EUNSUPPORTED, "nempc_create: the layered matrix-core path needs >= 1 hidden layer, hidden widths <= 1024, "
+                                            "w*(nx+nu) <= 32 and nx <= 16");
+        }
     }
 
     int rc = NEMPC_OK;
@@ -785,7 +797,8 @@ int nempc_last_row_kernel(nempc_handle hh) {
 
 int nempc_kernel_variant(nempc_handle hh) {
     if (!hh) return fail(NEMPC_EINVAL, "nempc_kernel_variant: null handle");
-    return reinterpret_cast<Handle*>(hh)->variant;
+    const Handle& h = *reinterpret_cast<Handle*>(hh);
+    return h.layered ? NEMPC_KERNEL_LAYERED : h.variant;
 }
 
 }  // extern "C"

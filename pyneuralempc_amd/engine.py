@@ -162,13 +162,14 @@ class CallbackEngine:
     @property
     def kernel_variant(self):
         v = self.lib.nempc_kernel_variant(self._handle)
-        return {_lib.KERNEL_VALU: "valu", _lib.KERNEL_MFMA: "mfma", _lib.KERNEL_MFMA_TILE: "mfma_tile"}[v]
+        return {_lib.KERNEL_VALU: "valu", _lib.KERNEL_MFMA: "mfma", _lib.KERNEL_MFMA_TILE: "mfma_tile",
+                _lib.KERNEL_LAYERED: "layered"}[v]
 
     @property
     def last_row_kernel(self):
         """Name of the row kernel the most recent evaluation launched."""
         return {0: None, 1: "rows_valu_kernel", 2: "rows_coop_kernel", 3: "rows_mfma_kernel", 4: "rows_coopfx_kernel",
-                5: "rows_coop_kernel+dense", 6: "rows_coopfx_kernel+sparse", 7: "rows_coop_kernel+sparse"}[
+                5: "rows_coop_kernel+dense", 6: "rows_coopfx_kernel+sparse", 7: "rows_coop_kernel+sparse", 8: "layered_gemm_kernel"}[
             self.lib.nempc_last_row_kernel(self._handle)]
 
     @property

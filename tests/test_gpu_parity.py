@@ -39,8 +39,8 @@ ALL = ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")
 
 
 # every golden case x every kernel family; per-layer activation mixes run on the generic kernel only
-_FP64_CASES = ([(n, k) for n in CASE_NAMES + ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile")] +
-               [(n, "valu") for n in ACT_MIXED_NAMES])
+_FP64_CASES = ([(n, k) for n in CASE_NAMES + ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile", "layered")] +
+               [(n, k) for n in ACT_MIXED_NAMES for k in ("valu", "layered")])
 
 
 @pytest.mark.parametrize("name,kernel", _FP64_CASES)
@@ -68,8 +68,8 @@ def test_golden_fp64(name, kernel):
 
 
 @pytest.mark.parametrize("name,kernel", [(n, k) for n in ["c2_discret", "c3_rk4", "c3_discret", "c5_box", "odd_dims"] +
-                                         ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile")] +
-                         [(n, "valu") for n in ACT_MIXED_NAMES])
+                                         ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile", "layered")] +
+                         [(n, k) for n in ACT_MIXED_NAMES for k in ("valu", "layered")])
 def test_golden_fp32(name, kernel):
     d, W, b = load_case(name)
     eng = _engine(d, W, b, torch.float32, kernel)
@@ -421,8 +421,10 @@ def test_shapes_outside_the_matrix_core_kernels(hidden):
     prob = orc.Problem(net, H, nx, nu, orc.RK4, 0.1)
     Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=6)
     eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator="rk4", DT=0.1, device="cuda:0", max_batch=B)
-    assert eng.kernel_variant == ("mfma" if hidden == [17, 33, 5] else "valu")
+    # (auto: what the register-resident matrix-core kernels do not take runs on the layer-at-a-time GEMM pipeline)
+    assert eng.kernel_variant == ("mfma" if hidden == [17, 33, 5] else "layered")
     res = eng.eval_numpy(Zh, X0h)
+    assert eng.last_row_kernel == ("layered_gemm_kernel" if eng.kernel_variant == "layered" else eng.last_row_kernel)
     f, grad, g, jac = prob.eval_batch(Zh, X0h)
     np.testing.assert_allclose(res["g"], g, **F64)
     np.testing.assert_allclose(res["jac_dense"], jac, rtol=1e-11, atol=1e-12)
@@ -578,11 +580,11 @@ def test_activation_family_seeded_against_oracle(act):
         np.testing.assert_allclose(outs["mfma"]["jac_dense"], outs["valu"]["jac_dense"], **F64)
 
 
-def test_mixed_activations_run_on_the_generic_kernel_and_are_refused_by_the_matrix_core_ones():
+def test_mixed_activations_run_on_the_layered_path_and_are_refused_by_the_register_resident_kernels():
     from pyneuralempc_amd import CallbackEngine, _lib
     net = orc.MLP.random(3, [32, 32], 2, seed=1, activations=["relu", "tanh", "linear"])
     eng = CallbackEngine(net.W, net.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=4, activations=net.act)
-    assert eng.kernel_variant == "valu"                     # auto: a per-layer mix has no matrix-core instantiation
+    assert eng.kernel_variant == "layered"                  # auto: a per-layer mix has no register-resident instantiation
     Zh, X0h = orc.synthetic_inputs(4, 6, 2, 1, seed=2)
     res = eng.eval_numpy(Zh, X0h)
     f, grad, g, jac = orc.Problem(net, 6, 2, 1).eval_batch(Zh, X0h)
@@ -597,7 +599,7 @@ def test_mixed_activations_run_on_the_generic_kernel_and_are_refused_by_the_matr
     # a non-linear OUTPUT layer with one hidden activation is a mix too
     n2 = orc.MLP.random(3, [32], 2, seed=1, activations=["tanh", "sigmoid"])
     e2 = CallbackEngine(n2.W, n2.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=4, activations=n2.act)
-    assert e2.kernel_variant == "valu"
+    assert e2.kernel_variant == "layered"
     np.testing.assert_allclose(e2.eval_numpy(Zh, X0h)["jac_dense"], orc.Problem(n2, 6, 2, 1).eval_batch(Zh, X0h)[3], **F64)
 
 
@@ -675,3 +677,93 @@ def test_every_matrix_core_instantiation_with_its_hessian_against_the_oracle():
         ref = np.stack([prob.hessian_values(Zh[i], X0h[i], lam[i], sig[i]) for i in range(B)])
         assert np.abs(hv - ref).max() / max(1.0, np.abs(ref).max()) < (2e-3 if dt == torch.float32 else 1e-9), tag
         del eng
+
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("hidden,acts,nx,nu,integ", [
+    ([256, 256], "tanh", 2, 1, "discret"),                                   # wide256_c2
+    ([64, 64, 64, 64], "tanh", 2, 1, "discret"),                            # deep4_c2
+    ([200, 130, 70], ["relu", "sigmoid", "elu", "softplus"], 3, 2, "unity"),  # ragged widths, a mix, non-linear output
+    ([144, 96, 96, 40, 24], ["tanh", "relu", "tanh", "softplus", "elu", "linear"], 6, 3, "rk4"),
+    ([512], "sigmoid", 1, 1, "rk4"),
+])
+def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu, integ):
+    """Networks outside the register-resident kernels (width > 128, more than three hidden layers, per-layer activation
+    mixes): one GEMM launch per layer on the matrix cores (csrc/kernels_layered.hip) -- every contract (g, dense, sparse,
+    tiles, objective), ragged batches incl. a chunk boundary inside a GEMM block, box rows -- against the oracle, and bit
+    for bit independent of the batch a row sits in."""
+    from pyneuralempc_amd import CallbackEngine
+    H = 7
+    DT = 0.1 if integ == "rk4" else 1.0
+    kind = {"discret": orc.DISCRET, "unity": orc.UNITY, "rk4": orc.RK4}[integ]
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=8, activations=acts)
+    box = (-1.5, 1.5) if integ == "discret" else None
+    prob = orc.Problem(net, H, nx, nu, kind, DT, box=box)
+    f64 = dtype == torch.float64
+    tol = dict(rtol=1e-11, atol=1e-11) if f64 else dict(rtol=3e-4, atol=3e-4)
+    ref_rows = None
+    for B in (1, 19, 150):
+        eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=dtype, device="cuda:0", max_batch=B,
+                             activations=net.act)
+        assert eng.kernel_variant == "layered"
+        if box:
+            eng.set_box_rows(*box)
+        Zh, X0h = orc.synthetic_inputs(150, H, nx, nu, seed=3)
+        Zh, X0h = Zh[:B], X0h[:B]
+        res = eng.eval_numpy(Zh, X0h, want=ALL)
+        assert eng.last_row_kernel == "layered_gemm_kernel"
+        k = min(B, 12)
+        f, grad, g, J = prob.eval_batch(Zh[:k], X0h[:k])
+        np.testing.assert_allclose(res["f"][:k], f, **tol)
+        np.testing.assert_allclose(res["grad"][:k], grad, **tol)
+        np.testing.assert_allclose(res["g"][:k], g, **tol)
+        np.testing.assert_allclose(res["jac_dense"][:k], J, **tol)
+        rows, cols = eng.jac_structure()
+        assert np.array_equal(res["jac_sparse"], res["jac_dense"][:, rows, cols])
+        assert np.array_equal(res["jac_dense"] != 0, (np.abs(res["jac_dense"]) > 0)) and np.isfinite(res["jac_dense"]).all()
+        only_g = eng.eval_numpy(Zh, X0h, want=("g",))["g"]
+        assert np.array_equal(only_g, res["g"])
+        if ref_rows is None:
+            ref_rows = res["jac_tiles"][0].copy()
+        else:
+            assert np.array_equal(res["jac_tiles"][0], ref_rows)       # problem 0 does not depend on the batch around it
+        # generic kernel of the same handle shape: agreement to rounding
+        if B == 19:
+            ev = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=dtype, device="cuda:0", max_batch=B,
+                                activations=net.act, kernel="valu")
+            if box:
+                ev.set_box_rows(*box)
+            rv = ev.eval_numpy(Zh, X0h, want=("g", "jac_tiles"))
+            assert ev.last_row_kernel == "rows_valu_kernel"
+            np.testing.assert_allclose(res["g"], rv["g"], **tol)
+            np.testing.assert_allclose(res["jac_tiles"], rv["jac_tiles"], **tol)
+            # the Lagrangian Hessian of such a model: generic kernel, unchanged
+            lam = np.random.default_rng(1).normal(size=(B, eng.m))
+            hv = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lam), eng.to_device(np.ones(B)))["hvals"]
+            assert eng.last_hess_kernel == "rowhess_valu_kernel"
+            for i in range(3):
+                refh = prob.hessian_values(Zh[i], X0h[i], lam[i], 1.0)
+                np.testing.assert_allclose(hv[i].to("cpu", torch.float64).numpy(), refh, rtol=0,
+                                           atol=(1e-9 if f64 else 5e-3) * max(1.0, np.abs(refh).max()))
+
+
+def test_layered_path_chunks_large_batches():
+    """More rows than one workspace chunk holds (NEMPC_LAYERED_CHUNK_ROWS shrinks the chunk for the test): the chunk loop,
+    with a last chunk that is not a whole GEMM block, gives the rows of the one-chunk evaluation bit for bit."""
+    import os
+    from pyneuralempc_amd import CallbackEngine
+    H, nx, nu, B = 5, 2, 1, 77
+    net = orc.MLP.random(nx + nu, [160, 160], nx, seed=2)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=3)
+    outs = []
+    for chunk in ("0", "128"):
+        os.environ["NEMPC_LAYERED_CHUNK_ROWS"] = chunk
+        try:
+            eng = CallbackEngine(net.W, net.b, H, nx, nu, dtype=torch.float64, device="cuda:0", max_batch=B)
+            outs.append(eng.eval_numpy(Zh, X0h, want=("g", "jac_tiles")))
+        finally:
+            del os.environ["NEMPC_LAYERED_CHUNK_ROWS"]
+    assert np.array_equal(outs[0]["g"], outs[1]["g"]) and np.array_equal(outs[0]["jac_tiles"], outs[1]["jac_tiles"])
+    f, grad, g, J = orc.Problem(net, H, nx, nu).eval_batch(Zh[:8], X0h[:8])
+    np.testing.assert_allclose(outs[1]["g"][:8], g, **F64)

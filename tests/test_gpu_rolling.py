@@ -20,7 +20,8 @@ def _kernels(d):
     tw = int(d["window"]) * (int(d["nx"]) + int(d["nu"]))
     ex = case_extra(d)
     fits = tw + (0 if ex is None else ex.shape[1]) <= 32 and tw <= 32     # matrix-core kernels: up to 32 network inputs
-    return ["valu", "mfma", "mfma_tile"] if fits else ["valu"]
+    # (the layer-at-a-time path takes windows of up to 32 decision inputs, any number of extra inputs)
+    return (["valu", "mfma", "mfma_tile"] if fits else ["valu"]) + (["layered"] if tw <= 32 else [])
 
 
 def _engine(d, W, b, dtype, kernel):
@@ -62,7 +63,7 @@ def test_rolling_golden_fp64(name):
         np.testing.assert_array_equal(cl, d["cl"])
         np.testing.assert_array_equal(cu, d["cu_bound"])
         # both matrix-core kernels serve rolling windows: "mfma" resolves to the cooperative one when it fits
-        expect = {"valu": "rows_valu_kernel", "mfma_tile": "rows_mfma_kernel"}.get(kernel)
+        expect = {"valu": "rows_valu_kernel", "mfma_tile": "rows_mfma_kernel", "layered": "layered_gemm_kernel"}.get(kernel)
         if expect is not None:
             assert eng.last_row_kernel == expect
         else:
