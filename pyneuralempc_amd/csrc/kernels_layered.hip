@@ -26,6 +26,7 @@
 // holds the vector pipe for its 64 cycles, so the bound is the matrix pipe; arbitrary M, N, K (edge tiles are
 // zero-filled on load and masked on store).
 #include <cstdlib>
+#include <type_traits>
 
 #include "activations.h"
 #include "kernels_mfma_impl.h"
@@ -53,53 +54,107 @@ struct GemmArgs {
     const void* bias;   // forward only, (N)
     long long lda, ldc, ldd;
     int ldb, M, N, K, mode, act;
+    int nblk;           // feature blocks (ceil(N / BN)), set by the launcher
     long long Rmod;     // reverse: rows per cotangent block (a multiple of LG_BM, so a block never straddles two)
 };
 
-template <typename T>
+// FT = 16-feature tiles per wave: a workgroup owns BN = 64 FT features x 64 rows.  Measured (tools/layered_bench.py,
+// NEMPC_LAYERED_FT, round 4): FT = 1 is the fastest everywhere -- 2 x 256 at B*H = 20480: 398 / 505 / 569 us for FT = 1 / 2 /
+// 4 in fp64, 244 / 264 / 304 us in fp32; 4 x 512 RK4 6/3 at B*H = 30720: 34.0 / 41.1 / 44.1 ms (0.51 / 0.42 / 0.39 of the fp64
+// matrix peak).  Wider blocks read the activations fewer times but run at two waves per SIMD with coarse launch tails; with
+// the XCD-aware block order below the narrow block gets its re-reads from L2 anyway.  FT > 1 stays as an A/B knob.
+template <int FT>
+struct LgShape {
+    static constexpr int BN = 64 * FT;
+    static constexpr int BK = FT == 4 ? 8 : 16;
+    static constexpr int LDW = BN + 16;       // (padding: the four k-rows of a fragment read land on different banks;
+    static constexpr int LDA = LG_BM + 16;    //  +8 with four workgroups per CU measured 6 % slower)
+    static constexpr int TILE = BK * (LDW + LDA);      // elements per buffer
+};
+
+template <typename T, int FT>
 __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
     using Ops = MfmaOps<T>;
     using V4 = typename Ops::V4;
-    __shared__ T Ws[2][LG_BK][LG_LD];
-    __shared__ T As[2][LG_BK][LG_LD];
+    using S = LgShape<FT>;
+    constexpr int BN = S::BN, BK = S::BK, LDW = S::LDW, LDA = S::LDA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lg_lds_raw[];
+    T* const lds = reinterpret_cast<T*>(lg_lds_raw);
+    auto Ws = [&](int buf, int k, int x) -> T& { return lds[buf * S::TILE + k * LDW + x]; };
+    auto As = [&](int buf, int k, int x) -> T& { return lds[buf * S::TILE + BK * LDW + k * LDA + x]; };
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int wn = w & 1, wm = w >> 1;
-    const long long m0 = (long long)blockIdx.x * LG_BM;
-    const int n0 = blockIdx.y * LG_BN;
+    // workgroup -> block, XCD-aware: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, each with
+    // an L2 of its own.  XCD x takes the row blocks = x (mod 8), and runs the NB feature blocks of one row block back to
+    // back: the row operand (the activations) then comes from HBM once and from that XCD's L2 for the other NB - 1 feature
+    // blocks.  (Row blocks fastest, as a plain 2-D grid has it, re-read the activations from memory once per feature block:
+    // 3.4 TB/s for a 256 x 256 layer at B*H = 20480 -- the kernel was bandwidth-bound at 0.47 of the matrix peak.)
+    const int NB = a.nblk;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nb = slot % NB, mb = (slot / NB) * 8 + xcd;
+    const long long m0 = (long long)mb * LG_BM;
+    if (m0 >= a.M) return;
+    const int n0 = nb * BN;
     const T* __restrict__ A = static_cast<const T*>(a.A);
     const T* __restrict__ Bw = static_cast<const T*>(a.Bw);
     const int K = a.K, N = a.N;
     const long long M = a.M;
 
-    // loader: element e = tid + 256 u of a 16 x 64 tile -> (kk = e / 64, x = e % 64): 64 consecutive threads read one
-    // contiguous row piece of either operand
-    const int lx = tid & 63, lk = tid >> 6;      // kk = lk + 4 u
-    T rw[4], ra[4];
-    auto load_chunk = [&](int ch) {
+    // loader: a wave-uniform base that steps by a chunk on the scalar unit plus per-thread 32-bit element offsets that never
+    // change -- no vector arithmetic per load (a v_mfma_f64 holds the vector pipe for its 64 cycles).  Columns beyond N / M
+    // are clamped onto the last one (their results are never stored); only the LAST chunk, where k may run past K, is masked.
+    constexpr int NW = BK * BN / 256, NA = BK * LG_BM / 256;       // elements per thread and chunk
+    int offW[NW], offA[NA];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = ch * LG_BK + lk + 4 * u;
-            const bool kin = k < K;
-            rw[u] = (kin && n0 + lx < N) ? Bw[(size_t)k * a.ldb + n0 + lx] : T(0);
-            ra[u] = (kin && m0 + lx < M) ? A[(size_t)k * a.lda + m0 + lx] : T(0);
+    for (int u = 0; u < NW; ++u) {
+        const int e = tid + 256 * u, kk = e / BN, x = e % BN;
+        offW[u] = kk * a.ldb + (n0 + x < N ? x : N - 1 - n0);
+    }
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+        const int e = tid + 256 * u, kk = e / LG_BM, x = e % LG_BM;
+        offA[u] = (int)((long long)kk * a.lda + (m0 + x < M ? x : M - 1 - m0));
+    }
+    const T* __restrict__ Wb = Bw + n0;
+    const T* __restrict__ Ab = A + m0;
+    const int nfull = K / BK;
+    T rw[NW], ra[NA];
+    auto load_chunk = [&](int ch) {
+        const T* __restrict__ wb = Wb + (size_t)ch * BK * a.ldb;
+        const T* __restrict__ ab = Ab + (size_t)ch * BK * a.lda;
+        if (ch < nfull) {
+#pragma unroll
+            for (int u = 0; u < NW; ++u) rw[u] = wb[offW[u]];
+#pragma unroll
+            for (int u = 0; u < NA; ++u) ra[u] = ab[offA[u]];
+        } else {
+#pragma unroll
+            for (int u = 0; u < NW; ++u) rw[u] = (ch * BK + (tid + 256 * u) / BN < K) ? wb[offW[u]] : T(0);
+#pragma unroll
+            for (int u = 0; u < NA; ++u) ra[u] = (ch * BK + (tid + 256 * u) / LG_BM < K) ? ab[offA[u]] : T(0);
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            Ws[buf][lk + 4 * u][lx] = rw[u];
-            As[buf][lk + 4 * u][lx] = ra[u];
+        for (int u = 0; u < NW; ++u) {
+            const int e = tid + 256 * u;
+            Ws(buf, e / BN, e % BN) = rw[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int e = tid + 256 * u;
+            As(buf, e / LG_BM, e % LG_BM) = ra[u];
         }
     };
 
-    V4 acc[2][2];
+    V4 acc[FT][4];
 #pragma unroll
-    for (int fn = 0; fn < 2; ++fn)
+    for (int fn = 0; fn < FT; ++fn)
 #pragma unroll
-        for (int rm = 0; rm < 2; ++rm) acc[fn][rm] = V4{T(0), T(0), T(0), T(0)};
+        for (int rm = 0; rm < 4; ++rm) acc[fn][rm] = V4{T(0), T(0), T(0), T(0)};
 
-    const int nchunks = (K + LG_BK - 1) / LG_BK;
+    const int nchunks = (K + BK - 1) / BK;
+    const int fb = w * 16 * FT;                 // this wave's features inside the block
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
@@ -108,16 +163,16 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
         const bool more = ch + 1 < nchunks;
         if (more) load_chunk(ch + 1);
 #pragma unroll
-        for (int ks = 0; ks < LG_BK / 4; ++ks) {
-            T af[2], bf[2];
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            T af[FT], bf[4];
 #pragma unroll
-            for (int fn = 0; fn < 2; ++fn) af[fn] = Ws[buf][4 * ks + q][32 * wn + 16 * fn + c];
+            for (int fn = 0; fn < FT; ++fn) af[fn] = Ws(buf, 4 * ks + q, fb + 16 * fn + c);
 #pragma unroll
-            for (int rm = 0; rm < 2; ++rm) bf[rm] = As[buf][4 * ks + q][32 * wm + 16 * rm + c];
+            for (int rm = 0; rm < 4; ++rm) bf[rm] = As(buf, 4 * ks + q, 16 * rm + c);
 #pragma unroll
-            for (int fn = 0; fn < 2; ++fn)
+            for (int fn = 0; fn < FT; ++fn)
 #pragma unroll
-                for (int rm = 0; rm < 2; ++rm) acc[fn][rm] = Ops::mma(af[fn], bf[rm], acc[fn][rm]);
+                for (int rm = 0; rm < 4; ++rm) acc[fn][rm] = Ops::mma(af[fn], bf[rm], acc[fn][rm]);
         }
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
@@ -131,14 +186,14 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
     // of 64), so one division per workgroup places it
     const long long mD0 = a.mode == LG_REVERSE ? m0 % a.Rmod - m0 : 0;
 #pragma unroll
-    for (int fn = 0; fn < 2; ++fn)
+    for (int fn = 0; fn < FT; ++fn)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = n0 + 32 * wn + 16 * fn + Ops::row(q, r);
+            const int n = n0 + fb + 16 * fn + Ops::row(q, r);
             if (n >= N) continue;
 #pragma unroll
-            for (int rm = 0; rm < 2; ++rm) {
-                const long long m = m0 + 32 * wm + 16 * rm + c;
+            for (int rm = 0; rm < 4; ++rm) {
+                const long long m = m0 + 16 * rm + c;
                 if (m >= M) continue;
                 const T v = acc[fn][rm][r];
                 if (a.mode == LG_FORWARD) {
@@ -173,34 +228,58 @@ __global__ void layered_gather_kernel(RowGather gk, int nin, int ne, const T* __
 }
 
 // N <= 32 outputs per column on the vector unit: out^T[n][m] = epi(sum_k A^T[k][m] Bw[k][n]).  mode 0: the network's
-// output layer (bias, activation; f and s'(z_L) stored), mode 2: plain (the last reverse step onto the inputs)
+// output layer (bias, activation; f and s'(z_L) stored), mode 2: plain (the last reverse step onto the inputs).
+// A block is 64 columns x 4 waves; wave w sums k = w, w + 4, ... (eight loads in flight per lane), the four partial sums
+// meet in LDS -- a thread per column walking all of K alone was a chain of K dependent-latency loads (141 us for K = 256).
 template <typename T>
-__global__ void layered_skinny_kernel(const T* __restrict__ A, long long lda, const T* __restrict__ Bw, int ldb, int K, int N,
-                                      long long M, T* __restrict__ out, long long ldo, const T* __restrict__ bias, int mode,
-                                      int act, T* __restrict__ dout) {
-    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
+__global__ __launch_bounds__(256) void layered_skinny_kernel(const T* __restrict__ A, long long lda, const T* __restrict__ Bw, int ldb,
+                                                             int K, int N, long long M, T* __restrict__ out, long long ldo,
+                                                             const T* __restrict__ bias, int mode, int act, T* __restrict__ dout) {
+    __shared__ T red[3][32][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long m = (long long)blockIdx.x * 64 + lane;
+    const bool live = m < M;
     T acc[32];
 #pragma unroll
     for (int n = 0; n < 32; ++n) acc[n] = T(0);
-    for (int k = 0; k < K; ++k) {
-        const T x = A[(size_t)k * lda + m];
-        const T* wrow = Bw + (size_t)k * ldb;
+    for (int k0 = w; k0 < K; k0 += 32) {
+        T x[8];
 #pragma unroll
-        for (int n = 0; n < 32; ++n)
-            if (n < N) acc[n] = fma(x, wrow[n], acc[n]);
-    }
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u;
+            x[u] = (live && k < K) ? A[(size_t)k * lda + m] : T(0);
+        }
 #pragma unroll
-    for (int n = 0; n < 32; ++n)
-        if (n < N) {
-            if (mode == 0) {
-                const T x = lg_act_f<T>(act, acc[n] + bias[n]);
-                out[(size_t)n * ldo + m] = x;
-                dout[(size_t)n * ldo + m] = act_d1<T>(act, x);
-            } else {
-                out[(size_t)n * ldo + m] = acc[n];
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u;
+            if (k < K) {
+                const T* wrow = Bw + (size_t)k * ldb;
+#pragma unroll
+                for (int n = 0; n < 32; ++n)
+                    if (n < N) acc[n] = fma(x[u], wrow[n], acc[n]);
             }
         }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int n = 0; n < 32; ++n)
+            if (n < N) red[w - 1][n][lane] = acc[n];
+    }
+    __syncthreads();
+    if (w == 0 && live) {
+#pragma unroll
+        for (int n = 0; n < 32; ++n)
+            if (n < N) {
+                const T v = ((acc[n] + red[0][n][lane]) + red[1][n][lane]) + red[2][n][lane];
+                if (mode == 0) {
+                    const T x = lg_act_f<T>(act, v + bias[n]);
+                    out[(size_t)n * ldo + m] = x;
+                    dout[(size_t)n * ldo + m] = act_d1<T>(act, x);
+                } else {
+                    out[(size_t)n * ldo + m] = v;
+                }
+            }
+    }
 }
 
 // seed of the reverse sweep: G^T[j][k Rp + r] = W_last[j][k] s_L'(z_L)[k][r] D_{L-2}^T[j][r]  (all nx cotangents side by side)
@@ -305,6 +384,21 @@ LayeredWs layered_offsets(const Handle& h, size_t Rp) {
     return o;
 }
 
+template <typename T, int FT>
+int gemm_ft(hipStream_t s, const GemmArgs& a) {
+    using S = LgShape<FT>;
+    const size_t bytes = (size_t)2 * S::TILE * sizeof(T);
+    auto kern = layered_gemm_kernel<T, FT>;
+    NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), bytes));
+    GemmArgs b = a;
+    b.nblk = (a.N + S::BN - 1) / S::BN;
+    const long long mblk = ((long long)a.M + LG_BM - 1) / LG_BM;
+    const dim3 grid((unsigned)(8 * b.nblk * ((mblk + 7) / 8)));      // (row blocks padded to the 8 XCDs; the surplus exits at once)
+    hipLaunchKernelGGL(kern, grid, dim3(256), bytes, s, b);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
 template <typename T>
 int gemm(hipStream_t s, int mode, int act, const T* A, long long lda, const T* Bw, int ldb, T* C, long long ldc, T* D,
          long long ldd, const T* bias, long long M, int N, int K, long long Rmod) {
@@ -312,10 +406,12 @@ int gemm(hipStream_t s, int mode, int act, const T* A, long long lda, const T* B
     a.A = A; a.Bw = Bw; a.C = C; a.D = D; a.bias = bias;
     a.lda = lda; a.ldc = ldc; a.ldd = ldd; a.ldb = ldb;
     a.M = (int)M; a.N = N; a.K = K; a.mode = mode; a.act = act; a.Rmod = Rmod;
-    const dim3 grid((unsigned)((M + LG_BM - 1) / LG_BM), (unsigned)((N + LG_BN - 1) / LG_BN));
-    hipLaunchKernelGGL(layered_gemm_kernel<T>, grid, dim3(256), 0, s, a);
-    NEMPC_HIP(hipGetLastError());
-    return NEMPC_OK;
+    // the widest block the layer fills: the activations are then read once per layer (NEMPC_LAYERED_FT: A/B knob)
+    static const int ft_env = [] { const char* e = getenv("NEMPC_LAYERED_FT"); return e ? atoi(e) : 0; }();
+    const int ft = ft_env ? ft_env : (N > 64 ? 2 : 1);
+    if (ft >= 4) return gemm_ft<T, 4>(s, a);
+    if (ft >= 2) return gemm_ft<T, 2>(s, a);
+    return gemm_ft<T, 1>(s, a);
 }
 
 template <typename T>
@@ -355,7 +451,7 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                     return rc;
                 in = out;
             }
-            hipLaunchKernelGGL(layered_skinny_kernel<T>, rg, rb, 0, s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx,
+            hipLaunchKernelGGL(layered_skinny_kernel<T>, dim3((unsigned)((R + 63) / 64)), rb, 0, s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx,
                                (long long)R, ws + o.f, Rp, static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl);
             NEMPC_HIP(hipGetLastError());
             // ---- reverse, all nx cotangents side by side: column k Rp + r is (cotangent k, row r)
@@ -376,7 +472,7 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
             // J^T[d][k Rp + r] = sum_o W_0[d][o] G_0[o][.]: operand W_0^T (out, in) = d_Wt[0], only the nin decision inputs
             {
                 const long long Mj = (long long)(nx - 1) * Rp + R;
-                hipLaunchKernelGGL(layered_skinny_kernel<T>, dim3((unsigned)((Mj + 255) / 256)), rb, 0, s, G, ldg,
+                hipLaunchKernelGGL(layered_skinny_kernel<T>, dim3((unsigned)((Mj + 63) / 64)), rb, 0, s, G, ldg,
                                    static_cast<const T*>(h.d_Wt[0]), h.din[0], h.dout[0], nin, Mj, ws + o.j, ldg,
                                    static_cast<const T*>(nullptr), 2, 0, static_cast<T*>(nullptr));
                 NEMPC_HIP(hipGetLastError());
