@@ -284,6 +284,12 @@ CASES = {
                       ["relu", "softplus", "elu", "sigmoid"]),
     "act_mixed_rk4": (2, 1, [24, 24], 7, orc.RK4, 0.2, None, 2, True, 0, 0, ["elu", "sigmoid", "tanh"]),
     "act_linear_hidden": (2, 1, [16, 16], 5, orc.UNITY, 1.0, None, 2, True, 0, 0, ["linear", "tanh", "linear"]),
+    # networks outside the register-resident kernels (round 4: the layer-at-a-time GEMM path, csrc/kernels_layered.hip):
+    # a width beyond 128, more than three hidden layers, and a deep ragged mix under RK4 (short horizons keep the files small)
+    "wide256_c2": (2, 1, [256, 256], 6, orc.DISCRET, 1.0, None, 2, True),
+    "deep4_c2": (2, 1, [64, 64, 64, 64], 6, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True),
+    "deep5_mixed_rk4": (2, 1, [144, 96, 96, 40, 24], 5, orc.RK4, 0.1, None, 2, True, 0, 0,
+                        ["tanh", "relu", "tanh", "softplus", "elu", "linear"]),
 }
 
 

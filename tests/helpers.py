@@ -13,6 +13,8 @@ CASE_NAMES = ["c1_discret", "c2_discret", "c2_unity", "c2_rk4", "c3_rk4", "c3_di
 # output layer (generic kernel only)
 ACT_UNIFORM_NAMES = [f"act_{a}_{c}" for a in ("relu", "sigmoid", "softplus", "elu") for c in ("c2", "c3")]
 ACT_MIXED_NAMES = ["act_mixed_box", "act_mixed_rk4", "act_linear_hidden"]
+# networks only the layer-at-a-time GEMM path (and the generic kernel) take: width > 128, more than three hidden layers
+WIDE_DEEP_NAMES = ["wide256_c2", "deep4_c2", "deep5_mixed_rk4"]
 ROLLING_NAMES = ["roll2_discret", "roll3_unity_rev", "roll3_discret_rev", "roll4_wide", "roll2_tvp_p", "roll4_short"]
 
 

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import nempc_oracle as orc
-from helpers import ACT_MIXED_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, case_activations, case_extra, load_case, oracle_problem
+from helpers import ACT_MIXED_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, WIDE_DEEP_NAMES, case_activations, case_extra, load_case, oracle_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -40,7 +40,7 @@ ALL = ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")
 
 # every golden case x every kernel family; per-layer activation mixes run on the generic kernel only
 _FP64_CASES = ([(n, k) for n in CASE_NAMES + ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile", "layered")] +
-               [(n, k) for n in ACT_MIXED_NAMES for k in ("valu", "layered")])
+               [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")])
 
 
 @pytest.mark.parametrize("name,kernel", _FP64_CASES)
@@ -69,7 +69,7 @@ def test_golden_fp64(name, kernel):
 
 @pytest.mark.parametrize("name,kernel", [(n, k) for n in ["c2_discret", "c3_rk4", "c3_discret", "c5_box", "odd_dims"] +
                                          ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile", "layered")] +
-                         [(n, k) for n in ACT_MIXED_NAMES for k in ("valu", "layered")])
+                         [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")])
 def test_golden_fp32(name, kernel):
     d, W, b = load_case(name)
     eng = _engine(d, W, b, torch.float32, kernel)
@@ -82,7 +82,7 @@ def test_golden_fp32(name, kernel):
 @pytest.mark.parametrize("name,kernel",
                          [(n, k) for n in [c for c in CASE_NAMES if c not in ("c3_rk4", "odd_dims", "c3_discret")] +
                           [c for c in ACT_UNIFORM_NAMES if c.endswith("_c2")] for k in ("valu", "mfma", "mfma_tile")] +
-                         [(n, "valu") for n in ACT_MIXED_NAMES])
+                         [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")])
 def test_golden_hessian_fp64(name, kernel):
     d, W, b = load_case(name)
     eng = _engine(d, W, b, torch.float64, kernel)

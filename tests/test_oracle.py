@@ -5,12 +5,12 @@ import pytest
 import torch
 
 from oracle import nempc_oracle as orc
-from helpers import ACT_MIXED_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, ROLLING_NAMES, load_case, oracle_problem
+from helpers import ACT_MIXED_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, ROLLING_NAMES, WIDE_DEEP_NAMES, load_case, oracle_problem
 
 TOL = dict(rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("name", CASE_NAMES + ACT_UNIFORM_NAMES + ACT_MIXED_NAMES)
+@pytest.mark.parametrize("name", CASE_NAMES + ACT_UNIFORM_NAMES + ACT_MIXED_NAMES + WIDE_DEEP_NAMES)
 def test_oracle_matches_reference_golden(name):
     d, W, b = load_case(name)
     prob = oracle_problem(d, W, b)
@@ -33,7 +33,7 @@ def test_oracle_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", [n for n in CASE_NAMES if n not in ("c3_rk4", "c3_discret", "odd_dims")] +
-                         [n for n in ACT_UNIFORM_NAMES if n.endswith("_c2")] + ACT_MIXED_NAMES)
+                         [n for n in ACT_UNIFORM_NAMES if n.endswith("_c2")] + ACT_MIXED_NAMES + WIDE_DEEP_NAMES)
 def test_oracle_hessian_matches_reference_golden(name):
     d, W, b = load_case(name)
     prob = oracle_problem(d, W, b)
