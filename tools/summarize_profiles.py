@@ -2,8 +2,8 @@
 """Condense rocprofv3 output dirs (gpurun_out/prof*_{trace,fetch,write,mfma}) into small tracked files
 under profiles/: the --stats kernel table as is, and a JSON of per-kernel mean counter values per launch.
 HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE/WRITE_SIZE are in KiB, FETCH_SIZE is doubled on
-gfx950 (128-B requests tallied at 64 B); WRITE_SIZE is exact for 16-B-per-lane stores and uncalibrated
-for narrower ones (flagged per kernel)."""
+gfx950 (128-B requests tallied at 64 B); WRITE_SIZE is exact for 8- / 16-B-per-lane streams and charges an isolated
+narrower store its whole 32-B sector (round-4 calibration: tools/ubench_write_size.hip)."""
 import collections, csv, glob, json, os, shutil, sys
 src, tag = sys.argv[1], sys.argv[2]          # e.g. gpurun_out/prof2  r01_c2_b1024
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,7 +37,10 @@ for k, v in agg.items():
         m["hbm_read_bytes_corrected"] = m["FETCH_SIZE"] * 1024 * 2
         m["hbm_write_bytes"] = m["WRITE_SIZE"] * 1024
         m["hbm_traffic_bytes"] = m["hbm_read_bytes_corrected"] + m["hbm_write_bytes"]
-        m["write_size_calibrated"] = "post_" in k or "assemble" in k   # 16-byte streaming stores only
+        # WRITE_SIZE is exact for 8- and 16-byte-per-lane STREAMS and charges an isolated 8- or 16-byte store one 32-byte
+        # sector, write-through or not (tools/ubench_write_size.hip, profiles/r04_write_size_calibration.txt): that is what
+        # the memory system moves for a partial-sector write, so the figure is traffic, not a counter artefact
+        m["write_size_calibrated"] = True
     res[k] = m
 json.dump(res, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1)[:1500])
