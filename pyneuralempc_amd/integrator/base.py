@@ -76,8 +76,10 @@ class DeviceIntegrator(Integrator):
         self._host = None
         if not self.on_device:
             from .host import HostAlgebra
-            if int(getattr(model, "rolling_window", 1)) > 1:
-                raise NotImplementedError("rolling-window models run on the device path only (MLPModelRollingInput)")
+            # a rolling-window callable (model.TorchModelRollingWindow): its block-layout Jacobian / Hessian are banded over
+            # the window and the index map of the host algebra places any band; the RK4 stage recursion is per-row only
+            if int(getattr(model, "rolling_window", 1)) > 1 and self.KIND == "rk4":
+                raise NotImplementedError("rolling-window models need the Discret or Unity integrator")
             self._host = HostAlgebra(model, H, self.KIND, DT)
 
     def _need_device(self, what):

@@ -9,4 +9,4 @@ from .base import Model
 from .mlp import MLPModel
 from .rolling import MLPModelRollingInput
 from .tensorflow import KerasTFModel, KerasTFModelRollingInput
-from .torch_model import TorchModel
+from .torch_model import TorchModel, TorchModelRollingWindow

@@ -1,7 +1,8 @@
 """Names kept for scripts written against the reference (model/jax.py:32,93): both classes wrap an arbitrary JAX
 callable there.  JAX is not part of this build.  The same contract -- a differentiable function of the whole trajectory,
 differentiated by autodiff, results in the reference's block layouts -- is offered for a torch callable by
-``model.TorchModel`` (torch.func on the device, through the integrators' host algebra and the unfused solver glue); dense
+``model.TorchModel`` / ``model.TorchModelRollingWindow`` (torch.func on the device, through the integrators' host algebra and
+the unfused solver glue); dense
 networks given by their weights run inside the HIP kernels (``MLPModel`` / ``KerasTFModel`` / ``MLPModelRollingInput``).
 Constructing one of the JAX classes explains the replacement instead of failing with an AttributeError."""
 from .base import Model
@@ -23,4 +24,6 @@ class DiffDiscretJaxModelRollingWindow(Model):
                  vector_mode=True, safe_mode=True):
         raise NotImplementedError(_MSG.format(
             name="DiffDiscretJaxModelRollingWindow",
-            rolling=", or model.MLPModelRollingInput(..., rolling_window=w) for a rolling-window network"))
+            rolling="; the rolling-window form of the callable is model.TorchModelRollingWindow(forward_func, x_dim, u_dim, "
+                    "p_dim, tvp_dim, rolling_window=w) with the same set_prev_data, a rolling-window network given by its "
+                    "weights model.MLPModelRollingInput(..., rolling_window=w)"))

@@ -107,3 +107,101 @@ class TorchModel(Model):
             out[t][:, us, xs] = blk[t, :, nx:, :nx]
             out[t][:, us, us] = blk[t, :, nx:, nx:]
         return out
+
+
+class TorchModelRollingWindow(TorchModel):
+    """Rolling-window dynamics given as a differentiable torch callable -- the counterpart of the reference's
+    ``DiffDiscretJaxModelRollingWindow`` (model/jax.py:93-259): every row sees the last ``rolling_window`` states and
+    controls,
+
+        forward_func(x_slided (H, w * x_dim), u_slided (H, w * u_dim), p=None, tvp=tvp_slided (H, w * tvp_dim) | None)
+
+    oldest row first inside a window (``_slide_input``, model/jax.py:141-153); ``set_prev_data`` supplies the w - 1 rows in
+    front of the horizon (model/jax.py:119-129).  The reference differentiates with respect to the SLIDED inputs and
+    projects the result back onto the decision variables with 0/1 matrices (``gen_jac_proj_mat``, model/jax.py:8-20,183-194,
+    211-255); here the window gather is part of the differentiated function -- a composition of torch indexing ops -- so
+    ``torch.func`` returns the derivatives with respect to the decision variables directly: the same numbers (the chain
+    rule through a 0/1 selection), the same layouts, no projection matrices.  Like the reference, only forward_rolling=True
+    and vector_mode=True exist.  A rolling-window NETWORK given by its weights runs in the HIP kernels instead
+    (``MLPModelRollingInput`` / ``KerasTFModelRollingInput``)."""
+
+    def __init__(self, forward_func, x_dim: int, u_dim: int, p_dim=0, tvp_dim=0, rolling_window=1, forward_rolling=True,
+                 vector_mode=True, safe_mode=True, device="cuda", dtype=torch.float64):
+        if not forward_rolling:
+            raise NotImplementedError("Sorry ='(")                       # (model/jax.py:108-109)
+        if not vector_mode:
+            raise NotImplementedError("")                               # (model/jax.py:161-162)
+        if not isinstance(rolling_window, int) or rolling_window < 1:
+            raise ValueError("Your rolling windows need to be an integer gretter than 1.")
+        self.rolling_window = rolling_window
+        self.forward_rolling = forward_rolling
+        self.prev_x = self.prev_u = self.prev_tvp = None
+        Model.__init__(self, x_dim, u_dim, int(p_dim or 0), int(tvp_dim or 0))
+        self.forward_func = forward_func
+        self.vector_mode = True
+        self.device, self.dtype = torch.device(device), dtype
+        if safe_mode:
+            keep = (self.prev_x, self.prev_u, self.prev_tvp)
+            try:
+                w = rolling_window
+                self.set_prev_data(np.zeros((w - 1, x_dim)), np.zeros((w - 1, u_dim)),
+                                   np.zeros((w - 1, self.tvp_dim)) if self.tvp_dim else None)
+                self.jacobian(np.zeros((2, x_dim)), np.zeros((2, u_dim)), p=np.zeros(self.p_dim) if self.p_dim else None,
+                              tvp=np.zeros((2, self.tvp_dim)) if self.tvp_dim else None)
+            except Exception as e:      # noqa: BLE001
+                raise ValueError(f"Your function is not differentiable w.r.t the torch.func library ({type(e).__name__}: {e})")
+            finally:
+                self.prev_x, self.prev_u, self.prev_tvp = keep
+
+    def set_prev_data(self, x_prev, u_prev, tvp_prev=None):
+        w = self.rolling_window
+        x_prev, u_prev = np.asarray(x_prev, dtype=np.float64), np.asarray(u_prev, dtype=np.float64)
+        assert x_prev.shape == (w - 1, self.x_dim), \
+            f"Your x prev tensor must have the following shape {(w - 1, self.x_dim)} (received : {x_prev.shape})"
+        assert u_prev.shape == (w - 1, self.u_dim), \
+            f"Your u prev tensor must have the following shape {(w - 1, self.u_dim)} (received : {u_prev.shape})"
+        self.prev_x, self.prev_u = x_prev, u_prev
+        if tvp_prev is not None:
+            tvp_prev = np.asarray(tvp_prev, dtype=np.float64)
+            assert tvp_prev.shape == (w - 1, self.tvp_dim), \
+                f"Your tvp prev tensor must have the following shape {(w - 1, self.tvp_dim)} (received : {tvp_prev.shape})"
+            self.prev_tvp = tvp_prev
+
+    def _windowed(self, P, T):
+        """the function of the DECISION rows (X (H, x_dim), U (H, u_dim)) that torch.func differentiates"""
+        assert self.prev_x is not None and self.prev_u is not None, \
+            "You must give history window with set_prev_data before calling any inferance function."
+        w = self.rolling_window
+        px, pu = self._t(self.prev_x), self._t(self.prev_u)
+        tv = None
+        if T is not None:
+            tv = self._slide(torch.cat([self._t(self.prev_tvp), T], dim=0), w)
+
+        def g(X, U):
+            return self.forward_func(self._slide(torch.cat([px, X], dim=0), w), self._slide(torch.cat([pu, U], dim=0), w),
+                                     p=P, tvp=tv)
+        return g
+
+    @staticmethod
+    def _slide(a, w):
+        n = a.shape[0] - w + 1
+        return torch.stack([a[i:i + w].reshape(-1) for i in range(n)])
+
+    def forward(self, x, u, p=None, tvp=None):
+        X, U, P, T = self._t(x), self._t(u), self._t(p), self._t(tvp)
+        with torch.no_grad():
+            return self._np(self._windowed(P, T)(X, U))
+
+    def jacobian(self, x, u, p=None, tvp=None):
+        X, U, P, T = self._t(x), self._t(u), self._t(p), self._t(tvp)
+        H, nx, nu = X.shape[0], self.x_dim, self.u_dim
+        jx, ju = torch.func.jacrev(self._windowed(P, T), argnums=(0, 1))(X, U)
+        return self._np(torch.cat([jx.reshape(H * nx, H * nx), ju.reshape(H * nx, H * nu)], dim=1))
+
+    def hessian(self, x, u, p=None, tvp=None):
+        X, U, P, T = self._t(x), self._t(u), self._t(p), self._t(tvp)
+        H, nx, nu = X.shape[0], self.x_dim, self.u_dim
+        (hxx, hxu), (hux, huu) = torch.func.hessian(self._windowed(P, T), argnums=(0, 1))(X, U)
+        top = torch.cat([hxx.reshape(H, nx, H * nx, H * nx), hxu.reshape(H, nx, H * nx, H * nu)], dim=3)
+        bot = torch.cat([hux.reshape(H, nx, H * nu, H * nx), huu.reshape(H, nx, H * nu, H * nu)], dim=3)
+        return self._np(torch.cat([top, bot], dim=2))

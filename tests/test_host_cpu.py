@@ -382,3 +382,42 @@ def test_torch_model_validation_and_the_jax_names():
     integ = DiscretIntegrator(m, 2)
     with pytest.raises(NotImplementedError, match="dense-network model"):
         integ.engine(4)
+
+
+@pytest.mark.parametrize("name", ["roll2_discret", "roll4_wide", "roll4_short"])
+def test_torch_rolling_window_model_matches_the_reference_made_goldens(name):
+    """model.TorchModelRollingWindow (the DiffDiscretJaxModelRollingWindow counterpart, model/jax.py:93-259: a rolling-window
+    callable differentiated by autodiff) through the Discret integrator's host algebra and the unfused glue -- against the
+    rolling goldens, whose Jacobians the reference's own gen_jac_proj_mat projected (tests/golden/make_golden.py).  The
+    callable is the fixture's network written with torch ops.  CPU torch device: no kernel is involved."""
+    import torch
+    from helpers import load_case, oracle_problem
+    from pyneuralempc_amd.model import TorchModelRollingWindow
+    from pyneuralempc_amd.integrator import DiscretIntegrator, RK4Integrator
+    d, W, b = load_case(name)
+    H, nx, nu, w = int(d["H"]), int(d["nx"]), int(d["nu"]), int(d["window"])
+    Wt, bt = [torch.tensor(x) for x in W], [torch.tensor(x) for x in b]
+
+    def f(xs, us, p=None, tvp=None):                 # (H, w nx), (H, w nu) -> (H, nx): [state window | control window]
+        a = torch.cat([xs, us], dim=-1)
+        for wt, bb in zip(Wt[:-1], bt[:-1]):
+            a = torch.tanh(a @ wt + bb)
+        return a @ Wt[-1] + bt[-1]
+    model = TorchModelRollingWindow(f, nx, nu, rolling_window=w, device="cpu")
+    integ = DiscretIntegrator(model, H)
+    assert not integ.on_device
+    with pytest.raises(NotImplementedError):
+        RK4Integrator(model, H, 0.1)
+    with pytest.raises(AssertionError, match="history window"):
+        model.forward(np.zeros((H, nx)), np.zeros((H, nu)))
+    for i in range(d["Z"].shape[0]):
+        model.set_prev_data(d["hist_x"][i], d["hist_u"][i])
+        z, x0 = d["Z"][i], d["X0"][i]
+        x, u = z[:H * nx].reshape(H, nx), z[H * nx:].reshape(H, nu)
+        np.testing.assert_allclose(integ.forward(x, u, x0), d["g"][i][:H * nx], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(integ.jacobian(x, u, x0), d["jac"][i][:H * nx], rtol=1e-11, atol=1e-12)
+        prob = oracle_problem(d, W, b, i)
+        Hc = np.tensordot(d["lam"][i][:H * nx], integ.hessian(x, u, x0), axes=1) + float(d["sigma"][i]) * prob.objective_hessian()
+        np.testing.assert_allclose(Hc, d["hdense"][i], rtol=1e-9, atol=1e-10)
+    with pytest.raises(NotImplementedError):
+        TorchModelRollingWindow(f, nx, nu, rolling_window=w, forward_rolling=False, device="cpu")
