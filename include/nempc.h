@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define NEMPC_ABI_VERSION 6
+#define NEMPC_ABI_VERSION 7
 #define NEMPC_MAX_LAYERS 8 /* dense layers incl. the linear output layer */
 
 /* status codes */
@@ -67,14 +67,19 @@ extern "C" {
 /* activation of a dense layer -- what the Keras Dense layers of the model KerasTFModel wraps are built with
  * (model/tensorflow.py:8-29 takes ANY feed-forward Keras model; tensorflow.py:49-109 differentiates it by autodiff).
  * Derivatives are evaluated from the layer's output a = s(z): s' = 1 (linear), 1 - a^2 (tanh), [a > 0] (relu: the
- * gradient at 0 is 0, as TensorFlow's), a(1-a) (sigmoid), 1 - e^-a (softplus), 1 | a+1 (elu, alpha = 1). */
+ * gradient at 0 is 0, as TensorFlow's), a(1-a) (sigmoid), 1 - e^-a (softplus), 1 | a + alpha (elu), 1 | alpha (leaky_relu),
+ * lambda | a + lambda alpha (selu, Keras' fixed constants) -- the MONOTONE activations, whose derivatives follow from the
+ * output alone.  swish / gelu are not monotone (their derivatives need the pre-activation) and are refused.
+ * elu and leaky_relu read their alpha from nempc_config.act_param (elu: > 0, leaky_relu: >= 0). */
 #define NEMPC_ACT_LINEAR 0
 #define NEMPC_ACT_TANH 1
 #define NEMPC_ACT_RELU 2
 #define NEMPC_ACT_SIGMOID 3
 #define NEMPC_ACT_SOFTPLUS 4
 #define NEMPC_ACT_ELU 5
-#define NEMPC_ACT_COUNT 6
+#define NEMPC_ACT_LEAKY_RELU 6
+#define NEMPC_ACT_SELU 7
+#define NEMPC_ACT_COUNT 8
 
 /* row-kernel implementation */
 #define NEMPC_KERNEL_AUTO 0
@@ -113,6 +118,10 @@ typedef struct nempc_config {
                                          nn_model.h5: tanh, tanh, linear).  Any mix runs on the generic kernel; the
                                          matrix-core kernels take one non-linear activation on all hidden layers and
                                          a linear output layer (NEMPC_KERNEL_AUTO picks accordingly) */
+    double act_param[NEMPC_MAX_LAYERS];    /* alpha of an elu / leaky_relu layer (Keras: ELU(alpha), LeakyReLU(negative_slope));
+                                         ignored for the other activations.  The register-resident matrix-core kernels take
+                                         elu with alpha = 1 only; leaky_relu, selu and elu(alpha != 1) run on the layered
+                                         matrix-core path and the generic kernel */
 } nempc_config;
 
 /* lifetime ------------------------------------------------------------------------------- */

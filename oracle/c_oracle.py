@@ -16,7 +16,8 @@ class _CProblem(ctypes.Structure):
                 ("DT", ctypes.c_double), ("nl", ctypes.c_int), ("din", ctypes.c_int * MAXL),
                 ("dout", ctypes.c_int * MAXL), ("W", ctypes.c_void_p * MAXL), ("b", ctypes.c_void_p * MAXL),
                 ("Q", ctypes.c_void_p), ("R", ctypes.c_void_p), ("xref", ctypes.c_void_p), ("uref", ctypes.c_void_p),
-                ("cx", ctypes.c_void_p), ("cu", ctypes.c_void_p), ("box", ctypes.c_int), ("act", ctypes.c_int * MAXL)]
+                ("cx", ctypes.c_void_p), ("cu", ctypes.c_void_p), ("box", ctypes.c_int), ("act", ctypes.c_int * MAXL),
+                ("actp", ctypes.c_double * MAXL)]
 
 
 def build(force=False):
@@ -47,9 +48,10 @@ class COracle:
             self._keep.append(a)
             setattr(c, name, a.ctypes.data)
         c.box = int(prob.box is not None)
-        from .nempc_oracle import ACT_IDS
-        for l, name in enumerate(prob.net.act):
-            c.act[l] = ACT_IDS[name]
+        from .nempc_oracle import ACT_IDS, act_split
+        for l, spec in enumerate(prob.net.act):
+            name, par = act_split(spec)
+            c.act[l], c.actp[l] = ACT_IDS[name], par
         self.c = c
 
     def eval(self, Z, X0, dense=True, nthreads=0):

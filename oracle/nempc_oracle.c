@@ -33,27 +33,35 @@ typedef struct {
     const double* b[MAXL];
     const double *Q, *R, *xref, *uref, *cx, *cu; /* (nx,nx) (nu,nu) (H,nx) (H,nu) (H,nx) (H,nu) */
     int box;
-    int act[MAXL]; /* per layer: 0 linear, 1 tanh, 2 relu, 3 sigmoid, 4 softplus, 5 elu (nempc_oracle.py ACT_IDS) */
+    int act[MAXL]; /* per layer: 0 linear, 1 tanh, 2 relu, 3 sigmoid, 4 softplus, 5 elu, 6 leaky_relu, 7 selu (nempc_oracle.py ACT_IDS) */
+    double actp[MAXL]; /* alpha of elu / leaky_relu */
 } oracle_problem;
 
+#define SELU_LAMBDA 1.0507009873554804934193349852946
+#define SELU_ALPHA 1.6732632423543772848170429916717
+
 /* activation and its derivative written in terms of the layer's output a = s(z) (table in nempc_oracle.py) */
-static double act_f(int code, double z) {
+static double act_f(int code, double z, double par) {
     switch (code) {
         case 1: return tanh(z);
         case 2: return z < 0.0 ? 0.0 : z;
         case 3: return 1.0 / (1.0 + exp(-z));
         case 4: return (z > 0.0 ? z : 0.0) + log1p(exp(-fabs(z)));
-        case 5: return z > 0.0 ? z : expm1(z);
+        case 5: return z > 0.0 ? z : par * expm1(z);
+        case 6: return z > 0.0 ? z : par * z;
+        case 7: return SELU_LAMBDA * (z > 0.0 ? z : SELU_ALPHA * expm1(z));
         default: return z;
     }
 }
-static double act_d1(int code, double a) {
+static double act_d1(int code, double a, double par) {
     switch (code) {
         case 1: return 1.0 - a * a;
         case 2: return a > 0.0 ? 1.0 : 0.0;
         case 3: return a * (1.0 - a);
         case 4: return -expm1(-a);
-        case 5: return a > 0.0 ? 1.0 : a + 1.0;
+        case 5: return a > 0.0 ? 1.0 : a + par;
+        case 6: return a > 0.0 ? 1.0 : (a != a ? a : par);
+        case 7: return a > 0.0 ? SELU_LAMBDA : a + SELU_LAMBDA * SELU_ALPHA;
         default: return 1.0;
     }
 }
@@ -74,14 +82,14 @@ static void net_eval(const oracle_problem* p, const double* xi, double* f, doubl
             const double* w = p->W[l] + (size_t)i * wo;
             for (int j = 0; j < wo; ++j) out[j] += a * w[j];
         }
-        if (p->act[l] != 0) for (int j = 0; j < wo; ++j) out[j] = act_f(p->act[l], out[j]);
+        if (p->act[l] != 0) for (int j = 0; j < wo; ++j) out[j] = act_f(p->act[l], out[j], p->actp[l]);
         in = out;
     }
     /* reverse sweep per output */
     for (int k = 0; k < p->nx; ++k) {
         double* c = cot;
         double* cn = cot + maxw;
-        const double dout_k = p->act[nl - 1] != 0 ? act_d1(p->act[nl - 1], f[k]) : 1.0;   /* output-layer activation */
+        const double dout_k = p->act[nl - 1] != 0 ? act_d1(p->act[nl - 1], f[k], p->actp[nl - 1]) : 1.0;   /* output-layer activation */
         if (nl == 1) {
             for (int d = 0; d < nin; ++d) J[k * nin + d] = p->W[0][(size_t)d * p->dout[0] + k] * dout_k;
             continue;
@@ -90,7 +98,7 @@ static void net_eval(const oracle_problem* p, const double* xi, double* f, doubl
             const int w = p->din[nl - 1];
             const double* a = act + (size_t)(nl - 2) * maxw;
             for (int j = 0; j < w; ++j)
-                c[j] = p->W[nl - 1][(size_t)j * p->nx + k] * dout_k * act_d1(p->act[nl - 2], a[j]);
+                c[j] = p->W[nl - 1][(size_t)j * p->nx + k] * dout_k * act_d1(p->act[nl - 2], a[j], p->actp[nl - 2]);
         }
         for (int l = nl - 2; l >= 0; --l) {
             const int wi = p->din[l], wo = p->dout[l];
@@ -99,7 +107,7 @@ static void net_eval(const oracle_problem* p, const double* xi, double* f, doubl
                 const double* w = p->W[l] + (size_t)i * wo;
                 double s = 0.0;
                 for (int j = 0; j < wo; ++j) s += w[j] * c[j];
-                if (l > 0) s *= act_d1(p->act[l - 1], act[(size_t)(l - 1) * maxw + i]);
+                if (l > 0) s *= act_d1(p->act[l - 1], act[(size_t)(l - 1) * maxw + i], p->actp[l - 1]);
                 dst[i] = s;
             }
             if (l > 0) { double* t = c; c = cn; cn = t; }

@@ -47,13 +47,36 @@ INTEGRATOR_NAMES = {DISCRET: "discret", UNITY: "unity", RK4: "rk4"}
 #   relu      a = max(z, 0)             d1 = [a > 0]                 r2 = 0           (TF's relu gradient at 0 is 0)
 #   sigmoid   a = 1/(1+e^-z)            d1 = a(1-a)                  r2 = 1 - 2a
 #   softplus  a = log(1+e^z)            d1 = 1 - e^-a (= sigmoid z)  r2 = e^-a (= 1 - sigmoid z)
-#   elu       a = z (z>0), e^z-1 (z<=0) d1 = 1 (a>0), a+1 (a<=0)     r2 = 0 (a>0), 1 (a<=0)   (alpha = 1, the Keras default)
+#   elu       a = z (z>0), al(e^z-1)    d1 = 1 (a>0), a+al (a<=0)    r2 = 0 (a>0), 1 (a<=0)   (al = alpha > 0, Keras default 1)
+#   leaky_relu a = z (z>0), al z        d1 = 1 (a>0), al (a<=0)      r2 = 0           (al >= 0; tf.nn.leaky_relu's gradient at 0 is al)
+#   selu      a = la z (z>0), la al(e^z-1)  d1 = la (a>0), a + la al  r2 = 0 (a>0), 1  (la, al: Keras' fixed constants)
+# The monotone activations above are the ones whose derivatives follow from the output alone; swish / gelu (not monotone)
+# would need the pre-activation and are not part of the family.  A parameterised activation is written "name:value"
+# ("elu:0.5", "leaky_relu:0.1"); the bare name takes the default (elu 1, leaky_relu 0.2 = keras.activations.leaky_relu).
 # --------------------------------------------------------------------------------------
-ACTIVATIONS = ("linear", "tanh", "relu", "sigmoid", "softplus", "elu")
+ACTIVATIONS = ("linear", "tanh", "relu", "sigmoid", "softplus", "elu", "leaky_relu", "selu")
 ACT_IDS = {name: i for i, name in enumerate(ACTIVATIONS)}     # the codes of include/nempc.h (NEMPC_ACT_*)
+ACT_DEFAULT_PARAM = {"elu": 1.0, "leaky_relu": 0.2}
+SELU_LAMBDA, SELU_ALPHA = 1.0507009873554804934193349852946, 1.6732632423543772848170429916717
+
+
+def act_split(spec):
+    """"name" or "name:value" -> (name, parameter); the parameter is alpha of elu / leaky_relu, 0.0 for the others"""
+    name, _, val = str(spec).partition(":")
+    if name not in ACTIVATIONS:
+        raise ValueError(f"unknown activation {spec!r}")
+    if val and name not in ACT_DEFAULT_PARAM:
+        raise ValueError(f"activation {name!r} takes no parameter ({spec!r})")
+    par = float(val) if val else ACT_DEFAULT_PARAM.get(name, 0.0)
+    if name == "elu" and not par > 0.0:
+        raise ValueError("elu needs alpha > 0 (its derivative is written from the output)")
+    if name == "leaky_relu" and not par >= 0.0:
+        raise ValueError("leaky_relu needs alpha >= 0")
+    return name, par
 
 
 def act_f(name, z):
+    name, par = act_split(name)
     if name == "linear":
         return z
     if name == "tanh":
@@ -66,11 +89,16 @@ def act_f(name, z):
     if name == "softplus":
         return np.maximum(z, 0.0) + np.log1p(np.exp(-np.abs(z)))
     if name == "elu":
-        return np.where(z > 0.0, z, np.expm1(np.minimum(z, 0.0)))
+        return np.where(z > 0.0, z, par * np.expm1(np.minimum(z, 0.0)))
+    if name == "leaky_relu":
+        return np.where(z > 0.0, z, par * z)
+    if name == "selu":
+        return SELU_LAMBDA * np.where(z > 0.0, z, SELU_ALPHA * np.expm1(np.minimum(z, 0.0)))
     raise ValueError(f"unknown activation {name!r}")
 
 
 def act_d1(name, a):
+    name, par = act_split(name)
     if name == "linear":
         return np.ones_like(a)
     if name == "tanh":
@@ -82,12 +110,17 @@ def act_d1(name, a):
     if name == "softplus":
         return -np.expm1(-a)
     if name == "elu":
-        return np.where(a > 0.0, 1.0, a + 1.0)
+        return np.where(a > 0.0, 1.0, a + par)
+    if name == "leaky_relu":
+        return np.where(a > 0.0, 1.0, np.where(np.isnan(a), a, par))
+    if name == "selu":
+        return np.where(a > 0.0, SELU_LAMBDA, a + SELU_LAMBDA * SELU_ALPHA)
     raise ValueError(f"unknown activation {name!r}")
 
 
 def act_r2(name, a):
-    if name in ("linear", "relu"):
+    name, par = act_split(name)
+    if name in ("linear", "relu", "leaky_relu"):
         return np.zeros_like(a)
     if name == "tanh":
         return -2.0 * a
@@ -95,7 +128,7 @@ def act_r2(name, a):
         return 1.0 - 2.0 * a
     if name == "softplus":
         return np.exp(-a)
-    if name == "elu":
+    if name in ("elu", "selu"):
         return np.where(a > 0.0, 0.0, 1.0)
     raise ValueError(f"unknown activation {name!r}")
 
@@ -121,7 +154,9 @@ class MLP:
         elif isinstance(activations, str):             # one name: every hidden layer, linear output
             activations = [activations] * (len(self.W) - 1) + ["linear"]
         self.act = [str(a) for a in activations]
-        assert len(self.act) == len(self.W) and all(a in ACTIVATIONS for a in self.act)
+        assert len(self.act) == len(self.W)
+        for a in self.act:
+            act_split(a)
 
     @staticmethod
     def random(n_in, hidden, n_out, seed=0, activations=None):

@@ -7,7 +7,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 # NEMPC_LIB: an alternative build of the same library (A/B kernel experiments, tools/build_variant.py)
 LIB_PATH = os.environ.get("NEMPC_LIB") or os.path.join(PKG, "libnempc.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 COMM_ID_BYTES = 128
 MAX_LAYERS = 8
 F64, F32 = 0, 1
@@ -17,7 +17,27 @@ KERNEL_NAMES = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA, "
                 "layered": KERNEL_LAYERED}
 INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
 # NEMPC_ACT_*: the activation of a dense layer (names as Keras spells them)
-ACTIVATION_IDS = {"linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3, "softplus": 4, "elu": 5}
+ACTIVATION_IDS = {"linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3, "softplus": 4, "elu": 5, "leaky_relu": 6, "selu": 7}
+# activations with a parameter (alpha), written "name:value" ("elu:0.5", "leaky_relu:0.1"); the bare name takes the default
+# (elu: Keras' 1.0; leaky_relu: keras.activations.leaky_relu's 0.2 -- the LeakyReLU LAYER carries its own negative_slope)
+ACTIVATION_DEFAULT_PARAM = {"elu": 1.0, "leaky_relu": 0.2}
+
+
+def split_activation(spec):
+    """"name" | "name:value" -> (name, parameter), validated like nempc_create does"""
+    name, _, val = str(spec).partition(":")
+    if name not in ACTIVATION_IDS:
+        raise NotImplementedError(f"activation '{spec}' is not supported on the device path (supported: "
+                                  f"{', '.join(ACTIVATION_IDS)}; swish / gelu are not monotone: their derivatives need the "
+                                  "pre-activation, which the kernels do not keep)")
+    if val and name not in ACTIVATION_DEFAULT_PARAM:
+        raise ValueError(f"activation '{name}' takes no parameter ('{spec}')")
+    par = float(val) if val else ACTIVATION_DEFAULT_PARAM.get(name, 0.0)
+    if name == "elu" and not par > 0.0:
+        raise ValueError("elu needs alpha > 0")
+    if name == "leaky_relu" and not par >= 0.0:
+        raise ValueError("leaky_relu needs alpha >= 0")
+    return name, par
 
 EXPORTS = ["nempc_create", "nempc_destroy", "nempc_reserve", "nempc_set_weights", "nempc_set_objective", "nempc_set_terminal_weight", "nempc_set_box_rows", "nempc_bind_extra", "nempc_bind_history",
            "nempc_dims", "nempc_constraint_bounds", "nempc_jac_structure", "nempc_hess_structure", "nempc_eval",
@@ -38,7 +58,7 @@ class NempcConfig(ctypes.Structure):
                 ("nu", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("widths", ctypes.c_int32 * MAX_LAYERS),
                 ("max_batch", ctypes.c_int32), ("kernel", ctypes.c_int32), ("n_extra", ctypes.c_int32),
                 ("rolling_window", ctypes.c_int32), ("rolling_reverse", ctypes.c_int32), ("DT", ctypes.c_double),
-                ("activations", ctypes.c_int32 * MAX_LAYERS)]
+                ("activations", ctypes.c_int32 * MAX_LAYERS), ("act_param", ctypes.c_double * MAX_LAYERS)]
 
 
 class NempcSolverOpts(ctypes.Structure):

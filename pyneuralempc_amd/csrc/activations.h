@@ -9,7 +9,9 @@
 //   relu      a = max(z, 0)              d1 = [a > 0]                 r2 = 0        (TensorFlow's relu gradient at 0 is 0)
 //   sigmoid   a = 1 / (1 + e^-z)         d1 = a (1 - a)               r2 = 1 - 2a
 //   softplus  a = log(1 + e^z)           d1 = 1 - e^-a (= sigmoid z)  r2 = e^-a
-//   elu       a = z (z > 0), e^z - 1     d1 = 1 (a > 0), a + 1        r2 = 0 (a > 0), 1          (alpha = 1, Keras' default)
+//   elu       a = z (z > 0), al(e^z - 1) d1 = 1 (a > 0), a + al       r2 = 0 (a > 0), 1          (al = alpha > 0; Keras' default 1)
+//   leaky_relu a = z (z > 0), al z       d1 = 1 (a > 0), al           r2 = 0                     (al >= 0; run-time forms only)
+//   selu      a = la z, la al(e^z - 1)   d1 = la (a > 0), a + la al   r2 = 0 (a > 0), 1          (Keras' constants; run-time forms only)
 // r2 is what the forward-over-reverse Hessian sweeps need: d(delta * s') = s' d(delta) + delta * r2 * da, da the tangent
 // of the activation itself.
 //
@@ -125,36 +127,45 @@ struct Act<T, NEMPC_ACT_ELU> {
     static __device__ __forceinline__ T r2(T a) { return a > T(0) ? T(0) : (a != a ? a : T(1)); }
 };
 
-// run-time forms (generic kernel: the code is wave-uniform, the switch a scalar branch)
+// run-time forms (generic kernel and the layered path: the code is wave-uniform, the switch a scalar branch).  `par` is the
+// layer's nempc_config.act_param: alpha of elu / leaky_relu.
+#define NEMPC_SELU_LAMBDA 1.0507009873554804934193349852946
+#define NEMPC_SELU_ALPHA 1.6732632423543772848170429916717
 template <typename T>
-__device__ __forceinline__ T act_f(int code, T x) {
+__device__ __forceinline__ T act_f(int code, T x, T par) {
     switch (code) {
         case NEMPC_ACT_TANH: return sizeof(T) == 8 ? (T)tanh((double)x) : (T)tanhf((float)x);
         case NEMPC_ACT_RELU: return Act<T, NEMPC_ACT_RELU>::f(x);
         case NEMPC_ACT_SIGMOID: return Act<T, NEMPC_ACT_SIGMOID>::f(x);
         case NEMPC_ACT_SOFTPLUS: return Act<T, NEMPC_ACT_SOFTPLUS>::f(x);
-        case NEMPC_ACT_ELU: return Act<T, NEMPC_ACT_ELU>::f(x);
+        case NEMPC_ACT_ELU: return x > T(0) ? x : par * nempc_expm1(x);                  // expm1(NaN) = NaN
+        case NEMPC_ACT_LEAKY_RELU: return x > T(0) ? x : par * x;
+        case NEMPC_ACT_SELU: return T(NEMPC_SELU_LAMBDA) * (x > T(0) ? x : T(NEMPC_SELU_ALPHA) * nempc_expm1(x));
         default: return x;
     }
 }
 template <typename T>
-__device__ __forceinline__ T act_d1(int code, T a) {
+__device__ __forceinline__ T act_d1(int code, T a, T par) {
     switch (code) {
         case NEMPC_ACT_TANH: return Act<T, NEMPC_ACT_TANH>::d1(a);
         case NEMPC_ACT_RELU: return Act<T, NEMPC_ACT_RELU>::d1(a);
         case NEMPC_ACT_SIGMOID: return Act<T, NEMPC_ACT_SIGMOID>::d1(a);
         case NEMPC_ACT_SOFTPLUS: return Act<T, NEMPC_ACT_SOFTPLUS>::d1(a);
-        case NEMPC_ACT_ELU: return Act<T, NEMPC_ACT_ELU>::d1(a);
+        case NEMPC_ACT_ELU: return a > T(0) ? T(1) : a + par;
+        case NEMPC_ACT_LEAKY_RELU: return a > T(0) ? T(1) : (a != a ? a : par);          // (tf.nn.leaky_relu: alpha at 0)
+        case NEMPC_ACT_SELU: return a > T(0) ? T(NEMPC_SELU_LAMBDA) : a + T(NEMPC_SELU_LAMBDA * NEMPC_SELU_ALPHA);
         default: return T(1);
     }
 }
 template <typename T>
-__device__ __forceinline__ T act_r2(int code, T a) {
+__device__ __forceinline__ T act_r2(int code, T a, T par) {
+    (void)par;
     switch (code) {
         case NEMPC_ACT_TANH: return Act<T, NEMPC_ACT_TANH>::r2(a);
         case NEMPC_ACT_SIGMOID: return Act<T, NEMPC_ACT_SIGMOID>::r2(a);
         case NEMPC_ACT_SOFTPLUS: return Act<T, NEMPC_ACT_SOFTPLUS>::r2(a);
-        case NEMPC_ACT_ELU: return Act<T, NEMPC_ACT_ELU>::r2(a);
+        case NEMPC_ACT_ELU:
+        case NEMPC_ACT_SELU: return a > T(0) ? T(0) : (a != a ? a : T(1));
         default: return T(0);
     }
 }

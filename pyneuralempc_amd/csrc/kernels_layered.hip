@@ -41,9 +41,9 @@ constexpr int LG_BM = 64, LG_BN = 64, LG_BK = 16, LG_LD = 80;     // LD: padded 
 enum { LG_FORWARD = 0, LG_REVERSE = 1 };
 
 template <typename T>
-__device__ __forceinline__ T lg_act_f(int code, T x) {
+__device__ __forceinline__ T lg_act_f(int code, T x, T par) {
     if (code == NEMPC_ACT_TANH) return Act<T, NEMPC_ACT_TANH>::f(x);     // the 24-slot tanh of the row kernels
-    return act_f<T>(code, x);
+    return act_f<T>(code, x, par);
 }
 
 struct GemmArgs {
@@ -55,6 +55,7 @@ struct GemmArgs {
     long long lda, ldc, ldd;
     int ldb, M, N, K, mode, act;
     int nblk;           // feature blocks (ceil(N / BN)), set by the launcher
+    double actp;        // alpha of an elu / leaky_relu layer
     long long Rmod;     // reverse: rows per cotangent block (a multiple of LG_BM, so a block never straddles two)
 };
 
@@ -197,9 +198,9 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
                 if (m >= M) continue;
                 const T v = acc[fn][rm][r];
                 if (a.mode == LG_FORWARD) {
-                    const T x = lg_act_f<T>(a.act, v + bias[n]);
+                    const T x = lg_act_f<T>(a.act, v + bias[n], (T)a.actp);
                     C[(size_t)n * a.ldc + m] = x;
-                    D[(size_t)n * a.ldd + m] = act_d1<T>(a.act, x);
+                    D[(size_t)n * a.ldd + m] = act_d1<T>(a.act, x, (T)a.actp);
                 } else {
                     C[(size_t)n * a.ldc + m] = v * D[(size_t)n * a.ldd + (m + mD0)];
                 }
@@ -234,7 +235,8 @@ __global__ void layered_gather_kernel(RowGather gk, int nin, int ne, const T* __
 template <typename T>
 __global__ __launch_bounds__(256) void layered_skinny_kernel(const T* __restrict__ A, long long lda, const T* __restrict__ Bw, int ldb,
                                                              int K, int N, long long M, T* __restrict__ out, long long ldo,
-                                                             const T* __restrict__ bias, int mode, int act, T* __restrict__ dout) {
+                                                             const T* __restrict__ bias, int mode, int act, T* __restrict__ dout,
+                                                             T actp) {
     __shared__ T red[3][32][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long m = (long long)blockIdx.x * 64 + lane;
@@ -272,9 +274,9 @@ __global__ __launch_bounds__(256) void layered_skinny_kernel(const T* __restrict
             if (n < N) {
                 const T v = ((acc[n] + red[0][n][lane]) + red[1][n][lane]) + red[2][n][lane];
                 if (mode == 0) {
-                    const T x = lg_act_f<T>(act, v + bias[n]);
+                    const T x = lg_act_f<T>(act, v + bias[n], actp);
                     out[(size_t)n * ldo + m] = x;
-                    dout[(size_t)n * ldo + m] = act_d1<T>(act, x);
+                    dout[(size_t)n * ldo + m] = act_d1<T>(act, x, actp);
                 } else {
                     out[(size_t)n * ldo + m] = v;
                 }
@@ -401,8 +403,9 @@ int gemm_ft(hipStream_t s, const GemmArgs& a) {
 
 template <typename T>
 int gemm(hipStream_t s, int mode, int act, const T* A, long long lda, const T* Bw, int ldb, T* C, long long ldc, T* D,
-         long long ldd, const T* bias, long long M, int N, int K, long long Rmod) {
+         long long ldd, const T* bias, long long M, int N, int K, long long Rmod, double actp = 0.0) {
     GemmArgs a{};
+    a.actp = actp;
     a.A = A; a.Bw = Bw; a.C = C; a.D = D; a.bias = bias;
     a.lda = lda; a.ldc = ldc; a.ldd = ldd; a.ldb = ldb;
     a.M = (int)M; a.N = N; a.K = K; a.mode = mode; a.act = act; a.Rmod = Rmod;
@@ -447,12 +450,13 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
             for (int l = 0; l < nl - 1; ++l) {
                 T* out = ws + ((l & 1) ? o.x1 : o.x0);
                 if ((rc = gemm<T>(s, LG_FORWARD, h.act[l], in, Rp, static_cast<const T*>(h.d_W[l]), h.dout[l], out, Rp, ws + o.d[l], Rp,
-                                  static_cast<const T*>(h.d_b[l]), R, h.dout[l], h.din[l], 0)))
+                                  static_cast<const T*>(h.d_b[l]), R, h.dout[l], h.din[l], 0, h.actp[l])))
                     return rc;
                 in = out;
             }
             hipLaunchKernelGGL(layered_skinny_kernel<T>, dim3((unsigned)((R + 63) / 64)), rb, 0, s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx,
-                               (long long)R, ws + o.f, Rp, static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl);
+                               (long long)R, ws + o.f, Rp, static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl,
+                               (T)h.actp[nl - 1]);
             NEMPC_HIP(hipGetLastError());
             // ---- reverse, all nx cotangents side by side: column k Rp + r is (cotangent k, row r)
             const long long ldg = (long long)nx * Rp;
@@ -474,7 +478,7 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                 const long long Mj = (long long)(nx - 1) * Rp + R;
                 hipLaunchKernelGGL(layered_skinny_kernel<T>, dim3((unsigned)((Mj + 63) / 64)), rb, 0, s, G, ldg,
                                    static_cast<const T*>(h.d_Wt[0]), h.din[0], h.dout[0], nin, Mj, ws + o.j, ldg,
-                                   static_cast<const T*>(nullptr), 2, 0, static_cast<T*>(nullptr));
+                                   static_cast<const T*>(nullptr), 2, 0, static_cast<T*>(nullptr), T(0));
                 NEMPC_HIP(hipGetLastError());
             }
             if (rk4) {

@@ -24,6 +24,7 @@ struct NetDev {
     RowGather gk;                    // where the nin window inputs of a row come from
     int din[NEMPC_MAX_LAYERS], dout[NEMPC_MAX_LAYERS];
     int act[NEMPC_MAX_LAYERS];       // NEMPC_ACT_* per layer
+    double actp[NEMPC_MAX_LAYERS];   // alpha of elu / leaky_relu layers
     const void* W[NEMPC_MAX_LAYERS];
     const void* Wt[NEMPC_MAX_LAYERS];
     const void* b[NEMPC_MAX_LAYERS];
@@ -91,7 +92,7 @@ __device__ void net_forward(const NetDev& net, T* ws, const WsOff& o, size_t R, 
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (jb + q < wout) out[(size_t)(jb + q) * R + r] = act_f<T>(net.act[l], acc[q]);
+                if (jb + q < wout) out[(size_t)(jb + q) * R + r] = act_f<T>(net.act[l], acc[q], (T)net.actp[l]);
         }
     }
 }
@@ -102,7 +103,7 @@ __device__ void net_jacobian_row(const NetDev& net, T* ws, const WsOff& o, size_
     const int nl = net.nl;
     T* jrow = ws + (size_t)(o.jst + k * net.nin) * R;
     // the output layer's own activation (1 for the usual linear output)
-    const T dLk = act_d1<T>(net.act[nl - 1], ws[(size_t)(o.fout + k) * R + r]);
+    const T dLk = act_d1<T>(net.act[nl - 1], ws[(size_t)(o.fout + k) * R + r], (T)net.actp[nl - 1]);
     if (nl == 1) {
         const T* W0 = (const T*)net.W[0];
         for (int d = 0; d < net.nin; ++d) jrow[(size_t)d * R + r] = W0[(size_t)d * net.dout[0] + k] * dLk;
@@ -120,7 +121,7 @@ __device__ void net_jacobian_row(const NetDev& net, T* ws, const WsOff& o, size_
             const T av = a[(size_t)j * R + r];
             T wv = WL[(size_t)j * net.dout[nl - 1] + k];
             if (!lin_out) wv *= dLk;
-            c[(size_t)j * R + r] = wv * act_d1<T>(net.act[nl - 2], av);
+            c[(size_t)j * R + r] = wv * act_d1<T>(net.act[nl - 2], av, (T)net.actp[nl - 2]);
         }
     }
     // hidden layers nl-2 .. 1 : cot_in[i] = (sum_j W_l[i][j] cot[j]) s'(z_{l-1}[i])
@@ -146,7 +147,7 @@ __device__ void net_jacobian_row(const NetDev& net, T* ws, const WsOff& o, size_
             for (int q = 0; q < 8; ++q) {
                 if (ib + q < win && (!first || ib + q < net.nin)) {   // extra inputs (tvp, p) get no Jacobian column
                     T v = acc[q];
-                    if (!first) v *= act_d1<T>(net.act[l - 1], aprev[(size_t)(ib + q) * R + r]);
+                    if (!first) v *= act_d1<T>(net.act[l - 1], aprev[(size_t)(ib + q) * R + r], (T)net.actp[l - 1]);
                     cn[(size_t)(ib + q) * R + r] = v;
                 }
             }
@@ -281,7 +282,7 @@ __device__ void net_hessian_contracted(const NetDev& net, T* ws, const WsOff& o,
                 } else {
                     for (int i = 0; i < win; ++i) {
                         const T av = aprev[(size_t)i * R + r];
-                        acc = fma(W[(size_t)i * wout + j], act_d1<T>(net.act[l - 1], av) * Pprev[(size_t)(i * nin + p) * R + r],
+                        acc = fma(W[(size_t)i * wout + j], act_d1<T>(net.act[l - 1], av, (T)net.actp[l - 1]) * Pprev[(size_t)(i * nin + p) * R + r],
                                   acc);
                     }
                 }
@@ -299,8 +300,8 @@ __device__ void net_hessian_contracted(const NetDev& net, T* ws, const WsOff& o,
         const T* P = ws + (size_t)(o.P + (nl - 1) * net.maxw * nin) * R;
         for (int k = 0; k < nx; ++k) {
             const T av = fo[(size_t)k * R + r];
-            const T s1 = act_d1<T>(net.act[nl - 1], av);
-            const T wgt = mult[(size_t)k * mstride] * (act_r2<T>(net.act[nl - 1], av) * s1);
+            const T s1 = act_d1<T>(net.act[nl - 1], av, (T)net.actp[nl - 1]);
+            const T wgt = mult[(size_t)k * mstride] * (act_r2<T>(net.act[nl - 1], av, (T)net.actp[nl - 1]) * s1);
             for (int p = 0; p < nin; ++p) {
                 const T pp = wgt * P[(size_t)(k * nin + p) * R + r];
                 for (int q = 0; q <= p; ++q)
@@ -327,8 +328,8 @@ __device__ void net_hessian_contracted(const NetDev& net, T* ws, const WsOff& o,
         T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;  // delta_l (wrt a_l)
         for (int j = 0; j < wout; ++j) {
             const T av = a[(size_t)j * R + r];
-            const T s1 = act_d1<T>(net.act[l], av);
-            const T wgt = c[(size_t)j * R + r] * (act_r2<T>(net.act[l], av) * s1);
+            const T s1 = act_d1<T>(net.act[l], av, (T)net.actp[l]);
+            const T wgt = c[(size_t)j * R + r] * (act_r2<T>(net.act[l], av, (T)net.actp[l]) * s1);
             for (int p = 0; p < nin; ++p) {
                 const T pp = wgt * P[(size_t)(j * nin + p) * R + r];
                 for (int q = 0; q <= p; ++q)
@@ -475,7 +476,7 @@ NetDev make_netdev(const Handle& h) {
     nd.ne = h.ne; nd.extra = h.d_extra;
     nd.gk = h.gather();
     for (int l = 0; l < h.nl; ++l) {
-        nd.din[l] = h.din[l]; nd.dout[l] = h.dout[l]; nd.act[l] = h.act[l];
+        nd.din[l] = h.din[l]; nd.dout[l] = h.dout[l]; nd.act[l] = h.act[l]; nd.actp[l] = h.actp[l];
         nd.W[l] = h.d_W[l]; nd.Wt[l] = h.d_Wt[l]; nd.b[l] = h.d_b[l];
     }
     return nd;

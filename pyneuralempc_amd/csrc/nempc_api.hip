@@ -323,6 +323,10 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
         if (cfg->widths[l] < 1) return fail(NEMPC_EINVAL, "nempc_create: layer width must be >= 1");
         if (cfg->activations[l] < 0 || cfg->activations[l] >= NEMPC_ACT_COUNT)
             return fail(NEMPC_EINVAL, "nempc_create: unknown activation code (NEMPC_ACT_*)");
+        if (cfg->activations[l] == NEMPC_ACT_ELU && !(cfg->act_param[l] > 0.0))
+            return fail(NEMPC_EINVAL, "nempc_create: elu needs act_param (alpha) > 0");
+        if (cfg->activations[l] == NEMPC_ACT_LEAKY_RELU && !(cfg->act_param[l] >= 0.0))
+            return fail(NEMPC_EINVAL, "nempc_create: leaky_relu needs act_param (alpha) >= 0");
     }
     if (cfg->max_batch < 1) return fail(NEMPC_EINVAL, "nempc_create: max_batch must be >= 1");
     if (cfg->n_extra < 0) return fail(NEMPC_EINVAL, "nempc_create: n_extra must be >= 0");
@@ -355,6 +359,7 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
         h->dout[l] = cfg->widths[l];
         if (l < h->nl - 1 && h->dout[l] > h->maxw) h->maxw = h->dout[l];
         h->act[l] = cfg->activations[l];
+        h->actp[l] = cfg->act_param[l];
     }
     // matrix-core kernels: one non-linear activation on every hidden layer, linear output
     h->mfma_act = -1;
@@ -362,6 +367,10 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
         h->mfma_act = h->act[0];
         for (int l = 1; l < h->nl - 1; ++l)
             if (h->act[l] != h->act[0]) h->mfma_act = -1;
+        // (the register-resident kernels are instantiated for tanh, relu, sigmoid, softplus and elu with alpha = 1)
+        if (h->mfma_act > NEMPC_ACT_ELU) h->mfma_act = -1;
+        for (int l = 0; l < h->nl - 1; ++l)
+            if (h->act[l] == NEMPC_ACT_ELU && h->actp[l] != 1.0) h->mfma_act = -1;
     }
     {
         // compute units of the device: every "fill the chip" launch geometry is sized from this, never from a literal.

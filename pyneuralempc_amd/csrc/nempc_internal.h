@@ -117,6 +117,7 @@ struct Handle {
     }
     int din[NEMPC_MAX_LAYERS]{}, dout[NEMPC_MAX_LAYERS]{};
     int act[NEMPC_MAX_LAYERS]{};   // NEMPC_ACT_* per layer (cfg.activations)
+    double actp[NEMPC_MAX_LAYERS]{};   // alpha of elu / leaky_relu layers (cfg.act_param)
     int mfma_act = -1;             // the one hidden activation when the matrix-core kernels can take the network
                                    // (same non-linear activation on every hidden layer, linear output layer), else -1
     int maxw = 0;

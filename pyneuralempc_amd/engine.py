@@ -18,7 +18,8 @@ _TORCH_DTYPES = {torch.float64: _lib.F64, torch.float32: _lib.F32}
 def resolve_activations(activations, n_layers):
     """Per-layer activation names of an n_layers-deep dense stack.  None: tanh hidden layers and a linear output layer
     (the reference's nn_model.h5); one name: that activation on every hidden layer, linear output; a sequence: one name
-    per layer, the output layer included.  Names as Keras spells them (_lib.ACTIVATION_IDS)."""
+    per layer, the output layer included.  Names as Keras spells them (_lib.ACTIVATION_IDS); "elu:0.5" / "leaky_relu:0.1"
+    carry their alpha (_lib.split_activation)."""
     if activations is None:
         names = ["tanh"] * (n_layers - 1) + ["linear"]
     elif isinstance(activations, str):
@@ -28,9 +29,7 @@ def resolve_activations(activations, n_layers):
         if len(names) != n_layers:
             raise ValueError(f"activations: expected one name per dense layer ({n_layers}), got {len(names)}")
     for a in names:
-        if a not in _lib.ACTIVATION_IDS:
-            raise NotImplementedError(f"activation '{a}' is not supported on the device path "
-                                      f"(supported: {', '.join(_lib.ACTIVATION_IDS)})")
+        _lib.split_activation(a)
     return names
 
 
@@ -103,7 +102,8 @@ class CallbackEngine:
         cfg.n_layers = len(self._weights)
         for i, w in enumerate(self._weights):
             cfg.widths[i] = w.shape[1]
-            cfg.activations[i] = _lib.ACTIVATION_IDS[self.activations[i]]
+            name, par = _lib.split_activation(self.activations[i])
+            cfg.activations[i], cfg.act_param[i] = _lib.ACTIVATION_IDS[name], par
         cfg.max_batch = max_batch
         cfg.kernel = _lib.KERNEL_NAMES[self.kernel] if isinstance(self.kernel, str) else int(self.kernel)
         cfg.n_extra = self.n_extra

@@ -3,8 +3,9 @@
 The reference wraps a live Keras model -- any feed-forward one (model/tensorflow.py:8-29) -- and differentiates it with
 tf.GradientTape on the CPU.  Here the Keras object is only *read*: its Dense kernels / biases / activation names are
 copied once and the network is evaluated by the HIP kernels.  Dense stacks with any of the activations linear, tanh,
-relu, sigmoid, softplus, elu (per layer, the output layer included) are taken; anything else -- other layer types,
-other activations -- is rejected loudly."""
+relu, sigmoid, softplus, elu(alpha), leaky_relu(alpha), selu (per layer, the output layer included; stand-alone Activation /
+ReLU / LeakyReLU / ELU layers fold into the Dense in front of them) are taken; anything else -- other layer types, the
+non-monotone activations swish / gelu -- is rejected loudly."""
 import numpy as np
 
 from .mlp import MLPModel
@@ -36,16 +37,20 @@ def _standalone_activation(layer, i):
     if kind == "Activation":
         return _activation_name(layer)
     if kind == "ReLU":
-        if (getattr(layer, "max_value", None) is not None or float(getattr(layer, "negative_slope", 0.0) or 0.0) != 0.0
-                or float(getattr(layer, "threshold", 0.0) or 0.0) != 0.0):
-            raise NotImplementedError(f"layer {i}: ReLU with max_value / negative_slope / threshold is unsupported on the device path")
-        return "relu"
+        if getattr(layer, "max_value", None) is not None or float(getattr(layer, "threshold", 0.0) or 0.0) != 0.0:
+            raise NotImplementedError(f"layer {i}: ReLU with max_value / threshold is unsupported on the device path")
+        slope = float(getattr(layer, "negative_slope", 0.0) or 0.0)
+        return "relu" if slope == 0.0 else f"leaky_relu:{slope!r}"
     if kind == "ELU":
-        if float(getattr(layer, "alpha", 1.0)) != 1.0:
-            raise NotImplementedError(f"layer {i}: elu with alpha != 1 is unsupported on the device path")
-        return "elu"
+        alpha = float(getattr(layer, "alpha", 1.0))
+        return "elu" if alpha == 1.0 else f"elu:{alpha!r}"
+    if kind == "LeakyReLU":
+        alpha = getattr(layer, "negative_slope", None)
+        if alpha is None:
+            alpha = getattr(layer, "alpha", 0.3)                     # (Keras 2 spelling; both default to 0.3)
+        return f"leaky_relu:{float(alpha)!r}"
     raise NotImplementedError(f"layer {i}: parameter-less layer '{kind}' is unsupported on the device path (it would be "
-                              "dropped from the network); supported: Dense, Activation, ReLU, ELU(alpha=1) and the "
+                              "dropped from the network); supported: Dense, Activation, ReLU, LeakyReLU, ELU and the "
                               "inference-identity layers " + ", ".join(sorted(_IDENTITY_LAYERS)))
 
 
@@ -70,9 +75,10 @@ def extract_dense_stack(keras_model):
             if activations[-1] != "linear":
                 raise NotImplementedError(f"layer {i}: activation '{name}' on top of a Dense layer that already applies "
                                           f"'{activations[-1]}' is unsupported on the device path")
-            if name not in _lib.ACTIVATION_IDS:
-                raise NotImplementedError(f"layer {i}: activation '{name}' unsupported on the device path (supported: "
-                                          f"{', '.join(_lib.ACTIVATION_IDS)})")
+            try:
+                _lib.split_activation(name)
+            except NotImplementedError as e:
+                raise NotImplementedError(f"layer {i}: {e}")
             activations[-1] = name
             continue
         if len(params) == 1 and np.ndim(params[0]) == 2:          # Dense(use_bias=False)
@@ -80,11 +86,12 @@ def extract_dense_stack(keras_model):
         if len(params) != 2 or np.ndim(params[0]) != 2 or np.ndim(params[1]) != 1:
             raise NotImplementedError("Only Dense layers (kernel, bias) are supported on the device path")
         name = _activation_name(layer)
-        if name not in _lib.ACTIVATION_IDS:
-            raise NotImplementedError(f"layer {i}: activation '{name}' unsupported on the device path (supported: "
-                                      f"{', '.join(_lib.ACTIVATION_IDS)})")
         if name == "elu" and float(getattr(layer.activation, "alpha", 1.0)) != 1.0:
-            raise NotImplementedError(f"layer {i}: elu with alpha != 1 is unsupported on the device path")
+            name = f"elu:{float(layer.activation.alpha)!r}"
+        try:
+            _lib.split_activation(name)
+        except NotImplementedError as e:
+            raise NotImplementedError(f"layer {i}: {e}")
         weights.append(np.asarray(params[0], dtype=np.float64))
         biases.append(np.asarray(params[1], dtype=np.float64))
         activations.append(name)

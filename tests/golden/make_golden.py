@@ -290,6 +290,10 @@ CASES = {
     "deep4_c2": (2, 1, [64, 64, 64, 64], 6, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True),
     "deep5_mixed_rk4": (2, 1, [144, 96, 96, 40, 24], 5, orc.RK4, 0.1, None, 2, True, 0, 0,
                         ["tanh", "relu", "tanh", "softplus", "elu", "linear"]),
+    # the parameterised / remaining monotone activations (ABI v7): leaky_relu(alpha), selu, elu(alpha != 1)
+    "act_param_box": (2, 1, [32, 24, 16], 9, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True, 0, 0,
+                      ["leaky_relu:0.1", "selu", "elu:0.5", "leaky_relu"]),
+    "act_selu_rk4": (2, 1, [48, 48], 7, orc.RK4, 0.2, None, 2, True, 0, 0, "selu"),
 }
 
 
@@ -302,13 +306,17 @@ def check_network_derivatives_by_ad(net, n_in, seed=11, rows=3, with_hess=True):
     Wt = [torch.tensor(w, dtype=torch.float64) for w in net.W]
     bt = [torch.tensor(b, dtype=torch.float64) for b in net.b]
 
-    tact = {"linear": lambda z: z, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid,
-            "softplus": torch.nn.functional.softplus, "elu": torch.nn.functional.elu}
+    def tact(spec):
+        name, par = orc.act_split(spec)
+        F = torch.nn.functional
+        return {"linear": lambda z: z, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid, "softplus": F.softplus,
+                "elu": lambda z: F.elu(z, alpha=par), "leaky_relu": lambda z: F.leaky_relu(z, negative_slope=par),
+                "selu": F.selu}[name]
 
     def f(xi):
         a = xi
         for w, b, name in zip(Wt, bt, net.act):
-            a = tact[name](a @ w + b)
+            a = tact(name)(a @ w + b)
         return a
 
     xi = np.random.default_rng(seed).normal(size=(rows, n_in))
@@ -368,7 +376,9 @@ def build_case(ref, plugins, name, spec):
     for i, (w, b) in enumerate(zip(net.W, net.b)):
         out[f"W{i}"], out[f"b{i}"] = w, b
     if activations is not None:
-        out["activations"] = np.array([orc.ACT_IDS[a] for a in net.act])     # NEMPC_ACT_* per layer
+        out["activations"] = np.array([orc.ACT_IDS[orc.act_split(a)[0]] for a in net.act])     # NEMPC_ACT_* per layer
+        if any(":" in a for a in net.act):
+            out["act_param"] = np.array([orc.act_split(a)[1] for a in net.act])               # alpha of elu / leaky_relu
 
     f, grad, g, jac, hvals, hdense = [], [], [], [], [], []
     g_int, j_int = [], []

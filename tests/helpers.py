@@ -12,7 +12,7 @@ CASE_NAMES = ["c1_discret", "c2_discret", "c2_unity", "c2_rk4", "c3_rk4", "c3_di
 # activation family: uniform hidden activation + linear output (every kernel family), and per-layer mixes incl. the
 # output layer (generic kernel only)
 ACT_UNIFORM_NAMES = [f"act_{a}_{c}" for a in ("relu", "sigmoid", "softplus", "elu") for c in ("c2", "c3")]
-ACT_MIXED_NAMES = ["act_mixed_box", "act_mixed_rk4", "act_linear_hidden"]
+ACT_MIXED_NAMES = ["act_mixed_box", "act_mixed_rk4", "act_linear_hidden", "act_param_box", "act_selu_rk4"]
 # networks only the layer-at-a-time GEMM path (and the generic kernel) take: width > 128, more than three hidden layers
 WIDE_DEEP_NAMES = ["wide256_c2", "deep4_c2", "deep5_mixed_rk4"]
 ROLLING_NAMES = ["roll2_discret", "roll3_unity_rev", "roll3_discret_rev", "roll4_wide", "roll2_tvp_p", "roll4_short"]
@@ -48,7 +48,10 @@ def case_activations(d):
     """Per-layer activation names of a golden case (None = the default tanh ... linear stack)."""
     if "activations" not in d:
         return None
-    return [orc.ACTIVATIONS[int(c)] for c in d["activations"]]
+    names = [orc.ACTIVATIONS[int(c)] for c in d["activations"]]
+    if "act_param" in d:            # alpha of the elu / leaky_relu layers ("name:value" specs)
+        names = [f"{n}:{float(p)!r}" if n in orc.ACT_DEFAULT_PARAM else n for n, p in zip(names, d["act_param"])]
+    return names
 
 
 def oracle_problem(d, W, b, i=0):

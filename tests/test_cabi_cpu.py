@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
 def test_config_struct_matches_header_layout():
     from pyneuralempc_amd import _lib
     # 8 int32 + 8 widths + 5 int32 = 21 int32 (84 B) -> padded to 88, + double = 96, + 8 activation codes = 128
-    assert ctypes.sizeof(_lib.NempcConfig) == 128
+    assert ctypes.sizeof(_lib.NempcConfig) == 192       # (ABI v7: + 8 doubles of per-layer activation parameters)
+    assert _lib.NempcConfig.act_param.offset == 128
     assert _lib.NempcConfig.rolling_window.offset == 76
     assert _lib.NempcConfig.DT.offset == 88
     assert _lib.NempcConfig.activations.offset == 96
@@ -54,9 +55,13 @@ def test_create_validates_before_touching_the_device_and_fails_loudly_without_gp
     cfg.widths[0] = 3          # last width != nx
     assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     cfg.widths[0] = 2
-    cfg.activations[0] = 6            # no such activation
+    cfg.activations[0] = 8            # no such activation
     assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"activation" in lib.nempc_last_error()
-    cfg.activations[0] = 0
+    cfg.activations[0], cfg.act_param[0] = 5, 0.0          # elu needs alpha > 0
+    assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"alpha" in lib.nempc_last_error()
+    cfg.activations[0], cfg.act_param[0] = 6, -0.5         # leaky_relu needs alpha >= 0
+    assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"alpha" in lib.nempc_last_error()
+    cfg.activations[0], cfg.act_param[0] = 0, 0.0
     cfg.max_batch = 1
     cfg.integrator, cfg.DT = 2, 0.0   # RK4 without DT
     assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1

@@ -339,8 +339,8 @@ def test_sparse_contract_fused_launch(name):
         # wherever the dense contract is one launch (fixed-shape or cooperative kernel), the sparse one is too; shapes only
         # the wave-per-tile kernel serves (fp64 3 x 128: the slices do not fit registers) keep the row + assembly launches
         expect = {"rows_coopfx_kernel": "rows_coopfx_kernel+sparse", "rows_coop_kernel+dense": "rows_coop_kernel+sparse"}
-        if k_dense in expect:
-            assert eng.last_row_kernel == expect[k_dense], (name, dtype)
+        if k_dense in expect:       # (fp32 with n % 4 != 0: no one-launch DENSE rows on the compiled shape, the band values still are)
+            assert eng.last_row_kernel in (expect[k_dense], "rows_coopfx_kernel+sparse"), (name, dtype)
         if name in ("c2_discret", "c5_box", "c1_discret", "c3_rk4") and not (name == "c3_rk4" and dtype == torch.float64):
             assert k_dense in expect, (name, dtype, k_dense)
         rows, cols = eng.jac_structure()

@@ -155,6 +155,9 @@ def test_keras_adapter_validation_without_device():
         pass
 
     class LeakyReLU(Dropout):
+        negative_slope = 0.3
+
+    class Softmax(Dropout):
         pass
 
     split = Fake([InputLayer(), Layer(np.ones((3, 8)), np.zeros(8), linear), Activation(tanh), Dropout(),
@@ -163,16 +166,30 @@ def test_keras_adapter_validation_without_device():
     W, b, acts = extract_dense_stack(split)
     assert len(W) == 4 and acts == ["tanh", "relu", "elu", "linear"]
     assert KerasTFModel(split, x_dim=2, u_dim=1).activations == acts
-    with pytest.raises(NotImplementedError, match="LeakyReLU"):
-        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), linear), LeakyReLU(),
+    with pytest.raises(NotImplementedError, match="Softmax"):
+        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), linear), Softmax(),
                                   Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
+    # the monotone parameterised family: LeakyReLU / ELU layers and ReLU(negative_slope) carry their alpha in the name
+    half = ELU()
+    half.alpha = 0.5
+    W, b, acts = extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), linear), LeakyReLU(),
+                                           Layer(np.ones((8, 8)), np.zeros(8), linear), half,
+                                           Layer(np.ones((8, 8)), np.zeros(8), "selu"),
+                                           Layer(np.ones((8, 2)), np.zeros(2), "leaky_relu")], 3, 2))
+    assert acts == ["leaky_relu:0.3", "elu:0.5", "selu", "leaky_relu"]
+    with pytest.raises(NotImplementedError, match="swish"):
+        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), "swish"), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
     with pytest.raises(NotImplementedError, match="already applies"):
         extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), tanh), Activation(relu),
                                   Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
     leaky = ReLU()
     leaky.negative_slope = 0.1
-    with pytest.raises(NotImplementedError, match="negative_slope"):
-        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), linear), leaky,
+    assert extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), linear), leaky,
+                                     Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))[2] == ["leaky_relu:0.1", "linear"]
+    capped = ReLU()
+    capped.max_value = 6.0
+    with pytest.raises(NotImplementedError, match="max_value"):
+        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), linear), capped,
                                   Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
 
     class NoBias:
@@ -188,8 +205,7 @@ def test_keras_adapter_validation_without_device():
 
     class Elu2:
         name, alpha = "elu", 0.5
-    with pytest.raises(NotImplementedError, match="alpha"):
-        KerasTFModel(Fake([Layer(np.ones((3, 2)), np.zeros(2), Elu2())], 3, 2), x_dim=2, u_dim=1)
+    assert KerasTFModel(Fake([Layer(np.ones((3, 2)), np.zeros(2), Elu2())], 3, 2), x_dim=2, u_dim=1).activations == ["elu:0.5"]
     rnn = Fake(good.layers, 3, 2)
     rnn.input_shape = (None, 5, 3)
     with pytest.raises(NotImplementedError, match="Recurrent"):

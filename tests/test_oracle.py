@@ -112,8 +112,12 @@ def test_bounds_and_warm_start_against_reference():
 
 
 # ---- the network derivative: independent AD (torch.func, fp64) ----
-_TORCH_ACT = {"linear": lambda z: z, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid,
-              "softplus": torch.nn.functional.softplus, "elu": torch.nn.functional.elu}
+def _torch_act(spec):
+    """torch's OWN activation for an oracle activation spec ("name" | "name:alpha")"""
+    name, par = orc.act_split(spec)
+    F = torch.nn.functional
+    return {"linear": lambda z: z, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid, "softplus": F.softplus,
+            "elu": lambda z: F.elu(z, alpha=par), "leaky_relu": lambda z: F.leaky_relu(z, negative_slope=par), "selu": F.selu}[name]
 
 
 def _torch_net(W, b, act=None):
@@ -124,13 +128,15 @@ def _torch_net(W, b, act=None):
     def f(xi):
         a = xi
         for w, bb, name in zip(Wt, bt, act):
-            a = _TORCH_ACT[name](a @ w + bb)
+            a = _torch_act(name)(a @ w + bb)
         return a
     return f
 
 
 @pytest.mark.parametrize("acts", ["relu", "sigmoid", "softplus", "elu", ["relu", "softplus", "sigmoid"],
-                                  ["elu", "sigmoid", "tanh"], ["linear", "tanh", "softplus"], ["sigmoid", "elu", "elu"]])
+                                  ["elu", "sigmoid", "tanh"], ["linear", "tanh", "softplus"], ["sigmoid", "elu", "elu"],
+                                  "selu", "leaky_relu", "elu:0.5", ["leaky_relu:0.05", "selu", "elu:1.7"],
+                                  ["selu", "leaky_relu:0.3", "selu"]])
 def test_activation_family_derivatives_vs_torch_ad(acts):
     """Every activation of the device family, uniform on the hidden layers and mixed per layer with a non-linear output
     layer: the oracle's first and second derivatives -- written from the layer OUTPUT a = s(z), as the kernels do -- against
@@ -161,6 +167,11 @@ def test_activation_functions_at_their_edges():
         assert np.isnan(orc.act_f(name, np.array([np.nan]))[0]), name
     assert orc.act_d1("relu", orc.act_f("relu", np.array([0.0])))[0] == 0.0          # TensorFlow's convention at the kink
     assert orc.act_d1("elu", orc.act_f("elu", np.array([0.0])))[0] == 1.0
+    assert orc.act_d1("elu:0.5", orc.act_f("elu:0.5", np.array([0.0])))[0] == 0.5
+    assert orc.act_d1("leaky_relu:0.1", orc.act_f("leaky_relu:0.1", np.array([0.0])))[0] == 0.1    # tf.nn.leaky_relu's gradient at 0
+    for bad in ("elu:0", "elu:-1", "leaky_relu:-0.1", "tanh:2", "swish", "gelu"):
+        with pytest.raises(ValueError):
+            orc.act_split(bad)
     np.testing.assert_allclose(orc.act_d1("softplus", orc.act_f("softplus", z)), 1.0 / (1.0 + np.exp(-np.clip(z, -700, 700))),
                                rtol=1e-12, atol=1e-300)
 
