@@ -621,6 +621,16 @@ class Rank:
                 print(json.dumps(out), flush=True)
                 os.dup2(2, 1)
             return
+        if args.only_sparse:
+            # profiling mode: the sparse-contract leg of one configuration alone (rocprofv3 kernel trace of ONE launch shape)
+            res = self.run_config(args.config, 5, 2, headline=False, kernel=args.kernel)
+            out = {"config": {"workload": res["cfg"]["label"], "batch_per_gpu": res["B"]}, "sparse_contract": self.sparse_leg(res)}
+            if self.rank == 0:
+                sys.stdout.flush()
+                os.dup2(self.saved_stdout, 1)
+                print(json.dumps(out), flush=True)
+                os.dup2(2, 1)
+            return
         res = self.run_config(args.config, args.steps, args.warmup, headline=True, kernel=args.kernel)
         cfg, B, eng, wall = res["cfg"], res["B"], res["eng"], res["wall"]
         primary, secondary, rf_extra = self.roofline_of(res)
@@ -916,6 +926,8 @@ def main():
                          "kernel trace of this command averages the headline launch alone")
     ap.add_argument("--only-hessian", action="store_true",
                     help="profiling mode: the Hessian-callback legs (exact + Gauss-Newton) of --config only")
+    ap.add_argument("--only-sparse", action="store_true",
+                    help="profiling mode: the sparse-contract leg (f, grad, g, band values in one launch) of --config only")
     ap.add_argument("--hessian", action="store_true", help="(kept for old command lines: the Hessian legs run by default)")
     ap.add_argument("--no-hessian", action="store_true", help="skip the Hessian-callback legs (exact Lagrangian + Gauss-Newton)")
     ap.add_argument("--evals-per-mpc-step", type=int, default=17,
@@ -923,7 +935,7 @@ def main():
     ap.add_argument("--prime-ms", type=float, default=40.0,
                     help="untimed run of the headline step before the warm-up steps, to reach the sustained clock (0: off)")
     ap.add_argument("--solver-iters", type=int, default=64)
-    ap.add_argument("--pmc-file", default="r03_c2_b1024_pmc.json")
+    ap.add_argument("--pmc-file", default="r04_c2_b1024_pmc.json")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -20,6 +20,8 @@ for f in newest(f"{src}_trace/*/*_kernel_stats.csv"):
     shutil.copy(f, os.path.join(out, f"{tag}_kernel_stats.csv"))
 for f in newest(f"{src}_hess_trace/*/*_kernel_stats.csv"):        # bench.py --only-hessian (the Hessian-callback legs alone)
     shutil.copy(f, os.path.join(out, f"{tag}_hess_kernel_stats.csv"))
+for f in newest(f"{src}_sparse_trace/*/*_kernel_stats.csv"):      # bench.py --only-sparse (the sparse-contract leg alone)
+    shutil.copy(f, os.path.join(out, f"{tag}_sparse_kernel_stats.csv"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for kind in ("fetch", "write", "mfma"):
     if not glob.glob(f"{src}_{kind}"):
