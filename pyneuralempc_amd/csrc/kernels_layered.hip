@@ -409,9 +409,9 @@ int gemm(hipStream_t s, int mode, int act, const T* A, long long lda, const T* B
     a.A = A; a.Bw = Bw; a.C = C; a.D = D; a.bias = bias;
     a.lda = lda; a.ldc = ldc; a.ldd = ldd; a.ldb = ldb;
     a.M = (int)M; a.N = N; a.K = K; a.mode = mode; a.act = act; a.Rmod = Rmod;
-    // the widest block the layer fills: the activations are then read once per layer (NEMPC_LAYERED_FT: A/B knob)
+    // 64-feature blocks (FT = 1) measured fastest at every width (LgShape above); NEMPC_LAYERED_FT = 2 | 4: A/B knob
     static const int ft_env = [] { const char* e = getenv("NEMPC_LAYERED_FT"); return e ? atoi(e) : 0; }();
-    const int ft = ft_env ? ft_env : (N > 64 ? 2 : 1);
+    const int ft = ft_env ? ft_env : 1;
     if (ft >= 4) return gemm_ft<T, 4>(s, a);
     if (ft >= 2) return gemm_ft<T, 2>(s, a);
     return gemm_ft<T, 1>(s, a);
