@@ -162,22 +162,44 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         const bool more = ch + 1 < nchunks;
+#ifndef NEMPC_LG_EXP_NOLOAD       // (timing experiments, tools/lg_limiter_exp.sh: never defined in the shipped build)
         if (more) load_chunk(ch + 1);
+#endif
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             T af[FT], bf[4];
+#ifdef NEMPC_LG_EXP_NOLDS
+#pragma unroll
+            for (int fn = 0; fn < FT; ++fn) af[fn] = T(1) + T(ks);
+#pragma unroll
+            for (int rm = 0; rm < 4; ++rm) bf[rm] = T(2) + T(rm);
+#else
 #pragma unroll
             for (int fn = 0; fn < FT; ++fn) af[fn] = Ws(buf, 4 * ks + q, fb + 16 * fn + c);
 #pragma unroll
             for (int rm = 0; rm < 4; ++rm) bf[rm] = As(buf, 4 * ks + q, 16 * rm + c);
+#endif
 #pragma unroll
             for (int fn = 0; fn < FT; ++fn)
 #pragma unroll
                 for (int rm = 0; rm < 4; ++rm) acc[fn][rm] = Ops::mma(af[fn], bf[rm], acc[fn][rm]);
         }
+#ifndef NEMPC_LG_EXP_NOLOAD
         if (more) store_chunk(buf ^ 1);
+#endif
+#ifndef NEMPC_LG_EXP_NOBARRIER
         __syncthreads();
+#endif
     }
+#ifdef NEMPC_LG_EXP_NOEPI
+    if (acc[0][0][0] == T(12345.678)) static_cast<T*>(a.C)[0] = acc[0][1][1] + acc[0][2][2] + acc[0][3][3];
+    return;
+#endif
+    // Where a 256 x 256 reverse product (B*H = 20480, fp64; 68 us at the matrix peak) spends its 148 us, by leaving parts out
+    // (gpurun_out/r04_lg_limiter.txt): no epilogue 110 us, no global loads 118, no LDS reads 143, no barrier 149, none of
+    // loads / LDS / barrier 125.  The epilogue's dependent round trip for s'(z) at the end of every workgroup is the largest
+    // piece; requesting those values under the last chunk's matrix instructions costs 32 more registers (occupancy 3 instead
+    // of 4-5) and measured no better overall (355 vs 360 us for the whole 2 x 256 evaluation, 34.5 vs 32.4 ms at 4 x 512).
 
     // ---- epilogue: register r of lane (c, q) is feature row(q, r) of the 16 x 16 tile, row c
     T* __restrict__ C = static_cast<T*>(a.C);
@@ -228,49 +250,53 @@ __global__ void layered_gather_kernel(RowGather gk, int nin, int ne, const T* __
     for (int j = 0; j < ne; ++j) xi[(size_t)(nin + j) * Rp + r] = extra[(size_t)gr * ne + j];
 }
 
-// N <= 32 outputs per column on the vector unit: out^T[n][m] = epi(sum_k A^T[k][m] Bw[k][n]).  mode 0: the network's
+// N <= NMAX outputs per column on the vector unit: out^T[n][m] = epi(sum_k A^T[k][m] Bw[k][n]).  mode 0: the network's
 // output layer (bias, activation; f and s'(z_L) stored), mode 2: plain (the last reverse step onto the inputs).
-// A block is 64 columns x 4 waves; wave w sums k = w, w + 4, ... (eight loads in flight per lane), the four partial sums
-// meet in LDS -- a thread per column walking all of K alone was a chain of K dependent-latency loads (141 us for K = 256).
-template <typename T>
+// A block is 64 columns x 4 waves; wave w sums k = w, w + 4, ... with sixteen loads in flight per lane, the four partial
+// sums meet in LDS.  (A thread per column walking all of K alone was a chain of K dependent-latency loads: 141 us for
+// K = 256; eight loads in flight and 32 accumulators for 3 outputs: 60 us, 1.4 TB/s; this form: ~30 us.)  NMAX = 4 | 16 | 32
+// keeps the accumulator count -- and with it the occupancy -- at what the layer needs.
+template <typename T, int NMAX>
 __global__ __launch_bounds__(256) void layered_skinny_kernel(const T* __restrict__ A, long long lda, const T* __restrict__ Bw, int ldb,
                                                              int K, int N, long long M, T* __restrict__ out, long long ldo,
                                                              const T* __restrict__ bias, int mode, int act, T* __restrict__ dout,
                                                              T actp) {
-    __shared__ T red[3][32][64];
+    __shared__ T red[3][NMAX][64];
+    constexpr int UN = 16;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long m = (long long)blockIdx.x * 64 + lane;
     const bool live = m < M;
-    T acc[32];
+    const long long mc = live ? m : M - 1;          // (clamped: the loads stay in range, the result is not stored)
+    T acc[NMAX];
 #pragma unroll
-    for (int n = 0; n < 32; ++n) acc[n] = T(0);
-    for (int k0 = w; k0 < K; k0 += 32) {
-        T x[8];
+    for (int n = 0; n < NMAX; ++n) acc[n] = T(0);
+    for (int k0 = w; k0 < K; k0 += 4 * UN) {
+        T x[UN];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const int k = k0 + 4 * u;
-            x[u] = (live && k < K) ? A[(size_t)k * lda + m] : T(0);
+            x[u] = k < K ? A[(size_t)k * lda + mc] : T(0);
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const int k = k0 + 4 * u;
             if (k < K) {
                 const T* wrow = Bw + (size_t)k * ldb;
 #pragma unroll
-                for (int n = 0; n < 32; ++n)
+                for (int n = 0; n < NMAX; ++n)
                     if (n < N) acc[n] = fma(x[u], wrow[n], acc[n]);
             }
         }
     }
     if (w > 0) {
 #pragma unroll
-        for (int n = 0; n < 32; ++n)
+        for (int n = 0; n < NMAX; ++n)
             if (n < N) red[w - 1][n][lane] = acc[n];
     }
     __syncthreads();
     if (w == 0 && live) {
 #pragma unroll
-        for (int n = 0; n < 32; ++n)
+        for (int n = 0; n < NMAX; ++n)
             if (n < N) {
                 const T v = ((acc[n] + red[0][n][lane]) + red[1][n][lane]) + red[2][n][lane];
                 if (mode == 0) {
@@ -282,6 +308,17 @@ __global__ __launch_bounds__(256) void layered_skinny_kernel(const T* __restrict
                 }
             }
     }
+}
+
+template <typename T>
+int skinny(hipStream_t s, const T* A, long long lda, const T* Bw, int ldb, int K, int N, long long M, T* out, long long ldo,
+           const T* bias, int mode, int act, T* dout, T actp) {
+    const dim3 grid((unsigned)((M + 63) / 64)), block(256);
+    if (N <= 4) hipLaunchKernelGGL((layered_skinny_kernel<T, 4>), grid, block, 0, s, A, lda, Bw, ldb, K, N, M, out, ldo, bias, mode, act, dout, actp);
+    else if (N <= 16) hipLaunchKernelGGL((layered_skinny_kernel<T, 16>), grid, block, 0, s, A, lda, Bw, ldb, K, N, M, out, ldo, bias, mode, act, dout, actp);
+    else hipLaunchKernelGGL((layered_skinny_kernel<T, 32>), grid, block, 0, s, A, lda, Bw, ldb, K, N, M, out, ldo, bias, mode, act, dout, actp);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
 }
 
 // seed of the reverse sweep: G^T[j][k Rp + r] = W_last[j][k] s_L'(z_L)[k][r] D_{L-2}^T[j][r]  (all nx cotangents side by side)
@@ -454,10 +491,9 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                     return rc;
                 in = out;
             }
-            hipLaunchKernelGGL(layered_skinny_kernel<T>, dim3((unsigned)((R + 63) / 64)), rb, 0, s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx,
-                               (long long)R, ws + o.f, Rp, static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl,
-                               (T)h.actp[nl - 1]);
-            NEMPC_HIP(hipGetLastError());
+            if ((rc = skinny<T>(s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, (long long)R, ws + o.f, Rp,
+                                static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl, (T)h.actp[nl - 1])))
+                return rc;
             // ---- reverse, all nx cotangents side by side: column k Rp + r is (cotangent k, row r)
             const long long ldg = (long long)nx * Rp;
             T* G = ws + o.g0;
@@ -476,10 +512,9 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
             // J^T[d][k Rp + r] = sum_o W_0[d][o] G_0[o][.]: operand W_0^T (out, in) = d_Wt[0], only the nin decision inputs
             {
                 const long long Mj = (long long)(nx - 1) * Rp + R;
-                hipLaunchKernelGGL(layered_skinny_kernel<T>, dim3((unsigned)((Mj + 63) / 64)), rb, 0, s, G, ldg,
-                                   static_cast<const T*>(h.d_Wt[0]), h.din[0], h.dout[0], nin, Mj, ws + o.j, ldg,
-                                   static_cast<const T*>(nullptr), 2, 0, static_cast<T*>(nullptr), T(0));
-                NEMPC_HIP(hipGetLastError());
+                if ((rc = skinny<T>(s, G, ldg, static_cast<const T*>(h.d_Wt[0]), h.din[0], h.dout[0], nin, Mj, ws + o.j, ldg,
+                                    static_cast<const T*>(nullptr), 2, 0, static_cast<T*>(nullptr), T(0))))
+                    return rc;
             }
             if (rk4) {
                 hipLaunchKernelGGL(layered_rk4_kernel<T>, rg, rb, 0, s, st, nx, nin, cdt, (st == 0 || st == 3) ? T(1) : T(2), ws + o.f,
