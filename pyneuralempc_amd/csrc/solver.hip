@@ -55,7 +55,11 @@ constexpr int INFO_LAM = 0, INFO_STEP = 1, INFO_AMAX = 2, INFO_G1 = 3, INFO_GINF
               INFO_RESTARTS = 7,
               INFO_LSK = 8, INFO_LSA = 9,   // deferred backtracking: rejected trials in a row, step length to retry with,
               INFO_LSR = 10,                // Riccati restarts of the iteration that opened the search (sticky over retries)
-              INFO_N = 11;
+              // non-monotone acceptance: the merit values of the last two accepted iterates, the penalty / barrier parameter
+              // they were computed under, how many of them are valid
+              INFO_PH1 = 11, INFO_PH2 = 12, INFO_PH3 = 13, INFO_PH4 = 14, INFO_PHNU = 15, INFO_PHMU = 16, INFO_PHN = 17,
+              INFO_PHUP = 18,               // 1: the last accepted step went uphill in the merit (watchdog, see solver_merit_body)
+              INFO_N = 19;
 
 struct SolverArgs {
     int B, H, nx, nu, nin, n, m;
@@ -99,6 +103,7 @@ struct SolverArgs {
                            // one attempt's region (gains, value function, temporaries) in the problem's LDS block
     double tol_g, tol_step, mu_min, mu_factor;
     double armijo_slack;                                                 // relative slack of the Armijo test (see merit kernel)
+    int nonmono;                                                         // merit values of previous iterates the test may refer to (0: monotone)
     double reg_relax;                                                    // factor by which the Levenberg term is relaxed after a clean sweep
     int max_ls;                                                          // halvings before the next LQ solve is damped
 };
@@ -1818,8 +1823,40 @@ __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* 
     // the slack absorbs the rounding of the merit value itself (f is a sum of ~n terms in T): without a dtype-sized one
     // an fp32 iterate close to its solution fails the test on noise, halves its step six times and gets damped
     const T slack = (T)a.armijo_slack;
-    const bool ok = (phit == phit) && phit <= ph0 + T(1e-4) * al * fmin(drb, T(0)) + slack * fabs(ph0);
+    // Non-monotone reference (Grippo-Lampariello-Lucidi): the trial point has to improve on the LARGEST merit value of the
+    // last iterates, not on the current one.  Near a feasible iterate a full SQP step moves along the constraint manifold
+    // and raises the l1 merit through the second-order constraint violation times a penalty that tracks the multipliers
+    // (order 250-700 at configs[2] dims): the monotone test cuts such steps to 2-5 % of their length for dozens of
+    // iterations -- the Maratos effect (tools/c3_slow_trace.py).  History is only comparable under the same penalty and
+    // barrier parameter; it starts over when either changes.
+    T phref = ph0;
+    const T phn = info[INFO_PHN];
+    const bool hist_ok = a.nonmono > 0 && phn > T(0) && info[INFO_PHNU] == nub && info[INFO_PHMU] == mub;
+    // Watchdog: after a step that was accepted UPHILL the next full step has to bring the merit below the value in front
+    // of that step (a Maratos step is followed by one that restores feasibility and does; an iterate chattering across a
+    // relu kink is not, and would otherwise be waved through forever), and a shortened one has to pass the monotone test.
+    const bool up = info[INFO_PHUP] > T(0);
+    if (hist_ok && !up) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (a.nonmono > k && phn > (T)k) phref = fmax(phref, info[INFO_PH1 + k]);
+    } else if (hist_ok && up && al >= T(1)) {
+        phref = info[INFO_PH1];
+    }
+    const bool ok = (phit == phit) && phit <= phref + T(1e-4) * al * fmin(drb, T(0)) + slack * fabs(phref);
     if (ok) {
+        if (lane == 0 && a.nonmono > 0) {
+            T* infw = (T*)a.info + (size_t)b * INFO_N;
+            const T h1 = info[INFO_PH1], h2 = info[INFO_PH2], h3 = info[INFO_PH3];
+            infw[INFO_PH4] = hist_ok ? h3 : ph0;
+            infw[INFO_PH3] = hist_ok ? h2 : ph0;
+            infw[INFO_PH2] = hist_ok ? h1 : ph0;
+            infw[INFO_PH1] = ph0;
+            infw[INFO_PHN] = hist_ok ? fmin(phn + T(1), T(4)) : T(1);
+            infw[INFO_PHNU] = nub;
+            infw[INFO_PHMU] = mub;
+            infw[INFO_PHUP] = phit > ph0 ? T(1) : T(0);
+        }
         T* lam = (T*)a.lam + (size_t)b * a.m;
         const T* lamn = (const T*)a.lamn + (size_t)b * a.m;
         // bound multipliers: their own step length, then kept within a factor kappa of mu / slack at the new point
@@ -1994,6 +2031,8 @@ __global__ __launch_bounds__(256) void solver_init_kernel(int B, int n, T* __res
         for (int k = 0; k < INFO_N; ++k) info[i * INFO_N + k] = std::numeric_limits<T>::max();   // "no previous step"
         info[i * INFO_N + INFO_LSK] = T(0);
         info[i * INFO_N + INFO_LSR] = T(0);
+        info[i * INFO_N + INFO_PHN] = T(0);
+        info[i * INFO_N + INFO_PHUP] = T(0);
     }
     if (i >= (size_t)B * n) return;
     const int k = (int)(i % n);
@@ -2540,6 +2579,19 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         a.armijo_slack = std::max(1e-12, slack_eps * (double)std::numeric_limits<T>::epsilon());
     }
     a.max_ls = o.max_linesearch;
+    {
+        // NEMPC_SOLVER_NONMONO: 0 monotone Armijo test (rounds 1-3), 1 .. 4 merit values of previous iterates the test may
+        // refer to (default 4).  configs[2] dims, B = 1024, converged after 40 / 60 / 80 / 160 iterations
+        // (profiles/r04_solver_nonmonotone.txt): 664 / 825 / 918 / 1008 monotone, 722 / 854 / 932 / 1014 (1), 747 / 881 / 966 /
+        // 1020 (2), 766 / 906 / 974 / 1019 (3), 775 / 924 / 985 / 1021 (4); C2 dims 965 / 979 / 997 / 1015 -> 968 / 994 / 1011 / 1019
+        static const int nm_env = [] { const char* e = getenv("NEMPC_SOLVER_NONMONO"); return e ? atoi(e) : 4; }();
+        a.nonmono = nm_env < 0 ? 0 : (nm_env > 4 ? 4 : nm_env);
+        // Piecewise-linear networks (relu, leaky_relu) have no second-order constraint violation for the relaxed test to
+        // forgive; what it does there is let an iterate chatter across a kink without its step ever shrinking.  They keep
+        // the monotone test.
+        for (int l = 0; l < h.nl; ++l)
+            if (h.act[l] == NEMPC_ACT_RELU || h.act[l] == NEMPC_ACT_LEAKY_RELU) a.nonmono = 0;
+    }
     {
         static const double relax_env = [] { const char* e = getenv("NEMPC_SOLVER_REG_RELAX"); return e ? atof(e) : 0.1; }();   // A/B knob
         a.reg_relax = relax_env > 0.0 && relax_env < 1.0 ? relax_env : 0.1;
