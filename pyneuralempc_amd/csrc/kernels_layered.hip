@@ -57,6 +57,17 @@ struct GemmArgs {
     int nblk;           // feature blocks (ceil(N / BN)), set by the launcher
     double actp;        // alpha of an elu / leaky_relu layer
     long long Rmod;     // reverse: rows per cotangent block (a multiple of LG_BM, so a block never straddles two)
+    // SEED (the first reverse product forms its operand on the fly instead of reading a seed matrix from memory):
+    //   A^T[j][k Rp + r] = (W_last[j][k] s_L'(z_L)[k][r]) D_{L-2}^T[j][r];  A = D_{L-2}^T with lda = Rp
+    const void* seedW;  // W_{L-1} (width, nx) row-major
+    const void* seedDl; // s_L'(z_L)^T (nx, Rmod)
+    int seed_nx;
+    // LAST (the last reverse product contracts its result with W_0 onto the nin inputs in the epilogue instead of writing
+    // it): Jp[nb][d][m] = sum over the features n of block nb of W_0^T[n][d] (C[n][m] . D[n][m])
+    const void* w0t;    // W_0^T (out, in) row-major
+    int ldw0, nin;
+    void* Jp;
+    long long ldj, jp_stride;
 };
 
 // FT = 16-feature tiles per wave: a workgroup owns BN = 64 FT features x 64 rows.  Measured (tools/layered_bench.py,
@@ -73,8 +84,9 @@ struct LgShape {
     static constexpr int TILE = BK * (LDW + LDA);      // elements per buffer
 };
 
-template <typename T, int FT>
+template <typename T, int FT, bool SEED = false, bool LAST = false>
 __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
+    static_assert(!(SEED || LAST) || FT == 1, "the fused reverse forms exist for the 64-feature block only");
     using Ops = MfmaOps<T>;
     using V4 = typename Ops::V4;
     using S = LgShape<FT>;
@@ -117,9 +129,22 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
         offA[u] = (int)((long long)kk * a.lda + (m0 + x < M ? x : M - 1 - m0));
     }
     const T* __restrict__ Wb = Bw + n0;
-    const T* __restrict__ Ab = A + m0;
+    // SEED: the operand's column m = (cotangent m / Rmod, row m % Rmod) reads column m % Rmod of D_{L-2}^T; a block of 64
+    // columns lies inside one cotangent (Rmod is a multiple of 64)
+    const long long mrow0 = (SEED || a.mode == LG_REVERSE) ? m0 % a.Rmod : 0;
+    const T* __restrict__ Ab = A + (SEED ? mrow0 : m0);
     const int nfull = K / BK;
     T rw[NW], ra[NA];
+    // SEED: thread (w, x) loads rows w, w + 4, ... of every chunk, always of column x: s_L'(z_L) of its column is fetched once,
+    // W_last[j][cotangent] is a scalar load per row and chunk (w is wave-uniform)
+    T seed_dl = T(0), seed_w[NA];
+    int seed_cot = 0;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if constexpr (SEED) {
+        const int x = tid % LG_BM;
+        seed_cot = (int)(m0 / a.Rmod);
+        seed_dl = static_cast<const T*>(a.seedDl)[(size_t)seed_cot * a.Rmod + mrow0 + (m0 + x < M ? x : M - 1 - m0)];
+    }
     auto load_chunk = [&](int ch) {
         const T* __restrict__ wb = Wb + (size_t)ch * BK * a.ldb;
         const T* __restrict__ ab = Ab + (size_t)ch * BK * a.lda;
@@ -134,6 +159,14 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int u = 0; u < NA; ++u) ra[u] = (ch * BK + (tid + 256 * u) / LG_BM < K) ? ab[offA[u]] : T(0);
         }
+        if constexpr (SEED) {
+            const T* __restrict__ sw = static_cast<const T*>(a.seedW);
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int k = ch * BK + wu + 4 * u;
+                seed_w[u] = k < K ? sw[(size_t)k * a.seed_nx + seed_cot] : T(0);
+            }
+        }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
@@ -144,7 +177,8 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int e = tid + 256 * u;
-            As(buf, e / LG_BM, e % LG_BM) = ra[u];
+            // (the seed kernel's order of operations: (W_last s_L') D)
+            As(buf, e / LG_BM, e % LG_BM) = SEED ? (seed_w[u] * seed_dl) * ra[u] : ra[u];
         }
     };
 
@@ -207,7 +241,58 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
     const T* __restrict__ bias = static_cast<const T*>(a.bias);
     // reverse: the derivative's column of m.  A block of 64 columns never straddles two cotangent blocks (Rmod is a multiple
     // of 64), so one division per workgroup places it
-    const long long mD0 = a.mode == LG_REVERSE ? m0 % a.Rmod - m0 : 0;
+    const long long mD0 = a.mode == LG_REVERSE ? mrow0 - m0 : 0;
+    if constexpr (LAST) {
+        // G_0 = acc . D_0 stays in registers: register r of lane (c, q) holds feature row(q, r), column c -- the four q of a
+        // register are a 4-deep k slab of features, i.e. the accumulator IS a B operand (kernels_mfma_impl.h), and
+        // J^T[d][m] = sum_n W_0^T[n][d] G_0[n][m] is four more matrix instructions per column tile with W_0's fragment as
+        // A operand.  The four waves' sums (16 features each) meet in LDS in wave order; feature blocks meet in
+        // layered_jreduce_kernel in block order: the summation order is fixed.
+        constexpr int LDP = sizeof(T) == 8 ? 80 : 68;       // (f64: q's rows 128 B apart mod 256; f32: 64 B)
+        static_assert((size_t)4 * 16 * LDP <= (size_t)2 * S::TILE, "partial tiles fit the operand buffers");
+        const T* __restrict__ W0 = static_cast<const T*>(a.w0t);
+        T* __restrict__ Jp = static_cast<T*>(a.Jp) + (size_t)nb * a.jp_stride;
+        T gd[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + fb + Ops::row(q, r);
+#pragma unroll
+            for (int rm = 0; rm < 4; ++rm) {
+                const long long m = m0 + 16 * rm + c;
+                gd[rm][r] = (n < N && m < M) ? acc[0][rm][r] * D[(size_t)n * a.ldd + (m + mD0)] : T(0);
+            }
+        }
+        const int ndt = (a.nin + 15) / 16;
+        for (int dt = 0; dt < ndt; ++dt) {
+            V4 P[4];
+#pragma unroll
+            for (int rm = 0; rm < 4; ++rm) P[rm] = V4{T(0), T(0), T(0), T(0)};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + fb + Ops::row(q, r), d = 16 * dt + c;
+                const T wf = (n < N && d < a.nin) ? W0[(size_t)n * a.ldw0 + d] : T(0);
+#pragma unroll
+                for (int rm = 0; rm < 4; ++rm) P[rm] = Ops::mma(wf, gd[rm][r], P[rm]);
+            }
+            if (dt > 0) __syncthreads();
+#pragma unroll
+            for (int rm = 0; rm < 4; ++rm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lds[(w * 16 + Ops::row(q, r)) * LDP + 16 * rm + c] = P[rm][r];
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + 256 * u, dd = e >> 6, col = e & 63;
+                const int d = 16 * dt + dd;
+                const long long m = m0 + col;
+                if (d < a.nin && m < M) {
+                    const T v = ((lds[dd * LDP + col] + lds[(16 + dd) * LDP + col]) + lds[(32 + dd) * LDP + col]) + lds[(48 + dd) * LDP + col];
+                    Jp[(size_t)d * a.ldj + m] = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int fn = 0; fn < FT; ++fn)
 #pragma unroll
@@ -423,11 +508,21 @@ LayeredWs layered_offsets(const Handle& h, size_t Rp) {
     return o;
 }
 
-template <typename T, int FT>
+// J^T = sum over the feature blocks' partial sums, in block order (the LAST form of the GEMM with more than one block)
+template <typename T>
+__global__ void layered_jreduce_kernel(const T* __restrict__ Jp, int nblk, long long stride, T* __restrict__ J, long long count) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        T v = Jp[i];
+        for (int b = 1; b < nblk; ++b) v += Jp[(size_t)b * stride + i];
+        J[i] = v;
+    }
+}
+
+template <typename T, int FT, bool SEED = false, bool LAST = false>
 int gemm_ft(hipStream_t s, const GemmArgs& a) {
     using S = LgShape<FT>;
     const size_t bytes = (size_t)2 * S::TILE * sizeof(T);
-    auto kern = layered_gemm_kernel<T, FT>;
+    auto kern = layered_gemm_kernel<T, FT, SEED, LAST>;
     NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), bytes));
     GemmArgs b = a;
     b.nblk = (a.N + S::BN - 1) / S::BN;
@@ -451,6 +546,25 @@ int gemm(hipStream_t s, int mode, int act, const T* A, long long lda, const T* B
     const int ft = ft_env ? ft_env : 1;
     if (ft >= 4) return gemm_ft<T, 4>(s, a);
     if (ft >= 2) return gemm_ft<T, 2>(s, a);
+    return gemm_ft<T, 1>(s, a);
+}
+
+// The fused forms of the reverse sweep (64-feature blocks only): NEMPC_LAYERED_FUSE=0 walks it with the seed kernel, plain
+// products and the skinny last step instead (A/B knob; also what NEMPC_LAYERED_FT > 1 does)
+bool layered_fuse() {
+    static const bool on = [] {
+        const char* e = getenv("NEMPC_LAYERED_FUSE");
+        const char* f = getenv("NEMPC_LAYERED_FT");
+        return !(e && atoi(e) == 0) && !(f && atoi(f) > 1);
+    }();
+    return on;
+}
+
+template <typename T>
+int gemm_reverse_fused(hipStream_t s, const GemmArgs& a, bool seed, bool last) {
+    if (seed && last) return gemm_ft<T, 1, true, true>(s, a);
+    if (seed) return gemm_ft<T, 1, true, false>(s, a);
+    if (last) return gemm_ft<T, 1, false, true>(s, a);
     return gemm_ft<T, 1>(s, a);
 }
 
@@ -496,6 +610,44 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                 return rc;
             // ---- reverse, all nx cotangents side by side: column k Rp + r is (cotangent k, row r)
             const long long ldg = (long long)nx * Rp;
+            if (nl >= 3 && layered_fuse()) {
+                // two hidden layers or more: the first product forms the seed in its loader, the last one contracts with
+                // W_0 in its epilogue -- neither the seed matrix nor G_0 goes through memory (2 x 256, B*H = 20480, fp64:
+                // 84 MB each way, twice)
+                const long long Mr = (long long)(nx - 1) * Rp + Rm;
+                T* G = nullptr;
+                for (int l = nl - 3; l >= 0; --l) {
+                    const bool first = l == nl - 3, last = l == 0;
+                    T* Gn = (G == ws + o.g0) ? ws + o.g1 : ws + o.g0;
+                    GemmArgs a{};
+                    a.mode = LG_REVERSE;
+                    a.Bw = h.d_Wt[l + 1]; a.ldb = h.dout[l];
+                    a.M = (int)Mr; a.N = h.dout[l]; a.K = h.dout[l + 1]; a.Rmod = Rp;
+                    a.D = ws + o.d[l]; a.ldd = Rp;
+                    if (first) {
+                        a.A = ws + o.d[nl - 2]; a.lda = Rp;
+                        a.seedW = h.d_W[nl - 1]; a.seedDl = ws + o.dl; a.seed_nx = nx;
+                    } else {
+                        a.A = G; a.lda = ldg;
+                    }
+                    const int nblk = (h.dout[l] + 63) / 64;
+                    if (last) {
+                        a.w0t = h.d_Wt[0]; a.ldw0 = h.din[0]; a.nin = nin;
+                        a.Jp = nblk == 1 ? ws + o.j : Gn;
+                        a.ldj = ldg; a.jp_stride = (long long)nin * ldg;
+                    } else {
+                        a.C = Gn; a.ldc = ldg;
+                    }
+                    if ((rc = gemm_reverse_fused<T>(s, a, first, last))) return rc;
+                    if (last && nblk > 1) {
+                        const long long count = (long long)nin * ldg;
+                        hipLaunchKernelGGL(layered_jreduce_kernel<T>, dim3((unsigned)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096)),
+                                           dim3(256), 0, s, Gn, nblk, a.jp_stride, ws + o.j, count);
+                        NEMPC_HIP(hipGetLastError());
+                    }
+                    G = Gn;
+                }
+            } else {
             T* G = ws + o.g0;
             hipLaunchKernelGGL(layered_seed_kernel<T>, dim3(rg.x, (unsigned)h.dout[nl - 2]), rb, 0, s, static_cast<const T*>(h.d_W[nl - 1]),
                                h.dout[nl - 2], nx, ws + o.dl, ws + o.d[nl - 2], R, Rp, G);
@@ -515,6 +667,7 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                 if ((rc = skinny<T>(s, G, ldg, static_cast<const T*>(h.d_Wt[0]), h.din[0], h.dout[0], nin, Mj, ws + o.j, ldg,
                                     static_cast<const T*>(nullptr), 2, 0, static_cast<T*>(nullptr), T(0))))
                     return rc;
+            }
             }
             if (rk4) {
                 hipLaunchKernelGGL(layered_rk4_kernel<T>, rg, rb, 0, s, st, nx, nin, cdt, (st == 0 || st == 3) ? T(1) : T(2), ws + o.f,

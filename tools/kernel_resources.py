@@ -19,6 +19,6 @@ for line in out.splitlines():
         k, v = body.rsplit(":", 1); rows[cur][k.strip()] = v.strip()
 for name, d in rows.items():
     dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
-    dem = re.sub(r"\(.*", "", dem).replace("nempc::", "").replace("void ", "")
+    dem = re.sub(r"\(.*", "", dem.replace("(anonymous namespace)::", "")).replace("nempc::", "").replace("void ", "")
     print(f"{dem:60s} VGPR {d.get('VGPRs','?'):>4} AGPR {d.get('AGPRs','?'):>4} spillV {d.get('VGPRs Spill','?'):>5} "
           f"scratch {d.get('ScratchSize [bytes/lane]','?'):>6} occ {d.get('Occupancy [waves/SIMD]','?'):>2} LDS {d.get('LDS Size [bytes/block]','?')}")
