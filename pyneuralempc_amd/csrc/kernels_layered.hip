@@ -62,13 +62,18 @@ struct GemmArgs {
     const void* seedW;  // W_{L-1} (width, nx) row-major
     const void* seedDl; // s_L'(z_L)^T (nx, Rmod)
     int seed_nx;
-    // LAST (the last reverse product contracts its result with W_0 onto the nin inputs in the epilogue instead of writing
-    // it): Jp[nb][d][m] = sum over the features n of block nb of W_0^T[n][d] (C[n][m] . D[n][m])
-    const void* w0t;    // W_0^T (out, in) row-major
+    // CONTRACT (the product's result is contracted with the next, skinny, matrix in the epilogue instead of being written):
+    //   Jp[nb][d][m] = sum over the features n of block nb of Wc[n][d] E[n][m],  d < nd <= 32
+    //   LG_CONTRACT_REVERSE  the last reverse product: E = C . D_0, Wc = W_0^T (out, in), nd = nin: the Jacobian's partial sums
+    //   LG_CONTRACT_FORWARD  the last hidden layer: E = s(C + b) (only s' is stored), Wc = W_{L-1} (in, out), nd = nx: the
+    //                        network output's partial sums (bias and activation: layered_outfinish_kernel)
+    const void* w0t;
     int ldw0, nin;
     void* Jp;
     long long ldj, jp_stride;
 };
+
+enum { LG_CONTRACT_NONE = 0, LG_CONTRACT_REVERSE = 1, LG_CONTRACT_FORWARD = 2 };
 
 // FT = 16-feature tiles per wave: a workgroup owns BN = 64 FT features x 64 rows.  Measured (tools/layered_bench.py,
 // NEMPC_LAYERED_FT, round 4): FT = 1 is the fastest everywhere -- 2 x 256 at B*H = 20480: 398 / 505 / 569 us for FT = 1 / 2 /
@@ -84,9 +89,9 @@ struct LgShape {
     static constexpr int TILE = BK * (LDW + LDA);      // elements per buffer
 };
 
-template <typename T, int FT, bool SEED = false, bool LAST = false>
+template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE>
 __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
-    static_assert(!(SEED || LAST) || FT == 1, "the fused reverse forms exist for the 64-feature block only");
+    static_assert(!(SEED || CONTRACT) || FT == 1, "the fused forms exist for the 64-feature block only");
     using Ops = MfmaOps<T>;
     using V4 = typename Ops::V4;
     using S = LgShape<FT>;
@@ -242,12 +247,12 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
     // reverse: the derivative's column of m.  A block of 64 columns never straddles two cotangent blocks (Rmod is a multiple
     // of 64), so one division per workgroup places it
     const long long mD0 = a.mode == LG_REVERSE ? mrow0 - m0 : 0;
-    if constexpr (LAST) {
-        // G_0 = acc . D_0 stays in registers: register r of lane (c, q) holds feature row(q, r), column c -- the four q of a
-        // register are a 4-deep k slab of features, i.e. the accumulator IS a B operand (kernels_mfma_impl.h), and
-        // J^T[d][m] = sum_n W_0^T[n][d] G_0[n][m] is four more matrix instructions per column tile with W_0's fragment as
-        // A operand.  The four waves' sums (16 features each) meet in LDS in wave order; feature blocks meet in
-        // layered_jreduce_kernel in block order: the summation order is fixed.
+    if constexpr (CONTRACT != LG_CONTRACT_NONE) {
+        // E (G_0 = acc . D_0, or the layer's activations) stays in registers: register r of lane (c, q) holds feature
+        // row(q, r), column c -- the four q of a register are a 4-deep k slab of features, i.e. the accumulator IS a B
+        // operand (kernels_mfma_impl.h), and sum_n Wc[n][d] E[n][m] is four more matrix instructions per column tile with
+        // Wc's fragment as A operand.  The four waves' sums (16 features each) meet in LDS in wave order; feature blocks
+        // meet in layered_jreduce_kernel / layered_outfinish_kernel in block order: the summation order is fixed.
         constexpr int LDP = sizeof(T) == 8 ? 80 : 68;       // (f64: q's rows 128 B apart mod 256; f32: 64 B)
         static_assert((size_t)4 * 16 * LDP <= (size_t)2 * S::TILE, "partial tiles fit the operand buffers");
         const T* __restrict__ W0 = static_cast<const T*>(a.w0t);
@@ -259,7 +264,16 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int rm = 0; rm < 4; ++rm) {
                 const long long m = m0 + 16 * rm + c;
-                gd[rm][r] = (n < N && m < M) ? acc[0][rm][r] * D[(size_t)n * a.ldd + (m + mD0)] : T(0);
+                if constexpr (CONTRACT == LG_CONTRACT_REVERSE) {
+                    gd[rm][r] = (n < N && m < M) ? acc[0][rm][r] * D[(size_t)n * a.ldd + (m + mD0)] : T(0);
+                } else {
+                    T x = T(0);
+                    if (n < N && m < M) {
+                        x = lg_act_f<T>(a.act, acc[0][rm][r] + bias[n], (T)a.actp);
+                        D[(size_t)n * a.ldd + m] = act_d1<T>(a.act, x, (T)a.actp);
+                    }
+                    gd[rm][r] = x;
+                }
             }
         }
         const int ndt = (a.nin + 15) / 16;
@@ -508,7 +522,22 @@ LayeredWs layered_offsets(const Handle& h, size_t Rp) {
     return o;
 }
 
-// J^T = sum over the feature blocks' partial sums, in block order (the LAST form of the GEMM with more than one block)
+// network output from the feature blocks' partial sums (LG_CONTRACT_FORWARD), in block order: f = s_L(sum + b), s_L'(z_L)
+template <typename T>
+__global__ void layered_outfinish_kernel(const T* __restrict__ P, int nblk, long long stride, int nx, int R, long long Rp,
+                                         const T* __restrict__ bias, int act, T actp, T* __restrict__ f, T* __restrict__ dl) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    for (int o = 0; o < nx; ++o) {
+        T v = P[(size_t)o * Rp + r];
+        for (int b = 1; b < nblk; ++b) v += P[(size_t)b * stride + (size_t)o * Rp + r];
+        const T x = lg_act_f<T>(act, v + bias[o], actp);
+        f[(size_t)o * Rp + r] = x;
+        dl[(size_t)o * Rp + r] = act_d1<T>(act, x, actp);
+    }
+}
+
+// J^T = sum over the feature blocks' partial sums, in block order (LG_CONTRACT_REVERSE with more than one block)
 template <typename T>
 __global__ void layered_jreduce_kernel(const T* __restrict__ Jp, int nblk, long long stride, T* __restrict__ J, long long count) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
@@ -518,11 +547,11 @@ __global__ void layered_jreduce_kernel(const T* __restrict__ Jp, int nblk, long 
     }
 }
 
-template <typename T, int FT, bool SEED = false, bool LAST = false>
+template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE>
 int gemm_ft(hipStream_t s, const GemmArgs& a) {
     using S = LgShape<FT>;
     const size_t bytes = (size_t)2 * S::TILE * sizeof(T);
-    auto kern = layered_gemm_kernel<T, FT, SEED, LAST>;
+    auto kern = layered_gemm_kernel<T, FT, SEED, CONTRACT>;
     NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), bytes));
     GemmArgs b = a;
     b.nblk = (a.N + S::BN - 1) / S::BN;
@@ -562,9 +591,9 @@ bool layered_fuse() {
 
 template <typename T>
 int gemm_reverse_fused(hipStream_t s, const GemmArgs& a, bool seed, bool last) {
-    if (seed && last) return gemm_ft<T, 1, true, true>(s, a);
-    if (seed) return gemm_ft<T, 1, true, false>(s, a);
-    if (last) return gemm_ft<T, 1, false, true>(s, a);
+    if (seed && last) return gemm_ft<T, 1, true, LG_CONTRACT_REVERSE>(s, a);
+    if (seed) return gemm_ft<T, 1, true, LG_CONTRACT_NONE>(s, a);
+    if (last) return gemm_ft<T, 1, false, LG_CONTRACT_REVERSE>(s, a);
     return gemm_ft<T, 1>(s, a);
 }
 
@@ -598,14 +627,32 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
             NEMPC_HIP(hipGetLastError());
             // ---- forward: hidden layers 0 .. nl-2 (GEMM), output layer nl-1 (skinny)
             const T* in = ws + o.xi;
+            const bool fuse_out = layered_fuse();
             for (int l = 0; l < nl - 1; ++l) {
                 T* out = ws + ((l & 1) ? o.x1 : o.x0);
+                if (l == nl - 2 && fuse_out) {
+                    // the last hidden layer: its activations go straight into the output layer's contraction (only s' is
+                    // stored); partial sums per feature block in the cotangent buffer, which the reverse sweep fills later
+                    GemmArgs a{};
+                    a.mode = LG_FORWARD; a.act = h.act[l]; a.actp = h.actp[l];
+                    a.A = in; a.lda = Rp; a.Bw = h.d_W[l]; a.ldb = h.dout[l];
+                    a.D = ws + o.d[l]; a.ldd = Rp; a.bias = h.d_b[l];
+                    a.M = R; a.N = h.dout[l]; a.K = h.din[l];
+                    a.w0t = h.d_W[nl - 1]; a.ldw0 = nx; a.nin = nx;
+                    a.Jp = ws + o.g0; a.ldj = Rp; a.jp_stride = (long long)nx * Rp;
+                    if ((rc = gemm_ft<T, 1, false, LG_CONTRACT_FORWARD>(s, a))) return rc;
+                    hipLaunchKernelGGL(layered_outfinish_kernel<T>, rg, rb, 0, s, ws + o.g0, (h.dout[l] + 63) / 64, a.jp_stride, nx, R, Rp,
+                                       static_cast<const T*>(h.d_b[nl - 1]), h.act[nl - 1], (T)h.actp[nl - 1], ws + o.f, ws + o.dl);
+                    NEMPC_HIP(hipGetLastError());
+                    break;
+                }
                 if ((rc = gemm<T>(s, LG_FORWARD, h.act[l], in, Rp, static_cast<const T*>(h.d_W[l]), h.dout[l], out, Rp, ws + o.d[l], Rp,
                                   static_cast<const T*>(h.d_b[l]), R, h.dout[l], h.din[l], 0, h.actp[l])))
                     return rc;
                 in = out;
             }
-            if ((rc = skinny<T>(s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, (long long)R, ws + o.f, Rp,
+            if (!fuse_out &&
+                (rc = skinny<T>(s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, (long long)R, ws + o.f, Rp,
                                 static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl, (T)h.actp[nl - 1])))
                 return rc;
             // ---- reverse, all nx cotangents side by side: column k Rp + r is (cotangent k, row r)
