@@ -75,11 +75,12 @@ struct GemmArgs {
 
 enum { LG_CONTRACT_NONE = 0, LG_CONTRACT_REVERSE = 1, LG_CONTRACT_FORWARD = 2 };
 
-// FT = 16-feature tiles per wave: a workgroup owns BN = 64 FT features x 64 rows.  Measured (tools/layered_bench.py,
-// NEMPC_LAYERED_FT, round 4): FT = 1 is the fastest everywhere -- 2 x 256 at B*H = 20480: 398 / 505 / 569 us for FT = 1 / 2 /
+// FT = 16-feature tiles per wave: a workgroup owns BN = 64 FT features x 64 rows.  Measured (tools/layered_bench.py, round 4,
+// with one chunk of load lead): FT = 1 is the fastest everywhere -- 2 x 256 at B*H = 20480: 398 / 505 / 569 us for FT = 1 / 2 /
 // 4 in fp64, 244 / 264 / 304 us in fp32; 4 x 512 RK4 6/3 at B*H = 30720: 34.0 / 41.1 / 44.1 ms (0.51 / 0.42 / 0.39 of the fp64
 // matrix peak).  Wider blocks read the activations fewer times but run at two waves per SIMD with coarse launch tails; with
-// the XCD-aware block order below the narrow block gets its re-reads from L2 anyway.  FT > 1 stays as an A/B knob.
+// the XCD-aware block order below the narrow block gets its re-reads from L2 anyway.  Only FT = 1 is instantiated (the wider shapes do not fit the
+// two-chunk load lead below into 128 registers).
 template <int FT>
 struct LgShape {
     static constexpr int BN = 64 * FT;
@@ -89,8 +90,30 @@ struct LgShape {
     static constexpr int TILE = BK * (LDW + LDA);      // elements per buffer
 };
 
+// Operand loads go through buffer descriptors: scalar base + 32-bit lane offset in one instruction (with plain pointers the
+// compiler kept a 64-bit pointer per load in vector registers and stepped all of them every chunk), and the range check
+// gives the zero fill for free -- a chunk's descriptor covers exactly the rows of K it has, so rows beyond K and whole
+// chunks beyond the last one load zeros without a branch (and without a memory access).
+__device__ __forceinline__ double lg_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, double) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(double, (u2)__builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, 0, 0));
+}
+__device__ __forceinline__ float lg_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, float) {
+    return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
+}
+template <typename T>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rows_rsrc(const T* base, int rows, int rows_max, long long ld) {
+    const int r = rows < 0 ? 0 : (rows > rows_max ? rows_max : rows);
+    // (every input is wave-uniform, which the compiler has to SEE: the clamp alone was done on the vector unit and each load
+    // then sat in a waterfall loop over "distinct" descriptors)
+    const unsigned long long pv = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pv), hi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
+    const int bytes = __builtin_amdgcn_readfirstlane((int)((long long)r * ld * (long long)sizeof(T)));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+
 template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE>
-__global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, 4) void layered_gemm_kernel(GemmArgs a) {
     static_assert(!(SEED || CONTRACT) || FT == 1, "the fused forms exist for the 64-feature block only");
     using Ops = MfmaOps<T>;
     using V4 = typename Ops::V4;
@@ -122,27 +145,34 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
     // change -- no vector arithmetic per load (a v_mfma_f64 holds the vector pipe for its 64 cycles).  Columns beyond N / M
     // are clamped onto the last one (their results are never stored); only the LAST chunk, where k may run past K, is masked.
     constexpr int NW = BK * BN / 256, NA = BK * LG_BM / 256;       // elements per thread and chunk
-    int offW[NW], offA[NA];
+    // (unsigned BYTE offsets inside a chunk; largest: 15 rows of 16 x 65536 elements of 8 bytes, 126 MB)
+    unsigned offW[NW], offA[NA];
 #pragma unroll
     for (int u = 0; u < NW; ++u) {
         const int e = tid + 256 * u, kk = e / BN, x = e % BN;
-        offW[u] = kk * a.ldb + (n0 + x < N ? x : N - 1 - n0);
+        offW[u] = (unsigned)(kk * a.ldb + (n0 + x < N ? x : N - 1 - n0)) * (unsigned)sizeof(T);
     }
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
         const int e = tid + 256 * u, kk = e / LG_BM, x = e % LG_BM;
-        offA[u] = (int)((long long)kk * a.lda + (m0 + x < M ? x : M - 1 - m0));
+        offA[u] = (unsigned)((long long)kk * a.lda + (m0 + x < M ? x : M - 1 - m0)) * (unsigned)sizeof(T);
     }
     const T* __restrict__ Wb = Bw + n0;
     // SEED: the operand's column m = (cotangent m / Rmod, row m % Rmod) reads column m % Rmod of D_{L-2}^T; a block of 64
     // columns lies inside one cotangent (Rmod is a multiple of 64)
     const long long mrow0 = (SEED || a.mode == LG_REVERSE) ? m0 % a.Rmod : 0;
     const T* __restrict__ Ab = A + (SEED ? mrow0 : m0);
-    const int nfull = K / BK;
-    T rw[NW], ra[NA];
+    // A chunk on its way from memory to LDS.  Two of them: the loads of chunk c + 2 are issued at the start of chunk c and
+    // written to LDS at the end of chunk c + 1 -- two chunks of matrix instructions (~3 us with four waves on the SIMD) to
+    // cover a memory round trip under load.  With one set (a single chunk of lead) the waves of the 256 x 256 reverse
+    // product spent 56 % of their cycles in s_waitcnt and the matrix pipe was busy 58 % of the launch
+    // (profiles/r04_layered_gemm_pipe.txt).
+    struct ChunkRegs {
+        T rw[NW], ra[NA], sw[NA];
+    };
     // SEED: thread (w, x) loads rows w, w + 4, ... of every chunk, always of column x: s_L'(z_L) of its column is fetched once,
     // W_last[j][cotangent] is a scalar load per row and chunk (w is wave-uniform)
-    T seed_dl = T(0), seed_w[NA];
+    T seed_dl = T(0);
     int seed_cot = 0;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (SEED) {
@@ -150,40 +180,33 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
         seed_cot = (int)(m0 / a.Rmod);
         seed_dl = static_cast<const T*>(a.seedDl)[(size_t)seed_cot * a.Rmod + mrow0 + (m0 + x < M ? x : M - 1 - m0)];
     }
-    auto load_chunk = [&](int ch) {
-        const T* __restrict__ wb = Wb + (size_t)ch * BK * a.ldb;
-        const T* __restrict__ ab = Ab + (size_t)ch * BK * a.lda;
-        if (ch < nfull) {
+    auto load_chunk = [&](int ch, ChunkRegs& cr) {
+        const __amdgpu_buffer_rsrc_t rw = lg_rows_rsrc<T>(Wb + (size_t)ch * BK * a.ldb, K - ch * BK, BK, a.ldb);
+        const __amdgpu_buffer_rsrc_t ra = lg_rows_rsrc<T>(Ab + (size_t)ch * BK * a.lda, K - ch * BK, BK, a.lda);
 #pragma unroll
-            for (int u = 0; u < NW; ++u) rw[u] = wb[offW[u]];
+        for (int u = 0; u < NW; ++u) cr.rw[u] = lg_buf_load(rw, offW[u], T(0));
 #pragma unroll
-            for (int u = 0; u < NA; ++u) ra[u] = ab[offA[u]];
-        } else {
-#pragma unroll
-            for (int u = 0; u < NW; ++u) rw[u] = (ch * BK + (tid + 256 * u) / BN < K) ? wb[offW[u]] : T(0);
-#pragma unroll
-            for (int u = 0; u < NA; ++u) ra[u] = (ch * BK + (tid + 256 * u) / LG_BM < K) ? ab[offA[u]] : T(0);
-        }
+        for (int u = 0; u < NA; ++u) cr.ra[u] = lg_buf_load(ra, offA[u], T(0));
         if constexpr (SEED) {
             const T* __restrict__ sw = static_cast<const T*>(a.seedW);
 #pragma unroll
             for (int u = 0; u < NA; ++u) {
-                const int k = ch * BK + wu + 4 * u;
-                seed_w[u] = k < K ? sw[(size_t)k * a.seed_nx + seed_cot] : T(0);
+                const int k = ch * BK + wu + 4 * u;          // (beyond K: any row -- the operand it scales loaded as zero)
+                cr.sw[u] = sw[(size_t)(k < K ? k : K - 1) * a.seed_nx + seed_cot];
             }
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const ChunkRegs& cr) {
 #pragma unroll
         for (int u = 0; u < NW; ++u) {
             const int e = tid + 256 * u;
-            Ws(buf, e / BN, e % BN) = rw[u];
+            Ws(buf, e / BN, e % BN) = cr.rw[u];
         }
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int e = tid + 256 * u;
             // (the seed kernel's order of operations: (W_last s_L') D)
-            As(buf, e / LG_BM, e % LG_BM) = SEED ? (seed_w[u] * seed_dl) * ra[u] : ra[u];
+            As(buf, e / LG_BM, e % LG_BM) = SEED ? (cr.sw[u] * seed_dl) * cr.ra[u] : cr.ra[u];
         }
     };
 
@@ -195,15 +218,7 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
 
     const int nchunks = (K + BK - 1) / BK;
     const int fb = w * 16 * FT;                 // this wave's features inside the block
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        const bool more = ch + 1 < nchunks;
-#ifndef NEMPC_LG_EXP_NOLOAD       // (timing experiments, tools/lg_limiter_exp.sh: never defined in the shipped build)
-        if (more) load_chunk(ch + 1);
-#endif
+    auto mma_chunk = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             T af[FT], bf[4];
@@ -223,13 +238,45 @@ __global__ __launch_bounds__(256, 2) void layered_gemm_kernel(GemmArgs a) {
 #pragma unroll
                 for (int rm = 0; rm < 4; ++rm) acc[fn][rm] = Ops::mma(af[fn], bf[rm], acc[fn][rm]);
         }
-#ifndef NEMPC_LG_EXP_NOLOAD
-        if (more) store_chunk(buf ^ 1);
-#endif
+    };
+    auto chunk_barrier = [&]() {
 #ifndef NEMPC_LG_EXP_NOBARRIER
         __syncthreads();
 #endif
+    };
+    ChunkRegs c0, c1;           // c0: even chunks, c1: odd chunks
+    load_chunk(0, c0);
+    load_chunk(1, c1);
+    store_chunk(0, c0);
+    __syncthreads();
+    // pairs of chunks (no exit in the middle of the body: with one, the accumulators were copied between two register sets
+    // every pass and every copy waited out the matrix pipe); an odd last chunk follows the loop
+    // pairs of chunks, no branch in the body: the compiler's wait-count bookkeeping stays exact -- a wait for the OLDER set only
+    // (behind a branch it falls back to vmcnt(0) and the lead is gone); loads beyond the last chunk return zeros.  An odd
+    // last chunk follows the loop.  (NEMPC_LG_EXP_NOLOAD: timing experiment of tools/lg_limiter_exp.sh, never defined in
+    // the shipped build)
+    int ch = 0;
+    for (; ch + 1 < nchunks; ch += 2) {
+#ifndef NEMPC_LG_EXP_NOLOAD
+        load_chunk(ch + 2, c0);
+        __builtin_amdgcn_sched_barrier(0);      // (issued HERE: left alone, the scheduler sinks the loads under the matrix instructions and half the lead is gone)
+#endif
+        mma_chunk(0);
+#ifndef NEMPC_LG_EXP_NOLOAD
+        store_chunk(1, c1);
+#endif
+        chunk_barrier();
+#ifndef NEMPC_LG_EXP_NOLOAD
+        load_chunk(ch + 3, c1);
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        mma_chunk(1);
+#ifndef NEMPC_LG_EXP_NOLOAD
+        store_chunk(0, c0);
+#endif
+        chunk_barrier();
     }
+    if (ch < nchunks) mma_chunk(0);
 #ifdef NEMPC_LG_EXP_NOEPI
     if (acc[0][0][0] == T(12345.678)) static_cast<T*>(a.C)[0] = acc[0][1][1] + acc[0][2][2] + acc[0][3][3];
     return;
@@ -570,21 +617,16 @@ int gemm(hipStream_t s, int mode, int act, const T* A, long long lda, const T* B
     a.A = A; a.Bw = Bw; a.C = C; a.D = D; a.bias = bias;
     a.lda = lda; a.ldc = ldc; a.ldd = ldd; a.ldb = ldb;
     a.M = (int)M; a.N = N; a.K = K; a.mode = mode; a.act = act; a.Rmod = Rmod;
-    // 64-feature blocks (FT = 1) measured fastest at every width (LgShape above); NEMPC_LAYERED_FT = 2 | 4: A/B knob
-    static const int ft_env = [] { const char* e = getenv("NEMPC_LAYERED_FT"); return e ? atoi(e) : 0; }();
-    const int ft = ft_env ? ft_env : 1;
-    if (ft >= 4) return gemm_ft<T, 4>(s, a);
-    if (ft >= 2) return gemm_ft<T, 2>(s, a);
+    // 64-feature blocks (FT = 1) measured fastest at every width (LgShape above); wider blocks are not instantiated
     return gemm_ft<T, 1>(s, a);
 }
 
 // The fused forms of the reverse sweep (64-feature blocks only): NEMPC_LAYERED_FUSE=0 walks it with the seed kernel, plain
-// products and the skinny last step instead (A/B knob; also what NEMPC_LAYERED_FT > 1 does)
+// products and the skinny last step instead (A/B knob)
 bool layered_fuse() {
     static const bool on = [] {
         const char* e = getenv("NEMPC_LAYERED_FUSE");
-        const char* f = getenv("NEMPC_LAYERED_FT");
-        return !(e && atoi(e) == 0) && !(f && atoi(f) > 1);
+        return !(e && atoi(e) == 0);
     }();
     return on;
 }

@@ -3,7 +3,7 @@
 # modes (--only-eval: the timed loop of the headline launch, the row-kernel-only timing loop and the accuracy check of
 # the timed launch; --only-hessian: the Hessian-callback legs alone), so every average in a kernel-stats CSV is an average
 # over launches of ONE configuration.  Counters in passes of their own (no trace domain combined with --pmc).
-# usage: tools/profile_round3.sh <tag> [part]   part: bench | trace | pmc | all   -> gpurun_out/<tag>_*
+# usage: tools/profile_round3.sh <tag> [part]   part: bench | trace | layered | pmc | all   -> gpurun_out/<tag>_*
 set -e -o pipefail
 TAG=${1:-r04}; PART=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -28,6 +28,8 @@ if [ "$PART" = trace ] || [ "$PART" = all ]; then
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_${cfg}_sparse_trace -- python3 bench.py --config $cfg --only-sparse --steps 800 > $O/${TAG}_${cfg}_sparse_trace.json 2> $O/${TAG}_${cfg}_sparse_trace.err
     echo "sparse trace $cfg done"
   done
+fi
+if [ "$PART" = trace ] || [ "$PART" = layered ] || [ "$PART" = all ]; then
   # the layer-at-a-time GEMM path (networks outside the register-resident kernels)
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_layered_wide256_trace -- python3 tools/layered_bench.py wide256_c2/float64 > $O/${TAG}_layered_wide256_trace.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_layered_wide512_trace -- python3 tools/layered_bench.py wide512x4_c3/float64 > $O/${TAG}_layered_wide512_trace.log 2>&1
