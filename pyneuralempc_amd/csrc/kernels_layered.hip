@@ -164,9 +164,9 @@ __global__ __launch_bounds__(256, 4) void layered_gemm_kernel(GemmArgs a) {
     const T* __restrict__ Ab = A + (SEED ? mrow0 : m0);
     // A chunk on its way from memory to LDS.  Two of them: the loads of chunk c + 2 are issued at the start of chunk c and
     // written to LDS at the end of chunk c + 1 -- two chunks of matrix instructions (~3 us with four waves on the SIMD) to
-    // cover a memory round trip under load.  With one set (a single chunk of lead) the waves of the 256 x 256 reverse
-    // product spent 56 % of their cycles in s_waitcnt and the matrix pipe was busy 58 % of the launch
-    // (profiles/r04_layered_gemm_pipe.txt).
+    // cover a memory round trip under load.  With a single set (one chunk of lead) the waves of the 256 x 256 reverse product
+    // sat in s_waitcnt for 56 % of their cycles (profiles/r04_layered_gemm_pipe.txt).  Measured, whole evaluations: 4 x 512
+    // RK4 28.4 -> 25.0 ms in fp64 and 16.6 -> 12.1 ms in fp32, 2 x 256 267 -> 252 us and 157 -> 133 us.
     struct ChunkRegs {
         T rw[NW], ra[NA], sw[NA];
     };
@@ -782,11 +782,12 @@ bool layered_supported(const Handle& h) {
     return true;
 }
 
-// chunk workspace: rows per chunk so that the whole workspace stays near 1.5 GB, between 4096 and 65536 rows
+// chunk workspace: rows per chunk so that the whole workspace stays near 6 GB (of 288), between 4096 and 65536 rows -- the
+// larger the products, the smaller the share of their launch tails (4 x 512, 6/3, B*H = 30720 in fp64 is one chunk of 2.3 GB)
 int layered_prepare(Handle& h) {
     const size_t cap = (size_t)h.cfg.max_batch * h.cfg.H;
     const LayeredWs per = layered_offsets(h, 1);
-    size_t rc_rows = ((size_t)1536 << 20) / (per.total * h.esz);
+    size_t rc_rows = ((size_t)6144 << 20) / (per.total * h.esz);
     if (rc_rows > 65536) rc_rows = 65536;
     if (rc_rows < 4096) rc_rows = 4096;
     if (const char* e = getenv("NEMPC_LAYERED_CHUNK_ROWS")) {     // (tests of the chunk loop)
