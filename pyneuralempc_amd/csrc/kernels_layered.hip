@@ -51,6 +51,9 @@ struct GemmArgs {
     const void* Bw;     // (K, N) row-major, element (k, n) at Bw[k * ldb + n]
     void* C;            // C^T: (N, M), element (n, m) at C[n * ldc + m]
     void* D;            // forward: s'(z) out, (N, M) like C;  reverse: s'(z) in, (N, Rmod) -- column m reads m % Rmod
+    void* E;            // second-order sweeps (null otherwise).  forward: s''(z) out, like D;  reverse: s''(z) in, like D
+    void* C2;           // reverse, with E: C2 = acc . E (the curvature weights of the layer), like C
+    void* Craw;         // reverse: acc itself (the pre-activation tangents), like C;  C may then be null
     const void* bias;   // forward only, (N)
     long long lda, ldc, ldd;
     int ldb, M, N, K, mode, act;
@@ -178,7 +181,8 @@ __global__ __launch_bounds__(256, 4) void layered_gemm_kernel(GemmArgs a) {
     if constexpr (SEED) {
         const int x = tid % LG_BM;
         seed_cot = (int)(m0 / a.Rmod);
-        seed_dl = static_cast<const T*>(a.seedDl)[(size_t)seed_cot * a.Rmod + mrow0 + (m0 + x < M ? x : M - 1 - m0)];
+        // (no s_L': the tangent sweep of the Hessian, whose seed is W_0^T . D_0)
+        seed_dl = a.seedDl ? static_cast<const T*>(a.seedDl)[(size_t)seed_cot * a.Rmod + mrow0 + (m0 + x < M ? x : M - 1 - m0)] : T(1);
     }
     auto load_chunk = [&](int ch, ChunkRegs& cr) {
         const __amdgpu_buffer_rsrc_t rw = lg_rows_rsrc<T>(Wb + (size_t)ch * BK * a.ldb, K - ch * BK, BK, a.ldb);
@@ -367,10 +371,14 @@ __global__ __launch_bounds__(256, 4) void layered_gemm_kernel(GemmArgs a) {
                 const T v = acc[fn][rm][r];
                 if (a.mode == LG_FORWARD) {
                     const T x = lg_act_f<T>(a.act, v + bias[n], (T)a.actp);
+                    const T d1 = act_d1<T>(a.act, x, (T)a.actp);
                     C[(size_t)n * a.ldc + m] = x;
-                    D[(size_t)n * a.ldd + m] = act_d1<T>(a.act, x, (T)a.actp);
+                    D[(size_t)n * a.ldd + m] = d1;
+                    if (a.E) static_cast<T*>(a.E)[(size_t)n * a.ldd + m] = act_r2<T>(a.act, x, (T)a.actp) * d1;
                 } else {
-                    C[(size_t)n * a.ldc + m] = v * D[(size_t)n * a.ldd + (m + mD0)];
+                    if (C) C[(size_t)n * a.ldc + m] = v * D[(size_t)n * a.ldd + (m + mD0)];
+                    if (a.Craw) static_cast<T*>(a.Craw)[(size_t)n * a.ldc + m] = v;
+                    if (a.C2) static_cast<T*>(a.C2)[(size_t)n * a.ldc + m] = v * static_cast<const T*>(a.E)[(size_t)n * a.ldd + (m + mD0)];
                 }
             }
         }
@@ -771,6 +779,283 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
     return NEMPC_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Contracted network Hessian  sum_k mult_k d2 f_k / d xi^2  of every row on the same GEMM kernel (model/tensorflow.py:77-109
+// takes tf.hessians per output; contracted with the multipliers as optimizer/ipopt.py:79-80 does).  The layer-wise form of
+// rowhess_valu_kernel / net_hessian_contracted (kernels_valu.hip):
+//
+//     H = sum_l P_l^T diag(w_l) P_l,    P_l = d z_l / d xi  (width_l x nin, pre-activation tangents),
+//                                       w_l = q_l . s_l''(z_l),   q_l = d(mult . f) / d a_l
+//
+//   forward            as the rows path, every layer also stores s''(z) = r2(a) s'(z)                    (GEMMs, R columns)
+//   reverse            ONE cotangent (the multipliers): q_{l-1} = W_l (q_l . D_l); the epilogue also writes w_l = q_l . E_l
+//                                                                                                         (GEMMs, R columns)
+//   tangents           P_0 = W_0^T (constant), P_l = W_l^T (D_{l-1} . P_{l-1}): all nin directions side by side; the first
+//                      product forms D_0 . W_0^T in its loader (the SEED form)                         (GEMMs, nin R columns)
+//   contraction        per layer, H[p][q][r] += sum_j w_l[j][r] P_l[j][p, r] P_l[j][q, r]: streams P_l once per block pair of
+//                      inputs, thread per row, four waves split the features                                (vector unit)
+// (2 + nin) GEMM sweeps instead of the 2 + 2 nin of forward-over-reverse.  RK4 models keep the generic kernel for now.
+
+struct LayeredHws {      // element offsets into the Hessian chunk workspace
+    size_t xi, x0, x1, d[NEMPC_MAX_LAYERS], e[NEMPC_MAX_LAYERS], cw[NEMPC_MAX_LAYERS], f, dl, cl, wl, q0, q1, P, a0, a1, pl, hacc, total;
+};
+
+LayeredHws layered_hess_offsets(const Handle& h, size_t Rp) {
+    LayeredHws o{};
+    const int nx = h.cfg.nx, nin = h.nin;
+    size_t p = 0;
+    o.xi = p; p += (size_t)(nin + h.ne) * Rp;
+    o.x0 = p; p += (size_t)h.maxw * Rp;
+    o.x1 = p; p += (size_t)h.maxw * Rp;
+    for (int l = 0; l < h.nl - 1; ++l) {
+        o.d[l] = p; p += (size_t)h.dout[l] * Rp;
+        o.e[l] = p; p += (size_t)h.dout[l] * Rp;
+        o.cw[l] = p; p += (size_t)h.dout[l] * Rp;
+    }
+    o.f = p; p += (size_t)nx * Rp;
+    o.dl = p; p += (size_t)nx * Rp;
+    o.cl = p; p += (size_t)nx * Rp;
+    o.wl = p; p += (size_t)nx * Rp;
+    o.q0 = p; p += (size_t)h.maxw * Rp;
+    o.q1 = p; p += (size_t)h.maxw * Rp;
+    o.P = p; p += (size_t)h.maxw * nin * Rp;
+    o.a0 = p; p += (size_t)h.maxw * nin * Rp;
+    o.a1 = p; p += (size_t)h.maxw * nin * Rp;
+    o.pl = p; p += (size_t)nx * nin * Rp;
+    o.hacc = p; p += (size_t)nin * nin * Rp;
+    o.total = p;
+    return o;
+}
+
+// multipliers of the chunk's rows, feature-major, times the output layer's derivatives: cl = mult . s_L' (the cotangent on
+// z_L), wl = mult . s_L'' (its curvature weights; zero for a linear output layer)
+template <typename T>
+__global__ void layered_hmult_kernel(int H, int nx, int m, const T* __restrict__ lam, long long r0, int R, long long Rp,
+                                     const T* __restrict__ f, const T* __restrict__ dl, int act, T actp, T* __restrict__ cl,
+                                     T* __restrict__ wl) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const long long gr = r0 + r;
+    const long long b = gr / H, t = gr - b * H;
+    const T* lrow = lam + (size_t)b * m + (size_t)t * nx;
+    for (int k = 0; k < nx; ++k) {
+        const T mu = lrow[k];
+        if (act == NEMPC_ACT_LINEAR) {
+            cl[(size_t)k * Rp + r] = mu;
+            wl[(size_t)k * Rp + r] = T(0);
+        } else {
+            const T s1 = dl[(size_t)k * Rp + r];
+            cl[(size_t)k * Rp + r] = mu * s1;
+            wl[(size_t)k * Rp + r] = mu * (act_r2<T>(act, f[(size_t)k * Rp + r], actp) * s1);
+        }
+    }
+}
+
+// the last hidden layer's cotangent: q[j][r] = sum_k W_last[j][k] cl[k][r];  w = q . E (curvature weights), delta = q . D
+template <typename T>
+__global__ void layered_hseed_kernel(const T* __restrict__ Wlast, int wdt, int nx, const T* __restrict__ cl, const T* __restrict__ Dh,
+                                     const T* __restrict__ Eh, int R, long long Rp, T* __restrict__ delta, T* __restrict__ w) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (r >= R || j >= wdt) return;
+    T q = T(0);
+    for (int k = 0; k < nx; ++k) q = fma(Wlast[(size_t)j * nx + k], cl[(size_t)k * Rp + r], q);
+    w[(size_t)j * Rp + r] = q * Eh[(size_t)j * Rp + r];
+    delta[(size_t)j * Rp + r] = q * Dh[(size_t)j * Rp + r];
+}
+
+// H[p][q][r] (+)= sum_j w[j][r] P[j][p Rp + r] P[j][q Rp + r] for the inputs p in block pb, q in block qb (PB each, q <= p
+// kept).  A block is 64 rows x 4 waves; wave v sums the features j = v, v + 4, ...; the partial sums meet in LDS.
+// W0 != null: layer 0, whose tangents are the constants P[j][p] = W0[p][j] (W_0 row-major (in, out)).
+template <typename T, int PB>
+__global__ __launch_bounds__(256) void layered_hcontract_kernel(const T* __restrict__ P, long long ldp, const T* __restrict__ W0, int ldw0,
+                                                                const T* __restrict__ w, int K, int nin, int R, long long Rp,
+                                                                T* __restrict__ Hacc, int accumulate) {
+    __shared__ T red[3][PB * PB][64];
+    const int lane = threadIdx.x & 63, v = threadIdx.x >> 6;
+    const int r = blockIdx.x * 64 + lane;
+    const bool live = r < R;
+    const int rc = live ? r : R - 1;
+    // block pair (pb, qb) with qb <= pb out of blockIdx.y
+    int pb = 0, rem = blockIdx.y;
+    while (rem > pb) { rem -= pb + 1; ++pb; }
+    const int qb = rem;
+    const int p0 = pb * PB, q0 = qb * PB;
+    T acc[PB][PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+#pragma unroll
+        for (int j = 0; j < PB; ++j) acc[i][j] = T(0);
+    for (int j = v; j < K; j += 4) {
+        const T wj = w[(size_t)j * Rp + rc];
+        T tp[PB], tq[PB];
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int p = p0 + i, q = q0 + i;
+            if (W0) {
+                tp[i] = p < nin ? W0[(size_t)p * ldw0 + j] : T(0);
+                tq[i] = q < nin ? W0[(size_t)q * ldw0 + j] : T(0);
+            } else {
+                tp[i] = p < nin ? P[(size_t)j * ldp + (size_t)p * Rp + rc] : T(0);
+                tq[i] = q < nin ? P[(size_t)j * ldp + (size_t)q * Rp + rc] : T(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const T pp = wj * tp[i];
+#pragma unroll
+            for (int jj = 0; jj < PB; ++jj) acc[i][jj] = fma(pp, tq[jj], acc[i][jj]);
+        }
+    }
+    if (v > 0) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+#pragma unroll
+            for (int jj = 0; jj < PB; ++jj) red[v - 1][i * PB + jj][lane] = acc[i][jj];
+    }
+    __syncthreads();
+    if (v == 0 && live) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+#pragma unroll
+            for (int jj = 0; jj < PB; ++jj) {
+                const int p = p0 + i, q = q0 + jj;
+                if (p < nin && q <= p) {
+                    const int e = i * PB + jj;
+                    const T s = ((acc[i][jj] + red[0][e][lane]) + red[1][e][lane]) + red[2][e][lane];
+                    T* dst = Hacc + (size_t)(p * nin + q) * Rp + r;
+                    *dst = accumulate ? *dst + s : s;
+                }
+            }
+    }
+}
+
+// blocks[(row)][p][q] row-major, both triangles, from the lower triangle of the accumulators
+template <typename T>
+__global__ void layered_hfinish_kernel(int nin, long long r0, int R, long long Rp, const T* __restrict__ Hacc, T* __restrict__ blocks) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    T* blk = blocks + (size_t)(r0 + r) * nin * nin;
+    for (int p = 0; p < nin; ++p)
+        for (int q = 0; q <= p; ++q) {
+            const T v = Hacc[(size_t)(p * nin + q) * Rp + r];
+            blk[p * nin + q] = v;
+            blk[q * nin + p] = v;
+        }
+}
+
+template <typename T>
+int hcontract(hipStream_t s, const T* P, long long ldp, const T* W0, int ldw0, const T* w, int K, int nin, int R, long long Rp, T* Hacc,
+              bool accumulate) {
+    const int PBs = nin <= 4 ? 4 : 8;
+    const int nb = (nin + PBs - 1) / PBs;
+    const dim3 grid((unsigned)((R + 63) / 64), (unsigned)(nb * (nb + 1) / 2)), block(256);
+    if (PBs == 4)
+        hipLaunchKernelGGL((layered_hcontract_kernel<T, 4>), grid, block, 0, s, P, ldp, W0, ldw0, w, K, nin, R, Rp, Hacc, accumulate ? 1 : 0);
+    else
+        hipLaunchKernelGGL((layered_hcontract_kernel<T, 8>), grid, block, 0, s, P, ldp, W0, ldw0, w, K, nin, R, Rp, Hacc, accumulate ? 1 : 0);
+    NEMPC_HIP(hipGetLastError());
+    return NEMPC_OK;
+}
+
+template <typename T>
+int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const void* lamv, void* blocksv, hipStream_t s) {
+    const T* Z = static_cast<const T*>(Zv);
+    const T* X0 = static_cast<const T*>(X0v);
+    const T* lam = static_cast<const T*>(lamv);
+    T* blocks = static_cast<T*>(blocksv);
+    const int nx = h.cfg.nx, nin = h.nin, ne = h.ne, nl = h.nl, H = h.cfg.H;
+    const long long rows = (long long)B * H;
+    const long long Rc = h.layered_hess_chunk_rows;
+    T* ws = static_cast<T*>(h.d_layered_hws);
+    const RowGather gk = h.gather();
+    const bool lin_out = h.act[nl - 1] == NEMPC_ACT_LINEAR;
+    int rc;
+    for (long long r0 = 0; r0 < rows; r0 += Rc) {
+        const int R = (int)(rows - r0 < Rc ? rows - r0 : Rc);
+        const long long Rp = ((long long)R + LG_BM - 1) / LG_BM * LG_BM;
+        const LayeredHws o = layered_hess_offsets(h, (size_t)Rp);
+        const dim3 rb(256), rg((unsigned)((R + 255) / 256));
+        // ---- forward, every layer's s' and s'' kept
+        hipLaunchKernelGGL(layered_gather_kernel<T>, rg, rb, 0, s, gk, nin, ne, static_cast<const T*>(h.d_extra), Z, X0, r0, R, Rp,
+                           ws + o.xi, static_cast<const T*>(nullptr), T(0));
+        NEMPC_HIP(hipGetLastError());
+        const T* in = ws + o.xi;
+        for (int l = 0; l < nl - 1; ++l) {
+            T* out = ws + ((l & 1) ? o.x1 : o.x0);
+            GemmArgs a{};
+            a.mode = LG_FORWARD; a.act = h.act[l]; a.actp = h.actp[l];
+            a.A = in; a.lda = Rp; a.Bw = h.d_W[l]; a.ldb = h.dout[l]; a.bias = h.d_b[l];
+            a.C = out; a.ldc = Rp; a.D = ws + o.d[l]; a.E = ws + o.e[l]; a.ldd = Rp;
+            a.M = R; a.N = h.dout[l]; a.K = h.din[l];
+            if ((rc = gemm_ft<T, 1>(s, a))) return rc;
+            in = out;
+        }
+        if ((rc = skinny<T>(s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, (long long)R, ws + o.f, Rp,
+                            static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl, (T)h.actp[nl - 1])))
+            return rc;
+        // ---- reverse with the multipliers as the one cotangent: curvature weights w_l of every hidden layer
+        hipLaunchKernelGGL(layered_hmult_kernel<T>, rg, rb, 0, s, H, nx, h.m, lam, r0, R, Rp, ws + o.f, ws + o.dl, h.act[nl - 1],
+                           (T)h.actp[nl - 1], ws + o.cl, ws + o.wl);
+        NEMPC_HIP(hipGetLastError());
+        T* dq = ws + o.q0;
+        hipLaunchKernelGGL(layered_hseed_kernel<T>, dim3(rg.x, (unsigned)h.dout[nl - 2]), rb, 0, s, static_cast<const T*>(h.d_W[nl - 1]),
+                           h.dout[nl - 2], nx, ws + o.cl, ws + o.d[nl - 2], ws + o.e[nl - 2], R, Rp, dq, ws + o.cw[nl - 2]);
+        NEMPC_HIP(hipGetLastError());
+        for (int l = nl - 3; l >= 0; --l) {
+            T* dn = (dq == ws + o.q0) ? ws + o.q1 : ws + o.q0;
+            GemmArgs a{};
+            a.mode = LG_REVERSE;
+            a.A = dq; a.lda = Rp; a.Bw = h.d_Wt[l + 1]; a.ldb = h.dout[l];
+            a.M = (int)Rp; a.N = h.dout[l]; a.K = h.dout[l + 1]; a.Rmod = Rp;
+            a.D = ws + o.d[l]; a.E = ws + o.e[l]; a.ldd = Rp;
+            a.C = l > 0 ? dn : nullptr; a.C2 = ws + o.cw[l]; a.ldc = Rp;
+            if ((rc = gemm_ft<T, 1>(s, a))) return rc;
+            dq = dn;
+        }
+        // ---- layer 0: constant tangents W_0^T
+        T* Hacc = ws + o.hacc;
+        if ((rc = hcontract<T>(s, nullptr, 0, static_cast<const T*>(h.d_W[0]), h.dout[0], ws + o.cw[0], h.dout[0], nin, R, Rp, Hacc, false)))
+            return rc;
+        // ---- tangents of all nin inputs side by side (column p Rp + r), contracted layer by layer
+        const long long ldt = (long long)nin * Rp;
+        const long long Mt = (long long)(nin - 1) * Rp + Rp;
+        const T* ta = nullptr;
+        for (int l = 1; l < nl - 1; ++l) {
+            T* tn = (ta == ws + o.a0) ? ws + o.a1 : ws + o.a0;
+            const bool need_a = l < nl - 2 || !lin_out;     // D_l . P_l feeds the next layer (or the output layer's curvature)
+            GemmArgs a{};
+            a.mode = LG_REVERSE;
+            a.Bw = h.d_W[l]; a.ldb = h.dout[l];
+            a.M = (int)Mt; a.N = h.dout[l]; a.K = h.din[l]; a.Rmod = Rp;
+            a.D = ws + o.d[l]; a.ldd = Rp;
+            a.C = need_a ? tn : nullptr; a.Craw = ws + o.P; a.ldc = ldt;
+            if (l == 1) {
+                a.A = ws + o.d[0]; a.lda = Rp;
+                a.seedW = h.d_Wt[0]; a.seed_nx = h.din[0]; a.seedDl = nullptr;
+                if ((rc = gemm_ft<T, 1, true, LG_CONTRACT_NONE>(s, a))) return rc;
+            } else {
+                a.A = ta; a.lda = ldt;
+                if ((rc = gemm_ft<T, 1>(s, a))) return rc;
+            }
+            if ((rc = hcontract<T>(s, ws + o.P, ldt, nullptr, 0, ws + o.cw[l], h.dout[l], nin, R, Rp, Hacc, true))) return rc;
+            ta = tn;
+        }
+        if (!lin_out) {
+            // the output layer's own curvature: P_L = W_L^T (D_{L-2} . P_{L-2}), weights mult . s_L''
+            const long long Mj = (long long)(nin - 1) * Rp + R;
+            if ((rc = skinny<T>(s, ta, ldt, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, Mj, ws + o.pl, ldt,
+                                static_cast<const T*>(nullptr), 2, 0, static_cast<T*>(nullptr), T(0))))
+                return rc;
+            if ((rc = hcontract<T>(s, ws + o.pl, ldt, nullptr, 0, ws + o.wl, nx, nin, R, Rp, Hacc, true))) return rc;
+        }
+        hipLaunchKernelGGL(layered_hfinish_kernel<T>, rg, rb, 0, s, nin, r0, R, Rp, Hacc, blocks);
+        NEMPC_HIP(hipGetLastError());
+    }
+    return NEMPC_OK;
+}
+
 }  // namespace
 
 // Which networks take this path: at least one hidden layer, decision + extra inputs within the skinny kernel's 32
@@ -812,6 +1097,47 @@ int layered_prepare(Handle& h) {
 void layered_free(Handle& h) {
     if (h.d_layered_ws) (void)hipFree(h.d_layered_ws);
     h.d_layered_ws = nullptr;
+    if (h.d_layered_hws) (void)hipFree(h.d_layered_hws);
+    h.d_layered_hws = nullptr;
+}
+
+// Hessian chunk workspace, sized like the rows one (about 6 GB at most, 4096 .. 65536 rows)
+int layered_hess_prepare(Handle& h) {
+    const size_t cap = (size_t)h.cfg.max_batch * h.cfg.H;
+    const LayeredHws per = layered_hess_offsets(h, 1);
+    size_t rc_rows = ((size_t)6144 << 20) / (per.total * h.esz);
+    if (rc_rows > 65536) rc_rows = 65536;
+    if (rc_rows < 4096) rc_rows = 4096;
+    if (const char* e = getenv("NEMPC_LAYERED_CHUNK_ROWS")) {     // (tests of the chunk loop)
+        const long long v = atoll(e);
+        if (v > 0) rc_rows = (size_t)v;
+    }
+    if (rc_rows > cap) rc_rows = cap;
+    rc_rows = (rc_rows + LG_BM - 1) / LG_BM * LG_BM;
+    if (h.d_layered_hws && h.layered_hess_chunk_rows == (long long)rc_rows) return NEMPC_OK;
+    if (h.d_layered_hws) (void)hipFree(h.d_layered_hws);
+    h.d_layered_hws = nullptr;
+    h.layered_hess_chunk_rows = (long long)rc_rows;
+    const size_t bytes = layered_hess_offsets(h, rc_rows).total * h.esz;
+    hipError_t e = hipMalloc(&h.d_layered_hws, bytes);
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc (layered Hessian workspace): ") + hipGetErrorString(e));
+        return NEMPC_ENOMEM;
+    }
+    return NEMPC_OK;
+}
+
+// Lagrangian blocks of Discret / Unity models on the GEMM path.  NEMPC_EUNSUPPORTED: RK4 (the generic kernel keeps it), a
+// nonlinear output layer behind a single hidden layer, NEMPC_LAYERED_HESS=0 (A/B knob).
+int launch_rowhess_layered(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks, hipStream_t s) {
+    static const bool off = [] { const char* e = getenv("NEMPC_LAYERED_HESS"); return e && atoi(e) == 0; }();
+    if (off || !h.layered || h.cfg.integrator == NEMPC_RK4) return NEMPC_EUNSUPPORTED;
+    if (h.nl < 2 || (h.nl == 2 && h.act[h.nl - 1] != NEMPC_ACT_LINEAR)) return NEMPC_EUNSUPPORTED;
+    int rc = layered_hess_prepare(h);
+    if (rc) return rc;
+    h.last_hess_kernel = 5;
+    return h.cfg.dtype == NEMPC_F64 ? run_layered_hess<double>(h, B, Z, X0, lambda, blocks, s)
+                                    : run_layered_hess<float>(h, B, Z, X0, lambda, blocks, s);
 }
 
 int launch_rows_layered(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s) {

@@ -511,6 +511,10 @@ int launch_rows_valu(Handle& h, int B, const void* Z, const void* X0, void* g, v
 
 int launch_rowhess_valu(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
                         hipStream_t s) {
+    if (h.layered) {        // Discret / Unity blocks of wide / deep networks: the GEMM path (kernels_layered.hip)
+        const int rc = launch_rowhess_layered(h, B, Z, X0, lambda, blocks, s);
+        if (rc != NEMPC_EUNSUPPORTED) return rc;
+    }
     const size_t rows = (size_t)B * h.cfg.H;
     const size_t Rcap = (size_t)h.cfg.max_batch * h.cfg.H;
     const dim3 block(256), grid((unsigned)((rows + 255) / 256));

@@ -163,6 +163,8 @@ struct Handle {
     bool layered = false;        // rows through the layer-at-a-time GEMM pipeline (kernels_layered.hip) instead of rows_valu_kernel
     void* d_layered_ws = nullptr;   // its chunk workspace (allocated on first use)
     long long layered_chunk_rows = 0;
+    void* d_layered_hws = nullptr;  // chunk workspace of its Hessian sweeps (allocated on first use)
+    long long layered_hess_chunk_rows = 0;
     void* solver_ws = nullptr;   // solver.hip
     void* comm = nullptr;        // comm.hip: RCCL communicator of the u0 all-gather
     mutable int last_row_kernel = 0;  // 1 valu, 2 coop, 3 wave-tile
@@ -203,6 +205,7 @@ int launch_rowhess_valu(Handle& h, int B, const void* Z, const void* X0, const v
 // ---- kernels_layered.hip : layer-at-a-time matrix-core path for wide / deep / mixed-activation networks
 bool layered_supported(const Handle& h);
 int launch_rows_layered(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s);
+int launch_rowhess_layered(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks, hipStream_t s);
 void layered_free(Handle& h);
 
 // ---- kernels_mfma.hip : matrix-core row kernel

@@ -177,7 +177,8 @@ class CallbackEngine:
         """Name of the network kernel the most recent Lagrangian-Hessian evaluation launched ("rk4:" prefix: inside the RK4
         pipeline)."""
         v = self.lib.nempc_last_hess_kernel(self._handle)
-        name = {0: None, 1: "rowhess_valu_kernel", 2: "rowhess_coop_kernel", 3: "rowhess_mfma_kernel", 4: "rowhess_coopfx_kernel"}[v % 10]
+        name = {0: None, 1: "rowhess_valu_kernel", 2: "rowhess_coop_kernel", 3: "rowhess_mfma_kernel", 4: "rowhess_coopfx_kernel",
+                5: "layered_gemm_kernel"}[v % 10]
         return ("rk4:" + name) if v >= 10 and name else name
 
     # ------------------------------------------------------------------ parameters

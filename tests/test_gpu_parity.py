@@ -687,6 +687,8 @@ def test_every_matrix_core_instantiation_with_its_hessian_against_the_oracle():
     ([200, 130, 70], ["relu", "sigmoid", "elu", "softplus"], 3, 2, "unity"),  # ragged widths, a mix, non-linear output
     ([144, 96, 96, 40, 24], ["tanh", "relu", "tanh", "softplus", "elu", "linear"], 6, 3, "rk4"),
     ([512], "sigmoid", 1, 1, "rk4"),
+    ([300], "tanh", 2, 1, "discret"),                                        # one hidden layer: no tangent products at all
+    ([160, 160], ["selu", "leaky_relu:0.1", "linear"], 4, 2, "discret"),
 ])
 def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu, integ):
     """Networks outside the register-resident kernels (width > 128, more than three hidden layers, per-layer activation
@@ -738,14 +740,20 @@ def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu
             assert ev.last_row_kernel == "rows_valu_kernel"
             np.testing.assert_allclose(res["g"], rv["g"], **tol)
             np.testing.assert_allclose(res["jac_tiles"], rv["jac_tiles"], **tol)
-            # the Lagrangian Hessian of such a model: generic kernel, unchanged
+            # the Lagrangian Hessian of such a model: the GEMM sweeps with the layer-wise contraction for Discret / Unity
+            # (csrc/kernels_layered.hip, "Contracted network Hessian"), the generic kernel for RK4 -- against the oracle and
+            # against the generic kernel
             lam = np.random.default_rng(1).normal(size=(B, eng.m))
             hv = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lam), eng.to_device(np.ones(B)))["hvals"]
-            assert eng.last_hess_kernel == "rowhess_valu_kernel"
+            assert eng.last_hess_kernel == ("rowhess_valu_kernel" if integ == "rk4" else "layered_gemm_kernel")
+            hv = hv.to("cpu", torch.float64).numpy()
             for i in range(3):
                 refh = prob.hessian_values(Zh[i], X0h[i], lam[i], 1.0)
-                np.testing.assert_allclose(hv[i].to("cpu", torch.float64).numpy(), refh, rtol=0,
-                                           atol=(1e-9 if f64 else 5e-3) * max(1.0, np.abs(refh).max()))
+                np.testing.assert_allclose(hv[i], refh, rtol=0, atol=(1e-9 if f64 else 5e-3) * max(1.0, np.abs(refh).max()))
+            hg = ev.hess(ev.to_device(Zh), ev.to_device(X0h), ev.to_device(lam), ev.to_device(np.ones(B)))["hvals"]
+            assert ev.last_hess_kernel == "rowhess_valu_kernel"
+            hg = hg.to("cpu", torch.float64).numpy()
+            np.testing.assert_allclose(hv, hg, rtol=0, atol=(1e-10 if f64 else 5e-3) * max(1.0, np.abs(hg).max()))
 
 
 def test_layered_path_chunks_large_batches():

@@ -43,6 +43,16 @@ for name, nx, nu, hidden, H, integ, acts in cases:
             row[kern] = {"us": t * 1e6, "tflops": flops / t / 1e12, "frac_of_matrix_peak": flops / t / 1e12 / peak, "kernel": eng.last_row_kernel}
             full, _ = eng.bind(Z, X0, ("f", "grad", "g", "jac_dense"))
             row[kern]["dense_eval_us"] = timed(full, 10 if kern == "layered" else 2) * 1e6
+            if integ != "rk4":
+                # the Lagrangian-Hessian callback (tril values): (2 + nin) GEMM sweeps + the layer-wise contraction
+                lam = eng.to_device(np.random.default_rng(2).normal(size=(B, eng.m)))
+                sig = eng.to_device(np.ones(B))
+                hfn = lambda: eng.hess(Z, X0, lam, sig)
+                th = timed(hfn, 10 if kern == "layered" else 2)
+                hflops = flops * (2 + nx + nu) / (1 + nx)
+                row[kern]["hess_us"] = th * 1e6
+                row[kern]["hess_kernel"] = eng.last_hess_kernel
+                row[kern]["hess_frac_of_matrix_peak"] = hflops / th / 1e12 / peak
             del eng
         out[f"{name}/{str(dt)[6:]}"] = {"gflop": flops / 1e9, **row}
         print(name, str(dt)[6:], json.dumps(row), flush=True)
