@@ -517,6 +517,22 @@ __global__ void layered_rk4_kernel(int stage, int nx, int nin, T cdt, T wgt, con
     }
 }
 
+// RK4 Hessian pipeline (kernels_rk4hess.hip): the record of (row, stage) = [xi_s | J_s (nx, nin) | dk_{s-1} (nx, nin)], written
+// between the stage's reverse sweep and its bookkeeping (dk still holds dk_{s-1})
+template <typename T>
+__global__ void layered_stage_record_kernel(int stage, int nx, int nin, long long r0, int R, long long Rp, const T* __restrict__ xi,
+                                            const T* __restrict__ J, const T* __restrict__ dk, T* __restrict__ out, int stride) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    T* rec = out + ((size_t)(r0 + r) * 4 + stage) * stride;
+    for (int d = 0; d < nin; ++d) rec[d] = xi[(size_t)d * Rp + r];
+    for (int i = 0; i < nx; ++i)
+        for (int d = 0; d < nin; ++d) {
+            rec[nin + i * nin + d] = J[(size_t)d * (nx * Rp) + (size_t)i * Rp + r];
+            rec[nin + nx * nin + i * nin + d] = stage > 0 ? dk[(size_t)(i * nin + d) * Rp + r] : T(0);
+        }
+}
+
 // defects, box rows and compact tiles of the chunk's rows (same formulas as rows_valu_kernel)
 template <typename T>
 __global__ void layered_finish_kernel(RowGather gk, int kind, T DT, int nin, const T* __restrict__ Z, const T* __restrict__ X0,
@@ -648,7 +664,8 @@ int gemm_reverse_fused(hipStream_t s, const GemmArgs& a, bool seed, bool last) {
 }
 
 template <typename T>
-int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, void* tilesv, hipStream_t s) {
+int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, void* tilesv, hipStream_t s, void* stage_out = nullptr,
+                int stage_stride = 0) {
     const T* Z = static_cast<const T*>(Zv);
     const T* X0 = static_cast<const T*>(X0v);
     T* g = static_cast<T*>(gv);
@@ -766,6 +783,11 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                     return rc;
             }
             }
+            if (rk4 && stage_out) {
+                hipLaunchKernelGGL(layered_stage_record_kernel<T>, rg, rb, 0, s, st, nx, nin, r0, R, Rp, ws + o.xi, ws + o.j, ws + o.dk,
+                                   static_cast<T*>(stage_out), stage_stride);
+                NEMPC_HIP(hipGetLastError());
+            }
             if (rk4) {
                 hipLaunchKernelGGL(layered_rk4_kernel<T>, rg, rb, 0, s, st, nx, nin, cdt, (st == 0 || st == 3) ? T(1) : T(2), ws + o.f,
                                    ws + o.j, R, Rp, ws + o.kprev, ws + o.acck, ws + o.dk, ws + o.dkn, ws + o.accdk);
@@ -830,15 +852,16 @@ LayeredHws layered_hess_offsets(const Handle& h, size_t Rp) {
 
 // multipliers of the chunk's rows, feature-major, times the output layer's derivatives: cl = mult . s_L' (the cotangent on
 // z_L), wl = mult . s_L'' (its curvature weights; zero for a linear output layer)
+// (direct: the rows are the (row, stage) pairs of the RK4 pipeline, multipliers nu[(pair)][nx] row-major)
 template <typename T>
-__global__ void layered_hmult_kernel(int H, int nx, int m, const T* __restrict__ lam, long long r0, int R, long long Rp,
+__global__ void layered_hmult_kernel(int H, int nx, int m, const T* __restrict__ lam, int direct, long long r0, int R, long long Rp,
                                      const T* __restrict__ f, const T* __restrict__ dl, int act, T actp, T* __restrict__ cl,
                                      T* __restrict__ wl) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const long long gr = r0 + r;
     const long long b = gr / H, t = gr - b * H;
-    const T* lrow = lam + (size_t)b * m + (size_t)t * nx;
+    const T* lrow = direct ? lam + (size_t)gr * nx : lam + (size_t)b * m + (size_t)t * nx;
     for (int k = 0; k < nx; ++k) {
         const T mu = lrow[k];
         if (act == NEMPC_ACT_LINEAR) {
@@ -931,6 +954,18 @@ __global__ __launch_bounds__(256) void layered_hcontract_kernel(const T* __restr
     }
 }
 
+// direct mode: xi^T[d][r] from the stage records (row r0 + r = (row, stage) pair), the extra inputs of the pair's row
+template <typename T>
+__global__ void layered_hgather_direct_kernel(const T* __restrict__ stage, int stride, int nin, int ne, const T* __restrict__ extra,
+                                              long long r0, int R, long long Rp, T* __restrict__ xi) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const long long gr = r0 + r;
+    const T* rec = stage + (size_t)gr * stride;
+    for (int d = 0; d < nin; ++d) xi[(size_t)d * Rp + r] = rec[d];
+    for (int j = 0; j < ne; ++j) xi[(size_t)(nin + j) * Rp + r] = extra[(size_t)(gr >> 2) * ne + j];
+}
+
 // blocks[(row)][p][q] row-major, both triangles, from the lower triangle of the accumulators
 template <typename T>
 __global__ void layered_hfinish_kernel(int nin, long long r0, int R, long long Rp, const T* __restrict__ Hacc, T* __restrict__ blocks) {
@@ -959,14 +994,17 @@ int hcontract(hipStream_t s, const T* P, long long ldp, const T* W0, int ldw0, c
     return NEMPC_OK;
 }
 
+// stage != null: direct mode -- `nrows` rows whose inputs are the stage records' xi and whose multipliers are lamv[(row)][nx]
 template <typename T>
-int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const void* lamv, void* blocksv, hipStream_t s) {
+int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const void* lamv, void* blocksv, hipStream_t s,
+                     const void* stagev = nullptr, int stage_stride = 0, long long nrows = 0) {
     const T* Z = static_cast<const T*>(Zv);
     const T* X0 = static_cast<const T*>(X0v);
     const T* lam = static_cast<const T*>(lamv);
+    const T* stage = static_cast<const T*>(stagev);
     T* blocks = static_cast<T*>(blocksv);
     const int nx = h.cfg.nx, nin = h.nin, ne = h.ne, nl = h.nl, H = h.cfg.H;
-    const long long rows = (long long)B * H;
+    const long long rows = stage ? nrows : (long long)B * H;
     const long long Rc = h.layered_hess_chunk_rows;
     T* ws = static_cast<T*>(h.d_layered_hws);
     const RowGather gk = h.gather();
@@ -978,8 +1016,12 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
         const LayeredHws o = layered_hess_offsets(h, (size_t)Rp);
         const dim3 rb(256), rg((unsigned)((R + 255) / 256));
         // ---- forward, every layer's s' and s'' kept
-        hipLaunchKernelGGL(layered_gather_kernel<T>, rg, rb, 0, s, gk, nin, ne, static_cast<const T*>(h.d_extra), Z, X0, r0, R, Rp,
-                           ws + o.xi, static_cast<const T*>(nullptr), T(0));
+        if (stage)
+            hipLaunchKernelGGL(layered_hgather_direct_kernel<T>, rg, rb, 0, s, stage, stage_stride, nin, ne, static_cast<const T*>(h.d_extra),
+                               r0, R, Rp, ws + o.xi);
+        else
+            hipLaunchKernelGGL(layered_gather_kernel<T>, rg, rb, 0, s, gk, nin, ne, static_cast<const T*>(h.d_extra), Z, X0, r0, R, Rp,
+                               ws + o.xi, static_cast<const T*>(nullptr), T(0));
         NEMPC_HIP(hipGetLastError());
         const T* in = ws + o.xi;
         for (int l = 0; l < nl - 1; ++l) {
@@ -996,7 +1038,7 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
                             static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl, (T)h.actp[nl - 1])))
             return rc;
         // ---- reverse with the multipliers as the one cotangent: curvature weights w_l of every hidden layer
-        hipLaunchKernelGGL(layered_hmult_kernel<T>, rg, rb, 0, s, H, nx, h.m, lam, r0, R, Rp, ws + o.f, ws + o.dl, h.act[nl - 1],
+        hipLaunchKernelGGL(layered_hmult_kernel<T>, rg, rb, 0, s, H, nx, h.m, lam, stage ? 1 : 0, r0, R, Rp, ws + o.f, ws + o.dl, h.act[nl - 1],
                            (T)h.actp[nl - 1], ws + o.cl, ws + o.wl);
         NEMPC_HIP(hipGetLastError());
         T* dq = ws + o.q0;
@@ -1127,17 +1169,42 @@ int layered_hess_prepare(Handle& h) {
     return NEMPC_OK;
 }
 
-// Lagrangian blocks of Discret / Unity models on the GEMM path.  NEMPC_EUNSUPPORTED: RK4 (the generic kernel keeps it), a
-// nonlinear output layer behind a single hidden layer, NEMPC_LAYERED_HESS=0 (A/B knob).
-int launch_rowhess_layered(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks, hipStream_t s) {
+// Lagrangian blocks on the GEMM path: Discret / Unity directly, RK4 through the stage pipeline of kernels_rk4hess.hip.
+// NEMPC_EUNSUPPORTED: a nonlinear output layer behind a single hidden layer, NEMPC_LAYERED_HESS=0 (A/B knob).
+static bool layered_hess_usable(const Handle& h) {
     static const bool off = [] { const char* e = getenv("NEMPC_LAYERED_HESS"); return e && atoi(e) == 0; }();
-    if (off || !h.layered || h.cfg.integrator == NEMPC_RK4) return NEMPC_EUNSUPPORTED;
-    if (h.nl < 2 || (h.nl == 2 && h.act[h.nl - 1] != NEMPC_ACT_LINEAR)) return NEMPC_EUNSUPPORTED;
+    if (off || !h.layered) return false;
+    return h.nl >= 2 && !(h.nl == 2 && h.act[h.nl - 1] != NEMPC_ACT_LINEAR);
+}
+
+int launch_rowhess_layered(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks, hipStream_t s) {
+    if (!layered_hess_usable(h)) return NEMPC_EUNSUPPORTED;
+    if (h.cfg.integrator == NEMPC_RK4) return launch_rowhess_rk4_layered(h, B, Z, X0, lambda, blocks, s, nullptr, nullptr);
     int rc = layered_hess_prepare(h);
     if (rc) return rc;
     h.last_hess_kernel = 5;
     return h.cfg.dtype == NEMPC_F64 ? run_layered_hess<double>(h, B, Z, X0, lambda, blocks, s)
                                     : run_layered_hess<float>(h, B, Z, X0, lambda, blocks, s);
+}
+
+// direct mode (RK4 pipeline, step 3): contracted network Hessians of `nrows` (row, stage) pairs at the records' inputs
+int launch_rowhess_layered_direct(Handle& h, long long nrows, const void* stage, int stride, const void* nu, void* out, hipStream_t s) {
+    if (!layered_hess_usable(h)) return NEMPC_EUNSUPPORTED;
+    int rc = layered_hess_prepare(h);
+    if (rc) return rc;
+    h.last_hess_kernel = 5;
+    return h.cfg.dtype == NEMPC_F64 ? run_layered_hess<double>(h, 0, nullptr, nullptr, nu, out, s, stage, stride, nrows)
+                                    : run_layered_hess<float>(h, 0, nullptr, nullptr, nu, out, s, stage, stride, nrows);
+}
+
+// rows with the stage records of the RK4 Hessian pipeline (step 1)
+int launch_rows_layered_stages(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* stage_out, int stage_stride,
+                               hipStream_t s) {
+    int rc = layered_prepare(h);
+    if (rc) return rc;
+    h.last_row_kernel = 8;
+    return h.cfg.dtype == NEMPC_F64 ? run_layered<double>(h, B, Z, X0, g, tiles, s, stage_out, stage_stride)
+                                    : run_layered<float>(h, B, Z, X0, g, tiles, s, stage_out, stage_stride);
 }
 
 int launch_rows_layered(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s) {

@@ -169,4 +169,27 @@ int launch_rowhess_rk4_mfma(Handle& h, int B, const void* Z, const void* X0, con
                : run_small_kernels<float>(h, R, lambda, blocks, stride, true, s);
 }
 
+// The same pipeline for networks on the layer-at-a-time GEMM path (kernels_layered.hip): steps 1 and 3 are its launches
+int launch_rowhess_rk4_layered(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks, hipStream_t s,
+                               void* g_out, void* tiles_out) {
+    const int nx = h.cfg.nx, nin = h.nin;
+    const int stride = nin + 2 * nx * nin;
+    const size_t Rcap = (size_t)h.cfg.max_batch * h.cfg.H, R = (size_t)B * h.cfg.H;
+    int rc;
+    if ((rc = dev_alloc_rk4(&h.d_rk4_stage, Rcap * 4 * stride * h.esz))) return rc;
+    if ((rc = dev_alloc_rk4(&h.d_rk4_nu, Rcap * 4 * nx * h.esz))) return rc;
+    if ((rc = dev_alloc_rk4(&h.d_rk4_ht, Rcap * 4 * nin * nin * h.esz))) return rc;
+    if ((rc = launch_rows_layered_stages(h, B, Z, X0, g_out ? g_out : h.d_g_ws, tiles_out ? tiles_out : h.d_tiles_ws, h.d_rk4_stage,
+                                         stride, s)))
+        return rc;
+    const bool f64 = h.cfg.dtype == NEMPC_F64;
+    if ((rc = f64 ? run_small_kernels<double>(h, R, lambda, blocks, stride, false, s)
+                  : run_small_kernels<float>(h, R, lambda, blocks, stride, false, s)))
+        return rc;
+    if ((rc = launch_rowhess_layered_direct(h, (long long)R * 4, h.d_rk4_stage, stride, h.d_rk4_nu, h.d_rk4_ht, s))) return rc;
+    h.last_hess_kernel += 10;
+    return f64 ? run_small_kernels<double>(h, R, lambda, blocks, stride, true, s)
+               : run_small_kernels<float>(h, R, lambda, blocks, stride, true, s);
+}
+
 }  // namespace nempc

@@ -206,6 +206,12 @@ int launch_rowhess_valu(Handle& h, int B, const void* Z, const void* X0, const v
 bool layered_supported(const Handle& h);
 int launch_rows_layered(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s);
 int launch_rowhess_layered(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks, hipStream_t s);
+int launch_rowhess_layered_direct(Handle& h, long long nrows, const void* stage, int stride, const void* nu, void* out, hipStream_t s);
+int launch_rows_layered_stages(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* stage_out, int stage_stride,
+                               hipStream_t s);
+// kernels_rk4hess.hip: the RK4 pipeline with the layered launches as steps 1 and 3
+int launch_rowhess_rk4_layered(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks, hipStream_t s,
+                               void* g_out, void* tiles_out);
 void layered_free(Handle& h);
 
 // ---- kernels_mfma.hip : matrix-core row kernel

@@ -740,12 +740,12 @@ def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu
             assert ev.last_row_kernel == "rows_valu_kernel"
             np.testing.assert_allclose(res["g"], rv["g"], **tol)
             np.testing.assert_allclose(res["jac_tiles"], rv["jac_tiles"], **tol)
-            # the Lagrangian Hessian of such a model: the GEMM sweeps with the layer-wise contraction for Discret / Unity
-            # (csrc/kernels_layered.hip, "Contracted network Hessian"), the generic kernel for RK4 -- against the oracle and
-            # against the generic kernel
+            # the Lagrangian Hessian of such a model: the GEMM sweeps with the layer-wise contraction (csrc/kernels_layered.hip,
+            # "Contracted network Hessian"), for RK4 inside the stage pipeline of kernels_rk4hess.hip -- against the oracle
+            # and against the generic kernel
             lam = np.random.default_rng(1).normal(size=(B, eng.m))
             hv = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lam), eng.to_device(np.ones(B)))["hvals"]
-            assert eng.last_hess_kernel == ("rowhess_valu_kernel" if integ == "rk4" else "layered_gemm_kernel")
+            assert eng.last_hess_kernel == ("rk4:layered_gemm_kernel" if integ == "rk4" else "layered_gemm_kernel")
             hv = hv.to("cpu", torch.float64).numpy()
             for i in range(3):
                 refh = prob.hessian_values(Zh[i], X0h[i], lam[i], 1.0)
