@@ -43,13 +43,14 @@ for name, nx, nu, hidden, H, integ, acts in cases:
             row[kern] = {"us": t * 1e6, "tflops": flops / t / 1e12, "frac_of_matrix_peak": flops / t / 1e12 / peak, "kernel": eng.last_row_kernel}
             full, _ = eng.bind(Z, X0, ("f", "grad", "g", "jac_dense"))
             row[kern]["dense_eval_us"] = timed(full, 10 if kern == "layered" else 2) * 1e6
-            if integ != "rk4":
-                # the Lagrangian-Hessian callback (tril values): (2 + nin) GEMM sweeps + the layer-wise contraction
+            if True:
+                # the Lagrangian-Hessian callback (tril values): (2 + nin) GEMM sweeps + the layer-wise contraction (RK4: per
+                # stage, inside the stage pipeline, after a rows launch that writes the stage records)
                 lam = eng.to_device(np.random.default_rng(2).normal(size=(B, eng.m)))
                 sig = eng.to_device(np.ones(B))
                 hfn = lambda: eng.hess(Z, X0, lam, sig)
                 th = timed(hfn, 10 if kern == "layered" else 2)
-                hflops = flops * (2 + nx + nu) / (1 + nx)
+                hflops = flops * (2 + nx + nu) / (1 + nx) + (flops if integ == "rk4" else 0)
                 row[kern]["hess_us"] = th * 1e6
                 row[kern]["hess_kernel"] = eng.last_hess_kernel
                 row[kern]["hess_frac_of_matrix_peak"] = hflops / th / 1e12 / peak
