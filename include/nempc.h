@@ -308,7 +308,7 @@ int nempc_last_row_kernel(nempc_handle h);
 /* network kernel the handle's most recent nempc_hess (or solver iteration) launched for the Lagrangian blocks: 1 generic
  * (rowhess_valu_kernel), 2 cooperative matrix-core, forward-over-reverse (rowhess_coop_kernel), 3 wave-per-tile
  * matrix-core (rowhess_mfma_kernel), 4 compiled for the problem's shape, layer-wise contraction (rowhess_coopfx_kernel);
- * 5 the layer-at-a-time GEMM sweeps of wide / deep networks (layered_gemm_kernel + layered_hcontract_kernel; Discret / Unity);
+ * 5 the layer-at-a-time GEMM sweeps of wide / deep networks (layered_gemm_kernel + layered_hcontract_kernel);
  * + 10 when it ran inside the RK4 pipeline (stage records, stage multipliers, that kernel in direct mode, congruence
  * sum: integrator/rk4.py:181-285); 0 = none yet */
 int nempc_last_hess_kernel(nempc_handle h);

@@ -889,14 +889,17 @@ __global__ void layered_hseed_kernel(const T* __restrict__ Wlast, int wdt, int n
 }
 
 // H[p][q][r] (+)= sum_j w[j][r] P[j][p Rp + r] P[j][q Rp + r] for the inputs p in block pb, q in block qb (PB each, q <= p
-// kept).  A block is 64 rows x 4 waves; wave v sums the features j = v, v + 4, ...; the partial sums meet in LDS.
+// kept).  A block is 64 rows x NW waves (4 .. 16, chosen by the host so that the launch has a few waves per SIMD: with 4
+// at B*H = 20480 there were 1.25, 20 KB of loads in flight per CU and 1.3 - 1.6 TB/s); wave v sums the features j = v,
+// v + NW, ...; the partial sums meet in LDS in a fixed tree.
 // W0 != null: layer 0, whose tangents are the constants P[j][p] = W0[p][j] (W_0 row-major (in, out)).
 template <typename T, int PB>
-__global__ __launch_bounds__(256) void layered_hcontract_kernel(const T* __restrict__ P, long long ldp, const T* __restrict__ W0, int ldw0,
+__global__ __launch_bounds__(PB == 4 ? 1024 : 512) void layered_hcontract_kernel(const T* __restrict__ P, long long ldp, const T* __restrict__ W0, int ldw0,
                                                                 const T* __restrict__ w, int K, int nin, int R, long long Rp,
                                                                 T* __restrict__ Hacc, int accumulate) {
-    __shared__ T red[3][PB * PB][64];
-    const int lane = threadIdx.x & 63, v = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) unsigned char hc_lds_raw[];
+    T* const red = reinterpret_cast<T*>(hc_lds_raw);       // [NW / 2][PB * PB][64]
+    const int lane = threadIdx.x & 63, v = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const int r = blockIdx.x * 64 + lane;
     const bool live = r < R;
     const int rc = live ? r : R - 1;
@@ -910,34 +913,56 @@ __global__ __launch_bounds__(256) void layered_hcontract_kernel(const T* __restr
     for (int i = 0; i < PB; ++i)
 #pragma unroll
         for (int j = 0; j < PB; ++j) acc[i][j] = T(0);
-    for (int j = v; j < K; j += 4) {
-        const T wj = w[(size_t)j * Rp + rc];
-        T tp[PB], tq[PB];
+    // UN features' loads in flight per lane before their multiply-adds (one feature at a time this loop was a chain of
+    // dependent-latency round trips: 76 us per layer at 2 x 256, B*H = 20480, where the bytes are worth 15 - 40)
+    constexpr int UN = PB == 4 ? (sizeof(T) == 8 ? 4 : 8) : (sizeof(T) == 8 ? 2 : 4);
+    const bool diag = pb == qb;
+    for (int j0 = v; j0 < K; j0 += NW * UN) {
+        T wj[UN], tp[UN][PB], tq[UN][PB];
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int p = p0 + i, q = q0 + i;
-            if (W0) {
-                tp[i] = p < nin ? W0[(size_t)p * ldw0 + j] : T(0);
-                tq[i] = q < nin ? W0[(size_t)q * ldw0 + j] : T(0);
-            } else {
-                tp[i] = p < nin ? P[(size_t)j * ldp + (size_t)p * Rp + rc] : T(0);
-                tq[i] = q < nin ? P[(size_t)j * ldp + (size_t)q * Rp + rc] : T(0);
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + NW * u;
+            const bool in = j < K;
+            const int jc = in ? j : K - 1;
+            wj[u] = in ? w[(size_t)jc * Rp + rc] : T(0);
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const int p = p0 + i, q = q0 + i;
+                if (W0) {
+                    tp[u][i] = p < nin ? W0[(size_t)p * ldw0 + jc] : T(0);
+                    tq[u][i] = q < nin ? W0[(size_t)q * ldw0 + jc] : T(0);
+                } else {
+                    tp[u][i] = p < nin ? P[(size_t)jc * ldp + (size_t)p * Rp + rc] : T(0);
+                    tq[u][i] = diag ? tp[u][i] : (q < nin ? P[(size_t)jc * ldp + (size_t)q * Rp + rc] : T(0));
+                }
             }
         }
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const T pp = wj * tp[i];
+        for (int u = 0; u < UN; ++u)
 #pragma unroll
-            for (int jj = 0; jj < PB; ++jj) acc[i][jj] = fma(pp, tq[jj], acc[i][jj]);
+            for (int i = 0; i < PB; ++i) {
+                const T pp = wj[u] * tp[u][i];
+#pragma unroll
+                for (int jj = 0; jj < PB; ++jj) acc[i][jj] = fma(pp, tq[u][jj], acc[i][jj]);
+            }
+    }
+    // fixed tree: waves [h, 2h) hand their sums to waves [0, h), h = NW/2, NW/4, ... 1
+    for (int hh = NW >> 1; hh >= 1; hh >>= 1) {
+        if (v >= hh && v < 2 * hh) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+#pragma unroll
+                for (int jj = 0; jj < PB; ++jj) red[((v - hh) * PB * PB + i * PB + jj) * 64 + lane] = acc[i][jj];
         }
-    }
-    if (v > 0) {
+        __syncthreads();
+        if (v < hh) {
 #pragma unroll
-        for (int i = 0; i < PB; ++i)
+            for (int i = 0; i < PB; ++i)
 #pragma unroll
-            for (int jj = 0; jj < PB; ++jj) red[v - 1][i * PB + jj][lane] = acc[i][jj];
+                for (int jj = 0; jj < PB; ++jj) acc[i][jj] += red[(v * PB * PB + i * PB + jj) * 64 + lane];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (v == 0 && live) {
 #pragma unroll
         for (int i = 0; i < PB; ++i)
@@ -945,10 +970,8 @@ __global__ __launch_bounds__(256) void layered_hcontract_kernel(const T* __restr
             for (int jj = 0; jj < PB; ++jj) {
                 const int p = p0 + i, q = q0 + jj;
                 if (p < nin && q <= p) {
-                    const int e = i * PB + jj;
-                    const T s = ((acc[i][jj] + red[0][e][lane]) + red[1][e][lane]) + red[2][e][lane];
                     T* dst = Hacc + (size_t)(p * nin + q) * Rp + r;
-                    *dst = accumulate ? *dst + s : s;
+                    *dst = accumulate ? *dst + acc[i][jj] : acc[i][jj];
                 }
             }
     }
@@ -985,11 +1008,21 @@ int hcontract(hipStream_t s, const T* P, long long ldp, const T* W0, int ldw0, c
               bool accumulate) {
     const int PBs = nin <= 4 ? 4 : 8;
     const int nb = (nin + PBs - 1) / PBs;
-    const dim3 grid((unsigned)((R + 63) / 64), (unsigned)(nb * (nb + 1) / 2)), block(256);
-    if (PBs == 4)
-        hipLaunchKernelGGL((layered_hcontract_kernel<T, 4>), grid, block, 0, s, P, ldp, W0, ldw0, w, K, nin, R, Rp, Hacc, accumulate ? 1 : 0);
-    else
-        hipLaunchKernelGGL((layered_hcontract_kernel<T, 8>), grid, block, 0, s, P, ldp, W0, ldw0, w, K, nin, R, Rp, Hacc, accumulate ? 1 : 0);
+    const dim3 grid((unsigned)((R + 63) / 64), (unsigned)(nb * (nb + 1) / 2));
+    // waves per block: about four per SIMD over the launch, within 4 .. 16 (8 for the 8 x 8 accumulator form: LDS) and the
+    // feature count
+    int nw = 4;
+    const int nwmax = PBs == 4 ? 16 : 8;
+    while (nw < nwmax && (long long)grid.x * grid.y * nw < 4096 && nw * 2 <= K) nw *= 2;
+    const size_t lds = (size_t)(nw / 2) * PBs * PBs * 64 * sizeof(T);
+    const dim3 block((unsigned)(nw * 64));
+    if (PBs == 4) {
+        NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(layered_hcontract_kernel<T, 4>), lds));
+        hipLaunchKernelGGL((layered_hcontract_kernel<T, 4>), grid, block, lds, s, P, ldp, W0, ldw0, w, K, nin, R, Rp, Hacc, accumulate ? 1 : 0);
+    } else {
+        NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(layered_hcontract_kernel<T, 8>), lds));
+        hipLaunchKernelGGL((layered_hcontract_kernel<T, 8>), grid, block, lds, s, P, ldp, W0, ldw0, w, K, nin, R, Rp, Hacc, accumulate ? 1 : 0);
+    }
     NEMPC_HIP(hipGetLastError());
     return NEMPC_OK;
 }
