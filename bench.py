@@ -733,6 +733,8 @@ class Rank:
                     others[nm] = entry
                     del r2
                 out["other_configs"] = others
+            if self.world == 1 and args.config == "c2" and not args.batch and not args.no_other_configs:
+                out["layered_path"] = self.layered_leg()
             if self.world == 1 and not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(cfg)
         if self.rank == 0:
@@ -743,6 +745,53 @@ class Rank:
         if self.dist is not None:
             self.barrier()
             self.dist.destroy_process_group()
+
+    def layered_leg(self):
+        """Networks outside the register-resident kernels (the reference wraps any feed-forward Keras model:
+        model/tensorflow.py:8-29): the layer-at-a-time GEMM path (csrc/kernels_layered.hip) on the headline's dims with a
+        2 x 256 and a 3 x 256 tanh network, fp64 -- whole evaluation (f, grad, g, dense Jacobian) and exact-Hessian callback,
+        HIP-event time, fraction of the FP64 matrix peak by algorithmic GEMM flops, error of the timed launches' own output
+        against the oracle on the first problems."""
+        np, torch = self.np, self.torch
+        from oracle import nempc_oracle as orc
+        from pyneuralempc_amd import CallbackEngine
+        B, H, nx, nu = 1024, 20, 2, 1
+        out = {}
+        for name, hidden in (("2x256", [256, 256]), ("3x256", [256, 256, 256])):
+            net = orc.MLP.random(nx + nu, hidden, nx, seed=0)
+            prob = orc.Problem(net, H, nx, nu, orc.DISCRET, 1.0, Q=np.eye(nx), R=0.1 * np.eye(nu))
+            eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator="discret", dtype=torch.float64, device=self.dev, max_batch=B)
+            eng.set_objective(Q=np.eye(nx), R=0.1 * np.eye(nu))
+            Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=1)
+            Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+            rng = np.random.default_rng(7)
+            lamh, sigh = rng.normal(size=(B, eng.m)), rng.uniform(0.5, 1.5, size=B)
+            lam, sig = eng.to_device(lamh), eng.to_device(sigh)
+            step, outs = eng.bind(Z, X0, ("f", "grad", "g", "jac_dense"))
+            t_e = self.timed_events(step, 30)
+            call_h, out_h = eng.bind_hess(Z, X0, lam, sig)
+            t_h = self.timed_events(call_h, 20)
+            torch.cuda.synchronize(self.dev)
+            dims = [nx + nu] + hidden + [nx]
+            F = 2 * sum(i * o for i, o in zip(dims[:-1], dims[1:]))
+            row_flops = B * H * (1 + nx) * F
+            hess_flops = B * H * (2 + nx + nu) * F
+            e_j = e_h = s_h = 0.0
+            for i in range(4):
+                f, grad, g, J = prob.eval_batch(Zh[i:i + 1], X0h[i:i + 1])
+                e_j = max(e_j, float(np.abs(outs["jac_dense"][i].cpu().numpy() - J[0]).max()), float(np.abs(outs["g"][i].cpu().numpy() - g[0]).max()))
+                ref = prob.hessian_values(Zh[i], X0h[i], lamh[i], sigh[i])
+                e_h = max(e_h, float(np.abs(out_h["hvals"][i].cpu().numpy() - ref).max()))
+                s_h = max(s_h, float(np.abs(ref).max()))
+            out[name] = {"workload": f"B={B}, H={H}, {nx}/{nu}, MLP {name} tanh, Discret, f64", "kernel_variant": eng.kernel_variant,
+                         "evaluation": {"us": t_e * 1e6, "kernel": eng.last_row_kernel, "gflop": row_flops / 1e9,
+                                        "frac_of_matrix_peak": row_flops / t_e / 1e12 / PEAK_F64_TFLOPS, "max_abs_err_vs_cpu": e_j},
+                         "hessian_callback": {"us": t_h * 1e6, "kernel": eng.last_hess_kernel, "gflop": hess_flops / 1e9,
+                                              "frac_of_matrix_peak": hess_flops / t_h / 1e12 / PEAK_F64_TFLOPS,
+                                              "flops_note": "(2 + nin) GEMM sweeps per row; the per-layer contraction is vector work and not counted",
+                                              "max_abs_err_vs_cpu": e_h, "max_abs_ref": s_h}}
+            del eng
+        return out
 
     def two_stream_leg(self, res):
         torch = self.torch
