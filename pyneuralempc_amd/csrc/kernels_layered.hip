@@ -36,7 +36,13 @@ namespace nempc {
 
 namespace {
 
-constexpr int LG_BM = 64, LG_BN = 64, LG_BK = 16, LG_LD = 80;     // LD: padded tile row (spreads the four k-rows of a fragment over banks)
+#ifndef NEMPC_LG_PAD
+#define NEMPC_LG_PAD 16      // elements of padding per LDS tile row (A/B: tools/build_variant.py -DNEMPC_LG_PAD=0)
+#endif
+#ifndef NEMPC_LG_WPE
+#define NEMPC_LG_WPE 4       // waves per SIMD the GEMM kernel's register allocation must allow
+#endif
+constexpr int LG_BM = 64, LG_BN = 64, LG_BK = 16;
 
 enum { LG_FORWARD = 0, LG_REVERSE = 1 };
 
@@ -88,8 +94,8 @@ template <int FT>
 struct LgShape {
     static constexpr int BN = 64 * FT;
     static constexpr int BK = FT == 4 ? 8 : 16;
-    static constexpr int LDW = BN + 16;       // (padding: the four k-rows of a fragment read land on different banks;
-    static constexpr int LDA = LG_BM + 16;    //  +8 with four workgroups per CU measured 6 % slower)
+    static constexpr int LDW = BN + NEMPC_LG_PAD;       // (padding: the four k-rows of a fragment read land on different banks;
+    static constexpr int LDA = LG_BM + NEMPC_LG_PAD;    //  +8 with four workgroups per CU measured 6 % slower)
     static constexpr int TILE = BK * (LDW + LDA);      // elements per buffer
 };
 
@@ -116,7 +122,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rows_rsrc(const T* base, in
 }
 
 template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE>
-__global__ __launch_bounds__(256, 4) void layered_gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArgs a) {
     static_assert(!(SEED || CONTRACT) || FT == 1, "the fused forms exist for the 64-feature block only");
     using Ops = MfmaOps<T>;
     using V4 = typename Ops::V4;
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(256, 4) void layered_gemm_kernel(GemmArgs a) {
         // operand (kernels_mfma_impl.h), and sum_n Wc[n][d] E[n][m] is four more matrix instructions per column tile with
         // Wc's fragment as A operand.  The four waves' sums (16 features each) meet in LDS in wave order; feature blocks
         // meet in layered_jreduce_kernel / layered_outfinish_kernel in block order: the summation order is fixed.
-        constexpr int LDP = sizeof(T) == 8 ? 80 : 68;       // (f64: q's rows 128 B apart mod 256; f32: 64 B)
+        constexpr int LDP = NEMPC_LG_PAD == 0 ? 64 : (sizeof(T) == 8 ? 80 : 68);       // (f64: q's rows 128 B apart mod 256; f32: 64 B)
         static_assert((size_t)4 * 16 * LDP <= (size_t)2 * S::TILE, "partial tiles fit the operand buffers");
         const T* __restrict__ W0 = static_cast<const T*>(a.w0t);
         T* __restrict__ Jp = static_cast<T*>(a.Jp) + (size_t)nb * a.jp_stride;
