@@ -69,7 +69,9 @@ extern "C" {
  * Derivatives are evaluated from the layer's output a = s(z): s' = 1 (linear), 1 - a^2 (tanh), [a > 0] (relu: the
  * gradient at 0 is 0, as TensorFlow's), a(1-a) (sigmoid), 1 - e^-a (softplus), 1 | a + alpha (elu), 1 | alpha (leaky_relu),
  * lambda | a + lambda alpha (selu, Keras' fixed constants) -- the MONOTONE activations, whose derivatives follow from the
- * output alone.  swish / gelu are not monotone (their derivatives need the pre-activation) and are refused.
+ * output alone.  swish (= silu, z sigmoid(z)) and gelu (z Phi(z), Keras' approximate=False) are not monotone: their
+ * derivatives are written from the pre-activation, which only the layer-at-a-time matrix-core path has in hand
+ * (NEMPC_KERNEL_LAYERED / AUTO; hidden layers only) -- a configuration that would put them on another kernel is refused.
  * elu and leaky_relu read their alpha from nempc_config.act_param (elu: > 0, leaky_relu: >= 0). */
 #define NEMPC_ACT_LINEAR 0
 #define NEMPC_ACT_TANH 1
@@ -79,7 +81,9 @@ extern "C" {
 #define NEMPC_ACT_ELU 5
 #define NEMPC_ACT_LEAKY_RELU 6
 #define NEMPC_ACT_SELU 7
-#define NEMPC_ACT_COUNT 8
+#define NEMPC_ACT_SWISH 8
+#define NEMPC_ACT_GELU 9
+#define NEMPC_ACT_COUNT 10
 
 /* row-kernel implementation */
 #define NEMPC_KERNEL_AUTO 0
@@ -93,7 +97,7 @@ extern "C" {
                                   activation per layer (output layer included), hidden widths <= 1024, up to 8 layers,
                                   w*(nx+nu) <= 32, nx <= 16 -- what any feed-forward Keras model the reference wraps
                                   (model/tensorflow.py:8-29) that NEMPC_KERNEL_MFMA does not take runs on under AUTO.
-                                  Rows only: the Lagrangian Hessian of such a model stays on the generic kernel */
+                                  Rows and Lagrangian blocks (Discret / Unity / RK4), hence the batched solver too */
 
 typedef struct nempc_handle_s* nempc_handle;
 

@@ -33,7 +33,7 @@ typedef struct {
     const double* b[MAXL];
     const double *Q, *R, *xref, *uref, *cx, *cu; /* (nx,nx) (nu,nu) (H,nx) (H,nu) (H,nx) (H,nu) */
     int box;
-    int act[MAXL]; /* per layer: 0 linear, 1 tanh, 2 relu, 3 sigmoid, 4 softplus, 5 elu, 6 leaky_relu, 7 selu (nempc_oracle.py ACT_IDS) */
+    int act[MAXL]; /* per layer: 0 linear, 1 tanh, 2 relu, 3 sigmoid, 4 softplus, 5 elu, 6 leaky_relu, 7 selu, 8 swish, 9 gelu (nempc_oracle.py ACT_IDS) */
     double actp[MAXL]; /* alpha of elu / leaky_relu */
 } oracle_problem;
 
@@ -50,8 +50,19 @@ static double act_f(int code, double z, double par) {
         case 5: return z > 0.0 ? z : par * expm1(z);
         case 6: return z > 0.0 ? z : par * z;
         case 7: return SELU_LAMBDA * (z > 0.0 ? z : SELU_ALPHA * expm1(z));
+        case 8: return z / (1.0 + exp(-z));
+        case 9: return 0.5 * z * (1.0 + erf(z * 0.70710678118654752440));
         default: return z;
     }
+}
+/* swish and gelu are not monotone: their derivative is written from the pre-activation z */
+static int act_zbased(int code) { return code == 8 || code == 9; }
+static double act_d1z(int code, double z) {
+    if (code == 8) {
+        const double sg = 1.0 / (1.0 + exp(-z));
+        return sg * (1.0 + z * (1.0 - sg));
+    }
+    return 0.5 * (1.0 + erf(z * 0.70710678118654752440)) + z * 0.39894228040143267794 * exp(-0.5 * z * z);
 }
 static double act_d1(int code, double a, double par) {
     switch (code) {
@@ -67,14 +78,15 @@ static double act_d1(int code, double a, double par) {
 }
 
 /* f (nx) and J (nx, nin) of the network at xi (nin); scratch holds activations + cotangents */
-static void net_eval(const oracle_problem* p, const double* xi, double* f, double* J, double* act, double* cot) {
+static void net_eval(const oracle_problem* p, const double* xi, double* f, double* J, double* act, double* cot, double* dact) {
     const int nl = p->nl, nin = p->nx + p->nu;
     int maxw = nin;
     for (int l = 0; l < nl; ++l) if (p->dout[l] > maxw) maxw = p->dout[l];
-    /* forward: act[l] = output of layer l (post-activation) */
+    /* forward: act[l] = output of layer l (post-activation), dact[l] = s'(z_l) */
     const double* in = xi;
     for (int l = 0; l < nl; ++l) {
         double* out = (l == nl - 1) ? f : act + (size_t)l * maxw;
+        double* dv = dact + (size_t)l * maxw;
         const int wi = p->din[l], wo = p->dout[l];
         for (int j = 0; j < wo; ++j) out[j] = p->b[l][j];
         for (int i = 0; i < wi; ++i) {
@@ -82,23 +94,26 @@ static void net_eval(const oracle_problem* p, const double* xi, double* f, doubl
             const double* w = p->W[l] + (size_t)i * wo;
             for (int j = 0; j < wo; ++j) out[j] += a * w[j];
         }
-        if (p->act[l] != 0) for (int j = 0; j < wo; ++j) out[j] = act_f(p->act[l], out[j], p->actp[l]);
+        for (int j = 0; j < wo; ++j) {
+            const double z = out[j];
+            if (p->act[l] != 0) out[j] = act_f(p->act[l], z, p->actp[l]);
+            dv[j] = act_zbased(p->act[l]) ? act_d1z(p->act[l], z) : act_d1(p->act[l], out[j], p->actp[l]);
+        }
         in = out;
     }
     /* reverse sweep per output */
     for (int k = 0; k < p->nx; ++k) {
         double* c = cot;
         double* cn = cot + maxw;
-        const double dout_k = p->act[nl - 1] != 0 ? act_d1(p->act[nl - 1], f[k], p->actp[nl - 1]) : 1.0;   /* output-layer activation */
+        const double dout_k = dact[(size_t)(nl - 1) * maxw + k];   /* output-layer activation */
         if (nl == 1) {
             for (int d = 0; d < nin; ++d) J[k * nin + d] = p->W[0][(size_t)d * p->dout[0] + k] * dout_k;
             continue;
         }
         {
             const int w = p->din[nl - 1];
-            const double* a = act + (size_t)(nl - 2) * maxw;
-            for (int j = 0; j < w; ++j)
-                c[j] = p->W[nl - 1][(size_t)j * p->nx + k] * dout_k * act_d1(p->act[nl - 2], a[j], p->actp[nl - 2]);
+            const double* da = dact + (size_t)(nl - 2) * maxw;
+            for (int j = 0; j < w; ++j) c[j] = p->W[nl - 1][(size_t)j * p->nx + k] * dout_k * da[j];
         }
         for (int l = nl - 2; l >= 0; --l) {
             const int wi = p->din[l], wo = p->dout[l];
@@ -107,7 +122,7 @@ static void net_eval(const oracle_problem* p, const double* xi, double* f, doubl
                 const double* w = p->W[l] + (size_t)i * wo;
                 double s = 0.0;
                 for (int j = 0; j < wo; ++j) s += w[j] * c[j];
-                if (l > 0) s *= act_d1(p->act[l - 1], act[(size_t)(l - 1) * maxw + i], p->actp[l - 1]);
+                if (l > 0) s *= dact[(size_t)(l - 1) * maxw + i];
                 dst[i] = s;
             }
             if (l > 0) { double* t = c; c = cn; cn = t; }
@@ -131,9 +146,10 @@ static void step_row(const oracle_problem* p, const double* xprev, const double*
     double* dkn = accdk + nx * nin;      /* nx*nin */
     double* act = dkn + nx * nin;        /* nl*maxw */
     double* cot = act + (size_t)p->nl * maxw; /* 2*maxw */
+    double* dact = cot + 2 * (size_t)maxw;    /* nl*maxw */
     for (int i = 0; i < nx; ++i) xi[i] = xprev[i];
     for (int j = 0; j < nu; ++j) xi[nx + j] = u[j];
-    net_eval(p, xi, f, J, act, cot);
+    net_eval(p, xi, f, J, act, cot, dact);
     if (p->kind != 2) {
         for (int i = 0; i < nx; ++i) {
             phi[i] = (p->kind == 0 ? xprev[i] : 0.0) + f[i];
@@ -148,7 +164,7 @@ static void step_row(const oracle_problem* p, const double* xprev, const double*
     for (int s = 0; s < 3; ++s) {
         const double c = (s == 2 ? 1.0 : 0.5) * p->DT, wgt = (s == 2 ? 1.0 : 2.0);
         for (int i = 0; i < nx; ++i) xi[i] = xprev[i] + c * k[i];
-        net_eval(p, xi, f, J, act, cot);
+        net_eval(p, xi, f, J, act, cot, dact);
         for (int i = 0; i < nx; ++i)
             for (int d = 0; d < nin; ++d) {
                 double v = 0.0;
@@ -168,7 +184,7 @@ static size_t ws_doubles(const oracle_problem* p) {
     const int nx = p->nx, nin = p->nx + p->nu;
     int maxw = nin;
     for (int l = 0; l < p->nl; ++l) if (p->dout[l] > maxw) maxw = p->dout[l];
-    return (size_t)nin + 3 * nx + 4 * (size_t)nx * nin + (size_t)p->nl * maxw + 2 * (size_t)maxw;
+    return (size_t)nin + 3 * nx + 4 * (size_t)nx * nin + 2 * (size_t)p->nl * maxw + 2 * (size_t)maxw;
 }
 
 /* One batched evaluation.  Any output pointer may be NULL.  jac is dense (B,m,n). Returns threads used. */

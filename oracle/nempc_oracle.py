@@ -54,7 +54,8 @@ INTEGRATOR_NAMES = {DISCRET: "discret", UNITY: "unity", RK4: "rk4"}
 # would need the pre-activation and are not part of the family.  A parameterised activation is written "name:value"
 # ("elu:0.5", "leaky_relu:0.1"); the bare name takes the default (elu 1, leaky_relu 0.2 = keras.activations.leaky_relu).
 # --------------------------------------------------------------------------------------
-ACTIVATIONS = ("linear", "tanh", "relu", "sigmoid", "softplus", "elu", "leaky_relu", "selu")
+ACTIVATIONS = ("linear", "tanh", "relu", "sigmoid", "softplus", "elu", "leaky_relu", "selu", "swish", "gelu")
+ZBASED = ("swish", "gelu")       # not monotone: s', s'' are written from the pre-activation z (act_s1 / act_s2 below)
 ACT_IDS = {name: i for i, name in enumerate(ACTIVATIONS)}     # the codes of include/nempc.h (NEMPC_ACT_*)
 ACT_DEFAULT_PARAM = {"elu": 1.0, "leaky_relu": 0.2}
 SELU_LAMBDA, SELU_ALPHA = 1.0507009873554804934193349852946, 1.6732632423543772848170429916717
@@ -94,7 +95,39 @@ def act_f(name, z):
         return np.where(z > 0.0, z, par * z)
     if name == "selu":
         return SELU_LAMBDA * np.where(z > 0.0, z, SELU_ALPHA * np.expm1(np.minimum(z, 0.0)))
+    if name == "swish":                                # Keras swish / silu: z sigmoid(z)
+        with np.errstate(over="ignore"):
+            return z / (1.0 + np.exp(-z))
+    if name == "gelu":                                 # Keras gelu, approximate=False: z Phi(z)
+        from scipy.special import erf
+        return 0.5 * z * (1.0 + erf(z / np.sqrt(2.0)))
     raise ValueError(f"unknown activation {name!r}")
+
+
+def act_s1(name, z, a):
+    """s'(z) of a layer with pre-activation z and output a: from the output for the monotone activations (act_d1: what
+    the register-resident kernels do), from z for swish / gelu"""
+    nm = act_split(name)[0]
+    if nm == "swish":
+        with np.errstate(over="ignore"):
+            sg = 1.0 / (1.0 + np.exp(-z))
+        return sg * (1.0 + z * (1.0 - sg))
+    if nm == "gelu":
+        from scipy.special import erf
+        return 0.5 * (1.0 + erf(z / np.sqrt(2.0))) + z * np.exp(-0.5 * z * z) / np.sqrt(2.0 * np.pi)
+    return act_d1(name, a)
+
+
+def act_s2(name, z, a):
+    """s''(z), same convention"""
+    nm = act_split(name)[0]
+    if nm == "swish":
+        with np.errstate(over="ignore"):
+            sg = 1.0 / (1.0 + np.exp(-z))
+        return sg * (1.0 - sg) * (2.0 + z * (1.0 - 2.0 * sg))
+    if nm == "gelu":
+        return np.exp(-0.5 * z * z) / np.sqrt(2.0 * np.pi) * (2.0 - z * z)
+    return act_r2(name, a) * act_d1(name, a)
 
 
 def act_d1(name, a):
@@ -169,12 +202,14 @@ class MLP:
             b.append(rng.normal(0.0, 0.1, size=(o,)))
         return MLP(W, b, activations)
 
-    def _acts(self, xi):
-        """Outputs of every layer, acts[0] = the input, acts[l+1] = output of layer l (post-activation)."""
-        acts = [np.asarray(xi, dtype=np.float64)]
+    def _acts(self, xi, with_z=False):
+        """Outputs of every layer, acts[0] = the input, acts[l+1] = output of layer l (post-activation); with_z: also the
+        pre-activations zs[l]"""
+        acts, zs = [np.asarray(xi, dtype=np.float64)], []
         for w, b, name in zip(self.W, self.b, self.act):
-            acts.append(act_f(name, acts[-1] @ w + b))
-        return acts
+            zs.append(acts[-1] @ w + b)
+            acts.append(act_f(name, zs[-1]))
+        return (acts, zs) if with_z else acts
 
     def forward(self, xi):
         """(R, n_in) -> (R, n_out)"""
@@ -187,7 +222,7 @@ class MLP:
         linear layer), the same value tf.GradientTape.jacobian returns per row (model/tensorflow.py:58-62) restricted
         to the t==t' blocks.
         """
-        acts = self._acts(xi)
+        acts, zs = self._acts(xi, with_z=True)
         f = acts[-1]
         R = f.shape[0]
         L = len(self.W)
@@ -195,10 +230,10 @@ class MLP:
         if self.act[-1] == "linear":
             cot = np.broadcast_to(self.W[-1].T[None, :, :], (R, self.n_out, self.W[-1].shape[0])).copy()
         else:
-            cot = act_d1(self.act[-1], f)[:, :, None] * self.W[-1].T[None, :, :]
+            cot = act_s1(self.act[-1], zs[-1], f)[:, :, None] * self.W[-1].T[None, :, :]
         for l in range(L - 2, -1, -1):
             if self.act[l] != "linear":
-                cot = cot * act_d1(self.act[l], acts[l + 1])[:, None, :]
+                cot = cot * act_s1(self.act[l], zs[l], acts[l + 1])[:, None, :]
             cot = cot @ self.W[l].T
         return f, cot
 
@@ -222,8 +257,8 @@ class MLP:
             z = a @ w + b
             if name != "linear":
                 a = act_f(name, z)
-                s1 = act_d1(name, a)
-                s2 = act_r2(name, a) * s1
+                s1 = act_s1(name, z, a)
+                s2 = act_s2(name, z, a)
                 D = s1[:, :, None] * P
                 S = s2[:, :, None, None] * P[:, :, :, None] * P[:, :, None, :] + s1[:, :, None, None] * WS
             else:

@@ -17,7 +17,9 @@ KERNEL_NAMES = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA, "
                 "layered": KERNEL_LAYERED}
 INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
 # NEMPC_ACT_*: the activation of a dense layer (names as Keras spells them)
-ACTIVATION_IDS = {"linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3, "softplus": 4, "elu": 5, "leaky_relu": 6, "selu": 7}
+ACTIVATION_IDS = {"linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3, "softplus": 4, "elu": 5, "leaky_relu": 6, "selu": 7,
+                  "swish": 8, "gelu": 9}
+ACTIVATION_ALIASES = {"silu": "swish"}       # (Keras: swish and silu are the same function)
 # activations with a parameter (alpha), written "name:value" ("elu:0.5", "leaky_relu:0.1"); the bare name takes the default
 # (elu: Keras' 1.0; leaky_relu: keras.activations.leaky_relu's 0.2 -- the LeakyReLU LAYER carries its own negative_slope)
 ACTIVATION_DEFAULT_PARAM = {"elu": 1.0, "leaky_relu": 0.2}
@@ -26,10 +28,10 @@ ACTIVATION_DEFAULT_PARAM = {"elu": 1.0, "leaky_relu": 0.2}
 def split_activation(spec):
     """"name" | "name:value" -> (name, parameter), validated like nempc_create does"""
     name, _, val = str(spec).partition(":")
+    name = ACTIVATION_ALIASES.get(name, name)
     if name not in ACTIVATION_IDS:
         raise NotImplementedError(f"activation '{spec}' is not supported on the device path (supported: "
-                                  f"{', '.join(ACTIVATION_IDS)}; swish / gelu are not monotone: their derivatives need the "
-                                  "pre-activation, which the kernels do not keep)")
+                                  f"{', '.join(ACTIVATION_IDS)})")
     if val and name not in ACTIVATION_DEFAULT_PARAM:
         raise ValueError(f"activation '{name}' takes no parameter ('{spec}')")
     par = float(val) if val else ACTIVATION_DEFAULT_PARAM.get(name, 0.0)

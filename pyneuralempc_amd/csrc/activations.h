@@ -170,4 +170,26 @@ __device__ __forceinline__ T act_r2(int code, T a, T par) {
     }
 }
 
+// swish / gelu: value and derivatives from the PRE-activation z (the layered path's GEMM epilogue has z = acc + bias in
+// registers).  swish: s = z g, s' = g (1 + z (1 - g)), s'' = g (1 - g) (2 + z (1 - 2 g)) with g = sigmoid(z);
+// gelu: s = z Phi, s' = Phi + z phi, s'' = phi (2 - z^2) with Phi / phi the standard normal cdf / pdf.
+__device__ __forceinline__ bool act_zbased(int code) { return code == NEMPC_ACT_SWISH || code == NEMPC_ACT_GELU; }
+__device__ __forceinline__ double nempc_erf(double x) { return erf(x); }
+__device__ __forceinline__ float nempc_erf(float x) { return erff(x); }
+template <typename T>
+__device__ __forceinline__ void act_from_z(int code, T z, T& a, T& d1, T& d2) {
+    if (code == NEMPC_ACT_SWISH) {
+        const T g = T(1) / (T(1) + nempc_exp(-z));
+        a = z * g;
+        d1 = g * (T(1) + z * (T(1) - g));
+        d2 = g * (T(1) - g) * (T(2) + z * (T(1) - T(2) * g));
+    } else {
+        const T Phi = T(0.5) * (T(1) + nempc_erf(z * T(0.70710678118654752440)));
+        const T phi = T(0.39894228040143267794) * nempc_exp(T(-0.5) * z * z);
+        a = z * Phi;
+        d1 = Phi + z * phi;
+        d2 = phi * (T(2) - z * z);
+    }
+}
+
 }  // namespace nempc

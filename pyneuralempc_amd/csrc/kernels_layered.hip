@@ -52,6 +52,19 @@ __device__ __forceinline__ T lg_act_f(int code, T x, T par) {
     return act_f<T>(code, x, par);
 }
 
+// a layer's output, s'(z) and (want_e) s''(z) from its pre-activation: from the output for the monotone activations (the
+// bits of the register-resident kernels), from z itself for swish / gelu
+template <typename T>
+__device__ __forceinline__ void lg_act_all(int code, T z, T par, bool want_e, T& a, T& d1, T& e) {
+    if (act_zbased(code)) {
+        act_from_z<T>(code, z, a, d1, e);
+    } else {
+        a = lg_act_f<T>(code, z, par);
+        d1 = act_d1<T>(code, a, par);
+        e = want_e ? act_r2<T>(code, a, par) * d1 : T(0);
+    }
+}
+
 struct GemmArgs {
     const void* A;      // A^T: (K, M) element (k, m) at A[k * lda + m]
     const void* Bw;     // (K, N) row-major, element (k, n) at Bw[k * ldb + n]
@@ -326,8 +339,9 @@ __global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArg
                 } else {
                     T x = T(0);
                     if (n < N && m < M) {
-                        x = lg_act_f<T>(a.act, acc[0][rm][r] + bias[n], (T)a.actp);
-                        D[(size_t)n * a.ldd + m] = act_d1<T>(a.act, x, (T)a.actp);
+                        T d1, e;
+                        lg_act_all<T>(a.act, acc[0][rm][r] + bias[n], (T)a.actp, false, x, d1, e);
+                        D[(size_t)n * a.ldd + m] = d1;
                     }
                     gd[rm][r] = x;
                 }
@@ -376,11 +390,11 @@ __global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArg
                 if (m >= M) continue;
                 const T v = acc[fn][rm][r];
                 if (a.mode == LG_FORWARD) {
-                    const T x = lg_act_f<T>(a.act, v + bias[n], (T)a.actp);
-                    const T d1 = act_d1<T>(a.act, x, (T)a.actp);
+                    T x, d1, e;
+                    lg_act_all<T>(a.act, v + bias[n], (T)a.actp, a.E != nullptr, x, d1, e);
                     C[(size_t)n * a.ldc + m] = x;
                     D[(size_t)n * a.ldd + m] = d1;
-                    if (a.E) static_cast<T*>(a.E)[(size_t)n * a.ldd + m] = act_r2<T>(a.act, x, (T)a.actp) * d1;
+                    if (a.E) static_cast<T*>(a.E)[(size_t)n * a.ldd + m] = e;
                 } else {
                     if (C) C[(size_t)n * a.ldc + m] = v * D[(size_t)n * a.ldd + (m + mD0)];
                     if (a.Craw) static_cast<T*>(a.Craw)[(size_t)n * a.ldc + m] = v;

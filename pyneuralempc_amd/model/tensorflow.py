@@ -3,9 +3,10 @@
 The reference wraps a live Keras model -- any feed-forward one (model/tensorflow.py:8-29) -- and differentiates it with
 tf.GradientTape on the CPU.  Here the Keras object is only *read*: its Dense kernels / biases / activation names are
 copied once and the network is evaluated by the HIP kernels.  Dense stacks with any of the activations linear, tanh,
-relu, sigmoid, softplus, elu(alpha), leaky_relu(alpha), selu (per layer, the output layer included; stand-alone Activation /
-ReLU / LeakyReLU / ELU layers fold into the Dense in front of them) are taken; anything else -- other layer types, the
-non-monotone activations swish / gelu -- is rejected loudly."""
+relu, sigmoid, softplus, elu(alpha), leaky_relu(alpha), selu (per layer, the output layer included), swish / silu and gelu
+(hidden layers; these two run on the layer-at-a-time matrix-core path only) are taken, stand-alone Activation / ReLU /
+LeakyReLU / ELU layers fold into the Dense in front of them; anything else -- other layer types, other activations -- is
+rejected loudly."""
 import numpy as np
 
 from .mlp import MLPModel

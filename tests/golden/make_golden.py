@@ -294,6 +294,9 @@ CASES = {
     "act_param_box": (2, 1, [32, 24, 16], 9, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True, 0, 0,
                       ["leaky_relu:0.1", "selu", "elu:0.5", "leaky_relu"]),
     "act_selu_rk4": (2, 1, [48, 48], 7, orc.RK4, 0.2, None, 2, True, 0, 0, "selu"),
+    # the non-monotone activations (derivatives from the pre-activation; the layered path only)
+    "act_swish_gelu_box": (2, 1, [48, 40], 9, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True, 0, 0, ["swish", "gelu", "linear"]),
+    "act_gelu_rk4": (2, 1, [40, 40], 7, orc.RK4, 0.2, None, 2, True, 0, 0, "gelu"),
 }
 
 
@@ -311,7 +314,7 @@ def check_network_derivatives_by_ad(net, n_in, seed=11, rows=3, with_hess=True):
         F = torch.nn.functional
         return {"linear": lambda z: z, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid, "softplus": F.softplus,
                 "elu": lambda z: F.elu(z, alpha=par), "leaky_relu": lambda z: F.leaky_relu(z, negative_slope=par),
-                "selu": F.selu}[name]
+                "selu": F.selu, "swish": F.silu, "gelu": F.gelu}[name]
 
     def f(xi):
         a = xi

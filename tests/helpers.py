@@ -15,6 +15,7 @@ ACT_UNIFORM_NAMES = [f"act_{a}_{c}" for a in ("relu", "sigmoid", "softplus", "el
 ACT_MIXED_NAMES = ["act_mixed_box", "act_mixed_rk4", "act_linear_hidden", "act_param_box", "act_selu_rk4"]
 # networks only the layer-at-a-time GEMM path (and the generic kernel) take: width > 128, more than three hidden layers
 WIDE_DEEP_NAMES = ["wide256_c2", "deep4_c2", "deep5_mixed_rk4"]
+ZBASED_NAMES = ["act_swish_gelu_box", "act_gelu_rk4"]     # swish / gelu: the layered path only
 ROLLING_NAMES = ["roll2_discret", "roll3_unity_rev", "roll3_discret_rev", "roll4_wide", "roll2_tvp_p", "roll4_short"]
 
 

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import nempc_oracle as orc
-from helpers import ACT_MIXED_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, WIDE_DEEP_NAMES, case_activations, case_extra, load_case, oracle_problem
+from helpers import ACT_MIXED_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, WIDE_DEEP_NAMES, ZBASED_NAMES, case_activations, case_extra, load_case, oracle_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -40,7 +40,8 @@ ALL = ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")
 
 # every golden case x every kernel family; per-layer activation mixes run on the generic kernel only
 _FP64_CASES = ([(n, k) for n in CASE_NAMES + ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile", "layered")] +
-               [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")])
+               [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")] +
+               [(n, "layered") for n in ZBASED_NAMES])        # (swish / gelu: derivatives from the pre-activation)
 
 
 @pytest.mark.parametrize("name,kernel", _FP64_CASES)
@@ -69,7 +70,8 @@ def test_golden_fp64(name, kernel):
 
 @pytest.mark.parametrize("name,kernel", [(n, k) for n in ["c2_discret", "c3_rk4", "c3_discret", "c5_box", "odd_dims"] +
                                          ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile", "layered")] +
-                         [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")])
+                         [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")] +
+                         [(n, "layered") for n in ZBASED_NAMES])
 def test_golden_fp32(name, kernel):
     d, W, b = load_case(name)
     eng = _engine(d, W, b, torch.float32, kernel)
@@ -82,7 +84,8 @@ def test_golden_fp32(name, kernel):
 @pytest.mark.parametrize("name,kernel",
                          [(n, k) for n in [c for c in CASE_NAMES if c not in ("c3_rk4", "odd_dims", "c3_discret")] +
                           [c for c in ACT_UNIFORM_NAMES if c.endswith("_c2")] for k in ("valu", "mfma", "mfma_tile")] +
-                         [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")])
+                         [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")] +
+                         [(n, "layered") for n in ZBASED_NAMES])
 def test_golden_hessian_fp64(name, kernel):
     d, W, b = load_case(name)
     eng = _engine(d, W, b, torch.float64, kernel)
@@ -592,8 +595,14 @@ def test_mixed_activations_run_on_the_layered_path_and_are_refused_by_the_regist
     np.testing.assert_allclose(res["g"], g, **F64)
     with pytest.raises(_lib.NempcError, match="activations"):
         CallbackEngine(net.W, net.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", kernel="mfma", activations=net.act)
-    with pytest.raises(NotImplementedError, match="swish"):
-        CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["swish", "tanh", "linear"])
+    with pytest.raises(NotImplementedError, match="mish"):
+        CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["mish", "tanh", "linear"])
+    # swish / gelu: the layered path only (their derivatives need the pre-activation)
+    assert CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["swish", "gelu", "linear"]).kernel_variant == "layered"
+    with pytest.raises(_lib.NempcError, match="swish / gelu"):
+        CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", kernel="valu", activations=["swish", "gelu", "linear"])
+    with pytest.raises(_lib.NempcError, match="swish / gelu"):
+        CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["tanh", "tanh", "gelu"])
     with pytest.raises(ValueError, match="one name per dense layer"):
         CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["tanh", "linear"])
     # a non-linear OUTPUT layer with one hidden activation is a mix too
@@ -689,6 +698,9 @@ def test_every_matrix_core_instantiation_with_its_hessian_against_the_oracle():
     ([512], "sigmoid", 1, 1, "rk4"),
     ([300], "tanh", 2, 1, "discret"),                                        # one hidden layer: no tangent products at all
     ([160, 160], ["selu", "leaky_relu:0.1", "linear"], 4, 2, "discret"),
+    ([192, 130], ["swish", "gelu", "linear"], 2, 1, "discret"),             # derivatives from the pre-activation
+    ([96, 96, 96], ["gelu", "tanh", "swish", "softplus"], 3, 2, "rk4"),
+    ([150], ["swish", "linear"], 2, 2, "unity"),
 ])
 def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu, integ):
     """Networks outside the register-resident kernels (width > 128, more than three hidden layers, per-layer activation
@@ -730,16 +742,19 @@ def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu
             ref_rows = res["jac_tiles"][0].copy()
         else:
             assert np.array_equal(res["jac_tiles"][0], ref_rows)       # problem 0 does not depend on the batch around it
-        # generic kernel of the same handle shape: agreement to rounding
+        # generic kernel of the same handle shape: agreement to rounding (swish / gelu exist on the layered path only)
+        zbased = any(str(a).split(":")[0] in ("swish", "gelu") for a in net.act)
         if B == 19:
-            ev = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=dtype, device="cuda:0", max_batch=B,
-                                activations=net.act, kernel="valu")
-            if box:
-                ev.set_box_rows(*box)
-            rv = ev.eval_numpy(Zh, X0h, want=("g", "jac_tiles"))
-            assert ev.last_row_kernel == "rows_valu_kernel"
-            np.testing.assert_allclose(res["g"], rv["g"], **tol)
-            np.testing.assert_allclose(res["jac_tiles"], rv["jac_tiles"], **tol)
+            ev = None
+            if not zbased:
+                ev = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=dtype, device="cuda:0", max_batch=B,
+                                    activations=net.act, kernel="valu")
+                if box:
+                    ev.set_box_rows(*box)
+                rv = ev.eval_numpy(Zh, X0h, want=("g", "jac_tiles"))
+                assert ev.last_row_kernel == "rows_valu_kernel"
+                np.testing.assert_allclose(res["g"], rv["g"], **tol)
+                np.testing.assert_allclose(res["jac_tiles"], rv["jac_tiles"], **tol)
             # the Lagrangian Hessian of such a model: the GEMM sweeps with the layer-wise contraction (csrc/kernels_layered.hip,
             # "Contracted network Hessian"), for RK4 inside the stage pipeline of kernels_rk4hess.hip -- against the oracle
             # and against the generic kernel
@@ -750,10 +765,11 @@ def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu
             for i in range(3):
                 refh = prob.hessian_values(Zh[i], X0h[i], lam[i], 1.0)
                 np.testing.assert_allclose(hv[i], refh, rtol=0, atol=(1e-9 if f64 else 5e-3) * max(1.0, np.abs(refh).max()))
-            hg = ev.hess(ev.to_device(Zh), ev.to_device(X0h), ev.to_device(lam), ev.to_device(np.ones(B)))["hvals"]
-            assert ev.last_hess_kernel == "rowhess_valu_kernel"
-            hg = hg.to("cpu", torch.float64).numpy()
-            np.testing.assert_allclose(hv, hg, rtol=0, atol=(1e-10 if f64 else 5e-3) * max(1.0, np.abs(hg).max()))
+            if ev is not None:
+                hg = ev.hess(ev.to_device(Zh), ev.to_device(X0h), ev.to_device(lam), ev.to_device(np.ones(B)))["hvals"]
+                assert ev.last_hess_kernel == "rowhess_valu_kernel"
+                hg = hg.to("cpu", torch.float64).numpy()
+                np.testing.assert_allclose(hv, hg, rtol=0, atol=(1e-10 if f64 else 5e-3) * max(1.0, np.abs(hg).max()))
 
 
 def test_layered_path_chunks_large_batches():

@@ -177,8 +177,11 @@ def test_keras_adapter_validation_without_device():
                                            Layer(np.ones((8, 8)), np.zeros(8), "selu"),
                                            Layer(np.ones((8, 2)), np.zeros(2), "leaky_relu")], 3, 2))
     assert acts == ["leaky_relu:0.3", "elu:0.5", "selu", "leaky_relu"]
-    with pytest.raises(NotImplementedError, match="swish"):
-        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), "swish"), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
+    # swish (= silu) and gelu are taken (layered path); an activation outside the family is refused by name
+    assert extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), "silu"), Layer(np.ones((8, 8)), np.zeros(8), "gelu"),
+                                     Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))[2] == ["silu", "gelu", "linear"]
+    with pytest.raises(NotImplementedError, match="mish"):
+        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), "mish"), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
     with pytest.raises(NotImplementedError, match="already applies"):
         extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), tanh), Activation(relu),
                                   Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
@@ -198,9 +201,9 @@ def test_keras_adapter_validation_without_device():
     W, b, acts = extract_dense_stack(Fake([NoBias(), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
     assert np.array_equal(b[0], np.zeros(8)) and acts == ["tanh", "linear"]
 
-    def swish(x): return x
-    bad = Fake([Layer(np.ones((3, 8)), np.zeros(8), swish), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2)
-    with pytest.raises(NotImplementedError, match="activation 'swish'"):
+    def mish(x): return x
+    bad = Fake([Layer(np.ones((3, 8)), np.zeros(8), mish), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2)
+    with pytest.raises(NotImplementedError, match="activation 'mish'"):
         KerasTFModel(bad, x_dim=2, u_dim=1)
 
     class Elu2:

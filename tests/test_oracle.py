@@ -5,12 +5,12 @@ import pytest
 import torch
 
 from oracle import nempc_oracle as orc
-from helpers import ACT_MIXED_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, ROLLING_NAMES, WIDE_DEEP_NAMES, load_case, oracle_problem
+from helpers import ACT_MIXED_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, ROLLING_NAMES, WIDE_DEEP_NAMES, ZBASED_NAMES, load_case, oracle_problem
 
 TOL = dict(rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("name", CASE_NAMES + ACT_UNIFORM_NAMES + ACT_MIXED_NAMES + WIDE_DEEP_NAMES)
+@pytest.mark.parametrize("name", CASE_NAMES + ACT_UNIFORM_NAMES + ACT_MIXED_NAMES + WIDE_DEEP_NAMES + ZBASED_NAMES)
 def test_oracle_matches_reference_golden(name):
     d, W, b = load_case(name)
     prob = oracle_problem(d, W, b)
@@ -33,7 +33,7 @@ def test_oracle_matches_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", [n for n in CASE_NAMES if n not in ("c3_rk4", "c3_discret", "odd_dims")] +
-                         [n for n in ACT_UNIFORM_NAMES if n.endswith("_c2")] + ACT_MIXED_NAMES + WIDE_DEEP_NAMES)
+                         [n for n in ACT_UNIFORM_NAMES if n.endswith("_c2")] + ACT_MIXED_NAMES + WIDE_DEEP_NAMES + ZBASED_NAMES)
 def test_oracle_hessian_matches_reference_golden(name):
     d, W, b = load_case(name)
     prob = oracle_problem(d, W, b)
@@ -117,7 +117,8 @@ def _torch_act(spec):
     name, par = orc.act_split(spec)
     F = torch.nn.functional
     return {"linear": lambda z: z, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid, "softplus": F.softplus,
-            "elu": lambda z: F.elu(z, alpha=par), "leaky_relu": lambda z: F.leaky_relu(z, negative_slope=par), "selu": F.selu}[name]
+            "elu": lambda z: F.elu(z, alpha=par), "leaky_relu": lambda z: F.leaky_relu(z, negative_slope=par), "selu": F.selu,
+            "swish": F.silu, "gelu": F.gelu}[name]
 
 
 def _torch_net(W, b, act=None):
@@ -136,10 +137,12 @@ def _torch_net(W, b, act=None):
 @pytest.mark.parametrize("acts", ["relu", "sigmoid", "softplus", "elu", ["relu", "softplus", "sigmoid"],
                                   ["elu", "sigmoid", "tanh"], ["linear", "tanh", "softplus"], ["sigmoid", "elu", "elu"],
                                   "selu", "leaky_relu", "elu:0.5", ["leaky_relu:0.05", "selu", "elu:1.7"],
-                                  ["selu", "leaky_relu:0.3", "selu"]])
+                                  ["selu", "leaky_relu:0.3", "selu"], "swish", "gelu", ["swish", "gelu", "tanh"],
+                                  ["gelu", "relu", "swish"]])
 def test_activation_family_derivatives_vs_torch_ad(acts):
     """Every activation of the device family, uniform on the hidden layers and mixed per layer with a non-linear output
-    layer: the oracle's first and second derivatives -- written from the layer OUTPUT a = s(z), as the kernels do -- against
+    layer: the oracle's first and second derivatives -- written from the layer OUTPUT a = s(z), as the kernels do (from the
+    pre-activation for the non-monotone swish / gelu) -- against
     torch's own activations under torch.func autodiff (fp64).  This is the guard the fixtures of these activations rest
     on (make_golden.check_network_derivatives_by_ad runs the same comparison while they are made)."""
     nin, hidden, nout = 5, [24, 17], 3
@@ -163,13 +166,15 @@ def test_activation_functions_at_their_edges():
     for name in orc.ACTIVATIONS:
         a = orc.act_f(name, z)
         assert np.all(np.isfinite(a)), name
-        assert np.all(np.isfinite(orc.act_d1(name, a))) and np.all(np.isfinite(orc.act_r2(name, a))), name
+        assert np.all(np.isfinite(orc.act_s1(name, z, a))) and np.all(np.isfinite(orc.act_s2(name, z, a))), name
+        if name not in orc.ZBASED:
+            assert np.all(np.isfinite(orc.act_d1(name, a))) and np.all(np.isfinite(orc.act_r2(name, a))), name
         assert np.isnan(orc.act_f(name, np.array([np.nan]))[0]), name
     assert orc.act_d1("relu", orc.act_f("relu", np.array([0.0])))[0] == 0.0          # TensorFlow's convention at the kink
     assert orc.act_d1("elu", orc.act_f("elu", np.array([0.0])))[0] == 1.0
     assert orc.act_d1("elu:0.5", orc.act_f("elu:0.5", np.array([0.0])))[0] == 0.5
     assert orc.act_d1("leaky_relu:0.1", orc.act_f("leaky_relu:0.1", np.array([0.0])))[0] == 0.1    # tf.nn.leaky_relu's gradient at 0
-    for bad in ("elu:0", "elu:-1", "leaky_relu:-0.1", "tanh:2", "swish", "gelu"):
+    for bad in ("elu:0", "elu:-1", "leaky_relu:-0.1", "tanh:2", "mish", "gelu:1"):
         with pytest.raises(ValueError):
             orc.act_split(bad)
     np.testing.assert_allclose(orc.act_d1("softplus", orc.act_f("softplus", z)), 1.0 / (1.0 + np.exp(-np.clip(z, -700, 700))),
@@ -238,7 +243,7 @@ def test_jacobian_and_gradient_vs_finite_differences():
 
 @pytest.mark.parametrize("name", ["c2_discret", "c2_unity", "c3_rk4", "c5_box", "odd_dims", "h1", "act_relu_c2",
                                   "act_sigmoid_c3", "act_softplus_c2", "act_elu_c3", "act_mixed_box", "act_mixed_rk4",
-                                  "act_linear_hidden"])
+                                  "act_linear_hidden", "act_param_box", "act_selu_rk4", "act_swish_gelu_box", "act_gelu_rk4"])
 def test_c_oracle_matches_numpy_oracle(name):
     from oracle.c_oracle import COracle
     d, W, b = load_case(name)
