@@ -1029,11 +1029,11 @@ int hcontract(hipStream_t s, const T* P, long long ldp, const T* W0, int ldw0, c
     const int PBs = nin <= 4 ? 4 : 8;
     const int nb = (nin + PBs - 1) / PBs;
     const dim3 grid((unsigned)((R + 63) / 64), (unsigned)(nb * (nb + 1) / 2));
-    // waves per block: about four per SIMD over the launch, within 4 .. 16 (8 for the 8 x 8 accumulator form: LDS) and the
-    // feature count
+    // waves per block: as many as keep the whole launch resident at once (4096 waves at four per SIMD -- a second, partly
+    // filled round of blocks doubled the time), within 4 .. 16 (8 for the 8 x 8 accumulator form: LDS) and the feature count
     int nw = 4;
     const int nwmax = PBs == 4 ? 16 : 8;
-    while (nw < nwmax && (long long)grid.x * grid.y * nw < 4096 && nw * 2 <= K) nw *= 2;
+    while (nw * 2 <= nwmax && (long long)grid.x * grid.y * nw * 2 <= 4096 && nw * 2 <= K) nw *= 2;
     const size_t lds = (size_t)(nw / 2) * PBs * PBs * 64 * sizeof(T);
     const dim3 block((unsigned)(nw * 64));
     if (PBs == 4) {
