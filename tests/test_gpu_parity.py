@@ -772,6 +772,37 @@ def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu
                 np.testing.assert_allclose(hv, hg, rtol=0, atol=(1e-10 if f64 else 5e-3) * max(1.0, np.abs(hg).max()))
 
 
+@pytest.mark.parametrize("hidden,nx,nu,integ,H,B", [
+    ([1024, 1000], 16, 16, "discret", 3, 3),         # the widest layers, 32 network inputs, 16 cotangents
+    ([40] * 7, 2, 1, "rk4", 4, 5),                   # eight dense layers
+    ([72, 72], 3, 1, "unity", 1, 1),                 # one row
+    ([130], 5, 4, "rk4", 2, 70),                     # one hidden layer, more rows than one GEMM block
+])
+def test_layered_path_at_the_edges_of_its_shape_range(hidden, nx, nu, integ, H, B):
+    """The layered path's limits (widths <= 1024, <= 8 layers, <= 32 network inputs, nx <= 16) and its smallest launches:
+    rows and Lagrangian blocks against the oracle."""
+    from pyneuralempc_amd import CallbackEngine
+    DT = 0.1 if integ == "rk4" else 1.0
+    kind = {"discret": orc.DISCRET, "unity": orc.UNITY, "rk4": orc.RK4}[integ]
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=21)
+    prob = orc.Problem(net, H, nx, nu, kind, DT)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=torch.float64, device="cuda:0", max_batch=B,
+                         kernel="layered")
+    assert eng.kernel_variant == "layered"
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=4)
+    res = eng.eval_numpy(Zh, X0h, want=("g", "jac_dense"))
+    k = min(B, 3)
+    f, grad, g, J = prob.eval_batch(Zh[:k], X0h[:k])
+    np.testing.assert_allclose(res["g"][:k], g, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(res["jac_dense"][:k], J, rtol=1e-10, atol=1e-10)
+    lam = np.random.default_rng(2).normal(size=(B, eng.m))
+    hv = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lam), eng.to_device(np.ones(B)))["hvals"].cpu().numpy()
+    assert eng.last_hess_kernel.endswith("layered_gemm_kernel")
+    for i in range(min(B, 2)):
+        ref = prob.hessian_values(Zh[i], X0h[i], lam[i], 1.0)
+        np.testing.assert_allclose(hv[i], ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+
+
 def test_layered_path_chunks_large_batches():
     """More rows than one workspace chunk holds (NEMPC_LAYERED_CHUNK_ROWS shrinks the chunk for the test): the chunk loop,
     with a last chunk that is not a whole GEMM block, gives the rows of the one-chunk evaluation bit for bit."""
