@@ -83,7 +83,7 @@ def test_golden_fp32(name, kernel):
 
 @pytest.mark.parametrize("name,kernel",
                          [(n, k) for n in [c for c in CASE_NAMES if c not in ("c3_rk4", "odd_dims", "c3_discret")] +
-                          [c for c in ACT_UNIFORM_NAMES if c.endswith("_c2")] for k in ("valu", "mfma", "mfma_tile")] +
+                          [c for c in ACT_UNIFORM_NAMES if c.endswith("_c2")] for k in ("valu", "mfma", "mfma_tile", "layered")] +
                          [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")] +
                          [(n, "layered") for n in ZBASED_NAMES])
 def test_golden_hessian_fp64(name, kernel):
