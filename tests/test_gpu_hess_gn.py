@@ -21,7 +21,7 @@ def _engine(net, H, nx, nu, B, kind="discret", DT=1.0, kernel="auto", dtype=torc
     return eng
 
 
-@pytest.mark.parametrize("kernel", ["mfma", "mfma_tile", "valu"])
+@pytest.mark.parametrize("kernel", ["mfma", "mfma_tile", "valu", "layered"])
 @pytest.mark.parametrize("shape", [(2, 1, [64, 64], 50, "discret", 1.0, (-2.0, 2.0)),      # configs[4] dims
                                    (2, 1, [64, 64], 20, "rk4", 0.1, None),
                                    (3, 2, [24, 40], 7, "unity", 1.0, None)])
