@@ -103,12 +103,13 @@ enum { LG_CONTRACT_NONE = 0, LG_CONTRACT_REVERSE = 1, LG_CONTRACT_FORWARD = 2 };
 // matrix peak).  Wider blocks read the activations fewer times but run at two waves per SIMD with coarse launch tails; with
 // the XCD-aware block order below the narrow block gets its re-reads from L2 anyway.  Only FT = 1 is instantiated (the wider shapes do not fit the
 // two-chunk load lead below into 128 registers).
-template <int FT>
+template <int FT, int RM = 4>
 struct LgShape {
+    static constexpr int BM = 16 * RM;          // rows (columns of the transposed product) per workgroup: RM 16-row tiles per wave
     static constexpr int BN = 64 * FT;
     static constexpr int BK = FT == 4 ? 8 : 16;
     static constexpr int LDW = BN + NEMPC_LG_PAD;       // (padding: the four k-rows of a fragment read land on different banks;
-    static constexpr int LDA = LG_BM + NEMPC_LG_PAD;    //  +8 with four workgroups per CU measured 6 % slower)
+    static constexpr int LDA = BM + NEMPC_LG_PAD;    //  +8 with four workgroups per CU measured 6 % slower)
     static constexpr int TILE = BK * (LDW + LDA);      // elements per buffer
 };
 
@@ -134,12 +135,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rows_rsrc(const T* base, in
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
 }
 
-template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE>
-__global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArgs a) {
+template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE, int RM = 4>
+__global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : NEMPC_LG_WPE) void layered_gemm_kernel(GemmArgs a) {
+    static_assert(RM == 4 || !SEED, "the seed loader exists for the 64-row block only");
+    constexpr int BM = 16 * RM;
     static_assert(!(SEED || CONTRACT) || FT == 1, "the fused forms exist for the 64-feature block only");
     using Ops = MfmaOps<T>;
     using V4 = typename Ops::V4;
-    using S = LgShape<FT>;
+    using S = LgShape<FT, RM>;
     constexpr int BN = S::BN, BK = S::BK, LDW = S::LDW, LDA = S::LDA;
     extern __shared__ __attribute__((aligned(16))) unsigned char lg_lds_raw[];
     T* const lds = reinterpret_cast<T*>(lg_lds_raw);
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArg
     const int NB = a.nblk;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int nb = slot % NB, mb = (slot / NB) * 8 + xcd;
-    const long long m0 = (long long)mb * LG_BM;
+    const long long m0 = (long long)mb * BM;
     if (m0 >= a.M) return;
     const int n0 = nb * BN;
     const T* __restrict__ A = static_cast<const T*>(a.A);
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArg
     // loader: a wave-uniform base that steps by a chunk on the scalar unit plus per-thread 32-bit element offsets that never
     // change -- no vector arithmetic per load (a v_mfma_f64 holds the vector pipe for its 64 cycles).  Columns beyond N / M
     // are clamped onto the last one (their results are never stored); only the LAST chunk, where k may run past K, is masked.
-    constexpr int NW = BK * BN / 256, NA = BK * LG_BM / 256;       // elements per thread and chunk
+    constexpr int NW = BK * BN / 256, NA = BK * BM / 256;       // elements per thread and chunk
     // (unsigned BYTE offsets inside a chunk; largest: 15 rows of 16 x 65536 elements of 8 bytes, 126 MB)
     unsigned offW[NW], offA[NA];
 #pragma unroll
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArg
     }
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
-        const int e = tid + 256 * u, kk = e / LG_BM, x = e % LG_BM;
+        const int e = tid + 256 * u, kk = e / BM, x = e % BM;
         offA[u] = (unsigned)((long long)kk * a.lda + (m0 + x < M ? x : M - 1 - m0)) * (unsigned)sizeof(T);
     }
     const T* __restrict__ Wb = Bw + n0;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArg
     int seed_cot = 0;
     const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
     if constexpr (SEED) {
-        const int x = tid % LG_BM;
+        const int x = tid % BM;
         seed_cot = (int)(m0 / a.Rmod);
         // (no s_L': the tangent sweep of the Hessian, whose seed is W_0^T . D_0)
         seed_dl = a.seedDl ? static_cast<const T*>(a.seedDl)[(size_t)seed_cot * a.Rmod + mrow0 + (m0 + x < M ? x : M - 1 - m0)] : T(1);
@@ -229,37 +232,37 @@ __global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArg
         for (int u = 0; u < NA; ++u) {
             const int e = tid + 256 * u;
             // (the seed kernel's order of operations: (W_last s_L') D)
-            As(buf, e / LG_BM, e % LG_BM) = SEED ? (cr.sw[u] * seed_dl) * cr.ra[u] : cr.ra[u];
+            As(buf, e / BM, e % BM) = SEED ? (cr.sw[u] * seed_dl) * cr.ra[u] : cr.ra[u];
         }
     };
 
-    V4 acc[FT][4];
+    V4 acc[FT][RM];
 #pragma unroll
     for (int fn = 0; fn < FT; ++fn)
 #pragma unroll
-        for (int rm = 0; rm < 4; ++rm) acc[fn][rm] = V4{T(0), T(0), T(0), T(0)};
+        for (int rm = 0; rm < RM; ++rm) acc[fn][rm] = V4{T(0), T(0), T(0), T(0)};
 
     const int nchunks = (K + BK - 1) / BK;
     const int fb = w * 16 * FT;                 // this wave's features inside the block
     auto mma_chunk = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
-            T af[FT], bf[4];
+            T af[FT], bf[RM];
 #ifdef NEMPC_LG_EXP_NOLDS
 #pragma unroll
             for (int fn = 0; fn < FT; ++fn) af[fn] = T(1) + T(ks);
 #pragma unroll
-            for (int rm = 0; rm < 4; ++rm) bf[rm] = T(2) + T(rm);
+            for (int rm = 0; rm < RM; ++rm) bf[rm] = T(2) + T(rm);
 #else
 #pragma unroll
             for (int fn = 0; fn < FT; ++fn) af[fn] = Ws(buf, 4 * ks + q, fb + 16 * fn + c);
 #pragma unroll
-            for (int rm = 0; rm < 4; ++rm) bf[rm] = As(buf, 4 * ks + q, 16 * rm + c);
+            for (int rm = 0; rm < RM; ++rm) bf[rm] = As(buf, 4 * ks + q, 16 * rm + c);
 #endif
 #pragma unroll
             for (int fn = 0; fn < FT; ++fn)
 #pragma unroll
-                for (int rm = 0; rm < 4; ++rm) acc[fn][rm] = Ops::mma(af[fn], bf[rm], acc[fn][rm]);
+                for (int rm = 0; rm < RM; ++rm) acc[fn][rm] = Ops::mma(af[fn], bf[rm], acc[fn][rm]);
         }
     };
     auto chunk_barrier = [&]() {
@@ -323,16 +326,17 @@ __global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArg
         // operand (kernels_mfma_impl.h), and sum_n Wc[n][d] E[n][m] is four more matrix instructions per column tile with
         // Wc's fragment as A operand.  The four waves' sums (16 features each) meet in LDS in wave order; feature blocks
         // meet in layered_jreduce_kernel / layered_outfinish_kernel in block order: the summation order is fixed.
-        constexpr int LDP = NEMPC_LG_PAD == 0 ? 64 : (sizeof(T) == 8 ? 80 : 68);       // (f64: q's rows 128 B apart mod 256; f32: 64 B)
+        constexpr int LDP = RM == 4 ? (NEMPC_LG_PAD == 0 ? 64 : (sizeof(T) == 8 ? 80 : 68))       // (f64: q's rows 128 B apart mod 256; f32: 64 B)
+                                    : BM + 8;
         static_assert((size_t)4 * 16 * LDP <= (size_t)2 * S::TILE, "partial tiles fit the operand buffers");
         const T* __restrict__ W0 = static_cast<const T*>(a.w0t);
         T* __restrict__ Jp = static_cast<T*>(a.Jp) + (size_t)nb * a.jp_stride;
-        T gd[4][4];
+        T gd[RM][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + fb + Ops::row(q, r);
 #pragma unroll
-            for (int rm = 0; rm < 4; ++rm) {
+            for (int rm = 0; rm < RM; ++rm) {
                 const long long m = m0 + 16 * rm + c;
                 if constexpr (CONTRACT == LG_CONTRACT_REVERSE) {
                     gd[rm][r] = (n < N && m < M) ? acc[0][rm][r] * D[(size_t)n * a.ldd + (m + mD0)] : T(0);
@@ -349,25 +353,25 @@ __global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArg
         }
         const int ndt = (a.nin + 15) / 16;
         for (int dt = 0; dt < ndt; ++dt) {
-            V4 P[4];
+            V4 P[RM];
 #pragma unroll
-            for (int rm = 0; rm < 4; ++rm) P[rm] = V4{T(0), T(0), T(0), T(0)};
+            for (int rm = 0; rm < RM; ++rm) P[rm] = V4{T(0), T(0), T(0), T(0)};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + fb + Ops::row(q, r), d = 16 * dt + c;
                 const T wf = (n < N && d < a.nin) ? W0[(size_t)n * a.ldw0 + d] : T(0);
 #pragma unroll
-                for (int rm = 0; rm < 4; ++rm) P[rm] = Ops::mma(wf, gd[rm][r], P[rm]);
+                for (int rm = 0; rm < RM; ++rm) P[rm] = Ops::mma(wf, gd[rm][r], P[rm]);
             }
             if (dt > 0) __syncthreads();
 #pragma unroll
-            for (int rm = 0; rm < 4; ++rm)
+            for (int rm = 0; rm < RM; ++rm)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) lds[(w * 16 + Ops::row(q, r)) * LDP + 16 * rm + c] = P[rm][r];
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = tid + 256 * u, dd = e >> 6, col = e & 63;
+            for (int u = 0; u < RM; ++u) {
+                const int e = tid + 256 * u, dd = e / BM, col = e % BM;
                 const int d = 16 * dt + dd;
                 const long long m = m0 + col;
                 if (d < a.nin && m < M) {
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256, NEMPC_LG_WPE) void layered_gemm_kernel(GemmArg
             const int n = n0 + fb + 16 * fn + Ops::row(q, r);
             if (n >= N) continue;
 #pragma unroll
-            for (int rm = 0; rm < 4; ++rm) {
+            for (int rm = 0; rm < RM; ++rm) {
                 const long long m = m0 + 16 * rm + c;
                 if (m >= M) continue;
                 const T v = acc[fn][rm][r];
@@ -638,23 +642,42 @@ __global__ void layered_jreduce_kernel(const T* __restrict__ Jp, int nblk, long 
     }
 }
 
-template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE>
+template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE, int RM = 4>
 int gemm_ft(hipStream_t s, const GemmArgs& a) {
-    using S = LgShape<FT>;
+    using S = LgShape<FT, RM>;
     const size_t bytes = (size_t)2 * S::TILE * sizeof(T);
-    auto kern = layered_gemm_kernel<T, FT, SEED, CONTRACT>;
+    auto kern = layered_gemm_kernel<T, FT, SEED, CONTRACT, RM>;
     NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), bytes));
     GemmArgs b = a;
     b.nblk = (a.N + S::BN - 1) / S::BN;
-    const long long mblk = ((long long)a.M + LG_BM - 1) / LG_BM;
+    const long long mblk = ((long long)a.M + S::BM - 1) / S::BM;
     const dim3 grid((unsigned)(8 * b.nblk * ((mblk + 7) / 8)));      // (row blocks padded to the 8 XCDs; the surplus exits at once)
     hipLaunchKernelGGL(kern, grid, dim3(256), bytes, s, b);
     NEMPC_HIP(hipGetLastError());
     return NEMPC_OK;
 }
 
+// fp64 FORWARD products (activation + two or three stores per element in the epilogue) whose 64-row tiling gives the launch
+// less than about two rounds of workgroups run on 32-row blocks: twice the workgroups, five or six waves per SIMD instead of
+// four, so that one workgroup's epilogue runs under the others' matrix instructions.  Measured at 2 x 256, B*H = 20480
+// (tools/lg_rm_ab.sh): plain forward products 74 -> 53 us, the last hidden layer with the output contraction 82 -> 76 us.
+// Not the reverse products (a load and a store per element: 5 % slower that way) and not fp32 (six to eight waves per SIMD
+// already; the contraction form measured 9 % slower).  NEMPC_LG_RM = 2 | 4 forces one form (A/B, tests).
 template <typename T>
-int gemm(hipStream_t s, int mode, int act, const T* A, long long lda, const T* Bw, int ldb, T* C, long long ldc, T* D,
+bool lg_rows32(int num_cus, long long M, int N) {
+    static const int rm_env = [] { const char* e = getenv("NEMPC_LG_RM"); return e ? atoi(e) : 0; }();
+    if (rm_env == 2) return true;
+    if (rm_env == 4 || sizeof(T) != 8) return false;
+    const long long tiles64 = ((M + 63) / 64) * (long long)((N + 63) / 64);
+    return tiles64 <= (long long)2 * num_cus * 4;
+}
+template <typename T, int CONTRACT>
+int gemm_forward(int num_cus, hipStream_t s, const GemmArgs& a) {
+    return lg_rows32<T>(num_cus, a.M, a.N) ? gemm_ft<T, 1, false, CONTRACT, 2>(s, a) : gemm_ft<T, 1, false, CONTRACT, 4>(s, a);
+}
+
+template <typename T>
+int gemm(int num_cus, hipStream_t s, int mode, int act, const T* A, long long lda, const T* Bw, int ldb, T* C, long long ldc, T* D,
          long long ldd, const T* bias, long long M, int N, int K, long long Rmod, double actp = 0.0) {
     GemmArgs a{};
     a.actp = actp;
@@ -662,6 +685,7 @@ int gemm(hipStream_t s, int mode, int act, const T* A, long long lda, const T* B
     a.lda = lda; a.ldc = ldc; a.ldd = ldd; a.ldb = ldb;
     a.M = (int)M; a.N = N; a.K = K; a.mode = mode; a.act = act; a.Rmod = Rmod;
     // 64-feature blocks (FT = 1) measured fastest at every width (LgShape above); wider blocks are not instantiated
+    if (mode == LG_FORWARD) return gemm_forward<T, LG_CONTRACT_NONE>(num_cus, s, a);
     return gemm_ft<T, 1>(s, a);
 }
 
@@ -727,13 +751,13 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                     a.M = R; a.N = h.dout[l]; a.K = h.din[l];
                     a.w0t = h.d_W[nl - 1]; a.ldw0 = nx; a.nin = nx;
                     a.Jp = ws + o.g0; a.ldj = Rp; a.jp_stride = (long long)nx * Rp;
-                    if ((rc = gemm_ft<T, 1, false, LG_CONTRACT_FORWARD>(s, a))) return rc;
+                    if ((rc = gemm_forward<T, LG_CONTRACT_FORWARD>(h.num_cus, s, a))) return rc;
                     hipLaunchKernelGGL(layered_outfinish_kernel<T>, rg, rb, 0, s, ws + o.g0, (h.dout[l] + 63) / 64, a.jp_stride, nx, R, Rp,
                                        static_cast<const T*>(h.d_b[nl - 1]), h.act[nl - 1], (T)h.actp[nl - 1], ws + o.f, ws + o.dl);
                     NEMPC_HIP(hipGetLastError());
                     break;
                 }
-                if ((rc = gemm<T>(s, LG_FORWARD, h.act[l], in, Rp, static_cast<const T*>(h.d_W[l]), h.dout[l], out, Rp, ws + o.d[l], Rp,
+                if ((rc = gemm<T>(h.num_cus, s, LG_FORWARD, h.act[l], in, Rp, static_cast<const T*>(h.d_W[l]), h.dout[l], out, Rp, ws + o.d[l], Rp,
                                   static_cast<const T*>(h.d_b[l]), R, h.dout[l], h.din[l], 0, h.actp[l])))
                     return rc;
                 in = out;
@@ -790,7 +814,7 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                 // G_l = (W_{l+1} G_{l+1}) . D_l : K = dout[l+1], N = dout[l], operand W_{l+1}^T row-major (out, in) = d_Wt[l+1]
                 T* Gn = (G == ws + o.g0) ? ws + o.g1 : ws + o.g0;
                 // the nx blocks of Rp columns are covered as one run of columns; block k's columns beyond Rm are never read
-                if ((rc = gemm<T>(s, LG_REVERSE, 0, G, ldg, static_cast<const T*>(h.d_Wt[l + 1]), h.dout[l], Gn, ldg, ws + o.d[l], Rp,
+                if ((rc = gemm<T>(h.num_cus, s, LG_REVERSE, 0, G, ldg, static_cast<const T*>(h.d_Wt[l + 1]), h.dout[l], Gn, ldg, ws + o.d[l], Rp,
                                   nullptr, (long long)(nx - 1) * Rp + Rm, h.dout[l], h.dout[l + 1], Rp)))
                     return rc;
                 G = Gn;
@@ -1084,7 +1108,7 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
             a.A = in; a.lda = Rp; a.Bw = h.d_W[l]; a.ldb = h.dout[l]; a.bias = h.d_b[l];
             a.C = out; a.ldc = Rp; a.D = ws + o.d[l]; a.E = ws + o.e[l]; a.ldd = Rp;
             a.M = R; a.N = h.dout[l]; a.K = h.din[l];
-            if ((rc = gemm_ft<T, 1>(s, a))) return rc;
+            if ((rc = gemm_forward<T, LG_CONTRACT_NONE>(h.num_cus, s, a))) return rc;
             in = out;
         }
         if ((rc = skinny<T>(s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, (long long)R, ws + o.f, Rp,
