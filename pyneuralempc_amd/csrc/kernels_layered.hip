@@ -1130,7 +1130,9 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
             a.M = (int)Rp; a.N = h.dout[l]; a.K = h.dout[l + 1]; a.Rmod = Rp;
             a.D = ws + o.d[l]; a.E = ws + o.e[l]; a.ldd = Rp;
             a.C = l > 0 ? dn : nullptr; a.C2 = ws + o.cw[l]; a.ldc = Rp;
-            if ((rc = gemm_ft<T, 1>(s, a))) return rc;
+            // (two loads and two stores per element in the epilogue and only B*H columns: the small-launch rule of the
+            // forward products applies)
+            if ((rc = gemm_forward<T, LG_CONTRACT_NONE>(h.num_cus, s, a))) return rc;
             dq = dn;
         }
         // ---- layer 0: constant tangents W_0^T
