@@ -344,8 +344,9 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : NEMPC_LG_WPE) v
                     T x = T(0);
                     if (n < N && m < M) {
                         T d1, e;
-                        lg_act_all<T>(a.act, acc[0][rm][r] + bias[n], (T)a.actp, false, x, d1, e);
+                        lg_act_all<T>(a.act, acc[0][rm][r] + bias[n], (T)a.actp, a.E != nullptr, x, d1, e);
                         D[(size_t)n * a.ldd + m] = d1;
+                        if (a.E) static_cast<T*>(a.E)[(size_t)n * a.ldd + m] = e;
                     }
                     gd[rm][r] = x;
                 }
@@ -1103,16 +1104,29 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
         const T* in = ws + o.xi;
         for (int l = 0; l < nl - 1; ++l) {
             T* out = ws + ((l & 1) ? o.x1 : o.x0);
+            const bool contract = l == nl - 2 && layered_fuse();      // the output layer in the last hidden layer's epilogue
             GemmArgs a{};
             a.mode = LG_FORWARD; a.act = h.act[l]; a.actp = h.actp[l];
             a.A = in; a.lda = Rp; a.Bw = h.d_W[l]; a.ldb = h.dout[l]; a.bias = h.d_b[l];
-            a.C = out; a.ldc = Rp; a.D = ws + o.d[l]; a.E = ws + o.e[l]; a.ldd = Rp;
+            a.D = ws + o.d[l]; a.E = ws + o.e[l]; a.ldd = Rp;
             a.M = R; a.N = h.dout[l]; a.K = h.din[l];
+            if (contract) {
+                // (partial sums per feature block in the tangent buffer, free until the tangent sweep)
+                a.w0t = h.d_W[nl - 1]; a.ldw0 = nx; a.nin = nx;
+                a.Jp = ws + o.P; a.ldj = Rp; a.jp_stride = (long long)nx * Rp;
+                if ((rc = gemm_forward<T, LG_CONTRACT_FORWARD>(h.num_cus, s, a))) return rc;
+                hipLaunchKernelGGL(layered_outfinish_kernel<T>, rg, rb, 0, s, ws + o.P, (h.dout[l] + 63) / 64, a.jp_stride, nx, R, Rp,
+                                   static_cast<const T*>(h.d_b[nl - 1]), h.act[nl - 1], (T)h.actp[nl - 1], ws + o.f, ws + o.dl);
+                NEMPC_HIP(hipGetLastError());
+                in = nullptr;
+                break;
+            }
+            a.C = out; a.ldc = Rp;
             if ((rc = gemm_forward<T, LG_CONTRACT_NONE>(h.num_cus, s, a))) return rc;
             in = out;
         }
-        if ((rc = skinny<T>(s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, (long long)R, ws + o.f, Rp,
-                            static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl, (T)h.actp[nl - 1])))
+        if (in && (rc = skinny<T>(s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, (long long)R, ws + o.f, Rp,
+                                  static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl, (T)h.actp[nl - 1])))
             return rc;
         // ---- reverse with the multipliers as the one cotangent: curvature weights w_l of every hidden layer
         hipLaunchKernelGGL(layered_hmult_kernel<T>, rg, rb, 0, s, H, nx, h.m, lam, stage ? 1 : 0, r0, R, Rp, ws + o.f, ws + o.dl, h.act[nl - 1],
