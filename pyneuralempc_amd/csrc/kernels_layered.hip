@@ -865,7 +865,7 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
 // (2 + nin) GEMM sweeps instead of the 2 + 2 nin of forward-over-reverse.  RK4 models keep the generic kernel for now.
 
 struct LayeredHws {      // element offsets into the Hessian chunk workspace
-    size_t xi, x0, x1, d[NEMPC_MAX_LAYERS], e[NEMPC_MAX_LAYERS], cw[NEMPC_MAX_LAYERS], f, dl, cl, wl, q0, q1, P, a0, a1, pl, hacc, total;
+    size_t xi, x0, x1, d[NEMPC_MAX_LAYERS], e[NEMPC_MAX_LAYERS], cw[NEMPC_MAX_LAYERS], f, dl, cl, wl, q0, q1, P, a0, a1, pl, hacc, l0p, total;
 };
 
 LayeredHws layered_hess_offsets(const Handle& h, size_t Rp) {
@@ -891,6 +891,7 @@ LayeredHws layered_hess_offsets(const Handle& h, size_t Rp) {
     o.a1 = p; p += (size_t)h.maxw * nin * Rp;
     o.pl = p; p += (size_t)nx * nin * Rp;
     o.hacc = p; p += (size_t)nin * nin * Rp;
+    o.l0p = p; p += (size_t)((h.maxw + 63) / 64) * 32 * Rp;      // layer 0's curvature term per feature block (<= 32 pairs)
     o.total = p;
     return o;
 }
@@ -1034,15 +1035,34 @@ __global__ void layered_hgather_direct_kernel(const T* __restrict__ stage, int s
     for (int j = 0; j < ne; ++j) xi[(size_t)(nin + j) * Rp + r] = extra[(size_t)(gr >> 2) * ne + j];
 }
 
-// blocks[(row)][p][q] row-major, both triangles, from the lower triangle of the accumulators
+// Ppair[n][p (p + 1) / 2 + q] = W_0[p][n] W_0[q][n], p >= q: with it layer 0's curvature term  sum_n w_0[n][r] W_0[p][n] W_0[q][n]
+// is a contraction of w_0 = q_0 . E_0 over the features -- the CONTRACT epilogue of the product that forms q_0
 template <typename T>
-__global__ void layered_hfinish_kernel(int nin, long long r0, int R, long long Rp, const T* __restrict__ Hacc, T* __restrict__ blocks) {
+__global__ void layered_pairs_kernel(const T* __restrict__ W0, int ldw0, int dout0, int nin, T* __restrict__ P) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= dout0) return;
+    const int np = nin * (nin + 1) / 2;
+    for (int p = 0; p < nin; ++p)
+        for (int q = 0; q <= p; ++q) P[(size_t)n * np + p * (p + 1) / 2 + q] = W0[(size_t)p * ldw0 + n] * W0[(size_t)q * ldw0 + n];
+}
+
+// blocks[(row)][p][q] row-major, both triangles, from the lower triangle of the accumulators (null: none) plus layer 0's term
+// as the feature blocks' partial sums (L0: nblk0 blocks, stride0 apart, pair-major; null: it is in the accumulators)
+template <typename T>
+__global__ void layered_hfinish_kernel(int nin, long long r0, int R, long long Rp, const T* __restrict__ Hacc, const T* __restrict__ L0,
+                                       int nblk0, long long stride0, T* __restrict__ blocks) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     T* blk = blocks + (size_t)(r0 + r) * nin * nin;
     for (int p = 0; p < nin; ++p)
         for (int q = 0; q <= p; ++q) {
-            const T v = Hacc[(size_t)(p * nin + q) * Rp + r];
+            T v = Hacc ? Hacc[(size_t)(p * nin + q) * Rp + r] : T(0);
+            if (L0) {
+                const size_t i = (size_t)(p * (p + 1) / 2 + q) * Rp + r;
+                T l0 = L0[i];
+                for (int b = 1; b < nblk0; ++b) l0 += L0[(size_t)b * stride0 + i];
+                v += l0;
+            }
             blk[p * nin + q] = v;
             blk[q * nin + p] = v;
         }
@@ -1088,6 +1108,17 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
     const RowGather gk = h.gather();
     const bool lin_out = h.act[nl - 1] == NEMPC_ACT_LINEAR;
     int rc;
+    // layer 0's curvature term from the epilogue of the product that forms q_0: two hidden layers or more (there is such a
+    // product), at most 32 input pairs (nin <= 7)
+    const int npair = nin * (nin + 1) / 2;
+    const bool fuse_l0 = layered_fuse() && nl >= 3 && npair <= 32;
+    if (fuse_l0 && !h.layered_pairs_valid) {
+        if (!h.d_layered_pairs) NEMPC_HIP(hipMalloc(&h.d_layered_pairs, (size_t)h.maxw * 32 * sizeof(double)));
+        hipLaunchKernelGGL(layered_pairs_kernel<T>, dim3((unsigned)((h.dout[0] + 255) / 256)), dim3(256), 0, s, static_cast<const T*>(h.d_W[0]),
+                           h.dout[0], h.dout[0], nin, static_cast<T*>(h.d_layered_pairs));
+        NEMPC_HIP(hipGetLastError());
+        h.layered_pairs_valid = true;
+    }
     for (long long r0 = 0; r0 < rows; r0 += Rc) {
         const int R = (int)(rows - r0 < Rc ? rows - r0 : Rc);
         const long long Rp = ((long long)R + LG_BM - 1) / LG_BM * LG_BM;
@@ -1143,6 +1174,14 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
             a.A = dq; a.lda = Rp; a.Bw = h.d_Wt[l + 1]; a.ldb = h.dout[l];
             a.M = (int)Rp; a.N = h.dout[l]; a.K = h.dout[l + 1]; a.Rmod = Rp;
             a.D = ws + o.d[l]; a.E = ws + o.e[l]; a.ldd = Rp;
+            if (l == 0 && fuse_l0) {
+                // layer 0's curvature term in this product's epilogue: w_0 = q_0 . E_0 contracted with the pair products
+                a.D = ws + o.e[0];
+                a.w0t = h.d_layered_pairs; a.ldw0 = npair; a.nin = npair;
+                a.Jp = ws + o.l0p; a.ldj = Rp; a.jp_stride = (long long)npair * Rp;
+                if ((rc = gemm_ft<T, 1, false, LG_CONTRACT_REVERSE>(s, a))) return rc;
+                break;
+            }
             a.C = l > 0 ? dn : nullptr; a.C2 = ws + o.cw[l]; a.ldc = Rp;
             // (two loads and two stores per element in the epilogue and only B*H columns: the small-launch rule of the
             // forward products applies)
@@ -1151,7 +1190,8 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
         }
         // ---- layer 0: constant tangents W_0^T
         T* Hacc = ws + o.hacc;
-        if ((rc = hcontract<T>(s, nullptr, 0, static_cast<const T*>(h.d_W[0]), h.dout[0], ws + o.cw[0], h.dout[0], nin, R, Rp, Hacc, false)))
+        if (!fuse_l0 &&
+            (rc = hcontract<T>(s, nullptr, 0, static_cast<const T*>(h.d_W[0]), h.dout[0], ws + o.cw[0], h.dout[0], nin, R, Rp, Hacc, false)))
             return rc;
         // ---- tangents of all nin inputs side by side (column p Rp + r), contracted layer by layer
         const long long ldt = (long long)nin * Rp;
@@ -1174,7 +1214,7 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
                 a.A = ta; a.lda = ldt;
                 if ((rc = gemm_ft<T, 1>(s, a))) return rc;
             }
-            if ((rc = hcontract<T>(s, ws + o.P, ldt, nullptr, 0, ws + o.cw[l], h.dout[l], nin, R, Rp, Hacc, true))) return rc;
+            if ((rc = hcontract<T>(s, ws + o.P, ldt, nullptr, 0, ws + o.cw[l], h.dout[l], nin, R, Rp, Hacc, !(fuse_l0 && l == 1)))) return rc;
             ta = tn;
         }
         if (!lin_out) {
@@ -1185,7 +1225,8 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
                 return rc;
             if ((rc = hcontract<T>(s, ws + o.pl, ldt, nullptr, 0, ws + o.wl, nx, nin, R, Rp, Hacc, true))) return rc;
         }
-        hipLaunchKernelGGL(layered_hfinish_kernel<T>, rg, rb, 0, s, nin, r0, R, Rp, Hacc, blocks);
+        hipLaunchKernelGGL(layered_hfinish_kernel<T>, rg, rb, 0, s, nin, r0, R, Rp, Hacc, fuse_l0 ? ws + o.l0p : static_cast<T*>(nullptr),
+                           (h.dout[0] + 63) / 64, (long long)npair * Rp, blocks);
         NEMPC_HIP(hipGetLastError());
     }
     return NEMPC_OK;
@@ -1234,6 +1275,8 @@ void layered_free(Handle& h) {
     h.d_layered_ws = nullptr;
     if (h.d_layered_hws) (void)hipFree(h.d_layered_hws);
     h.d_layered_hws = nullptr;
+    if (h.d_layered_pairs) (void)hipFree(h.d_layered_pairs);
+    h.d_layered_pairs = nullptr;
 }
 
 // Hessian chunk workspace, sized like the rows one (about 6 GB at most, 4096 .. 65536 rows)

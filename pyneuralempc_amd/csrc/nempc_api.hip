@@ -509,6 +509,7 @@ int nempc_set_weights(nempc_handle hh, const double* const* W, const double* con
         if (rc) return rc;
     }
     h.have_weights = true;
+    h.layered_pairs_valid = false;      // (the layered Hessian's table of first-layer weight products follows the weights)
     return NEMPC_OK;
 }
 

@@ -165,6 +165,8 @@ struct Handle {
     long long layered_chunk_rows = 0;
     void* d_layered_hws = nullptr;  // chunk workspace of its Hessian sweeps (allocated on first use)
     long long layered_hess_chunk_rows = 0;
+    void* d_layered_pairs = nullptr;    // (dout[0], nin (nin + 1) / 2): W_0[p][n] W_0[q][n], p >= q (layer 0's curvature term)
+    bool layered_pairs_valid = false;
     void* solver_ws = nullptr;   // solver.hip
     void* comm = nullptr;        // comm.hip: RCCL communicator of the u0 all-gather
     mutable int last_row_kernel = 0;  // 1 valu, 2 coop, 3 wave-tile
