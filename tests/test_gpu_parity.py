@@ -716,7 +716,7 @@ def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu
     prob = orc.Problem(net, H, nx, nu, kind, DT, box=box)
     f64 = dtype == torch.float64
     tol = dict(rtol=1e-11, atol=1e-11) if f64 else dict(rtol=3e-4, atol=3e-4)
-    ref_rows = None
+    ref_rows = ref_hess = None
     for B in (1, 19, 150):
         eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=dtype, device="cuda:0", max_batch=B,
                              activations=net.act)
@@ -738,6 +738,16 @@ def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu
         assert np.array_equal(res["jac_dense"] != 0, (np.abs(res["jac_dense"]) > 0)) and np.isfinite(res["jac_dense"]).all()
         only_g = eng.eval_numpy(Zh, X0h, want=("g",))["g"]
         assert np.array_equal(only_g, res["g"])
+        if B == 150:
+            # the Lagrangian blocks too: bit for bit what the same problems gave in the batch of 19, and the same again when
+            # the callback is repeated (fixed summation order in every sweep)
+            lam150 = np.random.default_rng(1).normal(size=(B, eng.m))
+            lam150[:7] = ref_hess[1]
+            args = (eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lam150), eng.to_device(np.ones(B)))
+            h1 = eng.hess(*args)["hvals"].to("cpu", torch.float64).numpy()
+            h2 = eng.hess(*args)["hvals"].to("cpu", torch.float64).numpy()
+            assert np.array_equal(h1, h2)
+            assert np.array_equal(h1[:7], ref_hess[0])
         if ref_rows is None:
             ref_rows = res["jac_tiles"][0].copy()
         else:
@@ -765,6 +775,7 @@ def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu
             for i in range(3):
                 refh = prob.hessian_values(Zh[i], X0h[i], lam[i], 1.0)
                 np.testing.assert_allclose(hv[i], refh, rtol=0, atol=(1e-9 if f64 else 5e-3) * max(1.0, np.abs(refh).max()))
+            ref_hess = (hv[:7].copy(), lam[:7].copy())
             if ev is not None:
                 hg = ev.hess(ev.to_device(Zh), ev.to_device(X0h), ev.to_device(lam), ev.to_device(np.ones(B)))["hvals"]
                 assert ev.last_hess_kernel == "rowhess_valu_kernel"
