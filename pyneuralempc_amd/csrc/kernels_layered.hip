@@ -137,7 +137,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rows_rsrc(const T* base, in
 
 template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE, int RM = 4>
 __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : NEMPC_LG_WPE) void layered_gemm_kernel(GemmArgs a) {
-    static_assert(RM == 4 || !SEED, "the seed loader exists for the 64-row block only");
+
     constexpr int BM = 16 * RM;
     static_assert(!(SEED || CONTRACT) || FT == 1, "the fused forms exist for the 64-feature block only");
     using Ops = MfmaOps<T>;
@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : NEMPC_LG_WPE) v
     // W_last[j][cotangent] is a scalar load per row and chunk (w is wave-uniform)
     T seed_dl = T(0);
     int seed_cot = 0;
-    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // row of the chunk this thread's u-th element sits in: tid / BM + (256 / BM) u -- wave-uniform for the 64-row block (a
+    // scalar load of W_last then), two rows per wave for the 32-row block
+    const int krow0 = RM == 4 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid / BM;
     if constexpr (SEED) {
         const int x = tid % BM;
         seed_cot = (int)(m0 / a.Rmod);
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : NEMPC_LG_WPE) v
             const T* __restrict__ sw = static_cast<const T*>(a.seedW);
 #pragma unroll
             for (int u = 0; u < NA; ++u) {
-                const int k = ch * BK + wu + 4 * u;          // (beyond K: any row -- the operand it scales loaded as zero)
+                const int k = ch * BK + krow0 + (256 / BM) * u;          // (beyond K: any row -- the operand it scales loaded as zero)
                 cr.sw[u] = sw[(size_t)(k < K ? k : K - 1) * a.seed_nx + seed_cot];
             }
         }
@@ -702,6 +704,10 @@ bool layered_fuse() {
 
 template <typename T>
 int gemm_reverse_fused(hipStream_t s, const GemmArgs& a, bool seed, bool last) {
+    // (A/B, NEMPC_LG_RM_REV=2: the seed + contraction product on 32-row blocks measured 7 - 11 % slower -- 2 x 256, B*H = 20480:
+    // 257 -> 274 us per evaluation in fp64, 136 -> 151 in fp32 -- so the reverse products keep the 64-row block)
+    static const int rm_env = [] { const char* e = getenv("NEMPC_LG_RM_REV"); return e ? atoi(e) : 0; }();
+    if (rm_env == 2 && seed && last) return gemm_ft<T, 1, true, LG_CONTRACT_REVERSE, 2>(s, a);
     if (seed && last) return gemm_ft<T, 1, true, LG_CONTRACT_REVERSE>(s, a);
     if (seed) return gemm_ft<T, 1, true, LG_CONTRACT_NONE>(s, a);
     if (last) return gemm_ft<T, 1, false, LG_CONTRACT_REVERSE>(s, a);
