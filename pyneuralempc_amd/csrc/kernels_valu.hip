@@ -514,6 +514,13 @@ int launch_rowhess_valu(Handle& h, int B, const void* Z, const void* X0, const v
     if (h.layered) {        // Discret / Unity blocks of wide / deep networks: the GEMM path (kernels_layered.hip)
         const int rc = launch_rowhess_layered(h, B, Z, X0, lambda, blocks, s);
         if (rc != NEMPC_EUNSUPPORTED) return rc;
+        // (the generic kernel writes every derivative from the layer OUTPUT: it has no form for swish / gelu, and must not be
+        // reached with them -- NEMPC_LAYERED_HESS=0 is an A/B switch for the monotone activations)
+        for (int l = 0; l < h.nl; ++l)
+            if (h.act[l] == NEMPC_ACT_SWISH || h.act[l] == NEMPC_ACT_GELU) {
+                set_error("nempc_hess: swish / gelu layers need the layered path's Hessian sweeps (NEMPC_LAYERED_HESS=0 is set?)");
+                return NEMPC_EUNSUPPORTED;
+            }
     }
     const size_t rows = (size_t)B * h.cfg.H;
     const size_t Rcap = (size_t)h.cfg.max_batch * h.cfg.H;
