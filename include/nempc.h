@@ -69,8 +69,9 @@ extern "C" {
  * Derivatives are evaluated from the layer's output a = s(z): s' = 1 (linear), 1 - a^2 (tanh), [a > 0] (relu: the
  * gradient at 0 is 0, as TensorFlow's), a(1-a) (sigmoid), 1 - e^-a (softplus), 1 | a + alpha (elu), 1 | alpha (leaky_relu),
  * lambda | a + lambda alpha (selu, Keras' fixed constants) -- the MONOTONE activations, whose derivatives follow from the
- * output alone.  swish (= silu, z sigmoid(z)) and gelu (z Phi(z), Keras' approximate=False) are not monotone: their
- * derivatives are written from the pre-activation, which only the layer-at-a-time matrix-core path has in hand
+ * output alone.  swish (= silu, z sigmoid(z)), gelu (z Phi(z), Keras' approximate=False), softsign, mish, exponential and relu6
+ * are written from the pre-activation (the first two and mish are not monotone; for the others it is simply the form at
+ * hand), which only the layer-at-a-time matrix-core path has
  * (NEMPC_KERNEL_LAYERED / AUTO; hidden layers only) -- a configuration that would put them on another kernel is refused.
  * elu and leaky_relu read their alpha from nempc_config.act_param (elu: > 0, leaky_relu: >= 0). */
 #define NEMPC_ACT_LINEAR 0
@@ -83,7 +84,12 @@ extern "C" {
 #define NEMPC_ACT_SELU 7
 #define NEMPC_ACT_SWISH 8
 #define NEMPC_ACT_GELU 9
-#define NEMPC_ACT_COUNT 10
+#define NEMPC_ACT_SOFTSIGN 10    /* z / (1 + |z|)                    -- these four, like swish / gelu, from the pre-activation: */
+#define NEMPC_ACT_MISH 11        /* z tanh(softplus(z))                  the layered path only, hidden layers only */
+#define NEMPC_ACT_EXPONENTIAL 12 /* e^z */
+#define NEMPC_ACT_RELU6 13       /* min(max(z, 0), 6): Keras' ReLU(max_value=6) */
+#define NEMPC_ACT_COUNT 14
+#define NEMPC_ACT_FIRST_ZBASED NEMPC_ACT_SWISH /* codes >= this one are written from the pre-activation */
 
 /* row-kernel implementation */
 #define NEMPC_KERNEL_AUTO 0

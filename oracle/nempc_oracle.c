@@ -33,7 +33,7 @@ typedef struct {
     const double* b[MAXL];
     const double *Q, *R, *xref, *uref, *cx, *cu; /* (nx,nx) (nu,nu) (H,nx) (H,nu) (H,nx) (H,nu) */
     int box;
-    int act[MAXL]; /* per layer: 0 linear, 1 tanh, 2 relu, 3 sigmoid, 4 softplus, 5 elu, 6 leaky_relu, 7 selu, 8 swish, 9 gelu (nempc_oracle.py ACT_IDS) */
+    int act[MAXL]; /* per layer: 0 linear, 1 tanh, 2 relu, 3 sigmoid, 4 softplus, 5 elu, 6 leaky_relu, 7 selu, 8 swish, 9 gelu, 10 softsign, 11 mish, 12 exponential, 13 relu6 (nempc_oracle.py ACT_IDS) */
     double actp[MAXL]; /* alpha of elu / leaky_relu */
 } oracle_problem;
 
@@ -52,16 +52,27 @@ static double act_f(int code, double z, double par) {
         case 7: return SELU_LAMBDA * (z > 0.0 ? z : SELU_ALPHA * expm1(z));
         case 8: return z / (1.0 + exp(-z));
         case 9: return 0.5 * z * (1.0 + erf(z * 0.70710678118654752440));
+        case 10: return z / (1.0 + fabs(z));
+        case 11: return z * tanh((z > 0.0 ? z : 0.0) + log1p(exp(-fabs(z))));
+        case 12: return exp(z);
+        case 13: return z < 0.0 ? 0.0 : (z > 6.0 ? 6.0 : z);
         default: return z;
     }
 }
 /* swish and gelu are not monotone: their derivative is written from the pre-activation z */
-static int act_zbased(int code) { return code == 8 || code == 9; }
+static int act_zbased(int code) { return code >= 8 && code <= 13; }
 static double act_d1z(int code, double z) {
     if (code == 8) {
         const double sg = 1.0 / (1.0 + exp(-z));
         return sg * (1.0 + z * (1.0 - sg));
     }
+    if (code == 10) { const double r = 1.0 / (1.0 + fabs(z)); return r * r; }
+    if (code == 11) {
+        const double t = tanh((z > 0.0 ? z : 0.0) + log1p(exp(-fabs(z)))), g = 1.0 / (1.0 + exp(-z));
+        return t + z * (1.0 - t * t) * g;
+    }
+    if (code == 12) return exp(z);
+    if (code == 13) return (z > 0.0 && z < 6.0) ? 1.0 : 0.0;
     return 0.5 * (1.0 + erf(z * 0.70710678118654752440)) + z * 0.39894228040143267794 * exp(-0.5 * z * z);
 }
 static double act_d1(int code, double a, double par) {

@@ -54,8 +54,9 @@ INTEGRATOR_NAMES = {DISCRET: "discret", UNITY: "unity", RK4: "rk4"}
 # would need the pre-activation and are not part of the family.  A parameterised activation is written "name:value"
 # ("elu:0.5", "leaky_relu:0.1"); the bare name takes the default (elu 1, leaky_relu 0.2 = keras.activations.leaky_relu).
 # --------------------------------------------------------------------------------------
-ACTIVATIONS = ("linear", "tanh", "relu", "sigmoid", "softplus", "elu", "leaky_relu", "selu", "swish", "gelu")
-ZBASED = ("swish", "gelu")       # not monotone: s', s'' are written from the pre-activation z (act_s1 / act_s2 below)
+ACTIVATIONS = ("linear", "tanh", "relu", "sigmoid", "softplus", "elu", "leaky_relu", "selu", "swish", "gelu", "softsign", "mish",
+               "exponential", "relu6")
+ZBASED = ("swish", "gelu", "softsign", "mish", "exponential", "relu6")      # s', s'' written from the pre-activation z (act_s1 / act_s2)
 ACT_IDS = {name: i for i, name in enumerate(ACTIVATIONS)}     # the codes of include/nempc.h (NEMPC_ACT_*)
 ACT_DEFAULT_PARAM = {"elu": 1.0, "leaky_relu": 0.2}
 SELU_LAMBDA, SELU_ALPHA = 1.0507009873554804934193349852946, 1.6732632423543772848170429916717
@@ -101,6 +102,15 @@ def act_f(name, z):
     if name == "gelu":                                 # Keras gelu, approximate=False: z Phi(z)
         from scipy.special import erf
         return 0.5 * z * (1.0 + erf(z / np.sqrt(2.0)))
+    if name == "softsign":
+        return z / (1.0 + np.abs(z))
+    if name == "mish":                                 # z tanh(softplus(z))
+        return z * np.tanh(np.maximum(z, 0.0) + np.log1p(np.exp(-np.abs(z))))
+    if name == "exponential":
+        with np.errstate(over="ignore"):
+            return np.exp(z)
+    if name == "relu6":                                # Keras ReLU(max_value=6)
+        return np.where(z < 0.0, 0.0, np.where(z > 6.0, 6.0, z))
     raise ValueError(f"unknown activation {name!r}")
 
 
@@ -115,6 +125,15 @@ def act_s1(name, z, a):
     if nm == "gelu":
         from scipy.special import erf
         return 0.5 * (1.0 + erf(z / np.sqrt(2.0))) + z * np.exp(-0.5 * z * z) / np.sqrt(2.0 * np.pi)
+    if nm == "softsign":
+        return 1.0 / (1.0 + np.abs(z)) ** 2
+    if nm == "mish":
+        t, g = _mish_parts(z)
+        return t + z * (1.0 - t * t) * g
+    if nm == "exponential":
+        return a
+    if nm == "relu6":
+        return np.where(np.isnan(z), z, ((z > 0.0) & (z < 6.0)).astype(np.float64))
     return act_d1(name, a)
 
 
@@ -127,7 +146,23 @@ def act_s2(name, z, a):
         return sg * (1.0 - sg) * (2.0 + z * (1.0 - 2.0 * sg))
     if nm == "gelu":
         return np.exp(-0.5 * z * z) / np.sqrt(2.0 * np.pi) * (2.0 - z * z)
+    if nm == "softsign":
+        return -2.0 * np.sign(z) / (1.0 + np.abs(z)) ** 3
+    if nm == "mish":
+        t, g = _mish_parts(z)
+        u = (1.0 - t * t) * g
+        return 2.0 * u + z * u * ((1.0 - g) - 2.0 * t * g)
+    if nm == "exponential":
+        return a
+    if nm == "relu6":
+        return np.where(np.isnan(z), z, 0.0)
     return act_r2(name, a) * act_d1(name, a)
+
+
+def _mish_parts(z):
+    """t = tanh(softplus z), g = sigmoid z"""
+    with np.errstate(over="ignore"):
+        return np.tanh(np.maximum(z, 0.0) + np.log1p(np.exp(-np.abs(z)))), 1.0 / (1.0 + np.exp(-z))
 
 
 def act_d1(name, a):

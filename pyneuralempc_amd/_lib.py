@@ -18,7 +18,7 @@ KERNEL_NAMES = {"auto": KERNEL_AUTO, "valu": KERNEL_VALU, "mfma": KERNEL_MFMA, "
 INTEGRATOR_IDS = {"discret": DISCRET, "unity": UNITY, "rk4": RK4}
 # NEMPC_ACT_*: the activation of a dense layer (names as Keras spells them)
 ACTIVATION_IDS = {"linear": 0, "tanh": 1, "relu": 2, "sigmoid": 3, "softplus": 4, "elu": 5, "leaky_relu": 6, "selu": 7,
-                  "swish": 8, "gelu": 9}
+                  "swish": 8, "gelu": 9, "softsign": 10, "mish": 11, "exponential": 12, "relu6": 13}
 ACTIVATION_ALIASES = {"silu": "swish"}       # (Keras: swish and silu are the same function)
 # activations with a parameter (alpha), written "name:value" ("elu:0.5", "leaky_relu:0.1"); the bare name takes the default
 # (elu: Keras' 1.0; leaky_relu: keras.activations.leaky_relu's 0.2 -- the LeakyReLU LAYER carries its own negative_slope)

@@ -170,10 +170,10 @@ __device__ __forceinline__ T act_r2(int code, T a, T par) {
     }
 }
 
-// swish / gelu: value and derivatives from the PRE-activation z (the layered path's GEMM epilogue has z = acc + bias in
-// registers).  swish: s = z g, s' = g (1 + z (1 - g)), s'' = g (1 - g) (2 + z (1 - 2 g)) with g = sigmoid(z);
+// swish, gelu, softsign, mish, exponential, relu6: value and derivatives from the PRE-activation z (the layered path's GEMM
+// epilogue has z = acc + bias in registers).  swish: s = z g, s' = g (1 + z (1 - g)), s'' = g (1 - g) (2 + z (1 - 2 g)) with g = sigmoid(z);
 // gelu: s = z Phi, s' = Phi + z phi, s'' = phi (2 - z^2) with Phi / phi the standard normal cdf / pdf.
-__device__ __forceinline__ bool act_zbased(int code) { return code == NEMPC_ACT_SWISH || code == NEMPC_ACT_GELU; }
+__device__ __host__ __forceinline__ bool act_zbased(int code) { return code >= NEMPC_ACT_FIRST_ZBASED && code < NEMPC_ACT_COUNT; }
 __device__ __forceinline__ double nempc_erf(double x) { return erf(x); }
 __device__ __forceinline__ float nempc_erf(float x) { return erff(x); }
 template <typename T>
@@ -183,12 +183,31 @@ __device__ __forceinline__ void act_from_z(int code, T z, T& a, T& d1, T& d2) {
         a = z * g;
         d1 = g * (T(1) + z * (T(1) - g));
         d2 = g * (T(1) - g) * (T(2) + z * (T(1) - T(2) * g));
-    } else {
+    } else if (code == NEMPC_ACT_GELU) {
         const T Phi = T(0.5) * (T(1) + nempc_erf(z * T(0.70710678118654752440)));
         const T phi = T(0.39894228040143267794) * nempc_exp(T(-0.5) * z * z);
         a = z * Phi;
         d1 = Phi + z * phi;
         d2 = phi * (T(2) - z * z);
+    } else if (code == NEMPC_ACT_SOFTSIGN) {             // z / (1 + |z|);  1 / (1 + |z|)^2;  -2 sign(z) / (1 + |z|)^3
+        const T r = T(1) / (T(1) + fabs(z));
+        a = z * r;
+        d1 = r * r;
+        d2 = (z < T(0) ? T(2) : (z > T(0) ? T(-2) : z * T(0))) * r * r * r;      // (a NaN stays a NaN)
+    } else if (code == NEMPC_ACT_MISH) {                 // z t, t = tanh(softplus z), g = sigmoid z
+        const T sp = (z > T(0) ? z : (z != z ? z : T(0))) + nempc_log1p(nempc_exp(-fabs(z)));
+        const T t = sizeof(T) == 8 ? (T)tanh((double)sp) : (T)tanhf((float)sp);
+        const T g = T(1) / (T(1) + nempc_exp(-z));
+        const T u = (T(1) - t * t) * g;                  // dt/dz
+        a = z * t;
+        d1 = t + z * u;
+        d2 = T(2) * u + z * u * ((T(1) - g) - T(2) * t * g);
+    } else if (code == NEMPC_ACT_EXPONENTIAL) {
+        a = d1 = d2 = nempc_exp(z);
+    } else {                                              // relu6: TensorFlow's gradient, 0 at both kinks
+        a = z < T(0) ? T(0) : (z > T(6) ? T(6) : z);
+        d1 = (z > T(0) && z < T(6)) ? T(1) : (z != z ? z : T(0));
+        d2 = z != z ? z : T(0);
     }
 }
 

@@ -517,8 +517,8 @@ int launch_rowhess_valu(Handle& h, int B, const void* Z, const void* X0, const v
         // (the generic kernel writes every derivative from the layer OUTPUT: it has no form for swish / gelu, and must not be
         // reached with them -- NEMPC_LAYERED_HESS=0 is an A/B switch for the monotone activations)
         for (int l = 0; l < h.nl; ++l)
-            if (h.act[l] == NEMPC_ACT_SWISH || h.act[l] == NEMPC_ACT_GELU) {
-                set_error("nempc_hess: swish / gelu layers need the layered path's Hessian sweeps (NEMPC_LAYERED_HESS=0 is set?)");
+            if (h.act[l] >= NEMPC_ACT_FIRST_ZBASED) {
+                set_error("nempc_hess: swish / gelu / softsign / mish / exponential / relu6 layers need the layered path's Hessian sweeps (NEMPC_LAYERED_HESS=0 is set?)");
                 return NEMPC_EUNSUPPORTED;
             }
     }

@@ -3,8 +3,8 @@
 The reference wraps a live Keras model -- any feed-forward one (model/tensorflow.py:8-29) -- and differentiates it with
 tf.GradientTape on the CPU.  Here the Keras object is only *read*: its Dense kernels / biases / activation names are
 copied once and the network is evaluated by the HIP kernels.  Dense stacks with any of the activations linear, tanh,
-relu, sigmoid, softplus, elu(alpha), leaky_relu(alpha), selu (per layer, the output layer included), swish / silu and gelu
-(hidden layers; these two run on the layer-at-a-time matrix-core path only) are taken, stand-alone Activation / ReLU /
+relu, sigmoid, softplus, elu(alpha), leaky_relu(alpha), selu (per layer, the output layer included), swish / silu, gelu,
+softsign, mish, exponential and relu6 (hidden layers; these six run on the layer-at-a-time matrix-core path only) are taken, stand-alone Activation / ReLU /
 LeakyReLU / ELU layers fold into the Dense in front of them; anything else -- other layer types, other activations -- is
 rejected loudly."""
 import numpy as np
@@ -38,9 +38,12 @@ def _standalone_activation(layer, i):
     if kind == "Activation":
         return _activation_name(layer)
     if kind == "ReLU":
-        if getattr(layer, "max_value", None) is not None or float(getattr(layer, "threshold", 0.0) or 0.0) != 0.0:
-            raise NotImplementedError(f"layer {i}: ReLU with max_value / threshold is unsupported on the device path")
         slope = float(getattr(layer, "negative_slope", 0.0) or 0.0)
+        mx = getattr(layer, "max_value", None)
+        if float(getattr(layer, "threshold", 0.0) or 0.0) != 0.0 or (mx is not None and (float(mx) != 6.0 or slope != 0.0)):
+            raise NotImplementedError(f"layer {i}: ReLU with a threshold, or a max_value other than 6, is unsupported on the device path")
+        if mx is not None:
+            return "relu6"
         return "relu" if slope == 0.0 else f"leaky_relu:{slope!r}"
     if kind == "ELU":
         alpha = float(getattr(layer, "alpha", 1.0))

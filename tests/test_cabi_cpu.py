@@ -55,7 +55,7 @@ def test_create_validates_before_touching_the_device_and_fails_loudly_without_gp
     cfg.widths[0] = 3          # last width != nx
     assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     cfg.widths[0] = 2
-    cfg.activations[0] = 10           # no such activation
+    cfg.activations[0] = 14           # no such activation
     assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"activation" in lib.nempc_last_error()
     cfg.activations[0], cfg.act_param[0] = 5, 0.0          # elu needs alpha > 0
     assert lib.nempc_create(ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"alpha" in lib.nempc_last_error()

@@ -595,8 +595,8 @@ def test_mixed_activations_run_on_the_layered_path_and_are_refused_by_the_regist
     np.testing.assert_allclose(res["g"], g, **F64)
     with pytest.raises(_lib.NempcError, match="activations"):
         CallbackEngine(net.W, net.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", kernel="mfma", activations=net.act)
-    with pytest.raises(NotImplementedError, match="mish"):
-        CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["mish", "tanh", "linear"])
+    with pytest.raises(NotImplementedError, match="hard_sigmoid"):
+        CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["hard_sigmoid", "tanh", "linear"])
     # swish / gelu: the layered path only (their derivatives need the pre-activation)
     assert CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["swish", "gelu", "linear"]).kernel_variant == "layered"
     with pytest.raises(_lib.NempcError, match="swish / gelu"):
@@ -701,6 +701,8 @@ def test_every_matrix_core_instantiation_with_its_hessian_against_the_oracle():
     ([192, 130], ["swish", "gelu", "linear"], 2, 1, "discret"),             # derivatives from the pre-activation
     ([96, 96, 96], ["gelu", "tanh", "swish", "softplus"], 3, 2, "rk4"),
     ([150], ["swish", "linear"], 2, 2, "unity"),
+    ([140, 90], ["mish", "softsign", "linear"], 2, 1, "discret"),
+    ([100, 100, 60], ["exponential", "relu6", "mish", "tanh"], 3, 1, "rk4"),
 ])
 def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu, integ):
     """Networks outside the register-resident kernels (width > 128, more than three hidden layers, per-layer activation
@@ -753,7 +755,7 @@ def test_layered_matrix_core_path_against_the_oracle(dtype, hidden, acts, nx, nu
         else:
             assert np.array_equal(res["jac_tiles"][0], ref_rows)       # problem 0 does not depend on the batch around it
         # generic kernel of the same handle shape: agreement to rounding (swish / gelu exist on the layered path only)
-        zbased = any(str(a).split(":")[0] in ("swish", "gelu") for a in net.act)
+        zbased = any(str(a).split(":")[0] in orc.ZBASED for a in net.act)
         if B == 19:
             ev = None
             if not zbased:

@@ -180,8 +180,8 @@ def test_keras_adapter_validation_without_device():
     # swish (= silu) and gelu are taken (layered path); an activation outside the family is refused by name
     assert extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), "silu"), Layer(np.ones((8, 8)), np.zeros(8), "gelu"),
                                      Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))[2] == ["silu", "gelu", "linear"]
-    with pytest.raises(NotImplementedError, match="mish"):
-        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), "mish"), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
+    with pytest.raises(NotImplementedError, match="hard_sigmoid"):
+        extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), "hard_sigmoid"), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
     with pytest.raises(NotImplementedError, match="already applies"):
         extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), tanh), Activation(relu),
                                   Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
@@ -191,6 +191,9 @@ def test_keras_adapter_validation_without_device():
                                      Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))[2] == ["leaky_relu:0.1", "linear"]
     capped = ReLU()
     capped.max_value = 6.0
+    assert extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), linear), capped,
+                                     Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))[2] == ["relu6", "linear"]
+    capped.max_value = 4.0
     with pytest.raises(NotImplementedError, match="max_value"):
         extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), linear), capped,
                                   Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
@@ -201,9 +204,9 @@ def test_keras_adapter_validation_without_device():
     W, b, acts = extract_dense_stack(Fake([NoBias(), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
     assert np.array_equal(b[0], np.zeros(8)) and acts == ["tanh", "linear"]
 
-    def mish(x): return x
-    bad = Fake([Layer(np.ones((3, 8)), np.zeros(8), mish), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2)
-    with pytest.raises(NotImplementedError, match="activation 'mish'"):
+    def hard_sigmoid(x): return x
+    bad = Fake([Layer(np.ones((3, 8)), np.zeros(8), hard_sigmoid), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2)
+    with pytest.raises(NotImplementedError, match="activation 'hard_sigmoid'"):
         KerasTFModel(bad, x_dim=2, u_dim=1)
 
     class Elu2:

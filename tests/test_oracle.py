@@ -118,7 +118,7 @@ def _torch_act(spec):
     F = torch.nn.functional
     return {"linear": lambda z: z, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid, "softplus": F.softplus,
             "elu": lambda z: F.elu(z, alpha=par), "leaky_relu": lambda z: F.leaky_relu(z, negative_slope=par), "selu": F.selu,
-            "swish": F.silu, "gelu": F.gelu}[name]
+            "swish": F.silu, "gelu": F.gelu, "softsign": F.softsign, "mish": F.mish, "exponential": torch.exp, "relu6": F.relu6}[name]
 
 
 def _torch_net(W, b, act=None):
@@ -138,7 +138,8 @@ def _torch_net(W, b, act=None):
                                   ["elu", "sigmoid", "tanh"], ["linear", "tanh", "softplus"], ["sigmoid", "elu", "elu"],
                                   "selu", "leaky_relu", "elu:0.5", ["leaky_relu:0.05", "selu", "elu:1.7"],
                                   ["selu", "leaky_relu:0.3", "selu"], "swish", "gelu", ["swish", "gelu", "tanh"],
-                                  ["gelu", "relu", "swish"]])
+                                  ["gelu", "relu", "swish"], "softsign", "mish", "exponential", "relu6",
+                                  ["mish", "softsign", "relu6"], ["exponential", "relu6", "mish"]])
 def test_activation_family_derivatives_vs_torch_ad(acts):
     """Every activation of the device family, uniform on the hidden layers and mixed per layer with a non-linear output
     layer: the oracle's first and second derivatives -- written from the layer OUTPUT a = s(z), as the kernels do (from the
@@ -164,6 +165,8 @@ def test_activation_functions_at_their_edges():
     """Values the formulas must survive: large |z| (no overflow / NaN), the kinks, NaN propagation."""
     z = np.array([-800.0, -40.0, -1e-300, 0.0, 1e-300, 40.0, 800.0])
     for name in orc.ACTIVATIONS:
+        if name == "exponential":
+            z = np.minimum(z, 40.0)          # (e^800 IS infinite: the function's own range, not a formula to survive)
         a = orc.act_f(name, z)
         assert np.all(np.isfinite(a)), name
         assert np.all(np.isfinite(orc.act_s1(name, z, a))) and np.all(np.isfinite(orc.act_s2(name, z, a))), name
@@ -174,7 +177,7 @@ def test_activation_functions_at_their_edges():
     assert orc.act_d1("elu", orc.act_f("elu", np.array([0.0])))[0] == 1.0
     assert orc.act_d1("elu:0.5", orc.act_f("elu:0.5", np.array([0.0])))[0] == 0.5
     assert orc.act_d1("leaky_relu:0.1", orc.act_f("leaky_relu:0.1", np.array([0.0])))[0] == 0.1    # tf.nn.leaky_relu's gradient at 0
-    for bad in ("elu:0", "elu:-1", "leaky_relu:-0.1", "tanh:2", "mish", "gelu:1"):
+    for bad in ("elu:0", "elu:-1", "leaky_relu:-0.1", "tanh:2", "hard_sigmoid", "gelu:1"):
         with pytest.raises(ValueError):
             orc.act_split(bad)
     np.testing.assert_allclose(orc.act_d1("softplus", orc.act_f("softplus", z)), 1.0 / (1.0 + np.exp(-np.clip(z, -700, 700))),

@@ -8,7 +8,8 @@ from oracle import nempc_oracle as orc
 from pyneuralempc_amd import CallbackEngine
 rng = np.random.default_rng(int(os.environ.get("NEMPC_SWEEP_SEED", "0")))
 N = int(os.environ.get("N", "40"))
-ACTS = ["tanh", "relu", "sigmoid", "softplus", "elu", "elu:0.6", "leaky_relu:0.15", "selu", "swish", "gelu", "linear"]
+ACTS = ["tanh", "relu", "sigmoid", "softplus", "elu", "elu:0.6", "leaky_relu:0.15", "selu", "swish", "gelu", "softsign", "mish",
+        "exponential", "relu6", "linear"]
 bad = 0
 for case in range(N):
     nx, nu = int(rng.integers(1, 7)), int(rng.integers(1, 5))
@@ -18,7 +19,7 @@ for case in range(N):
     H, B = int(rng.integers(1, 9)), int(rng.integers(1, 40))
     acts = [ACTS[int(rng.integers(0, len(ACTS)))] for _ in range(nl_h)]
     out_act = ["linear", "linear", "tanh", "softplus"][int(rng.integers(0, 4))]
-    zb = any(a in ("swish", "gelu") for a in acts)
+    zb = any(a in orc.ZBASED for a in acts)
     if nl_h == 1 and out_act != "linear" and zb:
         out_act = "linear"           # (the one shape nempc_create refuses for swish / gelu)
     acts = acts + [out_act]
