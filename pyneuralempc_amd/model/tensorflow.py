@@ -6,7 +6,7 @@ copied once and the network is evaluated by the HIP kernels.  Dense stacks with 
 relu, sigmoid, softplus, elu(alpha), leaky_relu(alpha), selu (per layer, the output layer included), swish / silu, gelu,
 softsign, mish, exponential and relu6 (hidden layers; these six run on the layer-at-a-time matrix-core path only) are taken, stand-alone Activation / ReLU /
 LeakyReLU / ELU layers fold into the Dense in front of them; anything else -- other layer types, other activations -- is
-rejected loudly."""
+rejected loudly.  BatchNormalization / Normalization / Rescaling layers are folded into the neighbouring Dense layer."""
 import numpy as np
 
 from .mlp import MLPModel
@@ -58,15 +58,56 @@ def _standalone_activation(layer, i):
                               "inference-identity layers " + ", ".join(sorted(_IDENTITY_LAYERS)))
 
 
+def _affine_layer(layer, i):
+    """(scale, shift) of a layer that is an elementwise affine map at inference -- BatchNormalization (moving statistics),
+    the Normalization / Rescaling preprocessing layers -- or None.  Such a layer folds into a neighbouring Dense layer exactly."""
+    kind = type(layer).__name__
+    if kind == "BatchNormalization":
+        params = [np.asarray(p, dtype=np.float64) for p in layer.get_weights()]
+        scale_on, center_on = bool(getattr(layer, "scale", True)), bool(getattr(layer, "center", True))
+        if len(params) != 2 + int(scale_on) + int(center_on) or any(p.ndim != 1 for p in params):
+            raise NotImplementedError(f"layer {i}: BatchNormalization over anything but the feature axis is unsupported on the device path")
+        mean, var = params[-2], params[-1]
+        gamma = params[0] if scale_on else np.ones_like(mean)
+        beta = params[int(scale_on)] if center_on else np.zeros_like(mean)
+        sc = gamma / np.sqrt(var + float(getattr(layer, "epsilon", 1e-3)))
+        return sc, beta - mean * sc
+    if kind == "Normalization":
+        if getattr(layer, "invert", False):
+            raise NotImplementedError(f"layer {i}: Normalization(invert=True) is unsupported on the device path")
+        mean = np.asarray(layer.mean, dtype=np.float64).reshape(-1)
+        var = np.asarray(layer.variance, dtype=np.float64).reshape(-1)
+        sc = 1.0 / np.maximum(np.sqrt(var), 1e-7)           # (Keras: max(sqrt(var), backend.epsilon()))
+        return sc, -mean * sc
+    if kind == "Rescaling":
+        sc = np.asarray(layer.scale, dtype=np.float64).reshape(-1)
+        return sc, np.broadcast_to(np.asarray(getattr(layer, "offset", 0.0), dtype=np.float64).reshape(-1), sc.shape) if sc.size > 1 \
+            else np.asarray(getattr(layer, "offset", 0.0), dtype=np.float64).reshape(-1)
+    return None
+
+
 def extract_dense_stack(keras_model):
     """-> (weights, biases, activations) from a duck-typed Keras Sequential/Functional model of Dense layers;
     activations holds one Keras activation name per dense layer.  EVERY layer is walked in order: a stand-alone activation
     layer (`Dense(64)` + `Activation('tanh')`, `ReLU()`, `ELU()`) is folded into the linear Dense in front of it, layers that
-    are the identity at inference (InputLayer, Dropout, ...) are skipped, anything else is refused -- the reference evaluates
-    the Keras model as built (model/tensorflow.py:49-51), so no layer may be ignored."""
+    are the identity at inference (InputLayer, Dropout, ...) are skipped, an elementwise affine layer (BatchNormalization with
+    its moving statistics, Normalization, Rescaling) is folded exactly into the Dense behind it -- or, right behind a Dense
+    that has not been given an activation yet, into that one -- and anything else is refused: the reference evaluates the
+    Keras model as built (model/tensorflow.py:49-51), so no layer may be ignored."""
     all_layers = list(getattr(keras_model, "layers", []))
     weights, biases, activations = [], [], []
+    pre = None                     # (scale, shift) waiting for the next Dense: x -> scale * x + shift in front of it
     for i, layer in enumerate(all_layers):
+        aff = _affine_layer(layer, i)
+        if aff is not None:
+            sc, sh = (np.asarray(v, dtype=np.float64) for v in aff)
+            if weights and activations[-1] == "linear" and pre is None:
+                # behind a linear Dense: y -> sc * (x W + b) + sh
+                weights[-1] = weights[-1] * sc[None, :]
+                biases[-1] = biases[-1] * sc + sh
+            else:
+                pre = (sc, sh) if pre is None else (pre[0] * sc, pre[1] * sc + sh)
+            continue
         params = layer.get_weights()
         if len(params) == 0:
             if type(layer).__name__ in _IDENTITY_LAYERS:
@@ -74,8 +115,8 @@ def extract_dense_stack(keras_model):
             name = _standalone_activation(layer, i)
             if name == "linear":
                 continue
-            if not activations:
-                raise NotImplementedError(f"layer {i}: an activation layer in front of the first Dense layer is unsupported")
+            if not activations or pre is not None:
+                raise NotImplementedError(f"layer {i}: an activation layer that does not follow a Dense layer directly is unsupported")
             if activations[-1] != "linear":
                 raise NotImplementedError(f"layer {i}: activation '{name}' on top of a Dense layer that already applies "
                                           f"'{activations[-1]}' is unsupported on the device path")
@@ -96,11 +137,20 @@ def extract_dense_stack(keras_model):
             _lib.split_activation(name)
         except NotImplementedError as e:
             raise NotImplementedError(f"layer {i}: {e}")
-        weights.append(np.asarray(params[0], dtype=np.float64))
-        biases.append(np.asarray(params[1], dtype=np.float64))
+        Wl, bl = np.asarray(params[0], dtype=np.float64), np.asarray(params[1], dtype=np.float64)
+        if pre is not None:          # (scale * x + shift) W + b = x (diag(scale) W) + (shift W + b)
+            sc, sh = (np.broadcast_to(v, (Wl.shape[0],)) for v in pre)
+            bl = bl + sh @ Wl
+            Wl = Wl * sc[:, None]
+            pre = None
+        weights.append(Wl)
+        biases.append(bl)
         activations.append(name)
     if not weights:
         raise ValueError("The provided model has no parameterised layers")
+    if pre is not None:
+        raise NotImplementedError("an affine layer (BatchNormalization / Normalization / Rescaling) behind the last non-linear layer "
+                                  "has no Dense layer to fold into")
     return weights, biases, activations
 
 

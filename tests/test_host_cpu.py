@@ -90,6 +90,66 @@ def test_factory_and_controller_contract():
         NMPC(FakeIntegrator(), object(), [], 3, 1.0, optimizer=Slsqp())
 
 
+def test_keras_adapter_folds_affine_layers_into_the_dense_stack():
+    """BatchNormalization (moving statistics), Normalization and Rescaling are elementwise affine maps at inference: the
+    adapter folds them exactly into the neighbouring Dense layer -- the extracted stack evaluates to what the layers
+    evaluate to one by one (what the reference's model.predict would return, model/tensorflow.py:49-51) -- and refuses the
+    placements that have no Dense to fold into."""
+    from pyneuralempc_amd.model.tensorflow import extract_dense_stack
+    rng = np.random.default_rng(0)
+
+    class Layer:
+        def __init__(self, W, b, act): self.W, self.b, self.activation = W, b, act
+        def get_weights(self): return [self.W, self.b]
+
+    class BatchNormalization:
+        scale, center, epsilon = True, True, 1e-3
+        def __init__(self, n, scale=True, center=True):
+            self.scale, self.center = scale, center
+            self.gamma, self.beta = rng.uniform(0.5, 1.5, n), rng.normal(size=n)
+            self.mean, self.var = rng.normal(size=n), rng.uniform(0.5, 2.0, n)
+        def get_weights(self):
+            return ([self.gamma] if self.scale else []) + ([self.beta] if self.center else []) + [self.mean, self.var]
+        def __call__(self, x):
+            y = (x - self.mean) / np.sqrt(self.var + self.epsilon)
+            return (self.gamma if self.scale else 1.0) * y + (self.beta if self.center else 0.0)
+
+    class Normalization:
+        invert = False
+        def __init__(self, n): self.mean, self.variance = rng.normal(size=(1, n)), rng.uniform(0.5, 2.0, (1, n))
+        def get_weights(self): return [self.mean, self.variance, np.array(0)]
+        def __call__(self, x): return (x - self.mean.ravel()) / np.sqrt(self.variance.ravel())
+
+    class Rescaling:
+        scale, offset = 0.5, -1.0
+        def get_weights(self): return []
+        def __call__(self, x): return x * self.scale + self.offset
+
+    class Activation:
+        def __init__(self, act): self.activation = act
+        def get_weights(self): return []
+
+    class Fake:
+        def __init__(self, layers): self.layers = layers
+
+    L1, L2, L3 = (Layer(rng.normal(size=(3, 8)), rng.normal(size=8), "linear"), Layer(rng.normal(size=(8, 8)), rng.normal(size=8), "tanh"),
+                  Layer(rng.normal(size=(8, 2)), rng.normal(size=2), "linear"))
+    N0, R0, B1, B2, B3 = Normalization(3), Rescaling(), BatchNormalization(8), BatchNormalization(8, scale=False), BatchNormalization(2, center=False)
+    W, b, acts = extract_dense_stack(Fake([N0, R0, L1, B1, Activation("tanh"), L2, B2, L3, B3]))
+    assert acts == ["tanh", "tanh", "linear"]
+    x = rng.normal(size=(6, 3))
+    y = B3(B2(np.tanh(np.tanh(B1(R0(N0(x)) @ L1.W + L1.b)) @ L2.W + L2.b)) @ L3.W + L3.b)
+    z = x
+    for Wl, bl, a in zip(W, b, acts):
+        z = z @ Wl + bl
+        z = np.tanh(z) if a == "tanh" else z
+    np.testing.assert_allclose(z, y, rtol=1e-13, atol=1e-13)
+    with pytest.raises(NotImplementedError, match="no Dense layer to fold into"):
+        extract_dense_stack(Fake([L1, Activation("tanh"), BatchNormalization(8)]))
+    with pytest.raises(NotImplementedError, match="does not follow a Dense layer directly"):
+        extract_dense_stack(Fake([L2, BatchNormalization(8), Activation("relu"), L3]))
+
+
 def test_keras_adapter_validation_without_device():
     from pyneuralempc_amd.model.tensorflow import KerasTFModel, extract_dense_stack
 
