@@ -94,7 +94,14 @@ def extract_dense_stack(keras_model):
     its moving statistics, Normalization, Rescaling) is folded exactly into the Dense behind it -- or, right behind a Dense
     that has not been given an activation yet, into that one -- and anything else is refused: the reference evaluates the
     Keras model as built (model/tensorflow.py:49-51), so no layer may be ignored."""
-    all_layers = list(getattr(keras_model, "layers", []))
+    def flat(layers):            # (a Sequential used as a layer of another model: its layers, in order)
+        for l in layers:
+            sub = getattr(l, "layers", None)
+            if sub is not None and type(l).__name__ in ("Sequential", "Functional", "Model"):
+                yield from flat(sub)
+            else:
+                yield l
+    all_layers = list(flat(getattr(keras_model, "layers", [])))
     weights, biases, activations = [], [], []
     pre = None                     # (scale, shift) waiting for the next Dense: x -> scale * x + shift in front of it
     for i, layer in enumerate(all_layers):

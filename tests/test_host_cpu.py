@@ -144,6 +144,11 @@ def test_keras_adapter_folds_affine_layers_into_the_dense_stack():
         z = z @ Wl + bl
         z = np.tanh(z) if a == "tanh" else z
     np.testing.assert_allclose(z, y, rtol=1e-13, atol=1e-13)
+    # a Sequential nested as a layer contributes its layers in order
+    class Sequential(Fake):
+        pass
+    W2, b2, acts2 = extract_dense_stack(Fake([N0, R0, Sequential([L1, B1, Activation("tanh")]), Sequential([L2, B2, Sequential([L3])]), B3]))
+    assert acts2 == acts and all(np.array_equal(p, q) for p, q in zip(W + b, W2 + b2))
     with pytest.raises(NotImplementedError, match="no Dense layer to fold into"):
         extract_dense_stack(Fake([L1, Activation("tanh"), BatchNormalization(8)]))
     with pytest.raises(NotImplementedError, match="does not follow a Dense layer directly"):
