@@ -67,6 +67,48 @@ def test_model_plugin_layouts():
     assert not MJ[mask].any()
 
 
+def test_torch_module_model_runs_on_the_kernels_and_matches_torch_autodiff():
+    """TorchMLPModel: a torch.nn.Sequential dense network (BatchNorm1d, SiLU, GELU, a nested Sequential) read once and
+    evaluated by the HIP kernels through the reference's Model surface -- forward / block-layout jacobian / hessian against
+    torch's own autodiff of the module, and a closed-loop step through NMPC with the device optimizer."""
+    import pyneuralempc_amd as nEMPC
+    nn = torch.nn
+    torch.manual_seed(1)
+    bn = nn.BatchNorm1d(48)
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+    net = nn.Sequential(nn.Linear(3, 48), bn, nn.SiLU(), nn.Sequential(nn.Linear(48, 40), nn.GELU()), nn.Linear(40, 2)).double().eval()
+    with torch.no_grad():
+        net[-1].weight.mul_(0.2); net[-1].bias.mul_(0.2)
+    for prm in net.parameters():
+        prm.requires_grad_(False)
+    model = nEMPC.model.TorchMLPModel(net, x_dim=2, u_dim=1, device="cuda:0")
+    rng = np.random.default_rng(0)
+    H = 5
+    x, u = rng.normal(size=(H, 2)), rng.normal(size=(H, 1))
+    xi = torch.tensor(np.concatenate([x, u], axis=1))
+    np.testing.assert_allclose(model.forward(x, u), net(xi).detach().numpy(), rtol=1e-11, atol=1e-12)
+    row = lambda v: net(v[None])[0]
+    MJ, Hs = model.jacobian(x, u), model.hessian(x, u)
+    for t in range(H):
+        J = torch.func.jacrev(row)(xi[t]).detach().numpy()
+        S = torch.func.hessian(row)(xi[t]).detach().numpy()
+        np.testing.assert_allclose(MJ[2 * t:2 * t + 2, 2 * t:2 * t + 2], J[:, :2], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(MJ[2 * t:2 * t + 2, 2 * H + t], J[:, 2], rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(Hs[t][:, 2 * t:2 * t + 2, 2 * t:2 * t + 2], S[:, :2, :2], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(Hs[t][:, 2 * H + t, 2 * H + t], S[:, 2, 2], rtol=1e-9, atol=1e-10)
+    integ = nEMPC.integrator.discret.DiscretIntegrator(model, 8)
+    obj = nEMPC.objective.QuadraticObjective(Q=np.eye(2), R=0.1 * np.eye(1), device="cuda:0")
+    dom = nEMPC.constraints.DomainConstraint(states_constraint=[[-5.0, 5.0]] * 2, control_constraint=[[-1.0, 1.0]])
+    mpc = nEMPC.controller.NMPC(integ, obj, [dom], 8, 1.0, optimizer=nEMPC.optimizer.DeviceSqp())
+    states, uu = mpc.next(np.array([0.4, -0.3]))
+    assert states is not None and states.shape == (8, 2) and np.all(np.abs(uu) <= 1.0 + 1e-9)
+    # the predicted states are the module's own roll-out of the controls
+    xk = torch.tensor([0.4, -0.3], dtype=torch.float64)
+    for t in range(8):
+        xk = xk + net(torch.cat([xk, torch.tensor(uu[t])])[None])[0]
+        np.testing.assert_allclose(states[t], xk.detach().numpy(), atol=1e-6)
+
+
 def test_integrator_hessian_blocks_like_reference():
     d, W, b = load_case("c1_discret")
     integ = _integrator(d, W, b)

@@ -155,6 +155,45 @@ def test_keras_adapter_folds_affine_layers_into_the_dense_stack():
         extract_dense_stack(Fake([L2, BatchNormalization(8), Activation("relu"), L3]))
 
 
+def test_torch_module_adapter_extracts_the_dense_stack():
+    """TorchMLPModel's reader: nn.Linear weights (transposed to (in, out)), activation modules folded into the Linear in front,
+    BatchNorm1d (eval) folded into its neighbour, nested Sequential flattened -- the extracted stack evaluates to the module's
+    own forward, with every activation module of the kernels' family; what the kernels cannot express is refused."""
+    import torch
+    from pyneuralempc_amd.model.torch_mlp import TorchMLPModel, extract_linear_stack
+    from oracle import nempc_oracle as orc
+    nn = torch.nn
+    torch.manual_seed(0)
+    bn = nn.BatchNorm1d(16)
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0); bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+    net = nn.Sequential(nn.Linear(3, 16), bn, nn.SiLU(), nn.Sequential(nn.Linear(16, 12, bias=False), nn.ELU(0.7), nn.Dropout(0.1)),
+                        nn.Linear(12, 8), nn.GELU(), nn.Linear(8, 2)).double().eval()
+    W, b, acts = extract_linear_stack(net)
+    assert acts == ["swish", "elu:0.7", "gelu", "linear"] and [w.shape for w in W] == [(3, 16), (16, 12), (12, 8), (8, 2)]
+    x = np.random.default_rng(0).normal(size=(7, 3))
+    np.testing.assert_allclose(orc.MLP(W, b, acts).forward(x), net(torch.tensor(x)).detach().numpy(), rtol=1e-13, atol=1e-14)
+    for mod, name in ((nn.Tanh(), "tanh"), (nn.ReLU(), "relu"), (nn.Sigmoid(), "sigmoid"), (nn.Softplus(), "softplus"), (nn.SELU(), "selu"),
+                      (nn.LeakyReLU(0.05), "leaky_relu:0.05"), (nn.Softsign(), "softsign"), (nn.Mish(), "mish"), (nn.ReLU6(), "relu6"),
+                      (nn.ELU(), "elu")):
+        m = nn.Sequential(nn.Linear(3, 5), mod, nn.Linear(5, 2)).double().eval()
+        Wm, bm, am = extract_linear_stack(m)
+        assert am == [name, "linear"]
+        np.testing.assert_allclose(orc.MLP(Wm, bm, am).forward(x), m(torch.tensor(x)).detach().numpy(), rtol=1e-12, atol=1e-13)
+    for bad, msg in ((nn.Sequential(nn.Linear(3, 4), nn.GELU(approximate="tanh"), nn.Linear(4, 2)), "approximate"),
+                     (nn.Sequential(nn.Linear(3, 4), nn.Softplus(beta=2.0), nn.Linear(4, 2)), "beta"),
+                     (nn.Sequential(nn.Linear(3, 4), nn.Hardtanh(), nn.Linear(4, 2)), "Hardtanh"),
+                     (nn.Sequential(nn.Linear(3, 4), nn.BatchNorm1d(4), nn.Linear(4, 2)).train(), "eval"),
+                     (nn.Sequential(nn.Conv1d(1, 1, 3)), "Conv1d")):
+        with pytest.raises(NotImplementedError, match=msg):
+            extract_linear_stack(bad)
+    with pytest.raises(ValueError, match="output dim"):
+        TorchMLPModel(net, x_dim=3, u_dim=0)
+    with pytest.raises(ValueError, match="input dim"):
+        TorchMLPModel(net, x_dim=2, u_dim=2)
+    m = TorchMLPModel(net, x_dim=2, u_dim=1)
+    assert m.activations == acts and (m.x_dim, m.u_dim) == (2, 1)
+
+
 def test_keras_adapter_validation_without_device():
     from pyneuralempc_amd.model.tensorflow import KerasTFModel, extract_dense_stack
 
