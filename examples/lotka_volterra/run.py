@@ -53,9 +53,7 @@ def fit_surrogate(iters=1500, seed=0):
         loss = torch.mean((net(xi) - target) ** 2)
         loss.backward()
         opt.step()
-    lin = [m for m in net if isinstance(m, torch.nn.Linear)]
-    # Keras `kernel` layout (in, out)
-    return [m.weight.detach().numpy().T.copy() for m in lin], [m.bias.detach().numpy().copy() for m in lin], float(loss.detach())
+    return net.eval(), float(loss.detach())
 
 
 def plant_step(x, u, dt):
@@ -65,11 +63,12 @@ def plant_step(x, u, dt):
 
 
 def main(steps=20, batch=0, fit_iters=1500, device="cuda:0", verbose=True, device_solver=False):
-    W, b, loss = fit_surrogate(fit_iters)
+    net, loss = fit_surrogate(fit_iters)
     if verbose:
         print(f"surrogate fitted, mse {loss:.2e}")
     H = Hb
-    model_nmpc = nEMPC.model.MLPModel(W, b, x_dim=2, u_dim=1, device=device)           # run.py:73
+    # run.py:73 hands the loaded Keras model to KerasTFModel; the torch module goes to its counterpart the same way
+    model_nmpc = nEMPC.model.TorchMLPModel(net, x_dim=2, u_dim=1, device=device)
     constraints_nmpc = [nEMPC.constraints.DomainConstraint(                            # run.py:77-79
         states_constraint=[[-np.inf, X_MAX], [-np.inf, np.inf]], control_constraint=[[U_MIN, U_MAX]])]
     integrator = nEMPC.integrator.rk4.RK4Integrator(model_nmpc, H, 0.1, cache_mode=True)   # run.py:82
