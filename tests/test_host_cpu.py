@@ -192,6 +192,17 @@ def test_torch_module_adapter_extracts_the_dense_stack():
         TorchMLPModel(net, x_dim=2, u_dim=2)
     m = TorchMLPModel(net, x_dim=2, u_dim=1)
     assert m.activations == acts and (m.x_dim, m.u_dim) == (2, 1)
+    # the rolling-window reader: rolling_window * (x + u) inputs (reference: KerasTFModelRollingInput, model/tensorflow.py:132-147)
+    from pyneuralempc_amd.model.torch_mlp import TorchMLPModelRollingInput
+    from pyneuralempc_amd.model.rolling import MLPModelRollingInput
+    roll = nn.Sequential(nn.Linear(9, 12), nn.Tanh(), nn.Linear(12, 2)).double().eval()
+    mr = TorchMLPModelRollingInput(roll, x_dim=2, u_dim=1, rolling_window=3)
+    Wr, br, ar = extract_linear_stack(roll)
+    ref = MLPModelRollingInput(Wr, br, 2, 1, rolling_window=3, activations=ar)
+    assert mr.rolling_window == ref.rolling_window == 3 and mr.activations == ref.activations
+    assert all(np.array_equal(p, q) for p, q in zip(mr.weights, ref.weights))
+    with pytest.raises(ValueError, match="output dim"):
+        TorchMLPModelRollingInput(roll, x_dim=3, u_dim=1, rolling_window=3)
 
 
 def test_keras_adapter_validation_without_device():
