@@ -749,18 +749,22 @@ class Rank:
     def layered_leg(self):
         """Networks outside the register-resident kernels (the reference wraps any feed-forward Keras model:
         model/tensorflow.py:8-29): the layer-at-a-time GEMM path (csrc/kernels_layered.hip) on the headline's dims with a
-        2 x 256 and a 3 x 256 tanh network, fp64 -- whole evaluation (f, grad, g, dense Jacobian) and exact-Hessian callback,
+        2 x 256 and a 3 x 256 tanh network in fp64, and on configs[2]'s dims (6/3, H = 30, RK4, fp32) with a 4 x 512 one -- whole evaluation (f, grad, g, dense Jacobian) and exact-Hessian callback,
         HIP-event time, fraction of the FP64 matrix peak by algorithmic GEMM flops, error of the timed launches' own output
         against the oracle on the first problems."""
         np, torch = self.np, self.torch
         from oracle import nempc_oracle as orc
         from pyneuralempc_amd import CallbackEngine
-        B, H, nx, nu = 1024, 20, 2, 1
         out = {}
-        for name, hidden in (("2x256", [256, 256]), ("3x256", [256, 256, 256])):
+        for name, hidden, (B, H, nx, nu), integ, DT, tdt in (("2x256", [256, 256], (1024, 20, 2, 1), "discret", 1.0, torch.float64),
+                                                            ("3x256", [256, 256, 256], (1024, 20, 2, 1), "discret", 1.0, torch.float64),
+                                                            # configs[2]'s dims and precision with a 4 x 512 network
+                                                            ("4x512_rk4", [512] * 4, (1024, 30, 6, 3), "rk4", 0.1, torch.float32)):
+            S = 4 if integ == "rk4" else 1
+            f64 = tdt == torch.float64
             net = orc.MLP.random(nx + nu, hidden, nx, seed=0)
-            prob = orc.Problem(net, H, nx, nu, orc.DISCRET, 1.0, Q=np.eye(nx), R=0.1 * np.eye(nu))
-            eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator="discret", dtype=torch.float64, device=self.dev, max_batch=B)
+            prob = orc.Problem(net, H, nx, nu, orc.RK4 if S == 4 else orc.DISCRET, DT, Q=np.eye(nx), R=0.1 * np.eye(nu))
+            eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=tdt, device=self.dev, max_batch=B)
             eng.set_objective(Q=np.eye(nx), R=0.1 * np.eye(nu))
             Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=1)
             Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
@@ -768,27 +772,31 @@ class Rank:
             lamh, sigh = rng.normal(size=(B, eng.m)), rng.uniform(0.5, 1.5, size=B)
             lam, sig = eng.to_device(lamh), eng.to_device(sigh)
             step, outs = eng.bind(Z, X0, ("f", "grad", "g", "jac_dense"))
-            t_e = self.timed_events(step, 30)
+            t_e = self.timed_events(step, 30 if S == 1 else 8)
             call_h, out_h = eng.bind_hess(Z, X0, lam, sig)
-            t_h = self.timed_events(call_h, 20)
+            t_h = self.timed_events(call_h, 20 if S == 1 else 4)
             torch.cuda.synchronize(self.dev)
             dims = [nx + nu] + hidden + [nx]
             F = 2 * sum(i * o for i, o in zip(dims[:-1], dims[1:]))
-            row_flops = B * H * (1 + nx) * F
-            hess_flops = B * H * (2 + nx + nu) * F
+            row_flops = B * H * S * (1 + nx) * F
+            hess_flops = B * H * S * (2 + nx + nu) * F + (row_flops if S == 4 else 0)
+            peak = PEAK_F64_TFLOPS if f64 else PEAK_F32_TFLOPS
             e_j = e_h = s_h = 0.0
-            for i in range(4):
+            for i in range(4 if S == 1 else 1):           # (the 6/3 RK4 oracle with 512-wide layers takes seconds per problem)
                 f, grad, g, J = prob.eval_batch(Zh[i:i + 1], X0h[i:i + 1])
-                e_j = max(e_j, float(np.abs(outs["jac_dense"][i].cpu().numpy() - J[0]).max()), float(np.abs(outs["g"][i].cpu().numpy() - g[0]).max()))
+                e_j = max(e_j, float(np.abs(outs["jac_dense"][i].to("cpu", torch.float64).numpy() - J[0]).max()),
+                          float(np.abs(outs["g"][i].to("cpu", torch.float64).numpy() - g[0]).max()))
                 ref = prob.hessian_values(Zh[i], X0h[i], lamh[i], sigh[i])
-                e_h = max(e_h, float(np.abs(out_h["hvals"][i].cpu().numpy() - ref).max()))
+                e_h = max(e_h, float(np.abs(out_h["hvals"][i].to("cpu", torch.float64).numpy() - ref).max()))
                 s_h = max(s_h, float(np.abs(ref).max()))
-            out[name] = {"workload": f"B={B}, H={H}, {nx}/{nu}, MLP {name} tanh, Discret, f64", "kernel_variant": eng.kernel_variant,
+            out[name] = {"workload": f"B={B}, H={H}, {nx}/{nu}, MLP {name.split('_')[0]} tanh, {'RK4' if S == 4 else 'Discret'}, {'f64' if f64 else 'f32'}",
+                         "kernel_variant": eng.kernel_variant,
                          "evaluation": {"us": t_e * 1e6, "kernel": eng.last_row_kernel, "gflop": row_flops / 1e9,
-                                        "frac_of_matrix_peak": row_flops / t_e / 1e12 / PEAK_F64_TFLOPS, "max_abs_err_vs_cpu": e_j},
+                                        "frac_of_matrix_peak": row_flops / t_e / 1e12 / peak, "max_abs_err_vs_cpu": e_j},
                          "hessian_callback": {"us": t_h * 1e6, "kernel": eng.last_hess_kernel, "gflop": hess_flops / 1e9,
-                                              "frac_of_matrix_peak": hess_flops / t_h / 1e12 / PEAK_F64_TFLOPS,
-                                              "flops_note": "(2 + nin) GEMM sweeps per row; the per-layer contraction is vector work and not counted",
+                                              "frac_of_matrix_peak": hess_flops / t_h / 1e12 / peak,
+                                              "flops_note": "(2 + nin) GEMM sweeps per row" + (" and RK4 stage + the stage-record rows launch" if S == 4 else "")
+                                                            + "; the per-layer contraction is vector work and not counted",
                                               "max_abs_err_vs_cpu": e_h, "max_abs_ref": s_h}}
             del eng
         return out
