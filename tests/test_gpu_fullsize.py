@@ -333,3 +333,42 @@ def test_compiled_shape_table_beyond_the_baseline_shape(dtype, hidden):
     assert (status == 0).mean() >= 0.9
     for i in np.nonzero(status == 0)[0][:16]:
         assert np.abs(prob.constraints(Zs[i], X0[i])).max() < (1e-6 if f64 else 2e-3)
+
+
+@pytest.mark.parametrize("case", [("discret", [256, 256], 2, 1, 20, 1024, torch.float64), ("rk4", [192, 160, 128], 6, 3, 30, 1024, torch.float32),
+                                  ("unity", [320], 3, 2, 12, 2600, torch.float64)])
+def test_layered_path_full_size(case):
+    """The layer-at-a-time GEMM path at the batch sizes its numbers are quoted on: rows and Lagrangian blocks against the
+    oracle on three slices of the batch, exact structural zeros, and -- the size-independent property -- a permutation of
+    the batch permutes the results bit for bit (rows of different problems share GEMM blocks, chunk boundaries and
+    feature-block partial sums; none of that may leak from one problem into another)."""
+    integ, hidden, nx, nu, H, B, dt = case
+    f64 = dt == torch.float64
+    DT = 0.1 if integ == "rk4" else 1.0
+    kind = {"discret": orc.DISCRET, "unity": orc.UNITY, "rk4": orc.RK4}[integ]
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=5)
+    prob = orc.Problem(net, H, nx, nu, kind, DT)
+    eng = _engine(net, H, nx, nu, B, "layered", integ, DT, dt)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=2)
+    lamh = np.random.default_rng(3).normal(size=(B, eng.m))
+    one = eng.to_device(np.ones(B))
+
+    def run(Zx, X0x, lx):
+        res = eng.eval_numpy(Zx, X0x, want=("g", "jac_dense", "jac_tiles"))
+        hv = eng.hess(eng.to_device(Zx), eng.to_device(X0x), eng.to_device(lx), one)["hvals"].cpu().numpy()
+        return res, hv
+    res, hv = run(Zh, X0h, lamh)
+    assert eng.last_row_kernel == "layered_gemm_kernel" and eng.last_hess_kernel.endswith("layered_gemm_kernel")
+    tol = dict(rtol=1e-10, atol=1e-10) if f64 else dict(rtol=2e-3, atol=2e-3)
+    for sl in _slices(B, 4 if integ == "rk4" else 8):
+        f, grad, g, J = prob.eval_batch(Zh[sl], X0h[sl])
+        np.testing.assert_allclose(res["g"][sl], g, **tol)
+        np.testing.assert_allclose(res["jac_dense"][sl], J, **tol)
+        assert np.array_equal(res["jac_dense"][sl] != 0, J != 0)
+        i = sl.start
+        ref = prob.hessian_values(Zh[i], X0h[i], lamh[i], 1.0)
+        np.testing.assert_allclose(hv[i], ref, rtol=0, atol=(1e-9 if f64 else 1e-2) * max(1.0, np.abs(ref).max()))
+    perm = np.random.default_rng(4).permutation(B)
+    res_p, hv_p = run(Zh[perm], X0h[perm], lamh[perm])
+    assert np.array_equal(res_p["g"], res["g"][perm]) and np.array_equal(res_p["jac_tiles"], res["jac_tiles"][perm])
+    assert np.array_equal(hv_p, hv[perm])
