@@ -71,6 +71,146 @@ def algorithmic_work(cfg, B, m, n):
     return dict(flops=flops * B, dense_bytes=dense_bytes * B, compact_bytes=compact_bytes * B)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# the line the driver reads
+# ------------------------------------------------------------------------------------------------------------------
+DRIVER_LINE_MAX = 4096         # bytes; tests/test_bench_line_cpu.py holds the line to it
+DETAILS_FILE = "bench_details.json"
+
+
+def _r(x, sig=6):
+    """a float at `sig` significant digits (the line is for a parser and a reader, not for bit-exact replay)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{sig}g}")
+
+
+def _pick(d, *keys):
+    return {k: _r(d[k]) for k in keys if isinstance(d, dict) and k in d}
+
+
+def _short_kernel(name):
+    """kernel name without the prose that follows it in the detailed record"""
+    name = str(name)
+    for stop in (":", " (", " writing"):
+        i = name.find(stop)
+        if i > 0:
+            name = name[:i]
+    return name[:64]
+
+
+def _compact_roofline(rf):
+    out = _pick(rf, "bound", "achieved", "peak", "unit", "frac", "traffic")
+    out["kernel"] = _short_kernel(rf.get("kernel", ""))
+    for k in ("kernel_us", "eval_us"):
+        if k in rf:
+            out["us"] = _r(rf[k])
+            break
+    return out
+
+
+def _leg(us, rf):
+    """one leg of the summary: microseconds, roofline fraction and which roofline"""
+    return {"us": _r(us, 5), "frac": _r(rf.get("frac"), 4), "bound": rf.get("bound")}
+
+
+def driver_line(full):
+    """The ONE stdout line of the driver's contract, from the detailed result `full`: the contract's keys, `roofline`,
+    `cpu_baseline` and one compact `summary` of the other legs (microseconds and roofline fraction each, no prose).
+    Everything else stays in DETAILS_FILE.  Strict JSON (no NaN / Infinity tokens), < DRIVER_LINE_MAX bytes."""
+    line = {k: _r(full[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in full}
+    cfg = full.get("config", {})
+    line["config"] = _pick(cfg, "workload", "batch_per_gpu", "H", "nx", "nu", "hidden", "integrator", "n", "m",
+                           "row_kernel", "parallelism", "clock")
+    for k in ("batch_evals_per_s", "jacobian_max_abs_err_vs_cpu", "value_from_cold_gpu"):
+        if full.get(k) is not None:
+            line[k] = _r(full[k])
+    if "roofline" in full:
+        line["roofline"] = _compact_roofline(full["roofline"])
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        line["cpu_baseline"] = _pick(cb, "value", "unit", "cores", "kind")
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:100]
+    summ = {}
+    for key, val in full.items():
+        if key.startswith("roofline_") and isinstance(val, dict) and "frac" in val:
+            summ[key[len("roofline_"):]] = _leg(val.get("kernel_us", val.get("eval_us")), val)
+    if "steady_state" in full:
+        summ["steady_state"] = {k: _r(v, 4) for k, v in full["steady_state"].items() if not isinstance(v, str)}
+    hc = full.get("hessian_callback")
+    if hc:
+        summ["hess_exact"] = _leg(hc["exact"]["us"], hc["exact"]["roofline"])
+        summ["hess_gn"] = _leg(hc["gauss_newton"]["us"], hc["gauss_newton"]["roofline"])
+    if "sparse_contract" in full:
+        summ["sparse"] = _leg(full["sparse_contract"]["us"], full["sparse_contract"]["roofline"])
+    bs = full.get("batched_solver")
+    if bs:
+        summ["solver"] = _pick(bs, "mpc_solved_per_s", "iterations", "converged_frac", "solve_ms")
+    ag = full.get("allgather_u0")
+    if ag:
+        summ["allgather_u0_us"] = _r(ag.get("latency_us"), 4)
+    for nm, e in (full.get("other_configs") or {}).items():
+        o = {"dense": _leg(e["ms_per_step"] * 1e3, e["roofline"]), "jac_err": _r(e["max_abs_err_vs_cpu"]["jac"], 3)}
+        if "ms_per_step_rotating_outputs" in e:
+            o["dense"]["us_rotating"] = _r(e["ms_per_step_rotating_outputs"] * 1e3, 5)
+        if "sparse_contract" in e:
+            o["sparse"] = _leg(e["sparse_contract"]["us"], e["sparse_contract"]["roofline"])
+        if "hessian_callback" in e:
+            o["hess_exact"] = _leg(e["hessian_callback"]["exact"]["us"], e["hessian_callback"]["exact"]["roofline"])
+        if "batched_solver" in e:
+            o["solver"] = _pick(e["batched_solver"], "mpc_solved_per_s", "iterations", "converged_frac")
+        summ[nm] = o
+    for nm, e in (full.get("layered_path") or {}).items():
+        summ["layered_" + nm] = {"eval_us": _r(e["evaluation"]["us"], 5), "eval_frac": _r(e["evaluation"]["frac_of_matrix_peak"], 4),
+                                 "hess_us": _r(e["hessian_callback"]["us"], 5),
+                                 "hess_frac": _r(e["hessian_callback"]["frac_of_matrix_peak"], 4)}
+    for nm, e in (full.get("narrow_networks") or {}).items():
+        summ["narrow_" + nm] = {"eval_us": _r(e["evaluation"]["us"], 5), "eval_frac": _r(e["evaluation"]["frac_of_matrix_peak"], 4),
+                                "variant": e.get("kernel_variant")}
+    if "shard_c4" in full:
+        summ["shard_c4_b512"] = _pick(full["shard_c4"], "us", "frac", "problem_evals_per_s")
+    if summ:
+        line["summary"] = summ
+    line["details"] = DETAILS_FILE
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= DRIVER_LINE_MAX:          # never hand the driver an oversized line: drop the summary, keep the contract
+        line["summary"] = {"dropped": "summary exceeded the line budget; see " + DETAILS_FILE}
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    return text
+
+
+def _sanitize(x):
+    """NaN / Infinity -> None, so that the side file is strict JSON, too"""
+    if isinstance(x, float):
+        return x if (x == x and x not in (float("inf"), float("-inf"))) else None
+    if isinstance(x, dict):
+        return {str(k): _sanitize(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sanitize(v) for v in x]
+    return x
+
+
+def write_details(full, also_stderr=True):
+    """the detailed record: DETAILS_FILE next to bench.py's caller (and under gpurun_out/ when that directory exists, so
+    that a gpurun call brings it back), echoed on stderr"""
+    text = json.dumps(_sanitize(full), allow_nan=False, indent=1)
+    paths = [os.path.join(os.getcwd(), DETAILS_FILE)]
+    if os.path.isdir(os.path.join(REPO, "gpurun_out")):
+        paths.append(os.path.join(REPO, "gpurun_out", DETAILS_FILE))
+    for pth in paths:
+        try:
+            with open(pth, "w") as fh:
+                fh.write(text + "\n")
+        except OSError:
+            pass
+    if also_stderr:
+        sys.stderr.write("bench.py details: " + json.dumps(_sanitize(full), allow_nan=False) + "\n")
+        sys.stderr.flush()
+
+
 def usable_cpus():
     """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box hands a one-GPU job
     a share of the host, and more OpenMP threads than that share only get throttled)."""
@@ -605,6 +745,16 @@ class Rank:
         t = self.timed_events(fn, reps, prime_ms=0)
         return self.max_over_ranks(t) * 1e6
 
+    def emit(self, full):
+        """rank 0: detailed record to the side file and stderr, then the driver's line as the LAST stdout line"""
+        if self.rank != 0:
+            return
+        write_details(full)
+        sys.stdout.flush()
+        os.dup2(self.saved_stdout, 1)
+        print(driver_line(full), flush=True)
+        os.dup2(2, 1)
+
     # -------------------------------------------------------------------------------------------------------------
     def main(self):
         np, torch = self.np, self.torch
@@ -615,21 +765,13 @@ class Rank:
             res = self.run_config(args.config, 5, 2, headline=False, kernel=args.kernel)
             out = {"config": {"workload": res["cfg"]["label"], "batch_per_gpu": res["B"]},
                    "hessian_callback": self.hessian_leg(res)}
-            if self.rank == 0:
-                sys.stdout.flush()
-                os.dup2(self.saved_stdout, 1)
-                print(json.dumps(out), flush=True)
-                os.dup2(2, 1)
+            self.emit(out)
             return
         if args.only_sparse:
             # profiling mode: the sparse-contract leg of one configuration alone (rocprofv3 kernel trace of ONE launch shape)
             res = self.run_config(args.config, 5, 2, headline=False, kernel=args.kernel)
             out = {"config": {"workload": res["cfg"]["label"], "batch_per_gpu": res["B"]}, "sparse_contract": self.sparse_leg(res)}
-            if self.rank == 0:
-                sys.stdout.flush()
-                os.dup2(self.saved_stdout, 1)
-                print(json.dumps(out), flush=True)
-                os.dup2(2, 1)
+            self.emit(out)
             return
         res = self.run_config(args.config, args.steps, args.warmup, headline=True, kernel=args.kernel)
         cfg, B, eng, wall = res["cfg"], res["B"], res["eng"], res["wall"]
@@ -737,11 +879,7 @@ class Rank:
                 out["layered_path"] = self.layered_leg()
             if self.world == 1 and not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(cfg)
-        if self.rank == 0:
-            sys.stdout.flush()
-            os.dup2(self.saved_stdout, 1)
-            print(json.dumps(out), flush=True)
-            os.dup2(2, 1)
+        self.emit(out)
         if self.dist is not None:
             self.barrier()
             self.dist.destroy_process_group()

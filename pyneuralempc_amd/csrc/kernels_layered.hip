@@ -366,7 +366,10 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : NEMPC_LG_WPE) v
 #pragma unroll
                 for (int rm = 0; rm < RM; ++rm) P[rm] = Ops::mma(wf, gd[rm][r], P[rm]);
             }
-            if (dt > 0) __syncthreads();
+            // unconditional: the partial tiles go into the operand buffers, which the slower waves of the workgroup may still
+            // be reading -- an odd last chunk (`if (ch < nchunks) mma_chunk(0)`: every K <= 16 product and every width with an
+            // odd number of 16-deep chunks) has no barrier behind it; dt > 0: the previous pass's reads of the partial tiles
+            __syncthreads();
 #pragma unroll
             for (int rm = 0; rm < RM; ++rm)
 #pragma unroll

@@ -816,6 +816,50 @@ def test_layered_path_at_the_edges_of_its_shape_range(hidden, nx, nu, integ, H, 
         np.testing.assert_allclose(hv[i], ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("hidden,acts,nx,nu,integ", [
+    ([48], "tanh", 2, 1, "discret"),                    # K = nin <= 16: ONE chunk in every product
+    ([80, 48], "tanh", 2, 1, "discret"),                # 5 and 3 chunks
+    ([48, 80, 48], ["tanh", "sigmoid", "tanh", "linear"], 3, 2, "rk4"),
+    ([144, 176], ["swish", "gelu", "linear"], 2, 1, "unity"),   # 9 and 11 chunks; pre-activation derivatives
+])
+def test_layered_products_with_an_odd_number_of_chunks_on_a_full_chip(hidden, acts, nx, nu, integ):
+    """A product whose K has an odd number of 16-deep chunks ends on `mma_chunk(0)` with no barrier behind it; the fused
+    contractions then write their per-wave partial tiles into the operand buffers (round-4 advisor: a wave that finishes
+    early overwrote operands slower waves were still reading).  Enough rows that every SIMD holds several waves, every
+    row of the batch compared -- forward contraction, reverse contraction (J) and the Hessian sweeps -- with the generic
+    kernel where it exists and with the oracle on a slice, and twice bit for bit."""
+    from pyneuralempc_amd import CallbackEngine
+    H, B = 20, 1536
+    DT = 0.1 if integ == "rk4" else 1.0
+    kind = {"discret": orc.DISCRET, "unity": orc.UNITY, "rk4": orc.RK4}[integ]
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=13, activations=acts)
+    prob = orc.Problem(net, H, nx, nu, kind, DT)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=torch.float64, device="cuda:0", max_batch=B,
+                         activations=net.act, kernel="layered")
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=5)
+    lam = np.random.default_rng(3).normal(size=(B, eng.m))
+    dev = [eng.to_device(a) for a in (Zh, X0h, lam, np.ones(B))]
+    r1 = eng.eval_numpy(Zh, X0h, want=("g", "jac_tiles"))
+    h1 = eng.hess(*dev)["hvals"].cpu().numpy()
+    for _ in range(3):
+        r2 = eng.eval_numpy(Zh, X0h, want=("g", "jac_tiles"))
+        assert np.array_equal(r1["g"], r2["g"]) and np.array_equal(r1["jac_tiles"], r2["jac_tiles"])
+        assert np.array_equal(h1, eng.hess(*dev)["hvals"].cpu().numpy())
+    if not any(str(a).split(":")[0] in orc.ZBASED for a in net.act):
+        ev = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=torch.float64, device="cuda:0", max_batch=B,
+                            activations=net.act, kernel="valu")
+        rv = ev.eval_numpy(Zh, X0h, want=("g", "jac_tiles"))
+        np.testing.assert_allclose(r1["g"], rv["g"], rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(r1["jac_tiles"], rv["jac_tiles"], rtol=1e-11, atol=1e-11)
+        hg = ev.hess(*[ev.to_device(a) for a in (Zh, X0h, lam, np.ones(B))])["hvals"].cpu().numpy()
+        np.testing.assert_allclose(h1, hg, rtol=0, atol=1e-10 * max(1.0, np.abs(hg).max()))
+    for s0 in (0, B // 2, B - 2):
+        f, grad, g, J = prob.eval_batch(Zh[s0:s0 + 2], X0h[s0:s0 + 2])
+        np.testing.assert_allclose(r1["g"][s0:s0 + 2], g, rtol=1e-11, atol=1e-11)
+        ref = prob.hessian_values(Zh[s0], X0h[s0], lam[s0], 1.0)
+        np.testing.assert_allclose(h1[s0], ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+
+
 def test_layered_path_chunks_large_batches():
     """More rows than one workspace chunk holds (NEMPC_LAYERED_CHUNK_ROWS shrinks the chunk for the test): the chunk loop,
     with a last chunk that is not a whole GEMM block, gives the rows of the one-chunk evaluation bit for bit."""
