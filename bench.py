@@ -877,6 +877,8 @@ class Rank:
                 out["other_configs"] = others
             if self.world == 1 and args.config == "c2" and not args.batch and not args.no_other_configs:
                 out["layered_path"] = self.layered_leg()
+                out["steady_state"] = self.steady_state_leg(cfg)
+                out["shard_c4"] = self.shard_c4_leg()
             if self.world == 1 and not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(cfg)
         self.emit(out)
@@ -938,6 +940,34 @@ class Rank:
                                               "max_abs_err_vs_cpu": e_h, "max_abs_ref": s_h}}
             del eng
         return out
+
+    def steady_state_leg(self, cfg, B=8192):
+        """The headline kernel away from the launch-latency share: the same one-launch evaluation at B = 8192 (8 x the
+        tiles, the ~4 us of dispatch / first-round-trip / tail are then 1/8 of the share they are at B = 1024)."""
+        from oracle import nempc_oracle as orc
+        eng = self.make_engine(cfg, B)
+        Zh, X0h = orc.synthetic_inputs(B, cfg["H"], cfg["nx"], cfg["nu"], seed=1)
+        step, _ = eng.bind(eng.to_device(Zh), eng.to_device(X0h), ("f", "grad", "g", "jac_dense"))
+        t = self.timed_events(step, 100)
+        work = algorithmic_work(cfg, B, eng.m, eng.n)
+        peak = PEAK_F64_TFLOPS if cfg["dtype"] == "f64" else PEAK_F32_TFLOPS
+        return {"batch": B, "us": t * 1e6, "frac": work["flops"] / t / 1e12 / peak,
+                "hbm_frac_dense_contract": work["dense_bytes"] / t / 1e9 / PEAK_HBM_GBS, "kernel": str(eng.last_row_kernel)}
+
+    def shard_c4_leg(self):
+        """configs[3]'s per-rank shard on ONE GPU (B = 4096 / 8 = 512 problems of the configs[2] problem): the time a rank of
+        the 8-GPU job spends per evaluation, on record while no 8-GPU node has run the job."""
+        from oracle import nempc_oracle as orc
+        cfg = dict(CONFIGS["c4"], batch=512)
+        B = 512
+        eng = self.make_engine(cfg, B)
+        Zh, X0h = orc.synthetic_inputs(B, cfg["H"], cfg["nx"], cfg["nu"], seed=1)
+        step, _ = eng.bind(eng.to_device(Zh), eng.to_device(X0h), ("f", "grad", "g", "jac_dense"))
+        t = self.timed_events(step, 50)
+        work = algorithmic_work(cfg, B, eng.m, eng.n)
+        return {"batch_per_rank": B, "us": t * 1e6, "frac": work["flops"] / t / 1e12 / PEAK_F32_TFLOPS,
+                "problem_evals_per_s": B / t, "kernel": str(eng.last_row_kernel),
+                "note": "one rank's share of configs[3] (global batch 4096 over 8 GPUs), dense contract, HIP events"}
 
     def two_stream_leg(self, res):
         torch = self.torch

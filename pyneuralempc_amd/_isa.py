@@ -16,9 +16,13 @@ or a live-range-split copy at the top of the block that JOINS a divergent region
     v_accvgpr_read_b32 v18, a163             ; reload, all lanes: whatever the register file held (machine dependent)
 
 `v_readlane / v_writelane / v_readfirstlane` and scalar instructions do not depend on exec and are what the compiler means to
-have there (scalar-register spill reloads).  Moving the stray vector instructions directly behind the restore is the
-placement the allocator should have chosen: `s_or_b64` reads and writes scalar registers only, so no operand of the moved
-instruction changes, and nothing stands between the two positions.
+have there (scalar-register spill reloads).  Moving the stray spill stores directly behind the restore is the placement the
+allocator should have chosen.  `repair` moves ONLY spill stores (`v_accvgpr_write_b32 aN, vM`, `scratch_store_* ... Folded
+Spill`) and only when what they hop over is independent of them (`_check_movable`); every other finding stops the build
+(`IsaRepairError`).  The same placement is looked for at the other two places lanes come back: the else entry of an
+if / else (`s_or_saveexec_b64`) and the restore behind a divergent loop, reached by falling through its `s_cbranch_execnz`
+with exec == 0.  `tools/isa_defect_repro.hip` is a standalone reproducer of the compiler's placement, compiled and scanned by
+`tests/test_build_isa_cpu.py`: after a toolchain bump that test says whether the defect is still there.
 
 A second check, same stage (`scan_store_hazard`): a store of more than 64 bits written as inline asm whose data registers a
 vector instruction overwrites within two wait states.  The compiler pads its own wide stores (gfx9 "store data hazard") but
@@ -34,13 +38,26 @@ import re
 LABEL = re.compile(r"^([.\w$]+):")
 KERNEL = re.compile(r"^(_Z\w+):")
 SKIP = re.compile(r"^\s*s_cbranch_execz\s+([.\w$]+)")
-EXEC_RESTORE = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,\s*s\[")
-# what may stand between a join label and the restore: scalar instructions and the lane-addressed moves (exec-independent)
+LOOP_BACK = re.compile(r"^\s*s_cbranch_execnz\b")
+# the instructions that give lanes back: the plain restore at a join, and the else entry of an if / else (`s_or_saveexec_b64`
+# at the top of the flow block: exec |= the lanes that skipped the `then` side)
+EXEC_RESTORE = re.compile(r"^\s*(s_or_b64\s+exec,\s*exec,\s*s\[|s_or_saveexec_b64\b)")
+# what may stand in front of a restore: scalar instructions and the lane-addressed moves (exec-independent)
 SAFE = re.compile(r"^\s*(s_\w+|v_readlane_b32|v_writelane_b32|v_readfirstlane_b32)\b")
 BRANCH = re.compile(r"^\s*s_(cbranch\w*|branch|endpgm|setpc_b64)\b")
 # anything else that writes exec opens a region of its own (an `if` without a skip branch: saveexec, body, restore in one
 # block): what stands between it and its restore is the region's body, not a misplaced instruction
 EXEC_WRITE = re.compile(r"^\s*(s_\w+saveexec_b64\b|s_\w+\s+exec\s*,|v_cmpx_)")
+# the only instructions `repair` moves: the register allocator's spill stores.  Anything else in that position is not this
+# defect and fails the build (a lane-masked copy a later compiler puts there on purpose must not be moved silently)
+SPILL_AGPR = re.compile(r"^\s*v_accvgpr_write_b32\s+a(\d+),\s*v(\d+)\s*(;.*)?$")
+SPILL_SCRATCH = re.compile(r"^\s*scratch_store_\w+\s+.*;\s*\d+-byte Folded Spill\s*$")
+_SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+_VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+class IsaRepairError(RuntimeError):
+    """the text holds the defect in a form `repair` does not move: the build stops"""
 
 
 def _is_code(text):
@@ -48,13 +65,27 @@ def _is_code(text):
     return bool(s) and not s.startswith(";") and not s.startswith(".")
 
 
+def _regs(rx, text):
+    """register numbers of one file (s or v) an instruction mentions, ranges expanded; the comment is not an operand"""
+    out = set()
+    for m in rx.finditer(text.split(";")[0]):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
 def _walk(lines):
-    """Yields (kernel, restore_index, [indices of vector instructions between the join label and the restore])."""
-    # join labels: where the lanes that skipped a region (or left a divergent loop) arrive -- the targets of
-    # `s_cbranch_execz`.  A body laid out of line (entered by `s_cbranch_execnz`) legitimately ends with its own restore.
+    """Yields (kernel, restore_index, [indices of vector instructions that run in front of the restore with the lanes of
+    the region that ends there -- or with none].  Three placements:
+      * a join label (target of `s_cbranch_execz`) ... `s_or_b64 exec, exec, s[..]`          the skipped `if`
+      * a join label ... `s_or_saveexec_b64`                                                 the else entry of an if / else
+      * the fall-through of a loop's `s_cbranch_execnz` ... either restore                   a divergent loop's exit: exec == 0
+    A label in between does not end the stretch (the lanes that arrived at the join flow through it, too)."""
     joins = set(m.group(1) for m in (SKIP.match(t) for t in lines) if m)
     kernel = None
-    block = None            # indices since the last join label; None = not directly behind one
+    block = None            # indices since the last join label / loop exit; None = exec is not known to be narrowed here
     for i, text in enumerate(lines):
         m = KERNEL.match(text)
         if m:
@@ -62,7 +93,8 @@ def _walk(lines):
             continue
         m = LABEL.match(text)
         if m:
-            block = [] if m.group(1) in joins else None
+            if m.group(1) in joins:
+                block = []
             continue
         if not _is_code(text):
             continue
@@ -71,6 +103,9 @@ def _walk(lines):
             if bad:
                 yield kernel, i, bad
             block = None
+            continue
+        if LOOP_BACK.match(text):
+            block = []                      # not taken: every lane has left the loop, exec == 0 until the restore
             continue
         if BRANCH.match(text) or EXEC_WRITE.match(text):
             block = None
@@ -86,11 +121,42 @@ def scan(text):
             for k, r, bad in _walk(lines)]
 
 
+def _check_movable(lines, kernel, r, bad):
+    """The moved instructions hop over whatever stays between the first of them and the restore (scalar instructions,
+    lane-addressed moves).  That is only the same program when (i) every moved instruction is a spill store, (ii) no wait
+    count stands in between (a moved memory instruction would leave its cover), (iii) nothing in between writes or reads a
+    register the moved instructions use or define: a `v_writelane_b32 vN` in front of the moved spill of vN, an `s_mov` of
+    a scratch store's base."""
+    where = f"{kernel}, line {r + 1}"
+    for j in bad:
+        t = lines[j]
+        if not (SPILL_AGPR.match(t) or SPILL_SCRATCH.match(t)):
+            raise IsaRepairError(f"{where}: `{t.strip()}` stands in front of an exec restore and is not a register-allocator "
+                                 "spill store (v_accvgpr_write_b32 aN, vM / scratch_store_* ; Folded Spill): not moved")
+    mv_v = set().union(*(_regs(_VREG, lines[j]) for j in bad))
+    mv_s = set().union(*(_regs(_SREG, lines[j]) for j in bad))
+    has_mem = any(SPILL_SCRATCH.match(lines[j]) for j in bad)
+    badset = set(bad)
+    for j in range(bad[0] + 1, r):
+        t = lines[j]
+        if j in badset or not _is_code(t):
+            continue
+        name = t.split()[0]
+        if name == "s_waitcnt" and has_mem:
+            raise IsaRepairError(f"{where}: a spill store to scratch would be moved across `{t.strip()}`")
+        if _regs(_VREG, t) & mv_v or _regs(_SREG, t) & mv_s:
+            raise IsaRepairError(f"{where}: `{t.strip()}` between the spill store and the restore touches a register the "
+                                 "moved instruction uses")
+
+
 def repair(text):
-    """Moves every stray vector instruction directly behind its restore.  -> (new text, findings of the input)."""
+    """Moves every stray spill store directly behind its restore.  -> (new text, findings of the input).  Raises
+    IsaRepairError on a finding that is not a spill store or that cannot be moved without changing the program."""
     lines = text.split("\n")
     found = list(_walk(lines))
     findings = [{"kernel": k, "line": r + 1, "instructions": [(j + 1, lines[j].strip()) for j in bad]} for k, r, bad in found]
+    for k, r, bad in found:
+        _check_movable(lines, k, r, bad)
     # back to front, so that earlier indices stay valid
     for _, r, bad in reversed(found):
         moved = [lines[j] for j in bad]

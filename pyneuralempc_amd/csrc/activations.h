@@ -173,6 +173,10 @@ __device__ __forceinline__ T act_r2(int code, T a, T par) {
 // swish, gelu, softsign, mish, exponential, relu6: value and derivatives from the PRE-activation z (the layered path's GEMM
 // epilogue has z = acc + bias in registers).  swish: s = z g, s' = g (1 + z (1 - g)), s'' = g (1 - g) (2 + z (1 - 2 g)) with g = sigmoid(z);
 // gelu: s = z Phi, s' = Phi + z phi, s'' = phi (2 - z^2) with Phi / phi the standard normal cdf / pdf.
+// piecewise linear (s'' == 0 away from the kinks): no second-order constraint violation along such a network
+__device__ __host__ __forceinline__ bool act_is_piecewise_linear(int code) {
+    return code == NEMPC_ACT_RELU || code == NEMPC_ACT_LEAKY_RELU || code == NEMPC_ACT_RELU6;
+}
 __device__ __host__ __forceinline__ bool act_zbased(int code) { return code >= NEMPC_ACT_FIRST_ZBASED && code < NEMPC_ACT_COUNT; }
 __device__ __forceinline__ double nempc_erf(double x) { return erf(x); }
 __device__ __forceinline__ float nempc_erf(float x) { return erff(x); }

@@ -1314,6 +1314,27 @@ int layered_hess_prepare(Handle& h) {
     return NEMPC_OK;
 }
 
+static bool layered_hess_usable(const Handle& h);
+
+// nempc_create / nempc_reserve: both chunk workspaces and the first-layer pair table of the Hessian, so that no callback
+// allocates (the `*_prepare` calls in the launchers below then find everything in place and return at once)
+int layered_reserve(Handle& h) {
+    int rc = layered_prepare(h);
+    if (rc) return rc;
+    if (layered_hess_usable(h)) {
+        if ((rc = layered_hess_prepare(h))) return rc;
+        if (!h.d_layered_pairs) {
+            hipError_t e = hipMalloc(&h.d_layered_pairs, (size_t)h.maxw * 32 * sizeof(double));
+            if (e != hipSuccess) {
+                h.d_layered_pairs = nullptr;
+                set_error(std::string("hipMalloc (layered pair table): ") + hipGetErrorString(e));
+                return NEMPC_ENOMEM;
+            }
+        }
+    }
+    return NEMPC_OK;
+}
+
 // Lagrangian blocks on the GEMM path: Discret / Unity directly, RK4 through the stage pipeline of kernels_rk4hess.hip.
 // NEMPC_EUNSUPPORTED: a nonlinear output layer behind a single hidden layer, NEMPC_LAYERED_HESS=0 (A/B knob).
 static bool layered_hess_usable(const Handle& h) {

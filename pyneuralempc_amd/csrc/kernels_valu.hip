@@ -488,6 +488,22 @@ size_t valu_workspace_elems(const Handle& h) {
     return (size_t)ws_offsets(h).total * (size_t)h.cfg.max_batch * (size_t)h.cfg.H;
 }
 
+// The generic kernels' scratch (nhid * maxw * (nin + 1) elements per row: GBs for wide networks).  Handles on the generic
+// variant get it in nempc_create / nempc_reserve; a handle on the layered path never touches it except in the one
+// fallback below (Lagrangian blocks of a single hidden layer under a non-linear output layer, NEMPC_LAYERED_HESS=0) and
+// allocates it there, on first use.
+int ensure_valu_ws(Handle& h) {
+    if (h.d_valu_ws) return NEMPC_OK;
+    h.valu_ws_elems = valu_workspace_elems(h);
+    hipError_t e = hipMalloc(&h.d_valu_ws, h.valu_ws_elems * h.esz ? h.valu_ws_elems * h.esz : 16);
+    if (e != hipSuccess) {
+        h.d_valu_ws = nullptr;
+        set_error(std::string("hipMalloc (generic kernel workspace): ") + hipGetErrorString(e));
+        return NEMPC_ENOMEM;
+    }
+    return NEMPC_OK;
+}
+
 int launch_rows_valu(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s) {
     // networks outside the register-resident kernels' shapes: the rows come from the layer-at-a-time GEMM pipeline
     if (h.layered) return launch_rows_layered(h, B, Z, X0, g, tiles, s);
@@ -522,6 +538,7 @@ int launch_rowhess_valu(Handle& h, int B, const void* Z, const void* X0, const v
                 return NEMPC_EUNSUPPORTED;
             }
     }
+    if (int rc = ensure_valu_ws(h)) return rc;
     const size_t rows = (size_t)B * h.cfg.H;
     const size_t Rcap = (size_t)h.cfg.max_batch * h.cfg.H;
     const dim3 block(256), grid((unsigned)((rows + 255) / 256));

@@ -424,8 +424,13 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
     const size_t Bm = (size_t)cfg->max_batch;
     do {
         if ((rc = dev_alloc(&h->d_tiles_ws, Bm * cfg->H * cfg->nx * h->nin * h->esz))) break;
-        h->valu_ws_elems = valu_workspace_elems(*h);
-        if ((rc = dev_alloc(&h->d_valu_ws, h->valu_ws_elems * h->esz))) break;
+        // workspaces are sized and allocated HERE (and in nempc_reserve), not inside the first callback: an allocation is a
+        // synchronising call, is not stream-capture safe, and an out-of-memory belongs to create, not to the middle of a solve
+        if (h->layered) {
+            if ((rc = layered_reserve(*h))) break;
+        } else {
+            if ((rc = ensure_valu_ws(*h))) break;
+        }
         if ((rc = dev_alloc(&h->d_hess_ws, Bm * cfg->H * h->nin * h->nin * h->esz))) break;
         if ((rc = rebuild_structure(*h))) break;
         ObjHost o;
@@ -473,8 +478,11 @@ int nempc_reserve(nempc_handle hh, int32_t max_batch) {
     int rc = NEMPC_OK;
     do {
         if ((rc = dev_alloc(&h.d_tiles_ws, Bm * h.cfg.H * h.cfg.nx * h.nin * h.esz))) break;
-        h.valu_ws_elems = valu_workspace_elems(h);
-        if ((rc = dev_alloc(&h.d_valu_ws, h.valu_ws_elems * h.esz))) break;
+        if (h.layered) {
+            if ((rc = layered_reserve(h))) break;
+        } else {
+            if ((rc = ensure_valu_ws(h))) break;
+        }
         if ((rc = dev_alloc(&h.d_hess_ws, Bm * h.cfg.H * h.nin * h.nin * h.esz))) break;
         if ((rc = dev_alloc(&h.d_g_ws, Bm * h.m * h.esz))) break;
     } while (0);

@@ -200,6 +200,8 @@ hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
 
 // ---- kernels_valu.hip : generic thread-per-row kernel
 size_t valu_workspace_elems(const Handle& h);
+int ensure_valu_ws(Handle& h);          // generic kernels' scratch, allocated on first need (kernels_valu.hip)
+int layered_reserve(Handle& h);         // layered path: both chunk workspaces + pair table (kernels_layered.hip)
 int launch_rows_valu(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s);
 int launch_rowhess_valu(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
                         hipStream_t s);

@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "nempc_internal.h"
+#include "activations.h"
 #include "kernels_obj_impl.h"
 
 #ifndef NEMPC_REG_FLOOR
@@ -2586,11 +2587,11 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         // 1020 (2), 766 / 906 / 974 / 1019 (3), 775 / 924 / 985 / 1021 (4); C2 dims 965 / 979 / 997 / 1015 -> 968 / 994 / 1011 / 1019
         static const int nm_env = [] { const char* e = getenv("NEMPC_SOLVER_NONMONO"); return e ? atoi(e) : 4; }();
         a.nonmono = nm_env < 0 ? 0 : (nm_env > 4 ? 4 : nm_env);
-        // Piecewise-linear networks (relu, leaky_relu) have no second-order constraint violation for the relaxed test to
-        // forgive; what it does there is let an iterate chatter across a kink without its step ever shrinking.  They keep
-        // the monotone test.
+        // Piecewise-linear networks (relu, leaky_relu, relu6) have no second-order constraint violation for the relaxed test
+        // to forgive; what it does there is let an iterate chatter across a kink without its step ever shrinking.  A
+        // network with such a layer keeps the monotone test.
         for (int l = 0; l < h.nl; ++l)
-            if (h.act[l] == NEMPC_ACT_RELU || h.act[l] == NEMPC_ACT_LEAKY_RELU) a.nonmono = 0;
+            if (act_is_piecewise_linear(h.act[l])) a.nonmono = 0;
     }
     {
         static const double relax_env = [] { const char* e = getenv("NEMPC_SOLVER_REG_RELAX"); return e ? atof(e) : 0.1; }();   // A/B knob

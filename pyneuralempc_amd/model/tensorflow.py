@@ -118,6 +118,14 @@ def extract_dense_stack(keras_model):
         params = layer.get_weights()
         if len(params) == 0:
             if type(layer).__name__ in _IDENTITY_LAYERS:
+                if type(layer).__name__ == "Flatten":
+                    # the identity only on an input that is one vector per sample already
+                    shp = getattr(layer, "input_shape", None)
+                    if shp is None and getattr(layer, "input", None) is not None:
+                        shp = getattr(layer.input, "shape", None)
+                    if shp is not None and len(tuple(shp)) != 2:
+                        raise NotImplementedError(f"layer {i}: Flatten of a {len(tuple(shp)) - 1}-D sample is not the identity; "
+                                                  "unsupported on the device path")
                 continue
             name = _standalone_activation(layer, i)
             if name == "linear":
@@ -133,7 +141,12 @@ def extract_dense_stack(keras_model):
                 raise NotImplementedError(f"layer {i}: {e}")
             activations[-1] = name
             continue
-        if len(params) == 1 and np.ndim(params[0]) == 2:          # Dense(use_bias=False)
+        if len(params) == 1 and np.ndim(params[0]) == 2:
+            # Dense(use_bias=False) -- and nothing else: an Embedding or a custom layer also holds ONE matrix, and no layer
+            # may be evaluated as a different function
+            if type(layer).__name__ != "Dense" or getattr(layer, "use_bias", True) is not False:
+                raise NotImplementedError(f"layer {i}: '{type(layer).__name__}' holds a single matrix but is not Dense(use_bias=False); "
+                                          "only Dense layers (kernel[, bias]) are supported on the device path")
             params = [params[0], np.zeros(np.shape(params[0])[1])]
         if len(params) != 2 or np.ndim(params[0]) != 2 or np.ndim(params[1]) != 1:
             raise NotImplementedError("Only Dense layers (kernel, bias) are supported on the device path")

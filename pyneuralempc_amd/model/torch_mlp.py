@@ -17,6 +17,8 @@ from .tensorflow import extract_dense_stack
 
 # ---- duck-typed "Keras layers" for extract_dense_stack: the same walk, folding rules and refusals serve both adapters ----
 class Dense:
+    use_bias = True
+
     def __init__(self, W, b):
         self._p, self.activation = [W, b], "linear"
 

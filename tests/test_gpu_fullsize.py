@@ -29,7 +29,7 @@ def _engine(net, H, nx, nu, B, kernel="auto", integrator="discret", DT=1.0, dtyp
     return eng
 
 
-@pytest.mark.parametrize("B", [1024, 1000, 37, 1, 2600])
+@pytest.mark.parametrize("B", [1024, 256, 1000, 37, 1, 2600])       # 256: configs[1] to the letter
 def test_c2_fused_evaluation_full_size(B):
     """configs[1] dims: the one-launch evaluation (rows + dense Jacobian + objective, rows_coopfx_kernel) against the
     oracle and, bit for bit, against the unfused launch sequence of the same handle."""

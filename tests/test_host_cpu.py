@@ -313,11 +313,30 @@ def test_keras_adapter_validation_without_device():
         extract_dense_stack(Fake([Layer(np.ones((3, 8)), np.zeros(8), linear), capped,
                                   Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
 
-    class NoBias:
-        activation = "tanh"
+    # Dense(use_bias=False) -- by its class name and its use_bias flag, nothing else that happens to hold one matrix
+    class Dense:
+        activation, use_bias = "tanh", False
         def get_weights(self): return [np.ones((3, 8))]
-    W, b, acts = extract_dense_stack(Fake([NoBias(), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
+    W, b, acts = extract_dense_stack(Fake([Dense(), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
     assert np.array_equal(b[0], np.zeros(8)) and acts == ["tanh", "linear"]
+
+    class Embedding(Dense):
+        pass
+    with pytest.raises(NotImplementedError, match="Embedding"):
+        extract_dense_stack(Fake([Embedding(), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
+    biased = Dense()
+    biased.use_bias = True
+    with pytest.raises(NotImplementedError, match="single matrix"):
+        extract_dense_stack(Fake([biased, Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2))
+
+    # Flatten is the identity on one vector per sample only
+    class Flatten(Dropout):
+        input_shape = (None, 3)
+    assert extract_dense_stack(Fake([Flatten(), Layer(np.ones((3, 2)), np.zeros(2), linear)], 3, 2))[2] == ["linear"]
+    img = Flatten()
+    img.input_shape = (None, 3, 4)
+    with pytest.raises(NotImplementedError, match="Flatten"):
+        extract_dense_stack(Fake([img, Layer(np.ones((12, 2)), np.zeros(2), linear)], 12, 2))
 
     def hard_sigmoid(x): return x
     bad = Fake([Layer(np.ones((3, 8)), np.zeros(8), hard_sigmoid), Layer(np.ones((8, 2)), np.zeros(2), linear)], 3, 2)
