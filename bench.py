@@ -120,8 +120,9 @@ def driver_line(full):
     """The ONE stdout line of the driver's contract, from the detailed result `full`: the contract's keys, `roofline`,
     `cpu_baseline` and one compact `summary` of the other legs (microseconds and roofline fraction each, no prose).
     Everything else stays in DETAILS_FILE.  Strict JSON (no NaN / Infinity tokens), < DRIVER_LINE_MAX bytes."""
-    line = {k: _r(full[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
-                                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in full}
+    # (the contract's own numbers at full precision: value == n_gpus * B * steps / (ms_per_step * steps) has to hold to the bit)
+    line = {k: _sanitize(full[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                             "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in full}
     cfg = full.get("config", {})
     line["config"] = _pick(cfg, "workload", "batch_per_gpu", "H", "nx", "nu", "hidden", "integrator", "n", "m",
                            "row_kernel", "parallelism", "clock")

@@ -151,12 +151,13 @@ __device__ __forceinline__ void coop_zero_rows(T* o_jac, unsigned r0, int nrows,
         const int full = nv / NTHREADS;
         const int voff = tid * 16;
         for (int k = 0; k < full; ++k) {
-            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
             base += NTHREADS * 16;
         }
         if (tid < nv - full * NTHREADS)
-            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
-        asm volatile("s_nop 1" ::: "memory");      // store-data hazard: `zero`'s registers may be re-used right behind the run
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
+        // (store-data hazard: `zero`'s registers may be re-used right behind a store -- the wait states ride in the store's own
+        // asm statement: a separate `s_nop` statement does not keep the scheduler from placing an instruction in between)
     };
     if (!box) {
         run(fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) + (size_t)r0 * nx * row_bytes), (int)((size_t)drv * row_bytes / 16));
@@ -375,7 +376,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
     const T DT = cx.DT;
 
     int* RI = cx.RI;
-    COOP_STAMP(3);
+    COOP_STAMP(48);
 
     for (int stage = 0; stage < cx.nstages; ++stage) {
         const T cdt = (stage == 0) ? T(0) : ((stage == 3) ? DT : T(0.5) * DT);
@@ -412,7 +413,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[0][j][r] = A::f(a[0][j][r]);
         }
-        COOP_STAMP(4);
+        COOP_STAMP(12 * stage + 4);
         // ---- hidden-to-hidden layers.  The exchange buffer has two halves used alternately: a wave may
         // publish exchange e+1 while a slower wave still reads exchange e; the barrier of e+1 then fences
         // the readers of e before anyone writes e+2 into the same half.
@@ -443,7 +444,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[l][j][r] = A::f(a[l][j][r]);
         }
-        COOP_STAMP(5);
+        COOP_STAMP(12 * stage + 5);
         // ---- network output: K-split partial over this wave's block
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -461,7 +462,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[l][j][r] = A::d1(a[l][j][r]);
 
-        COOP_STAMP(6);
+        COOP_STAMP(12 * stage + 6);
         // ---- reverse sweep: KG cotangents (network outputs) at a time; an odd leftover is swept twice, its second copy
         //      is not stored
         constexpr int KG = coop_kg<T>(NT);
@@ -522,9 +523,9 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                     }
                 }
         }
-        COOP_STAMP(7);
+        COOP_STAMP(12 * stage + 7);
         lds_barrier();
-        COOP_STAMP(8);
+        COOP_STAMP(12 * stage + 8);
 
         // ---- reduce the K-split partials: f -> s_k[cc][o], J -> s_J[cc][k][d]; items = (column, row), flat
         {
@@ -547,6 +548,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
             }
         }
         lds_barrier();
+        COOP_STAMP(12 * stage + 10);
 
         // stage record for the Hessian pipeline: this stage's Jacobian and the chain Jacobian it was entered with
         if (SR) {
@@ -606,9 +608,10 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
             }
             lds_barrier();
         }
+        COOP_STAMP(12 * stage + 11);
     }
 
-    COOP_STAMP(9);
+    COOP_STAMP(49);
     // fused dense Jacobian (plain models): the background zeros of the pass's rows were streamed at its start
     // (coop_zero_rows); every wave waits for its own stores' acknowledgements, the barrier covers the workgroup, then the
     // non-zeros go over them with the compact outputs below (see fx_zero_rows in kernels_coopfx_impl.h for the ordering)
@@ -676,7 +679,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
         }
     }
     lds_barrier();
-    COOP_STAMP(11);
+    COOP_STAMP(50);
 }
 
 // Everything the kernel needs, prepared on the host (try_launch_coop): the kernel itself does no setup arithmetic.

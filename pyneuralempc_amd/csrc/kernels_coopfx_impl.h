@@ -21,6 +21,12 @@
 #define NEMPC_FX_ZERO_EARLY 0      // 1: background zeros before the pass's first barrier instead of behind layer 0
 #endif
 
+#ifdef NEMPC_STAMPS_NO_FX          // (tools/diag_stamps_c3.py: stamps in the run-time-dims kernel only)
+#undef COOP_WGSTAMP
+#undef COOP_WGSTAMP_REAL
+#define COOP_WGSTAMP(p, i) do { } while (0)
+#define COOP_WGSTAMP_REAL(p, i) do { } while (0)
+#endif
 // diagnostic builds only (tools/diag_stamps.py): the per-workgroup timeline has 13 event slots; -DNEMPC_STAMPS_PRO spends
 // them on the prologue instead of the pass
 #ifdef NEMPC_STAMPS_PRO
@@ -291,12 +297,13 @@ __device__ __forceinline__ void fx_zero_rows(T* o_jac, unsigned r0, int nrows, i
         const int full = nv / NTHREADS;
         const int voff = tid * 16;
         for (int k = 0; k < full; ++k) {
-            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
             base += NTHREADS * 16;
         }
         if (tid < nv - full * NTHREADS)
-            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
-        asm volatile("s_nop 1" ::: "memory");      // store-data hazard: `zero`'s registers may be re-used right behind the run
+            asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
+        // (store-data hazard: `zero`'s registers may be re-used right behind a store -- the wait states ride in the store's own
+        // asm statement: a separate `s_nop` statement does not keep the scheduler from placing an instruction in between)
     };
     if (!box) {
         run(fx_uniform_ptr(reinterpret_cast<const char*>(o_jac) + (size_t)r0 * NX * (size_t)n * sizeof(T)), drv * nvec);
@@ -739,7 +746,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rows_coopfx_kernel(
     (void)a;
 #endif
     COOP_WGSTAMP(pa.dbg, 0);
-#ifdef NEMPC_STAMPS
+#if defined(NEMPC_STAMPS) && !defined(NEMPC_STAMPS_NO_FX)
     if (pa.dbg && threadIdx.x == 0 && blockIdx.x < 4096)
         pa.dbg[1024 + blockIdx.x * 16 + 15] = ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
 #endif

@@ -122,20 +122,26 @@ def test_bench_two_rank_rehearsal_on_one_gpu():
     env = dict(os.environ, NEMPC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "34", "--warmup", "3",
-                        "--batch", "64", "--no-cpu", "--no-other-configs", "--no-hessian", "--prime-ms", "0",
-                        "--solver-iters", "10"], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    import tempfile
+    with tempfile.TemporaryDirectory() as cwd:
+        r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "34", "--warmup", "3",
+                            "--batch", "64", "--no-cpu", "--no-other-configs", "--no-hessian", "--prime-ms", "0",
+                            "--solver-iters", "10"], capture_output=True, text=True, env=env, timeout=600, cwd=cwd)
+        assert r.returncode == 0, r.stderr[-2000:]
+        details = json.load(open(os.path.join(cwd, "bench_details.json")))      # the detailed record (side file)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines) == 1 and r.stdout.rstrip().endswith(lines[0]), r.stdout[-2000:]      # ONE line, the last one
+    assert len(lines[0]) < 4096
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 34 and out["scaling"] == "weak"
     assert out["config"]["batch_per_gpu"] == 64 and out["config"]["parallelism"] == "problem-sharded x2"
     # whole-job aggregate: both ranks' problems over the slowest rank's time
     assert abs(out["value"] - 2 * 64 * 34 / (out["ms_per_step"] * 34 * 1e-3)) / out["value"] < 1e-9
-    ag = out["allgather_u0"]
+    assert details["value"] == out["value"] and details["ms_per_step"] == out["ms_per_step"]
+    ag = details["allgather_u0"]
     assert ag["issued_in_timed_loop"] == 2 and ag["rows_gathered"] == 128 and ag["latency_us"] > 0     # 34 steps / 17
-    assert out["batched_solver"]["gathered_rows"] == 128
+    assert out["summary"]["allgather_u0_us"] > 0
+    assert details["batched_solver"]["gathered_rows"] == 128
     assert out["jacobian_max_abs_err_vs_cpu"] < 1e-12
     assert out["roofline"]["frac"] > 0 and "FUSE = true" in out["roofline"]["kernel"]
 
