@@ -526,7 +526,6 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
         COOP_STAMP(12 * stage + 7);
         lds_barrier();
         COOP_STAMP(12 * stage + 8);
-
         // ---- reduce the K-split partials: f -> s_k[cc][o], J -> s_J[cc][k][d]; items = (column, row), flat
         {
             constexpr int ROWS = NT * 16;
