@@ -879,6 +879,7 @@ class Rank:
             if self.world == 1 and args.config == "c2" and not args.batch and not args.no_other_configs:
                 out["layered_path"] = self.layered_leg()
                 out["steady_state"] = self.steady_state_leg(cfg)
+                out["narrow_networks"] = self.narrow_leg()
                 out["shard_c4"] = self.shard_c4_leg()
             if self.world == 1 and not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(cfg)
@@ -939,6 +940,46 @@ class Rank:
                                               "flops_note": "(2 + nin) GEMM sweeps per row" + (" and RK4 stage + the stage-record rows launch" if S == 4 else "")
                                                             + "; the per-layer contraction is vector work and not counted",
                                               "max_abs_err_vs_cpu": e_h, "max_abs_ref": s_h}}
+            del eng
+        return out
+
+    def narrow_leg(self):
+        """Networks of width <= 128 with a per-layer activation mix or a fourth hidden layer (the reference wraps any
+        feed-forward Keras model, model/tensorflow.py:8-29): since round 5 on the register-resident matrix-core kernels with
+        run-time activation codes (before: the layered path).  Headline dims (2/1, H = 20, B = 1024); rows launch (g + tiles)
+        and exact-Hessian callback, HIP events, fraction of the matrix peak by (1 + nx) / (2 + nin) network passes."""
+        np, torch = self.np, self.torch
+        from oracle import nempc_oracle as orc
+        from pyneuralempc_amd import CallbackEngine
+        B, H, nx, nu = 1024, 20, 2, 1
+        out = {}
+        for name, hidden, acts, tdt in (("3x128_mix_f32", [128] * 3, ["relu", "tanh", "sigmoid", "linear"], torch.float32),
+                                        ("4x64_tanh_f32", [64] * 4, "tanh", torch.float32),
+                                        ("4x64_tanh_f64", [64] * 4, "tanh", torch.float64),
+                                        ("2x64_mix_f64", [64] * 2, ["tanh", "elu", "linear"], torch.float64)):
+            net = orc.MLP.random(nx + nu, hidden, nx, seed=0, activations=acts)
+            eng = CallbackEngine(net.W, net.b, H, nx, nu, dtype=tdt, device=self.dev, max_batch=B, activations=net.act)
+            Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=1)
+            Z, X0 = eng.to_device(Zh), eng.to_device(X0h)
+            lamh = np.random.default_rng(7).normal(size=(B, eng.m))
+            step, outs = eng.bind(Z, X0, ("g", "jac_tiles"))
+            t = self.timed_events(step, 50)
+            ch, outh = eng.bind_hess(Z, X0, eng.to_device(lamh), eng.to_device(np.ones(B)))
+            th = self.timed_events(ch, 20)
+            torch.cuda.synchronize(self.dev)
+            prob = orc.Problem(net, H, nx, nu)
+            _, _, g, _ = prob.eval_batch(Zh[:4], X0h[:4])
+            err = float(np.abs(outs["g"][:4].to("cpu", torch.float64).numpy() - g).max())
+            ref = prob.hessian_values(Zh[0], X0h[0], lamh[0], 1.0)
+            errh = float(np.abs(outh["hvals"][0].to("cpu", torch.float64).numpy() - ref).max())
+            dims = [nx + nu] + hidden + [nx]
+            F = 2 * sum(i * o for i, o in zip(dims[:-1], dims[1:]))
+            peak = PEAK_F64_TFLOPS if tdt == torch.float64 else PEAK_F32_TFLOPS
+            out[name] = {"kernel_variant": eng.kernel_variant,
+                         "evaluation": {"us": t * 1e6, "kernel": eng.last_row_kernel, "max_abs_err_vs_cpu": err,
+                                        "frac_of_matrix_peak": B * H * (1 + nx) * F / t / 1e12 / peak},
+                         "hessian_callback": {"us": th * 1e6, "kernel": eng.last_hess_kernel, "max_abs_err_vs_cpu": errh,
+                                              "frac_of_matrix_peak": B * H * (2 + nx + nu) * F / th / 1e12 / peak}}
             del eng
         return out
 

@@ -26,8 +26,8 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libnempc.so")
 # the matrix-core kernels: one translation unit per (dtype, hidden activation); tanh (the headline) first, it is the longest
-_MFMA_ACTS = ["relu", "sigmoid", "softplus", "elu"]
-SOURCES = (["kernels_mfma_f64.hip", "kernels_mfma_f32.hip", "solver.hip"] +
+_MFMA_ACTS = ["relu", "sigmoid", "softplus", "elu"]          # (+ "rt": per-layer codes at run time)
+SOURCES = (["kernels_mfma_f64_rt.hip", "kernels_mfma_f64.hip", "kernels_mfma_f32_rt.hip", "kernels_mfma_f32.hip", "solver.hip"] +
            [f"kernels_mfma_{t}_{a}.hip" for t in ("f64", "f32") for a in _MFMA_ACTS] +
            ["nempc_api.hip", "kernels_valu.hip", "kernels_layered.hip", "kernels_post.hip", "kernels_mfma.hip", "kernels_rk4hess.hip",
             "comm.hip"])
@@ -39,7 +39,7 @@ FLAGS = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=
 # per-source extra flags.  Kernel-argument preload: the leading 16 dwords of a kernel's plain arguments are placed in
 # scalar registers by the dispatcher (the fixed-shape row kernel lists what its first loads need there)
 EXTRA_FLAGS = {f: ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
-               for f in ["kernels_mfma_f64.hip"] + [f"kernels_mfma_f64_{a}.hip" for a in _MFMA_ACTS]}
+               for f in ["kernels_mfma_f64.hip", "kernels_mfma_f64_rt.hip"] + [f"kernels_mfma_f64_{a}.hip" for a in _MFMA_ACTS]}
 
 
 def _hipcc():

@@ -75,17 +75,86 @@ __device__ __forceinline__ float nempc_tanh(float x) {
     return x != x ? x : copysignf(t, x);
 }
 
-// exp / log1p / expm1 of the other activations.  fp64: the library routines (their cost is not on the headline path; what
-// they must be is accurate -- the fp64 parity bar is 1e-12 against NumPy's).  fp32: the hardware exp2 / log2 (branch-free;
-// absolute error ~1e-7, inside the fp32 configs' 1e-4 tolerance -- what nempc_tanh(float) does too); the arguments these
-// are called with keep them away from the cancellation a true expm1 / log1p guards against only to that same 1e-7.
-// A NaN flows through all of them.
-__device__ __forceinline__ double nempc_exp(double x) { return exp(x); }
+// exp / expm1 / log1p of the other activations.  fp64: lean forms built like nempc_tanh (round 5) -- the library routines
+// cost 35 .. 90 issue slots each and, inlined beside 150 - 250 live weight and activation registers, pushed the fp64
+// sigmoid / softplus / elu kernels into scratch (up to 756 bytes per lane in the run-time-activation unit); what the kernels
+// need is ABSOLUTE accuracy at the 1e-16 level (parity bar 1e-12 against NumPy's), NaN flowing through, 0 / inf at the ends:
+//  * exp(x): x clamped to [-1024, 1024] on its high dword, n = rint(x / ln2) by the 1.5 * 2^52 shift, s = x / 2 - n ln2 / 2,
+//    exp(2 s) by nempc_tanh's degree-11 fit, ldexp.  Relative error 2e-16 for |x| < 3, growing by 4e-17 per unit of |n|
+//    (the one-piece ln2 / 2): 3e-15 where the value is 1e-12, i.e. absolute error below 2.3e-16 everywhere on x <= 0
+//  * expm1(x): the same polynomial without its constant term IS expm1(2 s) to full relative accuracy; n == 0 returns it
+//  * log1p(t), 0 <= t <= 1 (its only arguments: e^-|x|): 2 atanh(t / (2 + t)), the odd series to u^33 (u <= 1/3)
+// fp32: the hardware exp2 / log2 (branch-free; absolute error ~1e-7, inside the fp32 configs' 1e-4 tolerance -- what
+// nempc_tanh(float) does too).  tools/ubench_explog.hip measures all three against the host's long double routines.
+__device__ __forceinline__ double nempc_exp2s_m1(double s) {          // exp(2 s) - 1, |s| <= ln2 / 4
+    double p = 5.1425357017013815e-05;
+    p = fma(p, s, 0.00028295822990378013);
+    p = fma(p, s, 0.0014109307350312432);
+    p = fma(p, s, 0.0063491802834760944);
+    p = fma(p, s, 0.025396825459260305);
+    p = fma(p, s, 0.08888888929481456);
+    p = fma(p, s, 0.26666666666622724);
+    p = fma(p, s, 0.6666666666638096);
+    p = fma(p, s, 1.3333333333333344);
+    p = fma(p, s, 2.0000000000000075);
+    p = fma(p, s, 2.0);
+    return p * s;
+}
+__device__ __forceinline__ void nempc_exp_reduce(double x, double& s, int& n) {
+    const int hx = __double2hiint(x);
+    const double xc = __hiloint2double(fabs(x) > 1024.0 ? ((hx & (int)0x80000000) | 0x40900000) : hx, __double2loint(x));
+    const double SHIFT = 6755399441055744.0;
+    const double t = fma(xc, 1.4426950408889634, SHIFT);                // x / ln2
+    const double nf = t - SHIFT;
+    s = fma(-nf, 0.34657359027997264, 0.5 * xc);
+    n = __double2loint(t);
+}
+__device__ __forceinline__ double nempc_exp(double x) {
+    double s;
+    int n;
+    nempc_exp_reduce(x, s, n);
+    return ldexp(nempc_exp2s_m1(s) + 1.0, n);
+}
 __device__ __forceinline__ float nempc_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-__device__ __forceinline__ double nempc_expm1(double x) { return expm1(x); }
+__device__ __forceinline__ double nempc_expm1(double x) {
+    double s;
+    int n;
+    nempc_exp_reduce(x, s, n);
+    const double q = nempc_exp2s_m1(s);
+    return n == 0 ? q : ldexp(q + 1.0, n) - 1.0;
+}
 __device__ __forceinline__ float nempc_expm1(float x) { return nempc_exp(x) - 1.0f; }
-__device__ __forceinline__ double nempc_log1p(double x) { return log1p(x); }
+__device__ __forceinline__ double nempc_log1p(double t) {             // 0 <= t <= 1
+    const double d = 2.0 + t;
+    double r = __builtin_amdgcn_rcp(d);
+    const double e = fma(-d, r, 1.0);
+    r = fma(fma(e, e, e), r, r);
+    const double u = t * r, w = u * u;
+    double p = 1.0 / 33.0;
+    p = fma(p, w, 1.0 / 31.0);
+    p = fma(p, w, 1.0 / 29.0);
+    p = fma(p, w, 1.0 / 27.0);
+    p = fma(p, w, 1.0 / 25.0);
+    p = fma(p, w, 1.0 / 23.0);
+    p = fma(p, w, 1.0 / 21.0);
+    p = fma(p, w, 1.0 / 19.0);
+    p = fma(p, w, 1.0 / 17.0);
+    p = fma(p, w, 1.0 / 15.0);
+    p = fma(p, w, 1.0 / 13.0);
+    p = fma(p, w, 1.0 / 11.0);
+    p = fma(p, w, 1.0 / 9.0);
+    p = fma(p, w, 1.0 / 7.0);
+    p = fma(p, w, 1.0 / 5.0);
+    p = fma(p, w, 1.0 / 3.0);
+    p = fma(p, w, 1.0);
+    return (u + u) * p;
+}
 __device__ __forceinline__ float nempc_log1p(float x) { return __builtin_amdgcn_logf(1.0f + x) * 0.6931471805599453f; }
+
+// sigmoid: fp64 as 1/2 + tanh(x / 2) / 2 on the kernels' own tanh (24 issue slots, absolute error 1.1e-16; a division alone is
+// 20); fp32 1 / (1 + e^-x) (e^-x = inf gives 0)
+__device__ __forceinline__ double nempc_sigmoid(double x) { return fma(0.5, nempc_tanh(0.5 * x), 0.5); }
+__device__ __forceinline__ float nempc_sigmoid(float x) { return 1.0f / (1.0f + nempc_exp(-x)); }
 
 template <typename T, int ACT>
 struct Act;
@@ -110,7 +179,7 @@ struct Act<T, NEMPC_ACT_RELU> {
 };
 template <typename T>
 struct Act<T, NEMPC_ACT_SIGMOID> {
-    static __device__ __forceinline__ T f(T x) { return T(1) / (T(1) + nempc_exp(-x)); }   // e^-x = inf gives 0
+    static __device__ __forceinline__ T f(T x) { return nempc_sigmoid(x); }
     static __device__ __forceinline__ T d1(T a) { return a * (T(1) - a); }
     static __device__ __forceinline__ T r2(T a) { return T(1) - T(2) * a; }
 };
@@ -169,6 +238,39 @@ __device__ __forceinline__ T act_r2(int code, T a, T par) {
         default: return T(0);
     }
 }
+
+// ---- per-layer activations of the register-resident matrix-core kernels.  ACT = an NEMPC_ACT_* code: the activation is
+// the template parameter (one translation unit per activation, the layer index is ignored).  ACT = NEMPC_ACT_RUNTIME: the
+// hidden layers' codes and parameters arrive in the launch arguments (ActSpec) -- any mix of the output-based family
+// (linear ... selu), elu / leaky_relu with any alpha; the code is wave-uniform, the switch a scalar branch beside the
+// layer's block of matrix instructions.  (The reference evaluates whatever per-layer activations the Keras model has:
+// model/tensorflow.py:49-51.)
+#define NEMPC_ACT_RUNTIME 100
+#define NEMPC_MFMA_MAX_HIDDEN 4
+struct ActSpec {
+    int32_t code[NEMPC_MFMA_MAX_HIDDEN];
+    double par[NEMPC_MFMA_MAX_HIDDEN];
+};
+template <typename T, int ACT>
+struct ActL {
+    static __device__ __forceinline__ T f(T x, const ActSpec& s, int l) {
+        if constexpr (ACT == NEMPC_ACT_RUNTIME) {
+            const int c = s.code[l];
+            if (c == NEMPC_ACT_TANH) return nempc_tanh(x);            // (the kernels' own tanh, as in the tanh instantiations)
+            return act_f<T>(c, x, (T)s.par[l]);
+        } else {
+            return Act<T, ACT>::f(x);
+        }
+    }
+    static __device__ __forceinline__ T d1(T a, const ActSpec& s, int l) {
+        if constexpr (ACT == NEMPC_ACT_RUNTIME) return act_d1<T>(s.code[l], a, (T)s.par[l]);
+        else return Act<T, ACT>::d1(a);
+    }
+    static __device__ __forceinline__ T r2(T a, const ActSpec& s, int l) {
+        if constexpr (ACT == NEMPC_ACT_RUNTIME) return act_r2<T>(s.code[l], a, (T)s.par[l]);
+        else return Act<T, ACT>::r2(a);
+    }
+};
 
 // swish, gelu, softsign, mish, exponential, relu6: value and derivatives from the PRE-activation z (the layered path's GEMM
 // epilogue has z = acc + bias in registers).  swish: s = z g, s' = g (1 + z (1 - g)), s'' = g (1 - g) (2 + z (1 - 2 g)) with g = sigmoid(z);

@@ -230,7 +230,7 @@ template <typename T>
 struct CoopCtx {
     const T* w0f;   // LDS
     const T* seed;  // LDS tail: seed at 0, bias[l] at bias_off[l], biasL at biasL_off
-    int bias_off[3], biasL_off;
+    int bias_off[NEMPC_MFMA_MAX_HIDDEN], biasL_off;
     T* X;
     T* PART;
     T* SCR;
@@ -254,6 +254,7 @@ struct CoopCtx {
     T* stage_out;                   // RK4 Hessian pipeline: per (row, stage) record [xi_s | J_s | dk_{s-1}], else null
     int stage_stride;
     long long* dbg;
+    ActSpec acts;                   // hidden layers' activations (NEMPC_ACT_RUNTIME instantiations)
 };
 
 // Inputs of a pass, fetched into registers first (so the loads can be issued ahead of the weight-slice
@@ -353,7 +354,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
                                           const StageRegs<T, WP / 16, TPW>& nxt, bool has_nxt, T* SCRnext, int* RInext,
                                           int nrows_next) {
     using Ops = MfmaOps<T>;
-    using A = Act<T, ACT>;
+    using A = ActL<T, ACT>;
     using V4 = typename Ops::V4;
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
@@ -411,7 +412,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[0][j][r] = A::f(a[0][j][r]);
+                for (int r = 0; r < 4; ++r) a[0][j][r] = A::f(a[0][j][r], cx.acts, 0);
         }
         COOP_STAMP(12 * stage + 4);
         // ---- hidden-to-hidden layers.  The exchange buffer has two halves used alternately: a wave may
@@ -442,7 +443,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[l][j][r] = A::f(a[l][j][r]);
+                for (int r = 0; r < 4; ++r) a[l][j][r] = A::f(a[l][j][r], cx.acts, l);
         }
         COOP_STAMP(12 * stage + 5);
         // ---- network output: K-split partial over this wave's block
@@ -460,7 +461,7 @@ __device__ __forceinline__ void coop_pass(const CoopCtx<T>& cx, const CoopWeight
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[l][j][r] = A::d1(a[l][j][r]);
+                for (int r = 0; r < 4; ++r) a[l][j][r] = A::d1(a[l][j][r], cx.acts, l);
 
         COOP_STAMP(12 * stage + 6);
         // ---- reverse sweep: KG cotangents (network outputs) at a time; an odd leftover is swept twice, its second copy
@@ -701,7 +702,7 @@ struct CoopArgs {
     int early;              // first-pass inputs through registers (plain models whose columns fit StageRegs)
     // ---- LDS carve-up (element offsets) and table offsets inside the LDS copy of `small`
     int l_w0f, l_tail, l_x, l_xhalf, l_part, l_scratch, l_scratch2, l_rowinfo, l_rowinfo2;   // *2: the second buffer
-    int bias_off[3], biasL_off;
+    int bias_off[NEMPC_MFMA_MAX_HIDDEN], biasL_off;
     // ---- the rest of CoopCtx
     void* g;
     void* tiles;
@@ -721,6 +722,7 @@ struct CoopArgs {
     const void* obj_P;
     ObjOffsets oo;
     int B;
+    ActSpec acts;           // hidden layers' activations (NEMPC_ACT_RUNTIME instantiations)
 };
 
 // SR: also write the per-(row, stage) records of the RK4 Hessian pipeline (its own instantiation: the extra stores and
@@ -810,7 +812,8 @@ __global__ __launch_bounds__((WP / 16) * 64, OCC) void rows_coop_kernel(CoopArgs
     // ---- the rest of the context (scalar loads in the shadow of the vector loads above)
     cx.w0f = lds + a.l_w0f;
     cx.seed = lds + a.l_tail;
-    for (int l = 0; l < 3; ++l) cx.bias_off[l] = a.bias_off[l];
+    for (int l = 0; l < NEMPC_MFMA_MAX_HIDDEN; ++l) cx.bias_off[l] = a.bias_off[l];
+    if constexpr (ACT == NEMPC_ACT_RUNTIME) cx.acts = a.acts;
     cx.biasL_off = a.biasL_off;
     cx.X = lds + a.l_x;
     cx.xhalf = a.l_xhalf;

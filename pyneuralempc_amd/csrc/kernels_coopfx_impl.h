@@ -332,6 +332,7 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
                                         const FxStage<T, TPW, (WP / 16) * 64, NX + NU + NX>& nxt, bool has_next, T* in_next) {
     using Ops = MfmaOps<T>;
     using A = Act<T, ACT>;
+    static_assert(ACT != NEMPC_ACT_RUNTIME, "the compiled-shape kernels take a compile-time activation");
     using V4 = typename Ops::V4;
     using L = FxLayout<T, WP, NH, TPW, NX, NU>;
     constexpr int MT = WP / 16, NTHREADS = MT * 64, NIN = NX + NU, KS = L::KS, JROW = L::JROW;

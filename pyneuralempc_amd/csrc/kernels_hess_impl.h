@@ -49,7 +49,7 @@ struct HessParams {
 template <typename T, int WP, int NH, bool WLDS, int ACT>
 __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
     using Ops = MfmaOps<T>;
-    using A = Act<T, ACT>;
+    using A = ActL<T, ACT>;
     using V4 = typename Ops::V4;
     constexpr int MT = WP / 16;
     const MfmaParams& p = hp.base;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S1[0][mo][r] = A::f(S1[0][mo][r]);
+                for (int r = 0; r < 4; ++r) S1[0][mo][r] = A::f(S1[0][mo][r], p.acts, 0);
         }
 #pragma unroll
         for (int l = 1; l < NH; ++l) {
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
 #pragma unroll
             for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S1[l][mo][r] = A::f(S1[l][mo][r]);
+                for (int r = 0; r < 4; ++r) S1[l][mo][r] = A::f(S1[l][mo][r], p.acts, l);
         }
 
         // ---- base reverse sweep: delta_l, then S1_l = 1 - a_l^2 and E_l = -2 delta_l a_l
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void rowhess_mfma_kernel(HessParams hp) {
                     V4 s1, e;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        s1[r] = A::d1(a[r]);
-                        e[r] = dl[mt][r] * A::r2(a[r]);
+                        s1[r] = A::d1(a[r], p.acts, l);
+                        e[r] = dl[mt][r] * A::r2(a[r], p.acts, l);
                     }
                     E[l][mt] = e;
                     S1[l][mt] = s1;

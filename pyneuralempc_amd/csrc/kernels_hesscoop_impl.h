@@ -27,7 +27,7 @@ struct HessCoopLayout {  // element offsets inside dynamic LDS
 template <typename T, int WP, int NH, int TG, int ACT>
 __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coop_kernel(HessParams hp, HessCoopLayout lay) {
     using Ops = MfmaOps<T>;
-    using A = Act<T, ACT>;
+    using A = ActL<T, ACT>;
     using V4 = typename Ops::V4;
     constexpr int MT = WP / 16;
     constexpr int NTHREADS = MT * 64;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coop_kernel(HessPar
                 S1[0] = Ops::mma(s_w0f[(ks * MT + w) * 64 + lane], v, S1[0]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S1[0][r] = A::f(S1[0][r]);
+            for (int r = 0; r < 4; ++r) S1[0][r] = A::f(S1[0][r], p.acts, 0);
         }
 #pragma unroll
         for (int l = 1; l < NH; ++l) {
@@ -136,7 +136,7 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coop_kernel(HessPar
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S1[l] = Ops::mma(W.wf[l - 1][mt * 4 + r], X[(mt * 4 + r) * 64 + lane], S1[l]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S1[l][r] = A::f(S1[l][r]);
+            for (int r = 0; r < 4; ++r) S1[l][r] = A::f(S1[l][r], p.acts, l);
         }
 
         // ---- base reverse sweep: delta_l = d(lambda.f)/d a_l; keep S1_l = s'(z_l) and E_l = delta_l r2(a_l) (tanh: 1 - a_l^2, -2 delta_l a_l)
@@ -153,8 +153,8 @@ __global__ __launch_bounds__((WP / 16) * 64, 2) void rowhess_coop_kernel(HessPar
                 V4 s1, e;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    s1[r] = A::d1(a[r]);
-                    e[r] = dl[r] * A::r2(a[r]);
+                    s1[r] = A::d1(a[r], p.acts, l);
+                    e[r] = dl[r] * A::r2(a[r], p.acts, l);
                 }
                 E[l] = e;
                 S1[l] = s1;

@@ -149,6 +149,7 @@ __device__ __forceinline__ void hfx_pass(const HfxArgs& a, T* lds, const T (&wf)
                                          T* in_next) {
     using Ops = MfmaOps<T>;
     using A = Act<T, ACT>;
+    static_assert(ACT != NEMPC_ACT_RUNTIME, "the compiled-shape kernels take a compile-time activation");
     using V4 = typename Ops::V4;
     using L = HfxLayout<T, WP, NH, NT, NX, NU, TG, EV>;
     constexpr int MT = WP / 16, NTHREADS = MT * 64, NIN = NX + NU, KS = L::KS, NPAIR = L::NPAIR, NVT = L::NVT;

@@ -60,11 +60,23 @@ int scratch_elems(const Handle& h) {
 
 bool mfma_supported(const Handle& h) {
     const int nh = h.nl - 1;
-    if (nh < 1 || nh > 3 || h.mfma_act < 0) return false;
+    if (nh < 1 || nh > NEMPC_MFMA_MAX_HIDDEN || h.mfma_act < 0) return false;
+    if (nh == 4 && padded_width(h) > 64) return false;             // a fourth hidden layer: up to width 64
     // network outputs on one 16-row block; inputs (window + extras) on up to kMaxKs k-steps, the window itself on up
     // to two 16-row blocks of the last reverse step (wave-per-tile kernels; the cooperative ones take <= 16)
     if (h.cfg.nx > 16 || h.nin + h.ne > 4 * kMaxKs || h.nin > 32) return false;
     return padded_width(h) != 0;
+}
+
+// Shapes the register-resident kernels take but the layered path runs faster (AUTO then picks the layered path; asking for
+// NEMPC_KERNEL_MFMA by name still gets them): fp64 networks with run-time activation codes whose weight slices do not fit
+// the cooperative kernel's registers (3 x 128, a fourth layer at width 64) -- the wave-per-tile kernel with the activation
+// switch inlined spills (800 B of scratch per lane) and measured 304 us against the layered path's 187 (3 x 128 relu / tanh /
+// sigmoid, B = 1024, H = 20; tools/narrow_bench.py).
+bool mfma_slower_than_layered(const Handle& h) {
+    if (h.mfma_act != NEMPC_ACT_RUNTIME || h.cfg.dtype != NEMPC_F64 || !layered_supported(h)) return false;
+    const int nh = h.nl - 1, MT = padded_width(h) / 16;
+    return ((nh - 1) * 2 * MT * 4 + 8) * 2 > 144;          // coop_fits_registers<double, WP, NH>() of kernels_mfma_typed.inc
 }
 
 void mfma_free(Handle& h) {
@@ -171,7 +183,7 @@ int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b)
     template <> int launch_rowhess_mfma_act<T, A>(const Handle& h, HessParams hp, hipStream_t s);
 #define NEMPC_DECL_ACTS(T)                                                                         \
     NEMPC_DECL_ACT(T, NEMPC_ACT_TANH) NEMPC_DECL_ACT(T, NEMPC_ACT_RELU) NEMPC_DECL_ACT(T, NEMPC_ACT_SIGMOID) \
-    NEMPC_DECL_ACT(T, NEMPC_ACT_SOFTPLUS) NEMPC_DECL_ACT(T, NEMPC_ACT_ELU)
+    NEMPC_DECL_ACT(T, NEMPC_ACT_SOFTPLUS) NEMPC_DECL_ACT(T, NEMPC_ACT_ELU) NEMPC_DECL_ACT(T, NEMPC_ACT_RUNTIME)
 NEMPC_DECL_ACTS(double)
 NEMPC_DECL_ACTS(float)
 #undef NEMPC_DECL_ACTS
@@ -185,6 +197,7 @@ int launch_rows_mfma_typed(const Handle& h, MfmaParams p, hipStream_t s) {
         case NEMPC_ACT_SIGMOID: return launch_rows_mfma_act<T, NEMPC_ACT_SIGMOID>(h, p, s);
         case NEMPC_ACT_SOFTPLUS: return launch_rows_mfma_act<T, NEMPC_ACT_SOFTPLUS>(h, p, s);
         case NEMPC_ACT_ELU: return launch_rows_mfma_act<T, NEMPC_ACT_ELU>(h, p, s);
+        case NEMPC_ACT_RUNTIME: return launch_rows_mfma_act<T, NEMPC_ACT_RUNTIME>(h, p, s);      // per-layer codes in p.acts
     }
     set_error("launch_rows_mfma: the matrix-core kernels do not take this network's activations");
     return NEMPC_EUNSUPPORTED;
@@ -198,6 +211,7 @@ int launch_rowhess_mfma_typed(const Handle& h, HessParams hp, hipStream_t s) {
         case NEMPC_ACT_SIGMOID: return launch_rowhess_mfma_act<T, NEMPC_ACT_SIGMOID>(h, hp, s);
         case NEMPC_ACT_SOFTPLUS: return launch_rowhess_mfma_act<T, NEMPC_ACT_SOFTPLUS>(h, hp, s);
         case NEMPC_ACT_ELU: return launch_rowhess_mfma_act<T, NEMPC_ACT_ELU>(h, hp, s);
+        case NEMPC_ACT_RUNTIME: return launch_rowhess_mfma_act<T, NEMPC_ACT_RUNTIME>(h, hp, s);
     }
     set_error("launch_rowhess_mfma: the matrix-core kernels do not take this network's activations");
     return NEMPC_EUNSUPPORTED;
@@ -213,6 +227,10 @@ static MfmaParams base_params(Handle& h, int B, const void* Z, const void* X0, v
     p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4; p.mb = (h.nin + 15) / 16;
     p.ne = h.ne; p.extra = h.d_extra;
     p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin, (int)h.esz);
+    for (int l = 0; l < NEMPC_MFMA_MAX_HIDDEN; ++l) {
+        p.acts.code[l] = l < h.nl - 1 ? h.act[l] : NEMPC_ACT_LINEAR;
+        p.acts.par[l] = l < h.nl - 1 ? h.actp[l] : 0.0;
+    }
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0; p.num_cus = h.num_cus;
     p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
@@ -302,6 +320,10 @@ int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, voi
     p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4; p.mb = (h.nin + 15) / 16;
     p.ne = h.ne; p.extra = h.d_extra;
     p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin, (int)h.esz);
+    for (int l = 0; l < NEMPC_MFMA_MAX_HIDDEN; ++l) {
+        p.acts.code[l] = l < h.nl - 1 ? h.act[l] : NEMPC_ACT_LINEAR;
+        p.acts.par[l] = l < h.nl - 1 ? h.actp[l] : 0.0;
+    }
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0; p.num_cus = h.num_cus;
     p.Z = Z; p.X0 = X0; p.g = g; p.tiles = tiles;
@@ -361,6 +383,10 @@ int launch_rowhess_mfma_direct(Handle& h, int B, const void* Z, const void* X0, 
     p.nx = h.cfg.nx; p.nu = h.cfg.nu; p.nin = h.nin; p.ks = (h.nin + h.ne + 3) / 4; p.mb = (h.nin + 15) / 16;
     p.ne = h.ne; p.extra = h.d_extra;
     p.off = make_offsets(h.mfma.wp, h.mfma.nh, p.ks, p.nx, p.nin, (int)h.esz);
+    for (int l = 0; l < NEMPC_MFMA_MAX_HIDDEN; ++l) {
+        p.acts.code[l] = l < h.nl - 1 ? h.act[l] : NEMPC_ACT_LINEAR;
+        p.acts.par[l] = l < h.nl - 1 ? h.actp[l] : 0.0;
+    }
     p.kind = h.cfg.integrator; p.DT = h.cfg.DT;
     p.B = B; p.H = h.cfg.H; p.m = h.m; p.box = h.box ? 1 : 0; p.num_cus = h.num_cus;
     p.Z = Z; p.X0 = X0; p.g = nullptr; p.tiles = nullptr;

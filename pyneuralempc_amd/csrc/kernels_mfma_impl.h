@@ -30,7 +30,7 @@ constexpr int kMaxKs = 8;   // first-layer k-steps: network inputs (window + ext
 struct MfmaOffsets {  // element offsets into the packed blob
     int w0f, wLf, w0b, seed, biasL;
     int p0tab, wLb;  // Hessian kernel tables: first-layer rows W_0[p,:], output-layer fragments for W_L lambda
-    int wf[3], wb[3], bias[3];
+    int wf[NEMPC_MFMA_MAX_HIDDEN], wb[NEMPC_MFMA_MAX_HIDDEN], bias[NEMPC_MFMA_MAX_HIDDEN];
     int total;
     // cooperative row kernel: the same numbers once more, laid out for its prologue (kernels_coop_impl.h) --
     //   coop_small   [w0f | seed | bias_l | biasL] contiguous (one flat copy to LDS),
@@ -81,6 +81,7 @@ struct MfmaParams {
     const int32_t* gn_smap;
     const void* gn_objc;
     int gn_nnz, gn_n_orph;
+    ActSpec acts;          // hidden layers' activations (read by the NEMPC_ACT_RUNTIME instantiations only)
 };
 
 // In-kernel stamps exist only in the diagnostic library built by tools/diag_stamps.py; the shipped
@@ -210,7 +211,7 @@ __device__ __forceinline__ void layer_mma(const T* __restrict__ w, int lane,
 template <typename T, int WP, int NH, bool WLDS, int MAXWAVES, int ACT>
 __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) {
     using Ops = MfmaOps<T>;
-    using A = Act<T, ACT>;
+    using A = ActL<T, ACT>;
     using V4 = typename Ops::V4;
     constexpr int MT = WP / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a[0][mo][r] = A::f(a[0][mo][r]);
+                    for (int r = 0; r < 4; ++r) a[0][mo][r] = A::f(a[0][mo][r], p.acts, 0);
             }
 #pragma unroll
             for (int l = 1; l < NH; ++l) {
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
 #pragma unroll
                 for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a[l][mo][r] = A::f(a[l][mo][r]);
+                    for (int r = 0; r < 4; ++r) a[l][mo][r] = A::f(a[l][mo][r], p.acts, l);
             }
             {
                 V4 fo;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(MAXWAVES * 64) void rows_mfma_kernel(MfmaParams p) 
 #pragma unroll
                     for (int mo = 0; mo < MT; ++mo)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) a[l][mo][r] = A::d1(a[l][mo][r]);
+                        for (int r = 0; r < 4; ++r) a[l][mo][r] = A::d1(a[l][mo][r], p.acts, l);
             }
 
             // ---- reverse sweep, one cotangent per network output (skipped by defect-only launches: tiles == null)

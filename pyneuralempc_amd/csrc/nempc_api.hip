@@ -10,6 +10,7 @@
 #include <utility>
 
 #include "nempc_internal.h"
+#include "activations.h"
 
 namespace nempc {
 
@@ -372,6 +373,14 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
         for (int l = 0; l < h->nl - 1; ++l)
             if (h->act[l] == NEMPC_ACT_ELU && h->actp[l] != 1.0) h->mfma_act = -1;
     }
+    // ... or any per-layer mix of the activations written from the layer's output (linear .. selu; elu / leaky_relu with
+    // any alpha): the same kernels with the hidden layers' codes as launch arguments (NEMPC_ACT_RUNTIME instantiations)
+    if (h->mfma_act < 0 && h->nl >= 2 && h->act[h->nl - 1] == NEMPC_ACT_LINEAR) {
+        bool ok = true;
+        for (int l = 0; l < h->nl - 1; ++l) ok = ok && h->act[l] >= NEMPC_ACT_LINEAR && h->act[l] < NEMPC_ACT_FIRST_ZBASED;
+        static const bool rt_off = [] { const char* e = getenv("NEMPC_MFMA_RUNTIME_ACT"); return e && atoi(e) == 0; }();    // (A/B: the layered path instead)
+        if (ok && !rt_off) h->mfma_act = NEMPC_ACT_RUNTIME;
+    }
     {
         // compute units of the device: every "fill the chip" launch geometry is sized from this, never from a literal.
         // NEMPC_NUM_CUS overrides it (tests of the launch planning on the one device a box has).
@@ -405,7 +414,7 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
             return fail(NEMPC_EUNSUPPORTED, "nempc_create: MFMA row kernel does not cover these layer dims / activations");
         }
         h->variant = cfg->kernel;
-    } else if (cfg->kernel == NEMPC_KERNEL_AUTO && mfma_supported(*h)) {
+    } else if (cfg->kernel == NEMPC_KERNEL_AUTO && mfma_supported(*h) && !mfma_slower_than_layered(*h)) {
         h->variant = NEMPC_KERNEL_MFMA;
     } else if (cfg->kernel == NEMPC_KERNEL_LAYERED || cfg->kernel == NEMPC_KERNEL_AUTO) {
         // wide / deep / mixed-activation networks: rows through the layer-at-a-time GEMM pipeline (kernels_layered.hip).

@@ -220,6 +220,7 @@ void layered_free(Handle& h);
 
 // ---- kernels_mfma.hip : matrix-core row kernel
 bool mfma_supported(const Handle& h);
+bool mfma_slower_than_layered(const Handle& h);    // AUTO prefers the layered path (kernels_mfma.hip)
 int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b);
 int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s);
 int launch_eval_fused(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, void* f,

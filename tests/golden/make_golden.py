@@ -294,6 +294,15 @@ CASES = {
     "act_param_box": (2, 1, [32, 24, 16], 9, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True, 0, 0,
                       ["leaky_relu:0.1", "selu", "elu:0.5", "leaky_relu"]),
     "act_selu_rk4": (2, 1, [48, 48], 7, orc.RK4, 0.2, None, 2, True, 0, 0, "selu"),
+    # per-layer mixes with a linear output layer, width <= 128: the register-resident matrix-core kernels with run-time
+    # activation codes (round 5; ActL in csrc/activations.h) -- the 3 x 128 relu / tanh / sigmoid mix on configs[1]'s dims
+    # with box rows, a parameterised pair under RK4 with the Lagrangian Hessian, configs[2]'s dims under RK4, and a fourth
+    # hidden layer with a mix
+    "act_mix3_c2": (2, 1, [128, 128, 128], 6, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True, 0, 0, ["relu", "tanh", "sigmoid", "linear"]),
+    "act_mix2_rk4": (2, 1, [64, 48], 7, orc.RK4, 0.2, None, 2, True, 0, 0, ["leaky_relu:0.1", "selu", "linear"]),
+    "act_mix_c3_rk4": (6, 3, [128, 128, 128], 4, orc.RK4, 0.1, None, 1, False, 0, 0, ["tanh", "softplus", "elu:0.5", "linear"]),
+    "deep4_mixed_c2": (2, 1, [64, 48, 64, 32], 6, orc.DISCRET, 1.0, None, 2, True, 0, 0,
+                       ["tanh", "relu", "sigmoid", "elu", "linear"]),
     # the non-monotone activations (derivatives from the pre-activation; the layered path only)
     "act_swish_gelu_box": (2, 1, [48, 40], 9, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True, 0, 0, ["swish", "gelu", "linear"]),
     "act_gelu_rk4": (2, 1, [40, 40], 7, orc.RK4, 0.2, None, 2, True, 0, 0, "gelu"),

@@ -13,6 +13,10 @@ CASE_NAMES = ["c1_discret", "c2_discret", "c2_unity", "c2_rk4", "c3_rk4", "c3_di
 # output layer (generic kernel only)
 ACT_UNIFORM_NAMES = [f"act_{a}_{c}" for a in ("relu", "sigmoid", "softplus", "elu") for c in ("c2", "c3")]
 ACT_MIXED_NAMES = ["act_mixed_box", "act_mixed_rk4", "act_linear_hidden", "act_param_box", "act_selu_rk4"]
+# per-layer mixes of the output-based family under a linear output layer, width <= 128, <= 3 hidden layers (4 up to width 64):
+# the register-resident matrix-core kernels with run-time activation codes (round 5) -- and every other kernel family
+ACT_RUNTIME_NAMES = ["act_mix3_c2", "act_mix2_rk4", "act_mix_c3_rk4", "deep4_mixed_c2", "act_linear_hidden", "act_selu_rk4",
+                     "deep4_c2"]
 # networks only the layer-at-a-time GEMM path (and the generic kernel) take: width > 128, more than three hidden layers
 WIDE_DEEP_NAMES = ["wide256_c2", "deep4_c2", "deep5_mixed_rk4"]
 ZBASED_NAMES = ["act_swish_gelu_box", "act_gelu_rk4"]     # swish / gelu: the layered path only

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import nempc_oracle as orc
-from helpers import ACT_MIXED_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, WIDE_DEEP_NAMES, ZBASED_NAMES, case_activations, case_extra, load_case, oracle_problem
+from helpers import ACT_MIXED_NAMES, ACT_RUNTIME_NAMES, ACT_UNIFORM_NAMES, CASE_NAMES, WIDE_DEEP_NAMES, ZBASED_NAMES, case_activations, case_extra, load_case, oracle_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -41,6 +41,8 @@ ALL = ("f", "grad", "g", "jac_dense", "jac_tiles", "jac_sparse")
 # every golden case x every kernel family; per-layer activation mixes run on the generic kernel only
 _FP64_CASES = ([(n, k) for n in CASE_NAMES + ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile", "layered")] +
                [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")] +
+               [(n, k) for n in ACT_RUNTIME_NAMES for k in ("mfma", "mfma_tile")] +
+               [(n, k) for n in ACT_RUNTIME_NAMES if n not in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")] +
                [(n, "layered") for n in ZBASED_NAMES])        # (swish / gelu: derivatives from the pre-activation)
 
 
@@ -71,6 +73,7 @@ def test_golden_fp64(name, kernel):
 @pytest.mark.parametrize("name,kernel", [(n, k) for n in ["c2_discret", "c3_rk4", "c3_discret", "c5_box", "odd_dims"] +
                                          ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile", "layered")] +
                          [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")] +
+                         [(n, k) for n in ACT_RUNTIME_NAMES for k in ("mfma", "mfma_tile")] +
                          [(n, "layered") for n in ZBASED_NAMES])
 def test_golden_fp32(name, kernel):
     d, W, b = load_case(name)
@@ -85,6 +88,9 @@ def test_golden_fp32(name, kernel):
                          [(n, k) for n in [c for c in CASE_NAMES if c not in ("c3_rk4", "odd_dims", "c3_discret")] +
                           [c for c in ACT_UNIFORM_NAMES if c.endswith("_c2")] for k in ("valu", "mfma", "mfma_tile", "layered")] +
                          [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")] +
+                         [(n, k) for n in ACT_RUNTIME_NAMES if n != "act_mix_c3_rk4" for k in ("mfma", "mfma_tile")] +
+                         [(n, k) for n in ACT_RUNTIME_NAMES if n not in ACT_MIXED_NAMES + WIDE_DEEP_NAMES + ["act_mix_c3_rk4"]
+                          for k in ("valu", "layered")] +
                          [(n, "layered") for n in ZBASED_NAMES])
 def test_golden_hessian_fp64(name, kernel):
     d, W, b = load_case(name)
@@ -587,14 +593,26 @@ def test_mixed_activations_run_on_the_layered_path_and_are_refused_by_the_regist
     from pyneuralempc_amd import CallbackEngine, _lib
     net = orc.MLP.random(3, [32, 32], 2, seed=1, activations=["relu", "tanh", "linear"])
     eng = CallbackEngine(net.W, net.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=4, activations=net.act)
-    assert eng.kernel_variant == "layered"                  # auto: a per-layer mix has no register-resident instantiation
+    # (round 5) a per-layer mix of output-based activations under a linear output layer: the register-resident kernels with
+    # run-time activation codes
+    assert eng.kernel_variant == "mfma"
     Zh, X0h = orc.synthetic_inputs(4, 6, 2, 1, seed=2)
     res = eng.eval_numpy(Zh, X0h)
     f, grad, g, jac = orc.Problem(net, 6, 2, 1).eval_batch(Zh, X0h)
     np.testing.assert_allclose(res["jac_dense"], jac, **F64)
     np.testing.assert_allclose(res["g"], g, **F64)
+    # fp64 mixes whose slices do not fit the cooperative kernel's registers: AUTO takes the layered path (measured faster),
+    # the kernels remain available by name; the same shape in fp32 stays register-resident
+    big = orc.MLP.random(3, [128, 128, 128], 2, seed=1, activations=["relu", "tanh", "sigmoid", "linear"])
+    assert CallbackEngine(big.W, big.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=4, activations=big.act).kernel_variant == "layered"
+    assert CallbackEngine(big.W, big.b, 6, 2, 1, dtype=torch.float32, device="cuda:0", max_batch=4, activations=big.act).kernel_variant == "mfma"
+    assert CallbackEngine(big.W, big.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=4, activations=big.act,
+                          kernel="mfma").kernel_variant == "mfma"
+    # a non-linear OUTPUT layer is outside them (the layered path takes it), and asking for them by name says so
+    nso = orc.MLP.random(3, [32, 32], 2, seed=1, activations=["relu", "tanh", "sigmoid"])
+    assert CallbackEngine(nso.W, nso.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=4, activations=nso.act).kernel_variant == "layered"
     with pytest.raises(_lib.NempcError, match="activations"):
-        CallbackEngine(net.W, net.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", kernel="mfma", activations=net.act)
+        CallbackEngine(nso.W, nso.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", kernel="mfma", activations=nso.act)
     with pytest.raises(NotImplementedError, match="hard_sigmoid"):
         CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["hard_sigmoid", "tanh", "linear"])
     # swish / gelu: the layered path only (their derivatives need the pre-activation)
@@ -692,7 +710,7 @@ def test_every_matrix_core_instantiation_with_its_hessian_against_the_oracle():
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("hidden,acts,nx,nu,integ", [
     ([256, 256], "tanh", 2, 1, "discret"),                                   # wide256_c2
-    ([64, 64, 64, 64], "tanh", 2, 1, "discret"),                            # deep4_c2
+    ([96, 96, 96, 96], "tanh", 2, 1, "discret"),                            # four hidden layers beyond width 64
     ([200, 130, 70], ["relu", "sigmoid", "elu", "softplus"], 3, 2, "unity"),  # ragged widths, a mix, non-linear output
     ([144, 96, 96, 40, 24], ["tanh", "relu", "tanh", "softplus", "elu", "linear"], 6, 3, "rk4"),
     ([512], "sigmoid", 1, 1, "rk4"),
