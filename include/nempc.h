@@ -71,8 +71,10 @@ extern "C" {
  * lambda | a + lambda alpha (selu, Keras' fixed constants) -- the MONOTONE activations, whose derivatives follow from the
  * output alone.  swish (= silu, z sigmoid(z)), gelu (z Phi(z), Keras' approximate=False), softsign, mish, exponential and relu6
  * are written from the pre-activation (the first two and mish are not monotone; for the others it is simply the form at
- * hand), which only the layer-at-a-time matrix-core path has
- * (NEMPC_KERNEL_LAYERED / AUTO; hidden layers only) -- a configuration that would put them on another kernel is refused.
+ * hand), which the layer-at-a-time matrix-core path and the generic kernel keep (NEMPC_KERNEL_LAYERED / AUTO / VALU; any
+ * layer, the output layer included) -- asking for the register-resident kernels (NEMPC_KERNEL_MFMA*) with them is refused.
+ * Per-layer MIXES of the monotone family under a linear output layer run on the register-resident kernels, too (hidden
+ * widths <= 128, <= 3 hidden layers, 4 up to width 64): the layers' codes are launch arguments there.
  * elu and leaky_relu read their alpha from nempc_config.act_param (elu: > 0, leaky_relu: >= 0). */
 #define NEMPC_ACT_LINEAR 0
 #define NEMPC_ACT_TANH 1
@@ -85,7 +87,7 @@ extern "C" {
 #define NEMPC_ACT_SWISH 8
 #define NEMPC_ACT_GELU 9
 #define NEMPC_ACT_SOFTSIGN 10    /* z / (1 + |z|)                    -- these four, like swish / gelu, from the pre-activation: */
-#define NEMPC_ACT_MISH 11        /* z tanh(softplus(z))                  the layered path only, hidden layers only */
+#define NEMPC_ACT_MISH 11        /* z tanh(softplus(z))                  the layered path and the generic kernel */
 #define NEMPC_ACT_EXPONENTIAL 12 /* e^z */
 #define NEMPC_ACT_RELU6 13       /* min(max(z, 0), 6): Keras' ReLU(max_value=6) */
 #define NEMPC_ACT_COUNT 14

@@ -444,7 +444,7 @@ template <typename T, int NMAX>
 __global__ __launch_bounds__(256) void layered_skinny_kernel(const T* __restrict__ A, long long lda, const T* __restrict__ Bw, int ldb,
                                                              int K, int N, long long M, T* __restrict__ out, long long ldo,
                                                              const T* __restrict__ bias, int mode, int act, T* __restrict__ dout,
-                                                             T actp) {
+                                                             T actp, T* __restrict__ eout) {
     __shared__ T red[3][NMAX][64];
     constexpr int UN = 16;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -484,9 +484,11 @@ __global__ __launch_bounds__(256) void layered_skinny_kernel(const T* __restrict
             if (n < N) {
                 const T v = ((acc[n] + red[0][n][lane]) + red[1][n][lane]) + red[2][n][lane];
                 if (mode == 0) {
-                    const T x = lg_act_f<T>(act, v + bias[n], actp);
+                    T x, d1, e;
+                    lg_act_all<T>(act, v + bias[n], actp, eout != nullptr, x, d1, e);
                     out[(size_t)n * ldo + m] = x;
-                    dout[(size_t)n * ldo + m] = act_d1<T>(act, x, actp);
+                    dout[(size_t)n * ldo + m] = d1;
+                    if (eout) eout[(size_t)n * ldo + m] = e;
                 } else {
                     out[(size_t)n * ldo + m] = v;
                 }
@@ -496,11 +498,11 @@ __global__ __launch_bounds__(256) void layered_skinny_kernel(const T* __restrict
 
 template <typename T>
 int skinny(hipStream_t s, const T* A, long long lda, const T* Bw, int ldb, int K, int N, long long M, T* out, long long ldo,
-           const T* bias, int mode, int act, T* dout, T actp) {
+           const T* bias, int mode, int act, T* dout, T actp, T* eout = nullptr) {
     const dim3 grid((unsigned)((M + 63) / 64)), block(256);
-    if (N <= 4) hipLaunchKernelGGL((layered_skinny_kernel<T, 4>), grid, block, 0, s, A, lda, Bw, ldb, K, N, M, out, ldo, bias, mode, act, dout, actp);
-    else if (N <= 16) hipLaunchKernelGGL((layered_skinny_kernel<T, 16>), grid, block, 0, s, A, lda, Bw, ldb, K, N, M, out, ldo, bias, mode, act, dout, actp);
-    else hipLaunchKernelGGL((layered_skinny_kernel<T, 32>), grid, block, 0, s, A, lda, Bw, ldb, K, N, M, out, ldo, bias, mode, act, dout, actp);
+    if (N <= 4) hipLaunchKernelGGL((layered_skinny_kernel<T, 4>), grid, block, 0, s, A, lda, Bw, ldb, K, N, M, out, ldo, bias, mode, act, dout, actp, eout);
+    else if (N <= 16) hipLaunchKernelGGL((layered_skinny_kernel<T, 16>), grid, block, 0, s, A, lda, Bw, ldb, K, N, M, out, ldo, bias, mode, act, dout, actp, eout);
+    else hipLaunchKernelGGL((layered_skinny_kernel<T, 32>), grid, block, 0, s, A, lda, Bw, ldb, K, N, M, out, ldo, bias, mode, act, dout, actp, eout);
     NEMPC_HIP(hipGetLastError());
     return NEMPC_OK;
 }
@@ -626,15 +628,19 @@ LayeredWs layered_offsets(const Handle& h, size_t Rp) {
 // network output from the feature blocks' partial sums (LG_CONTRACT_FORWARD), in block order: f = s_L(sum + b), s_L'(z_L)
 template <typename T>
 __global__ void layered_outfinish_kernel(const T* __restrict__ P, int nblk, long long stride, int nx, int R, long long Rp,
-                                         const T* __restrict__ bias, int act, T actp, T* __restrict__ f, T* __restrict__ dl) {
+                                         const T* __restrict__ bias, int act, T actp, T* __restrict__ f, T* __restrict__ dl,
+                                         T* __restrict__ el) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     for (int o = 0; o < nx; ++o) {
         T v = P[(size_t)o * Rp + r];
         for (int b = 1; b < nblk; ++b) v += P[(size_t)b * stride + (size_t)o * Rp + r];
-        const T x = lg_act_f<T>(act, v + bias[o], actp);
+        // (from the output for the monotone activations, from the pre-activation for swish / gelu ...: lg_act_all)
+        T x, d1, e;
+        lg_act_all<T>(act, v + bias[o], actp, el != nullptr, x, d1, e);
         f[(size_t)o * Rp + r] = x;
-        dl[(size_t)o * Rp + r] = act_d1<T>(act, x, actp);
+        dl[(size_t)o * Rp + r] = d1;
+        if (el) el[(size_t)o * Rp + r] = e;           // s_L''(z_L): the Hessian sweeps' output-layer curvature
     }
 }
 
@@ -763,7 +769,8 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                     a.Jp = ws + o.g0; a.ldj = Rp; a.jp_stride = (long long)nx * Rp;
                     if ((rc = gemm_forward<T, LG_CONTRACT_FORWARD>(h.num_cus, s, a))) return rc;
                     hipLaunchKernelGGL(layered_outfinish_kernel<T>, rg, rb, 0, s, ws + o.g0, (h.dout[l] + 63) / 64, a.jp_stride, nx, R, Rp,
-                                       static_cast<const T*>(h.d_b[nl - 1]), h.act[nl - 1], (T)h.actp[nl - 1], ws + o.f, ws + o.dl);
+                                       static_cast<const T*>(h.d_b[nl - 1]), h.act[nl - 1], (T)h.actp[nl - 1], ws + o.f, ws + o.dl,
+                                       static_cast<T*>(nullptr));
                     NEMPC_HIP(hipGetLastError());
                     break;
                 }
@@ -906,12 +913,11 @@ LayeredHws layered_hess_offsets(const Handle& h, size_t Rp) {
 }
 
 // multipliers of the chunk's rows, feature-major, times the output layer's derivatives: cl = mult . s_L' (the cotangent on
-// z_L), wl = mult . s_L'' (its curvature weights; zero for a linear output layer)
+// z_L), wl = mult . s_L'' (its curvature weights; zero for a linear output layer; s_L'' itself is in wl on entry)
 // (direct: the rows are the (row, stage) pairs of the RK4 pipeline, multipliers nu[(pair)][nx] row-major)
 template <typename T>
 __global__ void layered_hmult_kernel(int H, int nx, int m, const T* __restrict__ lam, int direct, long long r0, int R, long long Rp,
-                                     const T* __restrict__ f, const T* __restrict__ dl, int act, T actp, T* __restrict__ cl,
-                                     T* __restrict__ wl) {
+                                     const T* __restrict__ dl, int act, T* __restrict__ cl, T* __restrict__ wl) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const long long gr = r0 + r;
@@ -923,9 +929,8 @@ __global__ void layered_hmult_kernel(int H, int nx, int m, const T* __restrict__
             cl[(size_t)k * Rp + r] = mu;
             wl[(size_t)k * Rp + r] = T(0);
         } else {
-            const T s1 = dl[(size_t)k * Rp + r];
-            cl[(size_t)k * Rp + r] = mu * s1;
-            wl[(size_t)k * Rp + r] = mu * (act_r2<T>(act, f[(size_t)k * Rp + r], actp) * s1);
+            cl[(size_t)k * Rp + r] = mu * dl[(size_t)k * Rp + r];
+            wl[(size_t)k * Rp + r] = mu * wl[(size_t)k * Rp + r];          // (s_L''(z_L) on entry: the forward sweep's output step)
         }
     }
 }
@@ -1156,7 +1161,7 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
                 a.Jp = ws + o.P; a.ldj = Rp; a.jp_stride = (long long)nx * Rp;
                 if ((rc = gemm_forward<T, LG_CONTRACT_FORWARD>(h.num_cus, s, a))) return rc;
                 hipLaunchKernelGGL(layered_outfinish_kernel<T>, rg, rb, 0, s, ws + o.P, (h.dout[l] + 63) / 64, a.jp_stride, nx, R, Rp,
-                                   static_cast<const T*>(h.d_b[nl - 1]), h.act[nl - 1], (T)h.actp[nl - 1], ws + o.f, ws + o.dl);
+                                   static_cast<const T*>(h.d_b[nl - 1]), h.act[nl - 1], (T)h.actp[nl - 1], ws + o.f, ws + o.dl, ws + o.wl);
                 NEMPC_HIP(hipGetLastError());
                 in = nullptr;
                 break;
@@ -1166,11 +1171,11 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
             in = out;
         }
         if (in && (rc = skinny<T>(s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, (long long)R, ws + o.f, Rp,
-                                  static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl, (T)h.actp[nl - 1])))
+                                  static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl, (T)h.actp[nl - 1], ws + o.wl)))
             return rc;
         // ---- reverse with the multipliers as the one cotangent: curvature weights w_l of every hidden layer
-        hipLaunchKernelGGL(layered_hmult_kernel<T>, rg, rb, 0, s, H, nx, h.m, lam, stage ? 1 : 0, r0, R, Rp, ws + o.f, ws + o.dl, h.act[nl - 1],
-                           (T)h.actp[nl - 1], ws + o.cl, ws + o.wl);
+        hipLaunchKernelGGL(layered_hmult_kernel<T>, rg, rb, 0, s, H, nx, h.m, lam, stage ? 1 : 0, r0, R, Rp, ws + o.dl, h.act[nl - 1],
+                           ws + o.cl, ws + o.wl);
         NEMPC_HIP(hipGetLastError());
         T* dq = ws + o.q0;
         hipLaunchKernelGGL(layered_hseed_kernel<T>, dim3(rg.x, (unsigned)h.dout[nl - 2]), rb, 0, s, static_cast<const T*>(h.d_W[nl - 1]),

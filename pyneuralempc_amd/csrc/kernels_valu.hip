@@ -31,7 +31,7 @@ struct NetDev {
 };
 
 struct WsOff {  // slot offsets (multiply by Rcap)
-    int xi, act, cot, fout, jst, kcur, dk, acck, accdk, dkn, P, cL, rk_xin, rk_J, rk_dk, rk_nu, htmp, htmp2, total;
+    int xi, act, cot, fout, jst, kcur, dk, acck, accdk, dkn, P, cL, rk_xin, rk_J, rk_dk, rk_nu, htmp, htmp2, d1s, d2s, total;
 };
 
 WsOff ws_offsets(const Handle& h) {
@@ -56,6 +56,10 @@ WsOff ws_offsets(const Handle& h) {
     o.rk_nu = p; p += 4 * h.cfg.nx;
     o.htmp = p; p += h.nin * h.nin;
     o.htmp2 = p; p += h.nin * h.nin;
+    // s'(z) and s''(z) of every unit (hidden layers, then the output layer), written by the forward pass: from the output for
+    // the monotone activations, from the pre-activation for swish / gelu / softsign / mish / exponential / relu6
+    o.d1s = p; p += nhid * h.maxw + h.cfg.nx;
+    o.d2s = p; p += nhid * h.maxw + h.cfg.nx;
     o.total = p;
     return o;
 }
@@ -90,9 +94,23 @@ __device__ void net_forward(const NetDev& net, T* ws, const WsOff& o, size_t R, 
                         if (jb + q < wout) acc[q] = fma(a, w[q], acc[q]);
                 }
             }
+            // unit index in the derivative slots: hidden layer l at l * maxw, the output layer behind the hidden ones
+            const int u0 = (last ? (net.nl - 1) * net.maxw : l * net.maxw) + jb;
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                if (jb + q < wout) out[(size_t)(jb + q) * R + r] = act_f<T>(net.act[l], acc[q], (T)net.actp[l]);
+                if (jb + q < wout) {
+                    T a, d1, d2;
+                    if (act_zbased(net.act[l])) {
+                        act_from_z<T>(net.act[l], acc[q], a, d1, d2);
+                    } else {
+                        a = act_f<T>(net.act[l], acc[q], (T)net.actp[l]);
+                        d1 = act_d1<T>(net.act[l], a, (T)net.actp[l]);
+                        d2 = act_r2<T>(net.act[l], a, (T)net.actp[l]) * d1;
+                    }
+                    out[(size_t)(jb + q) * R + r] = a;
+                    ws[(size_t)(o.d1s + u0 + q) * R + r] = d1;
+                    ws[(size_t)(o.d2s + u0 + q) * R + r] = d2;
+                }
         }
     }
 }
@@ -103,7 +121,8 @@ __device__ void net_jacobian_row(const NetDev& net, T* ws, const WsOff& o, size_
     const int nl = net.nl;
     T* jrow = ws + (size_t)(o.jst + k * net.nin) * R;
     // the output layer's own activation (1 for the usual linear output)
-    const T dLk = act_d1<T>(net.act[nl - 1], ws[(size_t)(o.fout + k) * R + r], (T)net.actp[nl - 1]);
+    const T* d1s = ws + (size_t)o.d1s * R;      // s'(z) of every unit (net_forward)
+    const T dLk = d1s[(size_t)((nl - 1) * net.maxw + k) * R + r];
     if (nl == 1) {
         const T* W0 = (const T*)net.W[0];
         for (int d = 0; d < net.nin; ++d) jrow[(size_t)d * R + r] = W0[(size_t)d * net.dout[0] + k] * dLk;
@@ -114,14 +133,12 @@ __device__ void net_jacobian_row(const NetDev& net, T* ws, const WsOff& o, size_
     {
         const T* WL = (const T*)net.W[nl - 1];
         const int w = net.din[nl - 1];
-        const T* a = ws + (size_t)(o.act + (nl - 2) * net.maxw) * R;
         T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;
         const bool lin_out = net.act[nl - 1] == NEMPC_ACT_LINEAR;
         for (int j = 0; j < w; ++j) {
-            const T av = a[(size_t)j * R + r];
             T wv = WL[(size_t)j * net.dout[nl - 1] + k];
             if (!lin_out) wv *= dLk;
-            c[(size_t)j * R + r] = wv * act_d1<T>(net.act[nl - 2], av, (T)net.actp[nl - 2]);
+            c[(size_t)j * R + r] = wv * d1s[(size_t)((nl - 2) * net.maxw + j) * R + r];
         }
     }
     // hidden layers nl-2 .. 1 : cot_in[i] = (sum_j W_l[i][j] cot[j]) s'(z_{l-1}[i])
@@ -131,7 +148,6 @@ __device__ void net_jacobian_row(const NetDev& net, T* ws, const WsOff& o, size_
         const T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;
         const bool first = (l == 0);
         T* cn = first ? jrow : ws + (size_t)(o.cot + (cur ^ 1) * net.maxw) * R;
-        const T* aprev = first ? nullptr : ws + (size_t)(o.act + (l - 1) * net.maxw) * R;
         for (int ib = 0; ib < win; ib += 8) {
             T acc[8];
 #pragma unroll
@@ -147,7 +163,7 @@ __device__ void net_jacobian_row(const NetDev& net, T* ws, const WsOff& o, size_
             for (int q = 0; q < 8; ++q) {
                 if (ib + q < win && (!first || ib + q < net.nin)) {   // extra inputs (tvp, p) get no Jacobian column
                     T v = acc[q];
-                    if (!first) v *= act_d1<T>(net.act[l - 1], aprev[(size_t)(ib + q) * R + r], (T)net.actp[l - 1]);
+                    if (!first) v *= d1s[(size_t)((l - 1) * net.maxw + ib + q) * R + r];
                     cn[(size_t)(ib + q) * R + r] = v;
                 }
             }
@@ -273,18 +289,15 @@ __device__ void net_hessian_contracted(const NetDev& net, T* ws, const WsOff& o,
         const int win = net.din[l], wout = net.dout[l];
         T* P = ws + (size_t)(o.P + l * net.maxw * nin) * R;      // (the output layer's block follows the hidden ones)
         const T* Pprev = (l == 0) ? nullptr : ws + (size_t)(o.P + (l - 1) * net.maxw * nin) * R;
-        const T* aprev = (l == 0) ? nullptr : ws + (size_t)(o.act + (l - 1) * net.maxw) * R;
+        const T* d1prev = (l == 0) ? nullptr : ws + (size_t)(o.d1s + (l - 1) * net.maxw) * R;
         for (int p = 0; p < nin; ++p) {
             for (int j = 0; j < wout; ++j) {
                 T acc = T(0);
                 if (l == 0) {
                     acc = W[(size_t)p * wout + j];
                 } else {
-                    for (int i = 0; i < win; ++i) {
-                        const T av = aprev[(size_t)i * R + r];
-                        acc = fma(W[(size_t)i * wout + j], act_d1<T>(net.act[l - 1], av, (T)net.actp[l - 1]) * Pprev[(size_t)(i * nin + p) * R + r],
-                                  acc);
-                    }
+                    for (int i = 0; i < win; ++i)
+                        acc = fma(W[(size_t)i * wout + j], d1prev[(size_t)i * R + r] * Pprev[(size_t)(i * nin + p) * R + r], acc);
                 }
                 P[(size_t)(j * nin + p) * R + r] = acc;
             }
@@ -296,12 +309,10 @@ __device__ void net_hessian_contracted(const NetDev& net, T* ws, const WsOff& o,
     if (lin_out) {
         for (int k = 0; k < nx; ++k) cL[(size_t)k * R + r] = mult[(size_t)k * mstride];
     } else {
-        const T* fo = ws + (size_t)o.fout * R;
         const T* P = ws + (size_t)(o.P + (nl - 1) * net.maxw * nin) * R;
         for (int k = 0; k < nx; ++k) {
-            const T av = fo[(size_t)k * R + r];
-            const T s1 = act_d1<T>(net.act[nl - 1], av, (T)net.actp[nl - 1]);
-            const T wgt = mult[(size_t)k * mstride] * (act_r2<T>(net.act[nl - 1], av, (T)net.actp[nl - 1]) * s1);
+            const T s1 = ws[(size_t)(o.d1s + (nl - 1) * net.maxw + k) * R + r];
+            const T wgt = mult[(size_t)k * mstride] * ws[(size_t)(o.d2s + (nl - 1) * net.maxw + k) * R + r];
             for (int p = 0; p < nin; ++p) {
                 const T pp = wgt * P[(size_t)(k * nin + p) * R + r];
                 for (int q = 0; q <= p; ++q)
@@ -323,13 +334,11 @@ __device__ void net_hessian_contracted(const NetDev& net, T* ws, const WsOff& o,
     }
     for (int l = nl - 2; l >= 0; --l) {
         const int wout = net.dout[l];
-        const T* a = ws + (size_t)(o.act + l * net.maxw) * R;
         const T* P = ws + (size_t)(o.P + l * net.maxw * nin) * R;
         T* c = ws + (size_t)(o.cot + cur * net.maxw) * R;  // delta_l (wrt a_l)
         for (int j = 0; j < wout; ++j) {
-            const T av = a[(size_t)j * R + r];
-            const T s1 = act_d1<T>(net.act[l], av, (T)net.actp[l]);
-            const T wgt = c[(size_t)j * R + r] * (act_r2<T>(net.act[l], av, (T)net.actp[l]) * s1);
+            const T s1 = ws[(size_t)(o.d1s + l * net.maxw + j) * R + r];
+            const T wgt = c[(size_t)j * R + r] * ws[(size_t)(o.d2s + l * net.maxw + j) * R + r];
             for (int p = 0; p < nin; ++p) {
                 const T pp = wgt * P[(size_t)(j * nin + p) * R + r];
                 for (int q = 0; q <= p; ++q)
@@ -530,13 +539,6 @@ int launch_rowhess_valu(Handle& h, int B, const void* Z, const void* X0, const v
     if (h.layered) {        // Discret / Unity blocks of wide / deep networks: the GEMM path (kernels_layered.hip)
         const int rc = launch_rowhess_layered(h, B, Z, X0, lambda, blocks, s);
         if (rc != NEMPC_EUNSUPPORTED) return rc;
-        // (the generic kernel writes every derivative from the layer OUTPUT: it has no form for swish / gelu, and must not be
-        // reached with them -- NEMPC_LAYERED_HESS=0 is an A/B switch for the monotone activations)
-        for (int l = 0; l < h.nl; ++l)
-            if (h.act[l] >= NEMPC_ACT_FIRST_ZBASED) {
-                set_error("nempc_hess: swish / gelu / softsign / mish / exponential / relu6 layers need the layered path's Hessian sweeps (NEMPC_LAYERED_HESS=0 is set?)");
-                return NEMPC_EUNSUPPORTED;
-            }
     }
     if (int rc = ensure_valu_ws(h)) return rc;
     const size_t rows = (size_t)B * h.cfg.H;

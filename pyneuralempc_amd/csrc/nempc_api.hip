@@ -393,21 +393,9 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
         }
     }
     h->variant = NEMPC_KERNEL_VALU;
-    // swish / gelu / softsign / mish / exponential / relu6: written from the pre-activation -- the layered path only, hidden layers only
-    bool zbased = false;
-    for (int l = 0; l < h->nl; ++l) zbased = zbased || h->act[l] >= NEMPC_ACT_FIRST_ZBASED;
-    if (zbased) {
-        const bool out_z = h->act[h->nl - 1] >= NEMPC_ACT_FIRST_ZBASED;
-        // (a single hidden layer under a non-linear output layer is the one shape whose Lagrangian blocks the layered
-        // path hands to the generic kernel)
-        const bool one_hidden_nonlin_out = h->nl == 2 && h->act[1] != NEMPC_ACT_LINEAR;
-        if (out_z || one_hidden_nonlin_out || !(cfg->kernel == NEMPC_KERNEL_AUTO || cfg->kernel == NEMPC_KERNEL_LAYERED) ||
-            !layered_supported(*h)) {
-            delete h;
-            return fail(NEMPC_EUNSUPPORTED, "nempc_create: swish / gelu / softsign / mish / exponential / relu6 layers run on the layered matrix-core path only (kernel AUTO or "
-                                            "LAYERED; hidden layers only, widths <= 1024, w*(nx+nu) <= 32, nx <= 16)");
-        }
-    }
+    // swish / gelu / softsign / mish / exponential / relu6 are written from the pre-activation: the layered path (any layer,
+    // the output layer included: its output step has z) and the generic kernel (which keeps s', s'' of every unit from its
+    // forward pass) take them; the register-resident matrix-core kernels do not (mfma_act stays -1 for such a network)
     if (cfg->kernel == NEMPC_KERNEL_MFMA || cfg->kernel == NEMPC_KERNEL_MFMA_TILE) {
         if (!mfma_supported(*h)) {
             delete h;

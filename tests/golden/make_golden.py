@@ -306,6 +306,11 @@ CASES = {
     # the non-monotone activations (derivatives from the pre-activation; the layered path only)
     "act_swish_gelu_box": (2, 1, [48, 40], 9, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True, 0, 0, ["swish", "gelu", "linear"]),
     "act_gelu_rk4": (2, 1, [40, 40], 7, orc.RK4, 0.2, None, 2, True, 0, 0, "gelu"),
+    # ... on the OUTPUT layer too (round 5: the layered path's output step and the generic kernel keep the pre-activation):
+    # Discret with box rows, and a single hidden layer under a non-linear output layer under RK4 (the layered Hessian
+    # hands that shape to the generic kernel)
+    "act_zout_box": (2, 1, [40, 32], 7, orc.DISCRET, 1.0, (-2.0, 2.0), 2, True, 0, 0, ["tanh", "swish", "gelu"]),
+    "act_zout_rk4": (2, 1, [24], 6, orc.RK4, 0.2, None, 2, True, 0, 0, ["gelu", "softsign"]),
 }
 
 
@@ -323,7 +328,8 @@ def check_network_derivatives_by_ad(net, n_in, seed=11, rows=3, with_hess=True):
         F = torch.nn.functional
         return {"linear": lambda z: z, "tanh": torch.tanh, "relu": torch.relu, "sigmoid": torch.sigmoid, "softplus": F.softplus,
                 "elu": lambda z: F.elu(z, alpha=par), "leaky_relu": lambda z: F.leaky_relu(z, negative_slope=par),
-                "selu": F.selu, "swish": F.silu, "gelu": F.gelu}[name]
+                "selu": F.selu, "swish": F.silu, "gelu": F.gelu, "softsign": F.softsign, "mish": F.mish, "exponential": torch.exp,
+                "relu6": F.relu6}[name]
 
     def f(xi):
         a = xi

@@ -19,7 +19,7 @@ ACT_RUNTIME_NAMES = ["act_mix3_c2", "act_mix2_rk4", "act_mix_c3_rk4", "deep4_mix
                      "deep4_c2"]
 # networks only the layer-at-a-time GEMM path (and the generic kernel) take: width > 128, more than three hidden layers
 WIDE_DEEP_NAMES = ["wide256_c2", "deep4_c2", "deep5_mixed_rk4"]
-ZBASED_NAMES = ["act_swish_gelu_box", "act_gelu_rk4"]     # swish / gelu: the layered path only
+ZBASED_NAMES = ["act_swish_gelu_box", "act_gelu_rk4", "act_zout_box", "act_zout_rk4"]     # swish / gelu ...: the layered path and the generic kernel
 ROLLING_NAMES = ["roll2_discret", "roll3_unity_rev", "roll3_discret_rev", "roll4_wide", "roll2_tvp_p", "roll4_short"]
 
 

@@ -43,7 +43,7 @@ _FP64_CASES = ([(n, k) for n in CASE_NAMES + ACT_UNIFORM_NAMES for k in ("valu",
                [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")] +
                [(n, k) for n in ACT_RUNTIME_NAMES for k in ("mfma", "mfma_tile")] +
                [(n, k) for n in ACT_RUNTIME_NAMES if n not in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")] +
-               [(n, "layered") for n in ZBASED_NAMES])        # (swish / gelu: derivatives from the pre-activation)
+               [(n, k) for n in ZBASED_NAMES for k in ("layered", "valu")])        # (swish / gelu ...: derivatives from the pre-activation)
 
 
 @pytest.mark.parametrize("name,kernel", _FP64_CASES)
@@ -74,7 +74,7 @@ def test_golden_fp64(name, kernel):
                                          ACT_UNIFORM_NAMES for k in ("valu", "mfma", "mfma_tile", "layered")] +
                          [(n, k) for n in ACT_MIXED_NAMES + WIDE_DEEP_NAMES for k in ("valu", "layered")] +
                          [(n, k) for n in ACT_RUNTIME_NAMES for k in ("mfma", "mfma_tile")] +
-                         [(n, "layered") for n in ZBASED_NAMES])
+                         [(n, k) for n in ZBASED_NAMES for k in ("layered", "valu")])
 def test_golden_fp32(name, kernel):
     d, W, b = load_case(name)
     eng = _engine(d, W, b, torch.float32, kernel)
@@ -91,7 +91,7 @@ def test_golden_fp32(name, kernel):
                          [(n, k) for n in ACT_RUNTIME_NAMES if n != "act_mix_c3_rk4" for k in ("mfma", "mfma_tile")] +
                          [(n, k) for n in ACT_RUNTIME_NAMES if n not in ACT_MIXED_NAMES + WIDE_DEEP_NAMES + ["act_mix_c3_rk4"]
                           for k in ("valu", "layered")] +
-                         [(n, "layered") for n in ZBASED_NAMES])
+                         [(n, k) for n in ZBASED_NAMES for k in ("layered", "valu")])
 def test_golden_hessian_fp64(name, kernel):
     d, W, b = load_case(name)
     eng = _engine(d, W, b, torch.float64, kernel)
@@ -615,12 +615,16 @@ def test_mixed_activations_run_on_the_layered_path_and_are_refused_by_the_regist
         CallbackEngine(nso.W, nso.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", kernel="mfma", activations=nso.act)
     with pytest.raises(NotImplementedError, match="hard_sigmoid"):
         CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["hard_sigmoid", "tanh", "linear"])
-    # swish / gelu: the layered path only (their derivatives need the pre-activation)
+    # swish / gelu ... (derivatives from the pre-activation): the layered path, the generic kernel by name, any layer -- the
+    # output layer included (round 5); never the register-resident kernels
     assert CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["swish", "gelu", "linear"]).kernel_variant == "layered"
-    with pytest.raises(_lib.NempcError, match="swish / gelu"):
-        CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", kernel="valu", activations=["swish", "gelu", "linear"])
-    with pytest.raises(_lib.NempcError, match="swish / gelu"):
-        CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["tanh", "tanh", "gelu"])
+    assert CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", kernel="valu", activations=["swish", "gelu", "linear"]).kernel_variant == "valu"
+    zo = CallbackEngine(net.W, net.b, 6, 2, 1, dtype=torch.float64, device="cuda:0", max_batch=4, activations=["tanh", "tanh", "gelu"])
+    assert zo.kernel_variant == "layered"
+    nzo = orc.MLP(net.W, net.b, ["tanh", "tanh", "gelu"])
+    np.testing.assert_allclose(zo.eval_numpy(Zh, X0h)["jac_dense"], orc.Problem(nzo, 6, 2, 1).eval_batch(Zh, X0h)[3], **F64)
+    with pytest.raises(_lib.NempcError, match="activations"):
+        CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", kernel="mfma", activations=["swish", "gelu", "linear"])
     with pytest.raises(ValueError, match="one name per dense layer"):
         CallbackEngine(net.W, net.b, 6, 2, 1, device="cuda:0", activations=["tanh", "linear"])
     # a non-linear OUTPUT layer with one hidden activation is a mix too
