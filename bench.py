@@ -194,13 +194,14 @@ def _sanitize(x):
     return x
 
 
-def write_details(full, also_stderr=True):
+def write_details(full, also_stderr=True, name=None):
     """the detailed record: DETAILS_FILE next to bench.py's caller (and under gpurun_out/ when that directory exists, so
     that a gpurun call brings it back), echoed on stderr"""
     text = json.dumps(_sanitize(full), allow_nan=False, indent=1)
-    paths = [os.path.join(os.getcwd(), DETAILS_FILE)]
+    name = name or DETAILS_FILE
+    paths = [os.path.join(os.getcwd(), name)]
     if os.path.isdir(os.path.join(REPO, "gpurun_out")):
-        paths.append(os.path.join(REPO, "gpurun_out", DETAILS_FILE))
+        paths.append(os.path.join(REPO, "gpurun_out", os.path.basename(name)))
     for pth in paths:
         try:
             with open(pth, "w") as fh:
@@ -750,7 +751,7 @@ class Rank:
         """rank 0: detailed record to the side file and stderr, then the driver's line as the LAST stdout line"""
         if self.rank != 0:
             return
-        write_details(full)
+        write_details(full, name=self.args.details_file)
         sys.stdout.flush()
         os.dup2(self.saved_stdout, 1)
         print(driver_line(full), flush=True)
@@ -1202,7 +1203,8 @@ def main():
     ap.add_argument("--prime-ms", type=float, default=40.0,
                     help="untimed run of the headline step before the warm-up steps, to reach the sustained clock (0: off)")
     ap.add_argument("--solver-iters", type=int, default=64)
-    ap.add_argument("--pmc-file", default="r04_c2_b1024_pmc.json")
+    ap.add_argument("--pmc-file", default="r05_c2_b1024_pmc.json")
+    ap.add_argument("--details-file", default=None, help="name of the detailed record (default: bench_details.json)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

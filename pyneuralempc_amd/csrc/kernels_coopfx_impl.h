@@ -37,18 +37,8 @@
 #define FX_STAMP_PRO(p, i) do { } while (0)
 #endif
 
-// A/B (tools/build_variant.py -DNEMPC_FX_SETPRIO=1): raised wave priority over the matrix-instruction blocks.  Measured, round 4
-// (tools/quick_bench.py, two runs each): 15.92 / 16.03 us without, 15.89 / 15.93 us with it at C2 B=1024 -- no effect; off.
-#ifndef NEMPC_FX_SETPRIO
-#define NEMPC_FX_SETPRIO 0
-#endif
-#if NEMPC_FX_SETPRIO
-#define FX_PRIO(p) __builtin_amdgcn_s_setprio(p)
-#else
-#define FX_PRIO(p) \
-    do {           \
-    } while (0)
-#endif
+// (Raised wave priority -- s_setprio -- over the matrix-instruction blocks was measured in round 4: 15.89 / 15.93 us against
+// 15.92 / 16.03 without; no effect, removed.)
 
 namespace nempc {
 
@@ -393,7 +383,6 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
         for (int r = 0; r < 4; ++r) b0[r] = bias[r * 4 + q];
 #pragma unroll
         for (int j = 0; j < NT; ++j) a[l][j] = b0;
-        FX_PRIO(1);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -401,7 +390,6 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     a[l][j] = Ops::mma(W.wf[l - 1][mt * 4 + r], X[((j * MT + mt) * 4 + r) * 64 + lane], a[l][j]);
-        FX_PRIO(0);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -461,16 +449,14 @@ __device__ __forceinline__ void fx_pass(const FxCtx<T, WP, NH, TPW, NX, NU>& cx,
             V4 cn[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) cn[j] = V4{T(0), T(0), T(0), T(0)};
-            FX_PRIO(1);
-#pragma unroll
+    #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         cn[j] = Ops::mma(W.wb[l - 1][mt * 4 + r], X[((j * MT + mt) * 4 + r) * 64 + lane], cn[j]);
-            FX_PRIO(0);
-#pragma unroll
+    #pragma unroll
             for (int j = 0; j < NT; ++j) cv[j] = cn[j] * a[l - 1][j];
         }
         // last reverse step onto the NIN inputs, on the vector unit: J[k][d] partial = sum_r cv_r * W0[d][f(q,r)]

@@ -36,12 +36,8 @@ namespace nempc {
 
 namespace {
 
-#ifndef NEMPC_LG_PAD
-#define NEMPC_LG_PAD 16      // elements of padding per LDS tile row (A/B: tools/build_variant.py -DNEMPC_LG_PAD=0)
-#endif
-#ifndef NEMPC_LG_WPE
-#define NEMPC_LG_WPE 4       // waves per SIMD the GEMM kernel's register allocation must allow
-#endif
+constexpr int LG_PAD = 16;     // elements of padding per LDS tile row (0 and 8 measured slower, round 4)
+constexpr int LG_WPE = 4;      // waves per SIMD the GEMM kernel's register allocation must allow
 constexpr int LG_BM = 64, LG_BN = 64, LG_BK = 16;
 
 enum { LG_FORWARD = 0, LG_REVERSE = 1 };
@@ -108,8 +104,8 @@ struct LgShape {
     static constexpr int BM = 16 * RM;          // rows (columns of the transposed product) per workgroup: RM 16-row tiles per wave
     static constexpr int BN = 64 * FT;
     static constexpr int BK = FT == 4 ? 8 : 16;
-    static constexpr int LDW = BN + NEMPC_LG_PAD;       // (padding: the four k-rows of a fragment read land on different banks;
-    static constexpr int LDA = BM + NEMPC_LG_PAD;    //  +8 with four workgroups per CU measured 6 % slower)
+    static constexpr int LDW = BN + LG_PAD;       // (padding: the four k-rows of a fragment read land on different banks;
+    static constexpr int LDA = BM + LG_PAD;    //  +8 with four workgroups per CU measured 6 % slower)
     static constexpr int TILE = BK * (LDW + LDA);      // elements per buffer
 };
 
@@ -136,7 +132,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rows_rsrc(const T* base, in
 }
 
 template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE, int RM = 4>
-__global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : NEMPC_LG_WPE) void layered_gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void layered_gemm_kernel(GemmArgs a) {
 
     constexpr int BM = 16 * RM;
     static_assert(!(SEED || CONTRACT) || FT == 1, "the fused forms exist for the 64-feature block only");
@@ -250,28 +246,17 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : NEMPC_LG_WPE) v
 #pragma unroll
         for (int ks = 0; ks < BK / 4; ++ks) {
             T af[FT], bf[RM];
-#ifdef NEMPC_LG_EXP_NOLDS
-#pragma unroll
-            for (int fn = 0; fn < FT; ++fn) af[fn] = T(1) + T(ks);
-#pragma unroll
-            for (int rm = 0; rm < RM; ++rm) bf[rm] = T(2) + T(rm);
-#else
 #pragma unroll
             for (int fn = 0; fn < FT; ++fn) af[fn] = Ws(buf, 4 * ks + q, fb + 16 * fn + c);
 #pragma unroll
             for (int rm = 0; rm < RM; ++rm) bf[rm] = As(buf, 4 * ks + q, 16 * rm + c);
-#endif
 #pragma unroll
             for (int fn = 0; fn < FT; ++fn)
 #pragma unroll
                 for (int rm = 0; rm < RM; ++rm) acc[fn][rm] = Ops::mma(af[fn], bf[rm], acc[fn][rm]);
         }
     };
-    auto chunk_barrier = [&]() {
-#ifndef NEMPC_LG_EXP_NOBARRIER
-        __syncthreads();
-#endif
-    };
+    auto chunk_barrier = [&]() { __syncthreads(); };
     ChunkRegs c0, c1;           // c0: even chunks, c1: odd chunks
     load_chunk(0, c0);
     load_chunk(1, c1);
@@ -281,36 +266,23 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : NEMPC_LG_WPE) v
     // every pass and every copy waited out the matrix pipe); an odd last chunk follows the loop
     // pairs of chunks, no branch in the body: the compiler's wait-count bookkeeping stays exact -- a wait for the OLDER set only
     // (behind a branch it falls back to vmcnt(0) and the lead is gone); loads beyond the last chunk return zeros.  An odd
-    // last chunk follows the loop.  (NEMPC_LG_EXP_NOLOAD: timing experiment of tools/lg_limiter_exp.sh, never defined in
-    // the shipped build)
+    // last chunk follows the loop.
     int ch = 0;
     for (; ch + 1 < nchunks; ch += 2) {
-#ifndef NEMPC_LG_EXP_NOLOAD
         load_chunk(ch + 2, c0);
         __builtin_amdgcn_sched_barrier(0);      // (issued HERE: left alone, the scheduler sinks the loads under the matrix instructions and half the lead is gone)
-#endif
         mma_chunk(0);
-#ifndef NEMPC_LG_EXP_NOLOAD
         store_chunk(1, c1);
-#endif
         chunk_barrier();
-#ifndef NEMPC_LG_EXP_NOLOAD
         load_chunk(ch + 3, c1);
         __builtin_amdgcn_sched_barrier(0);
-#endif
         mma_chunk(1);
-#ifndef NEMPC_LG_EXP_NOLOAD
         store_chunk(0, c0);
-#endif
         chunk_barrier();
     }
     if (ch < nchunks) mma_chunk(0);
-#ifdef NEMPC_LG_EXP_NOEPI
-    if (acc[0][0][0] == T(12345.678)) static_cast<T*>(a.C)[0] = acc[0][1][1] + acc[0][2][2] + acc[0][3][3];
-    return;
-#endif
     // Where a 256 x 256 reverse product (B*H = 20480, fp64; 68 us at the matrix peak) spends its 148 us, by leaving parts out
-    // (gpurun_out/r04_lg_limiter.txt): no epilogue 110 us, no global loads 118, no LDS reads 143, no barrier 149, none of
+    // (profiles/r04_layered_gemm_limiter.txt; the experiment's switches are gone from the source): no epilogue 110 us, no global loads 118, no LDS reads 143, no barrier 149, none of
     // loads / LDS / barrier 125.  The epilogue's dependent round trip for s'(z) at the end of every workgroup is the largest
     // piece; requesting those values under the last chunk's matrix instructions costs 32 more registers (occupancy 3 instead
     // of 4-5) and measured no better overall (355 vs 360 us for the whole 2 x 256 evaluation, 34.5 vs 32.4 ms at 4 x 512).
@@ -328,7 +300,7 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : NEMPC_LG_WPE) v
         // operand (kernels_mfma_impl.h), and sum_n Wc[n][d] E[n][m] is four more matrix instructions per column tile with
         // Wc's fragment as A operand.  The four waves' sums (16 features each) meet in LDS in wave order; feature blocks
         // meet in layered_jreduce_kernel / layered_outfinish_kernel in block order: the summation order is fixed.
-        constexpr int LDP = RM == 4 ? (NEMPC_LG_PAD == 0 ? 64 : (sizeof(T) == 8 ? 80 : 68))       // (f64: q's rows 128 B apart mod 256; f32: 64 B)
+        constexpr int LDP = RM == 4 ? (LG_PAD == 0 ? 64 : (sizeof(T) == 8 ? 80 : 68))       // (f64: q's rows 128 B apart mod 256; f32: 64 B)
                                     : BM + 8;
         static_assert((size_t)4 * 16 * LDP <= (size_t)2 * S::TILE, "partial tiles fit the operand buffers");
         const T* __restrict__ W0 = static_cast<const T*>(a.w0t);

@@ -117,100 +117,6 @@ struct SolverArgs {
 // bound with a small multiplier, where mu/dl^2 explodes -- the stragglers of the primal version were exactly the
 // problems whose steps kept being cut by the boundary (NEMPC_SOLVER_TRACE).  Both terms keep the LQ structure.
 // Runs before the LQ kernel: writes the diagonal bh and folds the barrier gradient into grad.
-// Block-wise convexification of the stage Hessians (round 4).  The Riccati sweep needs positive definite control Hessians;
-// the exact Lagrangian blocks W_t = sum_k lambda_{t,k} d2 Phi_k are indefinite once the multipliers are large (order 250-450
-// at configs[2] dims), and the uniform Levenberg term the sweep falls back on then oscillates 0.1 <-> 1 <-> 10: every other
-// iteration restarts and the steps are those of a heavily damped Newton method.  Here a problem whose last sweep needed
-// damping (its term has not relaxed below `thr` yet) gets every stage block M_t = W_t + blockdiag(Qs, Rs) -- the objective's
-// share of those variables included -- replaced by V |D| V^T, its eigenvalues mirrored (floor eps_rel * max |d|): the sum
-// of the embedded blocks, and with it every Quu of the sweep, is then positive definite without a shift of the good
-// directions, and the block keeps its exact curvature wherever that was already positive.  Problems that have not needed
-// damping keep the exact blocks (and Newton's local rate).  Cyclic Jacobi per block, a thread per (problem, step); nin <= 16.
-template <typename T>
-__global__ __launch_bounds__(64) void solver_convexify_kernel(int B, int H, int nx, int nu, T* __restrict__ hblk,
-                                                             const T* __restrict__ obj, ObjOffsets oo, const T* __restrict__ reg,
-                                                             const int* __restrict__ status, double thr, double eps_rel) {
-    constexpr int NM = 16;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * H) return;
-    const int b = idx / H, t = idx - b * H;
-    if (status[b] >= 0 || !((double)reg[b] >= thr)) return;
-    const int nin = nx + nu;
-    const int o0 = t == 0 ? nx : 0;                 // step 0: x_{-1} = x0 is data, only the control block enters the sweep
-    const int n = nin - o0;
-    T* W = hblk + (size_t)idx * nin * nin;
-    const T* Qs = obj + oo.Qs;
-    const T* Rs = obj + oo.Rs;
-    double A[NM][NM], V[NM][NM];
-    auto objv = [&](int i, int j) -> double {      // blockdiag(Qs, Rs) at (i, j) of the [x | u] block
-        if (i < nx && j < nx) return (double)Qs[i * nx + j];
-        if (i >= nx && j >= nx) return (double)Rs[(i - nx) * nu + (j - nx)];
-        return 0.0;
-    };
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            const int gi = i + o0, gj = j + o0;
-            A[i][j] = 0.5 * ((double)W[gi * nin + gj] + (double)W[gj * nin + gi]) + 0.5 * (objv(gi, gj) + objv(gj, gi));
-            V[i][j] = i == j ? 1.0 : 0.0;
-        }
-    // cheap exit: Gershgorin says positive definite already
-    bool maybe_indef = false;
-    for (int i = 0; i < n; ++i) {
-        double r = 0.0;
-        for (int j = 0; j < n; ++j)
-            if (j != i) r += fabs(A[i][j]);
-        if (!(A[i][i] - r > 0.0)) maybe_indef = true;
-    }
-    if (!maybe_indef) return;
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        double off = 0.0, dia = 0.0;
-        for (int i = 0; i < n; ++i) {
-            dia += A[i][i] * A[i][i];
-            for (int j = i + 1; j < n; ++j) off += A[i][j] * A[i][j];
-        }
-        if (!(off > 1e-26 * (dia + off))) break;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = A[p][q];
-                if (fabs(apq) < 1e-300) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
-                for (int k = 0; k < n; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - sn * akq;
-                    A[k][q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - sn * aqk;
-                    A[q][k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < n; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - sn * vkq;
-                    V[k][q] = sn * vkp + c * vkq;
-                }
-            }
-    }
-    double dmax = 0.0, dmin = 1e300;
-    for (int i = 0; i < n; ++i) {
-        dmax = fmax(dmax, fabs(A[i][i]));
-        dmin = fmin(dmin, A[i][i]);
-    }
-    const double floor_ = eps_rel * fmax(dmax, 1e-300);
-    if (dmin >= floor_) return;                     // positive definite after all: the exact block stays
-    if (!(dmax < 1e300)) return;                    // (a NaN / Inf block: leave it to the sweep's own handling)
-    for (int i = 0; i < n; ++i) A[i][i] = fmax(fabs(A[i][i]), floor_);
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            double v = 0.0;
-            for (int k = 0; k < n; ++k) v += V[i][k] * A[k][k] * V[j][k];
-            const int gi = i + o0, gj = j + o0;
-            W[gi * nin + gj] = (T)(v - 0.5 * (objv(gi, gj) + objv(gj, gi)));
-        }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void solver_barrier_kernel(SolverArgs a) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2686,17 +2592,9 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
                            (const T*)nullptr, (T*)ws.gt, (T*)nullptr, (T*)nullptr, (T*)nullptr);
         return NEMPC_OK;
     };
-    // NEMPC_SOLVER_CONVEXIFY: 0 off (uniform Levenberg term only: the default), 1 mirrored stage blocks for the problems whose
-    // damping is at or above NEMPC_SOLVER_CONVEX_THR, 2 for every unfinished problem.  Measured at configs[2] dims, B = 1024
-    // (gpurun_out/r04_convex_c3.txt): converged after 40 / 60 / 80 / 160 iterations 664 / 825 / 918 / 1008 (off), 699 / 866 /
-    // 936 / 1017 (1), 614 / 861 / 953 / 1021 (2) -- a few per cent more problems through, NOT the >= 85 % at 40 iterations that
-    // was hoped for: indefiniteness is not what holds these solves back (the median problem needs 22-28 iterations either
-    // way; the steps are short because the l1 merit's penalty tracks multipliers of order 250-450).  The per-thread Jacobi costs
-    // 1.5 ms per iteration as written (88 -> 151 ms per 40 iterations), so it stays an A/B knob.
-    static const int convexify = [] { const char* e = getenv("NEMPC_SOLVER_CONVEXIFY"); return e ? atoi(e) : 0; }();
-    static const double convex_thr_env = [] { const char* e = getenv("NEMPC_SOLVER_CONVEX_THR"); return e ? atof(e) : 1e-5; }();
-    static const double convex_eps = [] { const char* e = getenv("NEMPC_SOLVER_CONVEX_EPS"); return e ? atof(e) : 1e-6; }();
-    const double convex_thr = convexify >= 2 ? 0.0 : convex_thr_env;
+    // (A block-wise mirrored convexification of the stage Hessians, for the problems whose sweep needed damping, was built and
+    // measured in round 4 -- profiles/r04_solver_convexify_c3.txt: +3 - 5 % problems converged at 1.5 ms per iteration; removed
+    // in round 5: indefiniteness is not what holds the configs[2] solves back, DESIGN "Batched solver".)
     for (; it < o.max_iter; ++it) {
         a.B = Bact;
         a.cur_it = it;
@@ -2744,13 +2642,6 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
                                                 : launch_rowhess_valu(h, Bact, Zc, X0c, ws.lamc[cur], ws.hblk, s);
         }
         if (rc) return rc;
-        // block-wise convexification for the problems whose last sweep needed damping (solver_convexify_kernel).  Not on the
-        // compiled 2/1 path, where the blocks of an accepted trial are carried over inside the LQ kernel itself.
-        if (convexify && !rolling && !have_eval && !(carry && hess_trial) && nin <= 16) {
-            hipLaunchKernelGGL(solver_convexify_kernel<T>, dim3((unsigned)(((size_t)Bact * H + 63) / 64)), dim3(64), 0, s, Bact, H, nx, nu,
-                               (T*)ws.hblk, (const T*)a.obj, a.oo, (const T*)a.reg, (const int*)a.status, convex_thr, convex_eps);
-            NEMPC_HIP(hipGetLastError());
-        }
         if (!fused_eval && (rc = launch_objective(h, Bact, Zc, ws.f, ws.grad, s))) return rc;
         // bounds: barrier diagonal for the LQ model, barrier gradient folded into grad
         if (!a.use_lds) hipLaunchKernelGGL(solver_barrier_kernel<T>, dim3(gAn), dim3(256), 0, s, a);

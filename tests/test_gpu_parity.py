@@ -882,6 +882,54 @@ def test_layered_products_with_an_odd_number_of_chunks_on_a_full_chip(hidden, ac
         np.testing.assert_allclose(h1[s0], ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
 
 
+_AB_WORKER = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from oracle import nempc_oracle as orc
+from pyneuralempc_amd import CallbackEngine
+out = {}
+for tag, hidden, acts, nx, nu, integ in (("a", [200, 136], ["tanh", "sigmoid", "linear"], 2, 1, "discret"), ("b", [144], "tanh", 3, 2, "rk4")):
+    H, B, DT = 6, 90, (0.1 if integ == "rk4" else 1.0)
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=5, activations=acts)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=torch.float64, device="cuda:0", max_batch=B,
+                         activations=net.act, kernel="layered")
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=6)
+    r = eng.eval_numpy(Zh, X0h, want=("g", "jac_tiles"))
+    lam = np.random.default_rng(2).normal(size=(B, eng.m))
+    hv = eng.hess(eng.to_device(Zh), eng.to_device(X0h), eng.to_device(lam), eng.to_device(np.ones(B)))["hvals"].cpu().numpy()
+    out[tag + "_g"], out[tag + "_J"], out[tag + "_H"] = r["g"], r["jac_tiles"], hv
+    out[tag + "_hk"] = np.array([len(eng.last_hess_kernel)])
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_layered_path_run_time_switches_agree_with_the_default(tmp_path):
+    """The layered path's run-time switches -- NEMPC_LAYERED_FUSE=0 (seed kernel, plain products, skinny last steps: also the
+    reverse sweep every single-hidden-layer network takes), NEMPC_LG_RM=2 / 4 and NEMPC_LG_RM_REV=2 (32- / 64-row blocks),
+    NEMPC_LAYERED_HESS=0 (Lagrangian blocks from the generic kernel) -- are read once per process: each runs in a process of
+    its own and has to reproduce the default's rows and Lagrangian blocks to rounding (round-4 review: switches nobody tests
+    are build variants nobody knows)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_AB_WORKER)
+    res = {}
+    for name, env in (("default", {}), ("nofuse", {"NEMPC_LAYERED_FUSE": "0"}), ("rm2", {"NEMPC_LG_RM": "2"}), ("rm4", {"NEMPC_LG_RM": "4"}),
+                      ("rmrev2", {"NEMPC_LG_RM_REV": "2"}), ("nohess", {"NEMPC_LAYERED_HESS": "0"})):
+        out = tmp_path / (name + ".npz")
+        r = subprocess.run([sys.executable, str(script), repo, str(out)], env=dict(os.environ, **env), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-1500:])
+        res[name] = dict(np.load(out))
+    ref = res["default"]
+    for name, got in res.items():
+        for k in ("a_g", "a_J", "a_H", "b_g", "b_J", "b_H"):
+            np.testing.assert_allclose(got[k], ref[k], rtol=0, atol=1e-11 * max(1.0, np.abs(ref[k]).max()), err_msg=f"{name}/{k}")
+    assert res["nohess"]["a_hk"][0] != ref["a_hk"][0]            # (the switch did switch: another kernel's name)
+
+
 def test_layered_path_chunks_large_batches():
     """More rows than one workspace chunk holds (NEMPC_LAYERED_CHUNK_ROWS shrinks the chunk for the test): the chunk loop,
     with a last chunk that is not a whole GEMM block, gives the rows of the one-chunk evaluation bit for bit."""
