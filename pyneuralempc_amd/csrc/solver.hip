@@ -226,7 +226,7 @@ template <typename T>
 __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* __restrict__ Zt, const T* __restrict__ gt,
                                                   const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls,
                                                   const int* __restrict__ list_in, int* __restrict__ list_out,
-                                                  int publish, int slot, int lane, int* n_active_word, int tag);
+                                                  int publish, int slot, int lane, int* n_active_word, int tag, int soc = 0);
 
 #ifdef NEMPC_LQ_STAMPS
 __device__ long long nempc_lq_stamps[16];
@@ -1648,7 +1648,7 @@ template <typename T>
 __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* __restrict__ Zt, const T* __restrict__ gt,
                                                   const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls,
                                                   const int* __restrict__ list_in, int* __restrict__ list_out,
-                                                  int publish, int slot, int lane, int* n_active_word, int tag) {
+                                                  int publish, int slot, int lane, int* n_active_word, int tag, int soc) {
     // list_in: the trial buffers (Zt, gt, ft) hold only the problems that were still searching after the previous trial,
     // densely, in the order of that list (inner-loop backtracking); null: one slot per problem.  list_out: the problems
     // this trial rejects are appended for the next one.  slot / lane: the problem slot this wave works on; n_active_word /
@@ -1686,7 +1686,9 @@ __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* 
     // array the merit value and the acceptance read (the loops below take it from registers in their first trip), the
     // first trips of the carried-over tiles / blocks -- and the objective's own loads follow in the same flight.
     const int done = a.lsdone[b];
-    const T mub = mu[b], nub = nu[b], al = alpha[b], ph0 = phi0[b], drb = dir[b];
+    // (soc: the second-order-correction trial of a step that was just rejected -- its length is the one that trial had;
+    //  alpha[b] was halved on the rejection)
+    const T mub = mu[b], nub = nu[b], al = soc ? alpha[b] * T(2) : alpha[b], ph0 = phi0[b], drb = dir[b];
     T ftb = ft ? ft[slot] : T(0);
     const T az = a.primal_dual ? ((const T*)a.alz)[b] : T(0);
     const T lsr = info[INFO_LSR], lsk = info[INFO_LSK], regb = reg[b];
@@ -1826,6 +1828,10 @@ __device__ __forceinline__ void solver_merit_body(const SolverArgs& a, const T* 
             if (!(lsr > T(0))) reg[b] = fmax(regb * (T)a.reg_relax, T(1e-9));
             ((T*)a.info)[(size_t)b * INFO_N + INFO_LSK] = T(0);
         }
+    } else if (lane == 0 && soc) {
+        // the corrected point is no better: the backtracking goes on from the halved length the rejection left
+        const int p = atomicAdd(a.n_pending, 1);
+        if (list_out) list_out[p] = b;
     } else if (lane == 0) {
         alpha[b] = al * T(0.5);
         if (last_ls == 2) {
@@ -1870,9 +1876,9 @@ template <typename T>
 __global__ __launch_bounds__(64) void solver_merit_kernel(SolverArgs a, const T* __restrict__ Zt, const T* __restrict__ gt,
                                                           const T* __restrict__ ft, T* __restrict__ Zcur, int last_ls,
                                                           const int* __restrict__ list_in, int* __restrict__ list_out,
-                                                          int publish, int seq) {
+                                                          int publish, int seq, int soc = 0) {
     solver_merit_body<T>(a, Zt, gt, ft, Zcur, last_ls, list_in, list_out, publish, (int)blockIdx.x, (int)threadIdx.x, a.n_active,
-                         a.cur_it + 1);
+                         a.cur_it + 1, soc);
     if (seq > 0 && threadIdx.x == 0) {
         __threadfence();                                    // this block's list entry and count are out
         const int t = atomicAdd(a.n_done, 1);
@@ -1903,6 +1909,44 @@ __global__ __launch_bounds__(64) void solver_trial_list_kernel(int n, int nx, in
     const int b = list[slot];
     const T al = alpha[b];
     for (int i = lane; i < n; i += 64) Zt[(size_t)slot * n + i] = fma(al, dz[(size_t)b * n + i], Z[(size_t)b * n + i]);
+    for (int i = lane; i < nx; i += 64) X0p[(size_t)slot * nx + i] = X0[(size_t)b * nx + i];
+    for (int i = lane; i < ex_per; i += 64) exp_[(size_t)slot * ex_per + i] = ex[(size_t)b * ex_per + i];
+}
+
+// Second-order correction against the Maratos effect (inner-loop backtracking).  A full SQP step along a curved constraint
+// manifold leaves defects c+ = c(z + alpha d) of second order in |d|; times the l1 merit's penalty (which tracks multipliers of
+// order 250 - 700 at configs[2] dims) they outweigh the decrease of the objective and the step is cut to a few per cent for
+// dozens of iterations (DESIGN "Batched solver", tools/c3_slow_trace.py).  The correction removes them to first order with the
+// Jacobian of the ITERATE, which is already in hand: states only, dx_t = A_t dx_{t-1} + c+_t (dx_{-1} = 0: x0 is data) --
+// a particular solution of  A delta = -c+  of the size of c+ itself -- one forward recursion per rejected problem, a wave each.
+// The corrected points of the problems on `list` go to Zs densely (with their x0 / extras, like solver_trial_list_kernel),
+// one defect-only row launch evaluates them, and the acceptance test takes them at the rejected trial's step length.  A
+// corrected state that leaves its bounds makes the barrier term NaN and is rejected by the test itself.
+template <typename T>
+__global__ __launch_bounds__(64) void solver_soc_kernel(int n, int nx, int nu, int H, int m, int ex_per, const int* __restrict__ list,
+                                                        const T* __restrict__ Zt, const T* __restrict__ gt,
+                                                        const T* __restrict__ tiles, const T* __restrict__ X0,
+                                                        const T* __restrict__ ex, T* __restrict__ Zs, T* __restrict__ X0p,
+                                                        T* __restrict__ exp_, int* __restrict__ n_pending) {
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (slot == 0 && lane == 0) *n_pending = 0;
+    const int b = list[slot];
+    const int nin = nx + nu;
+    const T* zt = Zt + (size_t)b * n;                   // (the rejected trial ran over every active problem: slot == problem)
+    const T* ct = gt + (size_t)b * m;
+    T* zs = Zs + (size_t)slot * n;
+    T dx = T(0);                                        // lane i < nx: dx_{t-1}[i]
+    for (int t = 0; t < H; ++t) {
+        const T* At = tiles + ((size_t)b * H + t) * nx * nin;        // row i: dPhi_i / d[x_{t-1} | u_t]
+        T acc = lane < nx ? ct[t * nx + lane] : T(0);
+        for (int e = 0; e < nx; ++e) {
+            const T de = __shfl(dx, e);
+            if (lane < nx) acc = fma(At[lane * nin + e], de, acc);
+        }
+        dx = acc;
+        if (lane < nx) zs[t * nx + lane] = zt[t * nx + lane] + dx;
+    }
+    for (int i = H * nx + lane; i < n; i += 64) zs[i] = zt[i];
     for (int i = lane; i < nx; i += 64) X0p[(size_t)slot * nx + i] = X0[(size_t)b * nx + i];
     for (int i = lane; i < ex_per; i += 64) exp_[(size_t)slot * ex_per + i] = ex[(size_t)b * ex_per + i];
 }
@@ -2143,6 +2187,7 @@ struct SolverWs {
     void *tiles_t = nullptr, *grad_t = nullptr;     // trial point's tiles and objective gradient (carried over on acceptance)
     void *lam_t = nullptr, *hblk_t = nullptr;       // ... its multipliers and Lagrangian blocks (blocks + evaluation in one launch)
     void *X0p = nullptr, *exp_ = nullptr;           // initial states / extras of the problems still backtracking, dense
+    void *Zsoc = nullptr, *gsoc = nullptr;          // second-order-correction trial points and their defects, dense
     int* pend[2] = {nullptr, nullptr};              // ... and their indices (two lists: one read, one appended to)
     void *lb = nullptr, *ub = nullptr, *mu = nullptr, *nu = nullptr, *reg = nullptr, *alpha = nullptr, *phi0 = nullptr,
          *dir = nullptr, *hblk = nullptr, *lam = nullptr, *lamn = nullptr, *sig = nullptr, *dz = nullptr, *Kst = nullptr, *kst = nullptr, *Pst = nullptr, *pst = nullptr,
@@ -2179,7 +2224,7 @@ void solver_free(Handle& h) {
     if (!w) return;
     void** ptrs[] = {&w->Zt, &w->f, &w->ft, &w->grad, &w->g, &w->gt, &w->tiles, &w->lb, &w->ub, &w->mu, &w->nu, &w->reg,
                      &w->alpha, &w->phi0, &w->dir, &w->hblk, &w->lam, &w->lamn, &w->sig, &w->dz, &w->Kst, &w->kst, &w->Pst, &w->pst, &w->tmp,
-                     &w->tiles_t, &w->grad_t, &w->X0p, &w->exp_, &w->lam_t, &w->hblk_t};
+                     &w->tiles_t, &w->grad_t, &w->X0p, &w->exp_, &w->lam_t, &w->hblk_t, &w->Zsoc, &w->gsoc};
     for (void** p : ptrs)
         if (*p) (void)hipFree(*p);
     if (w->lsdone) (void)hipFree(w->lsdone);
@@ -2244,7 +2289,8 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
                 {&w2.kst, Bn * H * nu * e}, {&w2.Pst, Bn * H * nx * nx * e}, {&w2.pst, Bn * H * nx * e},
                 {&w2.tmp, Bn * lq_tmp_elems(nx, nu) * e}, {&w2.dzl, Bn * n * e}, {&w2.dzu, Bn * n * e}, {&w2.alz, Bn * e},
                 {&w2.bh, Bn * n * e}, {&w2.tiles_t, Bn * H * nx * nin * e}, {&w2.grad_t, Bn * n * e},
-                {&w2.X0p, Bn * nx * e}, {&w2.exp_, Bn * ex_per * e}, {&w2.lam_t, Bn * m * e}, {&w2.hblk_t, Bn * H * nin * nin * e}};
+                {&w2.X0p, Bn * nx * e}, {&w2.exp_, Bn * ex_per * e}, {&w2.lam_t, Bn * m * e}, {&w2.hblk_t, Bn * H * nin * nin * e},
+                {&w2.Zsoc, Bn * n * e}, {&w2.gsoc, Bn * m * e}};
             for (auto& x : al) NEMPC_HIP(hipMalloc(x.p, x.bytes ? x.bytes : 16));
             for (int k = 0; k < 2; ++k) {
                 struct { void** p; size_t bytes; } al2[] = {
@@ -2595,6 +2641,7 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
     // (A block-wise mirrored convexification of the stage Hessians, for the problems whose sweep needed damping, was built and
     // measured in round 4 -- profiles/r04_solver_convexify_c3.txt: +3 - 5 % problems converged at 1.5 ms per iteration; removed
     // in round 5: indefiniteness is not what holds the configs[2] solves back, DESIGN "Batched solver".)
+    const bool soc_env = [] { const char* e = getenv("NEMPC_SOLVER_SOC"); return !(e && atoi(e) == 0); }();      // (read per solve)
     for (; it < o.max_iter; ++it) {
         a.B = Bact;
         a.cur_it = it;
@@ -2693,8 +2740,32 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
         // (rolling: one trial per iteration whatever was asked for -- the dense trial lists of the inner loop would need the
         //  callbacks' x0 / history gathered per list)
         const int lsm = rolling ? 2 : (o.linesearch == 0 ? (wave_wanted ? 1 : 2) : o.linesearch);
+        // second-order correction of rejected full steps: inner-loop backtracking only (the deferred form accepts inside the
+        // next LQ kernel); NEMPC_SOLVER_SOC=0 switches it off (A/B, tests)
+        const bool soc_on = lsm != 2 && !rolling && soc_env;
         int pending = 0;
+        int pflip = 0;          // which of the two lists of searching problems is read next (the correction stage swaps them)
         const void* const extra_all = h.d_extra;
+        // the acceptance kernel publishes the number of problems still searching under a sequence number: wait for it
+        auto poll_pending = [&](int seq, int* out) -> int {
+            volatile int* hp = ws.hpub;
+            const auto t0 = std::chrono::steady_clock::now();
+            long spins = 0;
+            while (hp[4] != seq) {
+                cpu_relax();
+                if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                    NEMPC_HIP(hipStreamSynchronize(s));      // a device fault surfaces here instead of a hang
+                    if (hp[4] != seq) {
+                        set_error("nempc_solve: iteration " + std::to_string(it) + ": the backtracking counter of trial " +
+                                  std::to_string(seq) + " was never published (stream drained, word still " +
+                                  std::to_string(hp[4]) + ")");
+                        return NEMPC_EHIP;
+                    }
+                }
+            }
+            *out = hp[5];
+            return NEMPC_OK;
+        };
         for (int ls = 0; ls < o.max_linesearch; ++ls) {
             // the first trial point comes from solver_step_kernel (or the Riccati kernel), for every active problem; later
             // ones (inner-loop backtracking) are built here for the problems still searching ONLY, densely: their
@@ -2703,7 +2774,7 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
             const void* X0t = X0c;
             if (ls > 0) {
                 hipLaunchKernelGGL(solver_trial_list_kernel<T>, dim3(nb), dim3(64), 0, s, n, nx, (int)ex_per,
-                                   (const int*)ws.pend[ls & 1], (const T*)Zc, (const T*)ws.dz, (const T*)ws.alpha, (const T*)X0c,
+                                   (const int*)ws.pend[(ls + pflip) & 1], (const T*)Zc, (const T*)ws.dz, (const T*)ws.alpha, (const T*)X0c,
                                    (const T*)extra_all, (T*)ws.Zt, (T*)ws.X0p, (T*)ws.exp_, a.n_pending);
                 X0t = ws.X0p;
                 if (ex_per) h.d_extra = ws.exp_;
@@ -2746,30 +2817,30 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
                 hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(nb), dim3(64), 0, s, a, (const T*)ws.Zt,
                                    (const T*)ws.gt, fused_trial ? (const T*)ws.ft : (const T*)nullptr, (T*)Zc,
                                    lsm == 2 ? 2 : (ls + 1 == o.max_linesearch ? 1 : 0),
-                                   ls > 0 ? (const int*)ws.pend[ls & 1] : (const int*)nullptr, ws.pend[(ls + 1) & 1],
+                                   ls > 0 ? (const int*)ws.pend[(ls + pflip) & 1] : (const int*)nullptr, ws.pend[(ls + 1 + pflip) & 1],
                                    ls == 0 ? 1 : 0, lsm == 2 ? 0 : ++pend_seq);
             have_eval = a.carry != 0;
             have_blocks = have_eval && a.hblk_t != nullptr;
             if (lsm == 2) break;          // one trial per outer iteration: nothing to poll
             // most iterations accept the first trial for every problem: one small poll saves the remaining
             // max_linesearch-1 callback evaluations
-            {
-                volatile int* hp = ws.hpub;
-                const auto t0 = std::chrono::steady_clock::now();
-                long spins = 0;
-                while (hp[4] != pend_seq) {
-                    cpu_relax();
-                    if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
-                        NEMPC_HIP(hipStreamSynchronize(s));      // a device fault surfaces here instead of a hang
-                        if (hp[4] != pend_seq) {
-                            set_error("nempc_solve: iteration " + std::to_string(it) + ": the backtracking counter of trial " +
-                                      std::to_string(pend_seq) + " was never published (stream drained, word still " +
-                                      std::to_string(hp[4]) + ")");
-                            return NEMPC_EHIP;
-                        }
-                    }
-                }
-                pending = hp[5];
+            if ((rc = poll_pending(pend_seq, &pending))) return rc;
+            if (pending > 0 && ls == 0 && soc_on && !a.carry) {
+                // second-order correction of the rejected full steps (solver_soc_kernel): one defect-only launch over the
+                // rejected problems, accepted at the rejected trial's step length; what is still rejected backtracks as before
+                const int* lin = ws.pend[(1 + pflip) & 1];
+                int* lout = ws.pend[pflip & 1];
+                hipLaunchKernelGGL(solver_soc_kernel<T>, dim3(pending), dim3(64), 0, s, n, nx, nu, H, m, (int)ex_per, lin, (const T*)ws.Zt,
+                                   (const T*)ws.gt, (const T*)ws.tiles, (const T*)X0c, (const T*)extra_all, (T*)ws.Zsoc, (T*)ws.X0p,
+                                   (T*)ws.exp_, a.n_pending);
+                if (ex_per) h.d_extra = ws.exp_;
+                rc = launch_rows(pending, ws.Zsoc, ws.X0p, ws.gsoc, nullptr, h.d_tiles_ws);
+                h.d_extra = extra_all;
+                if (rc) return rc;
+                hipLaunchKernelGGL(solver_merit_kernel<T>, dim3(pending), dim3(64), 0, s, a, (const T*)ws.Zsoc, (const T*)ws.gsoc,
+                                   (const T*)nullptr, (T*)Zc, 0, lin, lout, 0, ++pend_seq, 1);
+                if ((rc = poll_pending(pend_seq, &pending))) return rc;
+                pflip ^= 1;
             }
             if (pending == 0) break;
             if (lsm == 3 && ls == 0 && pending * 4 <= std::min(Bact, last_nact)) {
