@@ -61,6 +61,36 @@ __device__ __forceinline__ void lg_act_all(int code, T z, T par, bool want_e, T&
     }
 }
 
+// Derivatives from the stored ACTIVATION (round 5).  For the activations whose s' is a cheap function of the output (tanh, relu, sigmoid, elu, leaky_relu, selu -- not softplus, whose s' costs an exp, and not the ones written from the
+// pre-activation) a layer stores a = s(z) only; whoever needs s'(z) or s''(z) later reads a and forms d1(a) / r2(a) d1(a) in
+// its own loader / epilogue.  A forward product then writes one matrix instead of two (rows) or three (Hessian sweeps):
+// 2 x 256 at B*H = 20480 in fp64, 42 MB per layer and matrix.
+__host__ __device__ inline bool lg_d_from_a(int act) {
+    return act == NEMPC_ACT_TANH || act == NEMPC_ACT_RELU || act == NEMPC_ACT_SIGMOID || act == NEMPC_ACT_ELU ||
+           act == NEMPC_ACT_LEAKY_RELU || act == NEMPC_ACT_SELU;
+}
+// what a value read through a "derivative" pointer stands for: code 0 -- the derivative itself (stored as such); else the
+// layer's activation, turned into s' (use 0) or s'' (use 1)
+// (its own switch over the cheap codes -- the formulas of act_d1 / act_r2, hence their bits -- so that softplus' expm1 is not
+// compiled into every GEMM epilogue; NEMPC_ACT_LINEAR is code 0 and needs none: s' = 1 is what a linear layer stores)
+template <typename T>
+__device__ __forceinline__ T lg_dval(int code, T par, int use, T v) {
+    T d1, r2;
+    switch (code) {
+        case NEMPC_ACT_TANH: d1 = fma(-v, v, T(1)); r2 = T(-2) * v; break;
+        case NEMPC_ACT_RELU: d1 = v > T(0) ? T(1) : T(0); r2 = T(0); break;
+        case NEMPC_ACT_SIGMOID: d1 = v * (T(1) - v); r2 = T(1) - T(2) * v; break;
+        case NEMPC_ACT_ELU: d1 = v > T(0) ? T(1) : v + par; r2 = v > T(0) ? T(0) : (v != v ? v : T(1)); break;
+        case NEMPC_ACT_LEAKY_RELU: d1 = v > T(0) ? T(1) : (v != v ? v : par); r2 = T(0); break;
+        case NEMPC_ACT_SELU:
+            d1 = v > T(0) ? T(NEMPC_SELU_LAMBDA) : v + T(NEMPC_SELU_LAMBDA * NEMPC_SELU_ALPHA);
+            r2 = v > T(0) ? T(0) : (v != v ? v : T(1));
+            break;
+        default: return v;          // the derivative itself was stored
+    }
+    return use ? r2 * d1 : d1;
+}
+
 struct GemmArgs {
     const void* A;      // A^T: (K, M) element (k, m) at A[k * lda + m]
     const void* Bw;     // (K, N) row-major, element (k, n) at Bw[k * ldb + n]
@@ -85,13 +115,25 @@ struct GemmArgs {
     //   LG_CONTRACT_REVERSE  the last reverse product: E = C . D_0, Wc = W_0^T (out, in), nd = nin: the Jacobian's partial sums
     //   LG_CONTRACT_FORWARD  the last hidden layer: E = s(C + b) (only s' is stored), Wc = W_{L-1} (in, out), nd = nx: the
     //                        network output's partial sums (bias and activation: layered_outfinish_kernel)
+    //   LG_CONTRACT_HPAIR    the Hessian's tangent products with the columns INTERLEAVED (tile = 16 rows x RM = nin inputs:
+    //                        column m = (r / 16) 16 nin + p 16 + r % 16): a lane holds P[n][p][row] of all inputs p, so the
+    //                        layer's curvature term  sum_n w[n][row] P[n][p][row] P[n][q][row]  (p >= q) is formed from the
+    //                        accumulators -- the tangents are not written (Craw = null), no contraction launch reads them back;
+    //                        w0t = w_l^T (N, ldd), Jp[nb][pair][row] = the feature block's partial sums, Rmod = valid rows
     const void* w0t;
     int ldw0, nin;
     void* Jp;
     long long ldj, jp_stride;
+    // derivatives from the stored activation (lg_d_from_a):
+    int dact;           // != 0: D (and E) point at the layer's ACTIVATIONS; the epilogue forms s' / s'' from them
+    double dactp;
+    int duse;           // CONTRACT_REVERSE with dact: 0 the multiplier is s', 1 it is s'' (layer 0's curvature weights)
+    int sact;           // SEED: != 0: the loader's operand A is an activation matrix, s' is formed on the way to LDS
+    double sactp;
+    int store_a;        // forward: the D slot receives the activation itself (C / E are then not written by CONTRACT_FORWARD)
 };
 
-enum { LG_CONTRACT_NONE = 0, LG_CONTRACT_REVERSE = 1, LG_CONTRACT_FORWARD = 2 };
+enum { LG_CONTRACT_NONE = 0, LG_CONTRACT_REVERSE = 1, LG_CONTRACT_FORWARD = 2, LG_CONTRACT_HPAIR = 3 };
 
 // FT = 16-feature tiles per wave: a workgroup owns BN = 64 FT features x 64 rows.  Measured (tools/layered_bench.py, round 4,
 // with one chunk of load lead): FT = 1 is the fastest everywhere -- 2 x 256 at B*H = 20480: 398 / 505 / 569 us for FT = 1 / 2 /
@@ -135,6 +177,7 @@ template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE
 __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void layered_gemm_kernel(GemmArgs a) {
 
     constexpr int BM = 16 * RM;
+    constexpr bool IL = CONTRACT == LG_CONTRACT_HPAIR;       // interleaved columns: tile = 16 rows x RM inputs
     static_assert(!(SEED || CONTRACT) || FT == 1, "the fused forms exist for the 64-feature block only");
     using Ops = MfmaOps<T>;
     using V4 = typename Ops::V4;
@@ -176,13 +219,19 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
         const int e = tid + 256 * u, kk = e / BM, x = e % BM;
-        offA[u] = (unsigned)((long long)kk * a.lda + (m0 + x < M ? x : M - 1 - m0)) * (unsigned)sizeof(T);
+        if constexpr (IL && SEED) {
+            // the operand is D_0^T (or a_0^T): column x of the tile reads row 16 mb + x % 16, whatever its input x / 16
+            const long long row = (long long)mb * 16 + (x & 15);
+            offA[u] = (unsigned)((long long)kk * a.lda + (row < a.Rmod ? row : a.Rmod - 1)) * (unsigned)sizeof(T);
+        } else {
+            offA[u] = (unsigned)((long long)kk * a.lda + (m0 + x < M ? x : M - 1 - m0)) * (unsigned)sizeof(T);
+        }
     }
     const T* __restrict__ Wb = Bw + n0;
     // SEED: the operand's column m = (cotangent m / Rmod, row m % Rmod) reads column m % Rmod of D_{L-2}^T; a block of 64
     // columns lies inside one cotangent (Rmod is a multiple of 64)
-    const long long mrow0 = (SEED || a.mode == LG_REVERSE) ? m0 % a.Rmod : 0;
-    const T* __restrict__ Ab = A + (SEED ? mrow0 : m0);
+    const long long mrow0 = IL ? 0 : ((SEED || a.mode == LG_REVERSE) ? m0 % a.Rmod : 0);
+    const T* __restrict__ Ab = A + (IL ? (SEED ? 0 : m0) : (SEED ? mrow0 : m0));
     // A chunk on its way from memory to LDS.  Two of them: the loads of chunk c + 2 are issued at the start of chunk c and
     // written to LDS at the end of chunk c + 1 -- two chunks of matrix instructions (~3 us with four waves on the SIMD) to
     // cover a memory round trip under load.  With a single set (one chunk of lead) the waves of the 256 x 256 reverse product
@@ -198,7 +247,7 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
     // row of the chunk this thread's u-th element sits in: tid / BM + (256 / BM) u -- wave-uniform for the 64-row block (a
     // scalar load of W_last then), two rows per wave for the 32-row block
     const int krow0 = RM == 4 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid / BM;
-    if constexpr (SEED) {
+    if constexpr (SEED && !IL) {
         const int x = tid % BM;
         seed_cot = (int)(m0 / a.Rmod);
         // (no s_L': the tangent sweep of the Hessian, whose seed is W_0^T . D_0)
@@ -215,8 +264,14 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
             const T* __restrict__ sw = static_cast<const T*>(a.seedW);
 #pragma unroll
             for (int u = 0; u < NA; ++u) {
-                const int k = ch * BK + krow0 + (256 / BM) * u;          // (beyond K: any row -- the operand it scales loaded as zero)
-                cr.sw[u] = sw[(size_t)(k < K ? k : K - 1) * a.seed_nx + seed_cot];
+                if constexpr (IL) {
+                    // (48-column tiles: neither the chunk row nor the input of a thread's u-th element is fixed)
+                    const int e = tid + 256 * u, k = ch * BK + e / BM, pin = (e % BM) >> 4;
+                    cr.sw[u] = sw[(size_t)(k < K ? k : K - 1) * a.seed_nx + pin];
+                } else {
+                    const int k = ch * BK + krow0 + (256 / BM) * u;          // (beyond K: any row -- the operand it scales loaded as zero)
+                    cr.sw[u] = sw[(size_t)(k < K ? k : K - 1) * a.seed_nx + seed_cot];
+                }
             }
         }
     };
@@ -230,7 +285,7 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
         for (int u = 0; u < NA; ++u) {
             const int e = tid + 256 * u;
             // (the seed kernel's order of operations: (W_last s_L') D)
-            As(buf, e / BM, e % BM) = SEED ? (cr.sw[u] * seed_dl) * cr.ra[u] : cr.ra[u];
+            As(buf, e / BM, e % BM) = SEED ? (IL ? cr.sw[u] : cr.sw[u] * seed_dl) * lg_dval<T>(a.sact, (T)a.sactp, 0, cr.ra[u]) : cr.ra[u];
         }
     };
 
@@ -294,6 +349,59 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
     // reverse: the derivative's column of m.  A block of 64 columns never straddles two cotangent blocks (Rmod is a multiple
     // of 64), so one division per workgroup places it
     const long long mD0 = a.mode == LG_REVERSE ? mrow0 - m0 : 0;
+    if constexpr (IL) {
+        // ---- tangents P_l[n][p][row] in the accumulators (tile rm = input p, lane c = row 16 mb + c): the next layer's operand
+        //      D_l . P_l leaves in the same interleaved layout (when there is a next layer), the layer's curvature term
+        //      sum_n w_l[n][row] P[n][p] P[n][q] is summed over this lane's four features, the four feature groups of the wave
+        //      (two exchanges across the lane groups), the four waves (LDS, wave order) -- and over the feature blocks by
+        //      layered_hfinish_kernel, in block order: the summation order is fixed
+        constexpr int NP = RM * (RM + 1) / 2;
+        const long long row = (long long)mb * 16 + c;
+        const bool rok = row < a.Rmod;
+        const T* __restrict__ Wl = static_cast<const T*>(a.w0t);
+        T part[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) part[i] = T(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + fb + Ops::row(q, r);
+            const bool ok = n < N && rok;
+            const T wv = ok ? Wl[(size_t)n * a.ldd + row] : T(0);
+            if (C) {
+                const T dv = ok ? lg_dval<T>(a.dact, (T)a.dactp, 0, D[(size_t)n * a.ldd + row]) : T(0);
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm)
+                    if (n < N) C[(size_t)n * a.ldc + m0 + 16 * rm + c] = acc[0][rm][r] * dv;
+            }
+            int i = 0;
+#pragma unroll
+            for (int pp = 0; pp < RM; ++pp) {
+                const T wp = wv * acc[0][pp][r];
+#pragma unroll
+                for (int qq = 0; qq <= pp; ++qq, ++i) part[i] = fma(wp, acc[0][qq][r], part[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            part[i] += __shfl_xor(part[i], 16);
+            part[i] += __shfl_xor(part[i], 32);
+        }
+        __syncthreads();            // (the operand buffers are about to be reused: every wave is done reading them)
+        if (q == 0) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) lds[(w * NP + i) * 16 + c] = part[i];
+        }
+        __syncthreads();
+        if (tid < NP * 16) {
+            const int i = tid >> 4, cc = tid & 15;
+            const long long rw = (long long)mb * 16 + cc;
+            if (rw < a.Rmod) {
+                const T v = ((lds[(0 * NP + i) * 16 + cc] + lds[(1 * NP + i) * 16 + cc]) + lds[(2 * NP + i) * 16 + cc]) + lds[(3 * NP + i) * 16 + cc];
+                static_cast<T*>(a.Jp)[(size_t)nb * a.jp_stride + (size_t)i * a.ldj + rw] = v;
+            }
+        }
+        return;
+    } else
     if constexpr (CONTRACT != LG_CONTRACT_NONE) {
         // E (G_0 = acc . D_0, or the layer's activations) stays in registers: register r of lane (c, q) holds feature
         // row(q, r), column c -- the four q of a register are a 4-deep k slab of features, i.e. the accumulator IS a B
@@ -313,13 +421,13 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
             for (int rm = 0; rm < RM; ++rm) {
                 const long long m = m0 + 16 * rm + c;
                 if constexpr (CONTRACT == LG_CONTRACT_REVERSE) {
-                    gd[rm][r] = (n < N && m < M) ? acc[0][rm][r] * D[(size_t)n * a.ldd + (m + mD0)] : T(0);
+                    gd[rm][r] = (n < N && m < M) ? acc[0][rm][r] * lg_dval<T>(a.dact, (T)a.dactp, a.duse, D[(size_t)n * a.ldd + (m + mD0)]) : T(0);
                 } else {
                     T x = T(0);
                     if (n < N && m < M) {
                         T d1, e;
                         lg_act_all<T>(a.act, acc[0][rm][r] + bias[n], (T)a.actp, a.E != nullptr, x, d1, e);
-                        D[(size_t)n * a.ldd + m] = d1;
+                        D[(size_t)n * a.ldd + m] = a.store_a ? x : d1;
                         if (a.E) static_cast<T*>(a.E)[(size_t)n * a.ldd + m] = e;
                     }
                     gd[rm][r] = x;
@@ -375,12 +483,14 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
                     T x, d1, e;
                     lg_act_all<T>(a.act, v + bias[n], (T)a.actp, a.E != nullptr, x, d1, e);
                     C[(size_t)n * a.ldc + m] = x;
-                    D[(size_t)n * a.ldd + m] = d1;
+                    if (D) D[(size_t)n * a.ldd + m] = d1;          // (null: a layer whose derivatives follow from C itself)
                     if (a.E) static_cast<T*>(a.E)[(size_t)n * a.ldd + m] = e;
                 } else {
-                    if (C) C[(size_t)n * a.ldc + m] = v * D[(size_t)n * a.ldd + (m + mD0)];
+                    if (C) C[(size_t)n * a.ldc + m] = v * lg_dval<T>(a.dact, (T)a.dactp, 0, D[(size_t)n * a.ldd + (m + mD0)]);
                     if (a.Craw) static_cast<T*>(a.Craw)[(size_t)n * a.ldc + m] = v;
-                    if (a.C2) static_cast<T*>(a.C2)[(size_t)n * a.ldc + m] = v * static_cast<const T*>(a.E)[(size_t)n * a.ldd + (m + mD0)];
+                    if (a.C2)
+                        static_cast<T*>(a.C2)[(size_t)n * a.ldc + m] =
+                            v * lg_dval<T>(a.dact, (T)a.dactp, 1, static_cast<const T*>(a.E)[(size_t)n * a.ldd + (m + mD0)]);
                 }
             }
         }
@@ -482,11 +592,11 @@ int skinny(hipStream_t s, const T* A, long long lda, const T* Bw, int ldb, int K
 // seed of the reverse sweep: G^T[j][k Rp + r] = W_last[j][k] s_L'(z_L)[k][r] D_{L-2}^T[j][r]  (all nx cotangents side by side)
 template <typename T>
 __global__ void layered_seed_kernel(const T* __restrict__ Wlast, int wdt, int nx, const T* __restrict__ dL, const T* __restrict__ Dh,
-                                    int R, long long Rp, T* __restrict__ G) {
+                                    int R, long long Rp, T* __restrict__ G, int dact, T dactp) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
     if (r >= R || j >= wdt) return;
-    const T d = Dh[(size_t)j * Rp + r];
+    const T d = lg_dval<T>(dact, dactp, 0, Dh[(size_t)j * Rp + r]);
     for (int k = 0; k < nx; ++k) G[(size_t)j * (nx * Rp) + (size_t)k * Rp + r] = Wlast[(size_t)j * nx + k] * dL[(size_t)k * Rp + r] * d;
 }
 
@@ -662,9 +772,10 @@ int gemm_forward(int num_cus, hipStream_t s, const GemmArgs& a) {
 
 template <typename T>
 int gemm(int num_cus, hipStream_t s, int mode, int act, const T* A, long long lda, const T* Bw, int ldb, T* C, long long ldc, T* D,
-         long long ldd, const T* bias, long long M, int N, int K, long long Rmod, double actp = 0.0) {
+         long long ldd, const T* bias, long long M, int N, int K, long long Rmod, double actp = 0.0, int dact = 0, double dactp = 0.0) {
     GemmArgs a{};
     a.actp = actp;
+    a.dact = dact; a.dactp = dactp;
     a.A = A; a.Bw = Bw; a.C = C; a.D = D; a.bias = bias;
     a.lda = lda; a.ldc = ldc; a.ldd = ldd; a.ldb = ldb;
     a.M = (int)M; a.N = N; a.K = K; a.mode = mode; a.act = act; a.Rmod = Rmod;
@@ -681,6 +792,34 @@ bool layered_fuse() {
         return !(e && atoi(e) == 0);
     }();
     return on;
+}
+
+// NEMPC_LAYERED_DFA: 0 every layer stores s' (and s'') next to its activation, as in round 4; 1 (default) the Hessian sweeps of
+// networks up to width 384 form them from the activation; 2 everywhere (A/B; each tested against the default)
+int lg_dfa_on() {
+    static const int on = [] {
+        const char* e = getenv("NEMPC_LAYERED_DFA");
+        return e ? atoi(e) : 1;
+    }();
+    return on;
+}
+
+// NEMPC_LAYERED_HFOLD=0: the Hessian's tangents are written and contracted by layered_hcontract_kernel, as in round 4 (A/B,
+// tested against the default)
+bool lg_hfold_on() {
+    static const bool on = [] {
+        const char* e = getenv("NEMPC_LAYERED_HFOLD");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
+// tangent product with the layer's curvature term in its epilogue (interleaved columns, tile = 16 rows x nin inputs)
+template <typename T>
+int gemm_hpair(hipStream_t s, const GemmArgs& a, bool seed, int nin) {
+    if (nin == 2) return seed ? gemm_ft<T, 1, true, LG_CONTRACT_HPAIR, 2>(s, a) : gemm_ft<T, 1, false, LG_CONTRACT_HPAIR, 2>(s, a);
+    if (nin == 3) return seed ? gemm_ft<T, 1, true, LG_CONTRACT_HPAIR, 3>(s, a) : gemm_ft<T, 1, false, LG_CONTRACT_HPAIR, 3>(s, a);
+    return seed ? gemm_ft<T, 1, true, LG_CONTRACT_HPAIR, 4>(s, a) : gemm_ft<T, 1, false, LG_CONTRACT_HPAIR, 4>(s, a);
 }
 
 template <typename T>
@@ -727,8 +866,15 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
             // ---- forward: hidden layers 0 .. nl-2 (GEMM), output layer nl-1 (skinny)
             const T* in = ws + o.xi;
             const bool fuse_out = layered_fuse();
+            // layers that store their activation only (their s' is formed from it where it is needed: lg_d_from_a); the
+            // activation then lives in the layer's own slot (o.d[l]) instead of the two alternating ones
+            // (measured, tools/layered_bench.py with NEMPC_LAYERED_DFA = 0 | 1 on every launch: the ROWS path gains nothing --
+            // 2 x 256 fp64 267 -> 269 us, 3 x 256 476 -> 467, 4 x 512 RK4 25.3 -> 25.4 ms: its layer-0 product is latency-bound,
+            // not store-bound, and the last hidden layer stores one matrix either way -- so it keeps s' stored; the Hessian
+            // sweeps, which store three matrices per layer, take it: NEMPC_LAYERED_DFA=2 forces it here too, for the A/B)
+            auto dfa = [&](int l) { return lg_dfa_on() == 2 && lg_d_from_a(h.act[l]); };
             for (int l = 0; l < nl - 1; ++l) {
-                T* out = ws + ((l & 1) ? o.x1 : o.x0);
+                T* out = dfa(l) ? ws + o.d[l] : ws + ((l & 1) ? o.x1 : o.x0);
                 if (l == nl - 2 && fuse_out) {
                     // the last hidden layer: its activations go straight into the output layer's contraction (only s' is
                     // stored); partial sums per feature block in the cotangent buffer, which the reverse sweep fills later
@@ -736,6 +882,7 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                     a.mode = LG_FORWARD; a.act = h.act[l]; a.actp = h.actp[l];
                     a.A = in; a.lda = Rp; a.Bw = h.d_W[l]; a.ldb = h.dout[l];
                     a.D = ws + o.d[l]; a.ldd = Rp; a.bias = h.d_b[l];
+                    a.store_a = dfa(l) ? 1 : 0;
                     a.M = R; a.N = h.dout[l]; a.K = h.din[l];
                     a.w0t = h.d_W[nl - 1]; a.ldw0 = nx; a.nin = nx;
                     a.Jp = ws + o.g0; a.ldj = Rp; a.jp_stride = (long long)nx * Rp;
@@ -746,8 +893,9 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                     NEMPC_HIP(hipGetLastError());
                     break;
                 }
-                if ((rc = gemm<T>(h.num_cus, s, LG_FORWARD, h.act[l], in, Rp, static_cast<const T*>(h.d_W[l]), h.dout[l], out, Rp, ws + o.d[l], Rp,
-                                  static_cast<const T*>(h.d_b[l]), R, h.dout[l], h.din[l], 0, h.actp[l])))
+                if ((rc = gemm<T>(h.num_cus, s, LG_FORWARD, h.act[l], in, Rp, static_cast<const T*>(h.d_W[l]), h.dout[l], out, Rp,
+                                  dfa(l) ? static_cast<T*>(nullptr) : ws + o.d[l], Rp, static_cast<const T*>(h.d_b[l]), R, h.dout[l],
+                                  h.din[l], 0, h.actp[l])))
                     return rc;
                 in = out;
             }
@@ -771,9 +919,11 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                     a.Bw = h.d_Wt[l + 1]; a.ldb = h.dout[l];
                     a.M = (int)Mr; a.N = h.dout[l]; a.K = h.dout[l + 1]; a.Rmod = Rp;
                     a.D = ws + o.d[l]; a.ldd = Rp;
+                    if (dfa(l)) { a.dact = h.act[l]; a.dactp = h.actp[l]; }
                     if (first) {
                         a.A = ws + o.d[nl - 2]; a.lda = Rp;
                         a.seedW = h.d_W[nl - 1]; a.seedDl = ws + o.dl; a.seed_nx = nx;
+                        if (dfa(nl - 2)) { a.sact = h.act[nl - 2]; a.sactp = h.actp[nl - 2]; }
                     } else {
                         a.A = G; a.lda = ldg;
                     }
@@ -797,14 +947,14 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
             } else {
             T* G = ws + o.g0;
             hipLaunchKernelGGL(layered_seed_kernel<T>, dim3(rg.x, (unsigned)h.dout[nl - 2]), rb, 0, s, static_cast<const T*>(h.d_W[nl - 1]),
-                               h.dout[nl - 2], nx, ws + o.dl, ws + o.d[nl - 2], R, Rp, G);
+                               h.dout[nl - 2], nx, ws + o.dl, ws + o.d[nl - 2], R, Rp, G, dfa(nl - 2) ? h.act[nl - 2] : 0, (T)h.actp[nl - 2]);
             NEMPC_HIP(hipGetLastError());
             for (int l = nl - 3; l >= 0; --l) {
                 // G_l = (W_{l+1} G_{l+1}) . D_l : K = dout[l+1], N = dout[l], operand W_{l+1}^T row-major (out, in) = d_Wt[l+1]
                 T* Gn = (G == ws + o.g0) ? ws + o.g1 : ws + o.g0;
                 // the nx blocks of Rp columns are covered as one run of columns; block k's columns beyond Rm are never read
                 if ((rc = gemm<T>(h.num_cus, s, LG_REVERSE, 0, G, ldg, static_cast<const T*>(h.d_Wt[l + 1]), h.dout[l], Gn, ldg, ws + o.d[l], Rp,
-                                  nullptr, (long long)(nx - 1) * Rp + Rm, h.dout[l], h.dout[l + 1], Rp)))
+                                  nullptr, (long long)(nx - 1) * Rp + Rm, h.dout[l], h.dout[l + 1], Rp, 0.0, dfa(l) ? h.act[l] : 0, h.actp[l])))
                     return rc;
                 G = Gn;
             }
@@ -879,7 +1029,9 @@ LayeredHws layered_hess_offsets(const Handle& h, size_t Rp) {
     o.a1 = p; p += (size_t)h.maxw * nin * Rp;
     o.pl = p; p += (size_t)nx * nin * Rp;
     o.hacc = p; p += (size_t)nin * nin * Rp;
-    o.l0p = p; p += (size_t)((h.maxw + 63) / 64) * 32 * Rp;      // layer 0's curvature term per feature block (<= 32 pairs)
+    // curvature terms per feature block as pair-major partial sums (<= 32 pairs): layer 0's (CONTRACT_REVERSE of the product
+    // that forms q_0) and, with nin <= 4, every other hidden layer's (CONTRACT_HPAIR of its tangent product)
+    o.l0p = p; p += (size_t)((h.maxw + 63) / 64) * 32 * Rp * (size_t)(nin <= 4 ? h.nl - 1 : 1);
     o.total = p;
     return o;
 }
@@ -910,14 +1062,15 @@ __global__ void layered_hmult_kernel(int H, int nx, int m, const T* __restrict__
 // the last hidden layer's cotangent: q[j][r] = sum_k W_last[j][k] cl[k][r];  w = q . E (curvature weights), delta = q . D
 template <typename T>
 __global__ void layered_hseed_kernel(const T* __restrict__ Wlast, int wdt, int nx, const T* __restrict__ cl, const T* __restrict__ Dh,
-                                     const T* __restrict__ Eh, int R, long long Rp, T* __restrict__ delta, T* __restrict__ w) {
+                                     const T* __restrict__ Eh, int R, long long Rp, T* __restrict__ delta, T* __restrict__ w,
+                                     int dact, T dactp) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
     if (r >= R || j >= wdt) return;
     T q = T(0);
     for (int k = 0; k < nx; ++k) q = fma(Wlast[(size_t)j * nx + k], cl[(size_t)k * Rp + r], q);
-    w[(size_t)j * Rp + r] = q * Eh[(size_t)j * Rp + r];
-    delta[(size_t)j * Rp + r] = q * Dh[(size_t)j * Rp + r];
+    w[(size_t)j * Rp + r] = q * lg_dval<T>(dact, dactp, 1, Eh[(size_t)j * Rp + r]);
+    delta[(size_t)j * Rp + r] = q * lg_dval<T>(dact, dactp, 0, Dh[(size_t)j * Rp + r]);
 }
 
 // H[p][q][r] (+)= sum_j w[j][r] P[j][p Rp + r] P[j][q Rp + r] for the inputs p in block pb, q in block qb (PB each, q <= p
@@ -1119,13 +1272,23 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
                                ws + o.xi, static_cast<const T*>(nullptr), T(0));
         NEMPC_HIP(hipGetLastError());
         const T* in = ws + o.xi;
+        // Measured (profiles/r05_layered_dfa.txt): 2 x 256 fp64 503 -> 461 us, 3 x 256 898 -> 851 us; 4 x 512 RK4 83.9 -> 85.2 ms
+        // (compute-bound products: the stores were free, the extra vector work in loader and epilogue is not) -- hence the
+        // width rule
+        auto dfa = [&](int l) { return lg_dfa_on() && (h.maxw <= 384 || lg_dfa_on() == 2) && lg_d_from_a(h.act[l]); };
         for (int l = 0; l < nl - 1; ++l) {
-            T* out = ws + ((l & 1) ? o.x1 : o.x0);
+            T* out = dfa(l) ? ws + o.d[l] : ws + ((l & 1) ? o.x1 : o.x0);
             const bool contract = l == nl - 2 && layered_fuse();      // the output layer in the last hidden layer's epilogue
             GemmArgs a{};
             a.mode = LG_FORWARD; a.act = h.act[l]; a.actp = h.actp[l];
             a.A = in; a.lda = Rp; a.Bw = h.d_W[l]; a.ldb = h.dout[l]; a.bias = h.d_b[l];
-            a.D = ws + o.d[l]; a.E = ws + o.e[l]; a.ldd = Rp;
+            a.ldd = Rp;
+            if (dfa(l)) {
+                // the activation alone: in the layer's slot, through C (plain product) or through D (contracted product)
+                a.D = contract ? ws + o.d[l] : static_cast<T*>(nullptr); a.E = nullptr; a.store_a = contract ? 1 : 0;
+            } else {
+                a.D = ws + o.d[l]; a.E = ws + o.e[l];
+            }
             a.M = R; a.N = h.dout[l]; a.K = h.din[l];
             if (contract) {
                 // (partial sums per feature block in the tangent buffer, free until the tangent sweep)
@@ -1151,7 +1314,8 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
         NEMPC_HIP(hipGetLastError());
         T* dq = ws + o.q0;
         hipLaunchKernelGGL(layered_hseed_kernel<T>, dim3(rg.x, (unsigned)h.dout[nl - 2]), rb, 0, s, static_cast<const T*>(h.d_W[nl - 1]),
-                           h.dout[nl - 2], nx, ws + o.cl, ws + o.d[nl - 2], ws + o.e[nl - 2], R, Rp, dq, ws + o.cw[nl - 2]);
+                           h.dout[nl - 2], nx, ws + o.cl, ws + o.d[nl - 2], dfa(nl - 2) ? ws + o.d[nl - 2] : ws + o.e[nl - 2], R, Rp, dq,
+                           ws + o.cw[nl - 2], dfa(nl - 2) ? h.act[nl - 2] : 0, (T)h.actp[nl - 2]);
         NEMPC_HIP(hipGetLastError());
         for (int l = nl - 3; l >= 0; --l) {
             T* dn = (dq == ws + o.q0) ? ws + o.q1 : ws + o.q0;
@@ -1159,10 +1323,12 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
             a.mode = LG_REVERSE;
             a.A = dq; a.lda = Rp; a.Bw = h.d_Wt[l + 1]; a.ldb = h.dout[l];
             a.M = (int)Rp; a.N = h.dout[l]; a.K = h.dout[l + 1]; a.Rmod = Rp;
-            a.D = ws + o.d[l]; a.E = ws + o.e[l]; a.ldd = Rp;
+            a.D = ws + o.d[l]; a.E = dfa(l) ? ws + o.d[l] : ws + o.e[l]; a.ldd = Rp;
+            if (dfa(l)) { a.dact = h.act[l]; a.dactp = h.actp[l]; }
             if (l == 0 && fuse_l0) {
                 // layer 0's curvature term in this product's epilogue: w_0 = q_0 . E_0 contracted with the pair products
-                a.D = ws + o.e[0];
+                a.D = dfa(0) ? ws + o.d[0] : ws + o.e[0];
+                a.duse = 1;
                 a.w0t = h.d_layered_pairs; a.ldw0 = npair; a.nin = npair;
                 a.Jp = ws + o.l0p; a.ldj = Rp; a.jp_stride = (long long)npair * Rp;
                 if ((rc = gemm_ft<T, 1, false, LG_CONTRACT_REVERSE>(s, a))) return rc;
@@ -1180,27 +1346,44 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
             (rc = hcontract<T>(s, nullptr, 0, static_cast<const T*>(h.d_W[0]), h.dout[0], ws + o.cw[0], h.dout[0], nin, R, Rp, Hacc, false)))
             return rc;
         // ---- tangents of all nin inputs side by side (column p Rp + r), contracted layer by layer
-        const long long ldt = (long long)nin * Rp;
-        const long long Mt = (long long)(nin - 1) * Rp + Rp;
+        // Up to four inputs (round 5): the columns are INTERLEAVED -- a tile is 16 rows x nin inputs -- so that a lane of the
+        // product holds the tangents of every input of its row, and the layer's curvature term leaves from the epilogue
+        // (LG_CONTRACT_HPAIR): the tangents (126 MB at 2 x 256, B*H = 20480, fp64) are neither written nor read back, and the
+        // contraction launch is gone.  Otherwise: the tangents go through memory to layered_hcontract_kernel.
+        const bool fold = fuse_l0 && lin_out && nin >= 2 && nin <= 4 && lg_hfold_on();
+        const long long ldt = fold ? ((long long)R + 15) / 16 * 16 * nin : (long long)nin * Rp;
+        const long long Mt = fold ? ldt : (long long)(nin - 1) * Rp + Rp;
         const T* ta = nullptr;
+        int pblocks = fuse_l0 ? (h.dout[0] + 63) / 64 : 0;        // feature blocks of partial sums behind o.l0p so far
+        bool hacc_used = !fuse_l0;
         for (int l = 1; l < nl - 1; ++l) {
             T* tn = (ta == ws + o.a0) ? ws + o.a1 : ws + o.a0;
             const bool need_a = l < nl - 2 || !lin_out;     // D_l . P_l feeds the next layer (or the output layer's curvature)
             GemmArgs a{};
             a.mode = LG_REVERSE;
             a.Bw = h.d_W[l]; a.ldb = h.dout[l];
-            a.M = (int)Mt; a.N = h.dout[l]; a.K = h.din[l]; a.Rmod = Rp;
+            a.M = (int)Mt; a.N = h.dout[l]; a.K = h.din[l]; a.Rmod = fold ? (long long)R : Rp;
             a.D = ws + o.d[l]; a.ldd = Rp;
-            a.C = need_a ? tn : nullptr; a.Craw = ws + o.P; a.ldc = ldt;
+            if (dfa(l)) { a.dact = h.act[l]; a.dactp = h.actp[l]; }
+            a.C = need_a ? tn : nullptr; a.Craw = fold ? static_cast<T*>(nullptr) : ws + o.P; a.ldc = ldt;
             if (l == 1) {
                 a.A = ws + o.d[0]; a.lda = Rp;
                 a.seedW = h.d_Wt[0]; a.seed_nx = h.din[0]; a.seedDl = nullptr;
-                if ((rc = gemm_ft<T, 1, true, LG_CONTRACT_NONE>(s, a))) return rc;
+                if (dfa(0)) { a.sact = h.act[0]; a.sactp = h.actp[0]; }
             } else {
                 a.A = ta; a.lda = ldt;
-                if ((rc = gemm_ft<T, 1>(s, a))) return rc;
             }
-            if ((rc = hcontract<T>(s, ws + o.P, ldt, nullptr, 0, ws + o.cw[l], h.dout[l], nin, R, Rp, Hacc, !(fuse_l0 && l == 1)))) return rc;
+            if (fold) {
+                a.w0t = ws + o.cw[l];
+                a.Jp = ws + o.l0p + (size_t)pblocks * npair * Rp; a.ldj = Rp; a.jp_stride = (long long)npair * Rp;
+                if ((rc = gemm_hpair<T>(s, a, l == 1, nin))) return rc;
+                pblocks += (h.dout[l] + 63) / 64;
+            } else {
+                if (l == 1) { if ((rc = gemm_ft<T, 1, true, LG_CONTRACT_NONE>(s, a))) return rc; }
+                else if ((rc = gemm_ft<T, 1>(s, a))) return rc;
+                if ((rc = hcontract<T>(s, ws + o.P, ldt, nullptr, 0, ws + o.cw[l], h.dout[l], nin, R, Rp, Hacc, hacc_used))) return rc;
+                hacc_used = true;
+            }
             ta = tn;
         }
         if (!lin_out) {
@@ -1209,10 +1392,11 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
             if ((rc = skinny<T>(s, ta, ldt, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, Mj, ws + o.pl, ldt,
                                 static_cast<const T*>(nullptr), 2, 0, static_cast<T*>(nullptr), T(0))))
                 return rc;
-            if ((rc = hcontract<T>(s, ws + o.pl, ldt, nullptr, 0, ws + o.wl, nx, nin, R, Rp, Hacc, true))) return rc;
+            if ((rc = hcontract<T>(s, ws + o.pl, ldt, nullptr, 0, ws + o.wl, nx, nin, R, Rp, Hacc, hacc_used))) return rc;
+            hacc_used = true;
         }
-        hipLaunchKernelGGL(layered_hfinish_kernel<T>, rg, rb, 0, s, nin, r0, R, Rp, Hacc, fuse_l0 ? ws + o.l0p : static_cast<T*>(nullptr),
-                           (h.dout[0] + 63) / 64, (long long)npair * Rp, blocks);
+        hipLaunchKernelGGL(layered_hfinish_kernel<T>, rg, rb, 0, s, nin, r0, R, Rp, hacc_used ? Hacc : static_cast<T*>(nullptr),
+                           fuse_l0 ? ws + o.l0p : static_cast<T*>(nullptr), pblocks, (long long)npair * Rp, blocks);
         NEMPC_HIP(hipGetLastError());
     }
     return NEMPC_OK;

@@ -888,7 +888,9 @@ sys.path.insert(0, sys.argv[1])
 from oracle import nempc_oracle as orc
 from pyneuralempc_amd import CallbackEngine
 out = {}
-for tag, hidden, acts, nx, nu, integ in (("a", [200, 136], ["tanh", "sigmoid", "linear"], 2, 1, "discret"), ("b", [144], "tanh", 3, 2, "rk4")):
+for tag, hidden, acts, nx, nu, integ in (("a", [200, 136], ["tanh", "sigmoid", "linear"], 2, 1, "discret"), ("b", [144], "tanh", 3, 2, "rk4"),
+                                         ("c", [136, 150, 72], ["tanh", "softplus", "relu", "linear"], 2, 2, "rk4"),
+                                         ("d", [160, 130], "tanh", 1, 1, "unity")):
     H, B, DT = 6, 90, (0.1 if integ == "rk4" else 1.0)
     net = orc.MLP.random(nx + nu, hidden, nx, seed=5, activations=acts)
     eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=integ, DT=DT, dtype=torch.float64, device="cuda:0", max_batch=B,
@@ -906,7 +908,9 @@ np.savez(sys.argv[2], **out)
 def test_layered_path_run_time_switches_agree_with_the_default(tmp_path):
     """The layered path's run-time switches -- NEMPC_LAYERED_FUSE=0 (seed kernel, plain products, skinny last steps: also the
     reverse sweep every single-hidden-layer network takes), NEMPC_LG_RM=2 / 4 and NEMPC_LG_RM_REV=2 (32- / 64-row blocks),
-    NEMPC_LAYERED_HESS=0 (Lagrangian blocks from the generic kernel) -- are read once per process: each runs in a process of
+    NEMPC_LAYERED_HESS=0 (Lagrangian blocks from the generic kernel), NEMPC_LAYERED_DFA=0 / 2 (every layer stores s' / s'' next to
+    its activation; or none that can form them from it does, in the rows path too), NEMPC_LAYERED_HFOLD=0 (the Hessian's
+    tangents through memory and layered_hcontract_kernel instead of the tangent product's epilogue) -- are read once per process: each runs in a process of
     its own and has to reproduce the default's rows and Lagrangian blocks to rounding (round-4 review: switches nobody tests
     are build variants nobody knows)."""
     import os
@@ -917,7 +921,9 @@ def test_layered_path_run_time_switches_agree_with_the_default(tmp_path):
     script.write_text(_AB_WORKER)
     res = {}
     for name, env in (("default", {}), ("nofuse", {"NEMPC_LAYERED_FUSE": "0"}), ("rm2", {"NEMPC_LG_RM": "2"}), ("rm4", {"NEMPC_LG_RM": "4"}),
-                      ("rmrev2", {"NEMPC_LG_RM_REV": "2"}), ("nohess", {"NEMPC_LAYERED_HESS": "0"})):
+                      ("rmrev2", {"NEMPC_LG_RM_REV": "2"}), ("nohess", {"NEMPC_LAYERED_HESS": "0"}),
+                      ("nodfa", {"NEMPC_LAYERED_DFA": "0"}), ("dfa_all", {"NEMPC_LAYERED_DFA": "2"}), ("nohfold", {"NEMPC_LAYERED_HFOLD": "0"}),
+                      ("dfa_all_nofuse", {"NEMPC_LAYERED_DFA": "2", "NEMPC_LAYERED_FUSE": "0"})):
         out = tmp_path / (name + ".npz")
         r = subprocess.run([sys.executable, str(script), repo, str(out)], env=dict(os.environ, **env), capture_output=True, text=True,
                            timeout=600)
@@ -925,7 +931,7 @@ def test_layered_path_run_time_switches_agree_with_the_default(tmp_path):
         res[name] = dict(np.load(out))
     ref = res["default"]
     for name, got in res.items():
-        for k in ("a_g", "a_J", "a_H", "b_g", "b_J", "b_H"):
+        for k in [t + sfx for t in "abcd" for sfx in ("_g", "_J", "_H")]:
             np.testing.assert_allclose(got[k], ref[k], rtol=0, atol=1e-11 * max(1.0, np.abs(ref[k]).max()), err_msg=f"{name}/{k}")
     assert str(ref["a_hk"][0]) == "layered_gemm_kernel" and str(res["nohess"]["a_hk"][0]) == "rowhess_valu_kernel"    # (the switch did switch)
 
