@@ -516,6 +516,10 @@ __global__ void layered_gather_kernel(RowGather gk, int nin, int ne, const T* __
     for (int j = 0; j < ne; ++j) xi[(size_t)(nin + j) * Rp + r] = extra[(size_t)gr * ne + j];
 }
 
+// (Round 5 tried gather + layer 0 as ONE vector-unit launch -- a lane per row, a wave per run of features, weights as scalar
+// loads -- instead of the gather launch and a one-chunk launch of the GEMM kernel (36 us together at 256 features x 20480 rows):
+// slower, 2 x 256 fp64 270 -> 274 us per evaluation, 3 x 256 479 -> 493 (profiles/r05_layered_first.txt): its chain of scalar
+// weight loads per feature is as latency-bound as the GEMM kernel's prologue.  Removed.)
 // N <= NMAX outputs per column on the vector unit: out^T[n][m] = epi(sum_k A^T[k][m] Bw[k][n]).  mode 0: the network's
 // output layer (bias, activation; f and s'(z_L) stored), mode 2: plain (the last reverse step onto the inputs).
 // A block is 64 columns x 4 waves; wave w sums k = w, w + 4, ... with sixteen loads in flight per lane, the four partial
@@ -652,7 +656,7 @@ template <typename T>
 __global__ void layered_finish_kernel(RowGather gk, int kind, T DT, int nin, const T* __restrict__ Z, const T* __restrict__ X0,
                                       long long r0, int R, long long Rp, const T* __restrict__ f, const T* __restrict__ J,
                                       const T* __restrict__ acck, const T* __restrict__ accdk, T* __restrict__ g, int m, int box,
-                                      T* __restrict__ tiles) {
+                                      T* __restrict__ tiles, int jblk, long long jstride) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const long long gr = r0 + r;
@@ -673,7 +677,14 @@ __global__ void layered_finish_kernel(RowGather gk, int kind, T DT, int nin, con
         for (int d = 0; d < nin; ++d) {
             T v;
             if (kind == NEMPC_RK4) v = s6 * accdk[(size_t)(i * nin + d) * Rp + r] + (d == i ? T(1) : T(0));
-            else v = J[(size_t)d * (nx * Rp) + (size_t)i * Rp + r] + ((kind == NEMPC_DISCRET && d == gk.xcur + i) ? T(1) : T(0));
+            else {
+                // (jblk > 1: J is still the feature blocks' partial sums -- added here in block order, as layered_jreduce_kernel
+                //  would have: the reduction launch of its own is gone for Discret / Unity)
+                const size_t ji = (size_t)d * (nx * Rp) + (size_t)i * Rp + r;
+                T jv = J[ji];
+                for (int bb = 1; bb < jblk; ++bb) jv += J[(size_t)bb * jstride + ji];
+                v = jv + ((kind == NEMPC_DISCRET && d == gk.xcur + i) ? T(1) : T(0));
+            }
             tile[i * nin + d] = v;
         }
     }
@@ -858,14 +869,17 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
         const long long Rp = Rm;
         const LayeredWs o = layered_offsets(h, (size_t)Rp);
         const dim3 rb(256), rg((unsigned)((R + 255) / 256));
+        int jblk = 1;                       // the Jacobian as the finish kernel finds it: jblk feature blocks of partial sums
+        const T* jsrc = ws + o.j;
+        long long jstride = 0;
         for (int st = 0; st < nstages; ++st) {
             const T cdt = st == 0 ? T(0) : (st == 3 ? DT : T(0.5) * DT);
+            const bool fuse_out = layered_fuse();
             hipLaunchKernelGGL(layered_gather_kernel<T>, rg, rb, 0, s, gk, nin, ne, static_cast<const T*>(h.d_extra), Z, X0, r0, R, Rp,
                                ws + o.xi, st > 0 ? ws + o.kprev : nullptr, cdt);
             NEMPC_HIP(hipGetLastError());
             // ---- forward: hidden layers 0 .. nl-2 (GEMM), output layer nl-1 (skinny)
             const T* in = ws + o.xi;
-            const bool fuse_out = layered_fuse();
             // layers that store their activation only (their s' is formed from it where it is needed: lg_d_from_a); the
             // activation then lives in the layer's own slot (o.d[l]) instead of the two alternating ones
             // (measured, tools/layered_bench.py with NEMPC_LAYERED_DFA = 0 | 1 on every launch: the ROWS path gains nothing --
@@ -936,7 +950,10 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                         a.C = Gn; a.ldc = ldg;
                     }
                     if ((rc = gemm_reverse_fused<T>(s, a, first, last))) return rc;
-                    if (last && nblk > 1) {
+                    jblk = 1; jsrc = ws + o.j; jstride = 0;
+                    if (last && nblk > 1 && !rk4) {        // Discret / Unity: layered_finish_kernel adds the blocks itself
+                        jblk = nblk; jsrc = Gn; jstride = a.jp_stride;
+                    } else if (last && nblk > 1) {
                         const long long count = (long long)nin * ldg;
                         hipLaunchKernelGGL(layered_jreduce_kernel<T>, dim3((unsigned)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096)),
                                            dim3(256), 0, s, Gn, nblk, a.jp_stride, ws + o.j, count);
@@ -977,8 +994,8 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                 NEMPC_HIP(hipGetLastError());
             }
         }
-        hipLaunchKernelGGL(layered_finish_kernel<T>, rg, rb, 0, s, gk, h.cfg.integrator, DT, nin, Z, X0, r0, R, Rp, ws + o.f, ws + o.j,
-                           rk4 ? ws + o.acck : nullptr, rk4 ? ws + o.accdk : nullptr, g, h.m, h.box ? 1 : 0, tiles);
+        hipLaunchKernelGGL(layered_finish_kernel<T>, rg, rb, 0, s, gk, h.cfg.integrator, DT, nin, Z, X0, r0, R, Rp, ws + o.f, jsrc,
+                           rk4 ? ws + o.acck : nullptr, rk4 ? ws + o.accdk : nullptr, g, h.m, h.box ? 1 : 0, tiles, jblk, jstride);
         NEMPC_HIP(hipGetLastError());
     }
     return NEMPC_OK;
