@@ -151,9 +151,15 @@ __device__ __forceinline__ void coop_zero_rows(T* o_jac, unsigned r0, int nrows,
         const int full = nv / NTHREADS;
         const int voff = tid * 16;
         for (int k = 0; k < full; ++k) {
+#ifdef NEMPC_STAMPS      // (diagnostic builds: the stamps' asm statements cost the compiler its proof that `base` is uniform)
+            base = fx_uniform_ptr(base);
+#endif
             asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
             base += NTHREADS * 16;
         }
+#ifdef NEMPC_STAMPS
+        base = fx_uniform_ptr(base);
+#endif
         if (tid < nv - full * NTHREADS)
             asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(zero), "s"(base) : "memory");
         // (store-data hazard: `zero`'s registers may be re-used right behind a store -- the wait states ride in the store's own
