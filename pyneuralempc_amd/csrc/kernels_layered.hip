@@ -1499,7 +1499,7 @@ static bool layered_hess_usable(const Handle& h);
 // nempc_create / nempc_reserve: both chunk workspaces and the first-layer pair table of the Hessian, so that no callback
 // allocates (the `*_prepare` calls in the launchers below then find everything in place and return at once)
 int layered_reserve(Handle& h) {
-    int rc = layered_prepare(h);
+    int rc = h.layered ? layered_prepare(h) : NEMPC_OK;      // (layered_hess handles: the Hessian workspace only)
     if (rc) return rc;
     if (layered_hess_usable(h)) {
         if ((rc = layered_hess_prepare(h))) return rc;
@@ -1519,7 +1519,7 @@ int layered_reserve(Handle& h) {
 // NEMPC_EUNSUPPORTED: a nonlinear output layer behind a single hidden layer, NEMPC_LAYERED_HESS=0 (A/B knob).
 static bool layered_hess_usable(const Handle& h) {
     static const bool off = [] { const char* e = getenv("NEMPC_LAYERED_HESS"); return e && atoi(e) == 0; }();
-    if (off || !h.layered) return false;
+    if (off || !(h.layered || h.layered_hess)) return false;
     return h.nl >= 2 && !(h.nl == 2 && h.act[h.nl - 1] != NEMPC_ACT_LINEAR);
 }
 

@@ -79,6 +79,17 @@ bool mfma_slower_than_layered(const Handle& h) {
     return ((nh - 1) * 2 * MT * 4 + 8) * 2 > 144;          // coop_fits_registers<double, WP, NH>() of kernels_mfma_typed.inc
 }
 
+// Shapes whose ROWS are fastest on the register-resident kernels but whose Lagrangian blocks are not: fp64, padded width 128,
+// three hidden layers -- the weight slices do not fit the cooperative Hessian kernel, the wave-per-tile one streams 1.5 MB of
+// weights per tile: 565 us per callback at B = 1024, H = 20, 2/1 against 277 us for the layered sweeps (with the tangent
+// contraction folded in and s' / s'' from the activations, round 5), while the rows take 154 us against 190
+// (tools/narrow_bench.py).  Discret / Unity; the RK4 pipeline keeps its own network kernel.
+bool mfma_hess_on_layered(const Handle& h) {
+    static const bool off = [] { const char* e = getenv("NEMPC_MFMA_HESS_LAYERED"); return e && atoi(e) == 0; }();
+    if (off || h.cfg.dtype != NEMPC_F64 || h.cfg.integrator == NEMPC_RK4 || !layered_supported(h)) return false;
+    return padded_width(h) == 128 && h.nl - 1 == 3;
+}
+
 void mfma_free(Handle& h) {
     if (h.mfma.blob) (void)hipFree(h.mfma.blob);
     h.mfma.blob = nullptr;
@@ -349,6 +360,10 @@ int launch_rows_mfma_stages(Handle& h, int B, const void* Z, const void* X0, voi
 
 int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks,
                         hipStream_t s) {
+    if (h.layered_hess) {       // (mfma_hess_on_layered: this shape's blocks are faster on the layer-at-a-time sweeps)
+        const int rc = launch_rowhess_layered(h, B, Z, X0, lambda, blocks, s);
+        if (rc != NEMPC_EUNSUPPORTED) return rc;
+    }
     return launch_rowhess_mfma_direct(h, B, Z, X0, lambda, blocks, nullptr, 0, nullptr, 1, s);
 }
 
@@ -357,7 +372,7 @@ int launch_rowhess_mfma(Handle& h, int B, const void* Z, const void* X0, const v
 // rolling window (an entry then sums block elements of several rows).
 int launch_rowhess_mfma_hvals(Handle& h, int B, const void* Z, const void* X0, const void* lambda, const void* sigma,
                               void* hvals, hipStream_t s) {
-    if (h.w != 1 || !h.d_hess_smap || h.hess_n_orph < 0) return NEMPC_EUNSUPPORTED;
+    if (h.w != 1 || !h.d_hess_smap || h.hess_n_orph < 0 || h.layered_hess) return NEMPC_EUNSUPPORTED;
     return launch_rowhess_mfma_direct(h, B, Z, X0, lambda, nullptr, nullptr, 0, nullptr, 1, s, hvals, sigma);
 }
 

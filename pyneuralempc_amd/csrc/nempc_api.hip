@@ -404,6 +404,7 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
         h->variant = cfg->kernel;
     } else if (cfg->kernel == NEMPC_KERNEL_AUTO && mfma_supported(*h) && !mfma_slower_than_layered(*h)) {
         h->variant = NEMPC_KERNEL_MFMA;
+        h->layered_hess = mfma_hess_on_layered(*h);
     } else if (cfg->kernel == NEMPC_KERNEL_LAYERED || cfg->kernel == NEMPC_KERNEL_AUTO) {
         // wide / deep / mixed-activation networks: rows through the layer-at-a-time GEMM pipeline (kernels_layered.hip).
         // Internally the handle stays on the generic variant -- Hessian blocks and everything else the pipeline does not
@@ -427,6 +428,7 @@ int nempc_create(const nempc_config* cfg, nempc_handle* out) {
             if ((rc = layered_reserve(*h))) break;
         } else {
             if ((rc = ensure_valu_ws(*h))) break;
+            if (h->layered_hess && (rc = layered_reserve(*h))) break;
         }
         if ((rc = dev_alloc(&h->d_hess_ws, Bm * cfg->H * h->nin * h->nin * h->esz))) break;
         if ((rc = rebuild_structure(*h))) break;
@@ -479,6 +481,7 @@ int nempc_reserve(nempc_handle hh, int32_t max_batch) {
             if ((rc = layered_reserve(h))) break;
         } else {
             if ((rc = ensure_valu_ws(h))) break;
+            if (h.layered_hess && (rc = layered_reserve(h))) break;
         }
         if ((rc = dev_alloc(&h.d_hess_ws, Bm * h.cfg.H * h.nin * h.nin * h.esz))) break;
         if ((rc = dev_alloc(&h.d_g_ws, Bm * h.m * h.esz))) break;

@@ -165,6 +165,7 @@ struct Handle {
     long long layered_chunk_rows = 0;
     void* d_layered_hws = nullptr;  // chunk workspace of its Hessian sweeps (allocated on first use)
     long long layered_hess_chunk_rows = 0;
+    bool layered_hess = false;          // a register-resident (MFMA) handle whose Lagrangian blocks come from the layered sweeps (mfma_hess_on_layered)
     void* d_layered_pairs = nullptr;    // (dout[0], nin (nin + 1) / 2): W_0[p][n] W_0[q][n], p >= q (layer 0's curvature term)
     bool layered_pairs_valid = false;
     void* solver_ws = nullptr;   // solver.hip
@@ -221,6 +222,7 @@ void layered_free(Handle& h);
 // ---- kernels_mfma.hip : matrix-core row kernel
 bool mfma_supported(const Handle& h);
 bool mfma_slower_than_layered(const Handle& h);    // AUTO prefers the layered path (kernels_mfma.hip)
+bool mfma_hess_on_layered(const Handle& h);        // AUTO: rows on the register-resident kernels, Lagrangian blocks on the layered sweeps
 int mfma_pack_weights(Handle& h, const double* const* W, const double* const* b);
 int launch_rows_mfma(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s);
 int launch_eval_fused(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, void* jac, void* f,

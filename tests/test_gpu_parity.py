@@ -634,6 +634,39 @@ def test_mixed_activations_run_on_the_layered_path_and_are_refused_by_the_regist
     np.testing.assert_allclose(e2.eval_numpy(Zh, X0h)["jac_dense"], orc.Problem(n2, 6, 2, 1).eval_batch(Zh, X0h)[3], **F64)
 
 
+@pytest.mark.parametrize("kind", [0, 1])
+def test_fp64_three_by_128_rows_stay_register_resident_and_the_lagrangian_blocks_take_the_layered_sweeps(kind):
+    """AUTO, fp64, 3 x 128 (kernels_mfma.hip: mfma_hess_on_layered): the rows launch is the wave-per-tile kernel, the exact
+    Hessian the layer-at-a-time sweeps (2x faster than the wave-per-tile Hessian kernel there); both against the oracle
+    and against the wave-per-tile kernel asked for by name; hvals / dense / blocks outputs and the solver's entry."""
+    from pyneuralempc_amd import CallbackEngine
+    B, H, nx, nu = 37, 9, 3, 2
+    net = orc.MLP.random(nx + nu, [128, 128, 128], nx, seed=4)
+    Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=5)
+    rng = np.random.default_rng(6)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=KIND_NAME[kind], DT=0.1, dtype=torch.float64, device="cuda:0", max_batch=B)
+    byname = CallbackEngine(net.W, net.b, H, nx, nu, integrator=KIND_NAME[kind], DT=0.1, dtype=torch.float64, device="cuda:0",
+                            max_batch=B, kernel="mfma")
+    assert eng.kernel_variant == "mfma" and byname.kernel_variant == "mfma"
+    lamh, sigh = rng.normal(size=(B, eng.m)), rng.uniform(0.5, 2.0, size=B)
+    Z, X0, lam, sig = (eng.to_device(a) for a in (Zh, X0h, lamh, sigh))
+    res = eng.eval(Z, X0, ("g", "jac_dense"))
+    assert eng.last_row_kernel == "rows_mfma_kernel"      # (fp64 slices of 3 x 128 do not fit the cooperative kernel)
+    prob = orc.Problem(net, H, nx, nu, kind, 0.1)
+    _, _, g, jac = prob.eval_batch(Zh, X0h)
+    np.testing.assert_allclose(res["jac_dense"].cpu().numpy(), jac, **F64)
+    for want in (("hvals",), ("hvals", "hdense", "hblocks")):
+        out = eng.hess(Z, X0, lam, sig, want=want)
+        assert eng.last_hess_kernel == "layered_gemm_kernel"
+        ref = byname.hess(Z, X0, lam, sig, want=want)
+        assert byname.last_hess_kernel == "rowhess_mfma_kernel"
+        for k in want:
+            np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].cpu().numpy(), rtol=1e-10, atol=1e-11)
+    hd = out["hdense"].cpu().numpy()
+    for i in (0, B - 1):
+        np.testing.assert_allclose(hd[i], prob.lagrangian_hessian(Zh[i], X0h[i], lamh[i], sigh[i]), rtol=1e-10, atol=1e-11)
+
+
 @pytest.mark.parametrize("act", ["relu", "elu", "sigmoid", "softplus"])
 def test_nan_inputs_stay_visible_for_every_activation(act):
     from pyneuralempc_amd import CallbackEngine
