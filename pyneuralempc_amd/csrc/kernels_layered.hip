@@ -60,6 +60,26 @@ __device__ __forceinline__ void lg_act_all(int code, T z, T par, bool want_e, T&
         e = want_e ? act_r2<T>(code, a, par) * d1 : T(0);
     }
 }
+// ... of NV pre-activations at once with the (wave-uniform) switch over the code taken once for the common activations (see
+// lg_dval_n); the formulas -- and the bits -- are lg_act_all's
+template <typename T, int NV>
+__device__ __forceinline__ void lg_act_all_n(int code, T par, bool want_e, const T (&z)[NV], T (&a)[NV], T (&d1)[NV], T (&e)[NV]) {
+#define LG_ACT_CASE(CODE)                                                                                     \
+    case CODE:                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < NV; ++i) lg_act_all<T>(CODE, z[i], par, want_e, a[i], d1[i], e[i]); \
+        break;
+    switch (code) {
+        LG_ACT_CASE(NEMPC_ACT_TANH)
+        LG_ACT_CASE(NEMPC_ACT_RELU)
+        LG_ACT_CASE(NEMPC_ACT_SIGMOID)
+        LG_ACT_CASE(NEMPC_ACT_LINEAR)
+        default:
+#pragma unroll
+            for (int i = 0; i < NV; ++i) lg_act_all<T>(code, z[i], par, want_e, a[i], d1[i], e[i]);
+            break;
+    }
+#undef LG_ACT_CASE
+}
 
 // Derivatives from the stored ACTIVATION (round 5).  For the activations whose s' is a cheap function of the output (tanh, relu, sigmoid, elu, leaky_relu, selu -- not softplus, whose s' costs an exp, and not the ones written from the
 // pre-activation) a layer stores a = s(z) only; whoever needs s'(z) or s''(z) later reads a and forms d1(a) / r2(a) d1(a) in
@@ -90,6 +110,30 @@ __device__ __forceinline__ T lg_dval(int code, T par, int use, T v) {
     }
     return use ? r2 * d1 : d1;
 }
+// ... of NV values at once, the (wave-uniform) switches taken ONCE: per element they are a chain of scalar branches around every
+// value -- and while the other workgroups of the CU hold the vector pipe with 64-cycle matrix instructions, every instruction
+// of an epilogue costs its wave a pipe slot of that length (tools/diag_stamps_layered.py).  The formulas are lg_dval's.
+template <typename T, int NV>
+__device__ __forceinline__ void lg_dval_n(int code, T par, int use, T (&v)[NV]) {
+#define LG_DVAL_CASE(CODE)                                                                  \
+    case CODE:                                                                              \
+        if (use) {                                                                          \
+            _Pragma("unroll") for (int i = 0; i < NV; ++i) v[i] = lg_dval<T>(CODE, par, 1, v[i]); \
+        } else {                                                                            \
+            _Pragma("unroll") for (int i = 0; i < NV; ++i) v[i] = lg_dval<T>(CODE, par, 0, v[i]); \
+        }                                                                                   \
+        break;
+    switch (code) {
+        LG_DVAL_CASE(NEMPC_ACT_TANH)
+        LG_DVAL_CASE(NEMPC_ACT_RELU)
+        LG_DVAL_CASE(NEMPC_ACT_SIGMOID)
+        LG_DVAL_CASE(NEMPC_ACT_ELU)
+        LG_DVAL_CASE(NEMPC_ACT_LEAKY_RELU)
+        LG_DVAL_CASE(NEMPC_ACT_SELU)
+        default: break;          // the derivatives themselves were stored
+    }
+#undef LG_DVAL_CASE
+}
 
 struct GemmArgs {
     const void* A;      // A^T: (K, M) element (k, m) at A[k * lda + m]
@@ -103,6 +147,7 @@ struct GemmArgs {
     long long lda, ldc, ldd;
     int ldb, M, N, K, mode, act;
     int nblk;           // feature blocks (ceil(N / BN)), set by the launcher
+    unsigned nblk_magic;    // floor(2^32 / nblk) + 1: slot / nblk = umulhi(slot, magic) for slot < 2^32 / nblk (set by the launcher)
     double actp;        // alpha of an elu / leaky_relu layer
     long long Rmod;     // reverse: rows per cotangent block (a multiple of LG_BM, so a block never straddles two)
     // SEED (the first reverse product forms its operand on the fly instead of reading a seed matrix from memory):
@@ -131,7 +176,37 @@ struct GemmArgs {
     int sact;           // SEED: != 0: the loader's operand A is an activation matrix, s' is formed on the way to LDS
     double sactp;
     int store_a;        // forward: the D slot receives the activation itself (C / E are then not written by CONTRACT_FORWARD)
+    long long* dbg;     // diagnostic builds only (-DNEMPC_STAMPS, tools/diag_stamps_layered.py): per-workgroup timeline
 };
+
+#ifdef NEMPC_STAMPS
+// per-workgroup timeline of ONE of the products of an evaluation (NEMPC_LG_STAMP = 10 SEED + CONTRACT picks it; the last launch
+// of that form wins): word idx of the workgroup's 16-word record = shader clock; 13 = the chip's real-time counter at exit,
+// 15 = XCC id << 32 | HW_ID (kernels_coop_impl.h, COOP_WGSTAMP)
+long long* g_lg_dbg = nullptr;
+#define LG_WGSTAMP(idx)                                                                        \
+    do {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096)                                    \
+            a.dbg[1024 + blockIdx.x * 16 + (idx)] = (long long)__builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#define LG_WGSTAMP_EXIT()                                                                      \
+    do {                                                                                       \
+        LG_WGSTAMP(14);                                                                        \
+        if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096) {                                  \
+            a.dbg[1024 + blockIdx.x * 16 + 13] = (long long)__builtin_amdgcn_s_memrealtime();  \
+            a.dbg[1024 + blockIdx.x * 16 + 15] = ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); \
+        }                                                                                      \
+    } while (0)
+#else
+#define LG_WGSTAMP(idx) \
+    do {                \
+    } while (0)
+#define LG_WGSTAMP_EXIT() \
+    do {                  \
+    } while (0)
+#endif
 
 enum { LG_CONTRACT_NONE = 0, LG_CONTRACT_REVERSE = 1, LG_CONTRACT_FORWARD = 2, LG_CONTRACT_HPAIR = 3 };
 
@@ -194,11 +269,17 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
     // back: the row operand (the activations) then comes from HBM once and from that XCD's L2 for the other NB - 1 feature
     // blocks.  (Row blocks fastest, as a plain 2-D grid has it, re-read the activations from memory once per feature block:
     // 3.4 TB/s for a 256 x 256 layer at B*H = 20480 -- the kernel was bandwidth-bound at 0.47 of the matrix peak.)
+    // (The start of a workgroup runs beside three others that hold the vector pipe with 64-cycle matrix instructions: every
+    // vector instruction up here costs it such a slot.  So the block decomposition stays on the scalar unit -- the division by
+    // the number of feature blocks is a multiply-high with the launcher's reciprocal, the cotangent of a block a short
+    // subtraction loop -- where the compiler's integer divisions went through the vector unit's reciprocal.)
     const int NB = a.nblk;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int nb = slot % NB, mb = (slot / NB) * 8 + xcd;
+    const int sq = NB == 1 ? slot : (int)__builtin_amdgcn_readfirstlane((int)__umulhi((unsigned)slot, a.nblk_magic));       // slot / NB
+    const int nb = slot - sq * NB, mb = sq * 8 + xcd;
     const long long m0 = (long long)mb * BM;
     if (m0 >= a.M) return;
+    LG_WGSTAMP(0);
     const int n0 = nb * BN;
     const T* __restrict__ A = static_cast<const T*>(a.A);
     const T* __restrict__ Bw = static_cast<const T*>(a.Bw);
@@ -211,26 +292,43 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
     constexpr int NW = BK * BN / 256, NA = BK * BM / 256;       // elements per thread and chunk
     // (unsigned BYTE offsets inside a chunk; largest: 15 rows of 16 x 65536 elements of 8 bytes, 126 MB)
     unsigned offW[NW], offA[NA];
+    {
+        // element u of a thread sits 256 u / BN rows further down the chunk: one offset and scalar steps (64- and 32-wide tiles)
+        static_assert(256 % BN == 0, "a thread's elements of the weight tile are whole rows apart");
+        const int kk = tid / BN, x = tid % BN;
+        const unsigned o0 = (unsigned)(kk * a.ldb + (n0 + x < N ? x : N - 1 - n0)) * (unsigned)sizeof(T);
+        const unsigned step = (unsigned)((256 / BN) * a.ldb) * (unsigned)sizeof(T);
 #pragma unroll
-    for (int u = 0; u < NW; ++u) {
-        const int e = tid + 256 * u, kk = e / BN, x = e % BN;
-        offW[u] = (unsigned)(kk * a.ldb + (n0 + x < N ? x : N - 1 - n0)) * (unsigned)sizeof(T);
+        for (int u = 0; u < NW; ++u) offW[u] = o0 + (unsigned)u * step;
     }
+    if constexpr (256 % BM == 0 && !(IL && SEED)) {
+        const int kk = tid / BM, x = tid % BM;
+        const unsigned o0 = (unsigned)((long long)kk * a.lda + (m0 + x < M ? x : M - 1 - m0)) * (unsigned)sizeof(T);
+        const unsigned step = (unsigned)((long long)(256 / BM) * a.lda) * (unsigned)sizeof(T);
 #pragma unroll
-    for (int u = 0; u < NA; ++u) {
-        const int e = tid + 256 * u, kk = e / BM, x = e % BM;
-        if constexpr (IL && SEED) {
-            // the operand is D_0^T (or a_0^T): column x of the tile reads row 16 mb + x % 16, whatever its input x / 16
-            const long long row = (long long)mb * 16 + (x & 15);
-            offA[u] = (unsigned)((long long)kk * a.lda + (row < a.Rmod ? row : a.Rmod - 1)) * (unsigned)sizeof(T);
-        } else {
-            offA[u] = (unsigned)((long long)kk * a.lda + (m0 + x < M ? x : M - 1 - m0)) * (unsigned)sizeof(T);
+        for (int u = 0; u < NA; ++u) offA[u] = o0 + (unsigned)u * step;
+    } else {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int e = tid + 256 * u, kk = e / BM, x = e % BM;
+            if constexpr (IL && SEED) {
+                // the operand is D_0^T (or a_0^T): column x of the tile reads row 16 mb + x % 16, whatever its input x / 16
+                const long long row = (long long)mb * 16 + (x & 15);
+                offA[u] = (unsigned)((long long)kk * a.lda + (row < a.Rmod ? row : a.Rmod - 1)) * (unsigned)sizeof(T);
+            } else {
+                offA[u] = (unsigned)((long long)kk * a.lda + (m0 + x < M ? x : M - 1 - m0)) * (unsigned)sizeof(T);
+            }
         }
     }
     const T* __restrict__ Wb = Bw + n0;
     // SEED: the operand's column m = (cotangent m / Rmod, row m % Rmod) reads column m % Rmod of D_{L-2}^T; a block of 64
     // columns lies inside one cotangent (Rmod is a multiple of 64)
-    const long long mrow0 = IL ? 0 : ((SEED || a.mode == LG_REVERSE) ? m0 % a.Rmod : 0);
+    long long mrow0 = 0;
+    int mcot = 0;           // m0 = mcot Rmod + mrow0 (at most nx - 1, resp. nin - 1, subtractions)
+    if (!IL && (SEED || a.mode == LG_REVERSE)) {
+        mrow0 = m0;
+        while (mrow0 >= a.Rmod) { mrow0 -= a.Rmod; ++mcot; }
+    }
     const T* __restrict__ Ab = A + (IL ? (SEED ? 0 : m0) : (SEED ? mrow0 : m0));
     // A chunk on its way from memory to LDS.  Two of them: the loads of chunk c + 2 are issued at the start of chunk c and
     // written to LDS at the end of chunk c + 1 -- two chunks of matrix instructions (~3 us with four waves on the SIMD) to
@@ -249,7 +347,7 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
     const int krow0 = RM == 4 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid / BM;
     if constexpr (SEED && !IL) {
         const int x = tid % BM;
-        seed_cot = (int)(m0 / a.Rmod);
+        seed_cot = mcot;
         // (no s_L': the tangent sweep of the Hessian, whose seed is W_0^T . D_0)
         seed_dl = a.seedDl ? static_cast<const T*>(a.seedDl)[(size_t)seed_cot * a.Rmod + mrow0 + (m0 + x < M ? x : M - 1 - m0)] : T(1);
     }
@@ -281,11 +379,23 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
             const int e = tid + 256 * u;
             Ws(buf, e / BN, e % BN) = cr.rw[u];
         }
+        if constexpr (SEED) {
+            // (the seed kernel's order of operations: (W_last s_L') D; one switch over the activation for the chunk's elements)
+            T dv[NA];
 #pragma unroll
-        for (int u = 0; u < NA; ++u) {
-            const int e = tid + 256 * u;
-            // (the seed kernel's order of operations: (W_last s_L') D)
-            As(buf, e / BM, e % BM) = SEED ? (IL ? cr.sw[u] : cr.sw[u] * seed_dl) * lg_dval<T>(a.sact, (T)a.sactp, 0, cr.ra[u]) : cr.ra[u];
+            for (int u = 0; u < NA; ++u) dv[u] = cr.ra[u];
+            lg_dval_n<T, NA>(a.sact, (T)a.sactp, 0, dv);
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int e = tid + 256 * u;
+                As(buf, e / BM, e % BM) = (IL ? cr.sw[u] : cr.sw[u] * seed_dl) * dv[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int e = tid + 256 * u;
+                As(buf, e / BM, e % BM) = cr.ra[u];
+            }
         }
     };
 
@@ -315,8 +425,10 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
     ChunkRegs c0, c1;           // c0: even chunks, c1: odd chunks
     load_chunk(0, c0);
     load_chunk(1, c1);
+    LG_WGSTAMP(1);
     store_chunk(0, c0);
     __syncthreads();
+    LG_WGSTAMP(2);
     // pairs of chunks (no exit in the middle of the body: with one, the accumulators were copied between two register sets
     // every pass and every copy waited out the matrix pipe); an odd last chunk follows the loop
     // pairs of chunks, no branch in the body: the compiler's wait-count bookkeeping stays exact -- a wait for the OLDER set only
@@ -336,6 +448,7 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
         chunk_barrier();
     }
     if (ch < nchunks) mma_chunk(0);
+    LG_WGSTAMP(3);
     // Where a 256 x 256 reverse product (B*H = 20480, fp64; 68 us at the matrix peak) spends its 148 us, by leaving parts out
     // (profiles/r04_layered_gemm_limiter.txt; the experiment's switches are gone from the source): no epilogue 110 us, no global loads 118, no LDS reads 143, no barrier 149, none of
     // loads / LDS / barrier 125.  The epilogue's dependent round trip for s'(z) at the end of every workgroup is the largest
@@ -362,13 +475,23 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
         T part[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) part[i] = T(0);
+        T wv4[4], dv4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + fb + Ops::row(q, r);
+            const size_t at = (n < N && rok) ? (size_t)n * a.ldd + row : (size_t)n0 * a.ldd + (size_t)mb * 16;
+            wv4[r] = Wl[at];
+            dv4[r] = C ? D[at] : T(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (C) lg_dval_n<T, 4>(a.dact, (T)a.dactp, 0, dv4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + fb + Ops::row(q, r);
             const bool ok = n < N && rok;
-            const T wv = ok ? Wl[(size_t)n * a.ldd + row] : T(0);
+            const T wv = ok ? wv4[r] : T(0);
             if (C) {
-                const T dv = ok ? lg_dval<T>(a.dact, (T)a.dactp, 0, D[(size_t)n * a.ldd + row]) : T(0);
+                const T dv = ok ? dv4[r] : T(0);
 #pragma unroll
                 for (int rm = 0; rm < RM; ++rm)
                     if (n < N) C[(size_t)n * a.ldc + m0 + 16 * rm + c] = acc[0][rm][r] * dv;
@@ -400,6 +523,7 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
                 static_cast<T*>(a.Jp)[(size_t)nb * a.jp_stride + (size_t)i * a.ldj + rw] = v;
             }
         }
+        LG_WGSTAMP_EXIT();
         return;
     } else
     if constexpr (CONTRACT != LG_CONTRACT_NONE) {
@@ -414,6 +538,39 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
         const T* __restrict__ W0 = static_cast<const T*>(a.w0t);
         T* __restrict__ Jp = static_cast<T*>(a.Jp) + (size_t)nb * a.jp_stride;
         T gd[RM][4];
+        // the skinny matrix's fragment of the first output tile travels with the epilogue's other loads
+        T wf0[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + fb + Ops::row(q, r);
+            wf0[r] = (n < N && c < a.nin) ? W0[(size_t)n * a.ldw0 + c] : T(0);
+        }
+        if constexpr (CONTRACT == LG_CONTRACT_REVERSE) {
+            // every load of the epilogue in flight before the first value is used (left to the compiler each of the 16 was a
+            // round trip of its own -- 8 of a workgroup's 46 us, tools/diag_stamps_layered.py); out-of-range entries read
+            // the block's first element and are masked below
+            T dv[RM * 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + fb + Ops::row(q, r);
+                // (one address per feature row, the column tiles at constant offsets; a column beyond M stays inside the row's
+                // storage -- Rmod is a multiple of the block -- and its product is masked below)
+                const T* __restrict__ dp = D + (size_t)(n < N ? n : n0) * a.ldd + (m0 + mD0 + c);
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) dv[rm * 4 + r] = dp[16 * rm];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            lg_dval_n<T, RM * 4>(a.dact, (T)a.dactp, a.duse, dv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + fb + Ops::row(q, r);
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    const long long m = m0 + 16 * rm + c;
+                    gd[rm][r] = (n < N && m < M) ? acc[0][rm][r] * dv[rm * 4 + r] : T(0);
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = n0 + fb + Ops::row(q, r);
@@ -421,31 +578,61 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
             for (int rm = 0; rm < RM; ++rm) {
                 const long long m = m0 + 16 * rm + c;
                 if constexpr (CONTRACT == LG_CONTRACT_REVERSE) {
-                    gd[rm][r] = (n < N && m < M) ? acc[0][rm][r] * lg_dval<T>(a.dact, (T)a.dactp, a.duse, D[(size_t)n * a.ldd + (m + mD0)]) : T(0);
                 } else {
-                    T x = T(0);
-                    if (n < N && m < M) {
-                        T d1, e;
-                        lg_act_all<T>(a.act, acc[0][rm][r] + bias[n], (T)a.actp, a.E != nullptr, x, d1, e);
-                        D[(size_t)n * a.ldd + m] = a.store_a ? x : d1;
-                        if (a.E) static_cast<T*>(a.E)[(size_t)n * a.ldd + m] = e;
-                    }
-                    gd[rm][r] = x;
+                    (void)n; (void)m;
                 }
             }
         }
+        if constexpr (CONTRACT == LG_CONTRACT_FORWARD) {
+            T bn[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + fb + Ops::row(q, r);
+                bn[r] = bias[n < N ? n : n0];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            T z[RM * 4], x[RM * 4], d1[RM * 4], e[RM * 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) z[rm * 4 + r] = acc[0][rm][r] + bn[r];
+            lg_act_all_n<T, RM * 4>(a.act, (T)a.actp, a.E != nullptr, z, x, d1, e);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + fb + Ops::row(q, r);
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    const long long m = m0 + 16 * rm + c;
+                    const bool ok = n < N && m < M;
+                    if (ok) {
+                        D[(size_t)n * a.ldd + m] = a.store_a ? x[rm * 4 + r] : d1[rm * 4 + r];
+                        if (a.E) static_cast<T*>(a.E)[(size_t)n * a.ldd + m] = e[rm * 4 + r];
+                    }
+                    gd[rm][r] = ok ? x[rm * 4 + r] : T(0);
+                }
+            }
+        }
+        LG_WGSTAMP(4);
         const int ndt = (a.nin + 15) / 16;
         for (int dt = 0; dt < ndt; ++dt) {
             V4 P[RM];
 #pragma unroll
             for (int rm = 0; rm < RM; ++rm) P[rm] = V4{T(0), T(0), T(0), T(0)};
+            T wf[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + fb + Ops::row(q, r), d = 16 * dt + c;
-                const T wf = (n < N && d < a.nin) ? W0[(size_t)n * a.ldw0 + d] : T(0);
+            for (int r = 0; r < 4; ++r) wf[r] = wf0[r];
+            if (dt > 0) {
 #pragma unroll
-                for (int rm = 0; rm < RM; ++rm) P[rm] = Ops::mma(wf, gd[rm][r], P[rm]);
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + fb + Ops::row(q, r), d = 16 * dt + c;
+                    wf[r] = (n < N && d < a.nin) ? W0[(size_t)n * a.ldw0 + d] : T(0);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) P[rm] = Ops::mma(wf[r], gd[rm][r], P[rm]);
             // unconditional: the partial tiles go into the operand buffers, which the slower waves of the workgroup may still
             // be reading -- an odd last chunk (`if (ch < nchunks) mma_chunk(0)`: every K <= 16 product and every width with an
             // odd number of 16-deep chunks) has no barrier behind it; dt > 0: the previous pass's reads of the partial tiles
@@ -466,34 +653,71 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
                 }
             }
         }
+        LG_WGSTAMP_EXIT();
         return;
     }
+    // (loads first, one switch over the activation per workgroup, then the stores: see lg_dval_n)
 #pragma unroll
-    for (int fn = 0; fn < FT; ++fn)
+    for (int fn = 0; fn < FT; ++fn) {
+        if (a.mode == LG_FORWARD) {
+            T bn[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + fb + 16 * fn + Ops::row(q, r);
-            if (n >= N) continue;
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + fb + 16 * fn + Ops::row(q, r);
+                bn[r] = bias[n < N ? n : n0];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            T z[RM * 4], x[RM * 4], d1[RM * 4], e[RM * 4];
 #pragma unroll
-            for (int rm = 0; rm < RM; ++rm) {
-                const long long m = m0 + 16 * rm + c;
-                if (m >= M) continue;
-                const T v = acc[fn][rm][r];
-                if (a.mode == LG_FORWARD) {
-                    T x, d1, e;
-                    lg_act_all<T>(a.act, v + bias[n], (T)a.actp, a.E != nullptr, x, d1, e);
-                    C[(size_t)n * a.ldc + m] = x;
-                    if (D) D[(size_t)n * a.ldd + m] = d1;          // (null: a layer whose derivatives follow from C itself)
-                    if (a.E) static_cast<T*>(a.E)[(size_t)n * a.ldd + m] = e;
-                } else {
-                    if (C) C[(size_t)n * a.ldc + m] = v * lg_dval<T>(a.dact, (T)a.dactp, 0, D[(size_t)n * a.ldd + (m + mD0)]);
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) z[rm * 4 + r] = acc[fn][rm][r] + bn[r];
+            lg_act_all_n<T, RM * 4>(a.act, (T)a.actp, a.E != nullptr, z, x, d1, e);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + fb + 16 * fn + Ops::row(q, r);
+                if (n >= N) continue;
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    const long long m = m0 + 16 * rm + c;
+                    if (m >= M) continue;
+                    C[(size_t)n * a.ldc + m] = x[rm * 4 + r];
+                    if (D) D[(size_t)n * a.ldd + m] = d1[rm * 4 + r];          // (null: a layer whose derivatives follow from C itself)
+                    if (a.E) static_cast<T*>(a.E)[(size_t)n * a.ldd + m] = e[rm * 4 + r];
+                }
+            }
+        } else {
+            T dv[RM * 4], ev[RM * 4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + fb + 16 * fn + Ops::row(q, r);
+                const size_t at = (size_t)(n < N ? n : n0) * a.ldd + (m0 + mD0 + c);       // (see the contraction form above)
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    dv[rm * 4 + r] = C ? D[at + 16 * rm] : T(0);
+                    ev[rm * 4 + r] = a.C2 ? static_cast<const T*>(a.E)[at + 16 * rm] : T(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (C) lg_dval_n<T, RM * 4>(a.dact, (T)a.dactp, 0, dv);
+            if (a.C2) lg_dval_n<T, RM * 4>(a.dact, (T)a.dactp, 1, ev);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + fb + 16 * fn + Ops::row(q, r);
+                if (n >= N) continue;
+#pragma unroll
+                for (int rm = 0; rm < RM; ++rm) {
+                    const long long m = m0 + 16 * rm + c;
+                    if (m >= M) continue;
+                    const T v = acc[fn][rm][r];
+                    if (C) C[(size_t)n * a.ldc + m] = v * dv[rm * 4 + r];
                     if (a.Craw) static_cast<T*>(a.Craw)[(size_t)n * a.ldc + m] = v;
-                    if (a.C2)
-                        static_cast<T*>(a.C2)[(size_t)n * a.ldc + m] =
-                            v * lg_dval<T>(a.dact, (T)a.dactp, 1, static_cast<const T*>(a.E)[(size_t)n * a.ldd + (m + mD0)]);
+                    if (a.C2) static_cast<T*>(a.C2)[(size_t)n * a.ldc + m] = v * ev[rm * 4 + r];
                 }
             }
         }
+    }
+    LG_WGSTAMP_EXIT();
 }
 
 // ---- the small launches around the GEMMs (thread per row / per element; all feature-major, coalesced across rows) ----
@@ -754,7 +978,15 @@ int gemm_ft(hipStream_t s, const GemmArgs& a) {
     auto kern = layered_gemm_kernel<T, FT, SEED, CONTRACT, RM>;
     NEMPC_HIP(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), bytes));
     GemmArgs b = a;
+    b.dbg = nullptr;
+#ifdef NEMPC_STAMPS
+    {
+        static const int sel = [] { const char* e = getenv("NEMPC_LG_STAMP"); return e ? atoi(e) : 11; }();
+        if (sel == 10 * (int)SEED + CONTRACT) b.dbg = g_lg_dbg;
+    }
+#endif
     b.nblk = (a.N + S::BN - 1) / S::BN;
+    b.nblk_magic = b.nblk == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)b.nblk) + 1u;
     const long long mblk = ((long long)a.M + S::BM - 1) / S::BM;
     const dim3 grid((unsigned)(8 * b.nblk * ((mblk + 7) / 8)));      // (row blocks padded to the 8 XCDs; the surplus exits at once)
     hipLaunchKernelGGL(kern, grid, dim3(256), bytes, s, b);
@@ -1524,6 +1756,9 @@ static bool layered_hess_usable(const Handle& h) {
 }
 
 int launch_rowhess_layered(Handle& h, int B, const void* Z, const void* X0, const void* lambda, void* blocks, hipStream_t s) {
+#ifdef NEMPC_STAMPS
+    g_lg_dbg = h.d_dbg;
+#endif
     if (!layered_hess_usable(h)) return NEMPC_EUNSUPPORTED;
     if (h.cfg.integrator == NEMPC_RK4) return launch_rowhess_rk4_layered(h, B, Z, X0, lambda, blocks, s, nullptr, nullptr);
     int rc = layered_hess_prepare(h);
@@ -1554,6 +1789,9 @@ int launch_rows_layered_stages(Handle& h, int B, const void* Z, const void* X0, 
 }
 
 int launch_rows_layered(Handle& h, int B, const void* Z, const void* X0, void* g, void* tiles, hipStream_t s) {
+#ifdef NEMPC_STAMPS
+    g_lg_dbg = h.d_dbg;
+#endif
     int rc = layered_prepare(h);
     if (rc) return rc;
     h.last_row_kernel = 8;
