@@ -148,6 +148,8 @@ struct GemmArgs {
     int ldb, M, N, K, mode, act;
     int nblk;           // feature blocks (ceil(N / BN)), set by the launcher
     unsigned nblk_magic;    // floor(2^32 / nblk) + 1: slot / nblk = umulhi(slot, magic) for slot < 2^32 / nblk (set by the launcher)
+    int ncot, rbc;          // cotangents side by side in M and row blocks per cotangent (launcher; 1, - : plain order)
+    unsigned ncot_magic;
     double actp;        // alpha of an elu / leaky_relu layer
     long long Rmod;     // reverse: rows per cotangent block (a multiple of LG_BM, so a block never straddles two)
     // SEED (the first reverse product forms its operand on the fly instead of reading a seed matrix from memory):
@@ -199,7 +201,31 @@ long long* g_lg_dbg = nullptr;
             a.dbg[1024 + blockIdx.x * 16 + 15] = ((long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492); \
         }                                                                                      \
     } while (0)
+// time of wave 0 inside the main loop by segment (sums over the chunks, shader clocks): words 5.. of the record
+#define LG_SEG_DECL() unsigned long long lg_seg[5] = {0, 0, 0, 0, 0}, lg_tprev = __builtin_amdgcn_s_memtime()
+#define LG_SEG(i)                                                       \
+    do {                                                                \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();     \
+        lg_seg[i] += _t - lg_tprev;                                     \
+        lg_tprev = _t;                                                  \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    } while (0)
+#define LG_SEG_FLUSH()                                                                       \
+    do {                                                                                     \
+        if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096)                                  \
+            for (int _i = 0; _i < 5; ++_i) a.dbg[1024 + blockIdx.x * 16 + 5 + _i] = (long long)lg_seg[_i]; \
+    } while (0)
 #else
+#define LG_SEG_DECL() \
+    do {              \
+    } while (0)
+#define LG_SEG(i) \
+    do {          \
+    } while (0)
+#define LG_SEG_FLUSH() \
+    do {               \
+    } while (0)
 #define LG_WGSTAMP(idx) \
     do {                \
     } while (0)
@@ -237,15 +263,26 @@ __device__ __forceinline__ double lg_buf_load(__amdgpu_buffer_rsrc_t r, unsigned
 __device__ __forceinline__ float lg_buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, float) {
     return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, 0, 0));
 }
+// A chunk's descriptor, on the SCALAR unit end to end.  Every input is wave-uniform; written as a C clamp, min(max(rows, 0),
+// rows_max) was selected as v_med3_i32 (there is no scalar med3), its product as v_mul_lo_u32, and both came back through
+// v_readfirstlane -- five vector instructions per chunk and operand, each of which waits for a slot between the other
+// workgroups' 64-cycle matrix instructions: a third of the main loop's time (tools/diag_stamps_layered.py, "issue loads").
+__device__ __forceinline__ int lg_sclamp(int v, int hi) {       // min(max(v, 0), hi), scalar
+    int r;
+    asm("s_max_i32 %0, %1, 0\n\ts_min_i32 %0, %0, %2" : "=&s"(r) : "s"(v), "s"(hi) : "scc");
+    return r;
+}
 template <typename T>
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rows_rsrc(const T* base, int rows, int rows_max, long long ld) {
-    const int r = rows < 0 ? 0 : (rows > rows_max ? rows_max : rows);
-    // (every input is wave-uniform, which the compiler has to SEE: the clamp alone was done on the vector unit and each load
-    // then sat in a waterfall loop over "distinct" descriptors)
-    const unsigned long long pv = reinterpret_cast<unsigned long long>(base);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lg_rows_rsrc(const T* base, int rows, int rows_max, int ld_bytes) {
+    const int bytes = lg_sclamp(rows, rows_max) * ld_bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, bytes, 0x00020000);
+}
+// a pointer the whole wave agrees on, in scalar registers (once, in front of the loop: what is derived from it stays scalar)
+template <typename T>
+__device__ __forceinline__ const T* lg_uniform(const T* p) {
+    const unsigned long long pv = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)pv), hi = __builtin_amdgcn_readfirstlane((unsigned)(pv >> 32));
-    const int bytes = __builtin_amdgcn_readfirstlane((int)((long long)r * ld * (long long)sizeof(T)));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
 }
 
 template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE, int RM = 4>
@@ -276,7 +313,20 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
     const int NB = a.nblk;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int sq = NB == 1 ? slot : (int)__builtin_amdgcn_readfirstlane((int)__umulhi((unsigned)slot, a.nblk_magic));       // slot / NB
-    const int nb = slot - sq * NB, mb = sq * 8 + xcd;
+    const int nb = slot - sq * NB;
+    // reverse products over several cotangents (column m = cotangent * Rmod + row): the cotangents of ONE row block run back to
+    // back on the same XCD -- they read the same columns of the derivative matrix, which then comes from memory once and from
+    // that XCD's L2 for the other cotangents (cotangent-major, the second cotangent's pass came 1,280 workgroups later:
+    // L2 hit rate 0.74, 190 MB from memory for an 84 MB operand)
+    int mb;
+    if (a.ncot > 1) {
+        const int sg = (int)__builtin_amdgcn_readfirstlane((int)__umulhi((unsigned)sq, a.ncot_magic));      // sq / ncot
+        const int cot = sq - sg * a.ncot, mbl = sg * 8 + xcd;
+        if (mbl >= a.rbc) return;
+        mb = cot * a.rbc + mbl;
+    } else {
+        mb = sq * 8 + xcd;
+    }
     const long long m0 = (long long)mb * BM;
     if (m0 >= a.M) return;
     LG_WGSTAMP(0);
@@ -351,9 +401,14 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
         // (no s_L': the tangent sweep of the Hessian, whose seed is W_0^T . D_0)
         seed_dl = a.seedDl ? static_cast<const T*>(a.seedDl)[(size_t)seed_cot * a.Rmod + mrow0 + (m0 + x < M ? x : M - 1 - m0)] : T(1);
     }
+    const T* const Wbu = lg_uniform(Wb);
+    const T* const Abu = lg_uniform(Ab);
+    const int ldb_bytes = __builtin_amdgcn_readfirstlane(a.ldb * (int)sizeof(T));
+    const int lda_bytes = __builtin_amdgcn_readfirstlane((int)(a.lda * (long long)sizeof(T)));
+    const int Ku = __builtin_amdgcn_readfirstlane(K);
     auto load_chunk = [&](int ch, ChunkRegs& cr) {
-        const __amdgpu_buffer_rsrc_t rw = lg_rows_rsrc<T>(Wb + (size_t)ch * BK * a.ldb, K - ch * BK, BK, a.ldb);
-        const __amdgpu_buffer_rsrc_t ra = lg_rows_rsrc<T>(Ab + (size_t)ch * BK * a.lda, K - ch * BK, BK, a.lda);
+        const __amdgpu_buffer_rsrc_t rw = lg_rows_rsrc<T>(Wbu + (size_t)ch * BK * a.ldb, Ku - ch * BK, BK, ldb_bytes);
+        const __amdgpu_buffer_rsrc_t ra = lg_rows_rsrc<T>(Abu + (size_t)ch * BK * a.lda, Ku - ch * BK, BK, lda_bytes);
 #pragma unroll
         for (int u = 0; u < NW; ++u) cr.rw[u] = lg_buf_load(rw, offW[u], T(0));
 #pragma unroll
@@ -380,15 +435,24 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
             Ws(buf, e / BN, e % BN) = cr.rw[u];
         }
         if constexpr (SEED) {
-            // (the seed kernel's order of operations: (W_last s_L') D; one switch over the activation for the chunk's elements)
-            T dv[NA];
+            // (the seed kernel's order of operations: (W_last s_L') D.  One switch over the activation per chunk, and the LDS
+            // writes INSIDE its arms: merged behind it, the arms' results cost a register copy each)
+            auto put = [&](auto dfun) {
 #pragma unroll
-            for (int u = 0; u < NA; ++u) dv[u] = cr.ra[u];
-            lg_dval_n<T, NA>(a.sact, (T)a.sactp, 0, dv);
-#pragma unroll
-            for (int u = 0; u < NA; ++u) {
-                const int e = tid + 256 * u;
-                As(buf, e / BM, e % BM) = (IL ? cr.sw[u] : cr.sw[u] * seed_dl) * dv[u];
+                for (int u = 0; u < NA; ++u) {
+                    const int e = tid + 256 * u;
+                    As(buf, e / BM, e % BM) = (IL ? cr.sw[u] : cr.sw[u] * seed_dl) * dfun(cr.ra[u]);
+                }
+            };
+            const T sp = (T)a.sactp;
+            switch (a.sact) {
+                case NEMPC_ACT_TANH: put([&](T v) { return lg_dval<T>(NEMPC_ACT_TANH, sp, 0, v); }); break;
+                case NEMPC_ACT_RELU: put([&](T v) { return lg_dval<T>(NEMPC_ACT_RELU, sp, 0, v); }); break;
+                case NEMPC_ACT_SIGMOID: put([&](T v) { return lg_dval<T>(NEMPC_ACT_SIGMOID, sp, 0, v); }); break;
+                case NEMPC_ACT_ELU: put([&](T v) { return lg_dval<T>(NEMPC_ACT_ELU, sp, 0, v); }); break;
+                case NEMPC_ACT_LEAKY_RELU: put([&](T v) { return lg_dval<T>(NEMPC_ACT_LEAKY_RELU, sp, 0, v); }); break;
+                case NEMPC_ACT_SELU: put([&](T v) { return lg_dval<T>(NEMPC_ACT_SELU, sp, 0, v); }); break;
+                default: put([&](T v) { return v; }); break;          // the derivative itself was stored
             }
         } else {
 #pragma unroll
@@ -435,19 +499,29 @@ __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void la
     // (behind a branch it falls back to vmcnt(0) and the lead is gone); loads beyond the last chunk return zeros.  An odd
     // last chunk follows the loop.
     int ch = 0;
+    LG_SEG_DECL();
     for (; ch + 1 < nchunks; ch += 2) {
         load_chunk(ch + 2, c0);
         __builtin_amdgcn_sched_barrier(0);      // (issued HERE: left alone, the scheduler sinks the loads under the matrix instructions and half the lead is gone)
+        LG_SEG(0);
         mma_chunk(0);
+        LG_SEG(1);
         store_chunk(1, c1);
+        LG_SEG(2);
         chunk_barrier();
+        LG_SEG(3);
         load_chunk(ch + 3, c1);
         __builtin_amdgcn_sched_barrier(0);
+        LG_SEG(0);
         mma_chunk(1);
+        LG_SEG(1);
         store_chunk(0, c0);
+        LG_SEG(2);
         chunk_barrier();
+        LG_SEG(3);
     }
     if (ch < nchunks) mma_chunk(0);
+    LG_SEG_FLUSH();
     LG_WGSTAMP(3);
     // Where a 256 x 256 reverse product (B*H = 20480, fp64; 68 us at the matrix peak) spends its 148 us, by leaving parts out
     // (profiles/r04_layered_gemm_limiter.txt; the experiment's switches are gone from the source): no epilogue 110 us, no global loads 118, no LDS reads 143, no barrier 149, none of
@@ -988,7 +1062,17 @@ int gemm_ft(hipStream_t s, const GemmArgs& a) {
     b.nblk = (a.N + S::BN - 1) / S::BN;
     b.nblk_magic = b.nblk == 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)b.nblk) + 1u;
     const long long mblk = ((long long)a.M + S::BM - 1) / S::BM;
-    const dim3 grid((unsigned)(8 * b.nblk * ((mblk + 7) / 8)));      // (row blocks padded to the 8 XCDs; the surplus exits at once)
+    long long groups = (mblk + 7) / 8;
+    b.ncot = 1; b.rbc = 0; b.ncot_magic = 0;
+    constexpr bool il = CONTRACT == LG_CONTRACT_HPAIR;
+    static const bool cot_order = [] { const char* e = getenv("NEMPC_LG_COT_ORDER"); return !(e && atoi(e) == 0); }();
+    if (cot_order && !il && (SEED || a.mode == LG_REVERSE) && a.Rmod > 0 && a.Rmod % S::BM == 0 && a.M % a.Rmod == 0 && a.M / a.Rmod > 1) {
+        b.ncot = (int)(a.M / a.Rmod);
+        b.rbc = (int)(a.Rmod / S::BM);
+        b.ncot_magic = (unsigned)(0x100000000ull / (unsigned)b.ncot) + 1u;
+        groups = (long long)((b.rbc + 7) / 8) * b.ncot;
+    }
+    const dim3 grid((unsigned)(8 * b.nblk * groups));      // (row blocks padded to the 8 XCDs; the surplus exits at once)
     hipLaunchKernelGGL(kern, grid, dim3(256), bytes, s, b);
     NEMPC_HIP(hipGetLastError());
     return NEMPC_OK;

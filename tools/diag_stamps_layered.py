@@ -73,6 +73,16 @@ if __name__ == "__main__":
         d = d[~np.isnan(d)]
         if len(d):
             print(f"   {names[a]:>28s} -> {names[b]:<28s}: min {d.min():6.2f}  p10 {np.percentile(d, 10):6.2f}  median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us")
+    # wave 0's time inside the main loop by segment (sums over the chunks)
+    seg = wg[:, 5:9].astype(np.float64) / f_mhz
+    tot = seg.sum(axis=1)
+    print("   main loop of wave 0, us per workgroup (median / p10 / p90): " + "   ".join(
+        f"{nm} {np.median(seg[:, i]):.2f} / {np.percentile(seg[:, i], 10):.2f} / {np.percentile(seg[:, i], 90):.2f}"
+        for i, nm in enumerate(["issue loads", "LDS reads + matrix instr.", "wait loads + LDS writes", "barrier"])))
+    late = T[:, 0] > 0.6 * np.nanmax(T[:, 14])          # the last round: two workgroups per CU
+    for label, sel in (("first rounds", ~late), ("last round ", late)):
+        if sel.any():
+            print(f"      {label}: " + "   ".join(f"{np.median(seg[sel, i]):.2f}" for i in range(4)) + f"   (n = {int(sel.sum())})")
     # per CU: how many workgroups are in their main loop (matrix instructions) at a time
     span = np.nanmax(T[:, 14])
     grid = np.linspace(0, span, 400)
