@@ -285,6 +285,13 @@ __device__ __forceinline__ const T* lg_uniform(const T* p) {
     return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
 }
 
+// (Round 5 tried RESIDENT workgroups -- as many as the chip holds, each walking blocks blockIdx.x, blockIdx.x + gridDim.x, ... -- to
+// save the dispatch of a new workgroup and its cold argument loads, 2 - 4 us of a block's 45 (tools/diag_stamps_layered.py).  With the
+// block body inlined into the loop the register allocation of the fp64 forms collapses (300 - 900 B of scratch, spills inside the
+// main loop: 2 x 256 evaluations 238 -> 385 us with one block per workgroup, 337 us resident -- so residency itself is worth 12 %);
+// with the argument block re-read through an opaque kernarg pointer every iteration it still spills (120 - 930 B); as a
+// __noinline__ function per block (arguments made uniform on entry) the main loop is clean but the evaluation takes 289 - 300 us.
+// Not kept; profiles/r05_layered_resident.txt.)
 template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE, int RM = 4>
 __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void layered_gemm_kernel(GemmArgs a) {
 
