@@ -79,15 +79,16 @@ bool mfma_slower_than_layered(const Handle& h) {
     return ((nh - 1) * 2 * MT * 4 + 8) * 2 > 144;          // coop_fits_registers<double, WP, NH>() of kernels_mfma_typed.inc
 }
 
-// Shapes whose ROWS are fastest on the register-resident kernels but whose Lagrangian blocks are not: fp64, padded width 128,
-// three hidden layers -- the weight slices do not fit the cooperative Hessian kernel, the wave-per-tile one streams 1.5 MB of
-// weights per tile: 565 us per callback at B = 1024, H = 20, 2/1 against 277 us for the layered sweeps (with the tangent
-// contraction folded in and s' / s'' from the activations, round 5), while the rows take 154 us against 190
-// (tools/narrow_bench.py).  Discret / Unity; the RK4 pipeline keeps its own network kernel.
+// Shapes whose ROWS are fastest on the register-resident kernels but whose Lagrangian blocks are not (fp64, padded width 128,
+// Discret / Unity; the RK4 pipeline keeps its own network kernel; tools/narrow_bench.py, B = 1024, H = 20, 2/1, us per callback):
+//   three hidden layers, one activation: the weight slices do not fit the cooperative Hessian kernel, the wave-per-tile one
+//     streams 1.5 MB of weights per tile: 565 against 250 for the layered sweeps (the rows: 154 against 150 - 190)
+//   two hidden layers, run-time activation codes: the cooperative Hessian kernel with the activation switches inlined, 182
+//     against 161 (the rows: 101 against 105)
 bool mfma_hess_on_layered(const Handle& h) {
     static const bool off = [] { const char* e = getenv("NEMPC_MFMA_HESS_LAYERED"); return e && atoi(e) == 0; }();
     if (off || h.cfg.dtype != NEMPC_F64 || h.cfg.integrator == NEMPC_RK4 || !layered_supported(h)) return false;
-    return padded_width(h) == 128 && h.nl - 1 == 3;
+    return padded_width(h) == 128 && (h.nl - 1 == 3 || (h.nl - 1 == 2 && h.mfma_act == NEMPC_ACT_RUNTIME));
 }
 
 void mfma_free(Handle& h) {

@@ -635,23 +635,28 @@ def test_mixed_activations_run_on_the_layered_path_and_are_refused_by_the_regist
 
 
 @pytest.mark.parametrize("kind", [0, 1])
-def test_fp64_three_by_128_rows_stay_register_resident_and_the_lagrangian_blocks_take_the_layered_sweeps(kind):
-    """AUTO, fp64, 3 x 128 (kernels_mfma.hip: mfma_hess_on_layered): the rows launch is the wave-per-tile kernel, the exact
-    Hessian the layer-at-a-time sweeps (2x faster than the wave-per-tile Hessian kernel there); both against the oracle
-    and against the wave-per-tile kernel asked for by name; hvals / dense / blocks outputs and the solver's entry."""
+@pytest.mark.parametrize("shape", ["3x128_tanh", "2x128_mix"])
+def test_fp64_three_by_128_rows_stay_register_resident_and_the_lagrangian_blocks_take_the_layered_sweeps(kind, shape):
+    """AUTO, fp64, width 128 (kernels_mfma.hip: mfma_hess_on_layered) -- three hidden layers with one activation, two with a
+    per-layer mix: the rows launch is the register-resident kernel, the exact Hessian the layer-at-a-time sweeps (measured
+    faster there); both against the oracle and against the register-resident Hessian kernel asked for by name; hvals / dense /
+    blocks outputs."""
     from pyneuralempc_amd import CallbackEngine
     B, H, nx, nu = 37, 9, 3, 2
-    net = orc.MLP.random(nx + nu, [128, 128, 128], nx, seed=4)
+    hidden, acts, rowk, hessk = (([128, 128, 128], None, "rows_mfma_kernel", "rowhess_mfma_kernel") if shape == "3x128_tanh" else
+                                 ([128, 128], ["tanh", "softplus", "linear"], "rows_coop_kernel", "rowhess_coop_kernel"))
+    net = orc.MLP.random(nx + nu, hidden, nx, seed=4, activations=acts)
     Zh, X0h = orc.synthetic_inputs(B, H, nx, nu, seed=5)
     rng = np.random.default_rng(6)
-    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=KIND_NAME[kind], DT=0.1, dtype=torch.float64, device="cuda:0", max_batch=B)
+    eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator=KIND_NAME[kind], DT=0.1, dtype=torch.float64, device="cuda:0", max_batch=B,
+                         activations=net.act)
     byname = CallbackEngine(net.W, net.b, H, nx, nu, integrator=KIND_NAME[kind], DT=0.1, dtype=torch.float64, device="cuda:0",
-                            max_batch=B, kernel="mfma")
+                            max_batch=B, kernel="mfma", activations=net.act)
     assert eng.kernel_variant == "mfma" and byname.kernel_variant == "mfma"
     lamh, sigh = rng.normal(size=(B, eng.m)), rng.uniform(0.5, 2.0, size=B)
     Z, X0, lam, sig = (eng.to_device(a) for a in (Zh, X0h, lamh, sigh))
     res = eng.eval(Z, X0, ("g", "jac_dense"))
-    assert eng.last_row_kernel == "rows_mfma_kernel"      # (fp64 slices of 3 x 128 do not fit the cooperative kernel)
+    assert eng.last_row_kernel == rowk      # (fp64 slices of 3 x 128 do not fit the cooperative kernel)
     prob = orc.Problem(net, H, nx, nu, kind, 0.1)
     _, _, g, jac = prob.eval_batch(Zh, X0h)
     np.testing.assert_allclose(res["jac_dense"].cpu().numpy(), jac, **F64)
@@ -659,7 +664,7 @@ def test_fp64_three_by_128_rows_stay_register_resident_and_the_lagrangian_blocks
         out = eng.hess(Z, X0, lam, sig, want=want)
         assert eng.last_hess_kernel == "layered_gemm_kernel"
         ref = byname.hess(Z, X0, lam, sig, want=want)
-        assert byname.last_hess_kernel == "rowhess_mfma_kernel"
+        assert byname.last_hess_kernel == hessk
         for k in want:
             np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].cpu().numpy(), rtol=1e-10, atol=1e-11)
     hd = out["hdense"].cpu().numpy()
