@@ -821,10 +821,99 @@ __global__ void layered_gather_kernel(RowGather gk, int nin, int ne, const T* __
     for (int j = 0; j < ne; ++j) xi[(size_t)(nin + j) * Rp + r] = extra[(size_t)gr * ne + j];
 }
 
-// (Round 5 tried gather + layer 0 as ONE vector-unit launch -- a lane per row, a wave per run of features, weights as scalar
-// loads -- instead of the gather launch and a one-chunk launch of the GEMM kernel (36 us together at 256 features x 20480 rows):
-// slower, 2 x 256 fp64 270 -> 274 us per evaluation, 3 x 256 479 -> 493 (profiles/r05_layered_first.txt): its chain of scalar
-// weight loads per feature is as latency-bound as the GEMM kernel's prologue.  Removed.)
+// Gather + layer 0 as ONE vector-unit launch (networks with few inputs, K = nin + ne <= 8: the matrix pipe has nothing to do in a
+// 3-deep product).  A block is 64 rows x 64 features: a lane holds its row's K inputs in registers, wave w walks features
+// 16 w .. 16 w + 15 with the weight column and the bias read from LDS (one address for the whole wave: a broadcast), the activation
+// leaves as a coalesced 512-byte store per feature.  Replaces the gather launch and a one-chunk launch of the GEMM kernel (5.4 +
+// 21 us at 256 features x 20480 rows in fp64: that launch is bound by its 5,120 workgroups' fixed costs, and by 84 MB of stores
+// when s' is stored next to the activation).  A first version of this idea (a wave per run of features, the weights as a chain of
+// scalar loads per feature, s' stored) measured slower and was dropped (profiles/r05_layered_first.txt); this one stores the
+// activation only where the layer's s' can be formed from it.
+// (GENERIC = false: tanh / relu / sigmoid only -- the other activations' arithmetic in the same kernel sets its register count.
+//  KP = 4 | 8: the input count padded, so that a feature's K + 1 LDS reads are issued together, without a branch per input.)
+constexpr int LG_FIRST_KMAX = 8;
+template <typename T, bool GENERIC, int KP>
+__global__ __launch_bounds__(256, 4) void layered_first_kernel(RowGather gk, int nin, int ne, const T* __restrict__ extra, const T* __restrict__ Z,
+                                                               const T* __restrict__ X0, long long r0, int R, long long Rp,
+                                                               const T* __restrict__ W0, int N, const T* __restrict__ b0, int act, T actp,
+                                                               T* __restrict__ A, T* __restrict__ D, T* __restrict__ E) {
+    __shared__ T wl[KP + 1][64];            // rows 0 .. K-1: the weights (zero above), row KP: the bias
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n0 = blockIdx.y * 64, K = nin + ne;
+    for (int i = tid; i < (KP + 1) * 64; i += 256) {
+        const int k = i >> 6, x = i & 63, n = n0 + x;
+        wl[k][x] = n < N ? (k < K ? W0[(size_t)k * N + n] : (k == KP ? b0[n] : T(0))) : T(0);
+    }
+    const int r = blockIdx.x * 64 + lane;
+    const bool live = r < R;
+    const long long gr = r0 + (live ? r : R - 1);
+    const int b = (int)(gr / gk.H), t = (int)(gr - (long long)b * gk.H);
+    const T* z = Z + (size_t)b * gk.n;
+    // every input's address first, then the loads together
+    const T* xp[KP];
+#pragma unroll
+    for (int d = 0; d < KP; ++d)
+        xp[d] = d < nin ? gather_input_ptr<T>(gk, z, X0, b, t, d) : (d < K ? extra + ((size_t)gr * ne + (d - nin)) : Z);
+    __builtin_amdgcn_sched_barrier(0);
+    T x[KP];
+#pragma unroll
+    for (int d = 0; d < KP; ++d) x[d] = *xp[d];
+#pragma unroll
+    for (int d = 0; d < KP; ++d)
+        if (d >= K) x[d] = T(0);
+    __syncthreads();
+    const bool want_e = E != nullptr;
+    auto run = [&](auto actf) {
+        // (two features in flight per wave: fully unrolled the sixteen activations took 152 registers -- three waves per SIMD, the
+        // launch in two rounds)
+#pragma clang loop unroll_count(2)
+        for (int f = 0; f < 16; ++f) {
+            const int col = 16 * w + f, n = n0 + col;
+            T wv[KP + 1];
+#pragma unroll
+            for (int d = 0; d <= KP; ++d) wv[d] = wl[d][col];
+            T zz = T(0);            // (the product first, the bias last: the order of the GEMM kernel's epilogue)
+#pragma unroll
+            for (int d = 0; d < KP; ++d) zz = fma(x[d], wv[d], zz);
+            T a, d1, e;
+            actf(zz + wv[KP], a, d1, e);
+            if (live && n < N) {
+                A[(size_t)n * Rp + r] = a;
+                if (D) D[(size_t)n * Rp + r] = d1;
+                if (E) E[(size_t)n * Rp + r] = e;
+            }
+        }
+    };
+#define LG_FIRST_CASE(CODE) \
+    case CODE: run([&](T zv, T& a, T& d1, T& e) { lg_act_all<T>(CODE, zv, actp, want_e, a, d1, e); }); break;
+    if constexpr (GENERIC) {
+        run([&](T zv, T& a, T& d1, T& e) { lg_act_all<T>(act, zv, actp, want_e, a, d1, e); });
+    } else {
+        switch (act) {
+            LG_FIRST_CASE(NEMPC_ACT_TANH)
+            LG_FIRST_CASE(NEMPC_ACT_RELU)
+            default: run([&](T zv, T& a, T& d1, T& e) { lg_act_all<T>(NEMPC_ACT_SIGMOID, zv, actp, want_e, a, d1, e); }); break;
+        }
+    }
+#undef LG_FIRST_CASE
+}
+template <typename T, typename... Args>
+void launch_first(int act, int K, dim3 grid, hipStream_t s, Args... args) {
+    const bool lean = act == NEMPC_ACT_TANH || act == NEMPC_ACT_RELU || act == NEMPC_ACT_SIGMOID;
+    if (K <= 4) {
+        if (lean) hipLaunchKernelGGL((layered_first_kernel<T, false, 4>), grid, dim3(256), 0, s, args...);
+        else hipLaunchKernelGGL((layered_first_kernel<T, true, 4>), grid, dim3(256), 0, s, args...);
+    } else {
+        if (lean) hipLaunchKernelGGL((layered_first_kernel<T, false, 8>), grid, dim3(256), 0, s, args...);
+        else hipLaunchKernelGGL((layered_first_kernel<T, true, 8>), grid, dim3(256), 0, s, args...);
+    }
+}
+// NEMPC_LAYERED_FIRST=0: gather launch + one-chunk GEMM launch for layer 0, as before (A/B; tested against the default)
+bool lg_first_on() {
+    static const bool on = [] { const char* e = getenv("NEMPC_LAYERED_FIRST"); return !(e && atoi(e) == 0); }();
+    return on;
+}
+
 // N <= NMAX outputs per column on the vector unit: out^T[n][m] = epi(sum_k A^T[k][m] Bw[k][n]).  mode 0: the network's
 // output layer (bias, activation; f and s'(z_L) stored), mode 2: plain (the last reverse step onto the inputs).
 // A block is 64 columns x 4 waves; wave w sums k = w, w + 4, ... with sixteen loads in flight per lane, the four partial
@@ -961,9 +1050,16 @@ template <typename T>
 __global__ void layered_finish_kernel(RowGather gk, int kind, T DT, int nin, const T* __restrict__ Z, const T* __restrict__ X0,
                                       long long r0, int R, long long Rp, const T* __restrict__ f, const T* __restrict__ J,
                                       const T* __restrict__ acck, const T* __restrict__ accdk, T* __restrict__ g, int m, int box,
-                                      T* __restrict__ tiles, int jblk, long long jstride) {
+                                      T* __restrict__ tiles, int jblk, long long jstride, int fblk, long long fstride,
+                                      const T* __restrict__ fbias) {
+    // (fblk > 0: f is still the feature blocks' partial sums of a LINEAR output layer -- added here in block order, bias last,
+    //  as layered_outfinish_kernel would have: its launch is gone for such networks under Discret / Unity)
+    // A thread per (row, state i) -- blockIdx.y = i -- with the loads of a partial-sum run issued four at a time: as a thread per
+    // row walking i, d and the blocks in nested run-time loops this launch was a chain of ~ 30 dependent loads on 80 workgroups
+    // (10 us at B*H = 20480 with four feature blocks).
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
+    const int i = blockIdx.y;
     const long long gr = r0 + r;
     const int nx = gk.nx, H = gk.H;
     const int b = (int)(gr / H), t = (int)(gr - (long long)b * H);
@@ -971,12 +1067,35 @@ __global__ void layered_finish_kernel(RowGather gk, int kind, T DT, int nin, con
     T* gout = g + (size_t)b * m + (size_t)t * nx;
     T* tile = tiles + (size_t)gr * nx * nin;
     const T s6 = DT / T(6);
-    for (int i = 0; i < nx; ++i) {
+    // sum of `nb` blocks `stride` apart, in block order, four loads in flight
+    auto blocksum = [&](const T* __restrict__ p, int nb, long long stride) {
+        T v = p[0];
+        int bb = 1;
+        for (; bb + 3 < nb; bb += 4) {
+            const T a0 = p[(size_t)bb * stride], a1 = p[(size_t)(bb + 1) * stride], a2 = p[(size_t)(bb + 2) * stride],
+                    a3 = p[(size_t)(bb + 3) * stride];
+            v += a0; v += a1; v += a2; v += a3;
+        }
+        if (bb + 2 < nb) {
+            const T a0 = p[(size_t)bb * stride], a1 = p[(size_t)(bb + 1) * stride], a2 = p[(size_t)(bb + 2) * stride];
+            v += a0; v += a1; v += a2;
+        } else if (bb + 1 < nb) {
+            const T a0 = p[(size_t)bb * stride], a1 = p[(size_t)(bb + 1) * stride];
+            v += a0; v += a1;
+        } else if (bb < nb) {
+            v += p[(size_t)bb * stride];
+        }
+        return v;
+    };
+    {
         const T xp = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
         const T xt = z[t * nx + i];
         T phi;
         if (kind == NEMPC_RK4) phi = xp + s6 * acck[(size_t)i * Rp + r];
-        else phi = (kind == NEMPC_DISCRET ? xp : T(0)) + f[(size_t)i * Rp + r];
+        else {
+            T fv = fblk ? blocksum(f + (size_t)i * Rp + r, fblk, fstride) + fbias[i] : f[(size_t)i * Rp + r];
+            phi = (kind == NEMPC_DISCRET ? xp : T(0)) + fv;
+        }
         gout[i] = phi - xt;
         if (box) gout[(size_t)H * nx + i] = xt;
         for (int d = 0; d < nin; ++d) {
@@ -986,9 +1105,7 @@ __global__ void layered_finish_kernel(RowGather gk, int kind, T DT, int nin, con
                 // (jblk > 1: J is still the feature blocks' partial sums -- added here in block order, as layered_jreduce_kernel
                 //  would have: the reduction launch of its own is gone for Discret / Unity)
                 const size_t ji = (size_t)d * (nx * Rp) + (size_t)i * Rp + r;
-                T jv = J[ji];
-                for (int bb = 1; bb < jblk; ++bb) jv += J[(size_t)bb * jstride + ji];
-                v = jv + ((kind == NEMPC_DISCRET && d == gk.xcur + i) ? T(1) : T(0));
+                v = blocksum(J + ji, jblk, jstride) + ((kind == NEMPC_DISCRET && d == gk.xcur + i) ? T(1) : T(0));
             }
             tile[i * nin + d] = v;
         }
@@ -1198,12 +1315,24 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
         int jblk = 1;                       // the Jacobian as the finish kernel finds it: jblk feature blocks of partial sums
         const T* jsrc = ws + o.j;
         long long jstride = 0;
+        const T* fsrc = nullptr;            // the network output likewise (lin_skip: partial sums of a linear output layer)
+        int fblk = 0;
+        long long fstride = 0;
         for (int st = 0; st < nstages; ++st) {
             const T cdt = st == 0 ? T(0) : (st == 3 ? DT : T(0.5) * DT);
             const bool fuse_out = layered_fuse();
-            hipLaunchKernelGGL(layered_gather_kernel<T>, rg, rb, 0, s, gk, nin, ne, static_cast<const T*>(h.d_extra), Z, X0, r0, R, Rp,
-                               ws + o.xi, st > 0 ? ws + o.kprev : nullptr, cdt);
-            NEMPC_HIP(hipGetLastError());
+            static const bool outskip = [] { const char* e = getenv("NEMPC_LAYERED_OUTSKIP"); return !(e && atoi(e) == 0); }();      // (A/B, tested)
+            const bool lin_skip = outskip && fuse_out && nl >= 3 && !rk4 && h.act[nl - 1] == NEMPC_ACT_LINEAR;
+            // gather + layer 0 in one vector-unit launch (layered_first_kernel): few inputs, two hidden layers or more (layer 0 is
+            // not the layer the output contraction leaves from), Discret / Unity (the RK4 stages' inputs carry c DT k_{s-1} and
+            // their records want xi)
+            const bool first = lg_first_on() && !rk4 && nl - 1 >= 2 && nin + ne <= LG_FIRST_KMAX;
+            const bool first_dfa = first && lg_dfa_on() != 0 && lg_d_from_a(h.act[0]);
+            if (!first) {
+                hipLaunchKernelGGL(layered_gather_kernel<T>, rg, rb, 0, s, gk, nin, ne, static_cast<const T*>(h.d_extra), Z, X0, r0, R, Rp,
+                                   ws + o.xi, st > 0 ? ws + o.kprev : nullptr, cdt);
+                NEMPC_HIP(hipGetLastError());
+            }
             // ---- forward: hidden layers 0 .. nl-2 (GEMM), output layer nl-1 (skinny)
             const T* in = ws + o.xi;
             // layers that store their activation only (their s' is formed from it where it is needed: lg_d_from_a); the
@@ -1218,10 +1347,20 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
             // way.  So: 1 (default) every layer of a network with three or more hidden layers, up to width 384; 2 every layer of
             // every network; 0 none.
             auto dfa = [&](int l) {
+                if (l == 0 && first_dfa) return true;       // (layered_first_kernel is store-bound: one matrix instead of two)
                 return lg_d_from_a(h.act[l]) && (lg_dfa_on() == 2 || (lg_dfa_on() == 1 && h.maxw <= 384 && nl - 1 >= 3));
             };
             for (int l = 0; l < nl - 1; ++l) {
                 T* out = dfa(l) ? ws + o.d[l] : ws + ((l & 1) ? o.x1 : o.x0);
+                if (l == 0 && first) {
+                    launch_first<T>(h.act[0], nin + ne, dim3((unsigned)((R + 63) / 64), (unsigned)((h.dout[0] + 63) / 64)), s,
+                                    gk, nin, ne, static_cast<const T*>(h.d_extra), Z, X0, r0, R, Rp, static_cast<const T*>(h.d_W[0]),
+                                    h.dout[0], static_cast<const T*>(h.d_b[0]), h.act[0], (T)h.actp[0], out,
+                                    dfa(0) ? static_cast<T*>(nullptr) : ws + o.d[0], static_cast<T*>(nullptr));
+                    NEMPC_HIP(hipGetLastError());
+                    in = out;
+                    continue;
+                }
                 if (l == nl - 2 && fuse_out) {
                     // the last hidden layer: its activations go straight into the output layer's contraction (only s' is
                     // stored); partial sums per feature block in the cotangent buffer, which the reverse sweep fills later
@@ -1233,11 +1372,22 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                     a.M = R; a.N = h.dout[l]; a.K = h.din[l];
                     a.w0t = h.d_W[nl - 1]; a.ldw0 = nx; a.nin = nx;
                     a.Jp = ws + o.g0; a.ldj = Rp; a.jp_stride = (long long)nx * Rp;
+                    if (lin_skip) {
+                        // a LINEAR output layer, Discret / Unity: s_L' = 1 (the seed loader takes a null pointer for that) and
+                        // f = sum of the partial sums + bias is formed by layered_finish_kernel -- no output step.  The partial
+                        // sums wait in the activation buffer this product does not read (the cotangent buffers are overwritten by
+                        // the reverse sweep before the finish kernel runs).
+                        T* fp = (in == ws + o.x1) ? ws + o.x0 : ws + o.x1;
+                        a.Jp = fp;
+                        fsrc = fp; fblk = (h.dout[l] + 63) / 64; fstride = a.jp_stride;
+                    }
                     if ((rc = gemm_forward<T, LG_CONTRACT_FORWARD>(h.num_cus, s, a))) return rc;
-                    hipLaunchKernelGGL(layered_outfinish_kernel<T>, rg, rb, 0, s, ws + o.g0, (h.dout[l] + 63) / 64, a.jp_stride, nx, R, Rp,
-                                       static_cast<const T*>(h.d_b[nl - 1]), h.act[nl - 1], (T)h.actp[nl - 1], ws + o.f, ws + o.dl,
-                                       static_cast<T*>(nullptr));
-                    NEMPC_HIP(hipGetLastError());
+                    if (!lin_skip) {
+                        hipLaunchKernelGGL(layered_outfinish_kernel<T>, rg, rb, 0, s, ws + o.g0, (h.dout[l] + 63) / 64, a.jp_stride, nx, R, Rp,
+                                           static_cast<const T*>(h.d_b[nl - 1]), h.act[nl - 1], (T)h.actp[nl - 1], ws + o.f, ws + o.dl,
+                                           static_cast<T*>(nullptr));
+                        NEMPC_HIP(hipGetLastError());
+                    }
                     break;
                 }
                 if ((rc = gemm<T>(h.num_cus, s, LG_FORWARD, h.act[l], in, Rp, static_cast<const T*>(h.d_W[l]), h.dout[l], out, Rp,
@@ -1269,7 +1419,7 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                     if (dfa(l)) { a.dact = h.act[l]; a.dactp = h.actp[l]; }
                     if (first) {
                         a.A = ws + o.d[nl - 2]; a.lda = Rp;
-                        a.seedW = h.d_W[nl - 1]; a.seedDl = ws + o.dl; a.seed_nx = nx;
+                        a.seedW = h.d_W[nl - 1]; a.seedDl = lin_skip ? static_cast<const T*>(nullptr) : ws + o.dl; a.seed_nx = nx;
                         if (dfa(nl - 2)) { a.sact = h.act[nl - 2]; a.sactp = h.actp[nl - 2]; }
                     } else {
                         a.A = G; a.lda = ldg;
@@ -1327,8 +1477,9 @@ int run_layered(Handle& h, int B, const void* Zv, const void* X0v, void* gv, voi
                 NEMPC_HIP(hipGetLastError());
             }
         }
-        hipLaunchKernelGGL(layered_finish_kernel<T>, rg, rb, 0, s, gk, h.cfg.integrator, DT, nin, Z, X0, r0, R, Rp, ws + o.f, jsrc,
-                           rk4 ? ws + o.acck : nullptr, rk4 ? ws + o.accdk : nullptr, g, h.m, h.box ? 1 : 0, tiles, jblk, jstride);
+        hipLaunchKernelGGL(layered_finish_kernel<T>, dim3(rg.x, (unsigned)nx), rb, 0, s, gk, h.cfg.integrator, DT, nin, Z, X0, r0, R, Rp, fsrc ? fsrc : ws + o.f, jsrc,
+                           rk4 ? ws + o.acck : nullptr, rk4 ? ws + o.accdk : nullptr, g, h.m, h.box ? 1 : 0, tiles, jblk, jstride, fblk, fstride,
+                           static_cast<const T*>(h.d_b[nl - 1]));
         NEMPC_HIP(hipGetLastError());
     }
     return NEMPC_OK;
@@ -1614,10 +1765,11 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
         const LayeredHws o = layered_hess_offsets(h, (size_t)Rp);
         const dim3 rb(256), rg((unsigned)((R + 255) / 256));
         // ---- forward, every layer's s' and s'' kept
+        const bool first = lg_first_on() && !stage && nl - 1 >= 2 && nin + ne <= LG_FIRST_KMAX;        // (see run_layered)
         if (stage)
             hipLaunchKernelGGL(layered_hgather_direct_kernel<T>, rg, rb, 0, s, stage, stage_stride, nin, ne, static_cast<const T*>(h.d_extra),
                                r0, R, Rp, ws + o.xi);
-        else
+        else if (!first)
             hipLaunchKernelGGL(layered_gather_kernel<T>, rg, rb, 0, s, gk, nin, ne, static_cast<const T*>(h.d_extra), Z, X0, r0, R, Rp,
                                ws + o.xi, static_cast<const T*>(nullptr), T(0));
         NEMPC_HIP(hipGetLastError());
@@ -1629,6 +1781,15 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
         for (int l = 0; l < nl - 1; ++l) {
             T* out = dfa(l) ? ws + o.d[l] : ws + ((l & 1) ? o.x1 : o.x0);
             const bool contract = l == nl - 2 && layered_fuse();      // the output layer in the last hidden layer's epilogue
+            if (l == 0 && first) {
+                launch_first<T>(h.act[0], nin + ne, dim3((unsigned)((R + 63) / 64), (unsigned)((h.dout[0] + 63) / 64)), s, gk,
+                                nin, ne, static_cast<const T*>(h.d_extra), Z, X0, r0, R, Rp, static_cast<const T*>(h.d_W[0]), h.dout[0],
+                                static_cast<const T*>(h.d_b[0]), h.act[0], (T)h.actp[0], out,
+                                dfa(0) ? static_cast<T*>(nullptr) : ws + o.d[0], dfa(0) ? static_cast<T*>(nullptr) : ws + o.e[0]);
+                NEMPC_HIP(hipGetLastError());
+                in = out;
+                continue;
+            }
             GemmArgs a{};
             a.mode = LG_FORWARD; a.act = h.act[l]; a.actp = h.actp[l];
             a.A = in; a.lda = Rp; a.Bw = h.d_W[l]; a.ldb = h.dout[l]; a.bias = h.d_b[l];

@@ -62,6 +62,31 @@ __device__ __forceinline__ T gather_input(const RowGather& gk, const T* __restri
     return static_cast<const T*>(gk.hu)[((size_t)b * back + (back + tau)) * nu + c];
 }
 
+// ... and where that value lives (the same case analysis, as an address: a caller with several columns to fetch forms all the
+// addresses first and then has all the loads in flight together)
+template <typename T>
+__device__ __forceinline__ const T* gather_input_ptr(const RowGather& gk, const T* __restrict__ z, const T* __restrict__ X0,
+                                                     int b, int t, int d) {
+    const int nx = gk.nx, nu = gk.nu;
+    if (gk.w == 1) {
+        if (d < nx) return t == 0 ? X0 + ((size_t)b * nx + d) : z + ((t - 1) * nx + d);
+        return z + (gk.H * nx + t * nu + (d - nx));
+    }
+    const int wx = gk.w * nx, back = gk.w - 1;
+    if (d < wx) {
+        const int j = nx == 1 ? d : (int)__umulhi((unsigned)d, gk.inv_nx), c = d - j * nx;
+        const int tau = t + (gk.rev ? -j : j - back);   // index into [x0 ; states]: 0 is x0
+        if (tau >= 1) return z + ((tau - 1) * nx + c);
+        if (tau == 0) return X0 + ((size_t)b * nx + c);
+        return static_cast<const T*>(gk.hx) + (((size_t)b * back + (back + tau)) * nx + c);
+    }
+    d -= wx;
+    const int j = nu == 1 ? d : (int)__umulhi((unsigned)d, gk.inv_nu), c = d - j * nu;
+    const int tau = t + (gk.rev ? -j : j - back);
+    if (tau >= 0) return z + (gk.H * nx + tau * nu + c);
+    return static_cast<const T*>(gk.hu) + (((size_t)b * back + (back + tau)) * nu + c);
+}
+
 // MFMA-packed network (built by nempc_set_weights when the MFMA row kernel is selected)
 struct MfmaNet {
     int wp = 0;        // padded hidden width (multiple of 16): 32 | 64 | 128

@@ -949,7 +949,9 @@ def test_layered_path_run_time_switches_agree_with_the_default(tmp_path):
     NEMPC_LAYERED_HESS=0 (Lagrangian blocks from the generic kernel), NEMPC_LAYERED_DFA=0 / 2 (every layer stores s' / s'' next to
     its activation; or none that can form them from it does, in the rows path too), NEMPC_LAYERED_HFOLD=0 (the Hessian's
     tangents through memory and layered_hcontract_kernel instead of the tangent product's epilogue), NEMPC_LG_COT_ORDER=0 (the
-    reverse products' workgroups cotangent-major instead of row-block-major) -- are read once per process: each runs in a process of
+    reverse products' workgroups cotangent-major instead of row-block-major), NEMPC_LAYERED_FIRST=0 (gather launch + a one-chunk
+    product for layer 0 instead of layered_first_kernel), NEMPC_LAYERED_OUTSKIP=0 (a linear output layer's partial sums through
+    layered_outfinish_kernel instead of the finish kernel) -- are read once per process: each runs in a process of
     its own and has to reproduce the default's rows and Lagrangian blocks to rounding (round-4 review: switches nobody tests
     are build variants nobody knows)."""
     import os
@@ -963,7 +965,8 @@ def test_layered_path_run_time_switches_agree_with_the_default(tmp_path):
                       ("rmrev2", {"NEMPC_LG_RM_REV": "2"}), ("nohess", {"NEMPC_LAYERED_HESS": "0"}),
                       ("nodfa", {"NEMPC_LAYERED_DFA": "0"}), ("dfa_all", {"NEMPC_LAYERED_DFA": "2"}), ("nohfold", {"NEMPC_LAYERED_HFOLD": "0"}),
                       ("dfa_all_nofuse", {"NEMPC_LAYERED_DFA": "2", "NEMPC_LAYERED_FUSE": "0"}),
-                      ("cot_major", {"NEMPC_LG_COT_ORDER": "0"})):
+                      ("cot_major", {"NEMPC_LG_COT_ORDER": "0"}), ("nofirst", {"NEMPC_LAYERED_FIRST": "0"}),
+                      ("nofirst_nodfa", {"NEMPC_LAYERED_FIRST": "0", "NEMPC_LAYERED_DFA": "0"}), ("outstep", {"NEMPC_LAYERED_OUTSKIP": "0"})):
         out = tmp_path / (name + ".npz")
         r = subprocess.run([sys.executable, str(script), repo, str(out)], env=dict(os.environ, **env), capture_output=True, text=True,
                            timeout=600)
