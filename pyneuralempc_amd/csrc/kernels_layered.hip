@@ -1045,6 +1045,28 @@ __global__ void layered_stage_record_kernel(int stage, int nx, int nin, long lon
         }
 }
 
+// sum of `nb` partial sums `stride` elements apart, in block order, up to four loads in flight
+template <typename T>
+__device__ __forceinline__ T lg_blocksum(const T* __restrict__ p, int nb, long long stride) {
+    T v = p[0];
+    int bb = 1;
+    for (; bb + 3 < nb; bb += 4) {
+        const T a0 = p[(size_t)bb * stride], a1 = p[(size_t)(bb + 1) * stride], a2 = p[(size_t)(bb + 2) * stride],
+                a3 = p[(size_t)(bb + 3) * stride];
+        v += a0; v += a1; v += a2; v += a3;
+    }
+    if (bb + 2 < nb) {
+        const T a0 = p[(size_t)bb * stride], a1 = p[(size_t)(bb + 1) * stride], a2 = p[(size_t)(bb + 2) * stride];
+        v += a0; v += a1; v += a2;
+    } else if (bb + 1 < nb) {
+        const T a0 = p[(size_t)bb * stride], a1 = p[(size_t)(bb + 1) * stride];
+        v += a0; v += a1;
+    } else if (bb < nb) {
+        v += p[(size_t)bb * stride];
+    }
+    return v;
+}
+
 // defects, box rows and compact tiles of the chunk's rows (same formulas as rows_valu_kernel)
 template <typename T>
 __global__ void layered_finish_kernel(RowGather gk, int kind, T DT, int nin, const T* __restrict__ Z, const T* __restrict__ X0,
@@ -1067,33 +1089,13 @@ __global__ void layered_finish_kernel(RowGather gk, int kind, T DT, int nin, con
     T* gout = g + (size_t)b * m + (size_t)t * nx;
     T* tile = tiles + (size_t)gr * nx * nin;
     const T s6 = DT / T(6);
-    // sum of `nb` blocks `stride` apart, in block order, four loads in flight
-    auto blocksum = [&](const T* __restrict__ p, int nb, long long stride) {
-        T v = p[0];
-        int bb = 1;
-        for (; bb + 3 < nb; bb += 4) {
-            const T a0 = p[(size_t)bb * stride], a1 = p[(size_t)(bb + 1) * stride], a2 = p[(size_t)(bb + 2) * stride],
-                    a3 = p[(size_t)(bb + 3) * stride];
-            v += a0; v += a1; v += a2; v += a3;
-        }
-        if (bb + 2 < nb) {
-            const T a0 = p[(size_t)bb * stride], a1 = p[(size_t)(bb + 1) * stride], a2 = p[(size_t)(bb + 2) * stride];
-            v += a0; v += a1; v += a2;
-        } else if (bb + 1 < nb) {
-            const T a0 = p[(size_t)bb * stride], a1 = p[(size_t)(bb + 1) * stride];
-            v += a0; v += a1;
-        } else if (bb < nb) {
-            v += p[(size_t)bb * stride];
-        }
-        return v;
-    };
     {
         const T xp = (t == 0) ? X0[(size_t)b * nx + i] : z[(t - 1) * nx + i];
         const T xt = z[t * nx + i];
         T phi;
         if (kind == NEMPC_RK4) phi = xp + s6 * acck[(size_t)i * Rp + r];
         else {
-            T fv = fblk ? blocksum(f + (size_t)i * Rp + r, fblk, fstride) + fbias[i] : f[(size_t)i * Rp + r];
+            T fv = fblk ? lg_blocksum<T>(f + (size_t)i * Rp + r, fblk, fstride) + fbias[i] : f[(size_t)i * Rp + r];
             phi = (kind == NEMPC_DISCRET ? xp : T(0)) + fv;
         }
         gout[i] = phi - xt;
@@ -1105,7 +1107,7 @@ __global__ void layered_finish_kernel(RowGather gk, int kind, T DT, int nin, con
                 // (jblk > 1: J is still the feature blocks' partial sums -- added here in block order, as layered_jreduce_kernel
                 //  would have: the reduction launch of its own is gone for Discret / Unity)
                 const size_t ji = (size_t)d * (nx * Rp) + (size_t)i * Rp + r;
-                v = blocksum(J + ji, jblk, jstride) + ((kind == NEMPC_DISCRET && d == gk.xcur + i) ? T(1) : T(0));
+                v = lg_blocksum<T>(J + ji, jblk, jstride) + ((kind == NEMPC_DISCRET && d == gk.xcur + i) ? T(1) : T(0));
             }
             tile[i * nin + d] = v;
         }
@@ -1691,21 +1693,17 @@ __global__ void layered_pairs_kernel(const T* __restrict__ W0, int ldw0, int dou
 template <typename T>
 __global__ void layered_hfinish_kernel(int nin, long long r0, int R, long long Rp, const T* __restrict__ Hacc, const T* __restrict__ L0,
                                        int nblk0, long long stride0, T* __restrict__ blocks) {
+    // (a thread per (row, pair) -- blockIdx.y = p (p + 1) / 2 + q: as a thread per row this was a chain of pairs x blocks dependent
+    //  loads on 80 workgroups, 13 us at B*H = 20480)
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
+    int p = 0, q = blockIdx.y;
+    while (q > p) { ++p; q -= p; }
     T* blk = blocks + (size_t)(r0 + r) * nin * nin;
-    for (int p = 0; p < nin; ++p)
-        for (int q = 0; q <= p; ++q) {
-            T v = Hacc ? Hacc[(size_t)(p * nin + q) * Rp + r] : T(0);
-            if (L0) {
-                const size_t i = (size_t)(p * (p + 1) / 2 + q) * Rp + r;
-                T l0 = L0[i];
-                for (int b = 1; b < nblk0; ++b) l0 += L0[(size_t)b * stride0 + i];
-                v += l0;
-            }
-            blk[p * nin + q] = v;
-            blk[q * nin + p] = v;
-        }
+    T v = Hacc ? Hacc[(size_t)(p * nin + q) * Rp + r] : T(0);
+    if (L0) v += lg_blocksum<T>(L0 + (size_t)blockIdx.y * Rp + r, nblk0, stride0);
+    blk[p * nin + q] = v;
+    blk[q * nin + p] = v;
 }
 
 template <typename T>
@@ -1766,6 +1764,8 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
         const dim3 rb(256), rg((unsigned)((R + 255) / 256));
         // ---- forward, every layer's s' and s'' kept
         const bool first = lg_first_on() && !stage && nl - 1 >= 2 && nin + ne <= LG_FIRST_KMAX;        // (see run_layered)
+        static const bool outskip = [] { const char* e = getenv("NEMPC_LAYERED_OUTSKIP"); return !(e && atoi(e) == 0); }();
+        const bool lin_noout = outskip && lin_out;
         if (stage)
             hipLaunchKernelGGL(layered_hgather_direct_kernel<T>, rg, rb, 0, s, stage, stage_stride, nin, ne, static_cast<const T*>(h.d_extra),
                                r0, R, Rp, ws + o.xi);
@@ -1780,7 +1780,9 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
         auto dfa = [&](int l) { return lg_dfa_on() && (h.maxw <= 384 || lg_dfa_on() == 2) && lg_d_from_a(h.act[l]); };
         for (int l = 0; l < nl - 1; ++l) {
             T* out = dfa(l) ? ws + o.d[l] : ws + ((l & 1) ? o.x1 : o.x0);
-            const bool contract = l == nl - 2 && layered_fuse();      // the output layer in the last hidden layer's epilogue
+            // the output layer in the last hidden layer's epilogue -- unless it is LINEAR: the Hessian sweeps then need nothing of
+            // it (s_L' = 1, s_L'' = 0, and f is not an output of this callback): no contraction, no output step
+            const bool contract = l == nl - 2 && layered_fuse() && !lin_noout;
             if (l == 0 && first) {
                 launch_first<T>(h.act[0], nin + ne, dim3((unsigned)((R + 63) / 64), (unsigned)((h.dout[0] + 63) / 64)), s, gk,
                                 nin, ne, static_cast<const T*>(h.d_extra), Z, X0, r0, R, Rp, static_cast<const T*>(h.d_W[0]), h.dout[0],
@@ -1816,8 +1818,9 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
             if ((rc = gemm_forward<T, LG_CONTRACT_NONE>(h.num_cus, s, a))) return rc;
             in = out;
         }
-        if (in && (rc = skinny<T>(s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, (long long)R, ws + o.f, Rp,
-                                  static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl, (T)h.actp[nl - 1], ws + o.wl)))
+        if (in && !lin_noout &&
+            (rc = skinny<T>(s, in, Rp, static_cast<const T*>(h.d_W[nl - 1]), nx, h.din[nl - 1], nx, (long long)R, ws + o.f, Rp,
+                            static_cast<const T*>(h.d_b[nl - 1]), 0, h.act[nl - 1], ws + o.dl, (T)h.actp[nl - 1], ws + o.wl)))
             return rc;
         // ---- reverse with the multipliers as the one cotangent: curvature weights w_l of every hidden layer
         hipLaunchKernelGGL(layered_hmult_kernel<T>, rg, rb, 0, s, H, nx, h.m, lam, stage ? 1 : 0, r0, R, Rp, ws + o.dl, h.act[nl - 1],
@@ -1906,7 +1909,7 @@ int run_layered_hess(Handle& h, int B, const void* Zv, const void* X0v, const vo
             if ((rc = hcontract<T>(s, ws + o.pl, ldt, nullptr, 0, ws + o.wl, nx, nin, R, Rp, Hacc, hacc_used))) return rc;
             hacc_used = true;
         }
-        hipLaunchKernelGGL(layered_hfinish_kernel<T>, rg, rb, 0, s, nin, r0, R, Rp, hacc_used ? Hacc : static_cast<T*>(nullptr),
+        hipLaunchKernelGGL(layered_hfinish_kernel<T>, dim3(rg.x, (unsigned)npair), rb, 0, s, nin, r0, R, Rp, hacc_used ? Hacc : static_cast<T*>(nullptr),
                            fuse_l0 ? ws + o.l0p : static_cast<T*>(nullptr), pblocks, (long long)npair * Rp, blocks);
         NEMPC_HIP(hipGetLastError());
     }
