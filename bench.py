@@ -173,6 +173,9 @@ def driver_line(full):
                                 "variant": e.get("kernel_variant")}
     if "shard_c4" in full:
         summ["shard_c4_b512"] = _pick(full["shard_c4"], "us", "frac", "problem_evals_per_s")
+    if "solver_c3" in full:
+        summ["solver_c3"] = {k[len("budget_"):]: _pick(v, "converged_frac", "solve_ms") for k, v in full["solver_c3"].items()
+                             if k.startswith("budget_")}
     if summ:
         line["summary"] = summ
     line["details"] = DETAILS_FILE
@@ -882,12 +885,38 @@ class Rank:
                 out["steady_state"] = self.steady_state_leg(cfg)
                 out["narrow_networks"] = self.narrow_leg()
                 out["shard_c4"] = self.shard_c4_leg()
+                out["solver_c3"] = self.solver_c3_leg()
             if self.world == 1 and not args.no_cpu:
                 out["cpu_baseline"] = cpu_baseline(cfg)
         self.emit(out)
         if self.dist is not None:
             self.barrier()
             self.dist.destroy_process_group()
+
+    def solver_c3_leg(self):
+        """The batched solver at configs[2]'s dims (6/3, MLP 3 x 128, H = 30, RK4, fp32, B = 1024; bounds |x| <= 3, |u| <= 0.5; the
+        set-up of tools/solver_profile.py c3): share of the batch converged within 40 / 80 outer iterations and the time of the
+        solve (review item: >= 85 % at 40)."""
+        import time
+        np, torch = self.np, self.torch
+        from oracle import nempc_oracle as orc
+        from pyneuralempc_amd import CallbackEngine
+        nx, nu, H, B = 6, 3, 30, 1024
+        net = orc.MLP.random(nx + nu, [128, 128, 128], nx, seed=0)
+        eng = CallbackEngine(net.W, net.b, H, nx, nu, integrator="rk4", DT=0.1, dtype=torch.float32, device=self.dev, max_batch=B)
+        X0 = eng.to_device(np.random.default_rng(100).uniform(-0.5, 0.5, size=(B, nx)))
+        lb = np.concatenate([np.full(H * nx, -3.0), np.full(H * nu, -0.5)])
+        out = {"workload": "B=1024, H=30, 6/3, MLP 3x128 tanh, RK4, f32; |x| <= 3, |u| <= 0.5"}
+        for mi in (40, 80):
+            eng.solve(X0, lb=lb, ub=-lb, max_iter=3)
+            torch.cuda.synchronize(self.dev)
+            t = time.perf_counter()
+            Z, st, it = eng.solve(X0, lb=lb, ub=-lb, max_iter=mi)
+            torch.cuda.synchronize(self.dev)
+            dt = time.perf_counter() - t
+            ok = int((st == 0).sum())
+            out[f"budget_{mi}"] = {"iterations": int(it), "converged_frac": ok / B, "solve_ms": dt * 1e3, "mpc_solved_per_s": ok / dt}
+        return out
 
     def layered_leg(self):
         """Networks outside the register-resident kernels (the reference wraps any feed-forward Keras model:

@@ -65,6 +65,25 @@ def test_driver_line_is_small_strict_json_with_the_contract_keys():
     assert max(len(s) for s in strings(line)) <= 120
 
 
+def test_driver_line_of_the_round_5_record_with_every_leg_fits():
+    """the full round-5 record (layered, narrow, steady-state, shard and solver legs) still makes a line under 4 KB with its
+    summary in place (not dropped)"""
+    p = os.path.join(REPO, "profiles", "r05_bench_driver_form_details.json")
+    if not os.path.exists(p):
+        pytest.skip("no round-5 detailed record in profiles/")
+    full = json.load(open(p))
+    full.setdefault("solver_c3", {"workload": "x", "budget_40": {"iterations": 40, "converged_frac": 0.9727, "solve_ms": 71.5234567,
+                                                                  "mpc_solved_per_s": 13926.123},
+                                  "budget_80": {"iterations": 76, "converged_frac": 1.0, "solve_ms": 91.5234567, "mpc_solved_per_s": 11188.1}})
+    text = bench.driver_line(full)
+    assert len(text.encode()) < bench.DRIVER_LINE_MAX
+    line = strict_loads(text)
+    assert "dropped" not in line["summary"]
+    for k in ("layered_2x256", "steady_state", "solver", "solver_c3", "c3", "c5", "shard_c4_b512"):
+        assert k in line["summary"], k
+    assert line["summary"]["solver_c3"]["40"]["converged_frac"] == pytest.approx(full["solver_c3"]["budget_40"]["converged_frac"], rel=1e-3)
+
+
 def test_driver_line_never_carries_nan_or_infinity():
     full = copy.deepcopy(canned())
     full["roofline"]["traffic"] = float("nan")
