@@ -291,7 +291,8 @@ __device__ __forceinline__ const T* lg_uniform(const T* p) {
 // main loop: 2 x 256 evaluations 238 -> 385 us with one block per workgroup, 337 us resident -- so residency itself is worth 12 %);
 // with the argument block re-read through an opaque kernarg pointer every iteration it still spills (120 - 930 B); as a
 // __noinline__ function per block (arguments made uniform on entry) the main loop is clean but the evaluation takes 289 - 300 us.
-// Not kept; profiles/r05_layered_resident.txt.)
+// Not kept; profiles/r05_layered_resident.txt.  Wave priorities (`s_setprio`) either way -- a block's start and end ahead of the
+// other blocks' main loops, or behind them -- are slower than the oldest-first default: 2 x 256 fp64 197 -> 209 / 205 us.)
 template <typename T, int FT, bool SEED = false, int CONTRACT = LG_CONTRACT_NONE, int RM = 4>
 __global__ __launch_bounds__(256, RM == 2 ? (CONTRACT ? 5 : 6) : LG_WPE) void layered_gemm_kernel(GemmArgs a) {
 
