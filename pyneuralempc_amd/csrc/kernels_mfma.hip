@@ -86,8 +86,8 @@ bool mfma_slower_than_layered(const Handle& h) {
 //   two hidden layers, run-time activation codes: the cooperative Hessian kernel with the activation switches inlined, 182
 //     against 161 (the rows: 101 against 105)
 bool mfma_hess_on_layered(const Handle& h) {
-    static const bool off = [] { const char* e = getenv("NEMPC_MFMA_HESS_LAYERED"); return e && atoi(e) == 0; }();
-    if (off || h.cfg.dtype != NEMPC_F64 || h.cfg.integrator == NEMPC_RK4 || !layered_supported(h)) return false;
+    // (AUTO only: asking for NEMPC_KERNEL_MFMA by name keeps the register-resident Hessian kernels -- that is the A/B)
+    if (h.cfg.dtype != NEMPC_F64 || h.cfg.integrator == NEMPC_RK4 || !layered_supported(h)) return false;
     return padded_width(h) == 128 && (h.nl - 1 == 3 || (h.nl - 1 == 2 && h.mfma_act == NEMPC_ACT_RUNTIME));
 }
 
